@@ -1,0 +1,191 @@
+/* umgap_hip.h — C ABI of libumgap_hip.so: the MI355X (gfx950) implementation of UMGAP's
+ * pept2lca -> taxa2agg hot path.  Plain pointers and sizes only; no C++/torch types.
+ *
+ * The reference (unipept/umgap v1.1.1, Rust) has no FFI for this path: the path sits behind
+ * two in-process seams, which these entry points replace one for one (file:line relative to
+ * the reference tree):
+ *
+ *   fst::Map::{from_path,from_bytes}   src/commands/pept2lca.rs:74-79     -> umgap_index_open / _build9
+ *   fst::Map::get(&[u8])->Option<u64>  src/commands/pept2lca.rs:93,
+ *                                      src/commands/prot2kmer2lca.rs:176  -> umgap_index_lookup9[_dev]
+ *   fst::MapBuilder::{insert,finish}   src/commands/buildindex.rs:38-45   -> umgap_index_build9 + _save
+ *   taxon::{TaxonList,TaxonTree}::new,
+ *   TaxonTree::snapping                src/commands/taxa2agg.rs:104-109   -> umgap_taxonomy_create
+ *   trait agg::Aggregator::aggregate   src/agg/mod.rs:12-21 (+ count/filter :27-44 and the
+ *                                      record loop src/commands/taxa2agg.rs:161-180)
+ *                                                                         -> umgap_aggregate[_dev]
+ *   seedextend record state machine    src/commands/seedextend.rs:99-148  -> umgap_seedextend_dev
+ *
+ * Conventions
+ *   - every function returns UMGAP_OK (0) or a negative UMGAP_ERR_* code; the message is in the
+ *     thread-local umgap_last_error().  Nothing throws or aborts across this boundary.
+ *   - the caller owns every buffer it passes; the library owns device memory and streams.
+ *   - `_dev` variants take DEVICE pointers (resident in the handle's GPU's HBM) and a hipStream_t
+ *     passed as void* (NULL = default stream); they enqueue and return without synchronising.
+ *     The plain variants take HOST pointers, stage through pinned buffers and return when the
+ *     result is in the caller's memory.
+ *   - handles are thread-compatible: one in-flight call per handle; distinct handles may be used
+ *     from distinct threads.
+ *   - there is NO CPU fallback: without a usable GPU every compute entry point fails with
+ *     UMGAP_ERR_DEVICE.
+ *
+ * 9-mer packing convention: key45 = sum_i code(c_i) << (5*(8-i)), code = c-'A'
+ * for 'A'..'Z'.  A peptide holding any other byte is not representable: the host emits the miss
+ * value without calling the device (umgap_pack9 returns 0 for it).
+ */
+#ifndef UMGAP_HIP_H
+#define UMGAP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UMGAP_OK 0
+#define UMGAP_ERR_INVALID (-1)    /* bad argument */
+#define UMGAP_ERR_IO (-2)         /* file could not be read/written */
+#define UMGAP_ERR_FORMAT (-3)     /* malformed input (index file, taxonomy) */
+#define UMGAP_ERR_DEVICE (-4)     /* no GPU / HIP failure */
+#define UMGAP_ERR_NOMEM (-5)
+#define UMGAP_ERR_BUILD (-6)      /* index build failed (duplicate key, table too full) */
+#define UMGAP_ERR_PANIC (-7)      /* the reference would panic here (exit 101), e.g. "More than one root!" */
+
+/* per-read status written by umgap_aggregate (src/commands/taxa2agg.rs:161-180 outcomes) */
+#define UMGAP_READ_OK 0            /* out_taxon = snapping[aggregate]                       */
+#define UMGAP_READ_EMPTY 1         /* no taxa left after the filters: out_taxon = 1 (:174)  */
+#define UMGAP_READ_UNKNOWN_TAXON 2 /* Err(UnknownTaxon(out_taxon)): host aborts, exit 1     */
+#define UMGAP_READ_PANIC 3         /* index out of bounds / unwrap on None: host exits 101  */
+
+#define UMGAP_METHOD_TREE 0 /* -m tree (src/commands/taxa2agg.rs:186-190) */
+#define UMGAP_METHOD_RMQ 1  /* -m rmq  */
+#define UMGAP_STRATEGY_LCA_STAR 0 /* -a lca*   */
+#define UMGAP_STRATEGY_HYBRID 1   /* -a hybrid */
+#define UMGAP_STRATEGY_MRTL 2     /* -a mrtl   */
+
+#define UMGAP_NONE 0xFFFFFFFFu
+
+typedef struct umgap_index umgap_index;
+typedef struct umgap_taxonomy umgap_taxonomy;
+
+/* ---- library --------------------------------------------------------------------------- */
+const char* umgap_last_error(void);
+const char* umgap_version(void);      /* "1.1.1" — the reference version mirrored */
+int umgap_device_count(void);         /* number of visible GPUs, 0 if none (never fails) */
+
+/* Packs one 9-mer; returns 1 and writes *key45, or 0 if any byte is outside 'A'..'Z'. */
+int umgap_pack9(const char* nine_bytes, uint64_t* key45);
+void umgap_unpack9(uint64_t key45, char* nine_bytes);
+
+/* ---- index: 9-mer -> taxon table resident in HBM --------------------------------------- */
+/* Builds a table on `device` from host arrays (keys distinct, any order).  load_factor in
+ * (0,1): filled fraction of the 8-slot buckets (0 selects the default 0.6). */
+int umgap_index_build9(const uint64_t* keys45, const uint32_t* taxa, size_t n, double load_factor,
+                       int device, umgap_index** out);
+/* Same, key/value arrays already in device memory (on `device`). */
+int umgap_index_build9_dev(const uint64_t* d_keys45, const uint32_t* d_taxa, size_t n, double load_factor,
+                           int device, umgap_index** out);
+/* Writes / reads the table image ("UMGAPIX1" format).  device_mask: bit d set =
+ * GPU d may be used; the lowest set bit is chosen (one GPU per handle, one process per GPU).
+ * shard/n_shards: load only that contiguous bucket range (+ overflow halo); 0/1 = whole table. */
+int umgap_index_save(const umgap_index* ix, const char* path);
+int umgap_index_open(const char* path, uint32_t device_mask, umgap_index** out);
+int umgap_index_open_shard(const char* path, uint32_t device_mask, uint32_t shard, uint32_t n_shards,
+                           umgap_index** out);
+/* Restrict an already built whole-table handle to one shard (frees nothing; lookups of keys whose
+ * home bucket lies outside the shard return `miss_value`).  Used by the sharded multi-GPU mode. */
+int umgap_index_set_shard(umgap_index* ix, uint32_t shard, uint32_t n_shards);
+/* Owner shard of each key under an n_shards split (for the all-to-all exchange). */
+int umgap_index_owner9_dev(const umgap_index* ix, const uint64_t* d_keys45, size_t n, uint32_t n_shards,
+                           uint32_t* d_owner, void* stream);
+void umgap_index_free(umgap_index* ix);
+uint64_t umgap_index_num_keys(const umgap_index* ix);
+uint64_t umgap_index_num_buckets(const umgap_index* ix);
+uint64_t umgap_index_table_bytes(const umgap_index* ix);
+int umgap_index_device(const umgap_index* ix);
+
+/* get(): out_taxa[i] = value of keys45[i], or miss_value.  keys with bits above 45 set miss. */
+int umgap_index_lookup9(umgap_index* ix, const uint64_t* keys45, size_t n, uint32_t miss_value,
+                        uint32_t* out_taxa);
+int umgap_index_lookup9_dev(umgap_index* ix, const uint64_t* d_keys45, size_t n, uint32_t miss_value,
+                            uint32_t* d_out_taxa, void* stream);
+/* Fused prot2kmer2lca surface (src/commands/prot2kmer2lca.rs:172-179): `bytes` holds n_prot
+ * peptides, peptide p = bytes[offsets[p] .. offsets[p+1]); every window of k=9 residues is
+ * looked up; window w of peptide p lands in out[out_offsets[p] + w] where out_offsets[p] =
+ * sum over q<p of max(0, len_q - 8) (the caller computes it; device pointers). Windows that
+ * contain a byte outside 'A'..'Z' get miss_value. */
+int umgap_index_lookup_prot9_dev(umgap_index* ix, const uint8_t* d_bytes, const uint64_t* d_offsets,
+                                 const uint64_t* d_out_offsets, size_t n_prot, uint32_t miss_value,
+                                 uint32_t* d_out_taxa, void* stream);
+
+/* ---- taxonomy ---------------------------------------------------------------------------- */
+/* rows in TSV order: id, parent, valid (0/1), rank (index into src/rank.rs:10-41, 0 = "no rank").
+ * Children keep row order (Euler tour / preorder follow it, src/taxon.rs:224-247).
+ * Errors: UMGAP_ERR_PANIC for the reference's panics (no rows, "More than one root!",
+ * "There's no root!"); UMGAP_ERR_FORMAT for ids >= 2^32-1, duplicate ids or parent cycles
+ * (the reference loops forever on a cycle; duplicates are refused here). */
+int umgap_taxonomy_create(const uint32_t* id, const uint32_t* parent, const uint8_t* valid,
+                          const uint8_t* rank, size_t n, int device, umgap_taxonomy** out);
+void umgap_taxonomy_free(umgap_taxonomy* tx);
+uint32_t umgap_taxonomy_root(const umgap_taxonomy* tx);
+uint32_t umgap_taxonomy_len(const umgap_taxonomy* tx);     /* max id + 1 (TaxonList length)    */
+uint32_t umgap_taxonomy_reachable(const umgap_taxonomy* tx); /* nodes reachable from the root  */
+/* host copies of the derived per-id tables (len entries each; UMGAP_NONE = None) */
+int umgap_taxonomy_snapping(const umgap_taxonomy* tx, int ranked_only, uint32_t* out);
+int umgap_taxonomy_preorder(const umgap_taxonomy* tx, uint32_t* pre, uint32_t* last, uint32_t* depth);
+
+/* ---- aggregate: one consensus taxon per read ------------------------------------------------ */
+/* taxa/scores are CSR over reads: read r owns taxa[read_offsets[r] .. read_offsets[r+1]).
+ * Per read (src/commands/taxa2agg.rs:161-180): drop taxon 0, sum scores per taxon (1.0 each
+ * when scores == NULL), keep sums >= lower_bound, aggregate with (method, strategy, factor),
+ * snap to the nearest valid (and ranked if ranked_only) ancestor.
+ * Ties that the reference breaks by HashMap order are broken by smallest preorder index. */
+int umgap_aggregate(umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound,
+                    int ranked_only, const uint32_t* taxa, const float* scores,
+                    const uint64_t* read_offsets, size_t n_reads, uint32_t* out_taxon,
+                    uint32_t* out_status);
+int umgap_aggregate_dev(umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound,
+                        int ranked_only, const uint32_t* d_taxa, const float* d_scores,
+                        const uint64_t* d_read_offsets, size_t n_reads, uint32_t* d_out_taxon,
+                        uint32_t* d_out_status, void* stream);
+/* Fixed-stride form (every read owns `stride` consecutive taxa, 0 = padding/miss): the layout
+ * the fused 9-mer pipeline produces; avoids the offsets array. */
+int umgap_aggregate_strided_dev(umgap_taxonomy* tx, int method, int strategy, float factor,
+                                float lower_bound, int ranked_only, const uint32_t* d_taxa,
+                                uint32_t stride, size_t n_reads, uint32_t* d_out_taxon,
+                                uint32_t* d_out_status, void* stream);
+
+/* ---- seedextend on device (src/commands/seedextend.rs:99-148, unranked mode) ------------- */
+/* In place per record r = taxa[offsets[r]..offsets[r+1]): taxa outside every extended seed
+ * are overwritten with 0 (a dropped taxon and a 0 are equivalent for taxa2agg, which discards
+ * zeros, src/commands/taxa2agg.rs:169).  kept[r] (nullable) receives the number of taxa the
+ * reference's seedextend would print for the record. */
+int umgap_seedextend_dev(const uint64_t* d_offsets, size_t n_records, uint32_t min_seed_size,
+                         uint32_t max_gap_size, uint32_t* d_taxa, uint32_t* d_kept, int device,
+                         void* stream);
+/* Fixed-stride form: record r = d_taxa[r*stride .. (r+1)*stride). */
+int umgap_seedextend_strided_dev(uint32_t stride, size_t n_records, uint32_t min_seed_size,
+                                 uint32_t max_gap_size, uint32_t* d_taxa, uint32_t* d_kept, int device,
+                                 void* stream);
+
+/* ---- measurement helpers (bench.py; not part of the reference surface) ------------------- */
+/* Lane-per-key probe variant of umgap_index_lookup9_dev, kept for the A/B in DESIGN.md. */
+int umgap_index_lookup9_lane_dev(umgap_index* ix, const uint64_t* d_keys45, size_t n, uint32_t miss_value,
+                                 uint32_t* d_out_taxa, void* stream);
+/* Random 64-byte-sector gather microbenchmark over the index table: each of n probes reads one
+ * whole bucket chosen by a hash of its index; out receives a checksum per probe. */
+int umgap_bench_gather_dev(umgap_index* ix, size_t n, uint32_t bytes_per_probe, uint32_t* d_out, void* stream);
+/* Synthetic workload generators (DESIGN.md "Synthetic workload"), all on device. */
+int umgap_synth_index_build(uint64_t n_keys, const uint32_t* d_taxon_of_row, uint64_t n_tax,
+                            uint64_t mul_a, uint64_t add_b, double load_factor, int device,
+                            umgap_index** out);
+int umgap_synth_reads9_dev(const umgap_taxonomy* tx, const uint32_t* d_taxon_of_row,
+                           const uint32_t* d_row_of_id, uint64_t n_tax, uint64_t n_keys, uint64_t mul_a,
+                           uint64_t add_b, uint64_t seed, uint64_t first_pair, uint64_t n_pairs,
+                           uint32_t kmers_per_pair, uint64_t* d_keys45, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UMGAP_HIP_H */

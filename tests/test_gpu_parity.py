@@ -1,0 +1,368 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same
+inputs.  Integer/index work => bit-exact.  Run on the MI355X box: `pytest -m gpu`."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "these tests need the GPU box"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def api(torch_cuda):
+    from umgap_amd import api
+    return api
+
+
+def _golden():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "tests", "golden", "reference_vectors.json")) as f:
+        return json.load(f)
+
+
+def _fixture_taxonomy(api):
+    from umgap_amd.api import RANKS
+    rows = _golden()["fixture_taxonomy"]["rows"]
+    ids = [r[0] for r in rows]
+    par = [r[3] for r in rows]
+    valid = [int(r[4]) for r in rows]
+    rank = [RANKS.index(r[2]) for r in rows]
+    return api.Taxonomy(ids, par, valid, rank), O.Taxonomy.from_arrays(ids, par, valid, rank)
+
+
+def _csr(reads):
+    offs = np.zeros(len(reads) + 1, np.uint64)
+    offs[1:] = np.cumsum([len(r) for r in reads])
+    taxa = np.array([t for r in reads for t in r], np.uint32)
+    return taxa, offs
+
+
+# ---------------------------------------------------------------------------------------------
+# index: get() semantics (the fst seam: get(k) = v iff (k, v) was inserted)
+# ---------------------------------------------------------------------------------------------
+def test_lookup_matches_dict(api):
+    rng = np.random.default_rng(1)
+    n = 300_000
+    keys = np.unique(rng.integers(0, 1 << 45, n, dtype=np.uint64))
+    vals = rng.integers(1, 1 << 32, len(keys), dtype=np.uint64).astype(np.uint32)
+    ix = api.Index.build(keys, vals)
+    assert ix.num_keys == len(keys)
+    # every key present
+    assert (ix.lookup9(keys) == vals).all()
+    # mixed present / absent / out-of-range, ragged length (not a multiple of 64)
+    q = np.concatenate([keys[:5001], rng.integers(0, 1 << 45, 7777, dtype=np.uint64), np.array([1 << 45, (1 << 64) - 1], np.uint64)])
+    rng.shuffle(q)
+    d = dict(zip(keys.tolist(), vals.tolist()))
+    want = np.array([d.get(int(k), 0) for k in q], np.uint32)
+    assert (ix.lookup9(q, miss_value=0) == want).all()
+    want7 = np.array([d.get(int(k), 7) for k in q], np.uint32)
+    assert (ix.lookup9(q, miss_value=7) == want7).all()
+    # empty batch
+    assert len(ix.lookup9(np.zeros(0, np.uint64))) == 0
+
+
+def test_lookup_overflow_chains(api):
+    """A table filled to 95 % forces displacement chains; results must not change."""
+    rng = np.random.default_rng(2)
+    keys = np.unique(rng.integers(0, 1 << 45, 900_000, dtype=np.uint64))
+    vals = (np.arange(len(keys)) % 1000 + 1).astype(np.uint32)
+    for load in (0.3, 0.8, 0.95):
+        ix = api.Index.build(keys, vals, load_factor=load)
+        assert (ix.lookup9(keys) == vals).all(), load
+        absent = rng.integers(0, 1 << 45, 100_000, dtype=np.uint64)
+        absent = absent[~np.isin(absent, keys)]
+        assert (ix.lookup9(absent, miss_value=0) == 0).all(), load
+
+
+def test_lookup_variants_and_device_path(api, torch_cuda):
+    torch = torch_cuda
+    rng = np.random.default_rng(3)
+    keys = np.unique(rng.integers(0, 1 << 45, 200_000, dtype=np.uint64))
+    vals = rng.integers(1, 1 << 31, len(keys)).astype(np.uint32)
+    ix = api.Index.build(keys, vals, load_factor=0.85)
+    q = np.concatenate([keys[::3], rng.integers(0, 1 << 45, 50_001, dtype=np.uint64)])
+    want = ix.lookup9(q)
+    dq = torch.from_numpy(q.view(np.int64)).cuda()
+    for variant in ("quad", "lane"):
+        got = ix.lookup9_dev(dq, variant=variant)
+        torch.cuda.synchronize()
+        assert (got.cpu().numpy().view(np.uint32) == want).all(), variant
+
+
+def test_duplicate_keys_are_refused(api):
+    keys = np.array([5, 6, 5], np.uint64)
+    with pytest.raises(api.UmgapError, match="duplicate"):
+        api.Index.build(keys, np.array([1, 2, 3], np.uint32))
+    with pytest.raises(api.UmgapError, match="45-bit"):
+        api.Index.build(np.array([1 << 45], np.uint64), np.array([1], np.uint32))
+
+
+def test_index_file_roundtrip_and_shards(api, tmp_path):
+    rng = np.random.default_rng(4)
+    keys = np.unique(rng.integers(0, 1 << 45, 400_000, dtype=np.uint64))
+    vals = rng.integers(1, 1 << 31, len(keys)).astype(np.uint32)
+    ix = api.Index.build(keys, vals, load_factor=0.9)
+    path = tmp_path / "nine.umgapix"
+    ix.save(path)
+    q = np.concatenate([keys, rng.integers(0, 1 << 45, 10_000, dtype=np.uint64)])
+    want = ix.lookup9(q)
+    ix2 = api.Index.open(path)
+    assert ix2.num_keys == len(keys) and (ix2.lookup9(q) == want).all()
+    # shards: every key is answered by exactly one shard, misses by none
+    for n_shards in (2, 3, 8):
+        acc = np.zeros(len(q), np.uint32)
+        hits = np.zeros(len(q), np.int32)
+        for s in range(n_shards):
+            sh = api.Index.open(path, shard=s, n_shards=n_shards)
+            r = sh.lookup9(q, miss_value=0)
+            acc |= r
+            hits += (r != 0)
+        assert (acc == want).all() and hits.max() == 1
+    with pytest.raises(api.UmgapError):
+        api.Index.open(tmp_path / "missing.umgapix")
+    bad = tmp_path / "bad.fst"
+    bad.write_bytes(b"\x02" + b"\x00" * 63)
+    with pytest.raises(api.UmgapError, match="UMGAPIX1"):
+        api.Index.open(bad)
+
+
+def test_pept2lca_doc_example(api):
+    """src/commands/pept2lca.rs:24-46 on a 9-mer index (the doc's peptides are tryptic; shape only)."""
+    keys = [api.pack9(b"AAALTERAA"), api.pack9(b"ENFVYLAKW")]
+    ix = api.Index.build(np.array(keys, np.uint64), np.array([2, 3398], np.uint32))
+    q = np.array([api.pack9(b"AAALTERAA"), api.pack9(b"NOTATRYPT"), api.pack9(b"ENFVYLAKW")], np.uint64)
+    assert ix.lookup9(q, miss_value=0).tolist() == [2, 0, 3398]
+
+
+# ---------------------------------------------------------------------------------------------
+# aggregate: the reference's own known-answer tests, through the C ABI
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("method", ["tree", "rmq"])
+def test_lca_star_golden(api, method):
+    tx, _ = _fixture_taxonomy(api)
+    g = _golden()
+    reads = [c[0] for c in g["lca_tests"]["cases"]]
+    want = [c[1] for c in g["lca_tests"]["cases"]]
+    taxa, offs = _csr(reads)
+    t, s = tx.aggregate(taxa, offs, method=method, strategy="lca*")
+    assert s.tolist() == [0] * len(reads) and t.tolist() == want
+
+
+def test_lca_star_deeper_interns(api):
+    g = _golden()
+    rows = g["large_taxonomy"]["rows"]
+    tx = api.Taxonomy([r[0] for r in rows], [r[1] for r in rows])
+    reads = [c[0] for c in g["lca_deeper_interns"]["cases"]]
+    taxa, offs = _csr(reads)
+    for method in ("tree", "rmq"):
+        t, s = tx.aggregate(taxa, offs, method=method, strategy="lca*")
+        assert t.tolist() == [c[1] for c in g["lca_deeper_interns"]["cases"]] and not s.any()
+
+
+@pytest.mark.parametrize("method", ["tree", "rmq"])
+def test_agg_contract_lca(api, method):
+    """src/agg/mod.rs:67-118 at the record level: [] -> "1"/EMPTY, [t] -> t, unknown 5 -> UnknownTaxon(5)."""
+    tx, _ = _fixture_taxonomy(api)
+    ids = [1, 2, 10239, 12884, 185751, 185752]
+    reads = [[]] + [[t] for t in ids] + [[5], [1, 2, 5, 1], [0, 0]]
+    taxa, offs = _csr(reads)
+    t, s = tx.aggregate(taxa, offs, method=method, strategy="lca*")
+    assert (t[0], s[0]) == (1, api.READ_EMPTY)
+    assert t[1:7].tolist() == ids and not s[1:7].any()
+    assert (t[7], s[7]) == (5, api.READ_UNKNOWN_TAXON) and (t[8], s[8]) == (5, api.READ_UNKNOWN_TAXON)
+    assert (t[9], s[9]) == (1, api.READ_EMPTY)
+    # id beyond the list: tree panics (index out of bounds), rmq answers UnknownTaxon (HashMap miss)
+    t, s = tx.aggregate(np.array([999999], np.uint32), np.array([0, 1], np.uint64), method=method, strategy="lca*")
+    assert s[0] == (api.READ_PANIC if method == "tree" else api.READ_UNKNOWN_TAXON)
+
+
+def test_tree_mrtl_is_an_invalid_invocation(api):
+    tx, _ = _fixture_taxonomy(api)
+    with pytest.raises(api.UmgapError, match="cannot be combined"):
+        tx.aggregate(np.array([1], np.uint32), np.array([0, 1], np.uint64), method="tree", strategy="mrtl")
+
+
+def test_taxonomy_tables_match_oracle(api):
+    from umgap_amd.synth import synthetic_taxonomy
+    ids, par, valid, rank = synthetic_taxonomy(30_000, 50_000, max_depth=40)
+    tx = api.Taxonomy(ids, par, valid, rank)
+    ot = O.Taxonomy.from_arrays(ids, par, valid, rank)
+    assert tx.root == ot.root and len(tx) == len(ot) and tx.reachable == len(ids)
+    for ranked in (False, True):
+        want = ot.snapping(ranked)
+        got = tx.snapping(ranked).astype(np.uint64)
+        got[got == 0xFFFFFFFF] = O.NONE
+        assert (got == want).all()
+    # preorder = order of first occurrence in the reference's Euler tour (src/taxon.rs:309-392)
+    pre, last, depth = tx.preorder()
+    seen, k = {}, 0
+    for t, d in ot.euler():
+        if t not in seen:
+            seen[t] = (k, d)
+            k += 1
+    for t in ids[:2000]:
+        assert seen[int(t)] == (pre[t], depth[t])
+
+
+def _random_reads(rng, pool, n_reads, max_len, zero_frac=0.3):
+    reads = []
+    for _ in range(n_reads):
+        n = int(rng.integers(0, max_len + 1))
+        r = rng.choice(pool, n)
+        r[rng.random(n) < zero_frac] = 0
+        reads.append(r.tolist())
+    return reads
+
+
+@pytest.mark.parametrize("method", ["tree", "rmq"])
+@pytest.mark.parametrize("lower_bound", [0.0, 1.0, 2.0, 3.0])
+def test_lca_star_random_vs_oracle(api, method, lower_bound):
+    from umgap_amd.synth import synthetic_taxonomy
+    rng = np.random.default_rng(int(lower_bound) * 7 + (method == "rmq"))
+    ids, par, valid, rank = synthetic_taxonomy(3000, 5000, max_depth=25, seed=9)
+    tx = api.Taxonomy(ids, par, valid, rank)
+    ot = O.Taxonomy.from_arrays(ids, par, valid, rank)
+    agg = O.Aggregator(ot, method, "lca*")
+    # reads drawn from small pools so that taxa repeat; lengths 0..200 cover 1, 2 and 4 chunks of 64
+    reads = []
+    for _ in range(60):
+        pool = rng.choice(ids, int(rng.integers(1, 12)))
+        reads += _random_reads(rng, pool, 50, int(rng.choice([3, 20, 84, 200])))
+    taxa, offs = _csr(reads)
+    for ranked in (False, True):
+        t, s = tx.aggregate(taxa, offs, method=method, strategy="lca*", lower_bound=lower_bound, ranked_only=ranked)
+        nbad, bad, wt, ws = agg.taxa2agg_check(taxa, offs, t, s, ranked=ranked, lower_bound=lower_bound)
+        assert nbad == 0, (bad, [(reads[int(b)], t[int(b)], s[int(b)], wt[int(b)], ws[int(b)]) for b in bad[:3]])
+
+
+@pytest.mark.parametrize("method", ["tree", "rmq"])
+def test_lca_star_unknown_and_orphans_vs_oracle(api, method):
+    """Absent ids, ids beyond the list and taxa whose parent chain is broken."""
+    rng = np.random.default_rng(21)
+    ids = np.array([1, 2, 3, 4, 5, 6, 7, 8, 20, 21, 22, 30], np.uint32)
+    #            root              orphan chain: 20 -> 21 -> 99 (absent)   22 -> 400 (beyond the list)
+    par = np.array([1, 1, 1, 2, 2, 3, 3, 4, 21, 99, 400, 1], np.uint32)
+    tx = api.Taxonomy(ids, par)
+    ot = O.Taxonomy.from_arrays(ids, par)
+    agg = O.Aggregator(ot, method, "lca*")
+    pool = np.array([1, 2, 3, 4, 5, 6, 7, 8, 20, 21, 22, 30, 9, 10, 50, 99, 100, 400, 5000], np.uint32)
+    reads = _random_reads(rng, pool, 3000, 6, zero_frac=0.1)
+    taxa, offs = _csr(reads)
+    for lb in (0.0, 2.0):
+        t, s = tx.aggregate(taxa, offs, method=method, strategy="lca*", lower_bound=lb)
+        nbad, bad, wt, ws = agg.taxa2agg_check(taxa, offs, t, s, lower_bound=lb)
+        assert nbad == 0, [(reads[int(b)], t[int(b)], s[int(b)], wt[int(b)], ws[int(b)]) for b in bad[:5]]
+        assert (s == api.READ_UNKNOWN_TAXON).any() and (s == api.READ_OK).any()
+
+
+def test_lca_star_scored_vs_oracle(api):
+    from umgap_amd.synth import synthetic_taxonomy
+    rng = np.random.default_rng(33)
+    ids, par, valid, rank = synthetic_taxonomy(2000, 3000, max_depth=20, seed=5)
+    tx = api.Taxonomy(ids, par, valid, rank)
+    agg = O.Aggregator(O.Taxonomy.from_arrays(ids, par, valid, rank), "tree", "lca*")
+    reads = []
+    for _ in range(40):
+        pool = rng.choice(ids, 6)
+        reads += _random_reads(rng, pool, 40, 30)
+    taxa, offs = _csr(reads)
+    scores = rng.random(len(taxa)).astype(np.float32)
+    for lb in (0.0, 0.7, 1.5):
+        t, s = tx.aggregate(taxa, offs, method="tree", strategy="lca*", lower_bound=lb, scores=scores)
+        nbad, bad, _, _ = agg.taxa2agg_check(taxa, offs, t, s, scores=scores, lower_bound=lb)
+        assert nbad == 0, bad
+
+
+# ---------------------------------------------------------------------------------------------
+# seedextend on device vs the oracle's literal state machine
+# ---------------------------------------------------------------------------------------------
+def test_seedextend_vs_oracle(api, torch_cuda):
+    torch = torch_cuda
+    rng = np.random.default_rng(8)
+    recs = []
+    for _ in range(4000):
+        n = int(rng.integers(0, 45))
+        r = rng.choice(np.array([0, 0, 0, 5, 5, 5, 7, 9], np.uint32), n)
+        recs.append(r)
+    taxa, offs = _csr([r.tolist() for r in recs])
+    for (s, g) in ((2, 0), (3, 1), (2, 1), (4, 1), (3, 2)):
+        d_taxa = torch.from_numpy(taxa.view(np.int32).copy()).cuda()
+        d_offs = torch.from_numpy(offs.view(np.int64)).cuda()
+        d_kept = torch.zeros(len(recs), dtype=torch.int32, device="cuda")
+        api.seedextend_dev(d_taxa, d_offsets=d_offs, min_seed_size=s, max_gap_size=g, d_kept=d_kept)
+        torch.cuda.synchronize()
+        got = d_taxa.cpu().numpy().view(np.uint32)
+        kept = d_kept.cpu().numpy()
+        for i, r in enumerate(recs):
+            want = O.seedextend_record(r, s, g)
+            mine = got[int(offs[i]):int(offs[i + 1])]
+            assert kept[i] == len(want), (i, r, want, mine)
+            assert mine[mine != 0].tolist() == want[want != 0].tolist(), (i, r.tolist(), want, mine)
+
+
+# ---------------------------------------------------------------------------------------------
+# the synthetic 9-mer high-precision pipeline: lookup -> (seedextend) -> LCA* with -l 2
+# ---------------------------------------------------------------------------------------------
+def _pipeline_check(api, torch, n_tax, n_keys, n_pairs, with_seedextend):
+    from umgap_amd.synth import ADD_B, KMERS_PER_PAIR, MUL_A, SyntheticWorkload
+    w = SyntheticWorkload(n_tax=n_tax, n_keys=n_keys)
+    d_keys = w.reads(0, n_pairs)
+    d_hits = w.index.lookup9_dev(d_keys, miss_value=0)
+    torch.cuda.synchronize()
+    keys = d_keys.cpu().numpy().view(np.uint64)
+    hits = d_hits.cpu().numpy().view(np.uint32)
+    # (1) lookup parity against the closed-form oracle index
+    p = O.SynthIndexParams(n_keys, n_tax, MUL_A, ADD_B)
+    want_hits = O.synth_lookup9(p, w.taxon_of_row, keys, miss_value=0)
+    assert (hits == want_hits).all()
+    frac_hit = (hits != 0).mean()
+    assert 0.5 < frac_hit < 0.8, frac_hit
+    # (2) seedextend per fragment (42 k-mers), in place
+    if with_seedextend:
+        half = KMERS_PER_PAIR // 2
+        api.seedextend_dev(d_hits, stride=half, n_records=2 * n_pairs, min_seed_size=3, max_gap_size=1)
+        torch.cuda.synchronize()
+        se = d_hits.cpu().numpy().view(np.uint32)
+        for r in range(0, 2 * n_pairs, max(1, (2 * n_pairs) // 500)):
+            want = O.seedextend_record(want_hits[r * half:(r + 1) * half], 3, 1)
+            mine = se[r * half:(r + 1) * half]
+            assert mine[mine != 0].tolist() == want[want != 0].tolist()
+        want_hits = se
+    # (3) aggregate per pair: taxa2agg -l2 -a lca*  (scripts/umgap-analyse.sh:304)
+    d_t = torch.empty(n_pairs, dtype=torch.int32, device="cuda")
+    d_s = torch.empty(n_pairs, dtype=torch.int32, device="cuda")
+    w.taxonomy.aggregate_strided_dev(d_hits, KMERS_PER_PAIR, n_pairs, d_t, d_s, method="tree", strategy="lca*", lower_bound=2.0)
+    torch.cuda.synchronize()
+    ot = O.Taxonomy.from_arrays(w.ids, w.parents, w.valid, w.rank)
+    agg = O.Aggregator(ot, "tree", "lca*")
+    offs = np.arange(n_pairs + 1, dtype=np.uint64) * KMERS_PER_PAIR
+    t = d_t.cpu().numpy().view(np.uint32)
+    s = d_s.cpu().numpy().view(np.uint32)
+    nbad, bad, wt, ws = agg.taxa2agg_check(want_hits, offs, t, s, lower_bound=2.0, nthreads=8)
+    assert nbad == 0, (bad, t[bad.astype(int)], wt[bad.astype(int)])
+    return t, s
+
+
+def test_synth_pipeline_small(api, torch_cuda):
+    t, s = _pipeline_check(api, torch_cuda, n_tax=20_000, n_keys=1_000_000, n_pairs=20_000, with_seedextend=False)
+    assert (s == 0).mean() > 0.9 and len(np.unique(t)) > 1000
+
+
+def test_synth_pipeline_small_with_seedextend(api, torch_cuda):
+    _pipeline_check(api, torch_cuda, n_tax=20_000, n_keys=1_000_000, n_pairs=20_000, with_seedextend=True)
+
+
+def test_synth_pipeline_config2_one_million_pairs(api, torch_cuda):
+    """BASELINE.json configs[1]: 1 M synthetic pairs, bit-exact vs the CPU oracle (84 M lookups)."""
+    t, s = _pipeline_check(api, torch_cuda, n_tax=2_500_000, n_keys=256_000_000, n_pairs=1_000_000, with_seedextend=False)
+    assert (s == 0).mean() > 0.9

@@ -1,0 +1,106 @@
+// common.hpp — error plumbing and the HBM table layout shared by every translation unit of
+// libumgap_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "../../include/umgap_hip.h"
+
+namespace umgap {
+
+void set_error(const std::string& msg);
+int fail(int code, const std::string& msg);
+
+#define UMGAP_HIP(expr)                                                                          \
+    do {                                                                                         \
+        hipError_t e__ = (expr);                                                                 \
+        if (e__ != hipSuccess)                                                                   \
+            return ::umgap::fail(UMGAP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__)); \
+    } while (0)
+
+// Selects `device` after checking that a GPU exists at all.
+int use_device(int device);
+
+// ---------------------------------------------------------------------------------------------
+// 9-mer table layout in HBM.
+//
+//   key45 (5 bit/residue)  --mix45: bijection on [0,2^45)-->  h
+//   A = h >> 28   (17 bits: superblock)      R = h & 0x0FFFFFFF  (28 bits: remainder, stored)
+//   home bucket = A*m + (R*m >> 28)          nb = m << 17 buckets of 64 B = 8 slots of 8 B
+//   slot (u64): [63:32] taxon  [31] "this bucket overflowed" (slot 0 only)  [30:28] displacement
+//               [27:0] R.   Empty slot = all ones (displacement 7 never matches a probe).
+//   A key that does not fit its home bucket goes to bucket home+d (mod nb), d <= 6, and every
+//   bucket it skipped carries the overflow flag, so a probe walks on only past flagged buckets:
+//   a hit or a miss costs ONE 64-byte sector unless the home bucket overflowed at build time.
+//   (bucket, d, R) determines h, hence the key: exact match, no false positives.
+// ---------------------------------------------------------------------------------------------
+static constexpr uint64_t MASK45 = (1ull << 45) - 1;
+static constexpr uint32_t R_BITS = 28;
+static constexpr uint32_t R_MASK = (1u << R_BITS) - 1;
+static constexpr uint32_t A_BITS = 17;
+static constexpr uint32_t SLOTS = 8;
+static constexpr uint32_t MAX_DISP = 6;
+static constexpr uint32_t OVF_BIT = 0x80000000u;
+static constexpr uint32_t TAG_MASK = 0x7FFFFFFFu;
+static constexpr uint64_t EMPTY_SLOT = ~0ull;
+static constexpr uint64_t MIX_C1 = 0x1B0373871FADull;  // odd, < 2^45
+static constexpr uint64_t MIX_C2 = 0x0D6E8FEB8665ull;  // odd, < 2^45
+
+__host__ __device__ inline uint64_t mix45(uint64_t k) {
+    uint64_t h = k & MASK45;
+    h ^= h >> 23;
+    h = (h * MIX_C1) & MASK45;
+    h ^= h >> 21;
+    h = (h * MIX_C2) & MASK45;
+    h ^= h >> 24;
+    return h;
+}
+// home bucket and 28-bit tag of a key
+__host__ __device__ inline void probe_of_key(uint64_t key45, uint32_t m, uint32_t& bucket, uint32_t& tag) {
+    uint64_t h = mix45(key45);
+    uint32_t a = (uint32_t)(h >> R_BITS);
+    uint32_t r = (uint32_t)h & R_MASK;
+    bucket = a * m + (uint32_t)(((uint64_t)r * m) >> R_BITS);
+    tag = r;
+}
+
+struct TableView {
+    const uint64_t* slots;  // device pointer to slot 0 of bucket `first_bucket`
+    uint32_t m;             // sub-buckets per superblock
+    uint32_t nb;            // total buckets of the whole table = m << 17
+    uint32_t first_bucket;  // shard: first bucket resident here
+    uint32_t n_resident;    // shard: buckets resident (home range + halo)
+    uint32_t home_lo;       // shard owns home buckets [home_lo, home_hi)
+    uint32_t home_hi;
+};
+
+// "UMGAPIX1" file header (little endian), followed by nb*64 bytes of buckets.
+struct IndexFileHeader {
+    char magic[8];
+    uint32_t version;   // 1
+    uint32_t kind;      // 9 = 9-mer table
+    uint64_t n_keys;
+    uint32_t m;
+    uint32_t nb;
+    uint64_t mix_c1, mix_c2;
+    uint32_t r_bits, slots;
+    uint64_t reserved[2];
+};
+
+}  // namespace umgap
+
+struct umgap_index {
+    int device = 0;
+    uint64_t* d_slots = nullptr;  // nb * 8 slots (whole table) or the shard's range
+    uint64_t n_keys = 0;
+    umgap::TableView view{};
+    hipStream_t stream = nullptr;
+    // pinned staging for the host-pointer entry points
+    void* h_stage[2] = {nullptr, nullptr};
+    void* d_stage[2] = {nullptr, nullptr};
+    size_t stage_cap = 0;  // keys per staging buffer
+};

@@ -1,0 +1,663 @@
+// index.hip — the 9-mer -> taxon table in HBM: build, save/open, and the probe kernels.
+// Replaces fst::Map::{from_path,from_bytes,get} (call sites: src/commands/pept2lca.rs:74-79,93;
+// src/commands/prot2kmer2lca.rs:109-114,176) and fst::MapBuilder (src/commands/buildindex.rs:38-45).
+// Layout: common.hpp.  gfx950 only (wave64, DPP quad permutes).
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "common.hpp"
+
+using namespace umgap;
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t quad_xor1(uint32_t v) {  // quad_perm [1,0,3,2]
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t quad_xor2(uint32_t v) {  // quad_perm [2,3,0,1]
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t quad_or(uint32_t v) {
+    v |= quad_xor1(v);
+    v |= quad_xor2(v);
+    return v;
+}
+
+// Evaluates one 64-byte bucket held by a quad (lane j holds slots 2j, 2j+1 in `e`) against
+// `want` = tag | displacement << 28.  Returns bit0 = found, bit1 = bucket overflowed; the taxon of
+// the matching slot lands in `val` (quad-uniform).  All four lanes of a quad call this together.
+__device__ __forceinline__ uint32_t eval_bucket(u32x4 e, uint32_t want, uint32_t j, uint32_t& val) {
+    uint32_t m0 = (e.x & TAG_MASK) == want, m1 = (e.z & TAG_MASK) == want;
+    uint32_t v = m0 ? e.y : (m1 ? e.w : 0u);
+    uint32_t ovf = (j == 0 && e.x != 0xFFFFFFFFu) ? (e.x >> 31) : 0u;
+    val = quad_or(v);
+    return quad_or((m0 | m1) | (ovf << 1));
+}
+
+// home bucket -> (resident?, local index)
+__device__ __forceinline__ bool locate(const TableView& T, uint64_t key, uint32_t& local, uint32_t& tag) {
+    uint32_t b;
+    probe_of_key(key, T.m, b, tag);
+    local = b - T.home_lo;
+    return (key >> 45) == 0 && b >= T.home_lo && b < T.home_hi;
+}
+
+// The wave-cooperative part shared by every lookup surface.  Each lane brings one key (already
+// turned into local bucket + tag; bit 31 of `tagv` = valid).  The 64 keys are probed in four
+// rounds of 16 quad probes: a quad = 4 lanes x 16 B = one 64-byte bucket per load instruction, so
+// one wave instruction touches 16 buckets, each as one fully used 64-byte request.  The four
+// first-probe loads are issued back to back (4 sectors in flight per quad); a bucket that
+// overflowed at build time (rare) sends its quad down the displacement chain afterwards.
+// The quad leader of round r stores the result of key 16r+q: 64 contiguous bytes per round.
+__device__ __forceinline__ void wave_probe64(const TableView& T, uint32_t local, uint32_t tagv, uint32_t miss,
+                                             uint32_t* __restrict__ out, size_t base, size_t n, uint32_t lane) {
+    const uint32_t q = lane >> 2, j = lane & 3;
+    const u32x4* p[4];
+    uint32_t want[4];
+    u32x4 e[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        int src = 16 * r + (int)q;
+        uint32_t l = (uint32_t)__shfl((int)local, src, 64);
+        want[r] = (uint32_t)__shfl((int)tagv, src, 64);
+        l = (want[r] >> 31) ? l : 0u;  // invalid key: read bucket 0, result discarded
+        p[r] = reinterpret_cast<const u32x4*>(T.slots) + ((size_t)l * 4 + j);
+        e[r] = __builtin_nontemporal_load(p[r]);
+    }
+    uint32_t res[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const bool valid = want[r] >> 31;
+        uint32_t w = want[r] & R_MASK, val;
+        uint32_t f = eval_bucket(e[r], w, j, val);
+        // displacement chain: only past buckets flagged as overflowed (halo keeps p in range)
+        for (uint32_t d = 1; valid && !(f & 1u) && (f & 2u) && d <= MAX_DISP; d++) {
+            p[r] += 4;
+            w += 1u << R_BITS;
+            f = eval_bucket(__builtin_nontemporal_load(p[r]), w, j, val);
+        }
+        res[r] = (valid && (f & 1u)) ? val : miss;
+    }
+    if (j == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            size_t i = base + 16 * r + q;
+            if (i < n) out[i] = res[r];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// lookup kernels
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_lookup9(const uint64_t* __restrict__ keys, size_t n, uint32_t miss,
+                                                 uint32_t* __restrict__ out, TableView T) {
+    const uint32_t lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t base = wave * 64; base < n; base += nwaves * 64) {
+        size_t i = base + lane;
+        uint32_t local = 0, tag = 0, valid = 0;
+        if (i < n) {
+            uint64_t key = __builtin_nontemporal_load(keys + i);
+            valid = locate(T, key, local, tag) ? 1u : 0u;
+        }
+        wave_probe64(T, local, tag | (valid << 31), miss, out, base, n, lane);
+    }
+}
+
+// Lane-per-key variant (each lane reads its whole 64-byte bucket with four 16-byte loads).
+// Kept for the A/B measurement in DESIGN.md; k_lookup9 is the shipped one.
+__global__ __launch_bounds__(256) void k_lookup9_lane(const uint64_t* __restrict__ keys, size_t n, uint32_t miss,
+                                                      uint32_t* __restrict__ out, TableView T) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        uint32_t local, tag;
+        uint32_t res = miss;
+        if (locate(T, keys[i], local, tag)) {
+            const uint4* p = reinterpret_cast<const uint4*>(T.slots) + (size_t)local * 4;
+            uint32_t want = tag;
+            for (uint32_t d = 0;; d++) {
+                uint4 e0 = p[0], e1 = p[1], e2 = p[2], e3 = p[3];
+                bool hit = false;
+#define UMGAP_CMP(E)                                                              \
+    if ((E.x & TAG_MASK) == want) { res = E.y; hit = true; }                      \
+    if ((E.z & TAG_MASK) == want) { res = E.w; hit = true; }
+                UMGAP_CMP(e0) UMGAP_CMP(e1) UMGAP_CMP(e2) UMGAP_CMP(e3)
+#undef UMGAP_CMP
+                bool ovf = e0.x != 0xFFFFFFFFu && (e0.x >> 31);
+                if (hit || !ovf || d == MAX_DISP) break;
+                p += 4;
+                want += 1u << R_BITS;
+            }
+        }
+        out[i] = res;
+    }
+}
+
+// prot2kmer2lca surface: thread per output window; the peptide of a window is found by binary
+// search in out_offsets, the 9 residues are packed from the byte stream.
+__global__ __launch_bounds__(256) void k_lookup_prot9(const uint8_t* __restrict__ bytes,
+                                                      const uint64_t* __restrict__ offsets,
+                                                      const uint64_t* __restrict__ out_offsets, size_t n_prot,
+                                                      size_t n_windows, uint32_t miss, uint32_t* __restrict__ out,
+                                                      TableView T) {
+    const uint32_t lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t base = wave * 64; base < n_windows; base += nwaves * 64) {
+        size_t g = base + lane;
+        uint32_t local = 0, tag = 0, valid = 0;
+        if (g < n_windows) {
+            // largest p with out_offsets[p] <= g
+            size_t lo = 0, hi = n_prot;
+            while (hi - lo > 1) {
+                size_t mid = (lo + hi) >> 1;
+                if (out_offsets[mid] <= g) lo = mid; else hi = mid;
+            }
+            const uint8_t* s = bytes + offsets[lo] + (g - out_offsets[lo]);
+            uint64_t key = 0;
+            bool ok = true;
+#pragma unroll
+            for (int c = 0; c < 9; c++) {
+                uint32_t ch = s[c];
+                ok = ok && (ch >= 'A' && ch <= 'Z');
+                key = (key << 5) | ((ch - 'A') & 31u);
+            }
+            valid = (ok && locate(T, key, local, tag)) ? 1u : 0u;
+        }
+        wave_probe64(T, local, tag | (valid << 31), miss, out, base, n_windows, lane);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_owner9(const uint64_t* __restrict__ keys, size_t n, uint32_t m, uint32_t nb,
+                                                uint32_t n_shards, uint32_t* __restrict__ owner) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        uint32_t b, tag;
+        probe_of_key(keys[i], m, b, tag);
+        // shard s owns home buckets [nb*s/S, nb*(s+1)/S)
+        uint32_t s = (uint32_t)(((uint64_t)b * n_shards) / nb);
+        while ((uint64_t)nb * s / n_shards > b) s--;
+        while ((uint64_t)nb * (s + 1) / n_shards <= b) s++;
+        owner[i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// build kernels
+// ------------------------------------------------------------------------------------------
+struct BuildFlags { unsigned long long too_full, duplicate, bad_key; };
+
+__device__ __forceinline__ void insert_one(uint64_t* __restrict__ slots, uint32_t m, uint32_t nb, uint64_t key,
+                                           uint32_t val, BuildFlags* flags) {
+    if (key >> 45) { atomicAdd(&flags->bad_key, 1ull); return; }
+    uint32_t b, tag;
+    probe_of_key(key, m, b, tag);
+    for (uint32_t d = 0; d <= MAX_DISP; d++) {
+        uint32_t bucket = b + d;
+        if (bucket >= nb) bucket -= nb;
+        uint64_t* s = slots + (size_t)bucket * SLOTS;
+        uint32_t lo = tag | (d << R_BITS);
+        uint64_t entry = ((uint64_t)val << 32) | lo;
+        for (uint32_t k = 0; k < SLOTS; k++) {
+            unsigned long long old = atomicCAS((unsigned long long*)(s + k), (unsigned long long)EMPTY_SLOT,
+                                               (unsigned long long)entry);
+            if (old == EMPTY_SLOT) return;
+            if (((uint32_t)old & TAG_MASK) == lo) { atomicAdd(&flags->duplicate, 1ull); return; }
+        }
+        // bucket is full: flag it so probes walk on, then try the next bucket
+        atomicOr((unsigned long long*)s, (unsigned long long)OVF_BIT);
+    }
+    atomicAdd(&flags->too_full, 1ull);
+}
+
+__global__ __launch_bounds__(256) void k_insert(uint64_t* __restrict__ slots, uint32_t m, uint32_t nb,
+                                                const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                size_t n, BuildFlags* flags) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) insert_one(slots, m, nb, keys[i], vals[i], flags);
+}
+
+// synthetic index: key_i = pi(i) written base 20 over ACDEFGHIKLMNPQRSTVWY
+__device__ __forceinline__ uint64_t synth_key(uint64_t i, uint64_t a, uint64_t b) {
+    const uint64_t M = 512000000000ull;  // 20^9; a < 2^25 and i < 2^39 => no overflow
+    uint64_t x = (a * i + b) % M;
+    uint64_t key = 0;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        uint32_t d = (uint32_t)(x % 20);
+        x /= 20;
+        // letter code (c - 'A') of digit d in "ACDEFGHIKLMNPQRSTVWY"
+        uint32_t code = d + (d >= 1) + (d >= 8) + (d >= 12) + (d >= 17) + (d >= 19);
+        key |= (uint64_t)code << (5 * j);  // least significant digit = last letter = bits [4:0]
+    }
+    return key;
+}
+
+__global__ __launch_bounds__(256) void k_insert_synth(uint64_t* __restrict__ slots, uint32_t m, uint32_t nb,
+                                                      uint64_t n_keys, const uint32_t* __restrict__ taxon_of_row,
+                                                      uint64_t n_tax, uint64_t a, uint64_t b, BuildFlags* flags) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n_keys; i += stride) insert_one(slots, m, nb, synth_key(i, a, b), taxon_of_row[i % n_tax], flags);
+}
+
+// random-sector gather microbenchmark: probe i reads `lanes` x 16 B starting at a bucket chosen
+// by a hash of i; xor-folds what it read.
+template <int LANES>
+__global__ __launch_bounds__(256) void k_gather(const uint64_t* __restrict__ slots, uint32_t nb, size_t n,
+                                                uint32_t* __restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = ((size_t)gridDim.x * blockDim.x) / LANES;
+    const uint32_t j = threadIdx.x % LANES;
+    constexpr uint32_t BUCKETS = (LANES + 3) / 4;
+    for (size_t i = t / LANES; i < n; i += stride) {
+        uint64_t h = mix45(i * 0x9E3779B97F4A7C15ull >> 19);
+        uint32_t bucket = (uint32_t)(h % (nb - BUCKETS + 1));
+        const u32x4* p = reinterpret_cast<const u32x4*>(slots) + ((size_t)bucket * 4 + j);
+        u32x4 e = __builtin_nontemporal_load(p);
+        uint32_t x = e.x ^ e.y ^ e.z ^ e.w;
+#pragma unroll
+        for (int o = 1; o < LANES; o <<= 1) x ^= (uint32_t)__shfl_xor((int)x, o, 64);
+        if (j == 0) out[i] = x;
+    }
+}
+
+__global__ void k_fill(uint64_t* p, size_t n, uint64_t v) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+inline int grid_for(size_t n, int per_block = 256, int max_blocks = 256 * 8) {
+    size_t g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > (size_t)max_blocks) g = max_blocks;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+uint32_t choose_m(uint64_t n, double load) {
+    if (!(load > 0.0 && load < 1.0)) load = 0.6;
+    double buckets = std::ceil((double)n / (SLOTS * load));
+    uint64_t m = (uint64_t)std::ceil(buckets / (double)(1u << A_BITS));
+    if (m < 1) m = 1;
+    return (uint32_t)m;
+}
+
+int alloc_table(umgap_index* ix, uint32_t m) {
+    uint64_t nb64 = (uint64_t)m << A_BITS;
+    if (nb64 + MAX_DISP >= (1ull << 32)) return fail(UMGAP_ERR_INVALID, "index too large for one table (>= 2^32 buckets); shard it");
+    uint32_t nb = (uint32_t)nb64;
+    size_t slots = ((size_t)nb + MAX_DISP) * SLOTS;
+    if (ix->d_slots) { (void)hipFree(ix->d_slots); ix->d_slots = nullptr; }
+    hipError_t e = hipMalloc((void**)&ix->d_slots, slots * sizeof(uint64_t));
+    if (e != hipSuccess) return fail(UMGAP_ERR_NOMEM, std::string("hipMalloc of the table failed: ") + hipGetErrorString(e));
+    ix->view.slots = ix->d_slots;
+    ix->view.m = m;
+    ix->view.nb = nb;
+    ix->view.first_bucket = 0;
+    ix->view.n_resident = nb + MAX_DISP;
+    ix->view.home_lo = 0;
+    ix->view.home_hi = nb;
+    return UMGAP_OK;
+}
+
+// copy buckets [0, MAX_DISP) behind the last bucket so probes never wrap
+int finish_halo(umgap_index* ix) {
+    UMGAP_HIP(hipMemcpyAsync(ix->d_slots + (size_t)ix->view.nb * SLOTS, ix->d_slots, MAX_DISP * SLOTS * sizeof(uint64_t),
+                             hipMemcpyDeviceToDevice, ix->stream));
+    UMGAP_HIP(hipStreamSynchronize(ix->stream));
+    return UMGAP_OK;
+}
+
+int new_handle(int device, umgap_index** out) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    umgap_index* ix = new umgap_index();
+    ix->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ix; return fail(UMGAP_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    *out = ix;
+    return UMGAP_OK;
+}
+
+// Generic build driver: `insert(ix, flags)` enqueues the insert kernels on ix->stream.
+template <class F>
+int build_with(umgap_index* ix, uint64_t n, double load, F insert) {
+    uint32_t m = choose_m(n, load);
+    BuildFlags* d_flags = nullptr;
+    UMGAP_HIP(hipMalloc((void**)&d_flags, sizeof(BuildFlags)));
+    int rc = UMGAP_OK;
+    for (int attempt = 0; attempt < 4; attempt++) {
+        rc = alloc_table(ix, m);
+        if (rc) break;
+        size_t nslots = ((size_t)ix->view.nb + MAX_DISP) * SLOTS;
+        hipLaunchKernelGGL(k_fill, dim3(grid_for(nslots)), dim3(256), 0, ix->stream, ix->d_slots, nslots, EMPTY_SLOT);
+        hipError_t e = hipMemsetAsync(d_flags, 0, sizeof(BuildFlags), ix->stream);
+        if (e != hipSuccess) { rc = fail(UMGAP_ERR_DEVICE, hipGetErrorString(e)); break; }
+        rc = insert(ix, d_flags);
+        if (rc) break;
+        BuildFlags h{};
+        e = hipMemcpyAsync(&h, d_flags, sizeof(h), hipMemcpyDeviceToHost, ix->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+        if (e != hipSuccess) { rc = fail(UMGAP_ERR_DEVICE, std::string("index build: ") + hipGetErrorString(e)); break; }
+        if (h.bad_key) { rc = fail(UMGAP_ERR_BUILD, "index build: " + std::to_string(h.bad_key) + " keys are not 45-bit packed 9-mers"); break; }
+        if (h.duplicate) { rc = fail(UMGAP_ERR_BUILD, "index build: " + std::to_string(h.duplicate) + " duplicate keys (keys must be distinct, cf. fst::MapBuilder::insert)"); break; }
+        if (!h.too_full) { rc = finish_halo(ix); break; }
+        m = m + m / 4 + 1;  // grow and retry
+        rc = fail(UMGAP_ERR_BUILD, "index build: table too full");
+    }
+    (void)hipFree(d_flags);
+    ix->n_keys = n;
+    return rc;
+}
+
+int ensure_stage(umgap_index* ix) {
+    if (ix->stage_cap) return UMGAP_OK;
+    const size_t cap = 4u << 20;  // keys per chunk: 32 MiB keys + 16 MiB results
+    for (int i = 0; i < 2; i++) {
+        UMGAP_HIP(hipHostMalloc(&ix->h_stage[i], cap * 12, hipHostMallocDefault));
+        UMGAP_HIP(hipMalloc(&ix->d_stage[i], cap * 12));
+    }
+    ix->stage_cap = cap;
+    return UMGAP_OK;
+}
+
+}  // namespace
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" {
+
+int umgap_pack9(const char* s, uint64_t* key45) {
+    uint64_t k = 0;
+    for (int i = 0; i < 9; i++) {
+        unsigned char c = (unsigned char)s[i];
+        if (c < 'A' || c > 'Z') return 0;
+        k = (k << 5) | (uint64_t)(c - 'A');
+    }
+    *key45 = k;
+    return 1;
+}
+void umgap_unpack9(uint64_t key45, char* s) {
+    for (int i = 0; i < 9; i++) s[i] = (char)('A' + ((key45 >> (5 * (8 - i))) & 31));
+}
+
+int umgap_index_build9_dev(const uint64_t* d_keys, const uint32_t* d_taxa, size_t n, double load, int device,
+                           umgap_index** out) {
+    if (!out || (n && (!d_keys || !d_taxa))) return fail(UMGAP_ERR_INVALID, "umgap_index_build9_dev: null argument");
+    umgap_index* ix = nullptr;
+    int rc = new_handle(device, &ix);
+    if (rc) return rc;
+    rc = build_with(ix, n, load, [&](umgap_index* x, BuildFlags* f) {
+        if (n) hipLaunchKernelGGL(k_insert, dim3(grid_for(n)), dim3(256), 0, x->stream, x->d_slots, x->view.m, x->view.nb, d_keys, d_taxa, n, f);
+        return UMGAP_OK;
+    });
+    if (rc) { umgap_index_free(ix); return rc; }
+    *out = ix;
+    return UMGAP_OK;
+}
+
+int umgap_index_build9(const uint64_t* keys, const uint32_t* taxa, size_t n, double load, int device, umgap_index** out) {
+    if (!out || (n && (!keys || !taxa))) return fail(UMGAP_ERR_INVALID, "umgap_index_build9: null argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    uint64_t* dk = nullptr;
+    uint32_t* dv = nullptr;
+    if (n) {
+        UMGAP_HIP(hipMalloc((void**)&dk, n * sizeof(uint64_t)));
+        hipError_t e = hipMalloc((void**)&dv, n * sizeof(uint32_t));
+        if (e != hipSuccess) { (void)hipFree(dk); return fail(UMGAP_ERR_NOMEM, hipGetErrorString(e)); }
+        e = hipMemcpy(dk, keys, n * sizeof(uint64_t), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(dv, taxa, n * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(dk); (void)hipFree(dv); return fail(UMGAP_ERR_DEVICE, hipGetErrorString(e)); }
+    }
+    rc = umgap_index_build9_dev(dk, dv, n, load, device, out);
+    if (dk) (void)hipFree(dk);
+    if (dv) (void)hipFree(dv);
+    return rc;
+}
+
+int umgap_synth_index_build(uint64_t n_keys, const uint32_t* d_taxon_of_row, uint64_t n_tax, uint64_t a, uint64_t b,
+                            double load, int device, umgap_index** out) {
+    if (!out || !d_taxon_of_row || !n_tax) return fail(UMGAP_ERR_INVALID, "umgap_synth_index_build: null argument");
+    if (a >= (1ull << 25) || (a % 2) == 0 || (a % 5) == 0 || n_keys > 512000000000ull)
+        return fail(UMGAP_ERR_INVALID, "umgap_synth_index_build: need odd a < 2^25 with a % 5 != 0 and n_keys <= 20^9");
+    umgap_index* ix = nullptr;
+    int rc = new_handle(device, &ix);
+    if (rc) return rc;
+    rc = build_with(ix, n_keys, load, [&](umgap_index* x, BuildFlags* f) {
+        hipLaunchKernelGGL(k_insert_synth, dim3(grid_for(n_keys, 256, 256 * 16)), dim3(256), 0, x->stream, x->d_slots, x->view.m,
+                           x->view.nb, n_keys, d_taxon_of_row, n_tax, a, b % 512000000000ull, f);
+        return UMGAP_OK;
+    });
+    if (rc) { umgap_index_free(ix); return rc; }
+    *out = ix;
+    return UMGAP_OK;
+}
+
+void umgap_index_free(umgap_index* ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    if (ix->d_slots) (void)hipFree(ix->d_slots);
+    for (int i = 0; i < 2; i++) {
+        if (ix->h_stage[i]) (void)hipHostFree(ix->h_stage[i]);
+        if (ix->d_stage[i]) (void)hipFree(ix->d_stage[i]);
+    }
+    if (ix->stream) (void)hipStreamDestroy(ix->stream);
+    delete ix;
+}
+
+uint64_t umgap_index_num_keys(const umgap_index* ix) { return ix ? ix->n_keys : 0; }
+uint64_t umgap_index_num_buckets(const umgap_index* ix) { return ix ? ix->view.nb : 0; }
+uint64_t umgap_index_table_bytes(const umgap_index* ix) { return ix ? (uint64_t)ix->view.n_resident * 64 : 0; }
+int umgap_index_device(const umgap_index* ix) { return ix ? ix->device : -1; }
+
+int umgap_index_save(const umgap_index* ix, const char* path) {
+    if (!ix || !path) return fail(UMGAP_ERR_INVALID, "umgap_index_save: null argument");
+    if (ix->view.home_lo != 0 || ix->view.home_hi != ix->view.nb) return fail(UMGAP_ERR_INVALID, "umgap_index_save: handle holds a shard");
+    int rc = use_device(ix->device);
+    if (rc) return rc;
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(UMGAP_ERR_IO, std::string("cannot create ") + path + ": " + strerror(errno));
+    IndexFileHeader h{};
+    memcpy(h.magic, "UMGAPIX1", 8);
+    h.version = 1; h.kind = 9; h.n_keys = ix->n_keys; h.m = ix->view.m; h.nb = ix->view.nb;
+    h.mix_c1 = MIX_C1; h.mix_c2 = MIX_C2; h.r_bits = R_BITS; h.slots = SLOTS;
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
+    const size_t chunk = 64u << 20;
+    std::vector<char> buf(chunk);
+    size_t total = (size_t)ix->view.nb * 64;
+    for (size_t off = 0; ok && off < total; off += chunk) {
+        size_t len = std::min(chunk, total - off);
+        if (hipMemcpy(buf.data(), (const char*)ix->d_slots + off, len, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+        ok = fwrite(buf.data(), 1, len, f) == len;
+    }
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) return fail(UMGAP_ERR_IO, std::string("error writing ") + path);
+    return UMGAP_OK;
+}
+
+int umgap_index_open_shard(const char* path, uint32_t device_mask, uint32_t shard, uint32_t n_shards, umgap_index** out) {
+    if (!path || !out) return fail(UMGAP_ERR_INVALID, "umgap_index_open: null argument");
+    if (n_shards == 0) n_shards = 1;
+    if (shard >= n_shards) return fail(UMGAP_ERR_INVALID, "umgap_index_open: shard >= n_shards");
+    if (!device_mask) return fail(UMGAP_ERR_INVALID, "umgap_index_open: empty device mask");
+    int device = __builtin_ctz(device_mask);
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(UMGAP_ERR_IO, std::string("cannot open ") + path + ": " + strerror(errno));
+    IndexFileHeader h{};
+    if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "UMGAPIX1", 8) != 0) {
+        fclose(f);
+        return fail(UMGAP_ERR_FORMAT, std::string(path) + ": not a UMGAPIX1 index (fst files must be converted: umgap printindex | umgap buildindex)");
+    }
+    if (h.version != 1 || h.kind != 9 || h.r_bits != R_BITS || h.slots != SLOTS || h.mix_c1 != MIX_C1 || h.mix_c2 != MIX_C2 ||
+        h.m == 0 || h.nb != ((uint64_t)h.m << A_BITS)) {
+        fclose(f);
+        return fail(UMGAP_ERR_FORMAT, std::string(path) + ": unsupported UMGAPIX1 parameters");
+    }
+    umgap_index* ix = nullptr;
+    int rc = new_handle(device, &ix);
+    if (rc) { fclose(f); return rc; }
+    uint32_t lo = (uint32_t)((uint64_t)h.nb * shard / n_shards), hi = (uint32_t)((uint64_t)h.nb * (shard + 1) / n_shards);
+    uint32_t resident = hi - lo + MAX_DISP;
+    hipError_t e = hipMalloc((void**)&ix->d_slots, (size_t)resident * 64);
+    if (e != hipSuccess) { fclose(f); umgap_index_free(ix); return fail(UMGAP_ERR_NOMEM, std::string("hipMalloc of the table failed: ") + hipGetErrorString(e)); }
+    ix->n_keys = h.n_keys;
+    ix->view = TableView{ix->d_slots, h.m, h.nb, lo, resident, lo, hi};
+    // body [lo, hi) then the halo (wraps to bucket 0 for the last shard)
+    const size_t chunk = 64u << 20;
+    void* pinned = nullptr;
+    if (hipHostMalloc(&pinned, chunk, hipHostMallocDefault) != hipSuccess) { fclose(f); umgap_index_free(ix); return fail(UMGAP_ERR_NOMEM, "hipHostMalloc failed"); }
+    auto load_range = [&](uint64_t first_bucket, uint64_t count, size_t dst_bucket) -> bool {
+        if (fseeko(f, (off_t)(sizeof(h) + first_bucket * 64), SEEK_SET) != 0) return false;
+        size_t total = (size_t)count * 64, done = 0;
+        while (done < total) {
+            size_t len = std::min(chunk, total - done);
+            if (fread(pinned, 1, len, f) != len) return false;
+            if (hipMemcpy((char*)ix->d_slots + dst_bucket * 64 + done, pinned, len, hipMemcpyHostToDevice) != hipSuccess) return false;
+            done += len;
+        }
+        return true;
+    };
+    bool ok = load_range(lo, hi - lo, 0);
+    for (uint32_t d = 0; ok && d < MAX_DISP; d++) ok = load_range(((uint64_t)hi + d) % h.nb, 1, (size_t)(hi - lo) + d);
+    (void)hipHostFree(pinned);
+    fclose(f);
+    if (!ok) { umgap_index_free(ix); return fail(UMGAP_ERR_IO, std::string(path) + ": truncated or unreadable table"); }
+    *out = ix;
+    return UMGAP_OK;
+}
+
+int umgap_index_open(const char* path, uint32_t device_mask, umgap_index** out) {
+    return umgap_index_open_shard(path, device_mask, 0, 1, out);
+}
+
+int umgap_index_set_shard(umgap_index* ix, uint32_t shard, uint32_t n_shards) {
+    if (!ix || n_shards == 0 || shard >= n_shards) return fail(UMGAP_ERR_INVALID, "umgap_index_set_shard: bad argument");
+    if (ix->view.first_bucket != 0 || ix->view.n_resident != ix->view.nb + MAX_DISP) return fail(UMGAP_ERR_INVALID, "umgap_index_set_shard: handle does not hold the whole table");
+    uint32_t nb = ix->view.nb;
+    // the whole table stays resident; only the owned home range shrinks (slots pointer is kept at
+    // bucket 0, so "local" indices are offset back by home_lo)
+    ix->view.home_lo = (uint32_t)((uint64_t)nb * shard / n_shards);
+    ix->view.home_hi = (uint32_t)((uint64_t)nb * (shard + 1) / n_shards);
+    ix->view.slots = ix->d_slots + (size_t)ix->view.home_lo * SLOTS;
+    return UMGAP_OK;
+}
+
+int umgap_index_owner9_dev(const umgap_index* ix, const uint64_t* d_keys, size_t n, uint32_t n_shards, uint32_t* d_owner, void* stream) {
+    if (!ix || !n_shards || (n && (!d_keys || !d_owner))) return fail(UMGAP_ERR_INVALID, "umgap_index_owner9_dev: bad argument");
+    int rc = use_device(ix->device);
+    if (rc) return rc;
+    if (n) hipLaunchKernelGGL(k_owner9, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, d_keys, n, ix->view.m, ix->view.nb, n_shards, d_owner);
+    UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}
+
+int umgap_index_lookup9_dev(umgap_index* ix, const uint64_t* d_keys, size_t n, uint32_t miss, uint32_t* d_out, void* stream) {
+    if (!ix || (n && (!d_keys || !d_out))) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup9_dev: null argument");
+    int rc = use_device(ix->device);
+    if (rc) return rc;
+    if (n) hipLaunchKernelGGL(k_lookup9, dim3(grid_for(n, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, d_keys, n, miss, d_out, ix->view);
+    UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}
+
+// measurement-only entry: the lane-per-key variant
+int umgap_index_lookup9_lane_dev(umgap_index* ix, const uint64_t* d_keys, size_t n, uint32_t miss, uint32_t* d_out, void* stream) {
+    if (!ix || (n && (!d_keys || !d_out))) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup9_lane_dev: null argument");
+    int rc = use_device(ix->device);
+    if (rc) return rc;
+    if (n) hipLaunchKernelGGL(k_lookup9_lane, dim3(grid_for(n, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, d_keys, n, miss, d_out, ix->view);
+    UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}
+
+int umgap_index_lookup_prot9_dev(umgap_index* ix, const uint8_t* d_bytes, const uint64_t* d_offsets, const uint64_t* d_out_offsets,
+                                 size_t n_prot, uint32_t miss, uint32_t* d_out, void* stream) {
+    if (!ix || (n_prot && (!d_bytes || !d_offsets || !d_out_offsets || !d_out))) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup_prot9_dev: null argument");
+    int rc = use_device(ix->device);
+    if (rc) return rc;
+    if (!n_prot) return UMGAP_OK;
+    uint64_t n_windows = 0;
+    UMGAP_HIP(hipMemcpyAsync(&n_windows, d_out_offsets + n_prot, sizeof(uint64_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    UMGAP_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (n_windows) hipLaunchKernelGGL(k_lookup_prot9, dim3(grid_for(n_windows)), dim3(256), 0, (hipStream_t)stream, d_bytes, d_offsets, d_out_offsets, n_prot, (size_t)n_windows, miss, d_out, ix->view);
+    UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}
+
+int umgap_index_lookup9(umgap_index* ix, const uint64_t* keys, size_t n, uint32_t miss, uint32_t* out) {
+    if (!ix || (n && (!keys || !out))) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup9: null argument");
+    int rc = use_device(ix->device);
+    if (rc) return rc;
+    rc = ensure_stage(ix);
+    if (rc) return rc;
+    // two staging slots ping-pong on the handle's stream: H2D(k) -> probe(k) -> D2H(k); the host
+    // copies chunk k+1 into the other pinned slot while chunk k is in flight.
+    const size_t cap = ix->stage_cap;
+    hipEvent_t done[2];
+    for (int i = 0; i < 2; i++) UMGAP_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+    size_t pending_off[2] = {0, 0}, pending_len[2] = {0, 0};
+    int slot = 0;
+    auto drain = [&](int s) -> int {
+        if (!pending_len[s]) return UMGAP_OK;
+        UMGAP_HIP(hipEventSynchronize(done[s]));
+        memcpy(out + pending_off[s], (char*)ix->h_stage[s] + cap * 8, pending_len[s] * 4);
+        pending_len[s] = 0;
+        return UMGAP_OK;
+    };
+    for (size_t off = 0; off < n; off += cap, slot ^= 1) {
+        size_t len = std::min(cap, n - off);
+        rc = drain(slot);
+        if (rc) break;
+        memcpy(ix->h_stage[slot], keys + off, len * 8);
+        uint64_t* dk = (uint64_t*)ix->d_stage[slot];
+        uint32_t* dout = (uint32_t*)((char*)ix->d_stage[slot] + cap * 8);
+        UMGAP_HIP(hipMemcpyAsync(dk, ix->h_stage[slot], len * 8, hipMemcpyHostToDevice, ix->stream));
+        hipLaunchKernelGGL(k_lookup9, dim3(grid_for(len)), dim3(256), 0, ix->stream, dk, len, miss, dout, ix->view);
+        UMGAP_HIP(hipMemcpyAsync((char*)ix->h_stage[slot] + cap * 8, dout, len * 4, hipMemcpyDeviceToHost, ix->stream));
+        UMGAP_HIP(hipEventRecord(done[slot], ix->stream));
+        pending_off[slot] = off;
+        pending_len[slot] = len;
+    }
+    if (!rc) rc = drain(0);
+    if (!rc) rc = drain(1);
+    for (int i = 0; i < 2; i++) (void)hipEventDestroy(done[i]);
+    return rc;
+}
+
+int umgap_bench_gather_dev(umgap_index* ix, size_t n, uint32_t bytes_per_probe, uint32_t* d_out, void* stream) {
+    if (!ix || !d_out) return fail(UMGAP_ERR_INVALID, "umgap_bench_gather_dev: null argument");
+    int rc = use_device(ix->device);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t nb = ix->view.n_resident;
+    int g = 256 * 8;
+    switch (bytes_per_probe) {
+        case 16: hipLaunchKernelGGL(k_gather<1>, dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out); break;
+        case 32: hipLaunchKernelGGL(k_gather<2>, dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out); break;
+        case 64: hipLaunchKernelGGL(k_gather<4>, dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out); break;
+        case 128: hipLaunchKernelGGL(k_gather<8>, dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out); break;
+        case 256: hipLaunchKernelGGL(k_gather<16>, dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out); break;
+        default: return fail(UMGAP_ERR_INVALID, "umgap_bench_gather_dev: bytes_per_probe must be 16, 32, 64, 128 or 256");
+    }
+    UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,210 @@
+// pipeline.hip — library plumbing (errors, device selection), the seedextend stage on device and
+// the synthetic read generator used by bench.py / the parity tests.  gfx950 only.
+#include "taxonomy.hpp"
+
+namespace umgap {
+
+static thread_local std::string g_last_error;
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+int fail(int code, const std::string& msg) {
+    g_last_error = msg;
+    return code;
+}
+
+int use_device(int device) {
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(UMGAP_ERR_DEVICE, "no usable GPU (hipGetDeviceCount: " + std::string(e == hipSuccess ? "0 devices" : hipGetErrorString(e)) +
+                                          "); libumgap_hip has no CPU fallback");
+    if (device < 0 || device >= count) return fail(UMGAP_ERR_INVALID, "device " + std::to_string(device) + " out of range (" + std::to_string(count) + " visible)");
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(UMGAP_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    return UMGAP_OK;
+}
+
+}  // namespace umgap
+
+using namespace umgap;
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// seedextend, unranked mode: src/commands/seedextend.rs:99-148 restated per record, in place.
+// The reference appends a 0 sentinel (:99) and collects (start, end) seeds; here everything
+// outside the seeds is overwritten with 0 (taxa2agg drops zeros, src/commands/taxa2agg.rs:169).
+// One lane per record (records are short: <= a few hundred items).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_seedextend(const uint64_t* __restrict__ offsets, uint32_t stride, size_t n_records,
+                                                    uint32_t min_seed, uint32_t max_gap, uint32_t* __restrict__ taxa,
+                                                    uint32_t* __restrict__ kept) {
+    size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; r < n_records; r += step) {
+        uint64_t off = offsets ? offsets[r] : (uint64_t)r * stride;
+        uint32_t n = offsets ? (uint32_t)(offsets[r + 1] - off) : stride;
+        uint32_t* t = taxa + off;
+        auto at = [&](uint32_t i) -> uint32_t { return i < n ? t[i] : 0u; };  // index n = the sentinel
+        const uint32_t len = n + 1;
+        uint32_t cursor = 0, nkept = 0;
+        auto emit = [&](uint32_t s, uint32_t e) {  // seeds.push((s, e)); slices are clamped like taxons[s..e]
+            if (e > n) e = n;                      // the sentinel itself is never stored
+            if (s > e) s = e;
+            for (uint32_t i = cursor; i < s; i++) t[i] = 0;
+            nkept += e - s;
+            cursor = e > cursor ? e : cursor;
+        };
+        uint32_t start = 0, end = 1;
+        uint32_t last_tid = at(start), same_tid = 1, same_max = 1;
+        while (end < len) {
+            uint32_t cur = at(end);
+            if (last_tid == cur) { same_tid += 1; end += 1; continue; }                 // :109-113
+            if (last_tid == 0 && same_tid > max_gap) {                                  // :116-127
+                if (same_max >= min_seed) emit(start, end - same_tid);
+                start = end;
+                last_tid = cur;
+                same_tid = 1;
+                same_max = 1;
+                end += 1;
+                continue;
+            }
+            if (last_tid == 0 && (end - start) == same_tid) {                           // :130-134
+                end += 1;
+                start = end;
+                continue;
+            }
+            if (last_tid != 0) same_max = same_max > same_tid ? same_max : same_tid;    // :137-139
+            last_tid = cur;
+            same_tid = 1;
+            end += 1;
+        }
+        if (same_max >= min_seed) {                                                     // :143-148
+            if (last_tid == 0) end -= same_tid;
+            emit(start, end);
+        }
+        for (uint32_t i = cursor; i < n; i++) t[i] = 0;
+        if (kept) kept[r] = nkept;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// synthetic reads (DESIGN.md "Synthetic workload", seed 44)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ uint64_t synth_key(uint64_t i, uint64_t a, uint64_t b) {
+    const uint64_t M = 512000000000ull;
+    uint64_t x = (a * i + b) % M;
+    uint64_t key = 0;
+#pragma unroll
+    for (int j = 0; j < 9; j++) {
+        uint32_t d = (uint32_t)(x % 20);
+        x /= 20;
+        uint32_t code = d + (d >= 1) + (d >= 8) + (d >= 12) + (d >= 17) + (d >= 19);
+        key |= (uint64_t)code << (5 * j);
+    }
+    return key;
+}
+
+__global__ __launch_bounds__(256) void k_synth_reads(TaxView V, const uint32_t* __restrict__ taxon_of_row,
+                                                     const uint32_t* __restrict__ row_of_id, uint64_t n_tax, uint64_t n_keys,
+                                                     uint64_t a, uint64_t b, uint64_t seed, uint64_t first_pair,
+                                                     uint64_t n_pairs, uint32_t kpp, uint64_t* __restrict__ keys) {
+    const uint64_t M = 512000000000ull;
+    uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t total = n_pairs * kpp;
+    for (; g < total; g += step) {
+        uint64_t p = first_pair + g / kpp;
+        uint32_t j = (uint32_t)(g % kpp);
+        uint64_t r0 = splitmix64(seed ^ (p * 0x9E3779B97F4A7C15ull));
+        uint64_t s = r0 % n_tax;  // source taxon (row)
+        uint64_t rj = splitmix64(r0 + (uint64_t)(j + 1) * 0xD1B54A32D192ED03ull);
+        uint32_t cls = (uint32_t)(rj % 100);
+        uint64_t member = ~0ull;
+        if (cls < 60) {
+            // member whose taxon lies on the source's root path: half the time the source itself
+            uint32_t pre = V.by_id[taxon_of_row[s]].x;
+            uint32_t depth = V.depth[pre];
+            uint32_t up = ((rj >> 8) & 1) ? (uint32_t)((rj >> 9) % (depth + 1)) : 0u;
+            for (uint32_t k = 0; k < up; k++) pre = V.parent_pre[pre];
+            uint64_t ra = row_of_id[V.id_of_pre[pre]];
+            if (ra < n_keys) {
+                uint64_t cnt = (n_keys - ra + n_tax - 1) / n_tax;
+                member = ra + n_tax * ((rj >> 20) % cnt);
+            }
+        } else if (cls < 70) {
+            // unrelated member; slots j and j^1 share it, so some unrelated taxa occur twice and
+            // survive `-l 2`
+            uint64_t rp = splitmix64(r0 + (uint64_t)((j >> 1) + 1) * 0xA24BAED4963EE407ull);
+            member = rp % n_keys;
+        }
+        uint64_t key;
+        if (member != ~0ull) {
+            key = synth_key(member, a, b);
+        } else {
+            key = synth_key(n_keys + (rj >> 8) % (M - n_keys), a, b);  // pi(i), i >= n_keys: never a member
+            if (cls == 99) key = (key & ~(31ull << 10)) | (23ull << 10);  // an 'X': outside the 20-letter alphabet
+        }
+        keys[g] = key;
+    }
+}
+
+inline int grid_for(size_t n) {
+    size_t g = (n + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > 256 * 16) g = 256 * 16;
+    return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* umgap_last_error(void) { return g_last_error.c_str(); }
+const char* umgap_version(void) { return "1.1.1"; }
+int umgap_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
+int umgap_seedextend_dev(const uint64_t* d_offsets, size_t n_records, uint32_t min_seed_size, uint32_t max_gap_size,
+                         uint32_t* d_taxa, uint32_t* d_kept, int device, void* stream) {
+    if (n_records && (!d_offsets || !d_taxa)) return fail(UMGAP_ERR_INVALID, "umgap_seedextend_dev: null argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    if (n_records) hipLaunchKernelGGL(k_seedextend, dim3(grid_for(n_records)), dim3(256), 0, (hipStream_t)stream, d_offsets, 0u, n_records, min_seed_size, max_gap_size, d_taxa, d_kept);
+    UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}
+
+int umgap_seedextend_strided_dev(uint32_t stride, size_t n_records, uint32_t min_seed_size, uint32_t max_gap_size,
+                                 uint32_t* d_taxa, uint32_t* d_kept, int device, void* stream) {
+    if (n_records && !d_taxa) return fail(UMGAP_ERR_INVALID, "umgap_seedextend_strided_dev: null argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    if (n_records) hipLaunchKernelGGL(k_seedextend, dim3(grid_for(n_records)), dim3(256), 0, (hipStream_t)stream, (const uint64_t*)nullptr, stride, n_records, min_seed_size, max_gap_size, d_taxa, d_kept);
+    UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}
+
+int umgap_synth_reads9_dev(const umgap_taxonomy* tx, const uint32_t* d_taxon_of_row, const uint32_t* d_row_of_id, uint64_t n_tax,
+                           uint64_t n_keys, uint64_t a, uint64_t b, uint64_t seed, uint64_t first_pair, uint64_t n_pairs,
+                           uint32_t kmers_per_pair, uint64_t* d_keys45, void* stream) {
+    if (!tx || !d_taxon_of_row || !d_row_of_id || !d_keys45 || !n_tax || !n_keys || !kmers_per_pair) return fail(UMGAP_ERR_INVALID, "umgap_synth_reads9_dev: bad argument");
+    if (n_keys >= 512000000000ull) return fail(UMGAP_ERR_INVALID, "umgap_synth_reads9_dev: n_keys must be < 20^9");
+    int rc = use_device(tx->device);
+    if (rc) return rc;
+    TaxView V = view_of(tx, 0);
+    if (n_pairs) hipLaunchKernelGGL(k_synth_reads, dim3(grid_for(n_pairs * kmers_per_pair)), dim3(256), 0, (hipStream_t)stream, V, d_taxon_of_row, d_row_of_id, n_tax, n_keys, a, b % 512000000000ull, seed, first_pair, n_pairs, kmers_per_pair, d_keys45);
+    UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}
+
+}  // extern "C"

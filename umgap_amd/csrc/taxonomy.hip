@@ -1,0 +1,207 @@
+// taxonomy.hip — umgap_taxonomy_create: host-side derivation of the preorder-interval tables
+// (taxonomy.hpp) and their upload.  Start-up cost only (src/commands/taxa2agg.rs:104-109).
+#include <algorithm>
+
+#include "taxonomy.hpp"
+
+using namespace umgap;
+
+namespace {
+constexpr uint32_t NONE = UMGAP_NONE;
+
+template <class T>
+int upload(T** dst, const std::vector<T>& src) {
+    size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    hipError_t e = hipMalloc((void**)dst, bytes);
+    if (e != hipSuccess) return fail(UMGAP_ERR_NOMEM, std::string("hipMalloc(taxonomy): ") + hipGetErrorString(e));
+    if (!src.empty()) {
+        e = hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return fail(UMGAP_ERR_DEVICE, std::string("hipMemcpy(taxonomy): ") + hipGetErrorString(e));
+    }
+    return UMGAP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int umgap_taxonomy_create(const uint32_t* id, const uint32_t* parent, const uint8_t* valid, const uint8_t* rank, size_t n,
+                          int device, umgap_taxonomy** out) {
+    if (!out || (n && (!id || !parent || !valid || !rank))) return fail(UMGAP_ERR_INVALID, "umgap_taxonomy_create: null argument");
+    // TaxonTree::new indexes taxons[0] (src/taxon.rs:226): empty input panics
+    if (n == 0) return fail(UMGAP_ERR_PANIC, "index out of bounds: the len is 0 but the index is 0");
+    uint32_t max_id = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (id[i] == NONE || parent[i] == NONE) return fail(UMGAP_ERR_FORMAT, "taxon id >= 2^32-1 is not supported");
+        max_id = std::max(max_id, id[i]);
+    }
+    const uint32_t len = max_id + 1;  // TaxonList::new (src/taxon.rs:135-145)
+    std::vector<uint32_t> row_of_id(len, NONE);
+    for (size_t i = 0; i < n; i++) {
+        if (row_of_id[id[i]] != NONE) return fail(UMGAP_ERR_FORMAT, "duplicate taxon id " + std::to_string(id[i]) + " (refused; the reference keeps the last row but both child links)");
+        row_of_id[id[i]] = (uint32_t)i;
+    }
+    // root = the only taxon with id == parent (src/taxon.rs:228-246)
+    uint32_t root = NONE;
+    size_t n_roots = 0;
+    for (size_t i = 0; i < n; i++)
+        if (id[i] == parent[i]) { n_roots++; root = id[i]; }
+    if (n_roots > 1) return fail(UMGAP_ERR_PANIC, "More than one root!");
+    if (n_roots == 0) return fail(UMGAP_ERR_PANIC, "There's no root!");
+
+    // children in row order, CSR keyed by parent id (parents >= len can never be reached)
+    std::vector<uint32_t> child_start(len + 1, 0), child(n);
+    for (size_t i = 0; i < n; i++)
+        if (id[i] != parent[i] && parent[i] < len) child_start[parent[i] + 1]++;
+    for (uint32_t p = 0; p < len; p++) child_start[p + 1] += child_start[p];
+    {
+        std::vector<uint32_t> cur(child_start.begin(), child_start.end() - 1);
+        for (size_t i = 0; i < n; i++)
+            if (id[i] != parent[i] && parent[i] < len) child[cur[parent[i]]++] = id[i];
+    }
+
+    auto* tx = new umgap_taxonomy();
+    tx->device = device;
+    tx->root = root;
+    tx->len = len;
+    tx->n_rows = (uint32_t)n;
+    tx->h_pre.assign(len, NONE);
+    tx->h_last.assign(len, NONE);
+    tx->h_depth.assign(len, NONE);
+    tx->h_snap[0].assign(len, NONE);
+    tx->h_snap[1].assign(len, NONE);
+    std::vector<uint32_t> parent_pre, depth_of_pre, id_of_pre, snap_pre[2];
+    parent_pre.reserve(n); depth_of_pre.reserve(n); id_of_pre.reserve(n);
+    snap_pre[0].reserve(n); snap_pre[1].reserve(n);
+
+    // preorder DFS from the root, children in row order (= EulerIterator order, src/taxon.rs:309-392;
+    // = with_filtered order, src/taxon.rs:251-271).  snapping: nearest ancestor-or-self passing
+    // the filter, seeded with Some(root) (src/taxon.rs:279,294-301).
+    auto passes = [&](uint32_t t, int ranked) {
+        uint32_t r = row_of_id[t];
+        return r != NONE && valid[r] && (!ranked || rank[r] != 0);
+    };
+    struct Frame { uint32_t node, cursor, snap0, snap1; };
+    std::vector<Frame> stack;
+    uint32_t counter = 0;
+    auto enter = [&](uint32_t node, uint32_t inh0, uint32_t inh1, uint32_t par_pre, uint32_t depth) {
+        uint32_t s0 = passes(node, 0) ? node : inh0, s1 = passes(node, 1) ? node : inh1;
+        tx->h_pre[node] = counter;
+        tx->h_depth[node] = depth;
+        tx->h_snap[0][node] = s0;
+        tx->h_snap[1][node] = s1;
+        parent_pre.push_back(par_pre);
+        depth_of_pre.push_back(depth);
+        id_of_pre.push_back(node);
+        snap_pre[0].push_back(s0);
+        snap_pre[1].push_back(s1);
+        counter++;
+        stack.push_back({node, child_start[node], s0, s1});
+    };
+    enter(root, root, root, 0, 0);
+    while (!stack.empty()) {
+        Frame& f = stack.back();
+        if (f.cursor < child_start[f.node + 1]) {
+            uint32_t c = child[f.cursor++];
+            if (tx->h_pre[c] != NONE) {  // cannot happen without duplicate ids; guard against cycles
+                delete tx;
+                return fail(UMGAP_ERR_FORMAT, "taxon " + std::to_string(c) + " is reachable twice");
+            }
+            uint32_t ppre = tx->h_pre[f.node], d = tx->h_depth[f.node] + 1, s0 = f.snap0, s1 = f.snap1;
+            enter(c, s0, s1, ppre, d);
+        } else {
+            tx->h_last[f.node] = counter - 1;
+            stack.pop_back();
+        }
+    }
+    tx->n_reach = counter;
+
+    // error tables for ids that are not reachable (tree::Tree::new src/tree/mod.rs:35-46 and
+    // rmq::rtl src/rmq/rtl.rs:42-49 walk `parents`): first absent ancestor-or-self and the number of
+    // parent steps to it; kind 2 when the chain leaves the list (index out of bounds panic).
+    std::vector<uint8_t> err_kind(len, 0);
+    std::vector<uint32_t> err_payload(len, 0), err_dist(len, 0);
+    std::vector<uint8_t> state(len, 0);  // 0 unresolved, 1 on the current path, 2 resolved
+    for (uint32_t t = 0; t < len; t++) {
+        if (tx->h_pre[t] != NONE) { state[t] = 2; continue; }
+        if (row_of_id[t] == NONE) { state[t] = 2; err_kind[t] = 1; err_payload[t] = t; err_dist[t] = 0; }
+    }
+    std::vector<uint32_t> path;
+    for (uint32_t t0 = 0; t0 < len; t0++) {
+        if (state[t0] == 2) continue;
+        path.clear();
+        uint32_t t = t0;
+        uint8_t kind = 0;
+        uint32_t payload = 0, dist = 0;
+        for (;;) {
+            if (t >= len) { kind = 2; payload = t; dist = 0; break; }  // parents[t] out of bounds
+            if (state[t] == 2) { kind = err_kind[t]; payload = err_payload[t]; dist = err_dist[t]; break; }
+            if (state[t] == 1) {
+                delete tx;
+                return fail(UMGAP_ERR_FORMAT, "parent cycle through taxon " + std::to_string(t) + " (the reference would not terminate)");
+            }
+            state[t] = 1;
+            path.push_back(t);
+            t = parent[row_of_id[t]];
+        }
+        // kind 0 here would mean the chain reaches a reachable node, i.e. t0 is reachable: impossible
+        for (size_t k = path.size(); k-- > 0;) {
+            dist++;
+            uint32_t p = path[k];
+            state[p] = 2;
+            err_kind[p] = kind ? kind : 1;
+            err_payload[p] = payload;
+            err_dist[p] = dist;
+        }
+    }
+
+    int rc = use_device(device);
+    if (rc) { delete tx; return rc; }
+    std::vector<uint2> by_id(len);
+    for (uint32_t t = 0; t < len; t++) by_id[t] = make_uint2(tx->h_pre[t], tx->h_last[t]);
+    hipError_t e = hipStreamCreateWithFlags(&tx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete tx; return fail(UMGAP_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    rc = upload(&tx->d_by_id, by_id);
+    if (!rc) rc = upload(&tx->d_err_kind, err_kind);
+    if (!rc) rc = upload(&tx->d_err_payload, err_payload);
+    if (!rc) rc = upload(&tx->d_err_dist, err_dist);
+    if (!rc) rc = upload(&tx->d_parent_pre, parent_pre);
+    if (!rc) rc = upload(&tx->d_depth, depth_of_pre);
+    if (!rc) rc = upload(&tx->d_id_of_pre, id_of_pre);
+    if (!rc) rc = upload(&tx->d_snap_of_pre[0], snap_pre[0]);
+    if (!rc) rc = upload(&tx->d_snap_of_pre[1], snap_pre[1]);
+    if (rc) { umgap_taxonomy_free(tx); return rc; }
+    *out = tx;
+    return UMGAP_OK;
+}
+
+void umgap_taxonomy_free(umgap_taxonomy* tx) {
+    if (!tx) return;
+    (void)hipSetDevice(tx->device);
+    void* ptrs[] = {tx->d_by_id, tx->d_err_kind, tx->d_err_payload, tx->d_err_dist, tx->d_parent_pre, tx->d_depth,
+                    tx->d_id_of_pre, tx->d_snap_of_pre[0], tx->d_snap_of_pre[1], tx->d_stage};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (tx->stream) (void)hipStreamDestroy(tx->stream);
+    delete tx;
+}
+
+uint32_t umgap_taxonomy_root(const umgap_taxonomy* tx) { return tx ? tx->root : NONE; }
+uint32_t umgap_taxonomy_len(const umgap_taxonomy* tx) { return tx ? tx->len : 0; }
+uint32_t umgap_taxonomy_reachable(const umgap_taxonomy* tx) { return tx ? tx->n_reach : 0; }
+
+int umgap_taxonomy_snapping(const umgap_taxonomy* tx, int ranked_only, uint32_t* out) {
+    if (!tx || !out) return fail(UMGAP_ERR_INVALID, "umgap_taxonomy_snapping: null argument");
+    const std::vector<uint32_t>& s = tx->h_snap[ranked_only ? 1 : 0];
+    memcpy(out, s.data(), s.size() * sizeof(uint32_t));
+    return UMGAP_OK;
+}
+
+int umgap_taxonomy_preorder(const umgap_taxonomy* tx, uint32_t* pre, uint32_t* last, uint32_t* depth) {
+    if (!tx) return fail(UMGAP_ERR_INVALID, "umgap_taxonomy_preorder: null argument");
+    if (pre) memcpy(pre, tx->h_pre.data(), tx->len * sizeof(uint32_t));
+    if (last) memcpy(last, tx->h_last.data(), tx->len * sizeof(uint32_t));
+    if (depth) memcpy(depth, tx->h_depth.data(), tx->len * sizeof(uint32_t));
+    return UMGAP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// taxonomy.hpp — the taxonomy as it lives in HBM / Infinity Cache (gfx950 library internal).
+//
+// Replaces the start-up state of `umgap taxa2agg` (src/commands/taxa2agg.rs:104-109):
+// TaxonList (src/taxon.rs:131-178), TaxonTree + snapping (src/taxon.rs:214-302) and the
+// per-aggregator tables (parents: src/tree/lca.rs:25-30; ancestors: src/rmq/rtl.rs:27-31;
+// Euler tour + RMQ: src/rmq/lca.rs:23-39) by ONE preorder-interval encoding:
+//
+//   by id   (len = max id + 1):  {pre, last}   pre = preorder index of the taxon (children in TSV
+//                                 order, as the Euler tour visits them), last = largest preorder
+//                                 index in its subtree; pre = NONE if the id is absent or not
+//                                 reachable from the root
+//   by pre  (n_reach entries):   parent_pre, depth, id, snap_valid, snap_ranked
+//
+//   a is an ancestor-or-self of b   <=>   pre[a] <= pre[b] <= last[a]
+//   LCA(a, b), pre[a] < pre[b], a not an ancestor of b
+//          = first x on b's parent chain with pre[x] <= pre[a]      (walk in `parent_pre`)
+//
+// ~22 B per taxon (2.5 M taxa: ~55 MB): resident in the 256 MiB Infinity Cache, top levels in L2.
+#pragma once
+#include <vector>
+
+#include "common.hpp"
+
+struct umgap_taxonomy {
+    int device = 0;
+    uint32_t root = 0, len = 0, n_reach = 0, n_rows = 0;
+    // host copies (by id)
+    std::vector<uint32_t> h_pre, h_last, h_depth, h_snap[2];
+    // device, by id
+    uint2* d_by_id = nullptr;            // {pre, last}
+    uint8_t* d_err_kind = nullptr;       // 0 ok, 1 UnknownTaxon(payload), 2 panic (parent id out of bounds)
+    uint32_t* d_err_payload = nullptr;   // first absent ancestor-or-self
+    uint32_t* d_err_dist = nullptr;      // parent steps to reach it (BFS level in tree::Tree::new)
+    // device, by pre
+    uint32_t* d_parent_pre = nullptr;
+    uint32_t* d_depth = nullptr;
+    uint32_t* d_id_of_pre = nullptr;
+    uint32_t* d_snap_of_pre[2] = {nullptr, nullptr};  // [0] valid, [1] valid && ranked
+    hipStream_t stream = nullptr;
+    // staging for the host-pointer umgap_aggregate
+    void* d_stage = nullptr;
+    size_t d_stage_bytes = 0;
+};
+
+namespace umgap {
+struct TaxView {
+    const uint2* by_id;
+    const uint8_t* err_kind;
+    const uint32_t* err_payload;
+    const uint32_t* err_dist;
+    const uint32_t* parent_pre;
+    const uint32_t* depth;
+    const uint32_t* id_of_pre;
+    const uint32_t* snap_of_pre;  // chosen by ranked_only
+    uint32_t len, n_reach;
+};
+inline TaxView view_of(const umgap_taxonomy* tx, int ranked_only) {
+    return TaxView{tx->d_by_id,   tx->d_err_kind, tx->d_err_payload, tx->d_err_dist, tx->d_parent_pre,
+                   tx->d_depth,   tx->d_id_of_pre, tx->d_snap_of_pre[ranked_only ? 1 : 0], tx->len, tx->n_reach};
+}
+}  // namespace umgap
