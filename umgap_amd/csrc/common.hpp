@@ -37,6 +37,10 @@ int use_device(int device);
 //   bucket it skipped carries the overflow flag, so a probe walks on only past flagged buckets:
 //   a hit or a miss costs ONE 64-byte sector unless the home bucket overflowed at build time.
 //   (bucket, d, R) determines h, hence the key: exact match, no false positives.
+//   The very few keys (~1e-5 at load 0.6) whose chain would exceed MAX_DISP live in the STASH: a
+//   sorted array of (home bucket << 28 | R) -> taxon, binary-searched only by probes that walked
+//   the whole chain through flagged buckets.  This keeps the load factor (13.3 B/key at 0.6)
+//   independent of the table size.
 // ---------------------------------------------------------------------------------------------
 static constexpr uint64_t MASK45 = (1ull << 45) - 1;
 static constexpr uint32_t R_BITS = 28;
@@ -76,6 +80,9 @@ struct TableView {
     uint32_t n_resident;    // shard: buckets resident (home range + halo)
     uint32_t home_lo;       // shard owns home buckets [home_lo, home_hi)
     uint32_t home_hi;
+    const uint64_t* stash_keys;  // sorted (home bucket << 28 | R); whole stash on every shard
+    const uint32_t* stash_vals;
+    uint32_t n_stash;
 };
 
 // "UMGAPIX1" file header (little endian), followed by nb*64 bytes of buckets.
@@ -88,7 +95,8 @@ struct IndexFileHeader {
     uint32_t nb;
     uint64_t mix_c1, mix_c2;
     uint32_t r_bits, slots;
-    uint64_t reserved[2];
+    uint64_t n_stash;  // followed (after the buckets) by n_stash x {u64 key, u64 taxon}
+    uint64_t reserved;
 };
 
 }  // namespace umgap
@@ -97,6 +105,9 @@ struct umgap_index {
     int device = 0;
     uint64_t* d_slots = nullptr;  // nb * 8 slots (whole table) or the shard's range
     uint64_t n_keys = 0;
+    uint64_t* d_stash_keys = nullptr;
+    uint32_t* d_stash_vals = nullptr;
+    uint32_t n_stash = 0;
     umgap::TableView view{};
     hipStream_t stream = nullptr;
     // pinned staging for the host-pointer entry points

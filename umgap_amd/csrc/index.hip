@@ -40,6 +40,20 @@ __device__ __forceinline__ uint32_t eval_bucket(u32x4 e, uint32_t want, uint32_t
     return quad_or((m0 | m1) | (ovf << 1));
 }
 
+// Binary search of the stash (a few thousand entries, L2 resident); reached only by probes that
+// exhausted the displacement chain.
+__device__ __forceinline__ uint32_t stash_lookup(const TableView& T, uint32_t home, uint32_t tag, uint32_t miss) {
+    const uint64_t want = ((uint64_t)home << R_BITS) | tag;
+    uint32_t lo = 0, hi = T.n_stash;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        uint64_t k = T.stash_keys[mid];
+        if (k == want) return T.stash_vals[mid];
+        if (k < want) lo = mid + 1; else hi = mid;
+    }
+    return miss;
+}
+
 // home bucket -> (resident?, local index)
 __device__ __forceinline__ bool locate(const TableView& T, uint64_t key, uint32_t& local, uint32_t& tag) {
     uint32_t b;
@@ -77,12 +91,17 @@ __device__ __forceinline__ void wave_probe64(const TableView& T, uint32_t local,
         uint32_t w = want[r] & R_MASK, val;
         uint32_t f = eval_bucket(e[r], w, j, val);
         // displacement chain: only past buckets flagged as overflowed (halo keeps p in range)
-        for (uint32_t d = 1; valid && !(f & 1u) && (f & 2u) && d <= MAX_DISP; d++) {
+        uint32_t d = 1;
+        for (; valid && !(f & 1u) && (f & 2u) && d <= MAX_DISP; d++) {
             p[r] += 4;
             w += 1u << R_BITS;
             f = eval_bucket(__builtin_nontemporal_load(p[r]), w, j, val);
         }
         res[r] = (valid && (f & 1u)) ? val : miss;
+        if (valid && !(f & 1u) && (f & 2u) && T.n_stash) {  // chain exhausted through flagged buckets
+            uint32_t home = (uint32_t)((reinterpret_cast<const uint64_t*>(p[r]) - T.slots) / SLOTS) - MAX_DISP + T.home_lo;
+            res[r] = stash_lookup(T, home, want[r] & R_MASK, miss);
+        }
     }
     if (j == 0) {
 #pragma unroll
@@ -133,7 +152,8 @@ __global__ __launch_bounds__(256) void k_lookup9_lane(const uint64_t* __restrict
                 UMGAP_CMP(e0) UMGAP_CMP(e1) UMGAP_CMP(e2) UMGAP_CMP(e3)
 #undef UMGAP_CMP
                 bool ovf = e0.x != 0xFFFFFFFFu && (e0.x >> 31);
-                if (hit || !ovf || d == MAX_DISP) break;
+                if (hit || !ovf) break;
+                if (d == MAX_DISP) { if (T.n_stash) res = stash_lookup(T, local + T.home_lo, tag, miss); break; }
                 p += 4;
                 want += 1u << R_BITS;
             }
@@ -195,10 +215,11 @@ __global__ __launch_bounds__(256) void k_owner9(const uint64_t* __restrict__ key
 // ------------------------------------------------------------------------------------------
 // build kernels
 // ------------------------------------------------------------------------------------------
-struct BuildFlags { unsigned long long too_full, duplicate, bad_key; };
+struct BuildFlags { unsigned long long too_full, duplicate, bad_key, n_stash; };
+constexpr uint32_t STASH_CAP = 1u << 22;  // entries the build may divert before the table is grown
 
 __device__ __forceinline__ void insert_one(uint64_t* __restrict__ slots, uint32_t m, uint32_t nb, uint64_t key,
-                                           uint32_t val, BuildFlags* flags) {
+                                           uint32_t val, BuildFlags* flags, uint64_t* __restrict__ stash) {
     if (key >> 45) { atomicAdd(&flags->bad_key, 1ull); return; }
     uint32_t b, tag;
     probe_of_key(key, m, b, tag);
@@ -217,15 +238,22 @@ __device__ __forceinline__ void insert_one(uint64_t* __restrict__ slots, uint32_
         // bucket is full: flag it so probes walk on, then try the next bucket
         atomicOr((unsigned long long*)s, (unsigned long long)OVF_BIT);
     }
-    atomicAdd(&flags->too_full, 1ull);
+    // the whole chain is full: divert to the stash (sorted and de-duplicated on the host afterwards)
+    unsigned long long at = atomicAdd(&flags->n_stash, 1ull);
+    if (at < STASH_CAP) {
+        stash[2 * at] = ((uint64_t)b << R_BITS) | tag;
+        stash[2 * at + 1] = val;
+    } else {
+        atomicAdd(&flags->too_full, 1ull);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_insert(uint64_t* __restrict__ slots, uint32_t m, uint32_t nb,
                                                 const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                size_t n, BuildFlags* flags) {
+                                                size_t n, BuildFlags* flags, uint64_t* stash) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) insert_one(slots, m, nb, keys[i], vals[i], flags);
+    for (; i < n; i += stride) insert_one(slots, m, nb, keys[i], vals[i], flags, stash);
 }
 
 // synthetic index: key_i = pi(i) written base 20 over ACDEFGHIKLMNPQRSTVWY
@@ -246,10 +274,10 @@ __device__ __forceinline__ uint64_t synth_key(uint64_t i, uint64_t a, uint64_t b
 
 __global__ __launch_bounds__(256) void k_insert_synth(uint64_t* __restrict__ slots, uint32_t m, uint32_t nb,
                                                       uint64_t n_keys, const uint32_t* __restrict__ taxon_of_row,
-                                                      uint64_t n_tax, uint64_t a, uint64_t b, BuildFlags* flags) {
+                                                      uint64_t n_tax, uint64_t a, uint64_t b, BuildFlags* flags, uint64_t* stash) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (; i < n_keys; i += stride) insert_one(slots, m, nb, synth_key(i, a, b), taxon_of_row[i % n_tax], flags);
+    for (; i < n_keys; i += stride) insert_one(slots, m, nb, synth_key(i, a, b), taxon_of_row[i % n_tax], flags, stash);
 }
 
 // random-sector gather microbenchmark: probe i reads `lanes` x 16 B starting at a bucket chosen
@@ -312,6 +340,33 @@ int alloc_table(umgap_index* ix, uint32_t m) {
     ix->view.n_resident = nb + MAX_DISP;
     ix->view.home_lo = 0;
     ix->view.home_hi = nb;
+    ix->view.stash_keys = nullptr;
+    ix->view.stash_vals = nullptr;
+    ix->view.n_stash = 0;
+    return UMGAP_OK;
+}
+
+// install a stash given as host pairs {composite key, taxon}; sorts, refuses duplicates
+int set_stash(umgap_index* ix, std::vector<std::pair<uint64_t, uint64_t>>& entries) {
+    if (ix->d_stash_keys) { (void)hipFree(ix->d_stash_keys); ix->d_stash_keys = nullptr; }
+    if (ix->d_stash_vals) { (void)hipFree(ix->d_stash_vals); ix->d_stash_vals = nullptr; }
+    ix->n_stash = 0;
+    ix->view.stash_keys = nullptr; ix->view.stash_vals = nullptr; ix->view.n_stash = 0;
+    if (entries.empty()) return UMGAP_OK;
+    std::sort(entries.begin(), entries.end());
+    for (size_t i = 1; i < entries.size(); i++)
+        if (entries[i].first == entries[i - 1].first) return fail(UMGAP_ERR_BUILD, "index build: duplicate keys (keys must be distinct, cf. fst::MapBuilder::insert)");
+    std::vector<uint64_t> k(entries.size());
+    std::vector<uint32_t> v(entries.size());
+    for (size_t i = 0; i < entries.size(); i++) { k[i] = entries[i].first; v[i] = (uint32_t)entries[i].second; }
+    UMGAP_HIP(hipMalloc((void**)&ix->d_stash_keys, k.size() * 8));
+    UMGAP_HIP(hipMalloc((void**)&ix->d_stash_vals, v.size() * 4));
+    UMGAP_HIP(hipMemcpy(ix->d_stash_keys, k.data(), k.size() * 8, hipMemcpyHostToDevice));
+    UMGAP_HIP(hipMemcpy(ix->d_stash_vals, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    ix->n_stash = (uint32_t)k.size();
+    ix->view.stash_keys = ix->d_stash_keys;
+    ix->view.stash_vals = ix->d_stash_vals;
+    ix->view.n_stash = ix->n_stash;
     return UMGAP_OK;
 }
 
@@ -339,7 +394,9 @@ template <class F>
 int build_with(umgap_index* ix, uint64_t n, double load, F insert) {
     uint32_t m = choose_m(n, load);
     BuildFlags* d_flags = nullptr;
+    uint64_t* d_stash = nullptr;
     UMGAP_HIP(hipMalloc((void**)&d_flags, sizeof(BuildFlags)));
+    UMGAP_HIP(hipMalloc((void**)&d_stash, (size_t)STASH_CAP * 16));
     int rc = UMGAP_OK;
     for (int attempt = 0; attempt < 4; attempt++) {
         rc = alloc_table(ix, m);
@@ -348,7 +405,7 @@ int build_with(umgap_index* ix, uint64_t n, double load, F insert) {
         hipLaunchKernelGGL(k_fill, dim3(grid_for(nslots)), dim3(256), 0, ix->stream, ix->d_slots, nslots, EMPTY_SLOT);
         hipError_t e = hipMemsetAsync(d_flags, 0, sizeof(BuildFlags), ix->stream);
         if (e != hipSuccess) { rc = fail(UMGAP_ERR_DEVICE, hipGetErrorString(e)); break; }
-        rc = insert(ix, d_flags);
+        rc = insert(ix, d_flags, d_stash);
         if (rc) break;
         BuildFlags h{};
         e = hipMemcpyAsync(&h, d_flags, sizeof(h), hipMemcpyDeviceToHost, ix->stream);
@@ -356,11 +413,20 @@ int build_with(umgap_index* ix, uint64_t n, double load, F insert) {
         if (e != hipSuccess) { rc = fail(UMGAP_ERR_DEVICE, std::string("index build: ") + hipGetErrorString(e)); break; }
         if (h.bad_key) { rc = fail(UMGAP_ERR_BUILD, "index build: " + std::to_string(h.bad_key) + " keys are not 45-bit packed 9-mers"); break; }
         if (h.duplicate) { rc = fail(UMGAP_ERR_BUILD, "index build: " + std::to_string(h.duplicate) + " duplicate keys (keys must be distinct, cf. fst::MapBuilder::insert)"); break; }
-        if (!h.too_full) { rc = finish_halo(ix); break; }
-        m = m + m / 4 + 1;  // grow and retry
+        if (!h.too_full) {
+            std::vector<uint64_t> raw(2 * (size_t)h.n_stash);
+            if (h.n_stash && hipMemcpy(raw.data(), d_stash, raw.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(UMGAP_ERR_DEVICE, "index build: stash copy failed"); break; }
+            std::vector<std::pair<uint64_t, uint64_t>> entries(h.n_stash);
+            for (size_t i = 0; i < h.n_stash; i++) entries[i] = {raw[2 * i], raw[2 * i + 1]};
+            rc = set_stash(ix, entries);
+            if (!rc) rc = finish_halo(ix);
+            break;
+        }
+        m = m + m / 4 + 1;  // more than STASH_CAP keys did not fit: grow and retry
         rc = fail(UMGAP_ERR_BUILD, "index build: table too full");
     }
     (void)hipFree(d_flags);
+    (void)hipFree(d_stash);
     ix->n_keys = n;
     return rc;
 }
@@ -403,8 +469,8 @@ int umgap_index_build9_dev(const uint64_t* d_keys, const uint32_t* d_taxa, size_
     umgap_index* ix = nullptr;
     int rc = new_handle(device, &ix);
     if (rc) return rc;
-    rc = build_with(ix, n, load, [&](umgap_index* x, BuildFlags* f) {
-        if (n) hipLaunchKernelGGL(k_insert, dim3(grid_for(n)), dim3(256), 0, x->stream, x->d_slots, x->view.m, x->view.nb, d_keys, d_taxa, n, f);
+    rc = build_with(ix, n, load, [&](umgap_index* x, BuildFlags* f, uint64_t* st) {
+        if (n) hipLaunchKernelGGL(k_insert, dim3(grid_for(n)), dim3(256), 0, x->stream, x->d_slots, x->view.m, x->view.nb, d_keys, d_taxa, n, f, st);
         return UMGAP_OK;
     });
     if (rc) { umgap_index_free(ix); return rc; }
@@ -440,9 +506,9 @@ int umgap_synth_index_build(uint64_t n_keys, const uint32_t* d_taxon_of_row, uin
     umgap_index* ix = nullptr;
     int rc = new_handle(device, &ix);
     if (rc) return rc;
-    rc = build_with(ix, n_keys, load, [&](umgap_index* x, BuildFlags* f) {
+    rc = build_with(ix, n_keys, load, [&](umgap_index* x, BuildFlags* f, uint64_t* st) {
         hipLaunchKernelGGL(k_insert_synth, dim3(grid_for(n_keys, 256, 256 * 16)), dim3(256), 0, x->stream, x->d_slots, x->view.m,
-                           x->view.nb, n_keys, d_taxon_of_row, n_tax, a, b % 512000000000ull, f);
+                           x->view.nb, n_keys, d_taxon_of_row, n_tax, a, b % 512000000000ull, f, st);
         return UMGAP_OK;
     });
     if (rc) { umgap_index_free(ix); return rc; }
@@ -454,6 +520,8 @@ void umgap_index_free(umgap_index* ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
     if (ix->d_slots) (void)hipFree(ix->d_slots);
+    if (ix->d_stash_keys) (void)hipFree(ix->d_stash_keys);
+    if (ix->d_stash_vals) (void)hipFree(ix->d_stash_vals);
     for (int i = 0; i < 2; i++) {
         if (ix->h_stage[i]) (void)hipHostFree(ix->h_stage[i]);
         if (ix->d_stage[i]) (void)hipFree(ix->d_stage[i]);
@@ -478,6 +546,7 @@ int umgap_index_save(const umgap_index* ix, const char* path) {
     memcpy(h.magic, "UMGAPIX1", 8);
     h.version = 1; h.kind = 9; h.n_keys = ix->n_keys; h.m = ix->view.m; h.nb = ix->view.nb;
     h.mix_c1 = MIX_C1; h.mix_c2 = MIX_C2; h.r_bits = R_BITS; h.slots = SLOTS;
+    h.n_stash = ix->n_stash;
     bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
     const size_t chunk = 64u << 20;
     std::vector<char> buf(chunk);
@@ -486,6 +555,14 @@ int umgap_index_save(const umgap_index* ix, const char* path) {
         size_t len = std::min(chunk, total - off);
         if (hipMemcpy(buf.data(), (const char*)ix->d_slots + off, len, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
         ok = fwrite(buf.data(), 1, len, f) == len;
+    }
+    if (ok && ix->n_stash) {
+        std::vector<uint64_t> k(ix->n_stash), kv(2 * (size_t)ix->n_stash);
+        std::vector<uint32_t> v(ix->n_stash);
+        ok = hipMemcpy(k.data(), ix->d_stash_keys, k.size() * 8, hipMemcpyDeviceToHost) == hipSuccess &&
+             hipMemcpy(v.data(), ix->d_stash_vals, v.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
+        for (size_t i = 0; i < k.size(); i++) { kv[2 * i] = k[i]; kv[2 * i + 1] = v[i]; }
+        ok = ok && fwrite(kv.data(), 8, kv.size(), f) == kv.size();
     }
     ok = (fclose(f) == 0) && ok;
     if (!ok) return fail(UMGAP_ERR_IO, std::string("error writing ") + path);
@@ -518,7 +595,7 @@ int umgap_index_open_shard(const char* path, uint32_t device_mask, uint32_t shar
     hipError_t e = hipMalloc((void**)&ix->d_slots, (size_t)resident * 64);
     if (e != hipSuccess) { fclose(f); umgap_index_free(ix); return fail(UMGAP_ERR_NOMEM, std::string("hipMalloc of the table failed: ") + hipGetErrorString(e)); }
     ix->n_keys = h.n_keys;
-    ix->view = TableView{ix->d_slots, h.m, h.nb, lo, resident, lo, hi};
+    ix->view = TableView{ix->d_slots, h.m, h.nb, lo, resident, lo, hi, nullptr, nullptr, 0};
     // body [lo, hi) then the halo (wraps to bucket 0 for the last shard)
     const size_t chunk = 64u << 20;
     void* pinned = nullptr;
@@ -537,6 +614,15 @@ int umgap_index_open_shard(const char* path, uint32_t device_mask, uint32_t shar
     bool ok = load_range(lo, hi - lo, 0);
     for (uint32_t d = 0; ok && d < MAX_DISP; d++) ok = load_range(((uint64_t)hi + d) % h.nb, 1, (size_t)(hi - lo) + d);
     (void)hipHostFree(pinned);
+    if (ok && h.n_stash) {
+        std::vector<uint64_t> kv(2 * (size_t)h.n_stash);
+        ok = fseeko(f, (off_t)(sizeof(h) + (uint64_t)h.nb * 64), SEEK_SET) == 0 && fread(kv.data(), 8, kv.size(), f) == kv.size();
+        if (ok) {
+            std::vector<std::pair<uint64_t, uint64_t>> entries(h.n_stash);
+            for (size_t i = 0; i < h.n_stash; i++) entries[i] = {kv[2 * i], kv[2 * i + 1]};
+            if (set_stash(ix, entries)) { fclose(f); umgap_index_free(ix); return UMGAP_ERR_FORMAT; }
+        }
+    }
     fclose(f);
     if (!ok) { umgap_index_free(ix); return fail(UMGAP_ERR_IO, std::string(path) + ": truncated or unreadable table"); }
     *out = ix;
