@@ -6,29 +6,47 @@
 // rmq::mix src/rmq/mix.rs:57-93) and the snapping lookup (:178), over the preorder-interval
 // taxonomy of taxonomy.hpp.  One wavefront owns one read at a time.
 //
-// LCA* closed form (checked against the oracle's literal Tree::collapse):
-//   D = distinct taxa of the read that survive the filters;  M = the one with the largest preorder
-//   index (always a leaf of the induced tree);  h' = the smallest-preorder member of D that is NOT
-//   an ancestor-or-self of M (last[h] < pre[M]).  LCA* = M if h' does not exist, else LCA(h', M)
-//   = the first node on M's parent chain whose preorder index is <= pre[h'].
+// Stage 1, "peel" (agg::count + agg::filter): the read's taxa sit one per lane (two registers
+// cover 128 taxa).  Repeatedly: v = taxon of the first unprocessed lane; ballot(t == v) is the set
+// of its copies => multiplicity by popcount, all copies retired at once.  Iterations = number of
+// DISTINCT taxa, no memory traffic; one LEADER lane per surviving taxon carries it on.
+// Stage 2: leaders gather {pre, last} (the only taxonomy access that scales with the read).
+// Stage 3 (LCA*, SURVEY.md §8a row 15, checked against the oracle's literal Tree::collapse):
+//   M = surviving taxon with the largest preorder index (always a leaf of the induced tree);
+//   h' = smallest-preorder surviving taxon that is NOT an ancestor-or-self of M (last[h] < pre[M]);
+//   LCA* = M if there is no h', else LCA(h', M) = first node on M's parent chain with pre <= pre[h'].
 #include "taxonomy.hpp"
 
 using namespace umgap;
 
 namespace {
 constexpr uint32_t NONE = UMGAP_NONE;
+constexpr uint64_t NOERR = ~0ull;
 
-__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { uint32_t w = (uint32_t)__shfl_xor((int)v, o, 64); v = w > v ? w : v; }
-    return v;
+// ---- wave reductions: 4 DPP steps inside each row of 16, then 4 readlanes --------------------
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {  // all lanes must be active
+    v = max(v, dpp<0xB1>(v));   // quad_perm [1,0,3,2]
+    v = max(v, dpp<0x4E>(v));   // quad_perm [2,3,0,1]
+    v = max(v, dpp<0x141>(v));  // row_half_mirror
+    v = max(v, dpp<0x140>(v));  // row_mirror
+    uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    uint32_t c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
 }
 __device__ __forceinline__ uint32_t wave_min(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { uint32_t w = (uint32_t)__shfl_xor((int)v, o, 64); v = w < v ? w : v; }
-    return v;
+    v = min(v, dpp<0xB1>(v));
+    v = min(v, dpp<0x4E>(v));
+    v = min(v, dpp<0x141>(v));
+    v = min(v, dpp<0x140>(v));
+    uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    uint32_t c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return min(min(a, b), min(c, d));
 }
-__device__ __forceinline__ uint64_t wave_min64(uint64_t v) {
+__device__ __forceinline__ uint64_t wave_min64(uint64_t v) {  // error path only
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) {
         uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64);
@@ -39,61 +57,53 @@ __device__ __forceinline__ uint64_t wave_min64(uint64_t v) {
     return v;
 }
 
-// Sum of the scores of taxon `t` over the read, accumulated in input order exactly like
-// agg::count (src/agg/mod.rs:32-34: `*entry += count`, starting from 0.0).  Unscored input
-// counts 1.0 per occurrence (src/commands/taxa2agg.rs:150-152); integer counts are exact in f32.
-// `rp`/`sp` and `n` are wave-uniform, so the loads are scalar (s_load) and shared by all lanes.
-template <bool SCORED>
-__device__ __forceinline__ float read_sum(const uint32_t* __restrict__ rp, const float* __restrict__ sp, uint32_t n,
-                                          uint32_t t) {
-    if (SCORED) {
-        float acc = 0.0f;
-        for (uint32_t j = 0; j < n; j++) {
-            uint32_t tj = rp[j];
-            float sj = sp[j];
-            if (tj == t) acc = __fadd_rn(acc, sj);
-        }
-        return acc;
-    } else {
-        uint32_t c = 0;
-        uint32_t j = 0;
-        for (; j + 4 <= n; j += 4) {
-            uint32_t a = rp[j], b = rp[j + 1], cc = rp[j + 2], d = rp[j + 3];
-            c += (a == t) + (b == t) + (cc == t) + (d == t);
-        }
-        for (; j < n; j++) c += (rp[j] == t);
-        return (float)c;
-    }
-}
-
 struct Hit {
-    uint32_t pre, last;  // pre == NONE: this lane holds no surviving hit
+    uint32_t pre, last;  // pre == NONE: this lane holds no surviving taxon
 };
 
-// Classify one candidate taxon of the read: survives the filters?  known?  Returns the hit and
-// folds failures into `errkey` (smaller = reported first: BFS level, then Unknown before panic,
-// then payload — the order tree::Tree::new would meet them, src/tree/mod.rs:35-46).
-template <bool SCORED>
-__device__ __forceinline__ Hit classify(const TaxView& V, int method, const uint32_t* rp, const float* sp, uint32_t n,
-                                        uint32_t t, float lower_bound, bool counting, uint64_t& errkey) {
-    Hit h{NONE, NONE};
-    if (t == 0) return h;  // src/commands/taxa2agg.rs:169 drops taxon 0
-    if (counting) {
-        float s = read_sum<SCORED>(rp, sp, n, t);
-        if (!(s >= lower_bound)) return h;  // agg::filter keeps freq >= lower_bound
+// Position of (one of) the shallowest node(s) with preorder index in [a, b], a <= b, both
+// wave-uniform.  All 64 lanes take part: lanes read the partial 64-blocks at both ends (two
+// coalesced loads), lanes 0/1 the sparse-table entries covering the whole blocks in between; all
+// loads are independent (one round trip), then two DPP reductions.
+__device__ __forceinline__ uint32_t wave_argmin_depth(const TaxView& V, uint32_t a, uint32_t b, uint32_t lane) {
+    uint32_t d = NONE, pos = NONE;
+    const uint32_t ba = a >> 6, bb = b >> 6;
+    {   // left partial block (or the whole range when it sits in one block)
+        uint32_t p = a + lane, stop = ba == bb ? b : (a | 63u);
+        if (p <= stop) { d = V.depth[p]; pos = p; }
     }
+    if (bb > ba) {  // right partial block
+        uint32_t p = (b & ~63u) + lane;
+        if (p <= b) { uint32_t dd = V.depth[p]; if (dd < d) { d = dd; pos = p; } }
+        if (bb > ba + 1 && lane < 2) {  // whole blocks ba+1 .. bb-1
+            uint32_t len = bb - ba - 1, k = 31u - (uint32_t)__builtin_clz(len);
+            uint32_t start = lane == 0 ? ba + 1 : bb - (1u << k);
+            uint64_t e = V.sparse[(size_t)k * V.n_blocks + start];
+            uint32_t dd = (uint32_t)(e >> 32);
+            if (dd < d) { d = dd; pos = (uint32_t)e; }
+        }
+    }
+    const uint32_t m = wave_min(d);
+    return wave_min(d == m ? pos : NONE);
+}
+
+// Known?  Folds failures into `errkey` (smaller = reported first: BFS level in
+// tree::Tree::new (src/tree/mod.rs:35-46), then UnknownTaxon before panic, then payload).
+// tree_like: parents[]/ancestors[] walkers (tree::lca, tree::mix, rmq::rtl);
+// otherwise rmq::lca / rmq::mix, whose HashMap lookup fails with UnknownTaxon(t) itself.
+__device__ __forceinline__ Hit resolve(const TaxView& V, bool tree_like, uint32_t t, uint64_t& errkey) {
+    Hit h{NONE, NONE};
     if (t >= V.len) {
-        // tree/rtl: parents[id] out of bounds => panic; rmq::lca/mix: HashMap miss => UnknownTaxon(id)
-        errkey = min(errkey, method == UMGAP_METHOD_RMQ ? (uint64_t)t : ((1ull << 32) | t));
+        errkey = min(errkey, tree_like ? ((1ull << 32) | t) : (uint64_t)t);
         return h;
     }
     uint2 pl = V.by_id[t];
     if (pl.x == NONE) {
-        if (method == UMGAP_METHOD_RMQ) {
-            errkey = min(errkey, (uint64_t)t);  // first_occurence(t) fails (src/rmq/lca.rs:49-54)
-        } else {
+        if (tree_like) {
             uint64_t k = ((uint64_t)V.err_dist[t] << 33) | ((uint64_t)(V.err_kind[t] == 2) << 32) | V.err_payload[t];
             errkey = min(errkey, k);
+        } else {
+            errkey = min(errkey, (uint64_t)t);  // first_occurence(t) fails (src/rmq/lca.rs:49-54)
         }
         return h;
     }
@@ -103,7 +113,63 @@ __device__ __forceinline__ Hit classify(const TaxView& V, int method, const uint
 }
 
 // ---------------------------------------------------------------------------------------------
-// LCA* (both -m tree and -m rmq), one wave per read.
+// Stage 1 for reads of at most 128 taxa: t0/t1 = the lane's taxa (0 = none).  On return keep0 /
+// keep1 say whether the lane is the leader of a surviving distinct taxon, cnt0/cnt1 its sum.
+// Scores are summed in input order exactly like agg::count (src/agg/mod.rs:32-34).
+// ---------------------------------------------------------------------------------------------
+template <bool SCORED>
+__device__ __forceinline__ void peel(uint32_t t0, uint32_t t1, float s0, float s1, float lower_bound, uint32_t lane,
+                                     bool& keep0, bool& keep1, float& cnt0, float& cnt1) {
+    uint64_t rem0 = __ballot(t0 != 0), rem1 = __ballot(t1 != 0);
+    keep0 = keep1 = false;
+    cnt0 = cnt1 = 0.0f;
+    while (rem0 | rem1) {
+        const bool in0 = rem0 != 0;
+        const uint32_t src = in0 ? (uint32_t)__builtin_ctzll(rem0) : (uint32_t)__builtin_ctzll(rem1);
+        const uint32_t v = in0 ? __builtin_amdgcn_readlane(t0, src) : __builtin_amdgcn_readlane(t1, src);
+        const uint64_t m0 = __ballot(t0 == v), m1 = __ballot(t1 == v);
+        float sum;
+        if (SCORED) {
+            sum = 0.0f;
+            for (uint64_t b = m0; b; b &= b - 1) sum = __fadd_rn(sum, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(uint32_t, s0), (uint32_t)__builtin_ctzll(b))));
+            for (uint64_t b = m1; b; b &= b - 1) sum = __fadd_rn(sum, __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(uint32_t, s1), (uint32_t)__builtin_ctzll(b))));
+        } else {
+            sum = (float)(__builtin_popcountll(m0) + __builtin_popcountll(m1));
+        }
+        if (sum >= lower_bound) {  // agg::filter keeps freq >= lower_bound
+            if (in0) { if (lane == src) { keep0 = true; cnt0 = sum; } }
+            else     { if (lane == src) { keep1 = true; cnt1 = sum; } }
+        }
+        rem0 &= ~m0;
+        rem1 &= ~m1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic slow path for reads longer than 128 taxa: O(n^2) count with scalar loads; every lane
+// classifies the taxa at positions lane, lane+64, ...; only the FIRST occurrence of a taxon leads.
+// ---------------------------------------------------------------------------------------------
+template <bool SCORED>
+__device__ __forceinline__ bool survives_generic(const uint32_t* __restrict__ rp, const float* __restrict__ sp, uint32_t n,
+                                                 uint32_t j, uint32_t t, float lower_bound, float& sum) {
+    if (t == 0) return false;
+    sum = 0.0f;
+    uint32_t c = 0;
+    bool first = true;
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t ti = rp[i];
+        if (ti == t) {
+            if (i < j) first = false;
+            if (SCORED) sum = __fadd_rn(sum, sp[i]); else c++;
+        }
+    }
+    if (!SCORED) sum = (float)c;
+    return first && sum >= lower_bound;
+}
+
+// LCA* over an arbitrary number of taxa; `for_each` visits every surviving leader hit.
+// ---------------------------------------------------------------------------------------------
+// LCA* kernel (both -m tree and -m rmq), one wave per read.
 // ---------------------------------------------------------------------------------------------
 template <bool SCORED>
 __global__ __launch_bounds__(256) void k_agg_lca(TaxView V, int method, const uint32_t* __restrict__ taxa,
@@ -113,60 +179,76 @@ __global__ __launch_bounds__(256) void k_agg_lca(TaxView V, int method, const ui
     const uint32_t lane = threadIdx.x & 63;
     const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
-    // unscored input with lower_bound <= 1: every non-zero taxon has count >= 1 >= bound
-    const bool counting = SCORED || !(lower_bound <= 1.0f);
+    const bool tree_like = method != UMGAP_METHOD_RMQ;
     for (size_t r = wave0; r < n_reads; r += nwaves) {
         uint64_t off, end;
         if (offsets) { off = offsets[r]; end = offsets[r + 1]; } else { off = (uint64_t)r * stride; end = off + stride; }
-        // make the read's base and length scalar so that read_sum's loads are s_loads
         uint32_t off_lo = __builtin_amdgcn_readfirstlane((uint32_t)off), off_hi = __builtin_amdgcn_readfirstlane((uint32_t)(off >> 32));
         off = ((uint64_t)off_hi << 32) | off_lo;
         const uint32_t n = __builtin_amdgcn_readfirstlane((uint32_t)(end - off));
         const uint32_t* rp = taxa + off;
         const float* sp = SCORED ? scores + off : nullptr;
 
-        uint64_t errkey = ~0ull;
+        uint64_t errkey = NOERR;
         Hit h0{NONE, NONE}, h1{NONE, NONE};
-        uint32_t maxpre = 0;
+        uint32_t maxpre = 0, res_taxon, res_status;
         bool any = false;
-        // phase 1: classify every taxon, remember the first two chunks in registers
-        for (uint32_t c = 0; c * 64 < n; c++) {
-            uint32_t j = c * 64 + lane;
-            uint32_t t = j < n ? rp[j] : 0u;
-            Hit h = classify<SCORED>(V, method, rp, sp, n, t, lower_bound, counting, errkey);
-            if (c == 0) h0 = h;
-            if (c == 1) h1 = h;
-            if (h.pre != NONE) { any = true; maxpre = max(maxpre, h.pre); }
+        if (n <= 128) {
+            // ---- fast path: whole read in two registers per lane ----
+            uint32_t t0 = lane < n ? rp[lane] : 0u, t1 = 64 + lane < n ? rp[64 + lane] : 0u;
+            float s0 = 0.0f, s1 = 0.0f;
+            if (SCORED) { s0 = lane < n ? sp[lane] : 0.0f; s1 = 64 + lane < n ? sp[64 + lane] : 0.0f; }
+            bool keep0, keep1;
+            float c0, c1;
+            peel<SCORED>(t0, t1, s0, s1, lower_bound, lane, keep0, keep1, c0, c1);
+            if (keep0) h0 = resolve(V, tree_like, t0, errkey);
+            if (keep1) h1 = resolve(V, tree_like, t1, errkey);
+            if (h0.pre != NONE) { any = true; maxpre = h0.pre; }
+            if (h1.pre != NONE) { any = true; maxpre = max(maxpre, h1.pre); }
+        } else {
+            for (uint32_t c = 0; c * 64 < n; c++) {
+                uint32_t j = c * 64 + lane;
+                uint32_t t = j < n ? rp[j] : 0u;
+                float sum;
+                if (survives_generic<SCORED>(rp, sp, n, j, t, lower_bound, sum)) {
+                    Hit h = resolve(V, tree_like, t, errkey);
+                    if (h.pre != NONE) { any = true; maxpre = max(maxpre, h.pre); }
+                }
+            }
         }
-        uint32_t res_taxon, res_status;
-        uint64_t ek = wave_min64(errkey);
-        if (ek != ~0ull) {
-            bool panic = (ek >> 32) & 1;
-            res_status = panic ? UMGAP_READ_PANIC : UMGAP_READ_UNKNOWN_TAXON;
+        if (__any(errkey != NOERR)) {
+            uint64_t ek = wave_min64(errkey);
+            res_status = ((ek >> 32) & 1) ? UMGAP_READ_PANIC : UMGAP_READ_UNKNOWN_TAXON;
             res_taxon = (uint32_t)ek;
         } else if (!__any(any)) {
             res_status = UMGAP_READ_EMPTY;  // literal "1" (src/commands/taxa2agg.rs:174-175)
             res_taxon = 1;
         } else {
             const uint32_t M = wave_max(any ? maxpre : 0u);
-            // phase 2: smallest-preorder surviving taxon that is not an ancestor-or-self of M
             uint32_t hp = NONE;
-            if (h0.pre != NONE && h0.last < M) hp = min(hp, h0.pre);
-            if (h1.pre != NONE && h1.last < M) hp = min(hp, h1.pre);
-            for (uint32_t c = 2; c * 64 < n; c++) {  // long reads: classify again (rare)
-                uint32_t j = c * 64 + lane;
-                uint32_t t = j < n ? rp[j] : 0u;
-                uint64_t dummy = ~0ull;
-                Hit h = classify<SCORED>(V, method, rp, sp, n, t, lower_bound, counting, dummy);
-                if (h.pre != NONE && h.last < M) hp = min(hp, h.pre);
+            if (n <= 128) {
+                if (h0.pre != NONE && h0.last < M) hp = h0.pre;
+                if (h1.pre != NONE && h1.last < M) hp = min(hp, h1.pre);
+            } else {
+                for (uint32_t c = 0; c * 64 < n; c++) {  // long reads: classify again (rare)
+                    uint32_t j = c * 64 + lane;
+                    uint32_t t = j < n ? rp[j] : 0u;
+                    float sum;
+                    uint64_t dummy = NOERR;
+                    if (survives_generic<SCORED>(rp, sp, n, j, t, lower_bound, sum)) {
+                        Hit h = resolve(V, tree_like, t, dummy);
+                        if (h.pre != NONE && h.last < M) hp = min(hp, h.pre);
+                    }
+                }
             }
             hp = wave_min(hp);
-            uint32_t x = M;
             if (hp != NONE) {
-                // LCA(h', M): climb M's parent chain (uniform => scalar loads)
-                while (x > hp) x = __builtin_amdgcn_readfirstlane(V.parent_pre[x]);
+                // LCA(h', M) = parent of the shallowest node in (pre[h'], pre[M]]; its snap is precomputed
+                uint32_t c = wave_argmin_depth(V, hp + 1, M, lane);
+                res_taxon = V.psnap_of_pre[c];
+            } else {
+                res_taxon = V.snap_of_pre[M];  // snapping[aggregate] (src/commands/taxa2agg.rs:178)
             }
-            res_taxon = V.snap_of_pre[x];  // snapping[aggregate] (src/commands/taxa2agg.rs:178)
             res_status = res_taxon == NONE ? UMGAP_READ_PANIC : UMGAP_READ_OK;
         }
         if (lane == 0) {
@@ -204,7 +286,7 @@ int launch(umgap_taxonomy* tx, int method, int strategy, float factor, float low
     return UMGAP_OK;
 }
 
-}  // namespace
+}  // extern "C"
 
 extern "C" {
 

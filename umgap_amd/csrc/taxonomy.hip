@@ -154,6 +154,27 @@ int umgap_taxonomy_create(const uint32_t* id, const uint32_t* parent, const uint
         }
     }
 
+    // parent-snap tables and the sparse table of block-range depth minima (taxonomy.hpp)
+    std::vector<uint32_t> psnap_pre[2];
+    for (int k = 0; k < 2; k++) {
+        psnap_pre[k].resize(counter);
+        for (uint32_t p = 0; p < counter; p++) psnap_pre[k][p] = snap_pre[k][parent_pre[p]];
+    }
+    const uint32_t n_blocks = (counter + 63) / 64;
+    uint32_t n_levels = 1;
+    while ((1u << n_levels) <= n_blocks) n_levels++;
+    std::vector<uint64_t> sparse((size_t)n_levels * n_blocks, ~0ull);
+    for (uint32_t b = 0; b < n_blocks; b++) {
+        uint64_t best = ~0ull;
+        for (uint32_t p = b * 64; p < counter && p < b * 64 + 64; p++) best = std::min(best, ((uint64_t)depth_of_pre[p] << 32) | p);
+        sparse[b] = best;
+    }
+    for (uint32_t k = 1; k < n_levels; k++)
+        for (uint32_t b = 0; b + (1u << k) <= n_blocks; b++)
+            sparse[(size_t)k * n_blocks + b] = std::min(sparse[(size_t)(k - 1) * n_blocks + b], sparse[(size_t)(k - 1) * n_blocks + b + (1u << (k - 1))]);
+    tx->n_blocks = n_blocks;
+    tx->n_levels = n_levels;
+
     int rc = use_device(device);
     if (rc) { delete tx; return rc; }
     std::vector<uint2> by_id(len);
@@ -169,6 +190,9 @@ int umgap_taxonomy_create(const uint32_t* id, const uint32_t* parent, const uint
     if (!rc) rc = upload(&tx->d_id_of_pre, id_of_pre);
     if (!rc) rc = upload(&tx->d_snap_of_pre[0], snap_pre[0]);
     if (!rc) rc = upload(&tx->d_snap_of_pre[1], snap_pre[1]);
+    if (!rc) rc = upload(&tx->d_psnap_of_pre[0], psnap_pre[0]);
+    if (!rc) rc = upload(&tx->d_psnap_of_pre[1], psnap_pre[1]);
+    if (!rc) rc = upload(&tx->d_sparse, sparse);
     if (rc) { umgap_taxonomy_free(tx); return rc; }
     *out = tx;
     return UMGAP_OK;
@@ -178,7 +202,8 @@ void umgap_taxonomy_free(umgap_taxonomy* tx) {
     if (!tx) return;
     (void)hipSetDevice(tx->device);
     void* ptrs[] = {tx->d_by_id, tx->d_err_kind, tx->d_err_payload, tx->d_err_dist, tx->d_parent_pre, tx->d_depth,
-                    tx->d_id_of_pre, tx->d_snap_of_pre[0], tx->d_snap_of_pre[1], tx->d_stage};
+                    tx->d_id_of_pre, tx->d_snap_of_pre[0], tx->d_snap_of_pre[1], tx->d_psnap_of_pre[0], tx->d_psnap_of_pre[1],
+                    tx->d_sparse, tx->d_stage};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (tx->stream) (void)hipStreamDestroy(tx->stream);

@@ -13,7 +13,11 @@
 //
 //   a is an ancestor-or-self of b   <=>   pre[a] <= pre[b] <= last[a]
 //   LCA(a, b), pre[a] < pre[b], a not an ancestor of b
-//          = first x on b's parent chain with pre[x] <= pre[a]      (walk in `parent_pre`)
+//          = parent of the shallowest node with preorder index in (pre[a], pre[b]]
+//            (every node in that range is a proper descendant of the LCA, and the range holds the
+//             LCA's child on b's side).  Range-min over `depth` in O(1): the two partial 64-blocks
+//            are read by the wave (coalesced), whole blocks in between come from a sparse table
+//            of packed (depth << 32 | position) minima over 64-blocks (~5 MB, L2/Infinity Cache).
 //
 // ~22 B per taxon (2.5 M taxa: ~55 MB): resident in the 256 MiB Infinity Cache, top levels in L2.
 #pragma once
@@ -36,6 +40,9 @@ struct umgap_taxonomy {
     uint32_t* d_depth = nullptr;
     uint32_t* d_id_of_pre = nullptr;
     uint32_t* d_snap_of_pre[2] = {nullptr, nullptr};  // [0] valid, [1] valid && ranked
+    uint32_t* d_psnap_of_pre[2] = {nullptr, nullptr}; // snap of the PARENT of the node at pre (LCA answer in one load)
+    uint64_t* d_sparse = nullptr;                     // [levels][n_blocks] packed (depth << 32 | pos) block-range minima
+    uint32_t n_blocks = 0, n_levels = 0;
     hipStream_t stream = nullptr;
     // staging for the host-pointer umgap_aggregate
     void* d_stage = nullptr;
@@ -51,11 +58,14 @@ struct TaxView {
     const uint32_t* parent_pre;
     const uint32_t* depth;
     const uint32_t* id_of_pre;
-    const uint32_t* snap_of_pre;  // chosen by ranked_only
-    uint32_t len, n_reach;
+    const uint32_t* snap_of_pre;   // chosen by ranked_only
+    const uint32_t* psnap_of_pre;  // chosen by ranked_only
+    const uint64_t* sparse;
+    uint32_t len, n_reach, n_blocks;
 };
 inline TaxView view_of(const umgap_taxonomy* tx, int ranked_only) {
-    return TaxView{tx->d_by_id,   tx->d_err_kind, tx->d_err_payload, tx->d_err_dist, tx->d_parent_pre,
-                   tx->d_depth,   tx->d_id_of_pre, tx->d_snap_of_pre[ranked_only ? 1 : 0], tx->len, tx->n_reach};
+    return TaxView{tx->d_by_id, tx->d_err_kind, tx->d_err_payload, tx->d_err_dist, tx->d_parent_pre, tx->d_depth, tx->d_id_of_pre,
+                   tx->d_snap_of_pre[ranked_only ? 1 : 0], tx->d_psnap_of_pre[ranked_only ? 1 : 0], tx->d_sparse,
+                   tx->len, tx->n_reach, tx->n_blocks};
 }
 }  // namespace umgap
