@@ -6,10 +6,13 @@
 // rmq::mix src/rmq/mix.rs:57-93) and the snapping lookup (:178), over the preorder-interval
 // taxonomy of taxonomy.hpp.  One wavefront owns one read at a time.
 //
-// Stage 1, "peel" (agg::count + agg::filter): the read's taxa sit one per lane (two registers
-// cover 128 taxa).  Repeatedly: v = taxon of the first unprocessed lane; ballot(t == v) is the set
-// of its copies => multiplicity by popcount, all copies retired at once.  Iterations = number of
-// DISTINCT taxa, no memory traffic; one LEADER lane per surviving taxon carries it on.
+// Stage 1 (agg::count + agg::filter): the read's taxa sit one per lane (two registers cover 128
+// taxa).  Unscored reads count through a 256-slot open-addressing hash table in LDS private to the
+// wave: every lane inserts its taxon with ds_cmpst (the lane whose insert wins is the LEADER of
+// that distinct taxon) and bumps the slot's counter with ds_add -- ~50 wave instructions per read
+// whatever the number of distinct taxa.  Scored reads (-s) must add their scores in input order,
+// so they use a ballot "peel" instead: v = taxon of the first unprocessed lane, ballot(t == v) =
+// its copies, one iteration per DISTINCT taxon.
 // Stage 2: leaders gather {pre, last} (the only taxonomy access that scales with the read).
 // Stage 3 (LCA*, SURVEY.md §8a row 15, checked against the oracle's literal Tree::collapse):
 //   M = surviving taxon with the largest preorder index (always a leaf of the induced tree);
@@ -145,6 +148,48 @@ __device__ __forceinline__ void peel(uint32_t t0, uint32_t t1, float s0, float s
     }
 }
 
+// Unscored stage 1 through the wave's private LDS hash table (keys[256] all 0 = empty, cnt[256] all
+// 0 on entry and on exit).  One wave executes in lockstep and the LDS serves its instructions in
+// order, so every lane's ds_add has landed before any leader reads its counter back.
+__device__ __forceinline__ void lds_count(uint32_t* keys, uint32_t* cnt, uint32_t t0, uint32_t t1, float lower_bound,
+                                          bool& keep0, bool& keep1, float& cnt0, float& cnt1) {
+    uint32_t slot0 = 0, slot1 = 0;
+    bool lead0 = false, lead1 = false;
+    if (t0 != 0) {
+        slot0 = (t0 * 0x9E3779B1u) >> 24;
+        for (;;) {
+            uint32_t old = atomicCAS(&keys[slot0], 0u, t0);
+            if (old == 0u) { lead0 = true; break; }
+            if (old == t0) break;
+            slot0 = (slot0 + 1) & 255u;
+        }
+        atomicAdd(&cnt[slot0], 1u);
+    }
+    if (t1 != 0) {
+        slot1 = (t1 * 0x9E3779B1u) >> 24;
+        for (;;) {
+            uint32_t old = atomicCAS(&keys[slot1], 0u, t1);
+            if (old == 0u) { lead1 = true; break; }
+            if (old == t1) break;
+            slot1 = (slot1 + 1) & 255u;
+        }
+        atomicAdd(&cnt[slot1], 1u);
+    }
+    keep0 = keep1 = false;
+    cnt0 = cnt1 = 0.0f;
+    if (lead0) {
+        cnt0 = (float)atomicExch(&cnt[slot0], 0u);  // read the multiplicity and reset the slot
+        keep0 = cnt0 >= lower_bound;                // agg::filter keeps freq >= lower_bound
+    }
+    if (lead1) {
+        cnt1 = (float)atomicExch(&cnt[slot1], 0u);
+        keep1 = cnt1 >= lower_bound;
+    }
+    // every leader has read its counter before any key is cleared (lockstep), so no slot is reused early
+    if (lead0) atomicExch(&keys[slot0], 0u);
+    if (lead1) atomicExch(&keys[slot1], 0u);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Generic slow path for reads longer than 128 taxa: O(n^2) count with scalar loads; every lane
 // classifies the taxa at positions lane, lane+64, ...; only the FIRST occurrence of a taxon leads.
@@ -180,6 +225,13 @@ __global__ __launch_bounds__(256) void k_agg_lca(TaxView V, int method, const ui
     const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
     const bool tree_like = method != UMGAP_METHOD_RMQ;
+    __shared__ uint32_t lds_keys[4][256], lds_cnt[4][256];
+    uint32_t* wkeys = lds_keys[threadIdx.x >> 6];
+    uint32_t* wcnt = lds_cnt[threadIdx.x >> 6];
+    if (!SCORED) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) { wkeys[lane + 64 * i] = 0u; wcnt[lane + 64 * i] = 0u; }
+    }
     for (size_t r = wave0; r < n_reads; r += nwaves) {
         uint64_t off, end;
         if (offsets) { off = offsets[r]; end = offsets[r + 1]; } else { off = (uint64_t)r * stride; end = off + stride; }
@@ -200,7 +252,8 @@ __global__ __launch_bounds__(256) void k_agg_lca(TaxView V, int method, const ui
             if (SCORED) { s0 = lane < n ? sp[lane] : 0.0f; s1 = 64 + lane < n ? sp[64 + lane] : 0.0f; }
             bool keep0, keep1;
             float c0, c1;
-            peel<SCORED>(t0, t1, s0, s1, lower_bound, lane, keep0, keep1, c0, c1);
+            if (SCORED) peel<SCORED>(t0, t1, s0, s1, lower_bound, lane, keep0, keep1, c0, c1);
+            else lds_count(wkeys, wcnt, t0, t1, lower_bound, keep0, keep1, c0, c1);
             if (keep0) h0 = resolve(V, tree_like, t0, errkey);
             if (keep1) h1 = resolve(V, tree_like, t1, errkey);
             if (h0.pre != NONE) { any = true; maxpre = h0.pre; }
