@@ -284,6 +284,112 @@ def test_lca_star_scored_vs_oracle(api):
 
 
 # ---------------------------------------------------------------------------------------------
+# MRTL / hybrid (tree) / hybrid (rmq): golden vectors and random reads against the oracle's tie sets
+# ---------------------------------------------------------------------------------------------
+COMBOS = [("rmq", "mrtl", 0.0), ("tree", "hybrid", 0.25), ("tree", "hybrid", 0.0), ("tree", "hybrid", 1.0),
+          ("tree", "hybrid", 0.66), ("rmq", "hybrid", 0.5), ("rmq", "hybrid", 0.0), ("rmq", "hybrid", 1.0)]
+
+
+def _agg_one(tx, reads, method, strategy, factor=0.25, lower_bound=0.0, scores=None):
+    taxa, offs = _csr(reads)
+    return tx.aggregate(taxa, offs, method=method, strategy=strategy, factor=factor, lower_bound=lower_bound, scores=scores)
+
+
+def test_mrtl_golden(api):
+    tx, _ = _fixture_taxonomy(api)
+    cases = _golden()["mrtl_tests"]["cases"]
+    t, s = _agg_one(tx, [c[0] for c in cases], "rmq", "mrtl")
+    assert not s.any()
+    for got, (_, want) in zip(t.tolist(), cases):
+        assert got in want
+    assert t[-1] == 185751  # tie {185751, 185752}: smallest preorder index
+
+
+def test_tree_mix_golden(api):
+    tx, _ = _fixture_taxonomy(api)
+    for factor, taxa, want in _golden()["tree_mix_tests"]["cases"]:
+        t, s = _agg_one(tx, [taxa], "tree", "hybrid", factor)
+        assert s[0] == 0 and t[0] in want, (factor, taxa, t[0])
+
+
+def test_rmq_mix_golden(api):
+    tx, _ = _fixture_taxonomy(api)
+    for factor, taxa, want in _golden()["rmq_mix_tests"]["cases"]:
+        t, s = _agg_one(tx, [taxa], "rmq", "hybrid", factor)
+        assert s[0] == 0 and t[0] in want, (factor, taxa, t[0])
+
+
+def test_agg_contract_all_aggregators(api):
+    """src/agg/mod.rs:67-118 for the 9 aggregator instances (LCA* ones are covered above too)."""
+    tx, _ = _fixture_taxonomy(api)
+    g = _golden()["agg_contract"]
+    ids = [1, 2, 10239, 12884, 185751, 185752]
+    for method, strategy, factor in g["aggregators"]:
+        reads = [[]] + [[t] for t in ids] + g["unknown_inputs"]
+        t, s = _agg_one(tx, reads, method, strategy, factor)
+        assert (t[0], s[0]) == (1, api.READ_EMPTY)
+        assert t[1:7].tolist() == ids and not s[1:7].any(), (method, strategy)
+        for k in (7, 8):
+            assert (t[k], s[k]) == (g["unknown_payload"], api.READ_UNKNOWN_TAXON), (method, strategy)
+
+
+@pytest.mark.parametrize("method,strategy,factor", COMBOS)
+def test_general_random_vs_oracle(api, method, strategy, factor):
+    from umgap_amd.synth import synthetic_taxonomy
+    rng = np.random.default_rng(abs(hash((method, strategy, factor))) % 1000)
+    ids, par, valid, rank = synthetic_taxonomy(3000, 5000, max_depth=25, seed=13)
+    tx = api.Taxonomy(ids, par, valid, rank)
+    agg = O.Aggregator(O.Taxonomy.from_arrays(ids, par, valid, rank), method, strategy, factor)
+    reads = []
+    for _ in range(60):
+        pool = rng.choice(ids, int(rng.integers(1, 14)))
+        reads += _random_reads(rng, pool, 40, int(rng.choice([3, 20, 84, 200])))
+    # reads with many distinct taxa: > 64 distinct goes through the deferred large-scratch pass
+    for k in (70, 150, 400):
+        reads.append(rng.choice(ids, k).tolist())
+        reads.append(np.concatenate([rng.choice(ids, k), rng.choice(ids[:50], 300)]).tolist())
+    taxa, offs = _csr(reads)
+    for lb in (0.0, 1.0, 2.0):
+        for ranked in (False, True):
+            t, s = tx.aggregate(taxa, offs, method=method, strategy=strategy, factor=factor, lower_bound=lb, ranked_only=ranked)
+            nbad, bad, wt, ws = agg.taxa2agg_check(taxa, offs, t, s, ranked=ranked, lower_bound=lb)
+            assert nbad == 0, (lb, ranked, [(reads[int(b)][:12], int(t[int(b)]), int(s[int(b)]), int(wt[int(b)]), int(ws[int(b)])) for b in bad[:3]])
+
+
+@pytest.mark.parametrize("method,strategy,factor", [("rmq", "mrtl", 0.0), ("tree", "hybrid", 0.25), ("rmq", "hybrid", 0.5)])
+def test_general_unknown_and_orphans_vs_oracle(api, method, strategy, factor):
+    rng = np.random.default_rng(5)
+    ids = np.array([1, 2, 3, 4, 5, 6, 7, 8, 20, 21, 22, 30], np.uint32)
+    par = np.array([1, 1, 1, 2, 2, 3, 3, 4, 21, 99, 400, 1], np.uint32)
+    tx = api.Taxonomy(ids, par)
+    agg = O.Aggregator(O.Taxonomy.from_arrays(ids, par), method, strategy, factor)
+    pool = np.array([1, 2, 3, 4, 5, 6, 7, 8, 20, 21, 22, 30, 9, 10, 50, 99, 100, 400, 5000], np.uint32)
+    reads = _random_reads(rng, pool, 3000, 6, zero_frac=0.1)
+    taxa, offs = _csr(reads)
+    t, s = tx.aggregate(taxa, offs, method=method, strategy=strategy, factor=factor)
+    nbad, bad, wt, ws = agg.taxa2agg_check(taxa, offs, t, s)
+    assert nbad == 0, [(reads[int(b)], int(t[int(b)]), int(s[int(b)]), int(wt[int(b)]), int(ws[int(b)])) for b in bad[:5]]
+
+
+def test_mrtl_scored_vs_oracle(api):
+    """rmq::rtl adds ancestor scores nearest-first (src/rmq/rtl.rs:42-46): deterministic up to ties."""
+    from umgap_amd.synth import synthetic_taxonomy
+    rng = np.random.default_rng(77)
+    ids, par, valid, rank = synthetic_taxonomy(2000, 3000, max_depth=20, seed=5)
+    tx = api.Taxonomy(ids, par, valid, rank)
+    agg = O.Aggregator(O.Taxonomy.from_arrays(ids, par, valid, rank), "rmq", "mrtl")
+    reads = []
+    for _ in range(40):
+        pool = rng.choice(ids, 6)
+        reads += _random_reads(rng, pool, 40, 30)
+    taxa, offs = _csr(reads)
+    scores = (rng.integers(1, 64, len(taxa)) / 64.0).astype(np.float32)  # dyadic: sums exact in any order
+    t, s = tx.aggregate(taxa, offs, method="rmq", strategy="mrtl", lower_bound=0.5, scores=scores)
+    nbad, bad, _, _ = agg.taxa2agg_check(taxa, offs, t, s, scores=scores, lower_bound=0.5)
+    assert nbad == 0, bad
+
+
+# ---------------------------------------------------------------------------------------------
 # seedextend on device vs the oracle's literal state machine
 # ---------------------------------------------------------------------------------------------
 def test_seedextend_vs_oracle(api, torch_cuda):

@@ -18,102 +18,18 @@
 //   M = surviving taxon with the largest preorder index (always a leaf of the induced tree);
 //   h' = smallest-preorder surviving taxon that is NOT an ancestor-or-self of M (last[h] < pre[M]);
 //   LCA* = M if there is no h', else LCA(h', M) = first node on M's parent chain with pre <= pre[h'].
-#include "taxonomy.hpp"
+#include "agg_common.hpp"
 
 using namespace umgap;
 
+namespace umgap {
+int launch_general(const TaxView& V, int method, int strategy, float factor, float lower_bound, const uint32_t* d_taxa,
+                   const float* d_scores, const uint64_t* d_offsets, uint32_t stride, size_t n_reads, uint32_t* d_out_taxon,
+                   uint32_t* d_out_status, uint32_t* d_defer, hipStream_t stream);
+}
+
 namespace {
-constexpr uint32_t NONE = UMGAP_NONE;
-constexpr uint64_t NOERR = ~0ull;
-
-// ---- wave reductions: 4 DPP steps inside each row of 16, then 4 readlanes --------------------
-template <int CTRL>
-__device__ __forceinline__ uint32_t dpp(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xF, 0xF, false);
-}
-__device__ __forceinline__ uint32_t wave_max(uint32_t v) {  // all lanes must be active
-    v = max(v, dpp<0xB1>(v));   // quad_perm [1,0,3,2]
-    v = max(v, dpp<0x4E>(v));   // quad_perm [2,3,0,1]
-    v = max(v, dpp<0x141>(v));  // row_half_mirror
-    v = max(v, dpp<0x140>(v));  // row_mirror
-    uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
-    uint32_t c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
-    return max(max(a, b), max(c, d));
-}
-__device__ __forceinline__ uint32_t wave_min(uint32_t v) {
-    v = min(v, dpp<0xB1>(v));
-    v = min(v, dpp<0x4E>(v));
-    v = min(v, dpp<0x141>(v));
-    v = min(v, dpp<0x140>(v));
-    uint32_t a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
-    uint32_t c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
-    return min(min(a, b), min(c, d));
-}
-__device__ __forceinline__ uint64_t wave_min64(uint64_t v) {  // error path only
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) {
-        uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64);
-        uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64);
-        uint64_t w = ((uint64_t)hi << 32) | lo;
-        v = w < v ? w : v;
-    }
-    return v;
-}
-
-struct Hit {
-    uint32_t pre, last;  // pre == NONE: this lane holds no surviving taxon
-};
-
-// Position of (one of) the shallowest node(s) with preorder index in [a, b], a <= b, both
-// wave-uniform.  All 64 lanes take part: lanes read the partial 64-blocks at both ends (two
-// coalesced loads), lanes 0/1 the sparse-table entries covering the whole blocks in between; all
-// loads are independent (one round trip), then two DPP reductions.
-__device__ __forceinline__ uint32_t wave_argmin_depth(const TaxView& V, uint32_t a, uint32_t b, uint32_t lane) {
-    uint32_t d = NONE, pos = NONE;
-    const uint32_t ba = a >> 6, bb = b >> 6;
-    {   // left partial block (or the whole range when it sits in one block)
-        uint32_t p = a + lane, stop = ba == bb ? b : (a | 63u);
-        if (p <= stop) { d = V.depth[p]; pos = p; }
-    }
-    if (bb > ba) {  // right partial block
-        uint32_t p = (b & ~63u) + lane;
-        if (p <= b) { uint32_t dd = V.depth[p]; if (dd < d) { d = dd; pos = p; } }
-        if (bb > ba + 1 && lane < 2) {  // whole blocks ba+1 .. bb-1
-            uint32_t len = bb - ba - 1, k = 31u - (uint32_t)__builtin_clz(len);
-            uint32_t start = lane == 0 ? ba + 1 : bb - (1u << k);
-            uint64_t e = V.sparse[(size_t)k * V.n_blocks + start];
-            uint32_t dd = (uint32_t)(e >> 32);
-            if (dd < d) { d = dd; pos = (uint32_t)e; }
-        }
-    }
-    const uint32_t m = wave_min(d);
-    return wave_min(d == m ? pos : NONE);
-}
-
-// Known?  Folds failures into `errkey` (smaller = reported first: BFS level in
-// tree::Tree::new (src/tree/mod.rs:35-46), then UnknownTaxon before panic, then payload).
-// tree_like: parents[]/ancestors[] walkers (tree::lca, tree::mix, rmq::rtl);
-// otherwise rmq::lca / rmq::mix, whose HashMap lookup fails with UnknownTaxon(t) itself.
-__device__ __forceinline__ Hit resolve(const TaxView& V, bool tree_like, uint32_t t, uint64_t& errkey) {
-    Hit h{NONE, NONE};
-    if (t >= V.len) {
-        errkey = min(errkey, tree_like ? ((1ull << 32) | t) : (uint64_t)t);
-        return h;
-    }
-    uint2 pl = V.by_id[t];
-    if (pl.x == NONE) {
-        if (tree_like) {
-            uint64_t k = ((uint64_t)V.err_dist[t] << 33) | ((uint64_t)(V.err_kind[t] == 2) << 32) | V.err_payload[t];
-            errkey = min(errkey, k);
-        } else {
-            errkey = min(errkey, (uint64_t)t);  // first_occurence(t) fails (src/rmq/lca.rs:49-54)
-        }
-        return h;
-    }
-    h.pre = pl.x;
-    h.last = pl.y;
-    return h;
-}
+using namespace umgap::agg;
 
 // ---------------------------------------------------------------------------------------------
 // Stage 1 for reads of at most 128 taxa: t0/t1 = the lane's taxa (0 = none).  On return keep0 /
@@ -332,10 +248,19 @@ int launch(umgap_taxonomy* tx, int method, int strategy, float factor, float low
         if (d_scores) hipLaunchKernelGGL(k_agg_lca<true>, grid, block, 0, stream, V, method, d_taxa, d_scores, d_offsets, stride, n_reads, lower_bound, d_out_taxon, d_out_status);
         else hipLaunchKernelGGL(k_agg_lca<false>, grid, block, 0, stream, V, method, d_taxa, d_scores, d_offsets, stride, n_reads, lower_bound, d_out_taxon, d_out_status);
     } else {
-        return fail(UMGAP_ERR_INVALID, "strategy not implemented on the device yet");
+        size_t need = (n_reads + 1) * sizeof(uint32_t);
+        if (need > tx->d_defer_bytes) {
+            if (tx->d_defer) (void)hipFree(tx->d_defer);
+            tx->d_defer = nullptr;
+            tx->d_defer_bytes = 0;
+            hipError_t e = hipMalloc((void**)&tx->d_defer, need);
+            if (e != hipSuccess) return fail(UMGAP_ERR_NOMEM, std::string("hipMalloc(aggregate defer list): ") + hipGetErrorString(e));
+            tx->d_defer_bytes = need;
+        }
+        return launch_general(V, method, strategy, factor, lower_bound, d_taxa, d_scores, d_offsets, stride, n_reads, d_out_taxon,
+                              d_out_status, tx->d_defer, stream);
     }
     UMGAP_HIP(hipGetLastError());
-    (void)factor;
     return UMGAP_OK;
 }
 

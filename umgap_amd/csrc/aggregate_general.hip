@@ -1,0 +1,322 @@
+// aggregate_general.hip — MRTL, tree-hybrid and rmq-hybrid aggregation on the GPU (gfx950).
+//
+//   rmq::rtl::RTLCalculator   src/rmq/rtl.rs:39-57    (-m rmq  -a mrtl ; scripts/umgap-analyse.sh:282,293,298)
+//   tree::mix::MixCalculator  src/tree/mix.rs:43-64   (-m tree -a hybrid; the taxa2agg default, :288)
+//   rmq::mix::MixCalculator   src/rmq/mix.rs:57-93    (-m rmq  -a hybrid)
+//
+// One wavefront owns one read.  Per read, in the wave's private LDS scratch:
+//   1. distinct taxa + multiplicities through an open-addressing hash table (ds_cmpst / ds_add);
+//      scored reads (-s) elect leaders the same way but add the scores in input order
+//      (agg::count, src/agg/mod.rs:32-34);
+//   2. agg::filter (:39-44), then {pre,last} of the survivors; unknown ids end the read with the
+//      reference's error;  3. survivors sorted by preorder index (rank by counting);
+//   4. the strategy on the sorted list (closed forms: SURVEY.md §8a rows 16, 17, 20):
+//      MRTL    score(x) = count(x) + sum of counts of its ancestors in the list, nearest first
+//              (the order rtl.rs adds them); argmax.
+//      hybrid  the induced ("virtual") tree is implicit in the sorted list plus the depth of the
+//              LCA of each adjacent pair: a range [i,j] of the list is one subtree; its branching
+//              node sits at m = min adjacent-LCA depth; elements with depth == m are chain hits
+//              (Tree::collapse, src/tree/mod.rs:71-86); cuts at adjacent-LCA depth == m split it
+//              into the children, whose values are plain range sums (Tree::aggregate, :90-101).
+//      rmq mix candidates = the hits and the LCAs of adjacent hits (the LCA closure of the set);
+//              lca / rtl weights by interval tests; argmax of lca*f + rtl*(1-f) in f32.
+//   Ties (HashMap / HashSet order in the reference) -> smallest preorder index.
+// Reads with more than CAP distinct taxa are deferred to a second launch of the same kernel with a
+// large scratch (1 wave per workgroup); beyond that the read is flagged UMGAP_READ_UNSUPPORTED.
+#include "agg_common.hpp"
+
+using namespace umgap;
+using namespace umgap::agg;
+
+
+
+namespace {
+
+template <int CAP, int HCAP>
+struct Scratch {
+    uint32_t hkeys[HCAP], hcnt[HCAP];
+    uint32_t a_tax[CAP], a_slot[CAP];
+    float a_cnt[CAP];
+    uint32_t s_pre[CAP], s_last[CAP];
+    float s_cnt[CAP];
+    uint32_t b_pre[CAP], b_last[CAP];
+    float b_cnt[CAP];
+    uint32_t b_dep[CAP], b_adj[CAP], b_lca[CAP];
+};
+
+__device__ __forceinline__ void wave_sync() {  // LDS hand-off between lanes of one wave
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ uint64_t lanemask_lt(uint32_t lane) { return (1ull << lane) - 1ull; }
+__device__ __forceinline__ float wave_maxf(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { float w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+    return v;
+}
+
+// LCA of two list members by preorder index, u < v, u not an ancestor of v: binary lifting from v
+// to the highest ancestor that still starts after u; its parent is the LCA.
+__device__ __forceinline__ uint32_t lane_lca(const TaxView& V, uint32_t u, uint32_t v) {
+    uint32_t y = v;
+    for (int k = (int)V.up_levels - 1; k >= 0; k--) {
+        uint32_t c = V.up[(size_t)k * V.n_reach + y];
+        if (c > u) y = c;
+    }
+    return V.parent_pre[y];
+}
+
+template <bool SCORED, int CAP, int HCAP, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_agg_general(TaxView V, int method, int strategy, float factor,
+                                                            const uint32_t* __restrict__ taxa, const float* __restrict__ scores,
+                                                            const uint64_t* __restrict__ offsets, uint32_t stride, size_t n_reads,
+                                                            float lower_bound, uint32_t* __restrict__ out_taxon,
+                                                            uint32_t* __restrict__ out_status,
+                                                            const uint32_t* __restrict__ todo, const uint32_t* __restrict__ todo_count,
+                                                            uint32_t* __restrict__ defer, uint32_t* __restrict__ defer_count) {
+    __shared__ Scratch<CAP, HCAP> scratch[WAVES];
+    Scratch<CAP, HCAP>& S = scratch[threadIdx.x >> 6];
+    const uint32_t lane = threadIdx.x & 63;
+    const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    // rmq::rtl walks `ancestors` like the tree aggregators (src/rmq/rtl.rs:42-49)
+    const bool tree_like = method != UMGAP_METHOD_RMQ || strategy == UMGAP_STRATEGY_MRTL;
+    for (uint32_t i = lane; i < HCAP; i += 64) { S.hkeys[i] = 0u; S.hcnt[i] = 0u; }
+    wave_sync();
+    const size_t n_work = todo ? (size_t)*todo_count : n_reads;
+
+    for (size_t w = wave0; w < n_work; w += nwaves) {
+        const size_t r = todo ? (size_t)todo[w] : w;
+        uint64_t off, end;
+        if (offsets) { off = offsets[r]; end = offsets[r + 1]; } else { off = (uint64_t)r * stride; end = off + stride; }
+        uint32_t off_lo = __builtin_amdgcn_readfirstlane((uint32_t)off), off_hi = __builtin_amdgcn_readfirstlane((uint32_t)(off >> 32));
+        off = ((uint64_t)off_hi << 32) | off_lo;
+        uint32_t n_lo = __builtin_amdgcn_readfirstlane((uint32_t)(end - off)), n_hi = __builtin_amdgcn_readfirstlane((uint32_t)((end - off) >> 32));
+        const uint64_t n = ((uint64_t)n_hi << 32) | n_lo;
+        const uint32_t* rp = taxa + off;
+        const float* sp = SCORED ? scores + off : nullptr;
+        uint32_t res_taxon = 0, res_status = UMGAP_READ_OK;
+        bool done = false;
+
+        // ---- 1. distinct taxa (a_tax) with their slots -----------------------------------
+        uint32_t nd = 0;
+        bool overflow = false;
+        for (uint64_t base = 0; base < n && !overflow; base += 64) {
+            uint64_t j = base + lane;
+            uint32_t t = j < n ? rp[j] : 0u;
+            bool lead = false, full = false;
+            uint32_t slot = 0;
+            if (t != 0) {  // src/commands/taxa2agg.rs:169 drops taxon 0
+                slot = (t * 0x9E3779B1u) >> (32 - __builtin_ctz(HCAP));
+                uint32_t probes = 0;
+                for (;;) {
+                    uint32_t old = atomicCAS(&S.hkeys[slot], 0u, t);
+                    if (old == 0u) { lead = true; break; }
+                    if (old == t) break;
+                    slot = (slot + 1) & (HCAP - 1);
+                    if (++probes == HCAP) { full = true; break; }
+                }
+                if (!SCORED && !full) atomicAdd(&S.hcnt[slot], 1u);
+            }
+            uint64_t lm = __ballot(lead);
+            uint32_t idx = nd + (uint32_t)__builtin_popcountll(lm & lanemask_lt(lane));
+            if (lead && idx < CAP) { S.a_tax[idx] = t; S.a_slot[idx] = slot; }
+            nd += (uint32_t)__builtin_popcountll(lm);
+            overflow = nd > CAP || __any(full);
+        }
+        wave_sync();
+        if (overflow) {
+            // give the table back clean and hand the read to the large-scratch pass
+            for (uint32_t i = lane; i < HCAP; i += 64) { S.hkeys[i] = 0u; S.hcnt[i] = 0u; }
+            wave_sync();
+            if (lane == 0) {
+                if (defer) defer[atomicAdd(defer_count, 1u)] = (uint32_t)r;
+                else { out_taxon[r] = 0; out_status[r] = UMGAP_READ_UNSUPPORTED; }
+            }
+            continue;
+        }
+        // multiplicities, then clean the slots this read used
+        for (uint32_t e = lane; e < nd; e += 64) {
+            uint32_t slot = S.a_slot[e];
+            if (!SCORED) S.a_cnt[e] = (float)S.hcnt[slot];
+            S.hkeys[slot] = 0u;
+            S.hcnt[slot] = 0u;
+        }
+        if (SCORED) {
+            // scores are added in input order (agg::count): every lane scans the read for its taxa
+            for (uint32_t eb = 0; eb < nd; eb += 64) {
+                uint32_t e = eb + lane;
+                uint32_t mine = e < nd ? S.a_tax[e] : 0u;
+                float acc = 0.0f;
+                for (uint64_t j = 0; j < n; j++) {
+                    uint32_t tj = rp[j];
+                    float sj = sp[j];
+                    if (tj == mine) acc = __fadd_rn(acc, sj);
+                }
+                if (e < nd) S.a_cnt[e] = acc;
+            }
+        }
+        wave_sync();
+
+        // ---- 2. filter + resolve + compact the survivors ---------------------------------
+        uint32_t D = 0;
+        uint64_t errkey = NOERR;
+        for (uint32_t eb = 0; eb < nd; eb += 64) {
+            uint32_t e = eb + lane;
+            bool ok = e < nd && S.a_cnt[e] >= lower_bound;  // agg::filter
+            Hit h{NONE, NONE};
+            if (ok) h = resolve(V, tree_like, S.a_tax[e], errkey);
+            bool surv = ok && h.pre != NONE;
+            uint64_t m = __ballot(surv);
+            uint32_t idx = D + (uint32_t)__builtin_popcountll(m & lanemask_lt(lane));
+            if (surv) { S.s_pre[idx] = h.pre; S.s_last[idx] = h.last; S.s_cnt[idx] = S.a_cnt[e]; }
+            D += (uint32_t)__builtin_popcountll(m);
+        }
+        wave_sync();
+        if (__any(errkey != NOERR)) {
+            uint64_t ek = wave_min64(errkey);
+            res_status = ((ek >> 32) & 1) ? UMGAP_READ_PANIC : UMGAP_READ_UNKNOWN_TAXON;
+            res_taxon = (uint32_t)ek;
+            done = true;
+        } else if (D == 0) {
+            res_status = UMGAP_READ_EMPTY;  // literal "1" (src/commands/taxa2agg.rs:174-175)
+            res_taxon = 1;
+            done = true;
+        }
+
+        if (!done) {
+            // ---- 3. sort by preorder index (distinct taxa => distinct keys): rank by counting ----
+            for (uint32_t eb = 0; eb < D; eb += 64) {
+                uint32_t e = eb + lane;
+                uint32_t p = e < D ? S.s_pre[e] : 0u, rank = 0;
+                for (uint32_t f = 0; f < D; f++) rank += S.s_pre[f] < p;
+                if (e < D) { S.b_pre[rank] = p; S.b_last[rank] = S.s_last[e]; S.b_cnt[rank] = S.s_cnt[e]; }
+            }
+            wave_sync();
+            uint32_t ans = NONE;  // preorder index of the aggregate
+            if (strategy == UMGAP_STRATEGY_MRTL) {
+                // ---- MRTL ----
+                float best = -__builtin_inff();
+                uint32_t best_i = NONE;
+                for (uint32_t ib = 0; ib < D; ib += 64) {
+                    uint32_t i = ib + lane;
+                    if (i < D) {
+                        float score = S.b_cnt[i];
+                        uint32_t pi = S.b_pre[i];
+                        for (uint32_t j = i; j-- > 0;)
+                            if (S.b_last[j] >= pi) score = __fadd_rn(score, S.b_cnt[j]);  // ancestor, nearest first
+                        if (score > best) { best = score; best_i = i; }
+                    }
+                }
+                float m = wave_maxf(best);
+                uint32_t bi = wave_min(best == m ? best_i : NONE);
+                ans = S.b_pre[bi];
+            } else {
+                // adjacent LCAs (both hybrids)
+                for (uint32_t kb = 0; kb < D; kb += 64) {
+                    uint32_t k = kb + lane;
+                    if (k < D) S.b_dep[k] = V.depth[S.b_pre[k]];
+                    if (k + 1 < D) {
+                        uint32_t u = S.b_pre[k], v = S.b_pre[k + 1];
+                        uint32_t l = S.b_last[k] >= v ? u : lane_lca(V, u, v);
+                        S.b_lca[k] = l;
+                        S.b_adj[k] = V.depth[l];
+                    }
+                }
+                wave_sync();
+                if (method == UMGAP_METHOD_TREE) {
+                    // ---- tree::mix: greedy descent over the implicit induced tree (uniform code) ----
+                    uint32_t i = 0, j = D - 1;
+                    float wcur = 0.0f;
+                    for (uint32_t k = 0; k < D; k++) wcur = __fadd_rn(wcur, S.b_cnt[k]);
+                    for (;;) {
+                        if (i == j) { ans = S.b_pre[j]; break; }
+                        uint32_t m = NONE, node = NONE;
+                        for (uint32_t k = i; k < j; k++)
+                            if (S.b_adj[k] < m) { m = S.b_adj[k]; node = S.b_lca[k]; }
+                        if (S.b_dep[i] == m) { i++; continue; }  // chain hit: collapses into the node below
+                        float best_w = -1.0f, wsum = 0.0f;
+                        uint32_t best_s = i, best_e = i, s = i;
+                        for (uint32_t k = i; k <= j; k++) {
+                            wsum = __fadd_rn(wsum, S.b_cnt[k]);
+                            if (k == j || S.b_adj[k] == m) {
+                                if (wsum > best_w) { best_w = wsum; best_s = s; best_e = k; }
+                                s = k + 1;
+                                wsum = 0.0f;
+                            }
+                        }
+                        if (__fdiv_rn(best_w, wcur) < factor) { ans = node; break; }  // src/tree/mix.rs:57-59
+                        wcur = best_w;
+                        i = best_s;
+                        j = best_e;
+                    }
+                } else {
+                    // ---- rmq::mix: weights over hits + adjacent LCAs ----
+                    const float one_minus = __fsub_rn(1.0f, factor);
+                    float best = -__builtin_inff();
+                    uint32_t best_p = NONE;
+                    const uint32_t n_cand = 2 * D - 1;
+                    for (uint32_t cb = 0; cb < n_cand; cb += 64) {
+                        uint32_t c = cb + lane;
+                        if (c < n_cand) {
+                            uint32_t pc = c < D ? S.b_pre[c] : S.b_lca[c - D];
+                            uint32_t lc = c < D ? S.b_last[c] : V.last_of_pre[pc];
+                            float lw = 0.0f, rw = 0.0f;
+                            for (uint32_t k = 0; k < D; k++) {
+                                uint32_t pk = S.b_pre[k];
+                                if (pc <= pk && pk <= lc) lw = __fadd_rn(lw, S.b_cnt[k]);          // hit below-or-at the candidate
+                                if (pk <= pc && pc <= S.b_last[k]) rw = __fadd_rn(rw, S.b_cnt[k]);  // hit above-or-at the candidate
+                            }
+                            float score = __fadd_rn(__fmul_rn(lw, factor), __fmul_rn(rw, one_minus));  // src/rmq/mix.rs:52-54
+                            if (score > best || (score == best && pc < best_p)) { best = score; best_p = pc; }
+                        }
+                    }
+                    float m = wave_maxf(best);
+                    ans = wave_min(best == m ? best_p : NONE);
+                }
+            }
+            res_taxon = V.snap_of_pre[ans];  // snapping[aggregate] (src/commands/taxa2agg.rs:178)
+            res_status = res_taxon == NONE ? UMGAP_READ_PANIC : UMGAP_READ_OK;
+        }
+        wave_sync();
+        if (lane == 0) {
+            out_taxon[r] = res_taxon;
+            out_status[r] = res_status;
+        }
+    }
+}
+
+}  // namespace
+
+namespace umgap {
+
+// Launches the general aggregation: the compact-scratch pass over all reads, then the
+// large-scratch pass over whatever it deferred.  `d_defer` must hold n_reads + 1 u32.
+int launch_general(const TaxView& V, int method, int strategy, float factor, float lower_bound, const uint32_t* d_taxa,
+                   const float* d_scores, const uint64_t* d_offsets, uint32_t stride, size_t n_reads, uint32_t* d_out_taxon,
+                   uint32_t* d_out_status, uint32_t* d_defer, hipStream_t stream) {
+    uint32_t* d_count = d_defer;      // [0] = number of deferred reads
+    uint32_t* d_list = d_defer + 1;
+    UMGAP_HIP(hipMemsetAsync(d_count, 0, sizeof(uint32_t), stream));
+    size_t g = (n_reads + 3) / 4;
+    if (g > 256 * 4) g = 256 * 4;
+    if (g < 1) g = 1;
+    dim3 grid((unsigned)g), block(256), big_grid(256), big_block(64);
+    if (d_scores) {
+        hipLaunchKernelGGL((k_agg_general<true, 64, 512, 4>), grid, block, 0, stream, V, method, strategy, factor, d_taxa, d_scores, d_offsets, stride,
+                           n_reads, lower_bound, d_out_taxon, d_out_status, (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_list, d_count);
+        hipLaunchKernelGGL((k_agg_general<true, 1024, 4096, 1>), big_grid, big_block, 0, stream, V, method, strategy, factor, d_taxa, d_scores, d_offsets,
+                           stride, n_reads, lower_bound, d_out_taxon, d_out_status, (const uint32_t*)d_list, (const uint32_t*)d_count, (uint32_t*)nullptr,
+                           (uint32_t*)nullptr);
+    } else {
+        hipLaunchKernelGGL((k_agg_general<false, 64, 512, 4>), grid, block, 0, stream, V, method, strategy, factor, d_taxa, d_scores, d_offsets, stride,
+                           n_reads, lower_bound, d_out_taxon, d_out_status, (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_list, d_count);
+        hipLaunchKernelGGL((k_agg_general<false, 1024, 4096, 1>), big_grid, big_block, 0, stream, V, method, strategy, factor, d_taxa, d_scores, d_offsets,
+                           stride, n_reads, lower_bound, d_out_taxon, d_out_status, (const uint32_t*)d_list, (const uint32_t*)d_count, (uint32_t*)nullptr,
+                           (uint32_t*)nullptr);
+    }
+    UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}
+
+}  // namespace umgap

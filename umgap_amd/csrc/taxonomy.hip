@@ -174,6 +174,17 @@ int umgap_taxonomy_create(const uint32_t* id, const uint32_t* parent, const uint
             sparse[(size_t)k * n_blocks + b] = std::min(sparse[(size_t)(k - 1) * n_blocks + b], sparse[(size_t)(k - 1) * n_blocks + b + (1u << (k - 1))]);
     tx->n_blocks = n_blocks;
     tx->n_levels = n_levels;
+    // subtree ends by pre and the binary-lifting table (2^k-th ancestor, root maps to itself)
+    std::vector<uint32_t> last_of_pre(counter);
+    uint32_t max_depth = 0;
+    for (uint32_t p = 0; p < counter; p++) { last_of_pre[p] = tx->h_last[id_of_pre[p]]; max_depth = std::max(max_depth, depth_of_pre[p]); }
+    uint32_t up_levels = 1;
+    while ((1u << up_levels) <= max_depth) up_levels++;
+    std::vector<uint32_t> up((size_t)up_levels * counter);
+    for (uint32_t p = 0; p < counter; p++) up[p] = parent_pre[p];
+    for (uint32_t k = 1; k < up_levels; k++)
+        for (uint32_t p = 0; p < counter; p++) up[(size_t)k * counter + p] = up[(size_t)(k - 1) * counter + up[(size_t)(k - 1) * counter + p]];
+    tx->up_levels = up_levels;
 
     int rc = use_device(device);
     if (rc) { delete tx; return rc; }
@@ -193,6 +204,8 @@ int umgap_taxonomy_create(const uint32_t* id, const uint32_t* parent, const uint
     if (!rc) rc = upload(&tx->d_psnap_of_pre[0], psnap_pre[0]);
     if (!rc) rc = upload(&tx->d_psnap_of_pre[1], psnap_pre[1]);
     if (!rc) rc = upload(&tx->d_sparse, sparse);
+    if (!rc) rc = upload(&tx->d_last_of_pre, last_of_pre);
+    if (!rc) rc = upload(&tx->d_up, up);
     if (rc) { umgap_taxonomy_free(tx); return rc; }
     *out = tx;
     return UMGAP_OK;
@@ -203,7 +216,7 @@ void umgap_taxonomy_free(umgap_taxonomy* tx) {
     (void)hipSetDevice(tx->device);
     void* ptrs[] = {tx->d_by_id, tx->d_err_kind, tx->d_err_payload, tx->d_err_dist, tx->d_parent_pre, tx->d_depth,
                     tx->d_id_of_pre, tx->d_snap_of_pre[0], tx->d_snap_of_pre[1], tx->d_psnap_of_pre[0], tx->d_psnap_of_pre[1],
-                    tx->d_sparse, tx->d_stage};
+                    tx->d_sparse, tx->d_last_of_pre, tx->d_up, tx->d_stage, tx->d_defer};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (tx->stream) (void)hipStreamDestroy(tx->stream);

@@ -43,10 +43,16 @@ struct umgap_taxonomy {
     uint32_t* d_psnap_of_pre[2] = {nullptr, nullptr}; // snap of the PARENT of the node at pre (LCA answer in one load)
     uint64_t* d_sparse = nullptr;                     // [levels][n_blocks] packed (depth << 32 | pos) block-range minima
     uint32_t n_blocks = 0, n_levels = 0;
+    uint32_t* d_last_of_pre = nullptr;                // subtree end by pre
+    uint32_t* d_up = nullptr;                         // [up_levels][n_reach]: 2^k-th ancestor by pre (binary lifting, per-lane LCA)
+    uint32_t up_levels = 0;
     hipStream_t stream = nullptr;
     // staging for the host-pointer umgap_aggregate
     void* d_stage = nullptr;
     size_t d_stage_bytes = 0;
+    // deferred-read list of the general aggregation (aggregate_general.hip)
+    uint32_t* d_defer = nullptr;
+    size_t d_defer_bytes = 0;
 };
 
 namespace umgap {
@@ -61,11 +67,13 @@ struct TaxView {
     const uint32_t* snap_of_pre;   // chosen by ranked_only
     const uint32_t* psnap_of_pre;  // chosen by ranked_only
     const uint64_t* sparse;
-    uint32_t len, n_reach, n_blocks;
+    const uint32_t* last_of_pre;
+    const uint32_t* up;
+    uint32_t len, n_reach, n_blocks, up_levels;
 };
 inline TaxView view_of(const umgap_taxonomy* tx, int ranked_only) {
     return TaxView{tx->d_by_id, tx->d_err_kind, tx->d_err_payload, tx->d_err_dist, tx->d_parent_pre, tx->d_depth, tx->d_id_of_pre,
                    tx->d_snap_of_pre[ranked_only ? 1 : 0], tx->d_psnap_of_pre[ranked_only ? 1 : 0], tx->d_sparse,
-                   tx->len, tx->n_reach, tx->n_blocks};
+                   tx->d_last_of_pre, tx->d_up, tx->len, tx->n_reach, tx->n_blocks, tx->up_levels};
 }
 }  // namespace umgap
