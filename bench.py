@@ -113,8 +113,9 @@ def main():
     from umgap_amd import synth
     from umgap_amd.api import seedextend_dev
     t_setup = time.perf_counter()
+    sharded_mode = mode == "sharded" and world > 1
     w = synth.SyntheticWorkload(n_tax=args.n_tax, n_keys=args.n_keys, id_space=int(args.n_tax * 1.4), load_factor=args.load_factor,
-                                device=local_rank)
+                                device=local_rank, shard=rank if sharded_mode else 0, n_shards=world if sharded_mode else 1)
     torch.cuda.synchronize()
     B = args.pairs_per_step
     n_batches = max(1, min(args.batches, args.steps + args.warmup))
@@ -127,9 +128,9 @@ def main():
     t_setup = time.perf_counter() - t_setup
 
     sharded = None
-    if mode == "sharded" and world > 1:
-        from umgap_amd.dist import ShardedLookup
-        sharded = ShardedLookup(w.index, rank, world, B * KMERS, device)
+    if sharded_mode:
+        from umgap_amd.dist import GpuOps, ShardedLookup
+        sharded = ShardedLookup(GpuOps(w.index, device), rank, world, B * KMERS)
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
@@ -166,6 +167,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if sharded is not None:
+        sharded.check_overflow()
     # sanity on the last batch: statuses are OK/EMPTY only and the answers are not degenerate
     st = d_status.cpu().numpy()
     assert ((st == 0) | (st == 1)).all(), "unexpected per-read status in the bench output"

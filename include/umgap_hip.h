@@ -100,6 +100,13 @@ int umgap_index_set_shard(umgap_index* ix, uint32_t shard, uint32_t n_shards);
 /* Owner shard of each key under an n_shards split (for the all-to-all exchange). */
 int umgap_index_owner9_dev(const umgap_index* ix, const uint64_t* d_keys45, size_t n, uint32_t n_shards,
                            uint32_t* d_owner, void* stream);
+/* Sharded mode, send side: scatters the keys into `d_send` grouped by owner shard (n_shards
+ * regions of `cap` keys; the caller pre-fills d_send with an invalid key such as ~0 and zeroes
+ * d_cursor[n_shards] and *d_overflow) and records in d_perm[i] where key i went, so that the
+ * returned taxa can be gathered back.  *d_overflow != 0 afterwards = some region exceeded cap. */
+int umgap_index_partition9_dev(const umgap_index* ix, const uint64_t* d_keys45, size_t n, uint32_t n_shards,
+                               uint64_t cap, uint64_t* d_send, int64_t* d_perm, uint64_t* d_cursor,
+                               uint32_t* d_overflow, void* stream);
 void umgap_index_free(umgap_index* ix);
 uint64_t umgap_index_num_keys(const umgap_index* ix);
 uint64_t umgap_index_num_buckets(const umgap_index* ix);
@@ -181,6 +188,9 @@ int umgap_bench_gather_dev(umgap_index* ix, size_t n, uint32_t bytes_per_probe, 
 int umgap_synth_index_build(uint64_t n_keys, const uint32_t* d_taxon_of_row, uint64_t n_tax,
                             uint64_t mul_a, uint64_t add_b, double load_factor, int device,
                             umgap_index** out);
+int umgap_synth_index_build_shard(uint64_t n_keys, const uint32_t* d_taxon_of_row, uint64_t n_tax,
+                                  uint64_t mul_a, uint64_t add_b, double load_factor, int device,
+                                  uint32_t shard, uint32_t n_shards, umgap_index** out);
 int umgap_synth_reads9_dev(const umgap_taxonomy* tx, const uint32_t* d_taxon_of_row,
                            const uint32_t* d_row_of_id, uint64_t n_tax, uint64_t n_keys, uint64_t mul_a,
                            uint64_t add_b, uint64_t seed, uint64_t first_pair, uint64_t n_pairs,

@@ -472,3 +472,45 @@ def test_synth_pipeline_config2_one_million_pairs(api, torch_cuda):
     """BASELINE.json configs[1]: 1 M synthetic pairs, bit-exact vs the CPU oracle (84 M lookups)."""
     t, s = _pipeline_check(api, torch_cuda, n_tax=2_500_000, n_keys=256_000_000, n_pairs=1_000_000, with_seedextend=False)
     assert (s == 0).mean() > 0.9
+
+
+# ---------------------------------------------------------------------------------------------
+# sharded mode: shard-local builds + partition kernel, with the all-to-all emulated in one process
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_shards", [2, 3, 8])
+def test_sharded_components_single_gpu(api, torch_cuda, n_shards):
+    torch = torch_cuda
+    from umgap_amd import _lib
+    from umgap_amd.api import _dev_ptr, _stream_ptr
+    from umgap_amd.synth import ADD_B, MUL_A, SyntheticWorkload
+    n_tax, n_keys, n_pairs = 5000, 600_000, 3000
+    w = SyntheticWorkload(n_tax=n_tax, n_keys=n_keys)                      # whole table: the truth
+    keys = w.reads(0, n_pairs)
+    want = w.index.lookup9_dev(keys).clone()
+    shards = [api.Index.synthetic(n_keys, w.d_taxon_of_row, MUL_A, ADD_B, 0.0, s, n_shards) for s in range(n_shards)]
+    assert abs(sum(sh.table_bytes for sh in shards) - w.index.table_bytes) < n_shards * 6 * 64 * 2
+    K = keys.numel()
+    cap = int(K / n_shards * 1.2) + 4096
+    send = torch.full((n_shards * cap,), -1, dtype=torch.int64, device="cuda")
+    perm = torch.empty(K, dtype=torch.int64, device="cuda")
+    cursor = torch.zeros(n_shards, dtype=torch.int64, device="cuda")
+    overflow = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.check(_lib.load().umgap_index_partition9_dev(shards[0]._h, _dev_ptr(keys), K, n_shards, cap, _dev_ptr(send), _dev_ptr(perm),
+                                                      _dev_ptr(cursor), _dev_ptr(overflow), _stream_ptr(None)))
+    torch.cuda.synchronize()
+    assert int(overflow.item()) == 0 and int(cursor.sum().item()) == K
+    assert cursor.min().item() > 0.8 * K / n_shards        # the mixer spreads the keys evenly
+    owner = w.index.owner9_dev(keys, n_shards)
+    torch.cuda.synchronize()
+    assert (owner.cpu().numpy() == (perm // cap).cpu().numpy()).all()
+    # "all-to-all": region s is what shard s would receive; its answers travel back in place
+    back = torch.empty(n_shards * cap, dtype=torch.int32, device="cuda")
+    for s in range(n_shards):
+        shards[s].lookup9_dev(send[s * cap:(s + 1) * cap], back[s * cap:(s + 1) * cap])
+    hits = torch.index_select(back, 0, perm)
+    torch.cuda.synchronize()
+    assert (hits.cpu().numpy() == want.cpu().numpy()).all()
+    # a key sent to the wrong shard is a miss there, never a wrong taxon
+    wrong = shards[0].lookup9_dev(send[cap:2 * cap][: int(cursor[1].item())])
+    torch.cuda.synchronize()
+    assert (wrong.cpu().numpy() == 0).all()

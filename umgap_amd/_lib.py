@@ -68,6 +68,7 @@ def load():
         "umgap_index_open_shard": (i32, [C.c_char_p, u32, u32, u32, pp]),
         "umgap_index_set_shard": (i32, [vp, u32, u32]),
         "umgap_index_owner9_dev": (i32, [vp, vp, sz, u32, vp, vp]),
+        "umgap_index_partition9_dev": (i32, [vp, vp, sz, u32, u64, vp, vp, vp, vp, vp]),
         "umgap_index_free": (None, [vp]),
         "umgap_index_num_keys": (u64, [vp]),
         "umgap_index_num_buckets": (u64, [vp]),
@@ -91,6 +92,7 @@ def load():
         "umgap_seedextend_strided_dev": (i32, [u32, sz, u32, u32, vp, vp, i32, vp]),
         "umgap_bench_gather_dev": (i32, [vp, sz, u32, vp, vp]),
         "umgap_synth_index_build": (i32, [u64, vp, u64, u64, u64, dbl, i32, pp]),
+        "umgap_synth_index_build_shard": (i32, [u64, vp, u64, u64, u64, dbl, i32, u32, u32, pp]),
         "umgap_synth_reads9_dev": (i32, [vp, vp, vp, u64, u64, u64, u64, u64, u64, u64, u32, vp, vp]),
     }
     for name, (res, args) in sig.items():

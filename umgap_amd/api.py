@@ -114,11 +114,12 @@ class Index:
         return cls(h.value)
 
     @classmethod
-    def synthetic(cls, n_keys, d_taxon_of_row, mul_a, add_b, load_factor=0.0):
-        """Closed-form synthetic index generated on the device (DESIGN.md "Synthetic workload")."""
+    def synthetic(cls, n_keys, d_taxon_of_row, mul_a, add_b, load_factor=0.0, shard=0, n_shards=1):
+        """Closed-form synthetic index generated on the device (DESIGN.md "Synthetic workload");
+        with n_shards > 1 only the bucket range of `shard` is built and held."""
         h = C.c_void_p()
-        check(_lib.load().umgap_synth_index_build(n_keys, _dev_ptr(d_taxon_of_row), d_taxon_of_row.numel(), mul_a, add_b,
-                                                  load_factor, d_taxon_of_row.device.index or 0, C.byref(h)))
+        check(_lib.load().umgap_synth_index_build_shard(n_keys, _dev_ptr(d_taxon_of_row), d_taxon_of_row.numel(), mul_a, add_b,
+                                                        load_factor, d_taxon_of_row.device.index or 0, shard, n_shards, C.byref(h)))
         return cls(h.value)
 
     def save(self, path):

@@ -218,15 +218,20 @@ __global__ __launch_bounds__(256) void k_owner9(const uint64_t* __restrict__ key
 struct BuildFlags { unsigned long long too_full, duplicate, bad_key, n_stash; };
 constexpr uint32_t STASH_CAP = 1u << 22;  // entries the build may divert before the table is grown
 
-__device__ __forceinline__ void insert_one(uint64_t* __restrict__ slots, uint32_t m, uint32_t nb, uint64_t key,
-                                           uint32_t val, BuildFlags* flags, uint64_t* __restrict__ stash) {
+// `slots` points at bucket `lo`.  Whole table: lo = 0, hi = nb, chains wrap to bucket 0 (the halo
+// copy is made afterwards).  Shard build: only keys with home in [lo, hi) are inserted and chains
+// run on into the shard's own halo (no wrap): each shard is a self-contained valid table.
+__device__ __forceinline__ void insert_one(uint64_t* __restrict__ slots, uint32_t m, uint32_t nb, uint32_t lo, uint32_t hi,
+                                           uint64_t key, uint32_t val, BuildFlags* flags, uint64_t* __restrict__ stash) {
     if (key >> 45) { atomicAdd(&flags->bad_key, 1ull); return; }
     uint32_t b, tag;
     probe_of_key(key, m, b, tag);
+    if (b < lo || b >= hi) return;
+    const bool whole = (lo == 0 && hi == nb);
     for (uint32_t d = 0; d <= MAX_DISP; d++) {
         uint32_t bucket = b + d;
-        if (bucket >= nb) bucket -= nb;
-        uint64_t* s = slots + (size_t)bucket * SLOTS;
+        if (whole && bucket >= nb) bucket -= nb;
+        uint64_t* s = slots + (size_t)(bucket - lo) * SLOTS;
         uint32_t lo = tag | (d << R_BITS);
         uint64_t entry = ((uint64_t)val << 32) | lo;
         for (uint32_t k = 0; k < SLOTS; k++) {
@@ -248,12 +253,12 @@ __device__ __forceinline__ void insert_one(uint64_t* __restrict__ slots, uint32_
     }
 }
 
-__global__ __launch_bounds__(256) void k_insert(uint64_t* __restrict__ slots, uint32_t m, uint32_t nb,
+__global__ __launch_bounds__(256) void k_insert(uint64_t* __restrict__ slots, uint32_t m, uint32_t nb, uint32_t lo, uint32_t hi,
                                                 const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                 size_t n, BuildFlags* flags, uint64_t* stash) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += stride) insert_one(slots, m, nb, keys[i], vals[i], flags, stash);
+    for (; i < n; i += stride) insert_one(slots, m, nb, lo, hi, keys[i], vals[i], flags, stash);
 }
 
 // synthetic index: key_i = pi(i) written base 20 over ACDEFGHIKLMNPQRSTVWY
@@ -272,12 +277,50 @@ __device__ __forceinline__ uint64_t synth_key(uint64_t i, uint64_t a, uint64_t b
     return key;
 }
 
-__global__ __launch_bounds__(256) void k_insert_synth(uint64_t* __restrict__ slots, uint32_t m, uint32_t nb,
+__global__ __launch_bounds__(256) void k_insert_synth(uint64_t* __restrict__ slots, uint32_t m, uint32_t nb, uint32_t lo, uint32_t hi,
                                                       uint64_t n_keys, const uint32_t* __restrict__ taxon_of_row,
                                                       uint64_t n_tax, uint64_t a, uint64_t b, BuildFlags* flags, uint64_t* stash) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (; i < n_keys; i += stride) insert_one(slots, m, nb, synth_key(i, a, b), taxon_of_row[i % n_tax], flags, stash);
+    for (; i < n_keys; i += stride) insert_one(slots, m, nb, lo, hi, synth_key(i, a, b), taxon_of_row[i % n_tax], flags, stash);
+}
+
+// Partition a batch of keys by owner shard for the all-to-all exchange: key i goes to slot
+// perm[i] = owner*cap + (arrival index within that owner) of `send`; `cursor[o]` counts arrivals.
+// Wave-aggregated: one atomic per (wave, owner).  Keys beyond `cap` per owner set *overflow.
+__global__ __launch_bounds__(256) void k_partition(const uint64_t* __restrict__ keys, size_t n, uint32_t m, uint32_t nb,
+                                                   uint32_t n_shards, uint64_t cap, uint64_t* __restrict__ send,
+                                                   int64_t* __restrict__ perm, unsigned long long* __restrict__ cursor,
+                                                   uint32_t* __restrict__ overflow) {
+    const uint32_t lane = threadIdx.x & 63;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t n_round = (n + 63) & ~(size_t)63;
+    for (; i < n_round; i += stride) {
+        uint32_t owner = 0xFFFFFFFFu;
+        uint64_t key = 0;
+        if (i < n) {
+            key = keys[i];
+            uint32_t b, tag;
+            probe_of_key(key, m, b, tag);
+            uint32_t s = (uint32_t)(((uint64_t)b * n_shards) / nb);
+            while ((uint64_t)nb * s / n_shards > b) s--;
+            while ((uint64_t)nb * (s + 1) / n_shards <= b) s++;
+            owner = s;
+        }
+        for (uint32_t o = 0; o < n_shards; o++) {
+            uint64_t mask = __ballot(owner == o);
+            if (!mask) continue;
+            unsigned long long base = 0;
+            if (lane == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(&cursor[o], (unsigned long long)__builtin_popcountll(mask));
+            base = ((unsigned long long)__shfl((int)(base >> 32), __builtin_ctzll(mask), 64) << 32) | (uint32_t)__shfl((int)(uint32_t)base, __builtin_ctzll(mask), 64);
+            if (owner == o) {
+                uint64_t pos = base + (uint64_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+                if (pos < cap) { send[(size_t)o * cap + pos] = key; perm[i] = (int64_t)((size_t)o * cap + pos); }
+                else { perm[i] = 0; atomicExch(overflow, 1u); }
+            }
+        }
+    }
 }
 
 // random-sector gather microbenchmark: probe i reads `lanes` x 16 B starting at a bucket chosen
@@ -325,21 +368,22 @@ uint32_t choose_m(uint64_t n, double load) {
     return (uint32_t)m;
 }
 
-int alloc_table(umgap_index* ix, uint32_t m) {
+int alloc_table(umgap_index* ix, uint32_t m, uint32_t shard, uint32_t n_shards) {
     uint64_t nb64 = (uint64_t)m << A_BITS;
-    if (nb64 + MAX_DISP >= (1ull << 32)) return fail(UMGAP_ERR_INVALID, "index too large for one table (>= 2^32 buckets); shard it");
+    if (nb64 + MAX_DISP >= (1ull << 32)) return fail(UMGAP_ERR_INVALID, "index too large for one table (>= 2^32 buckets)");
     uint32_t nb = (uint32_t)nb64;
-    size_t slots = ((size_t)nb + MAX_DISP) * SLOTS;
+    uint32_t lo = (uint32_t)((uint64_t)nb * shard / n_shards), hi = (uint32_t)((uint64_t)nb * (shard + 1) / n_shards);
+    size_t slots = ((size_t)(hi - lo) + MAX_DISP) * SLOTS;
     if (ix->d_slots) { (void)hipFree(ix->d_slots); ix->d_slots = nullptr; }
     hipError_t e = hipMalloc((void**)&ix->d_slots, slots * sizeof(uint64_t));
     if (e != hipSuccess) return fail(UMGAP_ERR_NOMEM, std::string("hipMalloc of the table failed: ") + hipGetErrorString(e));
     ix->view.slots = ix->d_slots;
     ix->view.m = m;
     ix->view.nb = nb;
-    ix->view.first_bucket = 0;
-    ix->view.n_resident = nb + MAX_DISP;
-    ix->view.home_lo = 0;
-    ix->view.home_hi = nb;
+    ix->view.first_bucket = lo;
+    ix->view.n_resident = hi - lo + MAX_DISP;
+    ix->view.home_lo = lo;
+    ix->view.home_hi = hi;
     ix->view.stash_keys = nullptr;
     ix->view.stash_vals = nullptr;
     ix->view.n_stash = 0;
@@ -370,8 +414,9 @@ int set_stash(umgap_index* ix, std::vector<std::pair<uint64_t, uint64_t>>& entri
     return UMGAP_OK;
 }
 
-// copy buckets [0, MAX_DISP) behind the last bucket so probes never wrap
+// copy buckets [0, MAX_DISP) behind the last bucket so probes never wrap (whole tables only)
 int finish_halo(umgap_index* ix) {
+    if (!(ix->view.home_lo == 0 && ix->view.home_hi == ix->view.nb)) { UMGAP_HIP(hipStreamSynchronize(ix->stream)); return UMGAP_OK; }
     UMGAP_HIP(hipMemcpyAsync(ix->d_slots + (size_t)ix->view.nb * SLOTS, ix->d_slots, MAX_DISP * SLOTS * sizeof(uint64_t),
                              hipMemcpyDeviceToDevice, ix->stream));
     UMGAP_HIP(hipStreamSynchronize(ix->stream));
@@ -391,7 +436,7 @@ int new_handle(int device, umgap_index** out) {
 
 // Generic build driver: `insert(ix, flags)` enqueues the insert kernels on ix->stream.
 template <class F>
-int build_with(umgap_index* ix, uint64_t n, double load, F insert) {
+int build_with(umgap_index* ix, uint64_t n, double load, uint32_t shard, uint32_t n_shards, F insert) {
     uint32_t m = choose_m(n, load);
     BuildFlags* d_flags = nullptr;
     uint64_t* d_stash = nullptr;
@@ -399,9 +444,9 @@ int build_with(umgap_index* ix, uint64_t n, double load, F insert) {
     UMGAP_HIP(hipMalloc((void**)&d_stash, (size_t)STASH_CAP * 16));
     int rc = UMGAP_OK;
     for (int attempt = 0; attempt < 4; attempt++) {
-        rc = alloc_table(ix, m);
+        rc = alloc_table(ix, m, shard, n_shards);
         if (rc) break;
-        size_t nslots = ((size_t)ix->view.nb + MAX_DISP) * SLOTS;
+        size_t nslots = (size_t)ix->view.n_resident * SLOTS;
         hipLaunchKernelGGL(k_fill, dim3(grid_for(nslots)), dim3(256), 0, ix->stream, ix->d_slots, nslots, EMPTY_SLOT);
         hipError_t e = hipMemsetAsync(d_flags, 0, sizeof(BuildFlags), ix->stream);
         if (e != hipSuccess) { rc = fail(UMGAP_ERR_DEVICE, hipGetErrorString(e)); break; }
@@ -469,8 +514,8 @@ int umgap_index_build9_dev(const uint64_t* d_keys, const uint32_t* d_taxa, size_
     umgap_index* ix = nullptr;
     int rc = new_handle(device, &ix);
     if (rc) return rc;
-    rc = build_with(ix, n, load, [&](umgap_index* x, BuildFlags* f, uint64_t* st) {
-        if (n) hipLaunchKernelGGL(k_insert, dim3(grid_for(n)), dim3(256), 0, x->stream, x->d_slots, x->view.m, x->view.nb, d_keys, d_taxa, n, f, st);
+    rc = build_with(ix, n, load, 0, 1, [&](umgap_index* x, BuildFlags* f, uint64_t* st) {
+        if (n) hipLaunchKernelGGL(k_insert, dim3(grid_for(n)), dim3(256), 0, x->stream, x->d_slots, x->view.m, x->view.nb, x->view.home_lo, x->view.home_hi, d_keys, d_taxa, n, f, st);
         return UMGAP_OK;
     });
     if (rc) { umgap_index_free(ix); return rc; }
@@ -500,15 +545,21 @@ int umgap_index_build9(const uint64_t* keys, const uint32_t* taxa, size_t n, dou
 
 int umgap_synth_index_build(uint64_t n_keys, const uint32_t* d_taxon_of_row, uint64_t n_tax, uint64_t a, uint64_t b,
                             double load, int device, umgap_index** out) {
+    return umgap_synth_index_build_shard(n_keys, d_taxon_of_row, n_tax, a, b, load, device, 0, 1, out);
+}
+
+int umgap_synth_index_build_shard(uint64_t n_keys, const uint32_t* d_taxon_of_row, uint64_t n_tax, uint64_t a, uint64_t b,
+                                  double load, int device, uint32_t shard, uint32_t n_shards, umgap_index** out) {
     if (!out || !d_taxon_of_row || !n_tax) return fail(UMGAP_ERR_INVALID, "umgap_synth_index_build: null argument");
+    if (n_shards == 0 || shard >= n_shards) return fail(UMGAP_ERR_INVALID, "umgap_synth_index_build: shard >= n_shards");
     if (a >= (1ull << 25) || (a % 2) == 0 || (a % 5) == 0 || n_keys > 512000000000ull)
         return fail(UMGAP_ERR_INVALID, "umgap_synth_index_build: need odd a < 2^25 with a % 5 != 0 and n_keys <= 20^9");
     umgap_index* ix = nullptr;
     int rc = new_handle(device, &ix);
     if (rc) return rc;
-    rc = build_with(ix, n_keys, load, [&](umgap_index* x, BuildFlags* f, uint64_t* st) {
+    rc = build_with(ix, n_keys, load, shard, n_shards, [&](umgap_index* x, BuildFlags* f, uint64_t* st) {
         hipLaunchKernelGGL(k_insert_synth, dim3(grid_for(n_keys, 256, 256 * 16)), dim3(256), 0, x->stream, x->d_slots, x->view.m,
-                           x->view.nb, n_keys, d_taxon_of_row, n_tax, a, b % 512000000000ull, f, st);
+                           x->view.nb, x->view.home_lo, x->view.home_hi, n_keys, d_taxon_of_row, n_tax, a, b % 512000000000ull, f, st);
         return UMGAP_OK;
     });
     if (rc) { umgap_index_free(ix); return rc; }
@@ -650,6 +701,17 @@ int umgap_index_owner9_dev(const umgap_index* ix, const uint64_t* d_keys, size_t
     int rc = use_device(ix->device);
     if (rc) return rc;
     if (n) hipLaunchKernelGGL(k_owner9, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, d_keys, n, ix->view.m, ix->view.nb, n_shards, d_owner);
+    UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}
+
+int umgap_index_partition9_dev(const umgap_index* ix, const uint64_t* d_keys, size_t n, uint32_t n_shards, uint64_t cap,
+                               uint64_t* d_send, int64_t* d_perm, uint64_t* d_cursor, uint32_t* d_overflow, void* stream) {
+    if (!ix || !n_shards || n_shards > 64 || (n && (!d_keys || !d_send || !d_perm)) || !d_cursor || !d_overflow) return fail(UMGAP_ERR_INVALID, "umgap_index_partition9_dev: bad argument");
+    int rc = use_device(ix->device);
+    if (rc) return rc;
+    if (n) hipLaunchKernelGGL(k_partition, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, d_keys, n, ix->view.m, ix->view.nb, n_shards, cap,
+                              d_send, d_perm, (unsigned long long*)d_cursor, d_overflow);
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
 }

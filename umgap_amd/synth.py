@@ -80,7 +80,7 @@ def key_of_member(i, mul_a=MUL_A, add_b=ADD_B):
 class SyntheticWorkload:
     """Taxonomy + index + read generator bound to one GPU."""
 
-    def __init__(self, n_tax, n_keys, id_space=None, max_depth=45, load_factor=0.0, device=0, build_index=True):
+    def __init__(self, n_tax, n_keys, id_space=None, max_depth=45, load_factor=0.0, device=0, build_index=True, shard=0, n_shards=1):
         import torch
         from .api import Index, Taxonomy
         self.device = torch.device("cuda", device)
@@ -93,7 +93,7 @@ class SyntheticWorkload:
         row_of_id[self.ids] = np.arange(n_tax, dtype=np.uint32)
         self.d_taxon_of_row = torch.from_numpy(self.taxon_of_row.view(np.int32)).to(self.device)
         self.d_row_of_id = torch.from_numpy(row_of_id.view(np.int32)).to(self.device)
-        self.index = Index.synthetic(self.n_keys, self.d_taxon_of_row, MUL_A, ADD_B, load_factor) if build_index else None
+        self.index = Index.synthetic(self.n_keys, self.d_taxon_of_row, MUL_A, ADD_B, load_factor, shard, n_shards) if build_index else None
 
     def reads(self, first_pair, n_pairs, d_keys=None, kmers_per_pair=KMERS_PER_PAIR, stream=None):
         """Packed 9-mers of pairs [first_pair, first_pair+n_pairs) as an int64 CUDA tensor."""
