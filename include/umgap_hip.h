@@ -177,6 +177,17 @@ int umgap_seedextend_strided_dev(uint32_t stride, size_t n_records, uint32_t min
                                  uint32_t max_gap_size, uint32_t* d_taxa, uint32_t* d_kept, int device,
                                  void* stream);
 
+/* ---- fused 9-mer pipeline ------------------------------------------------------------------ */
+/* One kernel for `prot2kmer2lca -o | seedextend -g G -s S | uniq -d / | taxa2agg -l L -a lca*`
+ * (scripts/umgap-analyse.sh:299-310) over reads given as packed 9-mers: read r owns
+ * d_keys45[r*kmers_per_read .. +kmers_per_read) (<= 128).  fragments_per_read = 0 skips
+ * seedextend; otherwise each read is that many equal fragments (2 = the two ends of a pair) and
+ * seedextend (unranked) runs per fragment.  LCA* only; hits never leave the chip. */
+int umgap_classify9_dev(umgap_index* ix, umgap_taxonomy* tx, int method, float lower_bound, int ranked_only,
+                        const uint64_t* d_keys45, size_t n_reads, uint32_t kmers_per_read,
+                        uint32_t fragments_per_read, uint32_t min_seed_size, uint32_t max_gap_size,
+                        uint32_t* d_out_taxon, uint32_t* d_out_status, void* stream);
+
 /* ---- measurement helpers (bench.py; not part of the reference surface) ------------------- */
 /* Lane-per-key probe variant of umgap_index_lookup9_dev, kept for the A/B in DESIGN.md. */
 int umgap_index_lookup9_lane_dev(umgap_index* ix, const uint64_t* d_keys45, size_t n, uint32_t miss_value,

@@ -459,6 +459,46 @@ def _pipeline_check(api, torch, n_tax, n_keys, n_pairs, with_seedextend):
     return t, s
 
 
+@pytest.mark.parametrize("with_seedextend", [False, True])
+@pytest.mark.parametrize("stride,n_pairs", [(84, 20_001), (42, 5_000), (128, 3_001), (7, 1_000)])
+def test_fused_classify_vs_oracle(api, torch_cuda, stride, n_pairs, with_seedextend):
+    """umgap_classify9_dev (probe -> [seedextend] -> LCA* in one kernel) against the oracle stages."""
+    torch = torch_cuda
+    from umgap_amd.synth import ADD_B, MUL_A, SyntheticWorkload
+    if with_seedextend and stride % 2:
+        pytest.skip("two fragments need an even stride")
+    n_tax, n_keys = 20_000, 1_000_000
+    w = SyntheticWorkload(n_tax=n_tax, n_keys=n_keys)
+    d_keys = w.reads(0, n_pairs, kmers_per_pair=stride)
+    d_t = torch.empty(n_pairs, dtype=torch.int32, device="cuda")
+    d_s = torch.empty(n_pairs, dtype=torch.int32, device="cuda")
+    api.classify9_dev(w.index, w.taxonomy, d_keys, n_pairs, stride, d_t, d_s, method="tree", lower_bound=2.0,
+                      fragments_per_read=2 if with_seedextend else 0, min_seed_size=3, max_gap_size=1)
+    torch.cuda.synchronize()
+    keys = d_keys.cpu().numpy().view(np.uint64)
+    hits = O.synth_lookup9(O.SynthIndexParams(n_keys, n_tax, MUL_A, ADD_B), w.taxon_of_row, keys, 0)
+    if with_seedextend:
+        half = stride // 2
+        out = np.zeros_like(hits)
+        for r in range(2 * n_pairs):
+            kept = O.seedextend_record(hits[r * half:(r + 1) * half], 3, 1)
+            out[r * half:r * half + len(kept)] = kept      # order within the record is irrelevant to taxa2agg
+        hits = out
+    agg = O.Aggregator(O.Taxonomy.from_arrays(w.ids, w.parents, w.valid, w.rank), "tree", "lca*")
+    offs = np.arange(n_pairs + 1, dtype=np.uint64) * stride
+    t, s = d_t.cpu().numpy().view(np.uint32), d_s.cpu().numpy().view(np.uint32)
+    nbad, bad, wt, ws = agg.taxa2agg_check(hits, offs, t, s, lower_bound=2.0, nthreads=8)
+    assert nbad == 0, (bad, t[bad.astype(int)], wt[bad.astype(int)])
+    # and it agrees with the unfused device path bit for bit
+    d_hits = w.index.lookup9_dev(d_keys)
+    if with_seedextend:
+        api.seedextend_dev(d_hits, stride=stride // 2, n_records=2 * n_pairs, min_seed_size=3, max_gap_size=1)
+    d_t2, d_s2 = torch.empty_like(d_t), torch.empty_like(d_s)
+    w.taxonomy.aggregate_strided_dev(d_hits, stride, n_pairs, d_t2, d_s2, method="tree", strategy="lca*", lower_bound=2.0)
+    torch.cuda.synchronize()
+    assert torch.equal(d_t, d_t2) and torch.equal(d_s, d_s2)
+
+
 def test_synth_pipeline_small(api, torch_cuda):
     t, s = _pipeline_check(api, torch_cuda, n_tax=20_000, n_keys=1_000_000, n_pairs=20_000, with_seedextend=False)
     assert (s == 0).mean() > 0.9 and len(np.unique(t)) > 1000

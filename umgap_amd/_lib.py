@@ -88,6 +88,7 @@ def load():
         "umgap_aggregate": (i32, [vp, i32, i32, f32, f32, i32, vp, vp, vp, sz, vp, vp]),
         "umgap_aggregate_dev": (i32, [vp, i32, i32, f32, f32, i32, vp, vp, vp, sz, vp, vp, vp]),
         "umgap_aggregate_strided_dev": (i32, [vp, i32, i32, f32, f32, i32, vp, u32, sz, vp, vp, vp]),
+        "umgap_classify9_dev": (i32, [vp, vp, i32, f32, i32, vp, sz, u32, u32, u32, u32, vp, vp, vp]),
         "umgap_seedextend_dev": (i32, [vp, sz, u32, u32, vp, vp, i32, vp]),
         "umgap_seedextend_strided_dev": (i32, [u32, sz, u32, u32, vp, vp, i32, vp]),
         "umgap_bench_gather_dev": (i32, [vp, sz, u32, vp, vp]),

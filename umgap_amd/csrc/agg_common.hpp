@@ -98,5 +98,48 @@ __device__ __forceinline__ Hit resolve(const TaxView& V, bool tree_like, uint32_
 }
 
 
+// Unscored stage 1 through the wave's private LDS hash table (keys[256] all 0 = empty, cnt[256] all
+// 0 on entry and on exit).  One wave executes in lockstep and the LDS serves its instructions in
+// order, so every lane's ds_add has landed before any leader reads its counter back.
+__device__ __forceinline__ void lds_count(uint32_t* keys, uint32_t* cnt, uint32_t t0, uint32_t t1, float lower_bound,
+                                          bool& keep0, bool& keep1, float& cnt0, float& cnt1) {
+    uint32_t slot0 = 0, slot1 = 0;
+    bool lead0 = false, lead1 = false;
+    if (t0 != 0) {
+        slot0 = (t0 * 0x9E3779B1u) >> 24;
+        for (;;) {
+            uint32_t old = atomicCAS(&keys[slot0], 0u, t0);
+            if (old == 0u) { lead0 = true; break; }
+            if (old == t0) break;
+            slot0 = (slot0 + 1) & 255u;
+        }
+        atomicAdd(&cnt[slot0], 1u);
+    }
+    if (t1 != 0) {
+        slot1 = (t1 * 0x9E3779B1u) >> 24;
+        for (;;) {
+            uint32_t old = atomicCAS(&keys[slot1], 0u, t1);
+            if (old == 0u) { lead1 = true; break; }
+            if (old == t1) break;
+            slot1 = (slot1 + 1) & 255u;
+        }
+        atomicAdd(&cnt[slot1], 1u);
+    }
+    keep0 = keep1 = false;
+    cnt0 = cnt1 = 0.0f;
+    if (lead0) {
+        cnt0 = (float)atomicExch(&cnt[slot0], 0u);  // read the multiplicity and reset the slot
+        keep0 = cnt0 >= lower_bound;                // agg::filter keeps freq >= lower_bound
+    }
+    if (lead1) {
+        cnt1 = (float)atomicExch(&cnt[slot1], 0u);
+        keep1 = cnt1 >= lower_bound;
+    }
+    // every leader has read its counter before any key is cleared (lockstep), so no slot is reused early
+    if (lead0) atomicExch(&keys[slot0], 0u);
+    if (lead1) atomicExch(&keys[slot1], 0u);
+}
+
+
 }  // namespace agg
 }  // namespace umgap

@@ -1,0 +1,165 @@
+// classify.hip — the fused 9-mer high-precision pipeline in ONE kernel (gfx950, wave64):
+//     packed 9-mers -> table probe -> [seedextend per fragment] -> per-read LCA* -> snapped taxon
+// i.e. `prot2kmer2lca -o | seedextend -gG -sS | uniq -d / | taxa2agg -lL -a lca*`
+// (scripts/umgap-analyse.sh:299-310) for reads whose k-mers are already packed; the hits never
+// leave the CU.  Reference code per stage: src/commands/pept2lca.rs:93 (get), src/commands/
+// seedextend.rs:99-148, src/commands/taxa2agg.rs:161-180 + src/tree/lca.rs:32-40.
+//
+// Why fuse: the probe is bound by the chip's random-request rate (~40 G 64-byte requests/s, see
+// DESIGN.md) and leaves the ALUs idle; the aggregate is instruction/latency bound.  In one kernel
+// the aggregate of some waves runs under the memory waits of the others, and the 4 B/hit round
+// trip through HBM disappears.
+//
+// A wave owns R = floor(256 / stride) reads at a time (stride = k-mers per read, 84 -> R = 3,
+// 252 keys = four probe rounds of 64): probe -> taxa into the wave's LDS strip -> per read:
+// LDS hash-count, leaders gather {pre,last}, O(1) range-min LCA (aggregate.hip has the commentary).
+#include "agg_common.hpp"
+#include "probe_common.hpp"
+
+using namespace umgap;
+using namespace umgap::agg;
+using namespace umgap::probe;
+
+namespace {
+
+// seedextend state machine over one fragment held in LDS (unranked mode; pipeline.hip has the
+// device-memory twin with the line-by-line citations)
+__device__ __forceinline__ void seedextend_lds(uint32_t* t, uint32_t n, uint32_t min_seed, uint32_t max_gap) {
+    auto at = [&](uint32_t i) -> uint32_t { return i < n ? t[i] : 0u; };
+    const uint32_t len = n + 1;
+    uint32_t cursor = 0;
+    auto emit = [&](uint32_t s, uint32_t e) {
+        if (e > n) e = n;
+        if (s > e) s = e;
+        for (uint32_t i = cursor; i < s; i++) t[i] = 0;
+        cursor = e > cursor ? e : cursor;
+    };
+    uint32_t start = 0, end = 1;
+    uint32_t last_tid = at(0), same_tid = 1, same_max = 1;
+    while (end < len) {
+        uint32_t cur = at(end);
+        if (last_tid == cur) { same_tid += 1; end += 1; continue; }
+        if (last_tid == 0 && same_tid > max_gap) {
+            if (same_max >= min_seed) emit(start, end - same_tid);
+            start = end; last_tid = cur; same_tid = 1; same_max = 1; end += 1;
+            continue;
+        }
+        if (last_tid == 0 && (end - start) == same_tid) { end += 1; start = end; continue; }
+        if (last_tid != 0) same_max = same_max > same_tid ? same_max : same_tid;
+        last_tid = cur; same_tid = 1; end += 1;
+    }
+    if (same_max >= min_seed) {
+        if (last_tid == 0) end -= same_tid;
+        emit(start, end);
+    }
+    for (uint32_t i = cursor; i < n; i++) t[i] = 0;
+}
+
+__global__ __launch_bounds__(256) void k_classify9(TableView T, TaxView V, int method, const uint64_t* __restrict__ keys,
+                                                   size_t n_reads, uint32_t stride, uint32_t frags, uint32_t min_seed, uint32_t max_gap,
+                                                   float lower_bound, uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status) {
+    __shared__ uint32_t lds_taxa[4][256], lds_keys[4][256], lds_cnt[4][256];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
+    uint32_t* wtaxa = lds_taxa[wv];
+    uint32_t* wkeys = lds_keys[wv];
+    uint32_t* wcnt = lds_cnt[wv];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { wkeys[lane + 64 * i] = 0u; wcnt[lane + 64 * i] = 0u; }
+    const bool tree_like = method != UMGAP_METHOD_RMQ;
+    const uint32_t R = 256u / stride;                     // reads per wave iteration (stride <= 128 => R >= 2)
+    const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const size_t n_groups = (n_reads + R - 1) / R;
+    for (size_t g = wave0; g < n_groups; g += nwaves) {
+        const size_t r0 = g * R;
+        const uint32_t nr = (uint32_t)min((size_t)R, n_reads - r0);
+        const uint32_t nk = nr * stride;                   // keys of this group (<= 256)
+        const uint64_t* kp = keys + r0 * stride;
+        // ---- probe: up to four rounds of 64 keys, results into the LDS strip ----
+        for (uint32_t c = 0; c * 64 < nk; c++) {
+            uint32_t i = c * 64 + lane, local = 0, tag = 0, valid = 0;
+            if (i < nk) {
+                uint64_t key = __builtin_nontemporal_load(kp + i);
+                valid = locate(T, key, local, tag) ? 1u : 0u;
+            }
+            uint32_t res[4];
+            wave_probe64_vals(T, local, tag | (valid << 31), 0u, lane, res);
+            if (j == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) wtaxa[c * 64 + 16 * r + q] = res[r];   // slots >= nk hold 0
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- seedextend per fragment (one lane per fragment) ----
+        if (frags) {
+            const uint32_t flen = stride / frags;
+            if (lane < nr * frags) seedextend_lds(wtaxa + lane * flen, flen, min_seed, max_gap);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        // ---- aggregate each read of the group ----
+        for (uint32_t k = 0; k < nr; k++) {
+            const uint32_t* rt = wtaxa + k * stride;
+            uint32_t t0 = lane < stride ? rt[lane] : 0u, t1 = 64 + lane < stride ? rt[64 + lane] : 0u;
+            bool keep0, keep1;
+            float c0, c1;
+            lds_count(wkeys, wcnt, t0, t1, lower_bound, keep0, keep1, c0, c1);
+            uint64_t errkey = NOERR;
+            Hit h0{NONE, NONE}, h1{NONE, NONE};
+            if (keep0) h0 = resolve(V, tree_like, t0, errkey);
+            if (keep1) h1 = resolve(V, tree_like, t1, errkey);
+            bool any = false;
+            uint32_t maxpre = 0, res_taxon, res_status;
+            if (h0.pre != NONE) { any = true; maxpre = h0.pre; }
+            if (h1.pre != NONE) { any = true; maxpre = max(maxpre, h1.pre); }
+            if (__any(errkey != NOERR)) {
+                uint64_t ek = wave_min64(errkey);
+                res_status = ((ek >> 32) & 1) ? UMGAP_READ_PANIC : UMGAP_READ_UNKNOWN_TAXON;
+                res_taxon = (uint32_t)ek;
+            } else if (!__any(any)) {
+                res_status = UMGAP_READ_EMPTY;
+                res_taxon = 1;
+            } else {
+                const uint32_t M = wave_max(any ? maxpre : 0u);
+                uint32_t hp = NONE;
+                if (h0.pre != NONE && h0.last < M) hp = h0.pre;
+                if (h1.pre != NONE && h1.last < M) hp = min(hp, h1.pre);
+                hp = wave_min(hp);
+                if (hp != NONE) res_taxon = V.psnap_of_pre[wave_argmin_depth(V, hp + 1, M, lane)];
+                else res_taxon = V.snap_of_pre[M];
+                res_status = res_taxon == NONE ? UMGAP_READ_PANIC : UMGAP_READ_OK;
+            }
+            if (lane == 0) {
+                out_taxon[r0 + k] = res_taxon;
+                out_status[r0 + k] = res_status;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+}  // namespace
+
+extern "C" int umgap_classify9_dev(umgap_index* ix, umgap_taxonomy* tx, int method, float lower_bound, int ranked_only,
+                                   const uint64_t* d_keys45, size_t n_reads, uint32_t kmers_per_read, uint32_t fragments_per_read,
+                                   uint32_t min_seed_size, uint32_t max_gap_size, uint32_t* d_out_taxon, uint32_t* d_out_status,
+                                   void* stream) {
+    if (!ix || !tx || (n_reads && (!d_keys45 || !d_out_taxon || !d_out_status))) return fail(UMGAP_ERR_INVALID, "umgap_classify9_dev: null argument");
+    if (kmers_per_read == 0 || kmers_per_read > 128) return fail(UMGAP_ERR_INVALID, "umgap_classify9_dev: kmers_per_read must be in 1..128 (use lookup9 + aggregate for longer reads)");
+    if (fragments_per_read && (kmers_per_read % fragments_per_read) != 0) return fail(UMGAP_ERR_INVALID, "umgap_classify9_dev: kmers_per_read must be a multiple of fragments_per_read");
+    if (fragments_per_read * (256u / kmers_per_read) > 64) return fail(UMGAP_ERR_INVALID, "umgap_classify9_dev: too many fragments per wave");
+    if (method != UMGAP_METHOD_TREE && method != UMGAP_METHOD_RMQ) return fail(UMGAP_ERR_INVALID, "unknown method");
+    if (ix->device != tx->device) return fail(UMGAP_ERR_INVALID, "umgap_classify9_dev: index and taxonomy live on different devices");
+    int rc = use_device(ix->device);
+    if (rc) return rc;
+    if (!n_reads) return UMGAP_OK;
+    size_t groups = (n_reads + (256u / kmers_per_read) - 1) / (256u / kmers_per_read);
+    size_t g = (groups + 3) / 4;
+    if (g > 256 * 8) g = 256 * 8;
+    hipLaunchKernelGGL(k_classify9, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, d_keys45, n_reads,
+                       kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status);
+    UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}

@@ -1,0 +1,99 @@
+// probe_common.hpp — device-side probe primitives of the 9-mer table shared by the lookup kernels
+// (index.hip) and the fused classify kernel (classify.hip).  gfx950, wave64.  Layout: common.hpp.
+#pragma once
+#include "common.hpp"
+
+namespace umgap {
+namespace probe {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t quad_xor1(uint32_t v) {  // quad_perm [1,0,3,2]
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t quad_xor2(uint32_t v) {  // quad_perm [2,3,0,1]
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+}
+__device__ __forceinline__ uint32_t quad_or(uint32_t v) {
+    v |= quad_xor1(v);
+    v |= quad_xor2(v);
+    return v;
+}
+
+// Evaluates one 64-byte bucket held by a quad (lane j holds slots 2j, 2j+1 in `e`) against
+// `want` = tag | displacement << 28.  Returns bit0 = found, bit1 = bucket overflowed; the taxon of
+// the matching slot lands in `val` (quad-uniform).  All four lanes of a quad call this together.
+__device__ __forceinline__ uint32_t eval_bucket(u32x4 e, uint32_t want, uint32_t j, uint32_t& val) {
+    uint32_t m0 = (e.x & TAG_MASK) == want, m1 = (e.z & TAG_MASK) == want;
+    uint32_t v = m0 ? e.y : (m1 ? e.w : 0u);
+    uint32_t ovf = (j == 0 && e.x != 0xFFFFFFFFu) ? (e.x >> 31) : 0u;
+    val = quad_or(v);
+    return quad_or((m0 | m1) | (ovf << 1));
+}
+
+// Binary search of the stash (a few thousand entries, L2 resident); reached only by probes that
+// exhausted the displacement chain.
+__device__ __forceinline__ uint32_t stash_lookup(const TableView& T, uint32_t home, uint32_t tag, uint32_t miss) {
+    const uint64_t want = ((uint64_t)home << R_BITS) | tag;
+    uint32_t lo = 0, hi = T.n_stash;
+    while (lo < hi) {
+        uint32_t mid = (lo + hi) >> 1;
+        uint64_t k = T.stash_keys[mid];
+        if (k == want) return T.stash_vals[mid];
+        if (k < want) lo = mid + 1; else hi = mid;
+    }
+    return miss;
+}
+
+// home bucket -> (resident?, local index)
+__device__ __forceinline__ bool locate(const TableView& T, uint64_t key, uint32_t& local, uint32_t& tag) {
+    uint32_t b;
+    probe_of_key(key, T.m, b, tag);
+    local = b - T.home_lo;
+    return (key >> 45) == 0 && b >= T.home_lo && b < T.home_hi;
+}
+
+// The wave-cooperative probe shared by every lookup surface.  Each lane brings one key (already
+// turned into local bucket + tag; bit 31 of `tagv` = valid).  The 64 keys are probed in four
+// rounds of 16 quad probes: a quad = 4 lanes x 16 B = one 64-byte bucket per load instruction, so
+// one wave instruction touches 16 buckets, each as one fully used 64-byte request.  The four
+// first-probe loads are issued back to back (4 sectors in flight per quad); a bucket that
+// overflowed at build time (rare) sends its quad down the displacement chain afterwards.
+// res[r] (quad-uniform) = taxon of key 16r + (lane >> 2), or `miss`.
+__device__ __forceinline__ void wave_probe64_vals(const TableView& T, uint32_t local, uint32_t tagv, uint32_t miss,
+                                                  uint32_t lane, uint32_t (&res)[4]) {
+    const uint32_t q = lane >> 2, j = lane & 3;
+    const u32x4* p[4];
+    uint32_t want[4];
+    u32x4 e[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        int src = 16 * r + (int)q;
+        uint32_t l = (uint32_t)__shfl((int)local, src, 64);
+        want[r] = (uint32_t)__shfl((int)tagv, src, 64);
+        l = (want[r] >> 31) ? l : 0u;  // invalid key: read bucket 0, result discarded
+        p[r] = reinterpret_cast<const u32x4*>(T.slots) + ((size_t)l * 4 + j);
+        e[r] = __builtin_nontemporal_load(p[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const bool valid = want[r] >> 31;
+        uint32_t w = want[r] & R_MASK, val;
+        uint32_t f = eval_bucket(e[r], w, j, val);
+        // displacement chain: only past buckets flagged as overflowed (halo keeps p in range)
+        uint32_t d = 1;
+        for (; valid && !(f & 1u) && (f & 2u) && d <= MAX_DISP; d++) {
+            p[r] += 4;
+            w += 1u << R_BITS;
+            f = eval_bucket(__builtin_nontemporal_load(p[r]), w, j, val);
+        }
+        res[r] = (valid && (f & 1u)) ? val : miss;
+        if (valid && !(f & 1u) && (f & 2u) && T.n_stash) {  // chain exhausted through flagged buckets
+            uint32_t home = (uint32_t)((reinterpret_cast<const uint64_t*>(p[r]) - T.slots) / SLOTS) - MAX_DISP + T.home_lo;
+            res[r] = stash_lookup(T, home, want[r] & R_MASK, miss);
+        }
+    }
+}
+
+}  // namespace probe
+}  // namespace umgap
