@@ -127,6 +127,21 @@ int umgap_index_lookup_prot9_dev(umgap_index* ix, const uint8_t* d_bytes, const 
                                  const uint64_t* d_out_offsets, size_t n_prot, uint32_t miss_value,
                                  uint32_t* d_out_taxa, void* stream);
 
+/* ---- variable-length keys (tryptic peptides, 1..63 bytes) -------------------------------- */
+/* The same handle type; umgap_index_kind() tells 9 (packed 9-mer table) from 2 (byte-string table).
+ * Key i = bytes[offsets[i] .. offsets[i+1]).  Exact match (candidates are verified byte by byte).
+ * Replaces fst::Map::get for the tryptic index (src/commands/pept2lca.rs:93,
+ * src/commands/prot2tryp2lca.rs:130).  umgap_index_save / _open / _free work for both kinds. */
+int umgap_index_kind(const umgap_index* ix);
+int umgap_index_build_var(const uint8_t* bytes, const uint64_t* offsets, const uint32_t* taxa, size_t n,
+                          double load_factor, int device, umgap_index** out);
+int umgap_index_build_var_dev(const uint8_t* d_bytes, const uint64_t* d_offsets, const uint32_t* d_taxa, size_t n,
+                              uint64_t n_bytes, double load_factor, int device, umgap_index** out);
+int umgap_index_lookup_var(umgap_index* ix, const uint8_t* bytes, const uint64_t* offsets, size_t n,
+                           uint32_t miss_value, uint32_t* out_taxa);
+int umgap_index_lookup_var_dev(umgap_index* ix, const uint8_t* d_bytes, const uint64_t* d_offsets, size_t n,
+                               uint32_t miss_value, uint32_t* d_out_taxa, void* stream);
+
 /* ---- taxonomy ---------------------------------------------------------------------------- */
 /* rows in TSV order: id, parent, valid (0/1), rank (index into src/rank.rs:10-41, 0 = "no rank").
  * Children keep row order (Euler tour / preorder follow it, src/taxon.rs:224-247).

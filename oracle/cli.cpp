@@ -4,6 +4,7 @@
 //
 //   pept2lca      [-o] <index.tsv>            src/commands/pept2lca.rs
 //   prot2kmer2lca [-o] [-k K] <index.tsv>     src/commands/prot2kmer2lca.rs
+//   prot2tryp2lca [-o] [-l N] [-L N] [-k SET] [-d SET] <index.tsv>   src/commands/prot2tryp2lca.rs
 //   taxa2agg      [-s] [-r] [-m M] [-a A] [-f F] [-l L] <taxons.tsv>   src/commands/taxa2agg.rs
 //   seedextend    [-s N] [-g N] [-r taxons.tsv] [-p N]                 src/commands/seedextend.rs
 //   uniq          [-s SEP] [-w] [-d DELIM]                             src/commands/uniq.rs
@@ -53,6 +54,19 @@ int main(int argc, char** argv) {
             if (a.size() != 2) throw Error(ErrKind::InvalidInvocation, "usage");
             SortedIndex ix = load_index(a[1]);
             prot2kmer2lca(std::cin, std::cout, ix, k, o);
+        } else if (cmd == "prot2tryp2lca") {
+            bool o = flag("-o");
+            flag("-m");
+            opt("-c");
+            size_t l = 5, L = 50;
+            std::string keep, drop;
+            if (auto v = opt("-l")) l = parse_usize(*v);
+            if (auto v = opt("-L")) L = parse_usize(*v);
+            if (auto v = opt("-k")) keep = *v;
+            if (auto v = opt("-d")) drop = *v;
+            if (a.size() != 2) throw Error(ErrKind::InvalidInvocation, "usage");
+            SortedIndex ix = load_index(a[1]);
+            prot2tryp2lca(std::cin, std::cout, ix, o, l, L, keep, drop);
         } else if (cmd == "taxa2agg") {
             bool scored = flag("-s"), ranked = flag("-r");
             Method m = Method::Tree;

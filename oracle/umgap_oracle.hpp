@@ -1033,6 +1033,65 @@ inline void prot2kmer2lca(std::istream& in, std::ostream& out, const Index& inde
     }
 }
 
+// prot2tryp2lca — src/commands/prot2tryp2lca.rs:88-140 with the default cleavage pattern
+// "([KR])([^P])" (:66-67).  The regex is applied twice with "$1\n$2" (:112-115); one pass of
+// Regex::replace_all = leftmost non-overlapping matches, restated here character by character.
+inline std::string tryp_replace_pass(const std::string& s) {
+    std::string o;
+    size_t i = 0;
+    while (i < s.size()) {
+        char c = s[i];
+        if ((c == 'K' || c == 'R') && i + 1 < s.size() && s[i + 1] != 'P') {
+            // [^P] matches one whole UTF-8 character
+            size_t n = 1;
+            unsigned char d = (unsigned char)s[i + 1];
+            if (d >= 0xF0) n = 4; else if (d >= 0xE0) n = 3; else if (d >= 0xC0) n = 2;
+            o.push_back(c);
+            o.push_back('\n');
+            o.append(s, i + 1, n);
+            i += 1 + n;
+        } else {
+            o.push_back(c);
+            i++;
+        }
+    }
+    return o;
+}
+inline void prot2tryp2lca(std::istream& in, std::ostream& out, const Index& index, bool one_on_one, size_t min_length,
+                          size_t max_length, const std::string& contains, const std::string& lacks) {
+    std::optional<uint64_t> dflt;
+    if (one_on_one) dflt = 0;
+    std::set<char> cset(contains.begin(), contains.end()), lset(lacks.begin(), lacks.end());
+    FastaReader reader(in, false);
+    Record read;
+    while (reader.read_record(read)) {
+        out << '>' << read.header << '\n';
+        for (auto& seq : read.sequence) {
+            std::string d = tryp_replace_pass(tryp_replace_pass(seq));
+            for (auto& ch : d) if (ch == '*') ch = '\n';               // .replace("*", "\n")
+            size_t st = 0;
+            for (;;) {                                                   // .lines()
+                size_t p = d.find('\n', st);
+                std::string pep = d.substr(st, p == std::string::npos ? std::string::npos : p - st);
+                if (!pep.empty() && pep.back() == '\r') pep.pop_back();
+                bool ok = !pep.empty() && pep.size() >= min_length && pep.size() <= max_length;
+                if (ok && !(cset.empty() && lset.empty())) {
+                    std::set<char> have(pep.begin(), pep.end());
+                    for (char c : cset) if (!have.count(c)) ok = false;
+                    for (char c : lset) if (have.count(c)) ok = false;
+                }
+                if (ok) {
+                    std::optional<uint64_t> lca = index.get(pep);
+                    if (!lca) lca = dflt;
+                    if (lca) out << *lca << '\n';
+                }
+                if (p == std::string::npos) break;
+                st = p + 1;
+            }
+        }
+    }
+}
+
 // seedextend — src/commands/seedextend.rs:82-179
 inline void seedextend(std::istream& in, std::ostream& out, size_t min_seed_size, size_t max_gap_size,
                        const TaxonList* by_id /* -r, from new_with_unknown(.., true) */, size_t penalty) {

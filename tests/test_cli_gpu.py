@@ -215,3 +215,114 @@ def test_high_precision_pipeline_matches_oracle(world):
     mine = pipeline(run, world["idx"])
     ref = pipeline(O.run_cli, world["idx_tsv"])
     assert mine == ref and mine.count(b">") == 200
+
+
+@pytest.fixture(scope="module")
+def tryptic(tmp_path_factory, world):
+    """A tryptic-peptide index: TSV for the oracle, UMGAPIX1 (variable-length table) for the product."""
+    d = tmp_path_factory.mktemp("tryp")
+    rng = np.random.default_rng(7)
+    proteins = []
+    for _ in range(400):
+        proteins.append("".join(rng.choice(list(LETTERS + "KR"), int(rng.integers(30, 200)))))
+    peps = set()
+    for prot in proteins:
+        cur = ""
+        for i, c in enumerate(prot):
+            cur += c
+            if c in "KR" and i + 1 < len(prot) and prot[i + 1] != "P":
+                peps.add(cur)
+                cur = ""
+        peps.add(cur)
+    peps = sorted(p for p in peps if 5 <= len(p) <= 50)
+    vals = rng.choice(world["ids"], len(peps))
+    tsv = str(d / "tryptic.tsv")
+    with open(tsv, "w") as f:
+        for k, v in zip(peps, vals):
+            f.write("%s\t%d\n" % (k, v))
+    idx = str(d / "tryptic.umgapix")
+    with open(tsv, "rb") as fin, open(idx, "wb") as fout:
+        p = subprocess.run([UMGAP, "buildindex"], stdin=fin, stdout=fout, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr
+    return {"tsv": tsv, "idx": idx, "proteins": proteins, "peps": peps}
+
+
+def test_pept2lca_tryptic_doc_example(tmp_path):
+    """src/commands/pept2lca.rs:24-46 end to end through buildindex."""
+    tsv = tmp_path / "t.tsv"
+    tsv.write_text("AAALTER\t2\nENFVYLAK\t3398\n")
+    idx = tmp_path / "t.umgapix"
+    with open(tsv, "rb") as fin, open(idx, "wb") as fout:
+        assert subprocess.run([UMGAP, "buildindex"], stdin=fin, stdout=fout).returncode == 0
+    rc, out, _ = run(["pept2lca", str(idx)], b">header1\nAAALTER\nENFVYLAK\n")
+    assert rc == 0 and out == b">header1\n2\n3398\n"
+    rc, out, _ = run(["pept2lca", "-o", str(idx)], b">header1\nNOTATRYPTICPEPTIDE\nENFVYLAK\n")
+    assert rc == 0 and out == b">header1\n0\n3398\n"
+
+
+@pytest.mark.parametrize("flags", [[], ["-o"]])
+def test_pept2lca_tryptic_matches_oracle(tryptic, flags):
+    rng = np.random.default_rng(3)
+    recs = []
+    for r in range(400):
+        lines = [">r%d" % r]
+        for _ in range(int(rng.integers(0, 10))):
+            c = rng.random()
+            if c < 0.6:
+                lines.append(tryptic["peps"][int(rng.integers(0, len(tryptic["peps"])))])
+            elif c < 0.9:
+                lines.append("".join(rng.choice(list(LETTERS), int(rng.integers(1, 70)))))
+            else:
+                lines.append("")
+        recs.append("\n".join(lines))
+    fasta = ("\n".join(recs) + "\n").encode()
+    rc, out, err = run(["pept2lca"] + flags + [tryptic["idx"]], fasta)
+    orc, oout, _ = O.run_cli(["pept2lca"] + flags + [tryptic["tsv"]], fasta)
+    assert rc == 0 == orc and out == oout, err
+
+
+@pytest.mark.parametrize("flags", [[], ["-o"], ["-l", "9", "-L", "45"], ["-o", "-l9", "-L45"], ["-k", "AC"], ["-d", "W", "-o"]])
+def test_prot2tryp2lca_matches_oracle(tryptic, flags):
+    """src/commands/prot2tryp2lca.rs:88-140 incl. the settings of scripts/umgap-analyse.sh:291 (-l9 -L45)."""
+    rng = np.random.default_rng(9)
+    recs = []
+    for r in range(300):
+        prot = tryptic["proteins"][int(rng.integers(0, len(tryptic["proteins"])))]
+        if rng.random() < 0.3:
+            s = int(rng.integers(0, len(prot)))
+            prot = prot[:s] + "*" + prot[s:]
+        if rng.random() < 0.2:
+            prot = "KKRPKRRKP" + prot + "K"
+        # sequence lines are NOT unwrapped by prot2tryp2lca (Reader::new(stdin, false)): two lines = two digests
+        recs.append(">p%d\n%s\n%s\n" % (r, prot[: len(prot) // 2], prot[len(prot) // 2:]))
+    fasta = "".join(recs).encode()
+    rc, out, err = run(["prot2tryp2lca"] + flags + [tryptic["idx"]], fasta)
+    oflags = []
+    for a in flags:
+        oflags += {"-l9": ["-l", "9"], "-L45": ["-L", "45"]}.get(a, [a])
+    orc, oout, _ = O.run_cli(["prot2tryp2lca"] + oflags + [tryptic["tsv"]], fasta)
+    assert rc == 0 == orc and out == oout, err
+    assert out.count(b"\n") > 600
+
+
+def test_tryptic_precision_pipeline_matches_oracle(tryptic, world):
+    """scripts/umgap-analyse.sh:295-298 minus FGSpp: prot2tryp2lca -l9 -L45 | uniq -d / | taxa2agg -l5 -m rmq -a mrtl
+    (and the tryptic-sensitivity variant -l1)."""
+    rng = np.random.default_rng(21)
+    recs = []
+    for r in range(150):
+        for end in (1, 2):
+            prot = tryptic["proteins"][int(rng.integers(0, len(tryptic["proteins"])))]
+            recs.append(">read%d/%d\n%s\n" % (r, end, prot))
+    fasta = "".join(recs).encode()
+    for lb in ("1", "5"):
+        def pipeline(runner, idx):
+            rc, a, _ = runner(["prot2tryp2lca", "-l", "9", "-L", "45", idx], fasta)
+            assert rc == 0
+            rc, b, _ = runner(["uniq", "-d", "/"], a)
+            assert rc == 0
+            rc, c, _ = runner(["taxa2agg", "-l", lb, "-m", "rmq", "-a", "mrtl", world["tsv"]], b)
+            assert rc == 0
+            return c
+        mine, ref = pipeline(run, tryptic["idx"]), pipeline(O.run_cli, tryptic["tsv"])
+        assert mine == ref and mine.count(b">") == 150

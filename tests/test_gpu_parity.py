@@ -554,3 +554,49 @@ def test_sharded_components_single_gpu(api, torch_cuda, n_shards):
     wrong = shards[0].lookup9_dev(send[cap:2 * cap][: int(cursor[1].item())])
     torch.cuda.synchronize()
     assert (wrong.cpu().numpy() == 0).all()
+
+
+# ---------------------------------------------------------------------------------------------
+# variable-length (tryptic) index: exact byte-string keys
+# ---------------------------------------------------------------------------------------------
+def _random_peptides(rng, n, lo=5, hi=50):
+    letters = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    out = set()
+    while len(out) < n:
+        k = int(rng.integers(lo, hi + 1))
+        out.add(rng.choice(letters, k).tobytes())
+    return sorted(out)
+
+
+def test_var_index_matches_dict(api, tmp_path):
+    rng = np.random.default_rng(12)
+    peps = _random_peptides(rng, 120_000)
+    vals = rng.integers(1, 1 << 31, len(peps)).astype(np.uint32)
+    d = dict(zip(peps, vals.tolist()))
+    for load in (0.0, 0.9):       # 0.9 forces overflow chains
+        ix = api.Index.build_var(peps, vals, load_factor=load)
+        assert ix.kind == 2 and ix.num_keys == len(peps)
+        assert (ix.lookup_var(peps) == vals).all()
+        q = peps[:3000] + _random_peptides(rng, 3000) + [b"", b"A" * 64, b"K", peps[0][:-1], peps[0] + b"A", b"ACD*F", b"\xff\x00\x01"]
+        want = np.array([d.get(p, 0) for p in q], np.uint32)
+        assert (ix.lookup_var(q, miss_value=0) == want).all()
+        want9 = np.array([d.get(p, 9) for p in q], np.uint32)
+        assert (ix.lookup_var(q, miss_value=9) == want9).all()
+    path = tmp_path / "tryptic.umgapix"
+    ix.save(path)
+    ix2 = api.Index.open(path)
+    assert ix2.kind == 2 and (ix2.lookup_var(q) == want).all()
+    assert len(ix.lookup_var([])) == 0
+    with pytest.raises(api.UmgapError):
+        ix.lookup9(np.zeros(3, np.uint64))
+    with pytest.raises(api.UmgapError, match="duplicate"):
+        api.Index.build_var([b"AAAAA", b"CCCCC", b"AAAAA"], np.array([1, 2, 3], np.uint32))
+    with pytest.raises(api.UmgapError, match="63"):
+        api.Index.build_var([b"A" * 64], np.array([1], np.uint32))
+
+
+def test_pept2lca_doc_example_tryptic(api):
+    """src/commands/pept2lca.rs:24-46 verbatim."""
+    ix = api.Index.build_var([b"AAALTER", b"ENFVYLAK"], np.array([2, 3398], np.uint32))
+    assert ix.lookup_var([b"AAALTER", b"ENFVYLAK"]).tolist() == [2, 3398]
+    assert ix.lookup_var([b"NOTATRYPTICPEPTIDE", b"ENFVYLAK"], miss_value=0).tolist() == [0, 3398]

@@ -39,6 +39,17 @@ def _dev_ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+def _concat(strings):
+    """list of bytes -> (uint8 data, uint64 offsets[n+1])"""
+    offs = np.zeros(len(strings) + 1, np.uint64)
+    if len(strings):
+        offs[1:] = np.cumsum([len(s) for s in strings])
+    data = np.frombuffer(b"".join(strings), dtype=np.uint8) if len(strings) else np.zeros(0, np.uint8)
+    if data.size == 0:
+        data = np.zeros(1, np.uint8)
+    return np.ascontiguousarray(data), offs
+
+
 def pack9(peptide: bytes):
     """45-bit packed key of a 9-mer, or None if a byte is outside 'A'..'Z'."""
     if len(peptide) != 9:
@@ -121,6 +132,30 @@ class Index:
         check(_lib.load().umgap_synth_index_build_shard(n_keys, _dev_ptr(d_taxon_of_row), d_taxon_of_row.numel(), mul_a, add_b,
                                                         load_factor, d_taxon_of_row.device.index or 0, shard, n_shards, C.byref(h)))
         return cls(h.value)
+
+    @classmethod
+    def build_var(cls, peptides, taxa, load_factor=0.0, device=0):
+        """Variable-length index from a list of byte strings (1..63 bytes each)."""
+        data, offs = _concat(peptides)
+        vals = np.ascontiguousarray(taxa, dtype=np.uint32)
+        h = C.c_void_p()
+        check(_lib.load().umgap_index_build_var(_np_ptr(data), _np_ptr(offs), _np_ptr(vals), len(peptides), load_factor, device, C.byref(h)))
+        return cls(h.value)
+
+    @property
+    def kind(self):
+        return _lib.load().umgap_index_kind(self._h)
+
+    def lookup_var(self, peptides, miss_value=0):
+        data, offs = _concat(peptides)
+        out = np.empty(len(peptides), np.uint32)
+        check(_lib.load().umgap_index_lookup_var(self._h, _np_ptr(data), _np_ptr(offs), len(peptides), miss_value, _np_ptr(out)))
+        return out
+
+    def lookup_var_dev(self, d_bytes, d_offsets, d_out, miss_value=0, stream=None):
+        check(_lib.load().umgap_index_lookup_var_dev(self._h, _dev_ptr(d_bytes), _dev_ptr(d_offsets), d_offsets.numel() - 1, miss_value,
+                                                     _dev_ptr(d_out), _stream_ptr(stream)))
+        return d_out
 
     def save(self, path):
         check(_lib.load().umgap_index_save(self._h, str(path).encode()))

@@ -101,8 +101,12 @@ struct IndexFileHeader {
 
 }  // namespace umgap
 
+struct umgap_var_index;  // index_var.hip
+
 struct umgap_index {
     int device = 0;
+    int kind = 9;                      // 9 = packed 9-mer table, 2 = variable-length (byte string) table
+    umgap_var_index* var = nullptr;    // kind 2
     uint64_t* d_slots = nullptr;  // nb * 8 slots (whole table) or the shard's range
     uint64_t n_keys = 0;
     uint64_t* d_stash_keys = nullptr;

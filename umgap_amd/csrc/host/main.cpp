@@ -138,6 +138,34 @@ void append_u64(std::string& s, uint64_t v) {
     while (n) s.push_back(tmp[--n]);
 }
 
+// Looks up a batch of byte strings in either kind of index.  9-mer table: strings that are not
+// [A-Z]{9} miss without touching the device.  Result 0 = miss.
+struct StringBatch {
+    std::vector<uint8_t> bytes;
+    std::vector<uint64_t> offsets{0};
+    void add(std::string_view s) { bytes.insert(bytes.end(), s.begin(), s.end()); offsets.push_back(bytes.size()); }
+    size_t size() const { return offsets.size() - 1; }
+    void clear() { bytes.clear(); offsets.assign(1, 0); }
+};
+void lookup_strings(umgap_index* ix, const StringBatch& b, std::vector<uint32_t>& out) {
+    size_t n = b.size();
+    out.assign(n, 0u);
+    if (!n) return;
+    if (umgap_index_kind(ix) == 2) {
+        LIB(umgap_index_lookup_var(ix, b.bytes.data(), b.offsets.data(), n, 0u, out.data()));
+        return;
+    }
+    std::vector<uint64_t> keys;
+    std::vector<size_t> where;
+    for (size_t i = 0; i < n; i++) {
+        uint64_t key;
+        if (b.offsets[i + 1] - b.offsets[i] == 9 && umgap_pack9((const char*)b.bytes.data() + b.offsets[i], &key)) { keys.push_back(key); where.push_back(i); }
+    }
+    std::vector<uint32_t> t(keys.size());
+    if (!keys.empty()) LIB(umgap_index_lookup9(ix, keys.data(), keys.size(), 0u, t.data()));
+    for (size_t k = 0; k < keys.size(); k++) out[where[k]] = t[k];
+}
+
 // ---- pept2lca / prot2kmer2lca ---------------------------------------------------------------
 // One batch = many records: pack every peptide, ONE device lookup, then format in input order.
 void stream_lookup(FILE* in, FILE* outf, umgap_index* ix, bool one_on_one, bool kmer_mode, size_t k) {
@@ -219,12 +247,83 @@ umgap_index* open_index(const std::string& path) {
     return ix;
 }
 
+// record loop shared by pept2lca (variable-length index) and prot2tryp2lca: `expand` turns one
+// sequence line into the peptides to look up
+void stream_strings(FILE* in, FILE* outf, umgap_index* ix, bool one_on_one,
+                    const std::function<void(const std::string&, StringBatch&)>& expand) {
+    FastaReader reader(in, false);
+    Out out(outf);
+    std::vector<std::string> headers;
+    std::vector<size_t> first;  // index of the record's first peptide in the batch
+    StringBatch batch;
+    std::vector<uint32_t> taxa;
+    auto run = [&]() {
+        lookup_strings(ix, batch, taxa);
+        for (size_t r = 0; r < headers.size(); r++) {
+            out.buf.push_back('>'); out.buf.append(headers[r]); out.buf.push_back('\n');
+            size_t end = r + 1 < headers.size() ? first[r + 1] : batch.size();
+            for (size_t i = first[r]; i < end; i++)
+                if (taxa[i] != 0 || one_on_one) { append_u64(out.buf, taxa[i]); out.buf.push_back('\n'); }
+            out.maybe_flush();
+        }
+        headers.clear(); first.clear(); batch.clear();
+    };
+    Record rec;
+    try {
+        while (reader.read_record(rec)) {
+            first.push_back(batch.size());
+            headers.push_back(std::move(rec.header));
+            for (auto& s : rec.sequence) expand(s, batch);
+            if (batch.bytes.size() >= (64u << 20) || headers.size() >= (1u << 20)) run();
+        }
+    } catch (CliError&) { run(); out.flush(); throw; }
+    run();
+    out.flush();
+}
+
 int cmd_pept2lca(const std::vector<std::string>& args) {
     Parsed p = parse_args(args, {{'o', "one-on-one", false}, {'m', "in-memory", false}, {'c', "chunksize", true}});
     (void)opt_usize(p, "chunksize", 240);  // chunks only group output in the reference; accepted and validated
     std::string path = need_positional(p, "fst-file");
     umgap_index* ix = open_index(path);  // -m: the table is always resident (in HBM)
-    stream_lookup(stdin, stdout, ix, p.has("one-on-one"), false, 9);
+    if (umgap_index_kind(ix) == 2) stream_strings(stdin, stdout, ix, p.has("one-on-one"), [](const std::string& s, StringBatch& b) { b.add(s); });
+    else stream_lookup(stdin, stdout, ix, p.has("one-on-one"), false, 9);
+    umgap_index_free(ix);
+    return 0;
+}
+
+// prot2tryp2lca: src/commands/prot2tryp2lca.rs:88-140.  The default pattern "([KR])([^P])" applied twice
+// and '*' -> newline is: cut after every K/R that is not followed by P; '*' separates and is dropped.
+int cmd_prot2tryp2lca(const std::vector<std::string>& args) {
+    Parsed p = parse_args(args, {{'o', "one-on-one", false}, {'m', "in-memory", false}, {'c', "chunksize", true}, {'p', "pattern", true},
+                                 {'l', "minlen", true}, {'L', "maxlen", true}, {'k', "keep", true}, {'d', "drop", true}});
+    (void)opt_usize(p, "chunksize", 240);
+    size_t minlen = (size_t)opt_usize(p, "minlen", 5), maxlen = (size_t)opt_usize(p, "maxlen", 50);
+    std::string keep = p.get("keep").value_or(""), drop = p.get("drop").value_or("");
+    if (p.get("pattern").value_or("([KR])([^P])") != "([KR])([^P])")
+        throw CliError("only the default cleavage pattern ([KR])([^P]) is supported by the accelerated prot2tryp2lca");
+    std::string path = need_positional(p, "fst-file");
+    umgap_index* ix = open_index(path);
+    auto expand = [&](const std::string& seq, StringBatch& b) {
+        size_t st = 0;
+        auto emit = [&](size_t a, size_t e) {
+            std::string_view pep(seq.data() + a, e - a);
+            if (!pep.empty() && pep.back() == '\r') pep.remove_suffix(1);   // str::lines() strips a trailing CR
+            if (pep.empty() || pep.size() < minlen || pep.size() > maxlen) return;
+            if (!keep.empty() || !drop.empty()) {
+                for (char c : keep) if (pep.find(c) == std::string_view::npos) return;
+                for (char c : drop) if (pep.find(c) != std::string_view::npos) return;
+            }
+            b.add(pep);
+        };
+        for (size_t i = 0; i < seq.size(); i++) {
+            char c = seq[i];
+            if (c == '*' || c == '\n') { emit(st, i); st = i + 1; }
+            else if ((c == 'K' || c == 'R') && i + 1 < seq.size() && seq[i + 1] != 'P') { emit(st, i + 1); st = i + 1; }
+        }
+        emit(st, seq.size());
+    };
+    stream_strings(stdin, stdout, ix, p.has("one-on-one"), expand);
     umgap_index_free(ix);
     return 0;
 }
@@ -235,6 +334,7 @@ int cmd_prot2kmer2lca(const std::vector<std::string>& args) {
     (void)opt_usize(p, "chunksize", 240);
     std::string path = need_positional(p, "fst-file");
     umgap_index* ix = open_index(path);
+    if (umgap_index_kind(ix) != 9) throw CliError("prot2kmer2lca needs a 9-mer index");
     bool o = p.has("one-on-one");
     if (auto sock = p.get("socket")) {
         // src/commands/prot2kmer2lca.rs:116-137: sequential connections, status lines on stdout
@@ -451,6 +551,8 @@ int cmd_buildindex(const std::vector<std::string>& args) {
     std::string_view l;
     std::vector<uint64_t> keys;
     std::vector<uint32_t> vals;
+    StringBatch strs;
+    bool all9 = true;
     std::string prev;
     while (ls.next(l)) {
         if (l.empty()) continue;
@@ -462,14 +564,18 @@ int cmd_buildindex(const std::vector<std::string>& args) {
         // fst::MapBuilder::insert wants strictly increasing keys (src/commands/buildindex.rs:42)
         if (!prev.empty() && !(std::string_view(prev) < k)) throw CliError(std::string(prev == k ? "Error inserting duplicate key: " : "Error inserting out-of-order key: ") + std::string(k));
         prev.assign(k);
-        uint64_t key;
-        if (k.size() != 9 || !umgap_pack9(k.data(), &key)) throw CliError("key '" + std::string(k) + "' is not [A-Z]{9}: only 9-mer indexes are supported by the HBM table");
+        uint64_t key = 0;
+        if (k.size() != 9 || !umgap_pack9(k.data(), &key)) all9 = false;
+        if (k.empty() || k.size() > 63) throw CliError("key '" + std::string(k) + "': keys must be 1..63 bytes long");
         if (v > 0xFFFFFFFFull) throw CliError("taxon id does not fit 32 bits");
         keys.push_back(key);
+        strs.add(k);
         vals.push_back((uint32_t)v);
     }
+    // every key [A-Z]{9} => the packed 9-mer table; anything else => the variable-length table
     umgap_index* ix = nullptr;
-    LIB(umgap_index_build9(keys.data(), vals.data(), keys.size(), load, 0, &ix));
+    if (all9) LIB(umgap_index_build9(keys.data(), vals.data(), keys.size(), load, 0, &ix));
+    else LIB(umgap_index_build_var(strs.bytes.data(), strs.offsets.data(), vals.data(), vals.size(), load, 0, &ix));
     LIB(umgap_index_save(ix, "/dev/stdout"));
     umgap_index_free(ix);
     return 0;
@@ -486,6 +592,7 @@ int main(int argc, char** argv) {
         if (cmd == "-V" || cmd == "--version") { printf("umgap %s\n", umgap_version()); return 0; }  // scripts/umgap-analyse.sh:107
         if (cmd == "pept2lca") return cmd_pept2lca(args);
         if (cmd == "prot2kmer2lca") return cmd_prot2kmer2lca(args);
+        if (cmd == "prot2tryp2lca") return cmd_prot2tryp2lca(args);
         if (cmd == "taxa2agg") return cmd_taxa2agg(args);
         if (cmd == "seedextend") return cmd_seedextend(args);
         if (cmd == "uniq") return cmd_uniq(args);

@@ -8,6 +8,12 @@
 
 #include "probe_common.hpp"
 
+namespace umgap {
+void var_free(umgap_var_index* v);
+int var_save(const umgap_index* ix, FILE* f);
+int var_open(umgap_index* ix, const IndexFileHeader& h, FILE* f, const char* path);
+}
+
 using namespace umgap;
 
 namespace {
@@ -488,6 +494,7 @@ int umgap_synth_index_build_shard(uint64_t n_keys, const uint32_t* d_taxon_of_ro
 void umgap_index_free(umgap_index* ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
+    if (ix->var) var_free(ix->var);
     if (ix->d_slots) (void)hipFree(ix->d_slots);
     if (ix->d_stash_keys) (void)hipFree(ix->d_stash_keys);
     if (ix->d_stash_vals) (void)hipFree(ix->d_stash_vals);
@@ -506,6 +513,15 @@ int umgap_index_device(const umgap_index* ix) { return ix ? ix->device : -1; }
 
 int umgap_index_save(const umgap_index* ix, const char* path) {
     if (!ix || !path) return fail(UMGAP_ERR_INVALID, "umgap_index_save: null argument");
+    if (ix->kind == 2) {
+        int rcv = use_device(ix->device);
+        if (rcv) return rcv;
+        FILE* fv = fopen(path, "wb");
+        if (!fv) return fail(UMGAP_ERR_IO, std::string("cannot create ") + path + ": " + strerror(errno));
+        rcv = var_save(ix, fv);
+        if (fclose(fv) != 0 && !rcv) rcv = fail(UMGAP_ERR_IO, std::string("error writing ") + path);
+        return rcv;
+    }
     if (ix->view.home_lo != 0 || ix->view.home_hi != ix->view.nb) return fail(UMGAP_ERR_INVALID, "umgap_index_save: handle holds a shard");
     int rc = use_device(ix->device);
     if (rc) return rc;
@@ -550,6 +566,16 @@ int umgap_index_open_shard(const char* path, uint32_t device_mask, uint32_t shar
     if (fread(&h, sizeof(h), 1, f) != 1 || memcmp(h.magic, "UMGAPIX1", 8) != 0) {
         fclose(f);
         return fail(UMGAP_ERR_FORMAT, std::string(path) + ": not a UMGAPIX1 index (fst files must be converted: umgap printindex | umgap buildindex)");
+    }
+    if (h.version == 1 && h.kind == 2) {
+        if (n_shards != 1) { fclose(f); return fail(UMGAP_ERR_INVALID, "variable-length indexes cannot be sharded yet"); }
+        umgap_index* vx = nullptr;
+        int rcv = new_handle(device, &vx);
+        if (!rcv) rcv = var_open(vx, h, f, path);
+        fclose(f);
+        if (rcv) { if (vx) umgap_index_free(vx); return rcv; }
+        *out = vx;
+        return UMGAP_OK;
     }
     if (h.version != 1 || h.kind != 9 || h.r_bits != R_BITS || h.slots != SLOTS || h.mix_c1 != MIX_C1 || h.mix_c2 != MIX_C2 ||
         h.m == 0 || h.nb != ((uint64_t)h.m << A_BITS)) {
@@ -636,6 +662,7 @@ int umgap_index_partition9_dev(const umgap_index* ix, const uint64_t* d_keys, si
 
 int umgap_index_lookup9_dev(umgap_index* ix, const uint64_t* d_keys, size_t n, uint32_t miss, uint32_t* d_out, void* stream) {
     if (!ix || (n && (!d_keys || !d_out))) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup9_dev: null argument");
+    if (ix->kind != 9) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup9_dev: not a 9-mer index");
     int rc = use_device(ix->device);
     if (rc) return rc;
     if (n) hipLaunchKernelGGL(k_lookup9, dim3(grid_for(n, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, d_keys, n, miss, d_out, ix->view);
@@ -669,6 +696,7 @@ int umgap_index_lookup_prot9_dev(umgap_index* ix, const uint8_t* d_bytes, const 
 
 int umgap_index_lookup9(umgap_index* ix, const uint64_t* keys, size_t n, uint32_t miss, uint32_t* out) {
     if (!ix || (n && (!keys || !out))) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup9: null argument");
+    if (ix->kind != 9) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup9: not a 9-mer index");
     int rc = use_device(ix->device);
     if (rc) return rc;
     rc = ensure_stage(ix);

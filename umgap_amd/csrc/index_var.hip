@@ -1,0 +1,439 @@
+// index_var.hip — the variable-length (tryptic peptide) index: byte-string key -> taxon, exact.
+// Replaces fst::Map::get for keys of 1..63 bytes (src/commands/pept2lca.rs:93 with the tryptic
+// index, src/commands/prot2tryp2lca.rs:130; the pipelines use 9..45 residues,
+// scripts/umgap-analyse.sh:291).  gfx950 only.
+//
+// Layout: buckets of 64 B = 4 slots of 16 B, one slot per lane of a quad:
+//     w0 = tag (25 bits of the key's hash) | len << 25 (6 bits) | bucket-overflowed << 31 (slot 0 only)
+//     w1 = taxon      w2:w3 = offset of the key bytes in the HEAP (all ones = empty slot)
+// The heap is the concatenation of the key bytes as given at build time (kept resident).  A probe
+// reads the home bucket (hash-chosen); a slot whose tag and length agree is VERIFIED byte by byte
+// against the heap, so answers are exact; an overflowed bucket sends the probe on to the next one
+// (<= 15 steps, then the stash).  Hits cost two requests (bucket + heap line), misses one.
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <vector>
+
+#include "probe_common.hpp"
+
+using namespace umgap;
+using namespace umgap::probe;
+
+namespace umgap {
+static constexpr uint32_t VAR_SLOTS = 4, VAR_MAX_DISP = 15, VAR_MAX_LEN = 63;
+static constexpr uint64_t VAR_EMPTY = ~0ull;
+
+__host__ __device__ inline uint64_t hash_bytes(const uint8_t* p, uint32_t len) {
+    uint64_t h = 0xCBF29CE484222325ull ^ len;
+    for (uint32_t i = 0; i < len; i++) h = (h ^ p[i]) * 0x100000001B3ull;
+    h ^= h >> 32;
+    h *= 0xD6E8FEB86659FD93ull;
+    h ^= h >> 32;
+    return h;
+}
+}  // namespace umgap
+
+struct VarView {
+    const u32x4* slots;     // nb + VAR_MAX_DISP buckets x 4 slots
+    const uint8_t* heap;
+    uint64_t nb;
+    const uint64_t* stash_hash;  // sorted
+    const uint64_t* stash_off;
+    const uint32_t* stash_val;
+    uint32_t n_stash;
+};
+
+struct umgap_var_index {
+    u32x4* d_slots = nullptr;
+    uint8_t* d_heap = nullptr;
+    uint64_t heap_bytes = 0, nb = 0, n_keys = 0;
+    uint64_t* d_stash_hash = nullptr;
+    uint64_t* d_stash_off = nullptr;
+    uint32_t* d_stash_val = nullptr;
+    uint32_t n_stash = 0;
+    VarView view() const { return VarView{d_slots, d_heap, nb, d_stash_hash, d_stash_off, d_stash_val, n_stash}; }
+};
+
+namespace {
+
+struct VarFlags { unsigned long long too_full, bad_key, n_stash, mismatch; };
+constexpr uint32_t VAR_STASH_CAP = 1u << 20;
+
+__device__ __forceinline__ bool bytes_equal(const uint8_t* a, const uint8_t* b, uint32_t len) {
+    for (uint32_t i = 0; i < len; i++)
+        if (a[i] != b[i]) return false;
+    return true;
+}
+
+__device__ __forceinline__ uint32_t var_stash_lookup(const VarView& T, uint64_t h, const uint8_t* q, uint32_t len, uint32_t miss) {
+    uint32_t lo = 0, hi = T.n_stash;
+    while (lo < hi) {  // first entry with hash >= h
+        uint32_t mid = (lo + hi) >> 1;
+        if (T.stash_hash[mid] < h) lo = mid + 1; else hi = mid;
+    }
+    for (; lo < T.n_stash && T.stash_hash[lo] == h; lo++) {
+        uint64_t off = T.stash_off[lo];
+        // stash entries keep the length in the top 6 bits of the offset word
+        if ((uint32_t)(off >> 58) == len && bytes_equal(T.heap + (off & ((1ull << 58) - 1)), q, len)) return T.stash_val[lo];
+    }
+    return miss;
+}
+
+// One query per lane in; the 64 queries of a wave are probed in four rounds of 16 quads.
+__global__ __launch_bounds__(256) void k_lookup_var(const uint8_t* __restrict__ qbytes, const uint64_t* __restrict__ qoff, size_t n,
+                                                    uint32_t miss, uint32_t* __restrict__ out, VarView T) {
+    const uint32_t lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t base = wave * 64; base < n; base += nwaves * 64) {
+        size_t i = base + lane;
+        uint64_t h = 0, o = 0;
+        uint32_t len = 0, valid = 0;
+        if (i < n) {
+            o = qoff[i];
+            uint64_t l64 = qoff[i + 1] - o;
+            if (l64 >= 1 && l64 <= VAR_MAX_LEN) { len = (uint32_t)l64; h = hash_bytes(qbytes + o, len); valid = 1; }
+        }
+        uint32_t res[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int src = 16 * r + (int)q;
+            uint32_t v = (uint32_t)__shfl((int)valid, src, 64);
+            uint32_t hl = (uint32_t)__shfl((int)(uint32_t)h, src, 64), hh = (uint32_t)__shfl((int)(uint32_t)(h >> 32), src, 64);
+            uint32_t ol = (uint32_t)__shfl((int)(uint32_t)o, src, 64), oh = (uint32_t)__shfl((int)(uint32_t)(o >> 32), src, 64);
+            uint32_t ln = (uint32_t)__shfl((int)len, src, 64);
+            uint64_t hq = ((uint64_t)hh << 32) | hl;
+            const uint8_t* qp = qbytes + (((uint64_t)oh << 32) | ol);
+            uint32_t r_out = miss;
+            if (v) {  // quad-uniform
+                uint64_t bucket = __umul64hi(hq, T.nb);
+                uint32_t want = ((uint32_t)hq & 0x01FFFFFFu) | (ln << 25);
+                bool found = false, go = true;
+                for (uint32_t d = 0; go && d <= VAR_MAX_DISP; d++) {
+                    u32x4 e = __builtin_nontemporal_load(T.slots + (bucket + d) * VAR_SLOTS + j);
+                    uint64_t off = ((uint64_t)e.w << 32) | e.z;
+                    uint32_t val = 0, hit = 0;
+                    if (off != VAR_EMPTY && (e.x & 0x7FFFFFFFu) == want && bytes_equal(T.heap + off, qp, ln)) { hit = 1; val = e.y; }
+                    uint32_t ovf = (j == 0) ? (e.x >> 31) : 0u;
+                    uint32_t f = quad_or(hit | (ovf << 1));
+                    val = quad_or(val);
+                    if (f & 1u) { r_out = val; found = true; go = false; }
+                    else if (!(f & 2u)) go = false;
+                }
+                if (!found && go == true && T.n_stash) r_out = var_stash_lookup(T, hq, qp, ln, miss);  // chain exhausted
+            }
+            res[r] = r_out;
+        }
+        if (j == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                size_t k = base + 16 * r + q;
+                if (k < n) out[k] = res[r];
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_insert_var(u32x4* __restrict__ slots, uint64_t nb, const uint8_t* __restrict__ heap,
+                                                    const uint64_t* __restrict__ off, const uint32_t* __restrict__ vals, size_t n,
+                                                    VarFlags* flags, uint64_t* __restrict__ stash) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        uint64_t o = off[i], l64 = off[i + 1] - o;
+        if (l64 < 1 || l64 > VAR_MAX_LEN) { atomicAdd(&flags->bad_key, 1ull); continue; }
+        uint32_t len = (uint32_t)l64;
+        uint64_t h = hash_bytes(heap + o, len);
+        uint64_t bucket = __umul64hi(h, nb);
+        uint32_t w0 = ((uint32_t)h & 0x01FFFFFFu) | (len << 25);
+        bool placed = false;
+        for (uint32_t d = 0; d <= VAR_MAX_DISP && !placed; d++) {
+            uint32_t* s = reinterpret_cast<uint32_t*>(slots + (bucket + d) * VAR_SLOTS);
+            for (uint32_t k = 0; k < VAR_SLOTS && !placed; k++) {
+                unsigned long long* offp = reinterpret_cast<unsigned long long*>(s + 4 * k + 2);  // w2:w3, 8-byte aligned
+                if (atomicCAS(offp, (unsigned long long)VAR_EMPTY, (unsigned long long)o) == VAR_EMPTY) {
+                    s[4 * k + 1] = vals[i];
+                    atomicOr(s + 4 * k, w0);  // OR, not store: slot 0's word also carries the overflow flag
+                    placed = true;
+                }
+            }
+            if (!placed) atomicOr(s, 0x80000000u);  // bucket full: flag it, go on
+        }
+        if (!placed) {
+            unsigned long long at = atomicAdd(&flags->n_stash, 1ull);
+            if (at < VAR_STASH_CAP) { stash[3 * at] = h; stash[3 * at + 1] = o | ((uint64_t)len << 58); stash[3 * at + 2] = vals[i]; }
+            else atomicAdd(&flags->too_full, 1ull);
+        }
+    }
+}
+
+__global__ void k_fill_var(u32x4* p, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    u32x4 e = {0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    for (; i < n; i += stride) p[i] = e;
+}
+
+// after the build every key must find ITSELF (its own heap offset's taxon): anything else is a duplicate key
+__global__ void k_selfcheck_var(const uint32_t* __restrict__ got, const uint32_t* __restrict__ want, size_t n, VarFlags* flags) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride)
+        if (got[i] != want[i]) atomicAdd(&flags->mismatch, 1ull);
+}
+
+inline int grid_for(size_t n) {
+    size_t g = (n + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > 256 * 8) g = 256 * 8;
+    return (int)g;
+}
+
+}  // namespace
+
+namespace umgap {
+
+void var_free(umgap_var_index* v) {
+    if (!v) return;
+    void* ptrs[] = {v->d_slots, v->d_heap, v->d_stash_hash, v->d_stash_off, v->d_stash_val};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    delete v;
+}
+
+int var_set_stash(umgap_var_index* v, std::vector<std::array<uint64_t, 3>>& e) {
+    if (e.empty()) return UMGAP_OK;
+    std::sort(e.begin(), e.end());
+    std::vector<uint64_t> h(e.size()), o(e.size());
+    std::vector<uint32_t> t(e.size());
+    for (size_t i = 0; i < e.size(); i++) { h[i] = e[i][0]; o[i] = e[i][1]; t[i] = (uint32_t)e[i][2]; }
+    UMGAP_HIP(hipMalloc((void**)&v->d_stash_hash, h.size() * 8));
+    UMGAP_HIP(hipMalloc((void**)&v->d_stash_off, o.size() * 8));
+    UMGAP_HIP(hipMalloc((void**)&v->d_stash_val, t.size() * 4));
+    UMGAP_HIP(hipMemcpy(v->d_stash_hash, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+    UMGAP_HIP(hipMemcpy(v->d_stash_off, o.data(), o.size() * 8, hipMemcpyHostToDevice));
+    UMGAP_HIP(hipMemcpy(v->d_stash_val, t.data(), t.size() * 4, hipMemcpyHostToDevice));
+    v->n_stash = (uint32_t)e.size();
+    return UMGAP_OK;
+}
+
+// d_heap / d_off / d_vals: device arrays; the heap is adopted by the index (not copied) when own_heap.
+int var_build(umgap_var_index** out, uint8_t* d_heap, uint64_t heap_bytes, const uint64_t* d_off, const uint32_t* d_vals, size_t n,
+              double load, hipStream_t stream) {
+    if (!(load > 0.0 && load < 1.0)) load = 0.5;
+    auto* v = new umgap_var_index();
+    v->d_heap = d_heap;
+    v->heap_bytes = heap_bytes;
+    v->n_keys = n;
+    VarFlags* d_flags = nullptr;
+    uint64_t* d_stash = nullptr;
+    uint32_t* d_got = nullptr;
+    int rc = UMGAP_OK;
+    auto cleanup = [&]() { if (d_flags) (void)hipFree(d_flags); if (d_stash) (void)hipFree(d_stash); if (d_got) (void)hipFree(d_got); };
+    if (hipMalloc((void**)&d_flags, sizeof(VarFlags)) != hipSuccess || hipMalloc((void**)&d_stash, (size_t)VAR_STASH_CAP * 24) != hipSuccess ||
+        hipMalloc((void**)&d_got, std::max<size_t>(n, 1) * 4) != hipSuccess) { cleanup(); v->d_heap = nullptr; var_free(v); return fail(UMGAP_ERR_NOMEM, "hipMalloc(var index build)"); }
+    uint64_t nb = std::max<uint64_t>(1024, (uint64_t)std::ceil((double)n / (VAR_SLOTS * load)));
+    for (int attempt = 0; attempt < 4; attempt++) {
+        if (v->d_slots) { (void)hipFree(v->d_slots); v->d_slots = nullptr; }
+        size_t nslots = (size_t)(nb + VAR_MAX_DISP) * VAR_SLOTS;
+        if (hipMalloc((void**)&v->d_slots, nslots * 16) != hipSuccess) { rc = fail(UMGAP_ERR_NOMEM, "hipMalloc of the var table failed"); break; }
+        v->nb = nb;
+        hipLaunchKernelGGL(k_fill_var, dim3(grid_for(nslots)), dim3(256), 0, stream, v->d_slots, nslots);
+        (void)hipMemsetAsync(d_flags, 0, sizeof(VarFlags), stream);
+        if (n) hipLaunchKernelGGL(k_insert_var, dim3(grid_for(n)), dim3(256), 0, stream, v->d_slots, nb, d_heap, d_off, d_vals, n, d_flags, d_stash);
+        VarFlags h{};
+        hipError_t e = hipMemcpyAsync(&h, d_flags, sizeof(h), hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) { rc = fail(UMGAP_ERR_DEVICE, std::string("var index build: ") + hipGetErrorString(e)); break; }
+        if (h.bad_key) { rc = fail(UMGAP_ERR_BUILD, "index build: " + std::to_string(h.bad_key) + " keys are empty or longer than 63 bytes"); break; }
+        if (h.too_full) { nb = nb + nb / 4 + 1; rc = fail(UMGAP_ERR_BUILD, "index build: table too full"); continue; }
+        std::vector<uint64_t> raw(3 * (size_t)h.n_stash);
+        if (h.n_stash && hipMemcpy(raw.data(), d_stash, raw.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(UMGAP_ERR_DEVICE, "stash copy failed"); break; }
+        std::vector<std::array<uint64_t, 3>> entries(h.n_stash);
+        for (size_t i = 0; i < h.n_stash; i++) entries[i] = {raw[3 * i], raw[3 * i + 1], raw[3 * i + 2]};
+        rc = var_set_stash(v, entries);
+        if (rc) break;
+        // self check: every key finds its own taxon (a duplicate key finds the other copy's)
+        if (n) {
+            hipLaunchKernelGGL(k_lookup_var, dim3(grid_for(n)), dim3(256), 0, stream, d_heap, d_off, n, 0xFFFFFFFFu, d_got, v->view());
+            hipLaunchKernelGGL(k_selfcheck_var, dim3(grid_for(n)), dim3(256), 0, stream, d_got, d_vals, n, d_flags);
+            e = hipMemcpyAsync(&h, d_flags, sizeof(h), hipMemcpyDeviceToHost, stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) { rc = fail(UMGAP_ERR_DEVICE, std::string("var index self-check: ") + hipGetErrorString(e)); break; }
+            if (h.mismatch) { rc = fail(UMGAP_ERR_BUILD, "index build: duplicate keys (keys must be distinct, cf. fst::MapBuilder::insert)"); break; }
+        }
+        rc = UMGAP_OK;
+        break;
+    }
+    cleanup();
+    if (rc) { v->d_heap = nullptr; var_free(v); return rc; }
+    *out = v;
+    return UMGAP_OK;
+}
+
+int var_lookup_dev(const umgap_var_index* v, const uint8_t* d_bytes, const uint64_t* d_off, size_t n, uint32_t miss, uint32_t* d_out, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_lookup_var, dim3(grid_for(n)), dim3(256), 0, s, d_bytes, d_off, n, miss, d_out, v->view());
+    UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}
+
+}  // namespace umgap
+
+// ==========================================================================================
+// C ABI (variable-length keys)
+// ==========================================================================================
+namespace umgap { int use_device(int device); }
+
+namespace {
+int new_var_handle(int device, umgap_index** out) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    umgap_index* ix = new umgap_index();
+    ix->device = device;
+    ix->kind = 2;
+    hipError_t e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete ix; return fail(UMGAP_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    *out = ix;
+    return UMGAP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int umgap_index_kind(const umgap_index* ix) { return ix ? ix->kind : 0; }
+
+int umgap_index_build_var_dev(const uint8_t* d_bytes, const uint64_t* d_offsets, const uint32_t* d_taxa, size_t n, uint64_t n_bytes,
+                              double load_factor, int device, umgap_index** out) {
+    if (!out || (n && (!d_bytes || !d_offsets || !d_taxa))) return fail(UMGAP_ERR_INVALID, "umgap_index_build_var_dev: null argument");
+    umgap_index* ix = nullptr;
+    int rc = new_var_handle(device, &ix);
+    if (rc) return rc;
+    uint8_t* heap = nullptr;
+    hipError_t e = hipMalloc((void**)&heap, std::max<uint64_t>(n_bytes, 1));
+    if (e == hipSuccess && n_bytes) e = hipMemcpyAsync(heap, d_bytes, n_bytes, hipMemcpyDeviceToDevice, ix->stream);
+    if (e != hipSuccess) { if (heap) (void)hipFree(heap); umgap_index_free(ix); return fail(UMGAP_ERR_NOMEM, std::string("var index heap: ") + hipGetErrorString(e)); }
+    rc = var_build(&ix->var, heap, n_bytes, d_offsets, d_taxa, n, load_factor, ix->stream);
+    if (rc) { (void)hipFree(heap); umgap_index_free(ix); return rc; }
+    ix->n_keys = n;
+    *out = ix;
+    return UMGAP_OK;
+}
+
+int umgap_index_build_var(const uint8_t* bytes, const uint64_t* offsets, const uint32_t* taxa, size_t n, double load_factor, int device,
+                          umgap_index** out) {
+    if (!out || (n && (!bytes || !offsets || !taxa))) return fail(UMGAP_ERR_INVALID, "umgap_index_build_var: null argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    const uint64_t base = n ? offsets[0] : 0, n_bytes = n ? offsets[n] - base : 0;
+    std::vector<uint64_t> rel(n + 1, 0);
+    for (size_t i = 0; i <= n && n; i++) rel[i] = offsets[i] - base;
+    uint8_t* db = nullptr; uint64_t* doff = nullptr; uint32_t* dv = nullptr;
+    hipError_t e = hipMalloc((void**)&db, std::max<uint64_t>(n_bytes, 1));
+    if (e == hipSuccess) e = hipMalloc((void**)&doff, (n + 1) * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&dv, std::max<size_t>(n, 1) * 4);
+    if (e == hipSuccess && n_bytes) e = hipMemcpy(db, bytes + base, n_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(doff, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess && n) e = hipMemcpy(dv, taxa, n * 4, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = fail(UMGAP_ERR_NOMEM, std::string("umgap_index_build_var: ") + hipGetErrorString(e));
+    else rc = umgap_index_build_var_dev(db, doff, dv, n, n_bytes, load_factor, device, out);
+    if (db) (void)hipFree(db);
+    if (doff) (void)hipFree(doff);
+    if (dv) (void)hipFree(dv);
+    return rc;
+}
+
+int umgap_index_lookup_var_dev(umgap_index* ix, const uint8_t* d_bytes, const uint64_t* d_offsets, size_t n, uint32_t miss_value,
+                               uint32_t* d_out, void* stream) {
+    if (!ix || ix->kind != 2 || !ix->var) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup_var_dev: not a variable-length index");
+    if (n && (!d_bytes || !d_offsets || !d_out)) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup_var_dev: null argument");
+    int rc = use_device(ix->device);
+    if (rc) return rc;
+    return var_lookup_dev(ix->var, d_bytes, d_offsets, n, miss_value, d_out, (hipStream_t)stream);
+}
+
+int umgap_index_lookup_var(umgap_index* ix, const uint8_t* bytes, const uint64_t* offsets, size_t n, uint32_t miss_value, uint32_t* out) {
+    if (!ix || ix->kind != 2 || !ix->var) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup_var: not a variable-length index");
+    if (n && (!bytes || !offsets || !out)) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup_var: null argument");
+    int rc = use_device(ix->device);
+    if (rc) return rc;
+    if (!n) return UMGAP_OK;
+    const uint64_t base = offsets[0], n_bytes = offsets[n] - base;
+    std::vector<uint64_t> rel(n + 1);
+    for (size_t i = 0; i <= n; i++) rel[i] = offsets[i] - base;
+    uint8_t* db = nullptr; uint64_t* doff = nullptr; uint32_t* dout = nullptr;
+    hipError_t e = hipMalloc((void**)&db, std::max<uint64_t>(n_bytes, 1));
+    if (e == hipSuccess) e = hipMalloc((void**)&doff, (n + 1) * 8);
+    if (e == hipSuccess) e = hipMalloc((void**)&dout, n * 4);
+    if (e == hipSuccess && n_bytes) e = hipMemcpyAsync(db, bytes + base, n_bytes, hipMemcpyHostToDevice, ix->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(doff, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, ix->stream);
+    if (e == hipSuccess) {
+        rc = var_lookup_dev(ix->var, db, doff, n, miss_value, dout, ix->stream);
+        if (!rc) e = hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, ix->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+    }
+    if (e != hipSuccess && !rc) rc = fail(UMGAP_ERR_DEVICE, std::string("umgap_index_lookup_var: ") + hipGetErrorString(e));
+    if (db) (void)hipFree(db);
+    if (doff) (void)hipFree(doff);
+    if (dout) (void)hipFree(dout);
+    return rc;
+}
+
+}  // extern "C"
+
+namespace umgap {
+
+// "UMGAPIX1" kind 2: header, slots, heap, stash {hash, off|len<<58, taxon}
+int var_save(const umgap_index* ix, FILE* f) {
+    const umgap_var_index* v = ix->var;
+    IndexFileHeader h{};
+    memcpy(h.magic, "UMGAPIX1", 8);
+    h.version = 1; h.kind = 2; h.n_keys = v->n_keys; h.m = 0; h.nb = 0;
+    h.mix_c1 = v->nb; h.mix_c2 = v->heap_bytes; h.r_bits = VAR_MAX_DISP; h.slots = VAR_SLOTS; h.n_stash = v->n_stash;
+    bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
+    const size_t chunk = 64u << 20;
+    std::vector<char> buf(chunk);
+    auto dump = [&](const void* d, size_t total) {
+        for (size_t off = 0; ok && off < total; off += chunk) {
+            size_t len = std::min(chunk, total - off);
+            if (hipMemcpy(buf.data(), (const char*)d + off, len, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+            ok = fwrite(buf.data(), 1, len, f) == len;
+        }
+    };
+    dump(v->d_slots, (size_t)(v->nb + VAR_MAX_DISP) * 64);
+    dump(v->d_heap, v->heap_bytes);
+    dump(v->d_stash_hash, (size_t)v->n_stash * 8);
+    dump(v->d_stash_off, (size_t)v->n_stash * 8);
+    dump(v->d_stash_val, (size_t)v->n_stash * 4);
+    return ok ? UMGAP_OK : fail(UMGAP_ERR_IO, "error writing the index file");
+}
+
+int var_open(umgap_index* ix, const IndexFileHeader& h, FILE* f, const char* path) {
+    if (h.slots != VAR_SLOTS || h.r_bits != VAR_MAX_DISP) return fail(UMGAP_ERR_FORMAT, std::string(path) + ": unsupported UMGAPIX1 (var) parameters");
+    auto* v = new umgap_var_index();
+    ix->var = v;
+    ix->kind = 2;
+    v->nb = h.mix_c1; v->heap_bytes = h.mix_c2; v->n_keys = h.n_keys; v->n_stash = (uint32_t)h.n_stash;
+    ix->n_keys = h.n_keys;
+    const size_t chunk = 64u << 20;
+    std::vector<char> buf(chunk);
+    bool ok = true;
+    auto slurp = [&](void** d, size_t total) {
+        if (!ok) return;
+        if (hipMalloc(d, std::max<size_t>(total, 1)) != hipSuccess) { ok = false; return; }
+        for (size_t off = 0; ok && off < total; off += chunk) {
+            size_t len = std::min(chunk, total - off);
+            if (fread(buf.data(), 1, len, f) != len) { ok = false; break; }
+            if (hipMemcpy((char*)*d + off, buf.data(), len, hipMemcpyHostToDevice) != hipSuccess) ok = false;
+        }
+    };
+    slurp((void**)&v->d_slots, (size_t)(v->nb + VAR_MAX_DISP) * 64);
+    slurp((void**)&v->d_heap, v->heap_bytes);
+    slurp((void**)&v->d_stash_hash, (size_t)v->n_stash * 8);
+    slurp((void**)&v->d_stash_off, (size_t)v->n_stash * 8);
+    slurp((void**)&v->d_stash_val, (size_t)v->n_stash * 4);
+    if (!ok) return fail(UMGAP_ERR_IO, std::string(path) + ": truncated or unreadable table");
+    return UMGAP_OK;
+}
+
+}  // namespace umgap
