@@ -217,6 +217,10 @@ int umgap_synth_index_build(uint64_t n_keys, const uint32_t* d_taxon_of_row, uin
 int umgap_synth_index_build_shard(uint64_t n_keys, const uint32_t* d_taxon_of_row, uint64_t n_tax,
                                   uint64_t mul_a, uint64_t add_b, double load_factor, int device,
                                   uint32_t shard, uint32_t n_shards, umgap_index** out);
+/* Synthetic tryptic-like peptides: peptide i (global number first+i) fills
+ * d_bytes[d_offsets[i] .. d_offsets[i+1]) with letters determined by (seed, first+i). */
+int umgap_synth_peptides_dev(uint64_t first, size_t n, uint64_t seed, const uint64_t* d_offsets,
+                             uint8_t* d_bytes, int device, void* stream);
 int umgap_synth_reads9_dev(const umgap_taxonomy* tx, const uint32_t* d_taxon_of_row,
                            const uint32_t* d_row_of_id, uint64_t n_tax, uint64_t n_keys, uint64_t mul_a,
                            uint64_t add_b, uint64_t seed, uint64_t first_pair, uint64_t n_pairs,

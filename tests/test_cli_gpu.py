@@ -326,3 +326,94 @@ def test_tryptic_precision_pipeline_matches_oracle(tryptic, world):
             return c
         mine, ref = pipeline(run, tryptic["idx"]), pipeline(O.run_cli, tryptic["tsv"])
         assert mine == ref and mine.count(b">") == 150
+
+
+def test_prot2kmer2lca_socket_server(world, tmp_path):
+    """`umgap prot2kmer2lca -m -o -s <socket>` as scripts/umgap-analyse.sh:260 starts it; clients talk to it like
+    `nc -NU` (send, half-close, read to EOF).  Connections are served sequentially (src/commands/prot2kmer2lca.rs:116-137)."""
+    import socket
+    import time
+    sock = str(tmp_path / "umgap.sock")
+    rng = np.random.default_rng(2)
+    fastas = []
+    for c in range(3):
+        recs = []
+        for r in range(200):
+            pep = "".join(rng.choice(list(LETTERS), int(rng.integers(0, 60))))
+            if len(pep) > 20:
+                s = int(rng.integers(0, len(pep) - 10))
+                pep = pep[:s] + world["kmers"][int(rng.integers(0, len(world["kmers"])))] + pep[s + 9:]
+            recs.append(">c%dr%d\n%s\n" % (c, r, pep))
+        fastas.append("".join(recs).encode())
+    srv = subprocess.Popen([UMGAP, "prot2kmer2lca", "-m", "-o", "-s", sock, world["idx"]], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    try:
+        for _ in range(600):
+            if os.path.exists(sock):
+                break
+            time.sleep(0.1)
+        assert os.path.exists(sock), srv.stderr.read() if srv.poll() is not None else "socket never appeared"
+        for fasta in fastas:
+            c = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            c.connect(sock)
+            c.sendall(fasta)
+            c.shutdown(socket.SHUT_WR)
+            got = b""
+            while True:
+                chunk = c.recv(1 << 16)
+                if not chunk:
+                    break
+                got += chunk
+            c.close()
+            rc, want, _ = run(["prot2kmer2lca", "-o", world["idx"]], fasta)
+            assert rc == 0 and got == want and got.count(b">") > 100
+    finally:
+        srv.terminate()
+        out, _ = srv.communicate(timeout=10)
+    assert out.startswith(b"Socket created, listening for connections.\n")
+    assert out.count(b"Connection accepted. Processing...\n") == 3 and out.count(b"Connection finished succesfully.\n") == 3
+
+
+CODON = {}
+for i, a in enumerate("TCAG"):
+    for j, b in enumerate("TCAG"):
+        for k, c in enumerate("TCAG"):
+            CODON[a + b + c] = "FFLLSSSSYY**CC*WLLLLPPPPHHQQRRRRIIIMTTTTNNKKSSRRVVVVAAAADDEEGGGG"[16 * i + 4 * j + k]
+
+
+def _six_frames(dna):
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    rc = "".join(comp.get(c, "N") for c in reversed(dna))
+    for strand in (dna, rc):
+        for f in range(3):
+            yield "".join(CODON.get(strand[i:i + 3], "X") for i in range(f, len(strand) - 2, 3))
+
+
+def test_config1_testdata_plumbing(tryptic, world, golden):
+    """BASELINE.json configs[0]: the reference's own testdata (A1.fq + A2.fq) through the tryptic-precision stages
+    (scripts/umgap-analyse.sh:295-298; 6-frame translation stands in for FGSpp, which is not available): plumbing only --
+    headers survive, the two ends are joined by `uniq -d /`, one taxon per read pair, identical to the oracle."""
+    import json as _json
+    with open(os.path.join(ROOT, "tests", "golden", "testdata_A_first25.json")) as f:
+        td = _json.load(f)
+    recs = []
+    for a, b in zip(td["A1"], td["A2"]):
+        assert a["header"].endswith("/1") and b["header"].endswith("/2") and a["header"][:-2] == b["header"][:-2]
+        for end in (a, b):       # fastq2fasta interleaves the two files; translate -a emits 6 frames per read
+            for frame in _six_frames(end["seq"]):
+                recs.append(">%s\n%s\n" % (end["header"], frame))
+    fasta = "".join(recs).encode()
+
+    def pipeline(runner, idx):
+        rc, a, _ = runner(["prot2tryp2lca", "-o", "-l", "9", "-L", "45", idx], fasta)
+        assert rc == 0
+        rc, b, _ = runner(["uniq", "-d", "/"], a)
+        assert rc == 0
+        rc, c, _ = runner(["taxa2agg", "-l", "5", "-m", "rmq", "-a", "mrtl", world["tsv"]], b)
+        assert rc == 0
+        return c
+    mine, ref = pipeline(run, tryptic["idx"]), pipeline(O.run_cli, tryptic["tsv"])
+    assert mine == ref
+    lines = mine.decode().split("\n")
+    headers = [l[1:] for l in lines if l.startswith(">")]
+    assert headers == [a["header"][:-2] for a in td["A1"]]        # 25 pairs -> 25 records, header cut at '/'
+    assert all(l.isdigit() for l in lines if l and not l.startswith(">"))

@@ -99,6 +99,7 @@ def load():
         "umgap_bench_gather_dev": (i32, [vp, sz, u32, vp, vp]),
         "umgap_synth_index_build": (i32, [u64, vp, u64, u64, u64, dbl, i32, pp]),
         "umgap_synth_index_build_shard": (i32, [u64, vp, u64, u64, u64, dbl, i32, u32, u32, pp]),
+        "umgap_synth_peptides_dev": (i32, [u64, sz, u64, vp, vp, i32, vp]),
         "umgap_synth_reads9_dev": (i32, [vp, vp, vp, u64, u64, u64, u64, u64, u64, u64, u32, vp, vp]),
     }
     for name, (res, args) in sig.items():

@@ -24,9 +24,25 @@ namespace umgap {
 static constexpr uint32_t VAR_SLOTS = 4, VAR_MAX_DISP = 15, VAR_MAX_LEN = 63;
 static constexpr uint64_t VAR_EMPTY = ~0ull;
 
+typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+
+// 8 bytes at a time (unaligned 64-bit loads; the last word overlaps the previous one when len is
+// not a multiple of 8), byte-wise only for keys shorter than 8
 __host__ __device__ inline uint64_t hash_bytes(const uint8_t* p, uint32_t len) {
-    uint64_t h = 0xCBF29CE484222325ull ^ len;
-    for (uint32_t i = 0; i < len; i++) h = (h ^ p[i]) * 0x100000001B3ull;
+    uint64_t h = 0xCBF29CE484222325ull ^ ((uint64_t)len * 0x9E3779B97F4A7C15ull);
+    if (len >= 8) {
+        uint32_t i = 0;
+        for (; i + 8 <= len; i += 8) {
+            h = (h ^ *reinterpret_cast<const u64_unaligned*>(p + i)) * 0xD6E8FEB86659FD93ull;
+            h ^= h >> 29;
+        }
+        if (i < len) {
+            h = (h ^ *reinterpret_cast<const u64_unaligned*>(p + len - 8)) * 0xD6E8FEB86659FD93ull;
+            h ^= h >> 29;
+        }
+    } else {
+        for (uint32_t i = 0; i < len; i++) h = (h ^ p[i]) * 0x100000001B3ull;
+    }
     h ^= h >> 32;
     h *= 0xD6E8FEB86659FD93ull;
     h ^= h >> 32;
@@ -61,6 +77,12 @@ struct VarFlags { unsigned long long too_full, bad_key, n_stash, mismatch; };
 constexpr uint32_t VAR_STASH_CAP = 1u << 20;
 
 __device__ __forceinline__ bool bytes_equal(const uint8_t* a, const uint8_t* b, uint32_t len) {
+    if (len >= 8) {
+        uint32_t i = 0;
+        for (; i + 8 <= len; i += 8)
+            if (*reinterpret_cast<const u64_unaligned*>(a + i) != *reinterpret_cast<const u64_unaligned*>(b + i)) return false;
+        return i == len || *reinterpret_cast<const u64_unaligned*>(a + len - 8) == *reinterpret_cast<const u64_unaligned*>(b + len - 8);
+    }
     for (uint32_t i = 0; i < len; i++)
         if (a[i] != b[i]) return false;
     return true;

@@ -155,6 +155,25 @@ __global__ __launch_bounds__(256) void k_synth_reads(TaxView V, const uint32_t* 
     }
 }
 
+// synthetic tryptic-like peptides: peptide i has length offsets[i+1]-offsets[i] and letters drawn
+// from the 20 amino acids by a hash of (seed, i, position); the last letter is K or R
+__global__ __launch_bounds__(256) void k_synth_peptides(uint64_t first, size_t n, uint64_t seed, const uint64_t* __restrict__ offsets,
+                                                        uint8_t* __restrict__ bytes) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) {
+        uint64_t o = offsets[i], len = offsets[i + 1] - o;
+        uint64_t h = splitmix64(seed ^ ((first + i) * 0x9E3779B97F4A7C15ull));
+        for (uint64_t j = 0; j < len; j++) {
+            if ((j & 7) == 0 && j) h = splitmix64(h + j);
+            uint32_t d = (uint32_t)((h >> (8 * (j & 7))) & 0xFF) % 20;
+            uint32_t code = d + (d >= 1) + (d >= 8) + (d >= 12) + (d >= 17) + (d >= 19);
+            bytes[o + j] = (uint8_t)('A' + code);
+        }
+        if (len) bytes[o + len - 1] = (h >> 60) & 1 ? 'K' : 'R';
+    }
+}
+
 inline int grid_for(size_t n) {
     size_t g = (n + 255) / 256;
     if (g < 1) g = 1;
@@ -190,6 +209,15 @@ int umgap_seedextend_strided_dev(uint32_t stride, size_t n_records, uint32_t min
     int rc = use_device(device);
     if (rc) return rc;
     if (n_records) hipLaunchKernelGGL(k_seedextend, dim3(grid_for(n_records)), dim3(256), 0, (hipStream_t)stream, (const uint64_t*)nullptr, stride, n_records, min_seed_size, max_gap_size, d_taxa, d_kept);
+    UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}
+
+int umgap_synth_peptides_dev(uint64_t first, size_t n, uint64_t seed, const uint64_t* d_offsets, uint8_t* d_bytes, int device, void* stream) {
+    if (n && (!d_offsets || !d_bytes)) return fail(UMGAP_ERR_INVALID, "umgap_synth_peptides_dev: null argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    if (n) hipLaunchKernelGGL(k_synth_peptides, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, first, n, seed, d_offsets, d_bytes);
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
 }
