@@ -41,23 +41,26 @@ int main(int argc, char** argv) {
         if (cmd == "pept2lca") {
             bool o = flag("-o");
             flag("-m");
-            opt("-c");
+            size_t c = 240;
+            if (auto v = opt("-c")) c = parse_usize(*v);
             if (a.size() != 2) throw Error(ErrKind::InvalidInvocation, "usage");
             SortedIndex ix = load_index(a[1]);
-            pept2lca(std::cin, std::cout, ix, o);
+            pept2lca(std::cin, std::cout, ix, o, c);
         } else if (cmd == "prot2kmer2lca") {
             bool o = flag("-o");
             flag("-m");
-            opt("-c");
+            size_t c = 240;
+            if (auto v = opt("-c")) c = parse_usize(*v);
             size_t k = 9;
             if (auto v = opt("-k")) k = parse_usize(*v);
             if (a.size() != 2) throw Error(ErrKind::InvalidInvocation, "usage");
             SortedIndex ix = load_index(a[1]);
-            prot2kmer2lca(std::cin, std::cout, ix, k, o);
+            prot2kmer2lca(std::cin, std::cout, ix, k, o, c);
         } else if (cmd == "prot2tryp2lca") {
             bool o = flag("-o");
             flag("-m");
-            opt("-c");
+            size_t c = 240;
+            if (auto v = opt("-c")) c = parse_usize(*v);
             size_t l = 5, L = 50;
             std::string keep, drop;
             if (auto v = opt("-l")) l = parse_usize(*v);
@@ -66,7 +69,7 @@ int main(int argc, char** argv) {
             if (auto v = opt("-d")) drop = *v;
             if (a.size() != 2) throw Error(ErrKind::InvalidInvocation, "usage");
             SortedIndex ix = load_index(a[1]);
-            prot2tryp2lca(std::cin, std::cout, ix, o, l, L, keep, drop);
+            prot2tryp2lca(std::cin, std::cout, ix, o, l, L, keep, drop, c);
         } else if (cmd == "taxa2agg") {
             bool scored = flag("-s"), ranked = flag("-r");
             Method m = Method::Tree;

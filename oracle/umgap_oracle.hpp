@@ -992,44 +992,66 @@ struct SortedIndex : Index {
 // ---------------------------------------------------------------------------
 // commands
 // ---------------------------------------------------------------------------
+// ChunkedRecords::next — src/io/fasta.rs:118-137: up to chunk_size records; a read error is
+// returned AT ONCE and the records collected for this chunk are dropped with it.
+inline bool next_chunk(FastaReader& reader, size_t chunk_size, std::vector<Record>& chunk) {
+    chunk.clear();
+    Record r;
+    while (chunk.size() < chunk_size) {
+        if (!reader.read_record(r)) break;  // throws on Err
+        chunk.push_back(r);
+    }
+    return !chunk.empty();
+}
+
 // pept2lca record loop — src/commands/pept2lca.rs:81-101 with RAYON_NUM_THREADS=1 ordering
-// (input order).  chunk_size only groups output writes; bytes are identical.
-inline void pept2lca(std::istream& in, std::ostream& out, const Index& index, bool one_on_one) {
+// (input order).  Output is built per chunk and printed when the chunk is done (:89,:98): an
+// error or panic inside a chunk prints nothing of that chunk.
+inline void pept2lca(std::istream& in, std::ostream& out, const Index& index, bool one_on_one, size_t chunk_size = 240) {
     std::optional<uint64_t> dflt;
     if (one_on_one) dflt = 0;  // :81
     FastaReader reader(in, false);
-    Record read;
-    while (reader.read_record(read)) {
-        out << '>' << read.header << '\n';  // :91
-        for (auto& seq : read.sequence) {
-            std::optional<uint64_t> lca = index.get(seq);
-            if (!lca) lca = dflt;
-            if (lca) out << *lca << '\n';  // :93-95
+    std::vector<Record> chunk;
+    while (next_chunk(reader, chunk_size, chunk)) {
+        std::string chunk_output;
+        for (auto& read : chunk) {
+            chunk_output += ">" + read.header + "\n";  // :91
+            for (auto& seq : read.sequence) {
+                std::optional<uint64_t> lca = index.get(seq);
+                if (!lca) lca = dflt;
+                if (lca) chunk_output += std::to_string(*lca) + "\n";  // :93-95
+            }
         }
+        out << chunk_output;
     }
 }
 
 // prot2kmer2lca stream loop — src/commands/prot2kmer2lca.rs:150-193 (input order).
 inline void prot2kmer2lca(std::istream& in, std::ostream& out, const Index& index, size_t k,
-                          bool one_on_one) {
+                          bool one_on_one, size_t chunk_size = 240) {
     std::optional<uint64_t> dflt;
     if (one_on_one) dflt = 0;
     FastaReader reader(in, true);
-    Record read;
-    while (reader.read_record(read)) {
-        // :172 — `read.sequence.get(0).filter(|p| p.len() >= k)`; shorter reads vanish entirely
-        if (read.sequence.empty() || read.sequence[0].size() < k) continue;
-        const std::string& prot = read.sequence[0];
-        out << '>' << read.header << '\n';
-        // NB `&prot[i..i + k]` panics if the slice cuts a multi-byte UTF-8 char (:176).
-        for (size_t i = 0; i + k <= prot.size(); i++) {
-            if (((unsigned char)prot[i] & 0xC0) == 0x80 ||
-                (i + k < prot.size() && ((unsigned char)prot[i + k] & 0xC0) == 0x80))
-                throw Panic("byte index is not a char boundary");
-            std::optional<uint64_t> lca = index.get(prot.substr(i, k));
-            if (!lca) lca = dflt;
-            if (lca) out << *lca << '\n';
+    std::vector<Record> chunk;
+    while (next_chunk(reader, chunk_size, chunk)) {
+        std::string chunk_output;
+        for (auto& read : chunk) {
+            // :172 — `read.sequence.get(0).filter(|p| p.len() >= k)`; shorter reads vanish entirely
+            if (read.sequence.empty() || read.sequence[0].size() < k) continue;
+            const std::string& prot = read.sequence[0];
+            chunk_output += ">" + read.header + "\n";
+            // NB `&prot[i..i + k]` panics if the slice cuts a multi-byte UTF-8 char (:176); the chunk's
+            // output is then never written (:186-189)
+            for (size_t i = 0; i + k <= prot.size(); i++) {
+                if (((unsigned char)prot[i] & 0xC0) == 0x80 ||
+                    (i + k < prot.size() && ((unsigned char)prot[i + k] & 0xC0) == 0x80))
+                    throw Panic("byte index is not a char boundary");
+                std::optional<uint64_t> lca = index.get(prot.substr(i, k));
+                if (!lca) lca = dflt;
+                if (lca) chunk_output += std::to_string(*lca) + "\n";
+            }
         }
+        out << chunk_output;
     }
 }
 
@@ -1057,14 +1079,17 @@ inline std::string tryp_replace_pass(const std::string& s) {
     }
     return o;
 }
-inline void prot2tryp2lca(std::istream& in, std::ostream& out, const Index& index, bool one_on_one, size_t min_length,
-                          size_t max_length, const std::string& contains, const std::string& lacks) {
+inline bool next_chunk(FastaReader& reader, size_t chunk_size, std::vector<Record>& chunk);
+inline void prot2tryp2lca(std::istream& in, std::ostream& out_final, const Index& index, bool one_on_one, size_t min_length,
+                          size_t max_length, const std::string& contains, const std::string& lacks, size_t chunk_size = 240) {
     std::optional<uint64_t> dflt;
     if (one_on_one) dflt = 0;
     std::set<char> cset(contains.begin(), contains.end()), lset(lacks.begin(), lacks.end());
     FastaReader reader(in, false);
-    Record read;
-    while (reader.read_record(read)) {
+    std::vector<Record> chunk;
+    while (next_chunk(reader, chunk_size, chunk)) {
+      std::ostringstream out;  // chunk_output (:106,:136)
+      for (auto& read : chunk) {
         out << '>' << read.header << '\n';
         for (auto& seq : read.sequence) {
             std::string d = tryp_replace_pass(tryp_replace_pass(seq));
@@ -1089,6 +1114,8 @@ inline void prot2tryp2lca(std::istream& in, std::ostream& out, const Index& inde
                 st = p + 1;
             }
         }
+      }
+      out_final << out.str();
     }
 }
 

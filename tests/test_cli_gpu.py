@@ -417,3 +417,92 @@ def test_config1_testdata_plumbing(tryptic, world, golden):
     headers = [l[1:] for l in lines if l.startswith(">")]
     assert headers == [a["header"][:-2] for a in td["A1"]]        # 25 pairs -> 25 records, header cut at '/'
     assert all(l.isdigit() for l in lines if l and not l.startswith(">"))
+
+
+def _run_env(args, stdin, **env):
+    e = dict(os.environ)
+    e.update({k: str(v) for k, v in env.items()})
+    p = subprocess.run([UMGAP] + list(args), input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+    return p.returncode, p.stdout, p.stderr
+
+
+@pytest.mark.parametrize("block,threads", [(64, 3), (1000, 7), (4096, 16), (100000, 1)])
+def test_block_seams_and_threads(world, block, threads):
+    """The block-parallel tokenizer must not depend on where blocks and thread ranges are cut."""
+    rng = np.random.default_rng(block)
+    env = dict(UMGAP_BLOCK_BYTES=block, UMGAP_THREADS=threads)
+    fasta = _peptide_fasta(world, 300, rng)
+    for flags in ([], ["-o"]):
+        rc, out, _ = _run_env(["pept2lca"] + flags + [world["idx"]], fasta, **env)
+        orc, oout, _ = O.run_cli(["pept2lca"] + flags + [world["idx_tsv"]], fasta)
+        assert rc == orc == 0 and out == oout
+    prot = "".join(">p%d\n%s\n" % (r, "".join(rng.choice(list(LETTERS), int(rng.integers(0, 80))))) for r in range(300)).encode()
+    rc, out, _ = _run_env(["prot2kmer2lca", "-o", world["idx"]], prot, **env)
+    orc, oout, _ = O.run_cli(["prot2kmer2lca", "-o", world["idx_tsv"]], prot)
+    assert rc == orc == 0 and out == oout
+    taxa = _taxa_fasta(world, rng, 300)
+    for mode in (["-a", "lca*", "-l", "2"], ["-m", "rmq", "-a", "mrtl"], []):
+        rc, out, _ = _run_env(["taxa2agg"] + mode + [world["tsv"]], taxa, **env)
+        orc, oout, _ = O.run_cli(["taxa2agg"] + mode + [world["tsv"]], taxa)
+        assert rc == orc == 0 and out == oout
+    recs = "".join(">h%d/%d\n%s" % (r // 2, r % 2 + 1, "".join("%d\n" % t for t in rng.choice([0, 0, 5, 5, 7, 9], int(rng.integers(0, 40)))))
+                   for r in range(300)).encode()
+    for cmd in (["seedextend", "-g", "1", "-s", "3"], ["uniq", "-d", "/"], ["uniq"]):
+        rc, out, _ = _run_env(cmd, recs, **env)
+        orc, oout, _ = O.run_cli(cmd, recs)
+        assert rc == orc == 0 and out == oout, cmd
+
+
+@pytest.mark.parametrize("block", [48, 1 << 20])
+def test_line_ending_and_error_quirks_match_oracle(world, block):
+    env = dict(UMGAP_BLOCK_BYTES=block, UMGAP_THREADS=4)
+    k = world["kmers"]
+    ids = [int(x) for x in world["ids"][:6]]
+    cases = [
+        (["pept2lca", "-o", world["idx"]], ["pept2lca", "-o", world["idx_tsv"]],
+         [(">a\r\n%s\r\n%s\r\n>b\r\n%s" % (k[0], k[1], k[2])).encode(),            # CRLF + no final newline
+          (">a\n\n\n%s\n>b\n>c\n" % k[3]).encode(),                                 # empty items, empty records
+          b">a\n" + k[0].encode() + b"\n>b\n\xff\xfe\n" + k[1].encode() + b"\n>c\n" + k[2].encode() + b"\n",   # bad UTF-8 in an item
+          b">a\n" + k[0].encode() + b"\n>b\xff\n" + k[1].encode() + b"\n",           # bad UTF-8 in a header
+          b"nope\n>a\n", b"", b">only header", ">héader ü\n%s\n".encode() % k[0].encode()]),
+        (["prot2kmer2lca", "-o", world["idx"]], ["prot2kmer2lca", "-o", world["idx_tsv"]],
+         [(">a\r\n%sAC\r\nDE%s\r\n>b\nAAAA\n>c\n%s" % (k[0], k[1], k[2] + k[3])).encode(),
+          b">a\n" + (k[0] + k[1]).encode() + b"\n>b\nAC\xc3\xa9DEFGHIKLMN\n>c\n" + k[2].encode() + b"\n",   # window cuts a UTF-8 char: panic
+          b">a\n" + k[0].encode() + b"\n>b\n\xff\n"]),
+        (["taxa2agg", "-a", "lca*", world["tsv"]], ["taxa2agg", "-a", "lca*", world["tsv"]],
+         [(">a\r\n%d\r\n%d\r\n>b\r\n%d" % (ids[0], ids[1], ids[2])).encode(),
+          (">a\n%d\n>b\n%d\nxyz\n>c\n%d\n" % (ids[0], ids[1], ids[2])).encode(),     # parse error: b is dropped, a printed
+          (">a\n%d\n>b\n%d\n\xff\n>c\n%d\n" % (ids[0], ids[1], ids[2])).encode("latin1"),  # bad UTF-8: b printed, then error
+          (">a\n%d\n>b\n\n" % ids[0]).encode(), b">a\n+%d\n>b\n-1\n" % ids[3]]),
+        (["seedextend", "-s", "2"], ["seedextend", "-s", "2"],
+         [b">a\r\n5\r\n5\r\n0\r\n>b\n7\n7", b">a\n5\n5\n>b\n7\nq\n>c\n1\n1\n", b">a\n5\n5\n>b\n7\n\xff\n>c\n1\n1\n"]),
+        (["uniq", "-d", "/"], ["uniq", "-d", "/"],
+         [b">a/1\r\n5\r\n>a/2\r\n6\r\n>b/1\n7", b">a/1\n\n>a/2\n>b/1\n\n\n>c\n", b">a/1\n5\n>a/2\n\xff\n>b/1\n6\n", b">a\n>a\n>a\n"]),
+    ]
+    for mine, theirs, inputs in cases:
+        chunked = mine[0] in ("pept2lca", "prot2kmer2lca")
+        for cflag in ([[], ["-c", "1"], ["-c", "2"], ["-c", "3"]] if chunked else [[]]):
+            for data in inputs:
+                rc, out, err = _run_env(mine[:1] + cflag + mine[1:], data, **env)
+                orc, oout, oerr = O.run_cli(theirs[:1] + cflag + theirs[1:], data)
+                assert rc == orc, (mine, cflag, data, rc, orc, err, oerr)
+                assert out == oout, (mine, cflag, data, out, oout)
+
+
+def test_chunk_semantics_on_errors_long_stream(world):
+    """An error deep into a stream: everything of completed chunks is printed, nothing of the open one,
+    whatever the block size (src/io/fasta.rs:118-137)."""
+    k = world["kmers"]
+    good = "".join(">r%d\n%s\n%s\n" % (r, k[r % len(k)], k[(7 * r) % len(k)]) for r in range(1000)).encode()
+    bad = good + b">bad\n\xff\n>after\n" + k[0].encode() + b"\n"
+    for block in (256, 5000, 1 << 20):
+        for c in ("240", "7", "1000", "1001", "5000"):
+            rc, out, err = _run_env(["pept2lca", "-o", "-c", c, world["idx"]], bad, UMGAP_BLOCK_BYTES=block, UMGAP_THREADS=5)
+            orc, oout, _ = O.run_cli(["pept2lca", "-o", "-c", c, world["idx_tsv"]], bad)
+            assert rc == orc == 1 and out == oout, (block, c, len(out), len(oout))
+    prot = "".join(">p%d\n%s\n" % (r, k[r % len(k)] + k[(3 * r) % len(k)]) for r in range(700)).encode() + b">x\nAC\xc3\xa9DEFGHIKLMN\n>y\nAAAAAAAAAA\n"
+    for block in (300, 1 << 20):
+        for c in ("240", "1", "701"):
+            rc, out, err = _run_env(["prot2kmer2lca", "-o", "-c", c, world["idx"]], prot, UMGAP_BLOCK_BYTES=block, UMGAP_THREADS=3)
+            orc, oout, _ = O.run_cli(["prot2kmer2lca", "-o", "-c", c, world["idx_tsv"]], prot)
+            assert rc == orc == 101 and out == oout, (block, c, len(out), len(oout))

@@ -1,0 +1,148 @@
+// fastpath.hpp — block-parallel FASTA tokenizer for the `umgap` command (host side, no GPU).
+//
+// The reference reads stdin through a 10 MB BufReader and allocates a String per line
+// (src/io/fasta.rs:14,31,38-67); at GPU lookup rates that is the bottleneck (SURVEY.md §7 "Host
+// text I/O is the real ceiling").  Here stdin is read in large blocks cut at record boundaries
+// (a line that starts with '>'), each block is split into record-aligned ranges that worker threads
+// tokenize in place (no per-line allocation), one device call serves the whole block, and the
+// workers format their ranges' output, which is written in input order.
+//
+// Semantics kept from src/io/fasta.rs: lines end at '\n', one trailing '\r' is stripped, a last
+// line without '\n' counts, the first line of the stream must start with '>', every later line
+// that does not start with '>' is an item of the current record (empty lines included), invalid
+// UTF-8 ends the stream with an error AFTER the record that was being read has been emitted
+// truncated at the bad line (the Peekable stops at the Err, the next read_record returns it).
+#pragma once
+#include <algorithm>
+#include <functional>
+#include <thread>
+
+#include "text.hpp"
+
+namespace umgap_host {
+
+inline unsigned worker_count() {
+    const char* env = getenv("UMGAP_THREADS");
+    if (env && *env) {
+        int v = atoi(env);
+        if (v >= 1) return (unsigned)std::min(v, 64);
+    }
+    unsigned hw = std::thread::hardware_concurrency();
+    if (hw == 0) hw = 4;
+    return std::min(hw, 16u);
+}
+
+// Reads `f` in blocks that end right before a record start (or at EOF).
+class BlockReader {
+  public:
+    explicit BlockReader(FILE* f, size_t block = default_block()) : f_(f), buf_(block) {}
+    static size_t default_block() {
+        const char* env = getenv("UMGAP_BLOCK_BYTES");  // tests shrink it to exercise the block seams
+        if (env && *env) { long v = atol(env); if (v >= 16) return (size_t)v; }
+        return 64u << 20;
+    }
+    // Returns false when the stream is exhausted.  [data, data+len) holds whole records; the view
+    // stays valid until the next call.
+    bool next(const char*& data, size_t& len) {
+        if (carry_) { memmove(buf_.data(), buf_.data() + carry_off_, carry_); }
+        size_t have = carry_;
+        carry_ = 0;
+        for (;;) {
+            if (!eof_) {
+                size_t got = fread(buf_.data() + have, 1, buf_.size() - have, f_);
+                if (got == 0) {
+                    if (ferror(f_)) throw CliError(std::string(strerror(errno)));
+                    eof_ = true;
+                }
+                have += got;
+            }
+            if (have == 0) return false;
+            if (first_) {
+                // src/io/fasta.rs:44-49
+                if (buf_[0] != '>') { first_line_error_ = true; }
+                first_ = false;
+            }
+            if (eof_) { data = buf_.data(); len = have; return true; }
+            // last record start strictly inside the buffer
+            size_t cut = 0;
+            for (size_t p = have; p-- > 1;)
+                if (buf_[p] == '>' && buf_[p - 1] == '\n') { cut = p; break; }
+            if (cut > 0) {
+                carry_off_ = cut;
+                carry_ = have - cut;
+                data = buf_.data();
+                len = cut;
+                return true;
+            }
+            buf_.resize(buf_.size() * 2);  // one record larger than the block: keep reading
+        }
+    }
+    bool first_line_error() const { return first_line_error_; }
+
+  private:
+    FILE* f_;
+    std::vector<char> buf_;
+    size_t carry_ = 0, carry_off_ = 0;
+    bool eof_ = false, first_ = true, first_line_error_ = false;
+};
+
+// Record-aligned split of a block into at most `parts` ranges [begin[i], begin[i+1]).
+inline std::vector<size_t> split_records(const char* d, size_t len, unsigned parts) {
+    std::vector<size_t> b{0};
+    for (unsigned t = 1; t < parts; t++) {
+        size_t p = len * t / parts;
+        if (p <= b.back()) continue;
+        // advance to the next record start
+        const char* q = (const char*)memchr(d + p, '\n', len - p);
+        while (q && (size_t)(q - d) + 1 < len && q[1] != '>') q = (const char*)memchr(q + 1, '\n', len - (size_t)(q + 1 - d));
+        if (!q || (size_t)(q - d) + 1 >= len) break;
+        size_t s = (size_t)(q - d) + 1;
+        if (s > b.back()) b.push_back(s);
+    }
+    b.push_back(len);
+    return b;
+}
+
+// Calls fn(part) for part = 0..n-1 on worker threads (part 0 on the caller).
+inline void parallel_for(size_t n, const std::function<void(size_t)>& fn) {
+    if (n == 0) return;
+    std::vector<std::thread> th;
+    std::vector<std::exception_ptr> err(n);
+    for (size_t i = 1; i < n; i++)
+        th.emplace_back([&, i]() { try { fn(i); } catch (...) { err[i] = std::current_exception(); } });
+    try { fn(0); } catch (...) { err[0] = std::current_exception(); }
+    for (auto& t : th) t.join();
+    for (auto& e : err)
+        if (e) std::rethrow_exception(e);
+}
+
+// Line iterator over a range of whole records.  `line` excludes '\n' and one trailing '\r'.
+struct LineCursor {
+    const char* p;
+    const char* end;
+    bool next(std::string_view& line) {
+        if (p >= end) return false;
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+        const char* e = nl ? nl : end;
+        const char* le = e;
+        if (le > p && le[-1] == '\r') le--;
+        line = std::string_view(p, (size_t)(le - p));
+        p = nl ? nl + 1 : end;
+        return true;
+    }
+};
+
+inline bool line_utf8_ok(std::string_view l) {
+    for (unsigned char c : l)
+        if (c >= 0x80) return valid_utf8(l);
+    return true;
+}
+
+inline void append_uint(std::string& s, uint64_t v) {
+    char tmp[24];
+    int n = 0;
+    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+    while (n) s.push_back(tmp[--n]);
+}
+
+}  // namespace umgap_host

@@ -16,6 +16,7 @@
 #include <map>
 
 #include "../../../include/umgap_hip.h"
+#include "fastpath.hpp"
 #include "text.hpp"
 
 using namespace umgap_host;
@@ -166,78 +167,162 @@ void lookup_strings(umgap_index* ix, const StringBatch& b, std::vector<uint32_t>
     for (size_t k = 0; k < keys.size(); k++) out[where[k]] = t[k];
 }
 
-// ---- pept2lca / prot2kmer2lca ---------------------------------------------------------------
-// One batch = many records: pack every peptide, ONE device lookup, then format in input order.
-void stream_lookup(FILE* in, FILE* outf, umgap_index* ix, bool one_on_one, bool kmer_mode, size_t k) {
-    // peptides other than [A-Z]{9} cannot be in a 9-mer table: they miss without touching the device
-    FastaReader reader(in, kmer_mode);
-    Out out(outf);
-    const size_t BATCH_KEYS = 8u << 20;
-    std::vector<Record> recs;
+// ---- pept2lca / prot2kmer2lca on the packed 9-mer table -------------------------------------
+// Block-parallel (fastpath.hpp): workers tokenize record-aligned ranges of a block and pack the
+// 9-mers, ONE device lookup serves the block, workers format their ranges, output in input order.
+// Peptides / windows that are not [A-Z]{9} cannot be in the table: they miss without a device call.
+struct LookupPart {
+    std::vector<size_t> hdr_off;
+    std::vector<uint32_t> hdr_len, n_items;  // per record; n_items = items (pept2lca) or windows (prot2kmer2lca)
+    std::vector<uint8_t> emit;               // per record: printed at all? (prot2kmer2lca drops reads shorter than k)
+    std::vector<uint64_t> keys;              // packed keys of the `known` items, in order
+    std::vector<uint8_t> known;              // per item / window
+    size_t key_base = 0;
+    bool bad_utf8 = false, panic = false;    // the range stops at the record where this happened
+    std::string out;
+};
+
+void parse_lookup_part(const char* d, size_t begin, size_t end, bool kmer_mode, size_t k, LookupPart& P) {
+    LineCursor lc{d + begin, d + end};
+    std::string_view line;
+    std::string scratch;
+    bool have_rec = false;
+    // prot2kmer2lca: the record's sequence is the concatenation of its lines (unwrap, src/io/fasta.rs:62-64)
+    std::string_view seq1;
+    size_t n_lines = 0;
+    auto finish_kmer_record = [&]() {
+        if (!have_rec) return;
+        std::string_view seq = n_lines <= 1 ? seq1 : std::string_view(scratch);
+        if (seq.size() < k) { P.emit.back() = 0; return; }   // src/commands/prot2kmer2lca.rs:172
+        uint32_t windows = (uint32_t)(seq.size() - k + 1);
+        P.n_items.back() = windows;
+        bool ascii = true;
+        for (unsigned char c : seq) if (c >= 0x80) { ascii = false; break; }
+        if (!ascii) {
+            for (size_t i = 0; i + k <= seq.size(); i++)
+                if (((unsigned char)seq[i] & 0xC0) == 0x80 || (i + k < seq.size() && ((unsigned char)seq[i + k] & 0xC0) == 0x80)) { P.panic = true; P.emit.back() = 0; P.n_items.back() = 0; return; }
+        }
+        uint64_t key = 0;
+        uint32_t run = 0;
+        for (size_t i = 0; i < seq.size(); i++) {
+            unsigned c = (unsigned char)seq[i] - 'A';
+            if (c < 26) { key = ((key << 5) | c) & ((1ull << 45) - 1); run++; } else run = 0;
+            if (i + 1 >= k) {
+                bool ok = k == 9 && run >= 9;
+                P.known.push_back(ok);
+                if (ok) P.keys.push_back(key);
+            }
+        }
+    };
+    while (lc.next(line)) {
+        bool utf8 = line_utf8_ok(line);
+        if (!line.empty() && line[0] == '>' && utf8) {
+            if (kmer_mode) { finish_kmer_record(); if (P.panic) return; }
+            P.hdr_off.push_back((size_t)(line.data() - d) + 1);
+            P.hdr_len.push_back((uint32_t)line.size() - 1);
+            P.n_items.push_back(0);
+            P.emit.push_back(1);
+            have_rec = true;
+            n_lines = 0;
+            scratch.clear();
+            continue;
+        }
+        if (!utf8) {  // the record read so far is emitted, then the stream errors out
+            P.bad_utf8 = true;
+            break;
+        }
+        if (kmer_mode) {
+            if (n_lines == 0) seq1 = line;
+            else { if (n_lines == 1) scratch.assign(seq1); scratch.append(line); }
+            n_lines++;
+        } else {
+            uint64_t key;
+            bool ok = line.size() == 9 && umgap_pack9(line.data(), &key);
+            P.known.push_back(ok);
+            if (ok) P.keys.push_back(key);
+            P.n_items.back()++;
+        }
+    }
+    if (kmer_mode) finish_kmer_record();
+}
+
+// formats records [rb, re) of the part into `out`
+void format_lookup_part(const char* d, const uint32_t* taxa, bool one_on_one, const LookupPart& P, size_t rb, size_t re, std::string& out) {
+    size_t ki = 0, wi = 0;
+    for (size_t r = 0; r < rb; r++)
+        for (uint32_t i = 0; i < P.n_items[r] && wi < P.known.size(); i++, wi++) ki += P.known[wi];
+    for (size_t r = rb; r < re; r++) {
+        if (P.emit[r]) { out.push_back('>'); out.append(d + P.hdr_off[r], P.hdr_len[r]); out.push_back('\n'); }
+        for (uint32_t i = 0; i < P.n_items[r] && wi < P.known.size(); i++, wi++) {
+            uint32_t t = P.known[wi] ? taxa[P.key_base + ki++] : 0u;
+            if (P.emit[r] && (t != 0 || one_on_one)) { append_uint(out, t); out.push_back('\n'); }  // src/commands/pept2lca.rs:93-95
+        }
+    }
+}
+
+// Output follows the reference's chunking (src/io/fasta.rs:118-137, src/commands/pept2lca.rs:83-101): records
+// are printed per chunk of `chunk` records, and a read error or a panic prints nothing of the chunk it falls
+// in.  The partial chunk at the end of a block is therefore held back until the next block confirms it.
+void stream_lookup(FILE* in, FILE* outf, umgap_index* ix, bool one_on_one, bool kmer_mode, size_t k, size_t chunk) {
+    if (chunk == 0) chunk = 1;
+    BlockReader blocks(in);
+    const unsigned T = worker_count();
+    const char* d;
+    size_t len;
     std::vector<uint64_t> keys;
     std::vector<uint32_t> taxa;
-    std::vector<uint8_t> known;  // per item/window: 1 = looked up on the device
-    auto run = [&]() {
-        taxa.resize(keys.size());
-        if (!keys.empty()) LIB(umgap_index_lookup9(ix, keys.data(), keys.size(), 0u, taxa.data()));
-        size_t ki = 0, wi = 0;
-        for (auto& r : recs) {
-            if (kmer_mode) {
-                // src/commands/prot2kmer2lca.rs:172: reads shorter than k vanish, header included
-                const std::string& prot = r.sequence[0];
-                if (prot.size() < k) continue;
-                out.buf.push_back('>'); out.buf.append(r.header); out.buf.push_back('\n');
-                for (size_t i = 0; i + k <= prot.size(); i++, wi++) {
-                    uint32_t t = known[wi] ? taxa[ki++] : 0u;
-                    if (t != 0 || one_on_one) { append_u64(out.buf, t); out.buf.push_back('\n'); }
-                }
-            } else {
-                out.buf.push_back('>'); out.buf.append(r.header); out.buf.push_back('\n');  // src/commands/pept2lca.rs:91
-                for (size_t i = 0; i < r.sequence.size(); i++, wi++) {
-                    uint32_t t = known[wi] ? taxa[ki++] : 0u;
-                    if (t != 0 || one_on_one) { append_u64(out.buf, t); out.buf.push_back('\n'); }  // :93-95
-                }
-            }
-            out.maybe_flush();
+    std::string held;          // formatted records [held_from, g0): the still open chunk
+    size_t g0 = 0;             // global index of the block's first record
+    while (blocks.next(d, len)) {
+        if (blocks.first_line_error()) throw CliError("Expected > at beginning of fasta header.");
+        std::vector<size_t> cuts = split_records(d, len, T);
+        const size_t np = cuts.size() - 1;
+        std::vector<LookupPart> parts(np);
+        parallel_for(np, [&](size_t i) { parse_lookup_part(d, cuts[i], cuts[i + 1], kmer_mode, k, parts[i]); });
+        // a failing range ends the stream: later ranges are dropped
+        size_t used = np;
+        for (size_t i = 0; i < np; i++)
+            if (parts[i].bad_utf8 || parts[i].panic) { used = i + 1; break; }
+        const bool failed = parts[used - 1].bad_utf8 || parts[used - 1].panic;
+        size_t total = 0, n_rec = 0;
+        std::vector<size_t> rec_base(used + 1, 0);
+        for (size_t i = 0; i < used; i++) { parts[i].key_base = total; total += parts[i].keys.size(); rec_base[i] = n_rec; n_rec += parts[i].hdr_off.size(); }
+        rec_base[used] = n_rec;
+        // records of this block to print now: global indices [g0, limit)
+        size_t limit;
+        if (failed) {
+            // bad UTF-8: the error surfaces when the NEXT record is read, after n_rec good ones; panic: inside the last record
+            size_t e = parts[used - 1].panic ? g0 + n_rec - 1 : g0 + n_rec;
+            limit = e / chunk * chunk;
+        } else {
+            limit = (g0 + n_rec) / chunk * chunk;   // the open chunk at the end is held back (released at EOF below)
         }
-        recs.clear(); keys.clear(); known.clear();
-    };
-    Record rec;
-    try {
-        while (reader.read_record(rec)) {
-            if (kmer_mode) {
-                const std::string& prot = rec.sequence[0];
-                if (prot.size() >= k) {
-                    for (size_t i = 0; i + k <= prot.size(); i++) {
-                        // `&prot[i..i+k]` panics when it cuts a UTF-8 character (src/commands/prot2kmer2lca.rs:176)
-                        if (((unsigned char)prot[i] & 0xC0) == 0x80 || (i + k < prot.size() && ((unsigned char)prot[i + k] & 0xC0) == 0x80)) {
-                            run(); out.flush();
-                            throw CliPanic("byte index is not a char boundary");
-                        }
-                        uint64_t key;
-                        bool ok = k == 9 && umgap_pack9(prot.data() + i, &key);
-                        known.push_back(ok);
-                        if (ok) keys.push_back(key);
-                    }
-                }
-            } else {
-                for (auto& s : rec.sequence) {
-                    uint64_t key;
-                    bool ok = s.size() == 9 && umgap_pack9(s.data(), &key);
-                    known.push_back(ok);
-                    if (ok) keys.push_back(key);
-                }
-            }
-            recs.push_back(std::move(rec));
-            rec = Record();
-            if (keys.size() >= BATCH_KEYS || recs.size() >= (1u << 20)) run();
+        keys.resize(total);
+        parallel_for(used, [&](size_t i) { if (!parts[i].keys.empty()) memcpy(keys.data() + parts[i].key_base, parts[i].keys.data(), parts[i].keys.size() * 8); });
+        taxa.resize(total);
+        if (total) LIB(umgap_index_lookup9(ix, keys.data(), total, 0u, taxa.data()));
+        // per part: records below `limit` go to P.out, the rest to the tail (held back)
+        std::vector<std::string> tails(used);
+        parallel_for(used, [&](size_t i) {
+            size_t nr = parts[i].hdr_off.size(), lo = g0 + rec_base[i];
+            size_t cut = limit <= lo ? 0 : std::min(nr, limit - lo);
+            parts[i].out.reserve(nr * 24 + parts[i].known.size() * 8);
+            format_lookup_part(d, taxa.data(), one_on_one, parts[i], 0, cut, parts[i].out);
+            if (cut < nr && !failed) format_lookup_part(d, taxa.data(), one_on_one, parts[i], cut, nr, tails[i]);
+        });
+        const size_t held_from = g0 / chunk * chunk;
+        if (!held.empty() && limit > held_from) { fwrite(held.data(), 1, held.size(), outf); held.clear(); }
+        for (size_t i = 0; i < used; i++) fwrite(parts[i].out.data(), 1, parts[i].out.size(), outf);
+        if (failed) {
+            fflush(outf);
+            if (parts[used - 1].panic) throw CliPanic("byte index is not a char boundary");
+            throw CliError("stream did not contain valid UTF-8");
         }
-    } catch (CliError&) {
-        run(); out.flush();  // records before the failing one are still printed
-        throw;
+        for (size_t i = 0; i < used; i++) held.append(tails[i]);
+        g0 += n_rec;
     }
-    run();
-    out.flush();
+    fwrite(held.data(), 1, held.size(), outf);   // EOF closes the last chunk
+    fflush(outf);
 }
 
 umgap_index* open_index(const std::string& path) {
@@ -249,17 +334,19 @@ umgap_index* open_index(const std::string& path) {
 
 // record loop shared by pept2lca (variable-length index) and prot2tryp2lca: `expand` turns one
 // sequence line into the peptides to look up
-void stream_strings(FILE* in, FILE* outf, umgap_index* ix, bool one_on_one,
+void stream_strings(FILE* in, FILE* outf, umgap_index* ix, bool one_on_one, size_t chunk,
                     const std::function<void(const std::string&, StringBatch&)>& expand) {
+    if (chunk == 0) chunk = 1;
     FastaReader reader(in, false);
     Out out(outf);
     std::vector<std::string> headers;
     std::vector<size_t> first;  // index of the record's first peptide in the batch
     StringBatch batch;
     std::vector<uint32_t> taxa;
-    auto run = [&]() {
+    // `keep` = number of leading records of the batch to print (batches start on chunk boundaries)
+    auto run = [&](size_t keep) {
         lookup_strings(ix, batch, taxa);
-        for (size_t r = 0; r < headers.size(); r++) {
+        for (size_t r = 0; r < headers.size() && r < keep; r++) {
             out.buf.push_back('>'); out.buf.append(headers[r]); out.buf.push_back('\n');
             size_t end = r + 1 < headers.size() ? first[r + 1] : batch.size();
             for (size_t i = first[r]; i < end; i++)
@@ -274,20 +361,25 @@ void stream_strings(FILE* in, FILE* outf, umgap_index* ix, bool one_on_one,
             first.push_back(batch.size());
             headers.push_back(std::move(rec.header));
             for (auto& s : rec.sequence) expand(s, batch);
-            if (batch.bytes.size() >= (64u << 20) || headers.size() >= (1u << 20)) run();
+            // flush on chunk boundaries only, so that an error can still drop the whole open chunk
+            if ((batch.bytes.size() >= (64u << 20) || headers.size() >= (1u << 20)) && headers.size() % chunk == 0) run(headers.size());
         }
-    } catch (CliError&) { run(); out.flush(); throw; }
-    run();
+    } catch (CliError&) {
+        run(headers.size() / chunk * chunk);   // ChunkedRecords drops the chunk the error falls in (src/io/fasta.rs:125-131)
+        out.flush();
+        throw;
+    }
+    run(headers.size());
     out.flush();
 }
 
 int cmd_pept2lca(const std::vector<std::string>& args) {
     Parsed p = parse_args(args, {{'o', "one-on-one", false}, {'m', "in-memory", false}, {'c', "chunksize", true}});
-    (void)opt_usize(p, "chunksize", 240);  // chunks only group output in the reference; accepted and validated
+    size_t chunk = (size_t)opt_usize(p, "chunksize", 240);  // decides what is printed before an error (see stream_lookup)
     std::string path = need_positional(p, "fst-file");
     umgap_index* ix = open_index(path);  // -m: the table is always resident (in HBM)
-    if (umgap_index_kind(ix) == 2) stream_strings(stdin, stdout, ix, p.has("one-on-one"), [](const std::string& s, StringBatch& b) { b.add(s); });
-    else stream_lookup(stdin, stdout, ix, p.has("one-on-one"), false, 9);
+    if (umgap_index_kind(ix) == 2) stream_strings(stdin, stdout, ix, p.has("one-on-one"), chunk, [](const std::string& s, StringBatch& b) { b.add(s); });
+    else stream_lookup(stdin, stdout, ix, p.has("one-on-one"), false, 9, chunk);
     umgap_index_free(ix);
     return 0;
 }
@@ -297,7 +389,7 @@ int cmd_pept2lca(const std::vector<std::string>& args) {
 int cmd_prot2tryp2lca(const std::vector<std::string>& args) {
     Parsed p = parse_args(args, {{'o', "one-on-one", false}, {'m', "in-memory", false}, {'c', "chunksize", true}, {'p', "pattern", true},
                                  {'l', "minlen", true}, {'L', "maxlen", true}, {'k', "keep", true}, {'d', "drop", true}});
-    (void)opt_usize(p, "chunksize", 240);
+    size_t chunk = (size_t)opt_usize(p, "chunksize", 240);
     size_t minlen = (size_t)opt_usize(p, "minlen", 5), maxlen = (size_t)opt_usize(p, "maxlen", 50);
     std::string keep = p.get("keep").value_or(""), drop = p.get("drop").value_or("");
     if (p.get("pattern").value_or("([KR])([^P])") != "([KR])([^P])")
@@ -323,7 +415,7 @@ int cmd_prot2tryp2lca(const std::vector<std::string>& args) {
         }
         emit(st, seq.size());
     };
-    stream_strings(stdin, stdout, ix, p.has("one-on-one"), expand);
+    stream_strings(stdin, stdout, ix, p.has("one-on-one"), chunk, expand);
     umgap_index_free(ix);
     return 0;
 }
@@ -331,7 +423,7 @@ int cmd_prot2tryp2lca(const std::vector<std::string>& args) {
 int cmd_prot2kmer2lca(const std::vector<std::string>& args) {
     Parsed p = parse_args(args, {{'k', "length", true}, {'o', "one-on-one", false}, {'s', "socket", true}, {'m', "in-memory", false}, {'c', "chunksize", true}});
     size_t k = (size_t)opt_usize(p, "length", 9);
-    (void)opt_usize(p, "chunksize", 240);
+    size_t chunk = (size_t)opt_usize(p, "chunksize", 240);
     std::string path = need_positional(p, "fst-file");
     umgap_index* ix = open_index(path);
     if (umgap_index_kind(ix) != 9) throw CliError("prot2kmer2lca needs a 9-mer index");
@@ -353,7 +445,7 @@ int cmd_prot2kmer2lca(const std::vector<std::string>& args) {
             FILE* in = fdopen(c, "rb");
             FILE* outf = fdopen(dup(c), "wb");
             try {
-                stream_lookup(in, outf, ix, o, true, k);
+                stream_lookup(in, outf, ix, o, true, k, chunk);
                 printf("Connection finished succesfully.\n");
             } catch (CliError& e) { printf("Connection died with an error: %s\n", e.what()); }
             fflush(stdout);
@@ -361,7 +453,7 @@ int cmd_prot2kmer2lca(const std::vector<std::string>& args) {
             fclose(in);
         }
     }
-    stream_lookup(stdin, stdout, ix, o, true, k);
+    stream_lookup(stdin, stdout, ix, o, true, k, chunk);
     umgap_index_free(ix);
     return 0;
 }
@@ -399,66 +491,119 @@ int cmd_taxa2agg(const std::vector<std::string>& args) {
     if (method == UMGAP_METHOD_TREE && strategy == UMGAP_STRATEGY_MRTL)
         throw CliError("Invalid invocation: Tree and MaximumRootToLeafPath cannot be combined");  // :134-138
 
-    FastaReader reader(stdin, false);
-    Out out(stdout);
-    std::vector<std::string> headers;
+    // block-parallel record loop (fastpath.hpp): parse -> ONE umgap_aggregate per block -> format
+    struct AggPart {
+        std::vector<size_t> hdr_off;
+        std::vector<uint32_t> hdr_len;
+        std::vector<uint64_t> offsets{0};
+        std::vector<uint32_t> taxa;
+        std::vector<float> scores;
+        std::vector<uint64_t> big;         // ids that do not fit 32 bits, for the message
+        std::optional<CliError> error;     // stops the stream after the records parsed so far
+        size_t rec_base = 0;
+        std::string out;
+    };
+    BlockReader blocks(stdin);
+    const unsigned T = worker_count();
+    const char* d;
+    size_t len;
     std::vector<uint32_t> taxa, out_taxon, out_status;
-    std::vector<uint64_t> big;  // original values of ids that do not fit 32 bits (for the message)
     std::vector<float> scores;
-    std::vector<uint64_t> offsets{0};
-    std::optional<CliError> pending_error;
-    auto run = [&]() {
-        size_t n = headers.size();
-        out_taxon.resize(n); out_status.resize(n);
-        if (n) LIB(umgap_aggregate(tx, method, strategy, factor, lower_bound, ranked ? 1 : 0, taxa.data(), scored ? scores.data() : nullptr,
-                                   offsets.data(), n, out_taxon.data(), out_status.data()));
-        for (size_t r = 0; r < n; r++) {
-            if (out_status[r] == UMGAP_READ_UNKNOWN_TAXON) {
-                out.flush();
-                uint64_t t = out_taxon[r];
-                if (t == 0xFFFFFFFEu && !big.empty()) t = big[0];
+    std::vector<uint64_t> offsets;
+    while (blocks.next(d, len)) {
+        if (blocks.first_line_error()) throw CliError("Expected > at beginning of fasta header.");
+        std::vector<size_t> cuts = split_records(d, len, T);
+        const size_t np = cuts.size() - 1;
+        std::vector<AggPart> parts(np);
+        parallel_for(np, [&](size_t pi) {
+            AggPart& P = parts[pi];
+            LineCursor lc{d + cuts[pi], d + cuts[pi + 1]};
+            std::string_view line;
+            bool open = false;  // a record is being read
+            auto close = [&]() { if (open) { P.offsets.push_back(P.taxa.size()); open = false; } };
+            try {
+                while (lc.next(line)) {
+                    if (!line_utf8_ok(line)) {  // the record read so far still counts, then the stream errors
+                        close();
+                        P.error = CliError("stream did not contain valid UTF-8");
+                        return;
+                    }
+                    if (!line.empty() && line[0] == '>') {
+                        close();
+                        P.hdr_off.push_back((size_t)(line.data() - d) + 1);
+                        P.hdr_len.push_back((uint32_t)line.size() - 1);
+                        open = true;
+                        continue;
+                    }
+                    uint64_t t;
+                    if (scored) {  // with_score, src/commands/taxa2agg.rs:142-148
+                        size_t eq = line.find('=');
+                        if (eq == std::string_view::npos || line.find('=', eq + 1) != std::string_view::npos) throw CliError("Taxon without score");
+                        t = parse_usize(line.substr(0, eq));
+                        P.scores.push_back(parse_f32(line.substr(eq + 1)));
+                    } else {
+                        t = parse_usize(line);
+                    }
+                    if (t >= 0xFFFFFFFEull) { P.big.push_back(t); t = 0xFFFFFFFEull; }
+                    P.taxa.push_back((uint32_t)t);
+                }
+                close();
+            } catch (CliError& e) {
+                // the failing record is dropped; everything before it is still aggregated and printed
+                P.error = e;
+                P.hdr_off.pop_back();
+                P.hdr_len.pop_back();
+                P.taxa.resize(P.offsets.back());
+                if (scored) P.scores.resize(P.offsets.back());
+            }
+        });
+        size_t used = np;
+        for (size_t i = 0; i < np; i++)
+            if (parts[i].error) { used = i + 1; break; }
+        size_t n_rec = 0, n_tax = 0;
+        for (size_t i = 0; i < used; i++) { parts[i].rec_base = n_rec; n_rec += parts[i].hdr_off.size(); n_tax += parts[i].taxa.size(); }
+        taxa.clear(); scores.clear(); offsets.assign(1, 0);
+        taxa.reserve(n_tax); offsets.reserve(n_rec + 1);
+        for (size_t i = 0; i < used; i++) {
+            size_t base = taxa.size();
+            taxa.insert(taxa.end(), parts[i].taxa.begin(), parts[i].taxa.end());
+            if (scored) scores.insert(scores.end(), parts[i].scores.begin(), parts[i].scores.end());
+            for (size_t r = 1; r < parts[i].offsets.size(); r++) offsets.push_back(base + parts[i].offsets[r]);
+        }
+        out_taxon.resize(n_rec); out_status.resize(n_rec);
+        if (n_rec) LIB(umgap_aggregate(tx, method, strategy, factor, lower_bound, ranked ? 1 : 0, taxa.data(), scored ? scores.data() : nullptr,
+                                       offsets.data(), n_rec, out_taxon.data(), out_status.data()));
+        // the first failing record (if any) ends the output
+        size_t bad = n_rec;
+        for (size_t r = 0; r < n_rec; r++)
+            if (out_status[r] == UMGAP_READ_UNKNOWN_TAXON || out_status[r] == UMGAP_READ_PANIC || out_status[r] == 4u) { bad = r; break; }
+        parallel_for(used, [&](size_t pi) {
+            AggPart& P = parts[pi];
+            P.out.reserve(P.hdr_off.size() * 32);
+            for (size_t r = 0; r < P.hdr_off.size() && P.rec_base + r < bad; r++) {
+                P.out.push_back('>');
+                P.out.append(d + P.hdr_off[r], P.hdr_len[r]);
+                P.out.push_back('\n');
+                append_uint(P.out, out_taxon[P.rec_base + r]);
+                P.out.push_back('\n');
+            }
+        });
+        for (size_t i = 0; i < used; i++) fwrite(parts[i].out.data(), 1, parts[i].out.size(), stdout);
+        if (bad < n_rec) {
+            fflush(stdout);
+            if (out_status[bad] == UMGAP_READ_UNKNOWN_TAXON) {
+                uint64_t t = out_taxon[bad];
+                if (t == 0xFFFFFFFEu)
+                    for (size_t i = 0; i < used; i++) if (!parts[i].big.empty()) { t = parts[i].big[0]; break; }
                 throw CliError("Unknown Taxon ID: " + std::to_string(t));
             }
-            if (out_status[r] == UMGAP_READ_PANIC) { out.flush(); throw CliPanic("index out of bounds"); }
-            out.buf.push_back('>'); out.buf.append(headers[r]); out.buf.push_back('\n');
-            append_u64(out.buf, out_taxon[r]);
-            out.buf.push_back('\n');
-            out.maybe_flush();
+            if (out_status[bad] == 4u) throw CliError("a read holds more than 1024 distinct taxa: not supported by the device aggregator");
+            throw CliPanic("index out of bounds");
         }
-        headers.clear(); taxa.clear(); scores.clear(); big.clear(); offsets.assign(1, 0);
-    };
-    Record rec;
-    try {
-        while (reader.read_record(rec)) {
-            for (auto& s : rec.sequence) {
-                uint64_t t;
-                float sc = 1.0f;
-                if (scored) {  // with_score, src/commands/taxa2agg.rs:142-148
-                    size_t eq = s.find('=');
-                    if (eq == std::string::npos || s.find('=', eq + 1) != std::string::npos) throw CliError("Taxon without score");
-                    t = parse_usize(std::string_view(s).substr(0, eq));
-                    sc = parse_f32(std::string_view(s).substr(eq + 1));
-                    scores.push_back(sc);
-                } else {
-                    t = parse_usize(s);
-                }
-                if (t >= 0xFFFFFFFEull) { big.push_back(t); t = 0xFFFFFFFEull; }
-                taxa.push_back((uint32_t)t);
-            }
-            offsets.push_back(taxa.size());
-            headers.push_back(std::move(rec.header));
-            if (taxa.size() >= (16u << 20) || headers.size() >= (1u << 20)) run();
-        }
-    } catch (CliError& e) {
-        pending_error = e;
-        // the failing record is dropped; everything before it is still aggregated and printed
-        taxa.resize(offsets.back());
-        if (scored) scores.resize(offsets.back());
+        if (used < np || parts[used - 1].error) { fflush(stdout); throw *parts[used - 1].error; }
     }
-    run();
-    out.flush();
+    fflush(stdout);
     umgap_taxonomy_free(tx);
-    if (pending_error) throw *pending_error;
     return 0;
 }
 
@@ -469,46 +614,71 @@ int cmd_seedextend(const std::vector<std::string>& args) {
     (void)opt_usize(p, "penalty", 5);
     if (p.has("ranked")) throw CliError("seedextend --ranked is outside the accelerated path (scripts/umgap-analyse.sh never uses it)");
     if (!p.positional.empty()) usage_error("Found argument '" + p.positional[0] + "' which wasn't expected, or isn't valid in this context");
-    // host restatement of the record state machine for the text filter; the device kernel
-    // (umgap_seedextend_dev) serves the fused pipeline.  src/commands/seedextend.rs:99-148
-    FastaReader reader(stdin, false);
-    Out out(stdout);
-    Record rec;
-    std::vector<uint64_t> t;
-    std::vector<std::string> items;
-    try {
-        while (reader.read_record(rec)) {
-            t.clear();
-            for (auto& x : rec.sequence) t.push_back(parse_usize(x));
-            t.push_back(0);
-            std::vector<std::pair<size_t, size_t>> seeds;
-            size_t start = 0, end = 1, same_tid = 1, same_max = 1;
-            uint64_t last = t[0];
-            while (end < t.size()) {
-                if (last == t[end]) { same_tid++; end++; continue; }
-                if (last == 0 && same_tid > g) {
-                    if (same_max >= s) seeds.emplace_back(start, end - same_tid);
-                    start = end; last = t[end]; same_tid = 1; same_max = 1; end++;
-                    continue;
+    // host restatement of the record state machine for the text filter (the device kernels
+    // umgap_seedextend_dev / umgap_classify9_dev serve the fused pipeline), block-parallel over
+    // records.  src/commands/seedextend.rs:99-148
+    struct SePart { std::string out; std::optional<CliError> error; bool panic = false; };
+    BlockReader blocks(stdin);
+    const unsigned T = worker_count();
+    const char* d;
+    size_t len;
+    while (blocks.next(d, len)) {
+        if (blocks.first_line_error()) throw CliError("Expected > at beginning of fasta header.");
+        std::vector<size_t> cuts = split_records(d, len, T);
+        const size_t np = cuts.size() - 1;
+        std::vector<SePart> parts(np);
+        parallel_for(np, [&](size_t pi) {
+            SePart& P = parts[pi];
+            P.out.reserve((cuts[pi + 1] - cuts[pi]) / 2 + 64);
+            LineCursor lc{d + cuts[pi], d + cuts[pi + 1]};
+            std::string_view line, header;
+            std::vector<uint64_t> t;
+            bool open = false;
+            auto flush_record = [&]() {
+                if (!open) return;
+                open = false;
+                t.push_back(0);                                                   // :99
+                size_t start = 0, end = 1, same_tid = 1, same_max = 1;
+                uint64_t last = t[0];
+                const size_t mark = P.out.size();
+                P.out.push_back('>'); P.out.append(header); P.out.push_back('\n');
+                auto emit = [&](size_t a0, size_t e0) {
+                    if (a0 > e0 || e0 > t.size()) { P.panic = true; P.out.resize(mark); return; }
+                    for (size_t j = a0; j < e0; j++) { append_uint(P.out, t[j]); P.out.push_back('\n'); }
+                };
+                while (end < t.size()) {
+                    if (last == t[end]) { same_tid++; end++; continue; }
+                    if (last == 0 && same_tid > g) {
+                        if (same_max >= s) emit(start, end - same_tid);
+                        start = end; last = t[end]; same_tid = 1; same_max = 1; end++;
+                        continue;
+                    }
+                    if (last == 0 && (end - start) == same_tid) { end++; start = end; continue; }
+                    if (last != 0) same_max = std::max(same_max, same_tid);
+                    last = t[end]; same_tid = 1; end++;
                 }
-                if (last == 0 && (end - start) == same_tid) { end++; start = end; continue; }
-                if (last != 0) same_max = std::max(same_max, same_tid);
-                last = t[end]; same_tid = 1; end++;
-            }
-            if (same_max >= s) {
-                if (last == 0) end -= same_tid;
-                seeds.emplace_back(start, end);
-            }
-            items.clear();
-            for (auto& se : seeds) {
-                if (se.first > se.second || se.second > t.size()) { out.flush(); throw CliPanic("slice index out of range"); }
-                for (size_t j = se.first; j < se.second; j++) items.push_back(std::to_string(t[j]));
-            }
-            write_record(out.buf, rec.header, items, "\n", false);
-            out.maybe_flush();
+                if (same_max >= s) {
+                    if (last == 0) end -= same_tid;
+                    emit(start, end);
+                }
+                t.clear();
+            };
+            try {
+                while (lc.next(line) && !P.panic) {
+                    if (!line_utf8_ok(line)) { flush_record(); P.error = CliError("stream did not contain valid UTF-8"); return; }
+                    if (!line.empty() && line[0] == '>') { flush_record(); header = line.substr(1); open = true; continue; }
+                    t.push_back(parse_usize(line));
+                }
+                flush_record();
+            } catch (CliError& e) { P.error = e; }   // the failing record is not printed
+        });
+        for (size_t i = 0; i < np; i++) {
+            fwrite(parts[i].out.data(), 1, parts[i].out.size(), stdout);
+            if (parts[i].panic) { fflush(stdout); throw CliPanic("slice index out of range"); }
+            if (parts[i].error) { fflush(stdout); throw *parts[i].error; }
         }
-    } catch (CliError&) { out.flush(); throw; }
-    out.flush();
+    }
+    fflush(stdout);
     return 0;
 }
 
@@ -519,6 +689,79 @@ int cmd_uniq(const std::vector<std::string>& args) {
     bool wrap = p.has("wrap");
     auto delim = p.get("delimiter");
     if (!p.positional.empty()) usage_error("Found argument '" + p.positional[0] + "' which wasn't expected, or isn't valid in this context");
+    if (sep == "\n" && !wrap) {
+        // block-parallel tokenization into record descriptors; the merge of consecutive equal headers is a
+        // serial pass over descriptors; a record body is copied verbatim (items are already "item\n")
+        struct Rec { size_t hdr_off; uint32_t hdr_len; size_t body_off, body_len; uint32_t n_items; bool verbatim; };
+        struct UPart { std::vector<Rec> recs; bool bad_utf8 = false; };
+        BlockReader blocks(stdin);
+        const unsigned T = worker_count();
+        const char* d;
+        size_t len;
+        std::string out, cur_hdr;          // the record being merged (survives block boundaries)
+        std::string cur_body;
+        uint64_t cur_items = 0;
+        bool have_cur = false;
+        auto write_cur = [&]() {
+            if (!have_cur) return;
+            out.push_back('>'); out.append(cur_hdr); out.push_back('\n');
+            // items.join("\n") is empty iff there is no item or a single empty one (src/io/fasta.rs:168,176-178)
+            if (!(cur_items == 0 || (cur_items == 1 && cur_body.size() == 1))) out.append(cur_body);
+            have_cur = false;
+        };
+        while (blocks.next(d, len)) {
+            if (blocks.first_line_error()) throw CliError("Expected > at beginning of fasta header.");
+            std::vector<size_t> cuts = split_records(d, len, T);
+            const size_t np = cuts.size() - 1;
+            std::vector<UPart> parts(np);
+            parallel_for(np, [&](size_t pi) {
+                UPart& P = parts[pi];
+                LineCursor lc{d + cuts[pi], d + cuts[pi + 1]};
+                std::string_view line;
+                while (lc.next(line)) {
+                    if (!line_utf8_ok(line)) { P.bad_utf8 = true; return; }
+                    if (!line.empty() && line[0] == '>') {
+                        P.recs.push_back(Rec{(size_t)(line.data() - d) + 1, (uint32_t)line.size() - 1, (size_t)(lc.p - d), 0, 0, true});
+                        continue;
+                    }
+                    Rec& r = P.recs.back();
+                    r.n_items++;
+                    r.body_len = (size_t)(lc.p - d) - r.body_off;
+                    // verbatim copy needs "item\n" exactly: no stripped '\r', newline-terminated
+                    if ((line.data() + line.size() < d + len && line.data()[line.size()] == '\r') || lc.p[-1] != '\n') r.verbatim = false;
+                }
+            });
+            bool stop = false;
+            for (size_t pi = 0; pi < np && !stop; pi++) {
+                for (const Rec& r : parts[pi].recs) {
+                    std::string_view h(d + r.hdr_off, r.hdr_len);
+                    if (delim) { size_t at = h.find(*delim); if (at != std::string_view::npos) h = h.substr(0, at); }
+                    if (!(have_cur && h == std::string_view(cur_hdr))) {          // src/commands/uniq.rs:70-77
+                        write_cur();
+                        cur_hdr.assign(h); cur_body.clear(); cur_items = 0; have_cur = true;
+                    }
+                    cur_items += r.n_items;
+                    if (r.verbatim) cur_body.append(d + r.body_off, r.body_len);
+                    else {
+                        LineCursor lc{d + r.body_off, d + r.body_off + r.body_len};
+                        std::string_view line;
+                        while (lc.next(line)) { cur_body.append(line); cur_body.push_back('\n'); }
+                    }
+                }
+                if (parts[pi].bad_utf8) stop = true;
+            }
+            if (out.size() > (1u << 22) || stop) { fwrite(out.data(), 1, out.size(), stdout); out.clear(); }
+            if (stop) {
+                // the record read so far is NOT written by the reference (it is still held in `last`): only completed ones are
+                fflush(stdout);
+                throw CliError("stream did not contain valid UTF-8");
+            }
+        }
+        write_cur();
+        fwrite(out.data(), 1, out.size(), stdout);
+        fflush(stdout);
+        return 0;
+    }
     FastaReader reader(stdin, false);
     Out out(stdout);
     std::optional<Record> last;
