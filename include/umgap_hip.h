@@ -142,6 +142,13 @@ int umgap_index_lookup_var(umgap_index* ix, const uint8_t* bytes, const uint64_t
 int umgap_index_lookup_var_dev(umgap_index* ix, const uint8_t* d_bytes, const uint64_t* d_offsets, size_t n,
                                uint32_t miss_value, uint32_t* d_out_taxa, void* stream);
 
+/* ---- dump: fst::Map::stream() as used by `umgap printindex` (src/commands/printindex.rs:43-47) ---- */
+/* Every (key, taxon) of a whole table, in table order (the caller sorts).  *n_out = number of keys
+ * (also when it exceeds cap; then only the first cap are written). */
+int umgap_index_dump9(const umgap_index* ix, uint64_t* keys45, uint32_t* taxa, size_t cap, size_t* n_out);
+int umgap_index_dump_var(const umgap_index* ix, uint8_t* heap_out, uint64_t heap_cap, uint64_t* offsets_out,
+                         uint32_t* lens_out, uint32_t* taxa_out, size_t cap, size_t* n_out, uint64_t* heap_bytes_out);
+
 /* ---- taxonomy ---------------------------------------------------------------------------- */
 /* rows in TSV order: id, parent, valid (0/1), rank (index into src/rank.rs:10-41, 0 = "no rank").
  * Children keep row order (Euler tour / preorder follow it, src/taxon.rs:224-247).

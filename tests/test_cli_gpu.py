@@ -506,3 +506,24 @@ def test_chunk_semantics_on_errors_long_stream(world):
             rc, out, err = _run_env(["prot2kmer2lca", "-o", "-c", c, world["idx"]], prot, UMGAP_BLOCK_BYTES=block, UMGAP_THREADS=3)
             orc, oout, _ = O.run_cli(["prot2kmer2lca", "-o", "-c", c, world["idx_tsv"]], prot)
             assert rc == orc == 101 and out == oout, (block, c, len(out), len(oout))
+
+
+def test_buildindex_printindex_round_trip(world, tryptic, tmp_path):
+    """src/commands/buildindex.rs:20-28: `buildindex < tsv > index; printindex index` gives the TSV back."""
+    for kind in (world, tryptic):
+        tsv, idx = (kind["idx_tsv"], kind["idx"]) if "idx_tsv" in kind else (kind["tsv"], kind["idx"])
+        rc, out, err = run(["printindex", idx])
+        assert rc == 0, err
+        assert out == open(tsv, "rb").read()
+    # the documentation example
+    t = tmp_path / "tiny.tsv"
+    t.write_text("AAAAA\t2759\nBBBBBB\t9153\n")
+    i = tmp_path / "tiny.index"
+    with open(t, "rb") as fin, open(i, "wb") as fout:
+        assert subprocess.run([UMGAP, "buildindex"], stdin=fin, stdout=fout).returncode == 0
+    rc, out, _ = run(["printindex", str(i)])
+    assert rc == 0 and out == b"AAAAA\t2759\nBBBBBB\t9153\n"
+    # out-of-order and duplicate keys are refused like fst::MapBuilder::insert does
+    for bad in (b"BBBBB\t1\nAAAAA\t2\n", b"AAAAA\t1\nAAAAA\t2\n", b"AAAAA\tx\n", b"AAAAA\n"):
+        p = subprocess.run([UMGAP, "buildindex"], input=bad, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert p.returncode == 1 and p.stderr.startswith(b"Error: ")

@@ -83,6 +83,8 @@ def load():
         "umgap_index_build_var_dev": (i32, [vp, vp, vp, sz, u64, dbl, i32, pp]),
         "umgap_index_lookup_var": (i32, [vp, vp, vp, sz, u32, vp]),
         "umgap_index_lookup_var_dev": (i32, [vp, vp, vp, sz, u32, vp, vp]),
+        "umgap_index_dump9": (i32, [vp, vp, vp, sz, vp]),
+        "umgap_index_dump_var": (i32, [vp, vp, u64, vp, vp, vp, sz, vp, vp]),
         "umgap_taxonomy_create": (i32, [vp, vp, vp, vp, sz, i32, pp]),
         "umgap_taxonomy_free": (None, [vp]),
         "umgap_taxonomy_root": (u32, [vp]),

@@ -824,6 +824,51 @@ int cmd_buildindex(const std::vector<std::string>& args) {
     return 0;
 }
 
+// ---- printindex: the key/value pairs of an index as TSV, sorted by key (src/commands/printindex.rs:38-51) ----
+int cmd_printindex(const std::vector<std::string>& args) {
+    Parsed p = parse_args(args, {});
+    std::string path = need_positional(p, "fst-file");
+    umgap_index* ix = open_index(path);
+    Out out(stdout);
+    size_t n = 0;
+    if (umgap_index_kind(ix) == 9) {
+        size_t cap = (size_t)umgap_index_num_keys(ix);
+        std::vector<uint64_t> keys(cap);
+        std::vector<uint32_t> taxa(cap);
+        LIB(umgap_index_dump9(ix, keys.data(), taxa.data(), cap, &n));
+        if (n > cap) throw CliError("index holds more keys than its header says");
+        std::vector<size_t> order(n);
+        for (size_t i = 0; i < n; i++) order[i] = i;
+        std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return keys[a] < keys[b]; });  // packed order = byte order of [A-Z]{9}
+        char nine[9];
+        for (size_t i : order) {
+            umgap_unpack9(keys[i], nine);
+            out.buf.append(nine, 9); out.buf.push_back('\t'); append_u64(out.buf, taxa[i]); out.buf.push_back('\n');
+            out.maybe_flush();
+        }
+    } else {
+        size_t cap = (size_t)umgap_index_num_keys(ix);
+        uint64_t heap_bytes = 0;
+        std::vector<uint64_t> offs(cap);
+        std::vector<uint32_t> lens(cap), taxa(cap);
+        LIB(umgap_index_dump_var(ix, nullptr, 0, offs.data(), lens.data(), taxa.data(), cap, &n, &heap_bytes));
+        std::vector<uint8_t> heap(heap_bytes ? heap_bytes : 1);
+        LIB(umgap_index_dump_var(ix, heap.data(), heap.size(), offs.data(), lens.data(), taxa.data(), cap, &n, &heap_bytes));
+        if (n > cap) throw CliError("index holds more keys than its header says");
+        std::vector<size_t> order(n);
+        for (size_t i = 0; i < n; i++) order[i] = i;
+        auto key = [&](size_t i) { return std::string_view((const char*)heap.data() + offs[i], lens[i]); };
+        std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return key(a) < key(b); });
+        for (size_t i : order) {
+            out.buf.append(key(i)); out.buf.push_back('\t'); append_u64(out.buf, taxa[i]); out.buf.push_back('\n');
+            out.maybe_flush();
+        }
+    }
+    out.flush();
+    umgap_index_free(ix);
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -840,6 +885,7 @@ int main(int argc, char** argv) {
         if (cmd == "seedextend") return cmd_seedextend(args);
         if (cmd == "uniq") return cmd_uniq(args);
         if (cmd == "buildindex") return cmd_buildindex(args);
+        if (cmd == "printindex") return cmd_printindex(args);
         usage_error("Found argument '" + cmd + "' which wasn't expected, or isn't valid in this context");
     } catch (CliError& e) {
         fflush(stdout);

@@ -735,6 +735,60 @@ int umgap_index_lookup9(umgap_index* ix, const uint64_t* keys, size_t n, uint32_
     return rc;
 }
 
+// ---- dump (printindex): every (key, taxon) of the table back on the host ------------------------
+namespace {
+inline uint64_t inv_odd45(uint64_t c) {  // inverse of an odd constant modulo 2^45 (Newton)
+    uint64_t x = c;
+    for (int i = 0; i < 6; i++) x *= 2 - c * x;
+    return x & MASK45;
+}
+inline uint64_t unmix45(uint64_t h) {    // inverse of mix45 (common.hpp)
+    h ^= h >> 24;
+    h = (h * inv_odd45(MIX_C2)) & MASK45;
+    h ^= (h >> 21) ^ (h >> 42);
+    h = (h * inv_odd45(MIX_C1)) & MASK45;
+    h ^= h >> 23;
+    return h;
+}
+}  // namespace
+
+int umgap_index_dump9(const umgap_index* ix, uint64_t* keys45, uint32_t* taxa, size_t cap, size_t* n_out) {
+    if (!ix || ix->kind != 9 || !n_out) return fail(UMGAP_ERR_INVALID, "umgap_index_dump9: not a 9-mer index");
+    if (ix->view.home_lo != 0 || ix->view.home_hi != ix->view.nb) return fail(UMGAP_ERR_INVALID, "umgap_index_dump9: handle holds a shard");
+    int rc = use_device(ix->device);
+    if (rc) return rc;
+    const uint32_t m = ix->view.m, nb = ix->view.nb;
+    size_t n = 0;
+    const size_t chunk_buckets = 1u << 20;
+    std::vector<uint64_t> buf(chunk_buckets * SLOTS);
+    for (size_t b0 = 0; b0 < nb; b0 += chunk_buckets) {
+        size_t cnt = std::min<size_t>(chunk_buckets, nb - b0);
+        UMGAP_HIP(hipMemcpy(buf.data(), ix->d_slots + b0 * SLOTS, cnt * 64, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < cnt * SLOTS; i++) {
+            uint64_t e = buf[i];
+            if (e == EMPTY_SLOT) continue;
+            uint32_t lo = (uint32_t)e, d = (lo >> R_BITS) & 7u, r = lo & R_MASK;
+            uint64_t bucket = b0 + i / SLOTS, home = (bucket + nb - d) % nb;
+            uint64_t h = ((home / m) << R_BITS) | r;
+            if (n < cap) { keys45[n] = unmix45(h); taxa[n] = (uint32_t)(e >> 32); }
+            n++;
+        }
+    }
+    if (ix->n_stash) {
+        std::vector<uint64_t> sk(ix->n_stash);
+        std::vector<uint32_t> sv(ix->n_stash);
+        UMGAP_HIP(hipMemcpy(sk.data(), ix->d_stash_keys, sk.size() * 8, hipMemcpyDeviceToHost));
+        UMGAP_HIP(hipMemcpy(sv.data(), ix->d_stash_vals, sv.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < sk.size(); i++) {
+            uint64_t home = sk[i] >> R_BITS, r = sk[i] & R_MASK;
+            if (n < cap) { keys45[n] = unmix45(((home / m) << R_BITS) | r); taxa[n] = sv[i]; }
+            n++;
+        }
+    }
+    *n_out = n;
+    return UMGAP_OK;
+}
+
 int umgap_bench_gather_dev(umgap_index* ix, size_t n, uint32_t bytes_per_probe, uint32_t* d_out, void* stream) {
     if (!ix || !d_out) return fail(UMGAP_ERR_INVALID, "umgap_bench_gather_dev: null argument");
     int rc = use_device(ix->device);

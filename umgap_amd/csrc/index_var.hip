@@ -365,6 +365,42 @@ int umgap_index_build_var(const uint8_t* bytes, const uint64_t* offsets, const u
     return rc;
 }
 
+// dump (printindex): offsets_out[i] / lens_out[i] locate key i in the heap copy `heap_out` (heap_cap bytes)
+int umgap_index_dump_var(const umgap_index* ix, uint8_t* heap_out, uint64_t heap_cap, uint64_t* offsets_out, uint32_t* lens_out,
+                         uint32_t* taxa_out, size_t cap, size_t* n_out, uint64_t* heap_bytes_out) {
+    if (!ix || ix->kind != 2 || !ix->var || !n_out || !heap_bytes_out) return fail(UMGAP_ERR_INVALID, "umgap_index_dump_var: not a variable-length index");
+    int rc = use_device(ix->device);
+    if (rc) return rc;
+    const umgap_var_index* v = ix->var;
+    *heap_bytes_out = v->heap_bytes;
+    if (heap_out && heap_cap >= v->heap_bytes && v->heap_bytes) UMGAP_HIP(hipMemcpy(heap_out, v->d_heap, v->heap_bytes, hipMemcpyDeviceToHost));
+    size_t n = 0;
+    const size_t total = (size_t)(v->nb + VAR_MAX_DISP) * VAR_SLOTS, chunk = 1u << 22;
+    std::vector<uint32_t> buf(chunk * 4);
+    for (size_t s0 = 0; s0 < total; s0 += chunk) {
+        size_t cnt = std::min(chunk, total - s0);
+        UMGAP_HIP(hipMemcpy(buf.data(), v->d_slots + s0, cnt * 16, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < cnt; i++) {
+            uint64_t off = ((uint64_t)buf[4 * i + 3] << 32) | buf[4 * i + 2];
+            if (off == VAR_EMPTY) continue;
+            if (n < cap) { offsets_out[n] = off; lens_out[n] = (buf[4 * i] >> 25) & 63u; taxa_out[n] = buf[4 * i + 1]; }
+            n++;
+        }
+    }
+    if (v->n_stash) {
+        std::vector<uint64_t> so(v->n_stash);
+        std::vector<uint32_t> sv(v->n_stash);
+        UMGAP_HIP(hipMemcpy(so.data(), v->d_stash_off, so.size() * 8, hipMemcpyDeviceToHost));
+        UMGAP_HIP(hipMemcpy(sv.data(), v->d_stash_val, sv.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < so.size(); i++) {
+            if (n < cap) { offsets_out[n] = so[i] & ((1ull << 58) - 1); lens_out[n] = (uint32_t)(so[i] >> 58); taxa_out[n] = sv[i]; }
+            n++;
+        }
+    }
+    *n_out = n;
+    return UMGAP_OK;
+}
+
 int umgap_index_lookup_var_dev(umgap_index* ix, const uint8_t* d_bytes, const uint64_t* d_offsets, size_t n, uint32_t miss_value,
                                uint32_t* d_out, void* stream) {
     if (!ix || ix->kind != 2 || !ix->var) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup_var_dev: not a variable-length index");
