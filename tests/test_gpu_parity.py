@@ -600,3 +600,79 @@ def test_pept2lca_doc_example_tryptic(api):
     ix = api.Index.build_var([b"AAALTER", b"ENFVYLAK"], np.array([2, 3398], np.uint32))
     assert ix.lookup_var([b"AAALTER", b"ENFVYLAK"]).tolist() == [2, 3398]
     assert ix.lookup_var([b"NOTATRYPTICPEPTIDE", b"ENFVYLAK"], miss_value=0).tolist() == [0, 3398]
+
+
+# ---------------------------------------------------------------------------------------------
+# remaining device-pointer entry points of include/umgap_hip.h
+# ---------------------------------------------------------------------------------------------
+def test_lookup_prot9_dev_matches_windows(api, torch_cuda):
+    """umgap_index_lookup_prot9_dev = every 9-residue window of every peptide (src/commands/prot2kmer2lca.rs:172-179)."""
+    torch = torch_cuda
+    rng = np.random.default_rng(31)
+    letters = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    kmers = sorted({rng.choice(letters, 9).tobytes() for _ in range(5000)})
+    vals = rng.integers(1, 1 << 30, len(kmers)).astype(np.uint32)
+    keys, ok = api.pack9_array(kmers)
+    assert ok.all()
+    ix = api.Index.build(keys, vals)
+    d = dict(zip(kmers, vals.tolist()))
+    peps = []
+    for _ in range(3000):
+        n = int(rng.integers(0, 70))
+        p = bytearray(rng.choice(letters, n).tobytes())
+        if n >= 9 and rng.random() < 0.7:
+            s = int(rng.integers(0, n - 8))
+            p[s:s + 9] = kmers[int(rng.integers(0, len(kmers)))]
+        if n and rng.random() < 0.2:
+            p[int(rng.integers(0, n))] = ord("*")
+        peps.append(bytes(p))
+    data, offs = api._concat(peps)
+    out_offs = np.zeros(len(peps) + 1, np.uint64)
+    out_offs[1:] = np.cumsum([max(0, len(p) - 8) for p in peps])
+    d_bytes = torch.from_numpy(data.copy()).cuda()
+    d_offs = torch.from_numpy(offs.view(np.int64)).cuda()
+    d_oo = torch.from_numpy(out_offs.view(np.int64)).cuda()
+    d_out = torch.full((int(out_offs[-1]),), -1, dtype=torch.int32, device="cuda")
+    ix.lookup_prot9_dev(d_bytes, d_offs, d_oo, d_out, miss_value=0)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy().view(np.uint32)
+    want = np.array([d.get(p[i:i + 9], 0) for p in peps for i in range(max(0, len(p) - 8))], np.uint32)
+    assert (got == want).all() and (want != 0).sum() > 1000
+
+
+def test_device_pointer_variants(api, torch_cuda):
+    """build9_dev, aggregate_dev (CSR on the device), set_shard: same answers as the host-pointer forms."""
+    torch = torch_cuda
+    from umgap_amd.synth import synthetic_taxonomy
+    rng = np.random.default_rng(41)
+    keys = np.unique(rng.integers(0, 1 << 45, 100_000, dtype=np.uint64))
+    vals = rng.integers(1, 1 << 30, len(keys)).astype(np.uint32)
+    ix_h = api.Index.build(keys, vals)
+    ix_d = api.Index.build_dev(torch.from_numpy(keys.view(np.int64)).cuda(), torch.from_numpy(vals.view(np.int32)).cuda())
+    q = np.concatenate([keys[:5000], rng.integers(0, 1 << 45, 5000, dtype=np.uint64)])
+    assert (ix_h.lookup9(q) == ix_d.lookup9(q)).all()
+    # set_shard: the union of the shards answers everything exactly once
+    want = ix_h.lookup9(q)
+    acc = np.zeros(len(q), np.uint32)
+    for s in range(4):
+        ix_d.set_shard(s, 4)
+        r = ix_d.lookup9(q)
+        assert ((acc != 0) & (r != 0)).sum() == 0
+        acc |= r
+    assert (acc == want).all()
+    ids, par, valid, rank = synthetic_taxonomy(3000, 5000, max_depth=25, seed=2)
+    tx = api.Taxonomy(ids, par, valid, rank)
+    reads = []
+    for _ in range(30):
+        pool = rng.choice(ids, 6)
+        reads += _random_reads(rng, pool, 30, 40)
+    taxa, offs = _csr(reads)
+    d_taxa = torch.from_numpy(taxa.view(np.int32)).cuda()
+    d_offs = torch.from_numpy(offs.view(np.int64)).cuda()
+    for method, strategy in (("tree", "lca*"), ("rmq", "mrtl"), ("tree", "hybrid"), ("rmq", "hybrid")):
+        t, s = tx.aggregate(taxa, offs, method=method, strategy=strategy, lower_bound=1.0)
+        dt = torch.empty(len(reads), dtype=torch.int32, device="cuda")
+        ds = torch.empty_like(dt)
+        tx.aggregate_dev(d_taxa, d_offs, dt, ds, method=method, strategy=strategy, lower_bound=1.0)
+        torch.cuda.synchronize()
+        assert (dt.cpu().numpy().view(np.uint32) == t).all() and (ds.cpu().numpy().view(np.uint32) == s).all()
