@@ -87,9 +87,13 @@ def cpu_baseline(n_tax, ids, parents, valid, rank, taxonomy_handle, d_taxon_of_r
     t_agg = time.perf_counter() - t0
     # the reference runs the stages as concurrent processes: throughput = slowest stage
     value = n_pairs / max(t_lookup, t_agg)
+    import shutil
+    have_ref = bool(shutil.which("cargo")) or bool(shutil.which("rustc"))
     return {"value": round(value, 1), "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": "%d pairs (%d lookups) vs a %d-key sorted-array index; lookup on %d threads %.2fs, LCA* -l2 on 1 thread %.2fs; "
-                      "pipelined stages => rate of the slower one" % (n_pairs, n_pairs * KMERS, n_cpu_keys, cores, t_lookup, t_agg)}
+            "sample": "restated CPU baseline (not the Rust binary: %s on this box); %d pairs (%d lookups) vs a %d-key sorted-array index; "
+                      "lookup on %d threads %.2fs, LCA* -l2 on 1 thread %.2fs; pipelined stages => rate of the slower one" % (
+                          "a Rust toolchain exists but the reference sources do not travel" if have_ref else "no cargo/rustc",
+                          n_pairs, n_pairs * KMERS, n_cpu_keys, cores, t_lookup, t_agg)}
 
 
 def sharded_extra(args, w, keys, rank, world, local_rank, device, B, d_hits, d_taxon, d_status, main_out):
@@ -114,7 +118,7 @@ def sharded_extra(args, w, keys, rank, world, local_rank, device, B, d_hits, d_t
     dog.start()
     try:
         shard = Index.synthetic(args.n_keys, w.d_taxon_of_row, synth.MUL_A, synth.ADD_B, args.load_factor, rank, world)
-        sl = ShardedLookup(GpuOps(shard, device), rank, world, B * KMERS)
+        sl = ShardedLookup(GpuOps(shard, device), rank, world, B * KMERS, chunks=4)
         steps = max(2, min(3, args.steps))
 
         def one(i):
@@ -134,7 +138,7 @@ def sharded_extra(args, w, keys, rank, world, local_rank, device, B, d_hits, d_t
         assert ((st == 0) | (st == 1)).all()
         res = {"value": round(world * steps * B / float(el.item()), 1), "unit": "pairs/s", "steps": steps,
                "ms_per_step": round(1e3 * float(el.item()) / steps, 3), "shard_table_GB": round(shard.table_bytes / 1e9, 2),
-               "exchange": "all_to_all_single: 8 B/key out, 4 B/key back, %d keys per rank per step" % (B * KMERS)}
+               "exchange": "all_to_all_single: 8 B/key out, 4 B/key back, %d keys per rank per step, 4 pieces over 2 streams" % (B * KMERS)}
     except Exception as e:  # noqa: BLE001
         res = {"error": "%s: %s" % (type(e).__name__, e)}
     dog.cancel()
@@ -183,7 +187,7 @@ def main():
     sharded = None
     if sharded_mode:
         from umgap_amd.dist import GpuOps, ShardedLookup
-        sharded = ShardedLookup(GpuOps(w.index, device), rank, world, B * KMERS)
+        sharded = ShardedLookup(GpuOps(w.index, device), rank, world, B * KMERS, chunks=4)
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 

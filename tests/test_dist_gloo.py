@@ -65,7 +65,7 @@ def _worker(rank, world, port, n_keys, results):
     # a skewed batch must trip the overflow check instead of silently dropping keys
     skew = torch.from_numpy(np.full(n_keys, int(universe[0]) // world * world, np.int64))
     tight = ShardedLookup(CpuOps(rank, world, table), rank, world, n_keys, slack=0.0)
-    tight.cap = n_keys // world
+    tight.cap = n_keys // world   # regions too small for a batch that goes to one owner
     tight.lookup(skew, hits)
     try:
         tight.check_overflow()

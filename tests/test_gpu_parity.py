@@ -676,3 +676,31 @@ def test_device_pointer_variants(api, torch_cuda):
         tx.aggregate_dev(d_taxa, d_offs, dt, ds, method=method, strategy=strategy, lower_bound=1.0)
         torch.cuda.synchronize()
         assert (dt.cpu().numpy().view(np.uint32) == t).all() and (ds.cpu().numpy().view(np.uint32) == s).all()
+
+
+def test_sharded_lookup_pipelined_nccl_world1(api, torch_cuda):
+    """umgap_amd.dist.ShardedLookup with the two-stream pipelining, on a world-size-1 RCCL group: the stream
+    fork/join and buffer reuse must give the same hits as the plain probe."""
+    torch = torch_cuda
+    import torch.distributed as dist
+    from umgap_amd.dist import GpuOps, ShardedLookup
+    from umgap_amd.synth import SyntheticWorkload
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        w = SyntheticWorkload(n_tax=5000, n_keys=600_000)
+        keys = w.reads(0, 5001)
+        want = w.index.lookup9_dev(keys).clone()
+        dev = torch.device("cuda", 0)
+        for chunks in (1, 4, 5):
+            sl = ShardedLookup(GpuOps(w.index, dev), 0, 1, keys.numel(), chunks=chunks)
+            hits = torch.empty(keys.numel(), dtype=torch.int32, device=dev)
+            for _ in range(3):
+                hits.fill_(-7)
+                sl.lookup(keys, hits)
+            torch.cuda.synchronize()
+            sl.check_overflow()
+            assert torch.equal(hits, want), chunks
+    finally:
+        dist.destroy_process_group()
