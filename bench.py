@@ -272,6 +272,21 @@ def main():
                 out["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
         except Exception:
             pass
+    if world == 1 and fused and not args.seedextend:
+        # the full high-precision pipeline: seedextend -g1 -s3 per fragment between probe and aggregate
+        # (scripts/umgap-analyse.sh:302), same batches, same kernel with the stage switched on
+        def se_step(i):
+            classify9_dev(w.index, w.taxonomy, keys[i % n_batches], B, KMERS, d_taxon, d_status, method="tree", lower_bound=2.0,
+                          fragments_per_read=2, min_seed_size=3, max_gap_size=1)
+        se_step(0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            se_step(i + 1)
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        out["with_seedextend"] = {"value": round(args.steps * B / el, 1), "unit": "pairs/s", "ms_per_step": round(1e3 * el / args.steps, 3),
+                                  "pipeline": "probe -> seedextend -g1 -s3 (per read end) -> taxa2agg -l2 -a lca*, one fused kernel"}
     if rank == 0 and world == 1 and not args.no_gather:
         # measured random-sector gather ceilings over the same table (SURVEY.md §8d second denominator)
         n = 1 << 28
