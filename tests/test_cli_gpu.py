@@ -527,3 +527,27 @@ def test_buildindex_printindex_round_trip(world, tryptic, tmp_path):
     for bad in (b"BBBBB\t1\nAAAAA\t2\n", b"AAAAA\t1\nAAAAA\t2\n", b"AAAAA\tx\n", b"AAAAA\n"):
         p = subprocess.run([UMGAP, "buildindex"], input=bad, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert p.returncode == 1 and p.stderr.startswith(b"Error: ")
+
+
+@pytest.mark.parametrize("mode", [["-s", "-a", "lca*", "-l", "0.8"], ["-s", "-m", "rmq", "-a", "mrtl"], ["-s", "-a", "hybrid", "-f", "0.5"],
+                                  ["-s", "-m", "rmq", "-a", "hybrid", "-l", "0.3"]])
+def test_taxa2agg_scored_matches_oracle(world, mode):
+    """-s: `taxon=score` items (src/commands/taxa2agg.rs:142-148).  Scores are multiples of 1/64 so every f32 sum is exact
+    in any order (the reference's own summation order is HashMap-dependent for the hybrids)."""
+    rng = np.random.default_rng(len(mode) * 3 + 1)
+    ids = world["ids"]
+    recs = []
+    for r in range(400):
+        pool = rng.choice(ids, int(rng.integers(1, 6)))
+        items = ["%d=%s" % (t, repr(float(rng.integers(1, 64)) / 64.0)) for t in rng.choice(pool, int(rng.integers(0, 25)))]
+        if rng.random() < 0.2:
+            items.append("0=1")
+        recs.append(">r%d\n%s" % (r, "".join(i + "\n" for i in items)))
+    fasta = "".join(recs).encode()
+    rc, out, err = run(["taxa2agg"] + mode + [world["tsv"]], fasta)
+    orc, oout, _ = O.run_cli(["taxa2agg"] + mode + [world["tsv"]], fasta)
+    assert rc == orc == 0 and out == oout, err
+    for bad in (b">r\n5\n", b">r\n5=1=2\n", b">r\n5=abc\n", b">r\nx=1\n"):
+        rc, _, err = run(["taxa2agg", "-s", world["tsv"]], bad)
+        orc, _, oerr = O.run_cli(["taxa2agg", "-s", world["tsv"]], bad)
+        assert rc == orc == 1 and err.split(b"\n")[0] == oerr.split(b"\n")[0]

@@ -23,32 +23,37 @@ using namespace umgap::probe;
 namespace {
 
 // seedextend state machine over one fragment held in LDS (unranked mode; pipeline.hip has the
-// device-memory twin with the line-by-line citations)
+// device-memory twin with the line-by-line citations).  Streaming form: the reference's scanner
+// consumes the elements t[1..n] (t[n] = the 0 sentinel) strictly in order -- its one irregular
+// move, "don't start with a missing taxon" (src/commands/seedextend.rs:130-134), merely skips
+// element `end` and restarts right after it -- so the next element is prefetched while the
+// current one is processed (the LDS read latency is the cost of this stage).
 __device__ __forceinline__ void seedextend_lds(uint32_t* t, uint32_t n, uint32_t min_seed, uint32_t max_gap) {
-    auto at = [&](uint32_t i) -> uint32_t { return i < n ? t[i] : 0u; };
-    const uint32_t len = n + 1;
     uint32_t cursor = 0;
-    auto emit = [&](uint32_t s, uint32_t e) {
+    auto emit = [&](uint32_t s, uint32_t e) {   // seeds.push((s, e)): everything before s and after the last e is dropped
         if (e > n) e = n;
         if (s > e) s = e;
         for (uint32_t i = cursor; i < s; i++) t[i] = 0;
         cursor = e > cursor ? e : cursor;
     };
-    uint32_t start = 0, end = 1;
-    uint32_t last_tid = at(0), same_tid = 1, same_max = 1;
-    while (end < len) {
-        uint32_t cur = at(end);
-        if (last_tid == cur) { same_tid += 1; end += 1; continue; }
-        if (last_tid == 0 && same_tid > max_gap) {
+    if (n == 0) return;
+    uint32_t start = 0, last_tid = t[0], same_tid = 1, same_max = 1;
+    uint32_t nxt = n > 1 ? t[1] : 0u;
+    for (uint32_t end = 1; end <= n; end++) {
+        const uint32_t cur = nxt;                       // t[end], or the sentinel at end == n
+        nxt = end + 1 < n ? t[end + 1] : 0u;
+        if (last_tid == cur) { same_tid += 1; continue; }                                   // :109-113
+        if (last_tid == 0 && same_tid > max_gap) {                                          // :116-127
             if (same_max >= min_seed) emit(start, end - same_tid);
-            start = end; last_tid = cur; same_tid = 1; same_max = 1; end += 1;
+            start = end; last_tid = cur; same_tid = 1; same_max = 1;
             continue;
         }
-        if (last_tid == 0 && (end - start) == same_tid) { end += 1; start = end; continue; }
-        if (last_tid != 0) same_max = same_max > same_tid ? same_max : same_tid;
-        last_tid = cur; same_tid = 1; end += 1;
+        if (last_tid == 0 && (end - start) == same_tid) { start = end + 1; continue; }      // :130-134
+        if (last_tid != 0) same_max = same_max > same_tid ? same_max : same_tid;            // :137-139
+        last_tid = cur; same_tid = 1;
     }
-    if (same_max >= min_seed) {
+    if (same_max >= min_seed) {                                                             // :143-148
+        uint32_t end = n + 1;
         if (last_tid == 0) end -= same_tid;
         emit(start, end);
     }
