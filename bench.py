@@ -253,8 +253,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 keys / u32 taxa (integer, no MFMA)",
         "data": "synthetic",
         "config": {"workload": "BASELINE.json configs[2]: synthetic 150 bp paired reads (84 packed 9-mers per pair), "
-                               "%d resident batches x %d pairs per GPU; lookup + taxa2agg -l2 -a lca*%s" % (
-                                   n_batches, B, " + seedextend -g1 -s3" if args.seedextend else ""),
+                               "%d resident batches x %d pairs per GPU; lookup%s + taxa2agg -l2 -a lca*%s" % (
+                                   n_batches, B, " + seedextend -g1 -s3" if args.seedextend else "", " (one fused kernel)" if fused else ""),
                    "pairs_per_step_per_gpu": B, "n_keys": args.n_keys, "n_tax": args.n_tax,
                    "table_GB": round(w.index.table_bytes / 1e9, 2), "load_factor": args.load_factor,
                    "parallelism": ("1 GPU" if world == 1 else "%s x%d" % (mode, world)), "setup_s": round(t_setup, 1)},
