@@ -210,6 +210,17 @@ int umgap_classify9_dev(umgap_index* ix, umgap_taxonomy* tx, int method, float l
                         uint32_t fragments_per_read, uint32_t min_seed_size, uint32_t max_gap_size,
                         uint32_t* d_out_taxon, uint32_t* d_out_status, void* stream);
 
+/* Surface B of the same pipeline: the reads arrive as protein fragments (1 byte per residue, what
+ * `prot2kmer2lca` reads, src/commands/prot2kmer2lca.rs:172-179): read r owns fragments
+ * [r*F, (r+1)*F) of the CSR (d_bytes, d_frag_offsets[n_reads*F + 1]); every window of 9 residues of
+ * every fragment is looked up (fragments shorter than 9 have none; windows with a byte outside
+ * 'A'..'Z' miss).  A read with more than 128 windows or 384 bytes gets status
+ * UMGAP_READ_UNSUPPORTED (use umgap_index_lookup_prot9_dev + umgap_aggregate_dev for those). */
+int umgap_classify_prot9_dev(umgap_index* ix, umgap_taxonomy* tx, int method, float lower_bound, int ranked_only,
+                             const uint8_t* d_bytes, const uint64_t* d_frag_offsets, size_t n_reads,
+                             uint32_t fragments_per_read, int seedextend, uint32_t min_seed_size,
+                             uint32_t max_gap_size, uint32_t* d_out_taxon, uint32_t* d_out_status, void* stream);
+
 /* ---- measurement helpers (bench.py; not part of the reference surface) ------------------- */
 /* Lane-per-key probe variant of umgap_index_lookup9_dev, kept for the A/B in DESIGN.md. */
 int umgap_index_lookup9_lane_dev(umgap_index* ix, const uint64_t* d_keys45, size_t n, uint32_t miss_value,
@@ -228,6 +239,15 @@ int umgap_synth_index_build_shard(uint64_t n_keys, const uint32_t* d_taxon_of_ro
  * d_bytes[d_offsets[i] .. d_offsets[i+1]) with letters determined by (seed, first+i). */
 int umgap_synth_peptides_dev(uint64_t first, size_t n, uint64_t seed, const uint64_t* d_offsets,
                              uint8_t* d_bytes, int device, void* stream);
+/* Synthetic proteome (surface B): an index whose keys are all 9-residue windows of the given
+ * fragments (value = the fragment's taxon, smallest taxon on duplicate 9-mers), and reads made of
+ * mutated copies of proteome fragments. */
+int umgap_index_build_windows9_dev(const uint8_t* d_bytes, const uint64_t* d_offsets, const uint32_t* d_taxa,
+                                   size_t n_fragments, uint32_t max_fragment_len, uint64_t expected_keys,
+                                   double load_factor, int device, umgap_index** out);
+int umgap_synth_prot_reads_dev(const uint8_t* d_proteome, uint64_t n_proteome_fragments, uint32_t fragment_len,
+                               uint64_t seed, uint64_t first_read, size_t n_reads, uint32_t fragments_per_read,
+                               uint32_t mutations_per_mille, uint8_t* d_out, int device, void* stream);
 int umgap_synth_reads9_dev(const umgap_taxonomy* tx, const uint32_t* d_taxon_of_row,
                            const uint32_t* d_row_of_id, uint64_t n_tax, uint64_t n_keys, uint64_t mul_a,
                            uint64_t add_b, uint64_t seed, uint64_t first_pair, uint64_t n_pairs,

@@ -704,3 +704,129 @@ def test_sharded_lookup_pipelined_nccl_world1(api, torch_cuda):
             assert torch.equal(hits, want), chunks
     finally:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------
+# surface B: protein fragments in, fused kernel (LDS-staged k-mer packing) vs the oracle stages
+# ---------------------------------------------------------------------------------------------
+def _proteome(torch, w, n_frag, flen=50, seed=7):
+    from umgap_amd import _lib
+    from umgap_amd.api import _dev_ptr, _stream_ptr
+    offs = torch.arange(0, (n_frag + 1) * flen, flen, dtype=torch.int64, device="cuda")
+    data = torch.empty(n_frag * flen, dtype=torch.uint8, device="cuda")
+    _lib.check(_lib.load().umgap_synth_peptides_dev(0, n_frag, seed, _dev_ptr(offs), _dev_ptr(data), 0, _stream_ptr(None)))
+    taxa = w.d_taxon_of_row[torch.arange(n_frag, device="cuda") % w.n_tax].contiguous()
+    return data, offs, taxa
+
+
+def _pack_windows(arr2d):
+    """uint8 [n, L] -> (keys uint64 [n, L-8], ok bool [n, L-8])"""
+    n, L = arr2d.shape
+    code = arr2d.astype(np.int64) - 65
+    good = (code >= 0) & (code < 26)
+    keys = np.zeros((n, L - 8), np.uint64)
+    ok = np.ones((n, L - 8), bool)
+    for c in range(9):
+        keys = (keys << np.uint64(5)) | (code[:, c:c + L - 8] & 31).astype(np.uint64)
+        ok &= good[:, c:c + L - 8]
+    return keys, ok
+
+
+@pytest.mark.parametrize("with_seedextend", [False, True])
+def test_fused_classify_prot9_vs_oracle(api, torch_cuda, with_seedextend):
+    torch = torch_cuda
+    import ctypes as C
+    from umgap_amd import _lib
+    from umgap_amd.api import Index, _dev_ptr, _stream_ptr
+    from umgap_amd.synth import SyntheticWorkload
+    L = _lib.load()
+    n_tax, n_frag, flen, n_reads, F = 5000, 20_000, 50, 6000, 2
+    w = SyntheticWorkload(n_tax=n_tax, n_keys=1000, build_index=False)
+    prot, poffs, ptaxa = _proteome(torch, w, n_frag, flen)
+    h = C.c_void_p()
+    _lib.check(L.umgap_index_build_windows9_dev(_dev_ptr(prot), _dev_ptr(poffs), _dev_ptr(ptaxa), n_frag, flen, n_frag * (flen - 8), 0.0, 0, C.byref(h)))
+    ix = Index(h.value)
+    reads = torch.empty(n_reads * F * flen, dtype=torch.uint8, device="cuda")
+    _lib.check(L.umgap_synth_prot_reads_dev(_dev_ptr(prot), n_frag, flen, 44, 0, n_reads, F, 30, _dev_ptr(reads), 0, _stream_ptr(None)))
+    roffs = torch.arange(0, (n_reads * F + 1) * flen, flen, dtype=torch.int64, device="cuda")
+    d_t = torch.empty(n_reads, dtype=torch.int32, device="cuda")
+    d_s = torch.empty_like(d_t)
+    api.classify_prot9_dev(ix, w.taxonomy, reads, roffs, n_reads, F, d_t, d_s, method="tree", lower_bound=2.0, seedextend=with_seedextend,
+                           min_seed_size=3, max_gap_size=1)
+    torch.cuda.synchronize()
+    # oracle side: the index as a sorted (key -> min taxon) array, lookups by searchsorted
+    pk, pok = _pack_windows(prot.cpu().numpy().reshape(n_frag, flen))
+    pt = np.repeat(ptaxa.cpu().numpy().view(np.uint32), flen - 8)
+    order = np.lexsort((pt, pk.ravel()))
+    ks, ts = pk.ravel()[order], pt[order]
+    first = np.concatenate([[True], ks[1:] != ks[:-1]])
+    ukeys, utax = ks[first], ts[first]                       # smallest taxon per distinct 9-mer
+    assert pok.all()
+    rk, rok = _pack_windows(reads.cpu().numpy().reshape(n_reads * F, flen))
+    pos = np.searchsorted(ukeys, rk.ravel())
+    pos[pos >= len(ukeys)] = 0
+    hits = np.where((ukeys[pos] == rk.ravel()) & rok.ravel(), utax[pos], 0).astype(np.uint32)
+    assert 0.3 < (hits != 0).mean() < 0.95
+    # the unfused device path for the same bytes gives the same hits
+    oo = torch.arange(0, (n_reads * F + 1) * (flen - 8), flen - 8, dtype=torch.int64, device="cuda")
+    d_hits = torch.empty(n_reads * F * (flen - 8), dtype=torch.int32, device="cuda")
+    ix.lookup_prot9_dev(reads, roffs, oo, d_hits)
+    torch.cuda.synchronize()
+    assert (d_hits.cpu().numpy().view(np.uint32) == hits).all()
+    per = flen - 8
+    if with_seedextend:
+        out = np.zeros_like(hits)
+        for r in range(n_reads * F):
+            kept = O.seedextend_record(hits[r * per:(r + 1) * per], 3, 1)
+            out[r * per:r * per + len(kept)] = kept
+        hits = out
+    agg = O.Aggregator(O.Taxonomy.from_arrays(w.ids, w.parents, w.valid, w.rank), "tree", "lca*")
+    offs = np.arange(n_reads + 1, dtype=np.uint64) * (F * per)
+    t, s = d_t.cpu().numpy().view(np.uint32), d_s.cpu().numpy().view(np.uint32)
+    nbad, bad, wt, ws = agg.taxa2agg_check(hits, offs, t, s, lower_bound=2.0, nthreads=8)
+    assert nbad == 0, (bad, t[bad.astype(int)], s[bad.astype(int)], wt[bad.astype(int)])
+    assert (s == 0).mean() > 0.5
+
+
+def test_classify_prot9_ragged_fragments(api, torch_cuda):
+    """Fragments of different lengths (incl. shorter than 9, empty, with '*'), 1..12 fragments per read."""
+    torch = torch_cuda
+    rng = np.random.default_rng(77)
+    letters = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    kmers = sorted({rng.choice(letters, 9).tobytes() for _ in range(3000)})
+    ids = np.arange(1, 40, dtype=np.uint32)
+    par = np.maximum(1, ids // 2).astype(np.uint32)
+    par[0] = 1
+    tx = api.Taxonomy(ids, par)
+    agg = O.Aggregator(O.Taxonomy.from_arrays(ids, par), "tree", "lca*")
+    vals = rng.choice(ids, len(kmers)).astype(np.uint32)
+    keys, _ = api.pack9_array(kmers)
+    ix = api.Index.build(keys, vals)
+    d = dict(zip(kmers, vals.tolist()))
+    for F in (1, 2, 5, 12):
+        frags = []
+        for _ in range(400 * F):
+            n = int(rng.choice([0, 3, 8, 9, 10, 17]))
+            p = bytearray(rng.choice(letters, n).tobytes())
+            if n >= 9:
+                for _k in range(2):
+                    s0 = int(rng.integers(0, n - 8))
+                    p[s0:s0 + 9] = kmers[int(rng.integers(0, 40))]   # few distinct kmers => repeats survive -l 2
+            if n and rng.random() < 0.1:
+                p[int(rng.integers(0, n))] = ord("*")
+            frags.append(bytes(p))
+        data, offs = api._concat(frags)
+        n_reads = 400
+        d_t = torch.empty(n_reads, dtype=torch.int32, device="cuda")
+        d_s = torch.empty_like(d_t)
+        api.classify_prot9_dev(ix, tx, torch.from_numpy(data.copy()).cuda(), torch.from_numpy(offs.view(np.int64)).cuda(), n_reads, F, d_t, d_s,
+                               method="tree", lower_bound=2.0)
+        torch.cuda.synchronize()
+        hits, roffs = [], [0]
+        for r in range(n_reads):
+            for f in frags[r * F:(r + 1) * F]:
+                hits += [d.get(f[i:i + 9], 0) for i in range(max(0, len(f) - 8))]
+            roffs.append(len(hits))
+        t, s = d_t.cpu().numpy().view(np.uint32), d_s.cpu().numpy().view(np.uint32)
+        nbad, bad, wt, ws = agg.taxa2agg_check(np.array(hits, np.uint32), np.array(roffs, np.uint64), t, s, lower_bound=2.0)
+        assert nbad == 0, (F, bad)

@@ -145,6 +145,144 @@ __global__ __launch_bounds__(256) void k_classify9(TableView T, TaxView V, int m
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Surface B: the reads arrive as protein fragments (what FGSpp / `translate` emit and
+// `prot2kmer2lca` consumes, ~1.2 B per k-mer instead of 8 B): read r owns fragments
+// [r*F, (r+1)*F) of a CSR byte array.  One wave per read: the read's bytes are staged in LDS,
+// every lane packs the 9-mer window(s) it owns from LDS (src/commands/prot2kmer2lca.rs:172-179:
+// all len-8 windows of a fragment, none if it is shorter than 9), two probe batches (128
+// windows) are issued back to back, then seedextend per fragment and LCA* as in k_classify9.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t PROT_MAX_FRAGS = 16, PROT_MAX_BYTES = 384, PROT_MAX_WINDOWS = 128;
+
+__global__ __launch_bounds__(256) void k_classify_prot9(TableView T, TaxView V, int method, const uint8_t* __restrict__ bytes,
+                                                        const uint64_t* __restrict__ foff, size_t n_reads, uint32_t F, uint32_t do_seed,
+                                                        uint32_t min_seed, uint32_t max_gap, float lower_bound,
+                                                        uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status) {
+    __shared__ uint32_t lds_taxa[4][PROT_MAX_WINDOWS], lds_keys[4][256], lds_cnt[4][256];
+    __shared__ uint8_t lds_bytes[4][PROT_MAX_BYTES];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
+    uint32_t* wtaxa = lds_taxa[wv];
+    uint32_t* wkeys = lds_keys[wv];
+    uint32_t* wcnt = lds_cnt[wv];
+    uint8_t* wbytes = lds_bytes[wv];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { wkeys[lane + 64 * i] = 0u; wcnt[lane + 64 * i] = 0u; }
+    const bool tree_like = method != UMGAP_METHOD_RMQ;
+    const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    for (size_t r = wave0; r < n_reads; r += nwaves) {
+        // fragment boundaries relative to the read's first byte; lane f holds start of fragment f (f <= F)
+        const uint64_t base = foff[r * F];
+        uint32_t my_off = lane <= F ? (uint32_t)(foff[r * F + lane] - base) : 0u;
+        const uint32_t nbytes = __builtin_amdgcn_readlane(my_off, F);   // F is wave-uniform (kernel argument <= 16)
+        // (shuffle with every lane active: ds_bpermute returns 0 for a source lane that is masked off)
+        const uint32_t next_off = (uint32_t)__shfl((int)my_off, (int)((lane + 1) & 63), 64);
+        uint32_t my_len = lane < F ? next_off - my_off : 0u;
+        uint32_t my_win = my_len >= 9 ? my_len - 8 : 0u;                 // windows of fragment `lane`
+        // exclusive prefix of the window counts over the F fragments (F <= 16: serial over readlanes)
+        uint32_t wstart = 0, total = 0;
+        for (uint32_t f = 0; f < F; f++) {
+            uint32_t wf = __builtin_amdgcn_readlane(my_win, f);
+            if (lane == f) wstart = total;
+            total += wf;
+        }
+        uint32_t res_taxon = 0, res_status = UMGAP_READ_OK;
+        if (nbytes > PROT_MAX_BYTES || total > PROT_MAX_WINDOWS) {
+            res_status = 4u;  // UMGAP_READ_UNSUPPORTED: use lookup_prot9 + aggregate for such reads
+        } else {
+            // ---- stage the read's bytes in LDS ----
+            for (uint32_t i = lane; i < nbytes; i += 64) wbytes[i] = bytes[base + i];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---- every lane packs the windows lane and lane+64 from LDS ----
+            uint32_t loc[2] = {0, 0}, tg[2] = {0, 0};
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                uint32_t g = lane + 64 * h, valid = 0;
+                if (g < total) {
+                    uint32_t f = 0, ws = 0, fo = 0;
+                    for (uint32_t k = 0; k < F; k++) {   // the fragment that owns window g
+                        uint32_t wk = __builtin_amdgcn_readlane(wstart, k), nk = __builtin_amdgcn_readlane(my_win, k);
+                        uint32_t ok = __builtin_amdgcn_readlane(my_off, k);
+                        if (g >= wk && g < wk + nk) { f = k; ws = wk; fo = ok; }
+                    }
+                    (void)f;
+                    const uint8_t* sp = wbytes + fo + (g - ws);
+                    uint64_t key = 0;
+                    bool okc = true;
+#pragma unroll
+                    for (int c = 0; c < 9; c++) {
+                        uint32_t ch = sp[c];
+                        okc = okc && (ch >= 'A' && ch <= 'Z');
+                        key = (key << 5) | ((ch - 'A') & 31u);
+                    }
+                    valid = (okc && locate(T, key, loc[h], tg[h])) ? 1u : 0u;
+                }
+                tg[h] |= valid << 31;
+            }
+            // ---- two probe batches in flight ----
+            ProbeBatch B0, B1;
+            uint32_t r0[4], r1[4];
+            probe_issue(T, loc[0], tg[0], lane, B0);
+            if (total > 64) probe_issue(T, loc[1], tg[1], lane, B1);
+            probe_eval(T, B0, 0u, lane, r0);
+            if (total > 64) probe_eval(T, B1, 0u, lane, r1);
+            if (j == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    wtaxa[16 * k + q] = r0[k];
+                    if (total > 64) wtaxa[64 + 16 * k + q] = r1[k];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // ---- seedextend per fragment ----
+            if (do_seed) {
+                if (lane < F && my_win) seedextend_lds(wtaxa + wstart, my_win, min_seed, max_gap);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            // ---- aggregate ----
+            uint32_t t0 = lane < total ? wtaxa[lane] : 0u, t1 = 64 + lane < total ? wtaxa[64 + lane] : 0u;
+            bool keep0, keep1;
+            float c0, c1;
+            lds_count(wkeys, wcnt, t0, t1, lower_bound, keep0, keep1, c0, c1);
+            uint64_t errkey = NOERR;
+            Hit h0{NONE, NONE}, h1{NONE, NONE};
+            if (keep0) h0 = resolve(V, tree_like, t0, errkey);
+            if (keep1) h1 = resolve(V, tree_like, t1, errkey);
+            bool any = false;
+            uint32_t maxpre = 0;
+            if (h0.pre != NONE) { any = true; maxpre = h0.pre; }
+            if (h1.pre != NONE) { any = true; maxpre = max(maxpre, h1.pre); }
+            if (__any(errkey != NOERR)) {
+                uint64_t ek = wave_min64(errkey);
+                res_status = ((ek >> 32) & 1) ? UMGAP_READ_PANIC : UMGAP_READ_UNKNOWN_TAXON;
+                res_taxon = (uint32_t)ek;
+            } else if (!__any(any)) {
+                res_status = UMGAP_READ_EMPTY;
+                res_taxon = 1;
+            } else {
+                const uint32_t M = wave_max(any ? maxpre : 0u);
+                uint32_t hp = NONE;
+                if (h0.pre != NONE && h0.last < M) hp = h0.pre;
+                if (h1.pre != NONE && h1.last < M) hp = min(hp, h1.pre);
+                hp = wave_min(hp);
+                if (hp != NONE) res_taxon = V.psnap_of_pre[wave_argmin_depth(V, hp + 1, M, lane)];
+                else res_taxon = V.snap_of_pre[M];
+                res_status = res_taxon == NONE ? UMGAP_READ_PANIC : UMGAP_READ_OK;
+            }
+        }
+        if (lane == 0) {
+            out_taxon[r] = res_taxon;
+            out_status[r] = res_status;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace
 
 extern "C" int umgap_classify9_dev(umgap_index* ix, umgap_taxonomy* tx, int method, float lower_bound, int ranked_only,
@@ -165,6 +303,26 @@ extern "C" int umgap_classify9_dev(umgap_index* ix, umgap_taxonomy* tx, int meth
     if (g > 256 * 8) g = 256 * 8;
     hipLaunchKernelGGL(k_classify9, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, d_keys45, n_reads,
                        kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status);
+    UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}
+
+extern "C" int umgap_classify_prot9_dev(umgap_index* ix, umgap_taxonomy* tx, int method, float lower_bound, int ranked_only,
+                                        const uint8_t* d_bytes, const uint64_t* d_frag_offsets, size_t n_reads, uint32_t fragments_per_read,
+                                        int seedextend, uint32_t min_seed_size, uint32_t max_gap_size, uint32_t* d_out_taxon,
+                                        uint32_t* d_out_status, void* stream) {
+    if (!ix || !tx || (n_reads && (!d_bytes || !d_frag_offsets || !d_out_taxon || !d_out_status))) return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: null argument");
+    if (ix->kind != 9) return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: needs a 9-mer index");
+    if (fragments_per_read == 0 || fragments_per_read > PROT_MAX_FRAGS) return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: fragments_per_read must be in 1..16");
+    if (method != UMGAP_METHOD_TREE && method != UMGAP_METHOD_RMQ) return fail(UMGAP_ERR_INVALID, "unknown method");
+    if (ix->device != tx->device) return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: index and taxonomy live on different devices");
+    int rc = use_device(ix->device);
+    if (rc) return rc;
+    if (!n_reads) return UMGAP_OK;
+    size_t g = (n_reads + 3) / 4;
+    if (g > 256 * 8) g = 256 * 8;
+    hipLaunchKernelGGL(k_classify_prot9, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, d_bytes,
+                       d_frag_offsets, n_reads, fragments_per_read, seedextend ? 1u : 0u, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status);
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
 }

@@ -209,6 +209,51 @@ __global__ __launch_bounds__(256) void k_insert_synth(uint64_t* __restrict__ slo
     for (; i < n_keys; i += stride) insert_one(slots, m, nb, lo, hi, synth_key(i, a, b), taxon_of_row[i % n_tax], flags, stash);
 }
 
+// Index built from protein fragments: every 9-residue window of fragment i maps to taxa[i]; when the
+// same 9-mer occurs in several fragments the SMALLEST taxon wins (deterministic stand-in for the
+// LCA that `umgap joinkmers` would compute; only the synthetic proteome uses this).
+__global__ __launch_bounds__(256) void k_insert_windows(uint64_t* __restrict__ slots, uint32_t m, uint32_t nb, const uint8_t* __restrict__ bytes,
+                                                        const uint64_t* __restrict__ off, const uint32_t* __restrict__ taxa, size_t n_frag,
+                                                        uint32_t max_len, BuildFlags* flags) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, total = n_frag * max_len;
+    for (; g < total; g += stride) {
+        size_t i = g / max_len;
+        uint32_t w = (uint32_t)(g % max_len);
+        uint64_t o = off[i], len = off[i + 1] - o;
+        if (len < 9 || w + 9 > len) continue;
+        uint64_t key = 0;
+        bool ok = true;
+        for (int c = 0; c < 9; c++) {
+            uint32_t ch = bytes[o + w + c];
+            ok = ok && ch >= 'A' && ch <= 'Z';
+            key = (key << 5) | ((ch - 'A') & 31u);
+        }
+        if (!ok) continue;
+        uint32_t b, tag, val = taxa[i];
+        probe_of_key(key, m, b, tag);
+        bool done = false;
+        for (uint32_t d = 0; d <= MAX_DISP && !done; d++) {
+            uint32_t bucket = b + d;
+            if (bucket >= nb) bucket -= nb;
+            uint64_t* s = slots + (size_t)bucket * SLOTS;
+            uint32_t lo = tag | (d << R_BITS);
+            uint64_t entry = ((uint64_t)val << 32) | lo;
+            for (uint32_t k = 0; k < SLOTS && !done; k++) {
+                unsigned long long old = atomicCAS((unsigned long long*)(s + k), (unsigned long long)EMPTY_SLOT, (unsigned long long)entry);
+                if (old == EMPTY_SLOT) done = true;
+                else if (((uint32_t)old & TAG_MASK) == lo) {
+                    // same key already there: keep the smaller taxon (high word only: the low word may gain the overflow flag concurrently)
+                    atomicMin(reinterpret_cast<uint32_t*>(s + k) + 1, val);
+                    done = true;
+                }
+            }
+            if (!done) atomicOr((unsigned long long*)s, (unsigned long long)OVF_BIT);
+        }
+        if (!done) atomicAdd(&flags->too_full, 1ull);
+    }
+}
+
 // Partition a batch of keys by owner shard for the all-to-all exchange: key i goes to slot
 // perm[i] = owner*cap + (arrival index within that owner) of `send`; `cursor[o]` counts arrivals.
 // Wave-aggregated: one atomic per (wave, owner).  Keys beyond `cap` per owner set *overflow.
@@ -646,6 +691,23 @@ int umgap_index_owner9_dev(const umgap_index* ix, const uint64_t* d_keys, size_t
     if (rc) return rc;
     if (n) hipLaunchKernelGGL(k_owner9, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, d_keys, n, ix->view.m, ix->view.nb, n_shards, d_owner);
     UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}
+
+int umgap_index_build_windows9_dev(const uint8_t* d_bytes, const uint64_t* d_offsets, const uint32_t* d_taxa, size_t n_fragments,
+                                   uint32_t max_fragment_len, uint64_t expected_keys, double load, int device, umgap_index** out) {
+    if (!out || (n_fragments && (!d_bytes || !d_offsets || !d_taxa)) || max_fragment_len < 9) return fail(UMGAP_ERR_INVALID, "umgap_index_build_windows9_dev: bad argument");
+    umgap_index* ix = nullptr;
+    int rc = new_handle(device, &ix);
+    if (rc) return rc;
+    // no stash here: a chain longer than MAX_DISP grows the table instead (synthetic use only)
+    rc = build_with(ix, expected_keys, load, 0, 1, [&](umgap_index* x, BuildFlags* f, uint64_t*) {
+        if (n_fragments) hipLaunchKernelGGL(k_insert_windows, dim3(grid_for(n_fragments * (size_t)max_fragment_len, 256, 256 * 16)), dim3(256), 0, x->stream,
+                                            x->d_slots, x->view.m, x->view.nb, d_bytes, d_offsets, d_taxa, n_fragments, max_fragment_len, f);
+        return UMGAP_OK;
+    });
+    if (rc) { umgap_index_free(ix); return rc; }
+    *out = ix;
     return UMGAP_OK;
 }
 

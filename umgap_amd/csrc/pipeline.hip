@@ -174,6 +174,31 @@ __global__ __launch_bounds__(256) void k_synth_peptides(uint64_t first, size_t n
     }
 }
 
+// synthetic surface-B reads: read r = F fragments of `flen` residues, each a copy of a proteome
+// fragment of the read's source taxon family with point mutations (a mutated residue makes the up to
+// nine windows that cover it miss); 1 % of the residues become '*' (stop codon, not [A-Z]).
+__global__ __launch_bounds__(256) void k_synth_prot_reads(const uint8_t* __restrict__ proteome, uint64_t n_prot_frag, uint32_t flen, uint64_t seed,
+                                                          uint64_t first_read, size_t n_reads, uint32_t F, uint32_t mut_per_mille,
+                                                          uint8_t* __restrict__ out) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x, total = n_reads * F * flen;
+    for (; g < total; g += step) {
+        size_t r = g / ((size_t)F * flen);
+        uint32_t f = (uint32_t)((g / flen) % F), c = (uint32_t)(g % flen);
+        uint64_t r0 = splitmix64(seed ^ ((first_read + r) * 0x9E3779B97F4A7C15ull));
+        // the read's fragments come from neighbouring proteome fragments (same or nearby taxa)
+        uint64_t src = (r0 + (uint64_t)f * 0x632BE59BD9B4E019ull % 5) % n_prot_frag;
+        uint8_t ch = proteome[src * flen + c];
+        uint64_t hm = splitmix64(r0 ^ ((uint64_t)(f * flen + c + 1) * 0xD1B54A32D192ED03ull));
+        uint32_t roll = (uint32_t)(hm % 1000);
+        if (roll < mut_per_mille) {
+            uint32_t d = (uint32_t)((hm >> 20) % 20);
+            ch = roll < 10 ? (uint8_t)'*' : (uint8_t)('A' + d + (d >= 1) + (d >= 8) + (d >= 12) + (d >= 17) + (d >= 19));
+        }
+        out[g] = ch;
+    }
+}
+
 inline int grid_for(size_t n) {
     size_t g = (n + 255) / 256;
     if (g < 1) g = 1;
@@ -218,6 +243,17 @@ int umgap_synth_peptides_dev(uint64_t first, size_t n, uint64_t seed, const uint
     int rc = use_device(device);
     if (rc) return rc;
     if (n) hipLaunchKernelGGL(k_synth_peptides, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, first, n, seed, d_offsets, d_bytes);
+    UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}
+
+int umgap_synth_prot_reads_dev(const uint8_t* d_proteome, uint64_t n_proteome_fragments, uint32_t fragment_len, uint64_t seed, uint64_t first_read,
+                               size_t n_reads, uint32_t fragments_per_read, uint32_t mutations_per_mille, uint8_t* d_out, int device, void* stream) {
+    if (!d_proteome || !d_out || !n_proteome_fragments || !fragment_len || !fragments_per_read) return fail(UMGAP_ERR_INVALID, "umgap_synth_prot_reads_dev: bad argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    if (n_reads) hipLaunchKernelGGL(k_synth_prot_reads, dim3(grid_for(n_reads * fragments_per_read * (size_t)fragment_len)), dim3(256), 0, (hipStream_t)stream,
+                                    d_proteome, n_proteome_fragments, fragment_len, seed, first_read, n_reads, fragments_per_read, mutations_per_mille, d_out);
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
 }

@@ -59,40 +59,51 @@ __device__ __forceinline__ bool locate(const TableView& T, uint64_t key, uint32_
 // one wave instruction touches 16 buckets, each as one fully used 64-byte request.  The four
 // first-probe loads are issued back to back (4 sectors in flight per quad); a bucket that
 // overflowed at build time (rare) sends its quad down the displacement chain afterwards.
-// res[r] (quad-uniform) = taxon of key 16r + (lane >> 2), or `miss`.
-__device__ __forceinline__ void wave_probe64_vals(const TableView& T, uint32_t local, uint32_t tagv, uint32_t miss,
-                                                  uint32_t lane, uint32_t (&res)[4]) {
-    const uint32_t q = lane >> 2, j = lane & 3;
+// Split in two phases so that a caller can issue several batches of 64 before evaluating any.
+struct ProbeBatch {
     const u32x4* p[4];
     uint32_t want[4];
     u32x4 e[4];
+};
+__device__ __forceinline__ void probe_issue(const TableView& T, uint32_t local, uint32_t tagv, uint32_t lane, ProbeBatch& B) {
+    const uint32_t q = lane >> 2, j = lane & 3;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
         int src = 16 * r + (int)q;
         uint32_t l = (uint32_t)__shfl((int)local, src, 64);
-        want[r] = (uint32_t)__shfl((int)tagv, src, 64);
-        l = (want[r] >> 31) ? l : 0u;  // invalid key: read bucket 0, result discarded
-        p[r] = reinterpret_cast<const u32x4*>(T.slots) + ((size_t)l * 4 + j);
-        e[r] = __builtin_nontemporal_load(p[r]);
+        B.want[r] = (uint32_t)__shfl((int)tagv, src, 64);
+        l = (B.want[r] >> 31) ? l : 0u;  // invalid key: read bucket 0, result discarded
+        B.p[r] = reinterpret_cast<const u32x4*>(T.slots) + ((size_t)l * 4 + j);
+        B.e[r] = __builtin_nontemporal_load(B.p[r]);
     }
+}
+// res[r] (quad-uniform) = taxon of key 16r + (lane >> 2), or `miss`.
+__device__ __forceinline__ void probe_eval(const TableView& T, ProbeBatch& B, uint32_t miss, uint32_t lane, uint32_t (&res)[4]) {
+    const uint32_t j = lane & 3;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        const bool valid = want[r] >> 31;
-        uint32_t w = want[r] & R_MASK, val;
-        uint32_t f = eval_bucket(e[r], w, j, val);
+        const bool valid = B.want[r] >> 31;
+        uint32_t w = B.want[r] & R_MASK, val;
+        uint32_t f = eval_bucket(B.e[r], w, j, val);
         // displacement chain: only past buckets flagged as overflowed (halo keeps p in range)
         uint32_t d = 1;
         for (; valid && !(f & 1u) && (f & 2u) && d <= MAX_DISP; d++) {
-            p[r] += 4;
+            B.p[r] += 4;
             w += 1u << R_BITS;
-            f = eval_bucket(__builtin_nontemporal_load(p[r]), w, j, val);
+            f = eval_bucket(__builtin_nontemporal_load(B.p[r]), w, j, val);
         }
         res[r] = (valid && (f & 1u)) ? val : miss;
         if (valid && !(f & 1u) && (f & 2u) && T.n_stash) {  // chain exhausted through flagged buckets
-            uint32_t home = (uint32_t)((reinterpret_cast<const uint64_t*>(p[r]) - T.slots) / SLOTS) - MAX_DISP + T.home_lo;
-            res[r] = stash_lookup(T, home, want[r] & R_MASK, miss);
+            uint32_t home = (uint32_t)((reinterpret_cast<const uint64_t*>(B.p[r]) - T.slots) / SLOTS) - MAX_DISP + T.home_lo;
+            res[r] = stash_lookup(T, home, B.want[r] & R_MASK, miss);
         }
     }
+}
+__device__ __forceinline__ void wave_probe64_vals(const TableView& T, uint32_t local, uint32_t tagv, uint32_t miss,
+                                                  uint32_t lane, uint32_t (&res)[4]) {
+    ProbeBatch B;
+    probe_issue(T, local, tagv, lane, B);
+    probe_eval(T, B, miss, lane, res);
 }
 
 }  // namespace probe
