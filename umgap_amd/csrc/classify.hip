@@ -10,9 +10,10 @@
 // the aggregate of some waves runs under the memory waits of the others, and the 4 B/hit round
 // trip through HBM disappears.
 //
-// A wave owns R = floor(256 / stride) reads at a time (stride = k-mers per read, 84 -> R = 3,
-// 252 keys = four probe rounds of 64): probe -> taxa into the wave's LDS strip -> per read:
-// LDS hash-count, leaders gather {pre,last}, O(1) range-min LCA (aggregate.hip has the commentary).
+// A wave owns a group of reads at a time (stride = k-mers per read, 84 -> 12 reads = 1008 keys):
+// probe -> taxa into the wave's LDS strip -> seedextend on all the group's fragments in parallel
+// lanes -> per read: LDS hash-count, leaders gather {pre,last}, O(1) range-min LCA (aggregate.hip
+// has the commentary).
 #include "agg_common.hpp"
 #include "probe_common.hpp"
 
@@ -60,10 +61,54 @@ __device__ __forceinline__ void seedextend_lds(uint32_t* t, uint32_t n, uint32_t
     for (uint32_t i = cursor; i < n; i++) t[i] = 0;
 }
 
+// LCA* of one read whose taxa sit in LDS at rt[0..n) (n <= 128), shared by both fused kernels.
+__device__ __forceinline__ void lca_star_from_lds(const TaxView& V, bool tree_like, const uint32_t* rt, uint32_t n, float lower_bound,
+                                                  uint32_t* wkeys, uint32_t* wcnt, uint32_t lane, uint32_t& res_taxon, uint32_t& res_status) {
+    uint32_t t0 = lane < n ? rt[lane] : 0u, t1 = 64 + lane < n ? rt[64 + lane] : 0u;
+    bool keep0, keep1;
+    float c0, c1;
+    lds_count(wkeys, wcnt, t0, t1, lower_bound, keep0, keep1, c0, c1);
+    uint64_t errkey = NOERR;
+    Hit h0{NONE, NONE}, h1{NONE, NONE};
+    if (keep0) h0 = resolve(V, tree_like, t0, errkey);
+    if (keep1) h1 = resolve(V, tree_like, t1, errkey);
+    bool any = false;
+    uint32_t maxpre = 0;
+    if (h0.pre != NONE) { any = true; maxpre = h0.pre; }
+    if (h1.pre != NONE) { any = true; maxpre = max(maxpre, h1.pre); }
+    if (__any(errkey != NOERR)) {
+        uint64_t ek = wave_min64(errkey);
+        res_status = ((ek >> 32) & 1) ? UMGAP_READ_PANIC : UMGAP_READ_UNKNOWN_TAXON;
+        res_taxon = (uint32_t)ek;
+    } else if (!__any(any)) {
+        res_status = UMGAP_READ_EMPTY;   // literal "1" (src/commands/taxa2agg.rs:174-175)
+        res_taxon = 1;
+    } else {
+        const uint32_t M = wave_max(any ? maxpre : 0u);
+        uint32_t hp = NONE;
+        if (h0.pre != NONE && h0.last < M) hp = h0.pre;
+        if (h1.pre != NONE && h1.last < M) hp = min(hp, h1.pre);
+        hp = wave_min(hp);
+        if (hp != NONE) res_taxon = V.psnap_of_pre[wave_argmin_depth(V, hp + 1, M, lane)];
+        else res_taxon = V.snap_of_pre[M];
+        res_status = res_taxon == NONE ? UMGAP_READ_PANIC : UMGAP_READ_OK;
+    }
+}
+
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+constexpr uint32_t STRIP = 1024;  // taxa per wave held in LDS between the stages (4 KB)
+
+// A wave owns a GROUP of G = min(STRIP / stride, 64 / frags) reads at a time: all their keys are
+// probed (chunks of 64, two chunks in flight) into the LDS strip, seedextend then runs on all
+// G * frags fragments at once (one lane each), and the G reads are aggregated one after another.
 __global__ __launch_bounds__(256) void k_classify9(TableView T, TaxView V, int method, const uint64_t* __restrict__ keys,
                                                    size_t n_reads, uint32_t stride, uint32_t frags, uint32_t min_seed, uint32_t max_gap,
                                                    float lower_bound, uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status) {
-    __shared__ uint32_t lds_taxa[4][256], lds_keys[4][256], lds_cnt[4][256];
+    __shared__ uint32_t lds_taxa[4][STRIP], lds_keys[4][256], lds_cnt[4][256];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
     uint32_t* wtaxa = lds_taxa[wv];
     uint32_t* wkeys = lds_keys[wv];
@@ -71,77 +116,59 @@ __global__ __launch_bounds__(256) void k_classify9(TableView T, TaxView V, int m
 #pragma unroll
     for (int i = 0; i < 4; i++) { wkeys[lane + 64 * i] = 0u; wcnt[lane + 64 * i] = 0u; }
     const bool tree_like = method != UMGAP_METHOD_RMQ;
-    const uint32_t R = 256u / stride;                     // reads per wave iteration (stride <= 128 => R >= 2)
+    uint32_t G = STRIP / stride;
+    if (frags && G * frags > 64) G = 64 / frags;
     const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
-    const size_t n_groups = (n_reads + R - 1) / R;
+    const size_t n_groups = (n_reads + G - 1) / G;
     for (size_t g = wave0; g < n_groups; g += nwaves) {
-        const size_t r0 = g * R;
-        const uint32_t nr = (uint32_t)min((size_t)R, n_reads - r0);
-        const uint32_t nk = nr * stride;                   // keys of this group (<= 256)
+        const size_t r0 = g * G;
+        const uint32_t nr = (uint32_t)min((size_t)G, n_reads - r0);
+        const uint32_t nk = nr * stride;                   // keys of this group (<= STRIP)
         const uint64_t* kp = keys + r0 * stride;
-        // ---- probe: up to four rounds of 64 keys, results into the LDS strip ----
-        for (uint32_t c = 0; c * 64 < nk; c++) {
-            uint32_t i = c * 64 + lane, local = 0, tag = 0, valid = 0;
-            if (i < nk) {
-                uint64_t key = __builtin_nontemporal_load(kp + i);
-                valid = locate(T, key, local, tag) ? 1u : 0u;
+        // ---- probe: chunks of 64 keys, two chunks (8 sectors per quad) in flight ----
+        for (uint32_t c = 0; c * 64 < nk; c += 2) {
+            ProbeBatch B0, B1;
+            uint32_t res0[4], res1[4];
+            const bool two = (c + 1) * 64 < nk;
+            {
+                uint32_t i = c * 64 + lane, local = 0, tag = 0, valid = 0;
+                if (i < nk) valid = locate(T, __builtin_nontemporal_load(kp + i), local, tag) ? 1u : 0u;
+                probe_issue(T, local, tag | (valid << 31), lane, B0);
             }
-            uint32_t res[4];
-            wave_probe64_vals(T, local, tag | (valid << 31), 0u, lane, res);
+            if (two) {
+                uint32_t i = (c + 1) * 64 + lane, local = 0, tag = 0, valid = 0;
+                if (i < nk) valid = locate(T, __builtin_nontemporal_load(kp + i), local, tag) ? 1u : 0u;
+                probe_issue(T, local, tag | (valid << 31), lane, B1);
+            }
+            probe_eval(T, B0, 0u, lane, res0);
+            if (two) probe_eval(T, B1, 0u, lane, res1);
             if (j == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) wtaxa[c * 64 + 16 * r + q] = res[r];   // slots >= nk hold 0
+                for (int r = 0; r < 4; r++) {
+                    uint32_t i0 = c * 64 + 16 * r + q, i1 = i0 + 64;
+                    if (i0 < nk) wtaxa[i0] = res0[r];
+                    if (two && i1 < nk) wtaxa[i1] = res1[r];
+                }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // ---- seedextend per fragment (one lane per fragment) ----
+        wave_lds_sync();
+        // ---- seedextend per fragment (one lane per fragment, nr * frags <= 64) ----
         if (frags) {
             const uint32_t flen = stride / frags;
             if (lane < nr * frags) seedextend_lds(wtaxa + lane * flen, flen, min_seed, max_gap);
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
         }
         // ---- aggregate each read of the group ----
         for (uint32_t k = 0; k < nr; k++) {
-            const uint32_t* rt = wtaxa + k * stride;
-            uint32_t t0 = lane < stride ? rt[lane] : 0u, t1 = 64 + lane < stride ? rt[64 + lane] : 0u;
-            bool keep0, keep1;
-            float c0, c1;
-            lds_count(wkeys, wcnt, t0, t1, lower_bound, keep0, keep1, c0, c1);
-            uint64_t errkey = NOERR;
-            Hit h0{NONE, NONE}, h1{NONE, NONE};
-            if (keep0) h0 = resolve(V, tree_like, t0, errkey);
-            if (keep1) h1 = resolve(V, tree_like, t1, errkey);
-            bool any = false;
-            uint32_t maxpre = 0, res_taxon, res_status;
-            if (h0.pre != NONE) { any = true; maxpre = h0.pre; }
-            if (h1.pre != NONE) { any = true; maxpre = max(maxpre, h1.pre); }
-            if (__any(errkey != NOERR)) {
-                uint64_t ek = wave_min64(errkey);
-                res_status = ((ek >> 32) & 1) ? UMGAP_READ_PANIC : UMGAP_READ_UNKNOWN_TAXON;
-                res_taxon = (uint32_t)ek;
-            } else if (!__any(any)) {
-                res_status = UMGAP_READ_EMPTY;
-                res_taxon = 1;
-            } else {
-                const uint32_t M = wave_max(any ? maxpre : 0u);
-                uint32_t hp = NONE;
-                if (h0.pre != NONE && h0.last < M) hp = h0.pre;
-                if (h1.pre != NONE && h1.last < M) hp = min(hp, h1.pre);
-                hp = wave_min(hp);
-                if (hp != NONE) res_taxon = V.psnap_of_pre[wave_argmin_depth(V, hp + 1, M, lane)];
-                else res_taxon = V.snap_of_pre[M];
-                res_status = res_taxon == NONE ? UMGAP_READ_PANIC : UMGAP_READ_OK;
-            }
+            uint32_t res_taxon, res_status;
+            lca_star_from_lds(V, tree_like, wtaxa + k * stride, stride, lower_bound, wkeys, wcnt, lane, res_taxon, res_status);
             if (lane == 0) {
                 out_taxon[r0 + k] = res_taxon;
                 out_status[r0 + k] = res_status;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
     }
 }
 
@@ -153,13 +180,14 @@ __global__ __launch_bounds__(256) void k_classify9(TableView T, TaxView V, int m
 // all len-8 windows of a fragment, none if it is shorter than 9), two probe batches (128
 // windows) are issued back to back, then seedextend per fragment and LCA* as in k_classify9.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t PROT_MAX_FRAGS = 16, PROT_MAX_BYTES = 384, PROT_MAX_WINDOWS = 128;
+constexpr uint32_t PROT_MAX_FRAGS = 16, PROT_MAX_BYTES = 384, PROT_MAX_WINDOWS = 128, PROT_GROUP = STRIP / PROT_MAX_WINDOWS;  // 8 reads
 
 __global__ __launch_bounds__(256) void k_classify_prot9(TableView T, TaxView V, int method, const uint8_t* __restrict__ bytes,
                                                         const uint64_t* __restrict__ foff, size_t n_reads, uint32_t F, uint32_t do_seed,
                                                         uint32_t min_seed, uint32_t max_gap, float lower_bound,
                                                         uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status) {
-    __shared__ uint32_t lds_taxa[4][PROT_MAX_WINDOWS], lds_keys[4][256], lds_cnt[4][256];
+    __shared__ uint32_t lds_taxa[4][STRIP], lds_keys[4][256], lds_cnt[4][256];
+    __shared__ uint32_t lds_fstart[4][64], lds_fwin[4][64], lds_total[4][PROT_GROUP];
     __shared__ uint8_t lds_bytes[4][PROT_MAX_BYTES];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
     uint32_t* wtaxa = lds_taxa[wv];
@@ -169,46 +197,50 @@ __global__ __launch_bounds__(256) void k_classify_prot9(TableView T, TaxView V, 
 #pragma unroll
     for (int i = 0; i < 4; i++) { wkeys[lane + 64 * i] = 0u; wcnt[lane + 64 * i] = 0u; }
     const bool tree_like = method != UMGAP_METHOD_RMQ;
+    // group size: PROT_GROUP reads (128 strip slots each), and at most 64 fragments for the seedextend lanes
+    uint32_t G = PROT_GROUP;
+    if (G * F > 64) G = 64 / F;
     const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
-    for (size_t r = wave0; r < n_reads; r += nwaves) {
-        // fragment boundaries relative to the read's first byte; lane f holds start of fragment f (f <= F)
-        const uint64_t base = foff[r * F];
-        uint32_t my_off = lane <= F ? (uint32_t)(foff[r * F + lane] - base) : 0u;
-        const uint32_t nbytes = __builtin_amdgcn_readlane(my_off, F);   // F is wave-uniform (kernel argument <= 16)
-        // (shuffle with every lane active: ds_bpermute returns 0 for a source lane that is masked off)
-        const uint32_t next_off = (uint32_t)__shfl((int)my_off, (int)((lane + 1) & 63), 64);
-        uint32_t my_len = lane < F ? next_off - my_off : 0u;
-        uint32_t my_win = my_len >= 9 ? my_len - 8 : 0u;                 // windows of fragment `lane`
-        // exclusive prefix of the window counts over the F fragments (F <= 16: serial over readlanes)
-        uint32_t wstart = 0, total = 0;
-        for (uint32_t f = 0; f < F; f++) {
-            uint32_t wf = __builtin_amdgcn_readlane(my_win, f);
-            if (lane == f) wstart = total;
-            total += wf;
-        }
-        uint32_t res_taxon = 0, res_status = UMGAP_READ_OK;
-        if (nbytes > PROT_MAX_BYTES || total > PROT_MAX_WINDOWS) {
-            res_status = 4u;  // UMGAP_READ_UNSUPPORTED: use lookup_prot9 + aggregate for such reads
-        } else {
-            // ---- stage the read's bytes in LDS ----
+    const size_t n_groups = (n_reads + G - 1) / G;
+    for (size_t grp = wave0; grp < n_groups; grp += nwaves) {
+        const size_t r0 = grp * G;
+        const uint32_t nr = (uint32_t)min((size_t)G, n_reads - r0);
+        // ---- per read: stage bytes, pack windows, probe into the read's strip region [k*128, ...) ----
+        for (uint32_t k = 0; k < nr; k++) {
+            const size_t r = r0 + k;
+            // fragment boundaries relative to the read's first byte; lane f holds the start of fragment f (f <= F)
+            const uint64_t base = foff[r * F];
+            uint32_t my_off = lane <= F ? (uint32_t)(foff[r * F + lane] - base) : 0u;
+            const uint32_t nbytes = __builtin_amdgcn_readlane(my_off, F);   // F is wave-uniform (kernel argument <= 16)
+            // (shuffle with every lane active: ds_bpermute returns 0 for a source lane that is masked off)
+            const uint32_t next_off = (uint32_t)__shfl((int)my_off, (int)((lane + 1) & 63), 64);
+            uint32_t my_len = lane < F ? next_off - my_off : 0u;
+            uint32_t my_win = my_len >= 9 ? my_len - 8 : 0u;                 // windows of fragment `lane`
+            uint32_t wstart = 0, total = 0;                                   // exclusive prefix over the F fragments
+            for (uint32_t f = 0; f < F; f++) {
+                uint32_t wf = __builtin_amdgcn_readlane(my_win, f);
+                if (lane == f) wstart = total;
+                total += wf;
+            }
+            const bool unsupported = nbytes > PROT_MAX_BYTES || total > PROT_MAX_WINDOWS;
+            if (lane < F) { lds_fstart[wv][k * F + lane] = k * PROT_MAX_WINDOWS + wstart; lds_fwin[wv][k * F + lane] = unsupported ? 0u : my_win; }
+            if (lane == 0) lds_total[wv][k] = unsupported ? 0xFFFFFFFFu : total;
+            if (unsupported) continue;   // wave-uniform
             for (uint32_t i = lane; i < nbytes; i += 64) wbytes[i] = bytes[base + i];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // ---- every lane packs the windows lane and lane+64 from LDS ----
+            wave_lds_sync();
             uint32_t loc[2] = {0, 0}, tg[2] = {0, 0};
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                uint32_t g = lane + 64 * h, valid = 0;
-                if (g < total) {
-                    uint32_t f = 0, ws = 0, fo = 0;
-                    for (uint32_t k = 0; k < F; k++) {   // the fragment that owns window g
-                        uint32_t wk = __builtin_amdgcn_readlane(wstart, k), nk = __builtin_amdgcn_readlane(my_win, k);
-                        uint32_t ok = __builtin_amdgcn_readlane(my_off, k);
-                        if (g >= wk && g < wk + nk) { f = k; ws = wk; fo = ok; }
+                uint32_t gw = lane + 64 * h, valid = 0;
+                if (gw < total) {
+                    uint32_t ws = 0, fo = 0;
+                    for (uint32_t f = 0; f < F; f++) {   // the fragment that owns window gw
+                        uint32_t wk = __builtin_amdgcn_readlane(wstart, f), nk = __builtin_amdgcn_readlane(my_win, f);
+                        uint32_t ok = __builtin_amdgcn_readlane(my_off, f);
+                        if (gw >= wk && gw < wk + nk) { ws = wk; fo = ok; }
                     }
-                    (void)f;
-                    const uint8_t* sp = wbytes + fo + (g - ws);
+                    const uint8_t* sp = wbytes + fo + (gw - ws);
                     uint64_t key = 0;
                     bool okc = true;
 #pragma unroll
@@ -221,65 +253,39 @@ __global__ __launch_bounds__(256) void k_classify_prot9(TableView T, TaxView V, 
                 }
                 tg[h] |= valid << 31;
             }
-            // ---- two probe batches in flight ----
             ProbeBatch B0, B1;
-            uint32_t r0[4], r1[4];
+            uint32_t p0[4], p1[4];
             probe_issue(T, loc[0], tg[0], lane, B0);
             if (total > 64) probe_issue(T, loc[1], tg[1], lane, B1);
-            probe_eval(T, B0, 0u, lane, r0);
-            if (total > 64) probe_eval(T, B1, 0u, lane, r1);
+            probe_eval(T, B0, 0u, lane, p0);
+            if (total > 64) probe_eval(T, B1, 0u, lane, p1);
+            uint32_t* rt = wtaxa + k * PROT_MAX_WINDOWS;
             if (j == 0) {
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    wtaxa[16 * k + q] = r0[k];
-                    if (total > 64) wtaxa[64 + 16 * k + q] = r1[k];
+                for (int x = 0; x < 4; x++) {
+                    rt[16 * x + q] = p0[x];
+                    if (total > 64) rt[64 + 16 * x + q] = p1[x];
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            // ---- seedextend per fragment ----
-            if (do_seed) {
-                if (lane < F && my_win) seedextend_lds(wtaxa + wstart, my_win, min_seed, max_gap);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-            }
-            // ---- aggregate ----
-            uint32_t t0 = lane < total ? wtaxa[lane] : 0u, t1 = 64 + lane < total ? wtaxa[64 + lane] : 0u;
-            bool keep0, keep1;
-            float c0, c1;
-            lds_count(wkeys, wcnt, t0, t1, lower_bound, keep0, keep1, c0, c1);
-            uint64_t errkey = NOERR;
-            Hit h0{NONE, NONE}, h1{NONE, NONE};
-            if (keep0) h0 = resolve(V, tree_like, t0, errkey);
-            if (keep1) h1 = resolve(V, tree_like, t1, errkey);
-            bool any = false;
-            uint32_t maxpre = 0;
-            if (h0.pre != NONE) { any = true; maxpre = h0.pre; }
-            if (h1.pre != NONE) { any = true; maxpre = max(maxpre, h1.pre); }
-            if (__any(errkey != NOERR)) {
-                uint64_t ek = wave_min64(errkey);
-                res_status = ((ek >> 32) & 1) ? UMGAP_READ_PANIC : UMGAP_READ_UNKNOWN_TAXON;
-                res_taxon = (uint32_t)ek;
-            } else if (!__any(any)) {
-                res_status = UMGAP_READ_EMPTY;
-                res_taxon = 1;
-            } else {
-                const uint32_t M = wave_max(any ? maxpre : 0u);
-                uint32_t hp = NONE;
-                if (h0.pre != NONE && h0.last < M) hp = h0.pre;
-                if (h1.pre != NONE && h1.last < M) hp = min(hp, h1.pre);
-                hp = wave_min(hp);
-                if (hp != NONE) res_taxon = V.psnap_of_pre[wave_argmin_depth(V, hp + 1, M, lane)];
-                else res_taxon = V.snap_of_pre[M];
-                res_status = res_taxon == NONE ? UMGAP_READ_PANIC : UMGAP_READ_OK;
+            wave_lds_sync();   // also protects wbytes against the next read's staging
+        }
+        wave_lds_sync();
+        // ---- seedextend: all fragments of the group at once, one lane each ----
+        if (do_seed) {
+            if (lane < nr * F && lds_fwin[wv][lane]) seedextend_lds(wtaxa + lds_fstart[wv][lane], lds_fwin[wv][lane], min_seed, max_gap);
+            wave_lds_sync();
+        }
+        // ---- aggregate ----
+        for (uint32_t k = 0; k < nr; k++) {
+            const uint32_t total = lds_total[wv][k];
+            uint32_t res_taxon = 0, res_status = 4u;   // UMGAP_READ_UNSUPPORTED: use lookup_prot9 + aggregate for such reads
+            if (total != 0xFFFFFFFFu) lca_star_from_lds(V, tree_like, wtaxa + k * PROT_MAX_WINDOWS, total, lower_bound, wkeys, wcnt, lane, res_taxon, res_status);
+            if (lane == 0) {
+                out_taxon[r0 + k] = res_taxon;
+                out_status[r0 + k] = res_status;
             }
         }
-        if (lane == 0) {
-            out_taxon[r] = res_taxon;
-            out_status[r] = res_status;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+        wave_lds_sync();
     }
 }
 
@@ -292,13 +298,15 @@ extern "C" int umgap_classify9_dev(umgap_index* ix, umgap_taxonomy* tx, int meth
     if (!ix || !tx || (n_reads && (!d_keys45 || !d_out_taxon || !d_out_status))) return fail(UMGAP_ERR_INVALID, "umgap_classify9_dev: null argument");
     if (kmers_per_read == 0 || kmers_per_read > 128) return fail(UMGAP_ERR_INVALID, "umgap_classify9_dev: kmers_per_read must be in 1..128 (use lookup9 + aggregate for longer reads)");
     if (fragments_per_read && (kmers_per_read % fragments_per_read) != 0) return fail(UMGAP_ERR_INVALID, "umgap_classify9_dev: kmers_per_read must be a multiple of fragments_per_read");
-    if (fragments_per_read * (256u / kmers_per_read) > 64) return fail(UMGAP_ERR_INVALID, "umgap_classify9_dev: too many fragments per wave");
+    if (fragments_per_read > 64) return fail(UMGAP_ERR_INVALID, "umgap_classify9_dev: at most 64 fragments per read");
     if (method != UMGAP_METHOD_TREE && method != UMGAP_METHOD_RMQ) return fail(UMGAP_ERR_INVALID, "unknown method");
     if (ix->device != tx->device) return fail(UMGAP_ERR_INVALID, "umgap_classify9_dev: index and taxonomy live on different devices");
     int rc = use_device(ix->device);
     if (rc) return rc;
     if (!n_reads) return UMGAP_OK;
-    size_t groups = (n_reads + (256u / kmers_per_read) - 1) / (256u / kmers_per_read);
+    uint32_t G = 1024u / kmers_per_read;
+    if (fragments_per_read && G * fragments_per_read > 64) G = 64 / fragments_per_read;
+    size_t groups = (n_reads + G - 1) / G;
     size_t g = (groups + 3) / 4;
     if (g > 256 * 8) g = 256 * 8;
     hipLaunchKernelGGL(k_classify9, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, d_keys45, n_reads,
@@ -319,7 +327,9 @@ extern "C" int umgap_classify_prot9_dev(umgap_index* ix, umgap_taxonomy* tx, int
     int rc = use_device(ix->device);
     if (rc) return rc;
     if (!n_reads) return UMGAP_OK;
-    size_t g = (n_reads + 3) / 4;
+    uint32_t G = 8;
+    if (G * fragments_per_read > 64) G = 64 / fragments_per_read;
+    size_t g = ((n_reads + G - 1) / G + 3) / 4;
     if (g > 256 * 8) g = 256 * 8;
     hipLaunchKernelGGL(k_classify_prot9, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, d_bytes,
                        d_frag_offsets, n_reads, fragments_per_read, seedextend ? 1u : 0u, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status);
