@@ -830,3 +830,53 @@ def test_classify_prot9_ragged_fragments(api, torch_cuda):
         t, s = d_t.cpu().numpy().view(np.uint32), d_s.cpu().numpy().view(np.uint32)
         nbad, bad, wt, ws = agg.taxa2agg_check(np.array(hits, np.uint32), np.array(roffs, np.uint64), t, s, lower_bound=2.0)
         assert nbad == 0, (F, bad)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE.json configs[2] at full size: 50 M pairs (5 x 10 M), 8 G-key table, size-independent properties
+# ---------------------------------------------------------------------------------------------
+def test_full_size_50M_pairs_properties(api, torch_cuda):
+    torch = torch_cuda
+    from umgap_amd.synth import ADD_B, KMERS_PER_PAIR, MUL_A, SyntheticWorkload
+    free, _ = torch.cuda.mem_get_info()
+    if free < 200e9:
+        pytest.skip("needs ~150 GB of free HBM")
+    n_tax, n_keys, B = 2_500_000, 8_000_000_000, 10_000_000
+    w = SyntheticWorkload(n_tax=n_tax, n_keys=n_keys, id_space=int(n_tax * 1.4), load_factor=0.6)
+    assert 100e9 < w.index.table_bytes < 115e9          # 13.3 B/key at load 0.6: no grow-retries
+    snap = w.taxonomy.snapping(False)
+    ot = O.Taxonomy.from_arrays(w.ids, w.parents, w.valid, w.rank)
+    agg = O.Aggregator(ot, "tree", "lca*")
+    p = O.SynthIndexParams(n_keys, n_tax, MUL_A, ADD_B)
+    rng = np.random.default_rng(50)
+    d_t = torch.empty(B, dtype=torch.int32, device="cuda")
+    d_s = torch.empty_like(d_t)
+    d_t2, d_s2 = torch.empty_like(d_t), torch.empty_like(d_t)
+    hist = np.zeros(4, np.int64)
+    distinct = set()
+    for b in range(5):
+        keys = w.reads(b * B, B)
+        api.classify9_dev(w.index, w.taxonomy, keys, B, KMERS_PER_PAIR, d_t, d_s, method="tree", lower_bound=2.0)
+        # (1) fused == unfused, bit for bit, on the whole batch
+        hits = w.index.lookup9_dev(keys)
+        w.taxonomy.aggregate_strided_dev(hits, KMERS_PER_PAIR, B, d_t2, d_s2, method="tree", strategy="lca*", lower_bound=2.0)
+        torch.cuda.synchronize()
+        assert torch.equal(d_t, d_t2) and torch.equal(d_s, d_s2)
+        t, s = d_t.cpu().numpy().view(np.uint32), d_s.cpu().numpy().view(np.uint32)
+        # (2) output domain: status OK/EMPTY only; EMPTY prints the literal 1; every answer is its own snap (idempotent)
+        hist += np.bincount(s, minlength=4)[:4]
+        assert ((s == 0) | (s == 1)).all() and (t[s == 1] == 1).all()
+        assert (snap[t] == t).all()
+        distinct.update(np.unique(t[:200_000]).tolist())
+        # (3) a random sample of reads against the oracle, end to end (closed-form index + literal LCA*)
+        sample = np.sort(rng.choice(B, 20_000, replace=False))
+        kh = keys.view(-1, KMERS_PER_PAIR)[torch.from_numpy(sample).cuda()].cpu().numpy().view(np.uint64).reshape(-1)
+        want_hits = O.synth_lookup9(p, w.taxon_of_row, kh, 0)
+        got_hits = hits.view(-1, KMERS_PER_PAIR)[torch.from_numpy(sample).cuda()].cpu().numpy().view(np.uint32).reshape(-1)
+        assert (want_hits == got_hits).all()
+        offs = np.arange(len(sample) + 1, dtype=np.uint64) * KMERS_PER_PAIR
+        nbad, bad, _, _ = agg.taxa2agg_check(want_hits, offs, t[sample], s[sample], lower_bound=2.0, nthreads=8)
+        assert nbad == 0, bad
+        del keys, hits
+    assert hist[0] > 0.9 * 5 * B and hist[2] == 0 and hist[3] == 0
+    assert len(distinct) > 50_000      # the answers are spread over the taxonomy, not degenerate
