@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--seedextend", action="store_true", help="insert seedextend -g1 -s3 per fragment between lookup and aggregate")
+    ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (process group, barriers, sharded extra) even with one rank")
     ap.add_argument("--unfused", action="store_true", help="run lookup and aggregate as separate kernels (hits through HBM)")
     return ap.parse_args()
 
@@ -160,9 +161,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
     mode = args.mode
     if mode == "auto":
         mode = "replica"
@@ -217,7 +220,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -229,7 +232,7 @@ def main():
         step(args.warmup + i, i)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -304,13 +307,13 @@ def main():
         del d_out
         out["roofline"]["measured_gather_GBps"] = ceil
         out["roofline"]["frac_of_measured_64B_gather"] = round(lookups * 64 / (kernel_ms * 1e-3) / 1e9 / ceil["64"], 4)
-    if world > 1 and args.mode == "auto":
+    if multi and args.mode == "auto":
         out["sharded"] = sharded_extra(args, w, keys, rank, world, local_rank, device, B, d_hits, d_taxon, d_status, out)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.n_tax, w.ids, w.parents, w.valid, w.rank, w.taxonomy._h, w.d_taxon_of_row, w.d_row_of_id, device)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 

@@ -255,40 +255,63 @@ __global__ __launch_bounds__(256) void k_insert_windows(uint64_t* __restrict__ s
 }
 
 // Partition a batch of keys by owner shard for the all-to-all exchange: key i goes to slot
-// perm[i] = owner*cap + (arrival index within that owner) of `send`; `cursor[o]` counts arrivals.
-// Wave-aggregated: one atomic per (wave, owner).  Keys beyond `cap` per owner set *overflow.
+// perm[i] = owner*cap + position of `send`; `cursor[o]` counts arrivals per owner.
+// A workgroup handles a tile of 4096 keys: positions inside the tile are handed out through LDS
+// counters (one ds_add per wave and owner), then ONE global atomic per owner reserves the tile's
+// range -- 8 global atomics per 4096 keys instead of one per wave and owner (which serialises on a
+// few addresses: 180 ms for 840 M keys).  A tile's keys for one owner land in one compact range,
+// so the send writes and the later gather through `perm` stay cache friendly.
+constexpr int PART_PER_THREAD = 16;
 __global__ __launch_bounds__(256) void k_partition(const uint64_t* __restrict__ keys, size_t n, uint32_t m, uint32_t nb,
                                                    uint32_t n_shards, uint64_t cap, uint64_t* __restrict__ send,
                                                    int64_t* __restrict__ perm, unsigned long long* __restrict__ cursor,
                                                    uint32_t* __restrict__ overflow) {
+    __shared__ uint32_t cnt[64];
+    __shared__ unsigned long long base[64];
     const uint32_t lane = threadIdx.x & 63;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    const size_t n_round = (n + 63) & ~(size_t)63;
-    for (; i < n_round; i += stride) {
-        uint32_t owner = 0xFFFFFFFFu;
-        uint64_t key = 0;
-        if (i < n) {
-            key = keys[i];
-            uint32_t b, tag;
-            probe_of_key(key, m, b, tag);
-            uint32_t s = (uint32_t)(((uint64_t)b * n_shards) / nb);
-            while ((uint64_t)nb * s / n_shards > b) s--;
-            while ((uint64_t)nb * (s + 1) / n_shards <= b) s++;
-            owner = s;
+    const size_t tile = (size_t)blockDim.x * PART_PER_THREAD;
+    for (size_t t0 = (size_t)blockIdx.x * tile; t0 < n; t0 += (size_t)gridDim.x * tile) {
+        if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+        __syncthreads();
+        uint64_t key[PART_PER_THREAD];
+        uint32_t own[PART_PER_THREAD], lpos[PART_PER_THREAD];
+#pragma unroll
+        for (int k = 0; k < PART_PER_THREAD; k++) {
+            size_t i = t0 + (size_t)k * blockDim.x + threadIdx.x;
+            own[k] = 0xFFFFFFFFu;
+            key[k] = 0;
+            lpos[k] = 0;
+            if (i < n) {
+                key[k] = keys[i];
+                uint32_t b, tag;
+                probe_of_key(key[k], m, b, tag);
+                uint32_t s = (uint32_t)(((uint64_t)b * n_shards) / nb);
+                while ((uint64_t)nb * s / n_shards > b) s--;
+                while ((uint64_t)nb * (s + 1) / n_shards <= b) s++;
+                own[k] = s;
+            }
+            for (uint32_t o = 0; o < n_shards; o++) {     // wave-aggregated LDS reservation
+                uint64_t mask = __ballot(own[k] == o);
+                if (!mask) continue;
+                uint32_t leader = (uint32_t)__builtin_ctzll(mask), wbase = 0;
+                if (lane == leader) wbase = atomicAdd(&cnt[o], (uint32_t)__builtin_popcountll(mask));
+                wbase = (uint32_t)__shfl((int)wbase, (int)leader, 64);
+                if (own[k] == o) lpos[k] = wbase + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            }
         }
-        for (uint32_t o = 0; o < n_shards; o++) {
-            uint64_t mask = __ballot(owner == o);
-            if (!mask) continue;
-            unsigned long long base = 0;
-            if (lane == (uint32_t)__builtin_ctzll(mask)) base = atomicAdd(&cursor[o], (unsigned long long)__builtin_popcountll(mask));
-            base = ((unsigned long long)__shfl((int)(base >> 32), __builtin_ctzll(mask), 64) << 32) | (uint32_t)__shfl((int)(uint32_t)base, __builtin_ctzll(mask), 64);
-            if (owner == o) {
-                uint64_t pos = base + (uint64_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-                if (pos < cap) { send[(size_t)o * cap + pos] = key; perm[i] = (int64_t)((size_t)o * cap + pos); }
+        __syncthreads();
+        if (threadIdx.x < n_shards) base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], (unsigned long long)cnt[threadIdx.x]) : 0ull;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PART_PER_THREAD; k++) {
+            size_t i = t0 + (size_t)k * blockDim.x + threadIdx.x;
+            if (own[k] != 0xFFFFFFFFu) {
+                uint64_t pos = base[own[k]] + lpos[k];
+                if (pos < cap) { send[(size_t)own[k] * cap + pos] = key[k]; perm[i] = (int64_t)((size_t)own[k] * cap + pos); }
                 else { perm[i] = 0; atomicExch(overflow, 1u); }
             }
         }
+        __syncthreads();
     }
 }
 
@@ -716,7 +739,7 @@ int umgap_index_partition9_dev(const umgap_index* ix, const uint64_t* d_keys, si
     if (!ix || !n_shards || n_shards > 64 || (n && (!d_keys || !d_send || !d_perm)) || !d_cursor || !d_overflow) return fail(UMGAP_ERR_INVALID, "umgap_index_partition9_dev: bad argument");
     int rc = use_device(ix->device);
     if (rc) return rc;
-    if (n) hipLaunchKernelGGL(k_partition, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, d_keys, n, ix->view.m, ix->view.nb, n_shards, cap,
+    if (n) hipLaunchKernelGGL(k_partition, dim3(grid_for((n + PART_PER_THREAD - 1) / PART_PER_THREAD)), dim3(256), 0, (hipStream_t)stream, d_keys, n, ix->view.m, ix->view.nb, n_shards, cap,
                               d_send, d_perm, (unsigned long long*)d_cursor, d_overflow);
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;

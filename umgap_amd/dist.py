@@ -3,7 +3,8 @@ index sharded by bucket range, read keys / hits exchanged with torch.distributed
 (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
 
 Per step on every rank (B local pairs, K = 84 B keys):
-    partition : keys -> N regions of `cap` slots by owner shard (HIP kernel, one atomic per wave and owner)
+    partition : keys -> N regions of `cap` slots by owner shard (HIP kernel: LDS counters per 4096-key tile,
+                one global atomic per owner and tile)
     exchange  : all_to_all_single(keys)          8 B per key, each rank sends ~K/N to every peer
     probe     : local table shard (the same quad-probe kernel)
     exchange  : all_to_all_single(taxa)          4 B per key back
