@@ -29,7 +29,7 @@ def splitmix(x):
 
 def peptides(first, n, seed):
     idx = torch.arange(first, first + n, dtype=torch.int64, device=dev)
-    lens = 12 + (splitmix(idx ^ seed) & 0x7FFFFFFF) % 34          # 12..45 residues
+    lens = 14 + (splitmix(idx ^ seed) & 0x7FFFFFFF) % 32          # 14..45 residues (12-mers would collide at 1 G keys)
     offs = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     torch.cumsum(lens, 0, out=offs[1:])
     total = int(offs[-1].item())
