@@ -221,6 +221,21 @@ int umgap_classify_prot9_dev(umgap_index* ix, umgap_taxonomy* tx, int method, fl
                              uint32_t fragments_per_read, int seedextend, uint32_t min_seed_size,
                              uint32_t max_gap_size, uint32_t* d_out_taxon, uint32_t* d_out_status, void* stream);
 
+/* The same pipeline for a block of FASTA records held in HOST memory -- what a fused
+ * `prot2kmer2lca -o | seedextend -s S -g G | uniq [-d D] | taxa2agg ...` command needs per block
+ * (scripts/umgap-analyse.sh:257-310): fragment f = bytes[frag_offsets[f] .. frag_offsets[f+1]) is the
+ * sequence of one record prot2kmer2lca would print (src/commands/prot2kmer2lca.rs:172-179; the caller
+ * drops records shorter than 9 like :172 does), read r = fragments [read_frags[r], read_frags[r+1]) are
+ * the consecutive records `uniq` merges (src/commands/uniq.rs:66-79).  Every 9-residue window is
+ * looked up (miss = 0 as with -o), seedextend (unranked, src/commands/seedextend.rs:99-148) runs per
+ * fragment when `seedextend` != 0, and the read's surviving hits are aggregated exactly as
+ * umgap_aggregate does (any method / strategy; out_status as there).  Reads of any length. */
+int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int method, int strategy, float factor,
+                           float lower_bound, int ranked_only, const uint8_t* bytes,
+                           const uint64_t* frag_offsets, size_t n_fragments, const uint64_t* read_frags,
+                           size_t n_reads, int seedextend, uint32_t min_seed_size, uint32_t max_gap_size,
+                           uint32_t* out_taxon, uint32_t* out_status);
+
 /* ---- measurement helpers (bench.py; not part of the reference surface) ------------------- */
 /* Lane-per-key probe variant of umgap_index_lookup9_dev, kept for the A/B in DESIGN.md. */
 int umgap_index_lookup9_lane_dev(umgap_index* ix, const uint64_t* d_keys45, size_t n, uint32_t miss_value,

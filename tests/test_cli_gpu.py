@@ -551,3 +551,191 @@ def test_taxa2agg_scored_matches_oracle(world, mode):
         rc, _, err = run(["taxa2agg", "-s", world["tsv"]], bad)
         orc, _, oerr = O.run_cli(["taxa2agg", "-s", world["tsv"]], bad)
         assert rc == orc == 1 and err.split(b"\n")[0] == oerr.split(b"\n")[0]
+
+
+# ---- prot2kmer2agg: the four-stage 9-mer pipeline as one command -------------------
+@pytest.fixture(scope="module")
+def proteome(tmp_path_factory, world):
+    """An index in which consecutive 9-mers share taxa (all windows of a protein map to its taxon or an ancestor
+    of it), so that seedextend finds seeds; one key maps to a taxon the taxonomy does not hold."""
+    from umgap_amd.synth import synthetic_taxonomy
+    d = tmp_path_factory.mktemp("proteome")
+    rng = np.random.default_rng(23)
+    ids, par, valid, rank = synthetic_taxonomy(4000, 6000, max_depth=20, seed=3)
+    parent_of = dict(zip(ids.tolist(), par.tolist()))
+    proteins, table = [], {}
+    for _ in range(150):
+        prot = "".join(rng.choice(list(LETTERS), int(rng.integers(40, 160))))
+        t = int(rng.choice(ids))
+        proteins.append(prot)
+        for i in range(len(prot) - 8):
+            tt = t
+            if (i // 7) % 3 == 2:           # stretches annotated with the parent: LCA* has work to do
+                tt = parent_of[t]
+            table.setdefault(prot[i:i + 9], tt)
+    table["WWWWWWWWW"] = 7_000_001           # beyond the taxonomy's id range: parents[id] panics (src/tree/mod.rs:37)
+    missing = min(set(range(1, 6000)) - set(ids.tolist()))
+    table["YYYYYYYYY"] = missing             # inside the range but absent: UnknownTaxon
+    tsv = str(d / "index.tsv")
+    with open(tsv, "w") as f:
+        for k in sorted(table):
+            f.write("%s\t%d\n" % (k, table[k]))
+    idx = str(d / "ninemer.umgapix")
+    with open(tsv, "rb") as fin, open(idx, "wb") as fout:
+        p = subprocess.run([UMGAP, "buildindex"], stdin=fin, stdout=fout, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr
+    return {"idx": idx, "idx_tsv": tsv, "proteins": proteins, "missing": missing}
+
+
+def _read_fasta(pw, rng, n_reads, crlf=False):
+    out = []
+    for r in range(n_reads):
+        ends = int(rng.choice([1, 2, 2, 2, 3]))
+        for e in range(1, ends + 1):
+            prot = pw["proteins"][int(rng.integers(0, len(pw["proteins"])))]
+            c = rng.random()
+            if c < 0.08:
+                frag = "".join(rng.choice(list(LETTERS), int(rng.integers(0, 9))))          # shorter than k: dropped
+            else:
+                s = int(rng.integers(0, max(1, len(prot) - 20)))
+                frag = list(prot[s:s + int(rng.integers(12, 70))])
+                for i in range(len(frag)):
+                    m = rng.random()
+                    if m < 0.03:
+                        frag[i] = str(rng.choice(list(LETTERS)))
+                    elif m < 0.04:
+                        frag[i] = "*"
+                    elif m < 0.045:
+                        frag[i] = "x"
+                frag = "".join(frag)
+            hdr = ">read%d/%d some text" % (r, e) if rng.random() < 0.9 else ">read%d" % r
+            if rng.random() < 0.2 and len(frag) > 4:     # hard-wrapped record
+                cut = int(rng.integers(1, len(frag)))
+                out.append("%s\n%s\n%s\n" % (hdr, frag[:cut], frag[cut:]))
+            else:
+                out.append("%s\n%s\n" % (hdr, frag))
+    text = "".join(out)
+    if crlf:
+        text = text.replace("\n", "\r\n")
+    return text.encode()
+
+
+def _oracle_pipe(idx_tsv, tsv, fasta, se, uq, agg):
+    rc, a, _ = O.run_cli(["prot2kmer2lca", "-o", idx_tsv], fasta)
+    assert rc == 0
+    if se is not None:
+        rc, a, _ = O.run_cli(["seedextend"] + se, a)
+        assert rc == 0
+    rc, a, _ = O.run_cli(["uniq"] + uq, a)
+    assert rc == 0
+    return O.run_cli(["taxa2agg"] + agg + [tsv], a)
+
+
+FUSED_CASES = [
+    (["-g", "1", "-s", "3"], ["-d", "/"], ["-l", "2", "-a", "lca*"]),                    # high precision, umgap-analyse.sh:299-304
+    (["-g", "1", "-s", "4"], ["-d", "/"], ["-l", "5", "-a", "lca*"]),                    # max precision :305-310
+    (["-g", "1", "-s", "3"], ["-d", "/"], ["-l", "1", "-a", "hybrid", "-f", "0.25"]),    # high sensitivity :283-288
+    (["-g", "1", "-s", "2"], ["-d", "/"], ["-l", "1", "-m", "rmq", "-a", "mrtl"]),       # max sensitivity :277-282
+    (["-s", "2"], [], ["-a", "lca*", "-r"]),                                            # command defaults, no delimiter
+    (None, ["-d", " "], ["-m", "rmq", "-a", "lca*"]),                                   # no seedextend stage
+]
+
+
+@pytest.mark.parametrize("case", range(len(FUSED_CASES)))
+def test_prot2kmer2agg_matches_four_stage_pipe(world, proteome, case):
+    se, uq, agg = FUSED_CASES[case]
+    rng = np.random.default_rng(100 + case)
+    fasta = _read_fasta(proteome, rng, 400, crlf=(case == 4))
+    orc, ref, _ = _oracle_pipe(proteome["idx_tsv"], world["tsv"], fasta, se, uq, agg)
+    assert orc == 0
+    flags = (se if se is not None else ["--no-seedextend"]) + uq + agg
+    rc, out, err = run(["prot2kmer2agg"] + flags + [proteome["idx"], world["tsv"]], fasta)
+    assert rc == 0, err
+    assert out == ref
+    assert ref.count(b"\n1\n") < ref.count(b">")        # not all reads fell back to the root: seeds existed
+    # the same through the product's own four commands
+    rc, a, _ = run(["prot2kmer2lca", "-o", proteome["idx"]], fasta)
+    if se is not None:
+        rc, a, _ = run(["seedextend"] + se, a)
+    rc, a, _ = run(["uniq"] + uq, a)
+    rc, a, _ = run(["taxa2agg"] + agg + [world["tsv"]], a)
+    assert rc == 0 and a == ref
+
+
+@pytest.mark.parametrize("block,threads", [(64, 3), (700, 5), (5000, 16)])
+def test_prot2kmer2agg_block_seams(world, proteome, block, threads):
+    """Reads whose records fall into different blocks / thread ranges are still merged (uniq state is carried)."""
+    rng = np.random.default_rng(block)
+    fasta = _read_fasta(proteome, rng, 300)
+    se, uq, agg = FUSED_CASES[0]
+    orc, ref, _ = _oracle_pipe(proteome["idx_tsv"], world["tsv"], fasta, se, uq, agg)
+    rc, out, err = _run_env(["prot2kmer2agg"] + se + uq + agg + [proteome["idx"], world["tsv"]], fasta, UMGAP_BLOCK_BYTES=block, UMGAP_THREADS=threads)
+    assert rc == orc == 0 and out == ref, err
+
+
+def test_prot2kmer2agg_errors(world, proteome):
+    se, uq, agg = FUSED_CASES[0]
+    base = ["prot2kmer2agg"] + se + uq + agg
+    good = _read_fasta(proteome, np.random.default_rng(5), 50)
+    for letter, want_rc in (("Y", 1), ("W", 101)):
+        boom = (">boom/1\n%s\n>boom/2\n%s\n>after/1\n%s\n" % (letter * 13, letter * 12, proteome["proteins"][0][:40])).encode()
+        orc, ref, oerr = _oracle_pipe(proteome["idx_tsv"], world["tsv"], good + boom, se, uq, agg)
+        rc, out, err = run(base + [proteome["idx"], world["tsv"]], good + boom)
+        assert rc == orc == want_rc and out == ref          # the reads before the failing one, nothing after
+        if want_rc == 1:
+            msg = b"Unknown Taxon ID: %d" % proteome["missing"]
+            assert msg in err and msg in oerr
+    rc, out, err = run(base + [proteome["idx"], world["tsv"]], b"no header\n")
+    assert rc == 1 and b"Expected > at beginning of fasta header." in err
+    rc, out, err = run(base + [proteome["idx"], world["tsv"]], b"")
+    assert rc == 0 and out == b""
+    rc, out, err = run(base + [proteome["idx"]], b"")
+    assert rc == 1
+    rc, out, err = run(["prot2kmer2agg", "-s", "1", proteome["idx"], world["tsv"]], b"")
+    assert rc == 1 and b"min-seed-size" in err
+    rc, out, err = run(["prot2kmer2agg", "-m", "tree", "-a", "mrtl", proteome["idx"], world["tsv"]], b"")
+    assert rc == 1 and b"cannot be combined" in err
+    # a window edge inside a multi-byte character panics like &seq[i..i+k] does; reads before it are printed
+    rc, out, err = run(base + [proteome["idx"], world["tsv"]], good + ">p/1\nACDEFGHIKéLMNPQRST\n".encode())
+    orc, ref, _ = _oracle_pipe(proteome["idx_tsv"], world["tsv"], good, se, uq, agg)
+    assert rc == 101 and out == ref
+
+
+def test_prot2kmer2agg_socket_server(world, proteome, tmp_path):
+    """`--socket`: index and taxonomy stay resident, clients talk like `nc -NU` (scripts/umgap-analyse.sh:260-264);
+    a connection that dies with an error does not take the server down."""
+    import socket
+    import time
+    sock = str(tmp_path / "agg.sock")
+    se, uq, agg = FUSED_CASES[0]
+    flags = se + uq + agg
+    rng = np.random.default_rng(8)
+    fastas = [_read_fasta(proteome, rng, 150) for _ in range(2)]
+    fastas.insert(1, fastas[0][:2000] + b">boom/1\n" + b"Y" * 13 + b"\n")
+    srv = subprocess.Popen([UMGAP, "prot2kmer2agg"] + flags + ["--socket", sock, proteome["idx"], world["tsv"]], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    try:
+        for _ in range(600):
+            if os.path.exists(sock):
+                break
+            time.sleep(0.1)
+        assert os.path.exists(sock), srv.stderr.read() if srv.poll() is not None else "socket never appeared"
+        for fasta in fastas:
+            c = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+            c.connect(sock)
+            c.sendall(fasta)
+            c.shutdown(socket.SHUT_WR)
+            got = b""
+            while True:
+                chunk = c.recv(1 << 16)
+                if not chunk:
+                    break
+                got += chunk
+            c.close()
+            rc, want, _ = run(["prot2kmer2agg"] + flags + [proteome["idx"], world["tsv"]], fasta)
+            assert got == want and rc == (1 if b"boom" in fasta else 0)
+    finally:
+        srv.terminate()
+        out, _ = srv.communicate(timeout=10)
+    assert out.startswith(b"Socket created, listening for connections.\n")
+    assert out.count(b"Connection accepted. Processing...\n") == 3 and out.count(b"Connection finished succesfully.\n") == 2
+    assert b"Connection died with an error: Unknown Taxon ID: %d\n" % proteome["missing"] in out

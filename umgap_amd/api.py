@@ -341,6 +341,24 @@ def classify_prot9_dev(index, taxonomy, d_bytes, d_frag_offsets, n_reads, fragme
                                                max_gap_size, _dev_ptr(d_out_taxon), _dev_ptr(d_out_status), _stream_ptr(stream)))
 
 
+def classify_records(index, taxonomy, fragments, read_frags, method="tree", strategy="hybrid", factor=0.25, lower_bound=0.0,
+                     ranked_only=False, seedextend=True, min_seed_size=2, max_gap_size=0):
+    """`prot2kmer2lca -o | seedextend | uniq | taxa2agg` for host-side records: `fragments` = list of bytes (one
+    per FASTA record, each >= 9 residues), read r = fragments[read_frags[r]:read_frags[r+1]].  Returns
+    (out_taxon, out_status) numpy arrays (include/umgap_hip.h: umgap_classify_records)."""
+    offs = np.zeros(len(fragments) + 1, np.uint64)
+    if len(fragments):
+        offs[1:] = np.cumsum([len(f) for f in fragments], dtype=np.uint64)
+    data = np.frombuffer(b"".join(fragments) + b"\0", dtype=np.uint8)
+    rf = np.ascontiguousarray(read_frags, dtype=np.uint64)
+    n = len(rf) - 1
+    out_t, out_s = np.empty(n, np.uint32), np.empty(n, np.uint32)
+    check(_lib.load().umgap_classify_records(index._h, taxonomy._h, METHODS[method], STRATEGIES[strategy], factor, lower_bound, int(ranked_only),
+                                             _np_ptr(data), _np_ptr(offs), len(fragments), _np_ptr(rf), n, int(seedextend), min_seed_size,
+                                             max_gap_size, _np_ptr(out_t), _np_ptr(out_s)))
+    return out_t, out_s
+
+
 def seedextend_dev(d_taxa, d_offsets=None, stride=None, n_records=None, min_seed_size=2, max_gap_size=0, d_kept=None, stream=None):
     """seedextend (unranked) in place on a torch CUDA int32 tensor (src/commands/seedextend.rs:99-148)."""
     L = _lib.load()

@@ -11,6 +11,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <functional>
 #include <map>
@@ -786,6 +787,297 @@ int cmd_uniq(const std::vector<std::string>& args) {
     return 0;
 }
 
+// ---- prot2kmer2agg: `prot2kmer2lca -o IX | seedextend -s S -g G | uniq [-d D] | taxa2agg ... TAX` as ONE command ----
+// Not a reference subcommand: it is the four-stage 9-mer pipeline of scripts/umgap-analyse.sh:257-310 with the
+// three text pipes (84 decimal ids per read pair, parsed and printed three times) removed.  On every input the
+// four-stage pipe accepts it prints the same bytes as the pipe (tests/test_cli_gpu.py); the hits stay on the
+// device (umgap_classify_records).  Deliberate differences, all on error paths: a failing record (invalid UTF-8,
+// a window cutting a character, an unknown taxon) ends the run after the reads that precede it were printed.
+struct FusePart {
+    // per emitted record (sequence >= 9 residues): its header as `uniq` sees it (two more CRs stripped by the readers of
+    // seedextend and uniq, cut at the delimiter) and its sequence length
+    std::vector<size_t> hdr_off;
+    std::vector<uint32_t> hdr_len;
+    std::vector<uint64_t> frag_len;
+    std::vector<uint32_t> gstart;   // records that open a new `uniq` group inside this range (record 0 always does)
+    std::vector<uint8_t> bytes;
+    bool bad_utf8 = false, panic = false;
+    size_t rec_base = 0, byte_base = 0, group_base = 0, hdr_base = 0, hdr_bytes = 0;
+    bool merged = false;            // record 0 continues the group that was open before this range
+    std::string_view header(const char* d, size_t r) const { return std::string_view(d + hdr_off[r], hdr_len[r]); }
+};
+
+void parse_fuse_part(const char* d, size_t begin, size_t end, const std::optional<std::string>& delim, FusePart& P) {
+    LineCursor lc{d + begin, d + end};
+    std::string_view line;
+    bool open = false;
+    size_t rec_start = 0;
+    std::string_view cur;
+    P.bytes.reserve(end - begin);
+    auto finish = [&]() {
+        if (!open) return;
+        open = false;
+        size_t n = P.bytes.size() - rec_start;
+        if (n < 9) { P.bytes.resize(rec_start); return; }   // src/commands/prot2kmer2lca.rs:172: dropped, header and all
+        const uint8_t* q = P.bytes.data() + rec_start;
+        bool ascii = true;
+        for (size_t i = 0; i < n; i++) if (q[i] >= 0x80) { ascii = false; break; }
+        if (!ascii)  // &seq[i..i + k] panics when a window edge falls inside a character (:175)
+            for (size_t i = 0; i + 9 <= n; i++)
+                if ((q[i] & 0xC0) == 0x80 || (i + 9 < n && (q[i + 9] & 0xC0) == 0x80)) { P.panic = true; P.bytes.resize(rec_start); return; }
+        std::string_view h = cur;
+        // every reader of the pipe strips one trailing CR from a line (BufRead::lines): seedextend's and uniq's here
+        for (int k = 0; k < 2 && !h.empty() && h.back() == '\r'; k++) h.remove_suffix(1);
+        if (delim) { size_t at = h.find(*delim); if (at != std::string_view::npos) h = h.substr(0, at); }
+        size_t r = P.hdr_off.size();
+        if (r == 0 || h != P.header(d, r - 1)) { P.gstart.push_back((uint32_t)r); P.hdr_bytes += h.size(); }   // src/commands/uniq.rs:70-77
+        P.hdr_off.push_back((size_t)(h.data() - d));
+        P.hdr_len.push_back((uint32_t)h.size());
+        P.frag_len.push_back(n);
+    };
+    while (lc.next(line)) {
+        bool utf8 = line_utf8_ok(line);
+        if (!line.empty() && line[0] == '>' && utf8) {
+            finish();
+            if (P.panic) return;
+            cur = line.substr(1);
+            rec_start = P.bytes.size();
+            open = true;
+            continue;
+        }
+        if (!utf8) {
+            P.bad_utf8 = true;
+            if (open) P.bytes.resize(rec_start);
+            return;
+        }
+        P.bytes.insert(P.bytes.end(), line.begin(), line.end());   // unwrap: lines of a record are concatenated (src/io/fasta.rs:62-64)
+    }
+    finish();
+}
+
+// one block's worth of reads, self-contained (nothing points into the block buffer)
+struct FuseJob {
+    std::vector<uint8_t> bytes;
+    std::vector<uint64_t> frag_off, read_frags;
+    std::string hdrs;                 // the reads' headers, back to back
+    std::vector<uint64_t> hdr_end;    // n_reads + 1
+    size_t n_reads = 0;
+    std::vector<uint32_t> out_taxon, out_status;
+};
+
+int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
+    Parsed p = parse_args(args, {{'k', "length", true}, {'o', "one-on-one", false}, {'s', "min-seed-size", true}, {'g', "max-gap-size", true},
+                                 {'d', "delimiter", true}, {'m', "method", true}, {'a', "aggregate", true}, {'f', "factor", true},
+                                 {'l', "lower-bound", true}, {'r', "ranked", false}, {0, "no-seedextend", false}, {0, "socket", true}});
+    if (opt_usize(p, "length", 9) != 9) throw CliError("prot2kmer2agg needs k = 9");
+    uint64_t s = opt_usize(p, "min-seed-size", 2), g = opt_usize(p, "max-gap-size", 0);
+    bool se = !p.has("no-seedextend");
+    // with -s 0 / -s 1 the reference's seedextend can panic on a leading run of misses (slice start > end,
+    // src/commands/seedextend.rs:118,145); the device kernel has no such state, so those values stay with the separate command
+    if (se && s < 2) throw CliError("prot2kmer2agg needs --min-seed-size >= 2 (use the separate seedextend command below that)");
+    if (s > 0xFFFFFFFFull || g > 0xFFFFFFFFull) throw CliError("seed / gap size out of range");
+    auto delim = p.get("delimiter");
+    std::string m = p.get("method").value_or("tree"), a = p.get("aggregate").value_or("hybrid");
+    if (m != "tree" && m != "rmq") usage_error("'" + m + "' isn't a valid value for '--method <method>'\n\t[possible values: rmq, tree]");
+    if (a != "lca*" && a != "hybrid" && a != "mrtl") usage_error("'" + a + "' isn't a valid value for '--aggregate <strategy>'\n\t[possible values: hybrid, lca*, mrtl]");
+    float factor = opt_f32(p, "factor", 0.25f), lower_bound = opt_f32(p, "lower-bound", 0.0f);
+    bool ranked = p.has("ranked");
+    if (p.positional.size() != 2) usage_error("prot2kmer2agg takes <fst-file> <taxon-file>");
+    int method = m == "tree" ? UMGAP_METHOD_TREE : UMGAP_METHOD_RMQ;
+    int strategy = a == "lca*" ? UMGAP_STRATEGY_LCA_STAR : (a == "hybrid" ? UMGAP_STRATEGY_HYBRID : UMGAP_STRATEGY_MRTL);
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const bool timing = getenv("UMGAP_TIMING") != nullptr;   // phase times on stderr
+    const double t_begin = now();
+    umgap_index* ix = open_index(p.positional[0]);
+    if (umgap_index_kind(ix) != 9) throw CliError("prot2kmer2agg needs a 9-mer index");
+    umgap_taxonomy* tx = load_taxonomy(p.positional[1]);
+    if (method == UMGAP_METHOD_RMQ && strategy == UMGAP_STRATEGY_HYBRID)
+        fprintf(stderr, "Warning: this is a hybrid between LCA/MRTL, not LCA*/MRTL\n");
+    if (method == UMGAP_METHOD_TREE && strategy == UMGAP_STRATEGY_MRTL)
+        throw CliError("Invalid invocation: Tree and MaximumRootToLeafPath cannot be combined");
+    const double t_start = now();
+    const unsigned T = worker_count();
+    auto stream = [&](FILE* in, FILE* outf) {
+    double t_read = 0, t_parse = 0, t_group = 0, t_wait = 0, t_dev = 0, t_fmt = 0;
+
+    // stage 2 (its own thread, one job at a time): device call, format, write -- while stage 1 tokenizes the next block
+    auto run_job = [&](FuseJob& J) {
+        double t0 = now();
+        J.out_taxon.resize(J.n_reads);
+        J.out_status.resize(J.n_reads);
+        if (J.n_reads) LIB(umgap_classify_records(ix, tx, method, strategy, factor, lower_bound, ranked ? 1 : 0, J.bytes.data(), J.frag_off.data(),
+                                                  J.read_frags[J.n_reads], J.read_frags.data(), J.n_reads, se ? 1 : 0, (uint32_t)s, (uint32_t)g,
+                                                  J.out_taxon.data(), J.out_status.data()));
+        t_dev += now() - t0; t0 = now();
+        size_t bad = J.n_reads;
+        for (size_t r = 0; r < J.n_reads; r++)
+            if (J.out_status[r] == UMGAP_READ_UNKNOWN_TAXON || J.out_status[r] == UMGAP_READ_PANIC || J.out_status[r] == 4u) { bad = r; break; }
+        const size_t nt = std::max<size_t>(1, std::min<size_t>(T / 2, bad / 4096 + 1));
+        std::vector<std::string> outs(nt);
+        parallel_for(nt, [&](size_t t) {
+            size_t lo = bad * t / nt, hi = bad * (t + 1) / nt;
+            outs[t].reserve((hi - lo) * 12 + (size_t)(J.hdr_end[hi] - J.hdr_end[lo]));
+            for (size_t r = lo; r < hi; r++) {
+                outs[t].push_back('>'); outs[t].append(J.hdrs.data() + J.hdr_end[r], J.hdr_end[r + 1] - J.hdr_end[r]); outs[t].push_back('\n');
+                append_uint(outs[t], J.out_taxon[r]); outs[t].push_back('\n');
+            }
+        });
+        for (auto& o : outs) fwrite(o.data(), 1, o.size(), outf);
+        t_fmt += now() - t0;
+        if (bad < J.n_reads) {
+            fflush(outf);
+            if (J.out_status[bad] == UMGAP_READ_UNKNOWN_TAXON) throw CliError("Unknown Taxon ID: " + std::to_string(J.out_taxon[bad]));
+            if (J.out_status[bad] == 4u) throw CliError("a read holds more than 1024 distinct taxa: not supported by the device aggregator");
+            throw CliPanic("index out of bounds");
+        }
+    };
+    FuseJob jobs[2];          // declared before the thread that works on them (destroyed after it is joined)
+    int slot = 0;
+    std::thread worker;
+    std::exception_ptr worker_error;
+    auto join_worker = [&]() {
+        if (worker.joinable()) { double t0 = now(); worker.join(); t_wait += now() - t0; }
+        if (worker_error) { std::exception_ptr e = worker_error; worker_error = nullptr; std::rethrow_exception(e); }
+    };
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{worker};   // never leave a running thread behind
+
+    // the group `uniq` is still merging when a block ends (src/commands/uniq.rs:66-79): carried into the next block
+    struct Carry { bool have = false; std::string hdr; std::vector<uint8_t> bytes; std::vector<uint64_t> frag_len; } carry;
+    BlockReader blocks(in);
+    for (;;) {
+        const char* d = nullptr;
+        size_t len = 0;
+        double t0 = now();
+        const bool more = blocks.next(d, len);
+        t_read += now() - t0; t0 = now();
+        if (more && blocks.first_line_error()) { join_worker(); throw CliError("Expected > at beginning of fasta header."); }
+        std::vector<size_t> cuts = more ? split_records(d, len, T) : std::vector<size_t>{0};
+        const size_t np = cuts.size() - 1;
+        std::vector<FusePart> parts(np);
+        parallel_for(np, [&](size_t i) { parse_fuse_part(d, cuts[i], cuts[i + 1], delim, parts[i]); });
+        t_parse += now() - t0; t0 = now();
+        size_t used = np;
+        for (size_t i = 0; i < np; i++)
+            if (parts[i].bad_utf8 || parts[i].panic) { used = i + 1; break; }
+        const bool failed = used > 0 && (parts[used - 1].bad_utf8 || parts[used - 1].panic);
+        // layout: the carried group first, then the block's records in input order; groups across range seams are merged
+        FuseJob& J = jobs[slot];
+        size_t n_frag = carry.frag_len.size(), n_bytes = carry.bytes.size(), n_groups = carry.have ? 1 : 0, n_hdr = 0;
+        std::string_view prev = carry.hdr;
+        bool have_prev = carry.have;
+        for (size_t i = 0; i < used; i++) {
+            FusePart& P = parts[i];
+            P.rec_base = n_frag; P.byte_base = n_bytes; P.group_base = n_groups; P.hdr_base = n_hdr;
+            n_frag += P.frag_len.size(); n_bytes += P.bytes.size();
+            if (P.hdr_off.empty()) continue;
+            P.merged = have_prev && P.header(d, 0) == prev;
+            n_groups += P.gstart.size() - (P.merged ? 1 : 0);
+            n_hdr += P.hdr_bytes - (P.merged ? P.hdr_len[0] : 0);
+            prev = P.header(d, P.hdr_off.size() - 1);
+            have_prev = true;
+        }
+        J.bytes.resize(n_bytes + 1);
+        J.frag_off.resize(n_frag + 1);
+        J.read_frags.resize(n_groups + 1);
+        J.hdr_end.resize(n_groups + 1);
+        const size_t carry_hdr = carry.have ? carry.hdr.size() : 0;
+        J.hdrs.resize(carry_hdr + n_hdr);
+        J.frag_off[0] = 0;
+        if (!carry.bytes.empty()) memcpy(J.bytes.data(), carry.bytes.data(), carry.bytes.size());
+        for (size_t f = 0; f < carry.frag_len.size(); f++) J.frag_off[f + 1] = J.frag_off[f] + carry.frag_len[f];
+        if (carry.have) { J.read_frags[0] = 0; J.hdr_end[0] = 0; memcpy(J.hdrs.data(), carry.hdr.data(), carry_hdr); }
+        parallel_for(used, [&](size_t i) {
+            const FusePart& P = parts[i];
+            if (!P.bytes.empty()) memcpy(J.bytes.data() + P.byte_base, P.bytes.data(), P.bytes.size());
+            uint64_t o = P.byte_base;
+            for (size_t r = 0; r < P.frag_len.size(); r++) { o += P.frag_len[r]; J.frag_off[P.rec_base + r + 1] = o; }
+            size_t gi = P.group_base, ho = carry_hdr + P.hdr_base;
+            for (size_t k = P.merged ? 1 : 0; k < P.gstart.size(); k++, gi++) {
+                size_t r = P.gstart[k];
+                J.read_frags[gi] = P.rec_base + r;
+                J.hdr_end[gi] = ho;
+                memcpy(J.hdrs.data() + ho, d + P.hdr_off[r], P.hdr_len[r]);
+                ho += P.hdr_len[r];
+            }
+        });
+        J.read_frags[n_groups] = n_frag;
+        J.hdr_end[n_groups] = J.hdrs.size();
+        size_t n_now = n_groups;
+        Carry next;
+        if (more && !failed && n_groups > 0) {   // the last group may continue in the next block
+            n_now = n_groups - 1;
+            next.have = true;
+            next.hdr.assign(J.hdrs.data() + J.hdr_end[n_now], J.hdr_end[n_groups] - J.hdr_end[n_now]);
+            size_t f0 = J.read_frags[n_now];
+            next.bytes.assign(J.bytes.begin() + J.frag_off[f0], J.bytes.begin() + J.frag_off[n_frag]);
+            for (size_t f = f0; f < n_frag; f++) next.frag_len.push_back(J.frag_off[f + 1] - J.frag_off[f]);
+        }
+        J.n_reads = n_now;
+        // taxa2agg's reader strips one more CR from the header line it prints
+        for (size_t r = 0; r < n_now; r++)
+            if (J.hdr_end[r + 1] > J.hdr_end[r] && J.hdrs[J.hdr_end[r + 1] - 1] == '\r') {
+                // rare: rebuild the header table without those bytes
+                std::string h2; std::vector<uint64_t> e2(n_groups + 1, 0);
+                for (size_t q = 0; q < n_groups; q++) {
+                    std::string_view h(J.hdrs.data() + J.hdr_end[q], J.hdr_end[q + 1] - J.hdr_end[q]);
+                    if (q < n_now && !h.empty() && h.back() == '\r') h.remove_suffix(1);
+                    e2[q] = h2.size(); h2.append(h);
+                }
+                e2[n_groups] = h2.size();
+                J.hdrs.swap(h2); J.hdr_end.swap(e2);
+                break;
+            }
+        t_group += now() - t0;
+        join_worker();                                   // the previous block is out (or its error is raised here)
+        carry = std::move(next);
+        worker = std::thread([&, slot]() { try { run_job(jobs[slot]); } catch (...) { worker_error = std::current_exception(); } });
+        slot ^= 1;
+        if (failed) {
+            join_worker();
+            fflush(outf);
+            if (parts[used - 1].panic) throw CliPanic("byte index is not a char boundary");
+            throw CliError("stream did not contain valid UTF-8");
+        }
+        if (!more) break;
+    }
+    join_worker();
+    fflush(outf);
+    if (timing) fprintf(stderr, "prot2kmer2agg: open %.3f s | stage 1: read %.3f, tokenize %.3f, group %.3f, wait for stage 2 %.3f | stage 2: device %.3f, format+write %.3f\n",
+                        t_start - t_begin, t_read, t_parse, t_group, t_wait, t_dev, t_fmt);
+    };
+    if (auto sock = p.get("socket")) {
+        // the index and the taxonomy stay resident; connections are served one after another, with the status
+        // lines of `prot2kmer2lca -s` (src/commands/prot2kmer2lca.rs:116-137) on stdout
+        int fd = socket(AF_UNIX, SOCK_STREAM, 0);
+        if (fd < 0) throw CliError(strerror(errno));
+        sockaddr_un addr{};
+        addr.sun_family = AF_UNIX;
+        if (sock->size() >= sizeof(addr.sun_path)) throw CliError("path must be shorter than SUN_LEN");
+        strcpy(addr.sun_path, sock->c_str());
+        if (bind(fd, (sockaddr*)&addr, sizeof(addr)) != 0 || listen(fd, 128) != 0) throw CliError(std::string(strerror(errno)) + " (os error " + std::to_string(errno) + ")");
+        printf("Socket created, listening for connections.\n"); fflush(stdout);
+        for (;;) {
+            int c = accept(fd, nullptr, nullptr);
+            if (c < 0) continue;
+            printf("Connection accepted. Processing...\n"); fflush(stdout);
+            FILE* in = fdopen(c, "rb");
+            FILE* outf = fdopen(dup(c), "wb");
+            try {
+                stream(in, outf);
+                printf("Connection finished succesfully.\n");
+            } catch (CliError& e) { printf("Connection died with an error: %s\n", e.what()); }
+            catch (CliPanic& e) { printf("Connection died with an error: %s\n", e.what()); }
+            fflush(stdout);
+            fclose(outf);
+            fclose(in);
+        }
+    }
+    stream(stdin, stdout);
+    umgap_taxonomy_free(tx);
+    umgap_index_free(ix);
+    return 0;
+}
+
 // ---- buildindex: TSV (9-mer<TAB>taxon, sorted) on stdin -> UMGAPIX1 table on stdout ---------
 int cmd_buildindex(const std::vector<std::string>& args) {
     Parsed p = parse_args(args, {{'l', "load-factor", true}});
@@ -874,7 +1166,7 @@ int cmd_printindex(const std::vector<std::string>& args) {
 int main(int argc, char** argv) {
     std::vector<std::string> args(argv + 1, argv + argc);
     try {
-        if (args.empty()) usage_error("umgap: a subcommand is required (pept2lca, prot2kmer2lca, taxa2agg, seedextend, uniq, buildindex)");
+        if (args.empty()) usage_error("umgap: a subcommand is required (pept2lca, prot2kmer2lca, prot2tryp2lca, taxa2agg, seedextend, uniq, prot2kmer2agg, buildindex, printindex)");
         std::string cmd = args[0];
         args.erase(args.begin());
         if (cmd == "-V" || cmd == "--version") { printf("umgap %s\n", umgap_version()); return 0; }  // scripts/umgap-analyse.sh:107
@@ -882,6 +1174,7 @@ int main(int argc, char** argv) {
         if (cmd == "prot2kmer2lca") return cmd_prot2kmer2lca(args);
         if (cmd == "prot2tryp2lca") return cmd_prot2tryp2lca(args);
         if (cmd == "taxa2agg") return cmd_taxa2agg(args);
+        if (cmd == "prot2kmer2agg") return cmd_prot2kmer2agg(args);
         if (cmd == "seedextend") return cmd_seedextend(args);
         if (cmd == "uniq") return cmd_uniq(args);
         if (cmd == "buildindex") return cmd_buildindex(args);
