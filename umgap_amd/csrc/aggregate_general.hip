@@ -224,8 +224,41 @@ __global__ __launch_bounds__(64 * WAVES) void k_agg_general(TaxView V, int metho
                     }
                 }
                 wave_sync();
-                if (method == UMGAP_METHOD_TREE) {
-                    // ---- tree::mix: greedy descent over the implicit induced tree (uniform code) ----
+                if (method == UMGAP_METHOD_TREE && CAP <= 64 && !SCORED) {
+                    // ---- tree::mix, one lane per list element: every level of the greedy descent is three wave
+                    // reductions instead of two serial scans of the range.  Unscored counts are small integers, so
+                    // the children's values (Tree::aggregate) are exact differences of one prefix sum.
+                    const uint32_t k = lane;
+                    float pfx = k < D ? S.b_cnt[k] : 0.0f;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { float t = __shfl_up(pfx, o, 64); if (lane >= (uint32_t)o) pfx = __fadd_rn(pfx, t); }
+                    const uint32_t adj_k = k + 1 < D ? S.b_adj[k] : NONE;
+                    uint32_t i = 0, j = D - 1;
+                    float wcur = __shfl(pfx, (int)(D - 1), 64);
+                    for (;;) {
+                        if (i == j) { ans = S.b_pre[j]; break; }
+                        const bool inr = k >= i && k < j;
+                        const uint32_t m = wave_min(inr ? adj_k : NONE);
+                        if (S.b_dep[i] == m) { i++; continue; }  // chain hit: collapses into the node below
+                        const uint64_t eq = __ballot(inr && adj_k == m);
+                        const uint32_t node = S.b_lca[__builtin_ctzll(eq)];
+                        const uint64_t ends = eq | (1ull << j);              // a child ends at every cut and at j
+                        const bool is_end = (ends >> k) & 1ull;
+                        const uint64_t below = ends & lanemask_lt(k);
+                        const uint32_t st = below ? 64u - (uint32_t)__builtin_clzll(below) : i;   // where this child starts
+                        const float before_raw = __shfl(pfx, (int)((st - 1u) & 63u), 64);
+                        const float seg = is_end ? __fsub_rn(pfx, st ? before_raw : 0.0f) : -1.0f;
+                        const float best_w = wave_maxf(seg);
+                        const uint32_t best_e = wave_min(is_end && seg == best_w ? k : NONE);   // first maximum, like `wsum > best_w`
+                        const uint32_t best_s = (uint32_t)__shfl((int)st, (int)best_e, 64);
+                        if (__fdiv_rn(best_w, wcur) < factor) { ans = node; break; }  // src/tree/mix.rs:57-59
+                        wcur = best_w;
+                        i = best_s;
+                        j = best_e;
+                    }
+                } else if (method == UMGAP_METHOD_TREE) {
+                    // ---- tree::mix: greedy descent over the implicit induced tree (uniform code; scored reads, whose
+                    // f32 sums depend on the order, and the large-scratch pass) ----
                     uint32_t i = 0, j = D - 1;
                     float wcur = 0.0f;
                     for (uint32_t k = 0; k < D; k++) wcur = __fadd_rn(wcur, S.b_cnt[k]);
@@ -299,7 +332,7 @@ int launch_general(const TaxView& V, int method, int strategy, float factor, flo
     uint32_t* d_list = d_defer + 1;
     UMGAP_HIP(hipMemsetAsync(d_count, 0, sizeof(uint32_t), stream));
     size_t g = (n_reads + 3) / 4;
-    if (g > 256 * 4) g = 256 * 4;
+    if (g > 256 * 8) g = 256 * 8;
     if (g < 1) g = 1;
     dim3 grid((unsigned)g), block(256), big_grid(256), big_block(64);
     if (d_scores) {
@@ -309,7 +342,7 @@ int launch_general(const TaxView& V, int method, int strategy, float factor, flo
                            stride, n_reads, lower_bound, d_out_taxon, d_out_status, (const uint32_t*)d_list, (const uint32_t*)d_count, (uint32_t*)nullptr,
                            (uint32_t*)nullptr);
     } else {
-        hipLaunchKernelGGL((k_agg_general<false, 64, 512, 4>), grid, block, 0, stream, V, method, strategy, factor, d_taxa, d_scores, d_offsets, stride,
+        hipLaunchKernelGGL((k_agg_general<false, 64, 256, 4>), grid, block, 0, stream, V, method, strategy, factor, d_taxa, d_scores, d_offsets, stride,
                            n_reads, lower_bound, d_out_taxon, d_out_status, (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_list, d_count);
         hipLaunchKernelGGL((k_agg_general<false, 1024, 4096, 1>), big_grid, big_block, 0, stream, V, method, strategy, factor, d_taxa, d_scores, d_offsets,
                            stride, n_reads, lower_bound, d_out_taxon, d_out_status, (const uint32_t*)d_list, (const uint32_t*)d_count, (uint32_t*)nullptr,
