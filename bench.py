@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--batches", type=int, default=5, help="resident batches (5 x 10 M = the 50 M-pair config)")
     ap.add_argument("--n-keys", type=int, default=int(os.environ.get("UMGAP_BENCH_KEYS", 8_000_000_000)))
     ap.add_argument("--n-tax", type=int, default=2_500_000)
-    ap.add_argument("--load-factor", type=float, default=0.6)
+    ap.add_argument("--load-factor", type=float, default=0.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--seedextend", action="store_true", help="insert seedextend -g1 -s3 per fragment between lookup and aggregate")
@@ -118,6 +118,9 @@ def sharded_extra(args, w, keys, rank, world, local_rank, device, B, d_hits, d_t
     dog.daemon = True
     dog.start()
     try:
+        if w.index is not None:     # the replica has done its job: its HBM goes to the shard and the exchange buffers
+            w.index.close()
+            w.index = None
         shard = Index.synthetic(args.n_keys, w.d_taxon_of_row, synth.MUL_A, synth.ADD_B, args.load_factor, rank, world)
         sl = ShardedLookup(GpuOps(shard, device), rank, world, B * KMERS, chunks=4)
         steps = max(2, min(3, args.steps))
@@ -271,7 +274,8 @@ def main():
     if os.path.exists(tp):
         try:
             tj = json.load(open(tp))
-            if tj.get("pairs_per_step") == B and tj.get("n_keys") == args.n_keys and tj.get("kernel") == out["roofline"]["kernel"]:
+            if (tj.get("pairs_per_step") == B and tj.get("n_keys") == args.n_keys and tj.get("kernel") == out["roofline"]["kernel"]
+                    and tj.get("load_factor", args.load_factor) == args.load_factor):
                 out["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
         except Exception:
             pass
@@ -295,12 +299,13 @@ def main():
         n = 1 << 28
         d_out = torch.empty(n, dtype=torch.int32, device=device)
         ceil = {}
-        for bpp in (64, 128):
-            w.index.bench_gather_dev(n, bpp, d_out)
+        for bpp, in_flight in ((64, 8), (128, 4)):   # pure random reads, several in flight per lane like the probe
+            code = bpp | (in_flight << 16)
+            w.index.bench_gather_dev(n, code, d_out)
             torch.cuda.synchronize()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
-            w.index.bench_gather_dev(n, bpp, d_out)
+            w.index.bench_gather_dev(n, code, d_out)
             b.record()
             torch.cuda.synchronize()
             ceil[str(bpp)] = round(n * bpp / (a.elapsed_time(b) * 1e-3) / 1e9, 1)

@@ -81,7 +81,7 @@ void umgap_unpack9(uint64_t key45, char* nine_bytes);
 
 /* ---- index: 9-mer -> taxon table resident in HBM --------------------------------------- */
 /* Builds a table on `device` from host arrays (keys distinct, any order).  load_factor in
- * (0,1): filled fraction of the 8-slot buckets (0 selects the default 0.6). */
+ * (0,1): filled fraction of the 8-slot buckets (0 selects the default 0.5 = 16 B per key: 2.3 % of the buckets overflow, 6.6 % at 0.6). */
 int umgap_index_build9(const uint64_t* keys45, const uint32_t* taxa, size_t n, double load_factor,
                        int device, umgap_index** out);
 /* Same, key/value arrays already in device memory (on `device`). */
@@ -240,8 +240,10 @@ int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int method, int 
 /* Lane-per-key probe variant of umgap_index_lookup9_dev, kept for the A/B in DESIGN.md. */
 int umgap_index_lookup9_lane_dev(umgap_index* ix, const uint64_t* d_keys45, size_t n, uint32_t miss_value,
                                  uint32_t* d_out_taxa, void* stream);
-/* Random 64-byte-sector gather microbenchmark over the index table: each of n probes reads one
- * whole bucket chosen by a hash of its index; out receives a checksum per probe. */
+/* Random-sector gather microbenchmark over the index table: each of n probes reads bytes_per_probe
+ * (16..256) bytes at a bucket chosen by a hash of its index; out receives a checksum per probe.
+ * bytes_per_probe | (k << 16) selects the pure-read form: k probes in flight per lane and one store per
+ * lane at the end instead of one per probe (d_out still needs n entries). */
 int umgap_bench_gather_dev(umgap_index* ix, size_t n, uint32_t bytes_per_probe, uint32_t* d_out, void* stream);
 /* Synthetic workload generators (DESIGN.md "Synthetic workload"), all on device. */
 int umgap_synth_index_build(uint64_t n_keys, const uint32_t* d_taxon_of_row, uint64_t n_tax,

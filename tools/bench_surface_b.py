@@ -28,7 +28,7 @@ prot = torch.empty(n_frag * flen, dtype=torch.uint8, device=dev)
 _lib.check(L.umgap_synth_peptides_dev(0, n_frag, 7, _dev_ptr(offs), _dev_ptr(prot), 0, _stream_ptr(None)))
 taxa = w.d_taxon_of_row[torch.arange(n_frag, device=dev) % w.n_tax].contiguous()
 h = C.c_void_p()
-_lib.check(L.umgap_index_build_windows9_dev(_dev_ptr(prot), _dev_ptr(offs), _dev_ptr(taxa), n_frag, flen, n_frag * (flen - 8), 0.6, 0, C.byref(h)))
+_lib.check(L.umgap_index_build_windows9_dev(_dev_ptr(prot), _dev_ptr(offs), _dev_ptr(taxa), n_frag, flen, n_frag * (flen - 8), 0.5, 0, C.byref(h)))
 ix = Index(h.value)
 torch.cuda.synchronize()
 setup = time.perf_counter() - t0

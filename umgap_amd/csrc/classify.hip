@@ -128,27 +128,26 @@ __global__ __launch_bounds__(256) void k_classify9(TableView T, TaxView V, int m
         const uint64_t* kp = keys + r0 * stride;
         // ---- probe: chunks of 64 keys, two chunks (8 sectors per quad) in flight ----
         for (uint32_t c = 0; c * 64 < nk; c += 2) {
-            ProbeBatch B0, B1;
-            uint32_t res0[4], res1[4];
+            ProbeBatch B[2];
+            uint32_t res[2][4];
             const bool two = (c + 1) * 64 < nk;
             {
                 uint32_t i = c * 64 + lane, local = 0, tag = 0, valid = 0;
                 if (i < nk) valid = locate(T, __builtin_nontemporal_load(kp + i), local, tag) ? 1u : 0u;
-                probe_issue(T, local, tag | (valid << 31), lane, B0);
+                probe_issue(T, local, tag | (valid << 31), lane, B[0]);
             }
             if (two) {
                 uint32_t i = (c + 1) * 64 + lane, local = 0, tag = 0, valid = 0;
                 if (i < nk) valid = locate(T, __builtin_nontemporal_load(kp + i), local, tag) ? 1u : 0u;
-                probe_issue(T, local, tag | (valid << 31), lane, B1);
-            }
-            probe_eval(T, B0, 0u, lane, res0);
-            if (two) probe_eval(T, B1, 0u, lane, res1);
+                probe_issue(T, local, tag | (valid << 31), lane, B[1]);
+            } else probe_skip(B[1]);
+            probe_eval_multi<2>(T, B, 0u, lane, res);
             if (j == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     uint32_t i0 = c * 64 + 16 * r + q, i1 = i0 + 64;
-                    if (i0 < nk) wtaxa[i0] = res0[r];
-                    if (two && i1 < nk) wtaxa[i1] = res1[r];
+                    if (i0 < nk) wtaxa[i0] = res[0][r];
+                    if (two && i1 < nk) wtaxa[i1] = res[1][r];
                 }
             }
         }
@@ -175,29 +174,33 @@ __global__ __launch_bounds__(256) void k_classify9(TableView T, TaxView V, int m
 // ---------------------------------------------------------------------------------------------
 // Surface B: the reads arrive as protein fragments (what FGSpp / `translate` emit and
 // `prot2kmer2lca` consumes, ~1.2 B per k-mer instead of 8 B): read r owns fragments
-// [r*F, (r+1)*F) of a CSR byte array.  One wave per read: the read's bytes are staged in LDS,
-// every lane packs the 9-mer window(s) it owns from LDS (src/commands/prot2kmer2lca.rs:172-179:
-// all len-8 windows of a fragment, none if it is shorter than 9), two probe batches (128
-// windows) are issued back to back, then seedextend per fragment and LCA* as in k_classify9.
+// [r*F, (r+1)*F) of a CSR byte array.  A wave owns a group of up to 8 reads: their bytes are staged in LDS
+// (all loads in flight together), the group's 9-mer windows (src/commands/prot2kmer2lca.rs:172-179: all len-8
+// windows of a fragment, none if it is shorter than 9) form one flat list that is packed from LDS and probed in
+// chunks of 128 (two batches in flight) into a dense strip, then seedextend per fragment and LCA* per read as in
+// k_classify9.
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t PROT_MAX_FRAGS = 16, PROT_MAX_BYTES = 384, PROT_MAX_WINDOWS = 128, PROT_GROUP = STRIP / PROT_MAX_WINDOWS;  // 8 reads
 
-__global__ __launch_bounds__(256) void k_classify_prot9(TableView T, TaxView V, int method, const uint8_t* __restrict__ bytes,
+__global__ __launch_bounds__(256, 4) void k_classify_prot9(TableView T, TaxView V, int method, const uint8_t* __restrict__ bytes,
                                                         const uint64_t* __restrict__ foff, size_t n_reads, uint32_t F, uint32_t do_seed,
                                                         uint32_t min_seed, uint32_t max_gap, float lower_bound,
                                                         uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status) {
     __shared__ uint32_t lds_taxa[4][STRIP], lds_keys[4][256], lds_cnt[4][256];
-    __shared__ uint32_t lds_fstart[4][64], lds_fwin[4][64], lds_total[4][PROT_GROUP];
-    __shared__ uint8_t lds_bytes[4][PROT_MAX_BYTES];
+    __shared__ uint32_t lds_fstart[4][64], lds_fwin[4][64], lds_fbyte[4][64], lds_total[4][PROT_GROUP];
+    __shared__ uint8_t lds_bytes[4][PROT_GROUP * PROT_MAX_BYTES];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
     uint32_t* wtaxa = lds_taxa[wv];
     uint32_t* wkeys = lds_keys[wv];
     uint32_t* wcnt = lds_cnt[wv];
     uint8_t* wbytes = lds_bytes[wv];
+    uint32_t* wfstart = lds_fstart[wv];
+    uint32_t* wfwin = lds_fwin[wv];
+    uint32_t* wfbyte = lds_fbyte[wv];
 #pragma unroll
     for (int i = 0; i < 4; i++) { wkeys[lane + 64 * i] = 0u; wcnt[lane + 64 * i] = 0u; }
     const bool tree_like = method != UMGAP_METHOD_RMQ;
-    // group size: PROT_GROUP reads (128 strip slots each), and at most 64 fragments for the seedextend lanes
+    // group size: PROT_GROUP reads (<= 128 windows each, so the group fits the strip), at most 64 fragments (one lane each)
     uint32_t G = PROT_GROUP;
     if (G * F > 64) G = 64 / F;
     const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -206,80 +209,99 @@ __global__ __launch_bounds__(256) void k_classify_prot9(TableView T, TaxView V, 
     for (size_t grp = wave0; grp < n_groups; grp += nwaves) {
         const size_t r0 = grp * G;
         const uint32_t nr = (uint32_t)min((size_t)G, n_reads - r0);
-        // ---- per read: stage bytes, pack windows, probe into the read's strip region [k*128, ...) ----
+        const uint32_t nfr = nr * F;                       // fragments of the group, lane f owns fragment f
+        // ---- group layout: lane f = fragment f of the group (read k = f / F) ----
+        const uint32_t k_of = lane / F;
+        uint32_t my_len = 0, my_rel = 0, rd_bytes = 0;
+        uint64_t rd_base = 0;
+        if (lane < nfr) {
+            const uint64_t* fo = foff + r0 * F;
+            const uint64_t b0 = fo[lane], b1 = fo[lane + 1];
+            rd_base = fo[k_of * F];
+            const uint64_t rb = fo[k_of * F + F] - rd_base;
+            rd_bytes = rb > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)rb;
+            my_len = (b1 - b0) > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(b1 - b0);
+            my_rel = (uint32_t)(b0 - rd_base);
+        }
+        uint32_t my_win = my_len >= 9 ? my_len - 8 : 0u;
+        // windows of the lane's read (segmented sum over its F fragments; every lane takes part in the shuffles)
+        uint32_t rd_win = 0;
+        for (uint32_t t = 0; t < F; t++) {
+            uint32_t wsrc = (uint32_t)__shfl((int)my_win, (int)((k_of * F + t) & 63), 64);
+            uint32_t add = wsrc > PROT_MAX_WINDOWS ? PROT_MAX_WINDOWS + 1 : wsrc;
+            rd_win = rd_win + add > PROT_MAX_WINDOWS + 1 ? PROT_MAX_WINDOWS + 1 : rd_win + add;
+        }
+        const bool unsupported = lane < nfr && (rd_bytes > PROT_MAX_BYTES || rd_win > PROT_MAX_WINDOWS);
+        if (unsupported || lane >= nfr) my_win = 0;
+        // dense strip layout: exclusive prefix sum of the window counts
+        uint32_t incl = my_win;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= (uint32_t)o) incl += t; }
+        const uint32_t my_start = incl - my_win;
+        const uint32_t W = (uint32_t)__shfl((int)incl, 63, 64);          // windows of the group (<= STRIP)
+        wfstart[lane] = lane < nfr ? my_start : 0xFFFFFFFFu;
+        wfwin[lane] = my_win;
+        wfbyte[lane] = k_of * PROT_MAX_BYTES + my_rel;
+        if (lane < nfr && lane % F == 0) lds_total[wv][k_of] = unsupported ? 0xFFFFFFFFu : rd_win;
+        // ---- stage the reads' bytes (region k * PROT_MAX_BYTES per read; the loads of all reads are in flight together) ----
         for (uint32_t k = 0; k < nr; k++) {
-            const size_t r = r0 + k;
-            // fragment boundaries relative to the read's first byte; lane f holds the start of fragment f (f <= F)
-            const uint64_t base = foff[r * F];
-            uint32_t my_off = lane <= F ? (uint32_t)(foff[r * F + lane] - base) : 0u;
-            const uint32_t nbytes = __builtin_amdgcn_readlane(my_off, F);   // F is wave-uniform (kernel argument <= 16)
-            // (shuffle with every lane active: ds_bpermute returns 0 for a source lane that is masked off)
-            const uint32_t next_off = (uint32_t)__shfl((int)my_off, (int)((lane + 1) & 63), 64);
-            uint32_t my_len = lane < F ? next_off - my_off : 0u;
-            uint32_t my_win = my_len >= 9 ? my_len - 8 : 0u;                 // windows of fragment `lane`
-            uint32_t wstart = 0, total = 0;                                   // exclusive prefix over the F fragments
-            for (uint32_t f = 0; f < F; f++) {
-                uint32_t wf = __builtin_amdgcn_readlane(my_win, f);
-                if (lane == f) wstart = total;
-                total += wf;
-            }
-            const bool unsupported = nbytes > PROT_MAX_BYTES || total > PROT_MAX_WINDOWS;
-            if (lane < F) { lds_fstart[wv][k * F + lane] = k * PROT_MAX_WINDOWS + wstart; lds_fwin[wv][k * F + lane] = unsupported ? 0u : my_win; }
-            if (lane == 0) lds_total[wv][k] = unsupported ? 0xFFFFFFFFu : total;
-            if (unsupported) continue;   // wave-uniform
-            for (uint32_t i = lane; i < nbytes; i += 64) wbytes[i] = bytes[base + i];
-            wave_lds_sync();
-            uint32_t loc[2] = {0, 0}, tg[2] = {0, 0};
+            const uint32_t src = k * F;
+            const uint32_t nb_lo = (uint32_t)__shfl((int)rd_bytes, (int)src, 64);
+            const uint32_t b_lo = (uint32_t)__shfl((int)(uint32_t)rd_base, (int)src, 64), b_hi = (uint32_t)__shfl((int)(uint32_t)(rd_base >> 32), (int)src, 64);
+            const bool skip = (bool)__shfl((int)unsupported, (int)src, 64);
+            if (skip) continue;   // wave-uniform
+            const uint8_t* gp = bytes + (((uint64_t)b_hi << 32) | b_lo);
+            for (uint32_t i = lane; i < nb_lo; i += 64) wbytes[k * PROT_MAX_BYTES + i] = gp[i];
+        }
+        wave_lds_sync();
+        // ---- probe: the group's windows as one flat list, chunks of 128 (two batches in flight) ----
+        for (uint32_t c = 0; c < W; c += 128) {
+            ProbeBatch B[2];
+            uint32_t pr[2][4];
+            const bool two = c + 64 < W;
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                uint32_t gw = lane + 64 * h, valid = 0;
-                if (gw < total) {
-                    uint32_t ws = 0, fo = 0;
-                    for (uint32_t f = 0; f < F; f++) {   // the fragment that owns window gw
-                        uint32_t wk = __builtin_amdgcn_readlane(wstart, f), nk = __builtin_amdgcn_readlane(my_win, f);
-                        uint32_t ok = __builtin_amdgcn_readlane(my_off, f);
-                        if (gw >= wk && gw < wk + nk) { ws = wk; fo = ok; }
-                    }
-                    const uint8_t* sp = wbytes + fo + (gw - ws);
+                if (h == 1 && !two) { probe_skip(B[1]); break; }   // wave-uniform
+                const uint32_t gw = c + 64 * h + lane;
+                uint32_t valid = 0, loc = 0, tg = 0;
+                if (gw < W) {
+                    // the fragment that owns window gw: the last one whose first window is <= gw
+                    uint32_t lo = 0, hi = nfr;
+                    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (wfstart[mid] <= gw) lo = mid; else hi = mid; }
+                    const uint8_t* sp = wbytes + wfbyte[lo] + (gw - wfstart[lo]);
                     uint64_t key = 0;
                     bool okc = true;
 #pragma unroll
-                    for (int c = 0; c < 9; c++) {
-                        uint32_t ch = sp[c];
+                    for (int ch9 = 0; ch9 < 9; ch9++) {
+                        uint32_t ch = sp[ch9];
                         okc = okc && (ch >= 'A' && ch <= 'Z');
                         key = (key << 5) | ((ch - 'A') & 31u);
                     }
-                    valid = (okc && locate(T, key, loc[h], tg[h])) ? 1u : 0u;
+                    valid = (okc && locate(T, key, loc, tg)) ? 1u : 0u;
                 }
-                tg[h] |= valid << 31;
+                probe_issue(T, loc, tg | (valid << 31), lane, B[h]);
             }
-            ProbeBatch B0, B1;
-            uint32_t p0[4], p1[4];
-            probe_issue(T, loc[0], tg[0], lane, B0);
-            if (total > 64) probe_issue(T, loc[1], tg[1], lane, B1);
-            probe_eval(T, B0, 0u, lane, p0);
-            if (total > 64) probe_eval(T, B1, 0u, lane, p1);
-            uint32_t* rt = wtaxa + k * PROT_MAX_WINDOWS;
+            probe_eval_multi<2>(T, B, 0u, lane, pr);
             if (j == 0) {
 #pragma unroll
                 for (int x = 0; x < 4; x++) {
-                    rt[16 * x + q] = p0[x];
-                    if (total > 64) rt[64 + 16 * x + q] = p1[x];
+                    const uint32_t i0 = c + 16 * x + q, i1 = i0 + 64;
+                    if (i0 < W) wtaxa[i0] = pr[0][x];
+                    if (two && i1 < W) wtaxa[i1] = pr[1][x];
                 }
             }
-            wave_lds_sync();   // also protects wbytes against the next read's staging
         }
         wave_lds_sync();
         // ---- seedextend: all fragments of the group at once, one lane each ----
         if (do_seed) {
-            if (lane < nr * F && lds_fwin[wv][lane]) seedextend_lds(wtaxa + lds_fstart[wv][lane], lds_fwin[wv][lane], min_seed, max_gap);
+            if (lane < nfr && my_win) seedextend_lds(wtaxa + my_start, my_win, min_seed, max_gap);
             wave_lds_sync();
         }
         // ---- aggregate ----
         for (uint32_t k = 0; k < nr; k++) {
             const uint32_t total = lds_total[wv][k];
             uint32_t res_taxon = 0, res_status = 4u;   // UMGAP_READ_UNSUPPORTED: use lookup_prot9 + aggregate for such reads
-            if (total != 0xFFFFFFFFu) lca_star_from_lds(V, tree_like, wtaxa + k * PROT_MAX_WINDOWS, total, lower_bound, wkeys, wcnt, lane, res_taxon, res_status);
+            if (total != 0xFFFFFFFFu) lca_star_from_lds(V, tree_like, wtaxa + wfstart[k * F], total, lower_bound, wkeys, wcnt, lane, res_taxon, res_status);
             if (lane == 0) {
                 out_taxon[r0 + k] = res_taxon;
                 out_status[r0 + k] = res_status;

@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void k_gather(const uint64_t* __restrict__ slo
     constexpr uint32_t BUCKETS = (LANES + 3) / 4;
     for (size_t i = t / LANES; i < n; i += stride) {
         uint64_t h = mix45(i * 0x9E3779B97F4A7C15ull >> 19);
-        uint32_t bucket = (uint32_t)(h % (nb - BUCKETS + 1));
+        uint32_t bucket = __umulhi((uint32_t)h, nb - BUCKETS + 1);   // multiply-high, not a 64-bit modulo: the benchmark must not be ALU bound
         const u32x4* p = reinterpret_cast<const u32x4*>(slots) + ((size_t)bucket * 4 + j);
         u32x4 e = __builtin_nontemporal_load(p);
         uint32_t x = e.x ^ e.y ^ e.z ^ e.w;
@@ -338,6 +338,31 @@ __global__ __launch_bounds__(256) void k_gather(const uint64_t* __restrict__ slo
         for (int o = 1; o < LANES; o <<= 1) x ^= (uint32_t)__shfl_xor((int)x, o, 64);
         if (j == 0) out[i] = x;
     }
+}
+
+// the same with U independent probes in flight per lane (memory-level parallelism like the probe kernels') and no
+// store per probe: what was read is xor-folded in a register and written once per lane at the end, so the
+// figure is a pure random-read rate (the per-probe stores of k_gather cost it about a fifth)
+template <int LANES, int U>
+__global__ __launch_bounds__(256) void k_gather_mlp(const uint64_t* __restrict__ slots, uint32_t nb, size_t n,
+                                                    uint32_t* __restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = ((size_t)gridDim.x * blockDim.x) / LANES;
+    const uint32_t j = threadIdx.x % LANES;
+    uint32_t acc = 0;
+    for (size_t i = t / LANES; i < n; i += stride * U) {
+        u32x4 e[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            size_t ii = i + (size_t)u * stride;
+            uint64_t h = mix45(ii * 0x9E3779B97F4A7C15ull >> 19);
+            uint32_t bucket = __umulhi((uint32_t)h, nb);
+            e[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(slots) + ((size_t)bucket * 4 + j));
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) acc ^= e[u].x ^ e[u].y ^ e[u].z ^ e[u].w;
+    }
+    if (t < n) out[t] = acc;
 }
 
 __global__ void k_fill(uint64_t* p, size_t n, uint64_t v) {
@@ -357,7 +382,7 @@ inline int grid_for(size_t n, int per_block = 256, int max_blocks = 256 * 8) {
 // host side
 // ------------------------------------------------------------------------------------------
 uint32_t choose_m(uint64_t n, double load) {
-    if (!(load > 0.0 && load < 1.0)) load = 0.6;
+    if (!(load > 0.0 && load < 1.0)) load = 0.5;
     double buckets = std::ceil((double)n / (SLOTS * load));
     uint64_t m = (uint64_t)std::ceil(buckets / (double)(1u << A_BITS));
     if (m < 1) m = 1;
@@ -913,6 +938,17 @@ int umgap_bench_gather_dev(umgap_index* ix, size_t n, uint32_t bytes_per_probe, 
     hipStream_t s = (hipStream_t)stream;
     uint32_t nb = ix->view.n_resident;
     int g = 256 * 8;
+    if (bytes_per_probe >> 16) {   // bits 16+: that many probes in flight per lane, no store per probe (pure random-read rate)
+        const uint32_t fl = bytes_per_probe >> 16, bytes = bytes_per_probe & 0xFFFFu;
+        if (bytes == 64 && fl == 2) hipLaunchKernelGGL((k_gather_mlp<4, 2>), dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out);
+        else if (bytes == 64 && fl == 4) hipLaunchKernelGGL((k_gather_mlp<4, 4>), dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out);
+        else if (bytes == 64 && fl == 8) hipLaunchKernelGGL((k_gather_mlp<4, 8>), dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out);
+        else if (bytes == 128 && fl == 4) hipLaunchKernelGGL((k_gather_mlp<8, 4>), dim3(g), dim3(256), 0, s, ix->view.slots, nb - 1, n, d_out);
+        else if (bytes == 32 && fl == 8) hipLaunchKernelGGL((k_gather_mlp<2, 8>), dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out);
+        else return fail(UMGAP_ERR_INVALID, "umgap_bench_gather_dev: unsupported bytes / in-flight combination");
+        UMGAP_HIP(hipGetLastError());
+        return UMGAP_OK;
+    }
     switch (bytes_per_probe) {
         case 16: hipLaunchKernelGGL(k_gather<1>, dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out); break;
         case 32: hipLaunchKernelGGL(k_gather<2>, dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out); break;

@@ -61,10 +61,13 @@ __device__ __forceinline__ bool locate(const TableView& T, uint64_t key, uint32_
 // overflowed at build time (rare) sends its quad down the displacement chain afterwards.
 // Split in two phases so that a caller can issue several batches of 64 before evaluating any.
 struct ProbeBatch {
-    const u32x4* p[4];
-    uint32_t want[4];
-    u32x4 e[4];
+    uint32_t l[4];      // home bucket (local index) of the round's key, quad-uniform
+    uint32_t want[4];   // tag | valid << 31
+    u32x4 e[4];         // this lane's 16 bytes of the bucket being looked at
 };
+__device__ __forceinline__ const u32x4* bucket_ptr(const TableView& T, uint32_t l, uint32_t j) {
+    return reinterpret_cast<const u32x4*>(T.slots) + ((size_t)l * 4 + j);
+}
 __device__ __forceinline__ void probe_issue(const TableView& T, uint32_t local, uint32_t tagv, uint32_t lane, ProbeBatch& B) {
     const uint32_t q = lane >> 2, j = lane & 3;
 #pragma unroll
@@ -72,32 +75,67 @@ __device__ __forceinline__ void probe_issue(const TableView& T, uint32_t local, 
         int src = 16 * r + (int)q;
         uint32_t l = (uint32_t)__shfl((int)local, src, 64);
         B.want[r] = (uint32_t)__shfl((int)tagv, src, 64);
-        l = (B.want[r] >> 31) ? l : 0u;  // invalid key: read bucket 0, result discarded
-        B.p[r] = reinterpret_cast<const u32x4*>(T.slots) + ((size_t)l * 4 + j);
-        B.e[r] = __builtin_nontemporal_load(B.p[r]);
+        B.l[r] = (B.want[r] >> 31) ? l : 0u;  // invalid key: read bucket 0, result discarded
+        B.e[r] = __builtin_nontemporal_load(bucket_ptr(T, B.l[r], j));
     }
 }
-// res[r] (quad-uniform) = taxon of key 16r + (lane >> 2), or `miss`.
-__device__ __forceinline__ void probe_eval(const TableView& T, ProbeBatch& B, uint32_t miss, uint32_t lane, uint32_t (&res)[4]) {
-    const uint32_t j = lane & 3;
+// A batch that was not issued (tail of a group): every key invalid, nothing pending.
+__device__ __forceinline__ void probe_skip(ProbeBatch& B) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        const bool valid = B.want[r] >> 31;
-        uint32_t w = B.want[r] & R_MASK, val;
-        uint32_t f = eval_bucket(B.e[r], w, j, val);
-        // displacement chain: only past buckets flagged as overflowed (halo keeps p in range)
-        uint32_t d = 1;
-        for (; valid && !(f & 1u) && (f & 2u) && d <= MAX_DISP; d++) {
-            B.p[r] += 4;
-            w += 1u << R_BITS;
-            f = eval_bucket(__builtin_nontemporal_load(B.p[r]), w, j, val);
+    for (int r = 0; r < 4; r++) { B.l[r] = 0u; B.want[r] = 0u; B.e[r] = u32x4{0u, 0u, 0u, 0u}; }
+}
+// res[b][r] (quad-uniform) = taxon of key 16r + (lane >> 2) of batch b, or `miss`.
+// The displacement chains of ALL rounds of ALL batches advance together: step d = the loads of bucket home + d
+// for every quad that still has to look further (issued back to back), then their evaluation.  Walking the
+// chain of each round on its own, as the first version did, serialises up to NB*4 memory round trips per
+// call with a handful of requests in flight each -- at load 0.6 that, not the request rate, set the pace.
+template <int NB>
+__device__ __forceinline__ void probe_eval_multi(const TableView& T, ProbeBatch (&B)[NB], uint32_t miss, uint32_t lane, uint32_t (&res)[NB][4]) {
+    const uint32_t j = lane & 3;
+    uint32_t found = 0, pend = 0;  // bit b*4+r, quad-uniform: key found / must look in the next bucket
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            uint32_t val;
+            uint32_t f = eval_bucket(B[b].e[r], B[b].want[r] & R_MASK, j, val);
+            if (!(B[b].want[r] >> 31)) f = 0u;
+            res[b][r] = (f & 1u) ? val : miss;
+            found |= (f & 1u) << (b * 4 + r);
+            pend |= ((f & 3u) == 2u ? 1u : 0u) << (b * 4 + r);
         }
-        res[r] = (valid && (f & 1u)) ? val : miss;
-        if (valid && !(f & 1u) && (f & 2u) && T.n_stash) {  // chain exhausted through flagged buckets
-            uint32_t home = (uint32_t)((reinterpret_cast<const uint64_t*>(B.p[r]) - T.slots) / SLOTS) - MAX_DISP + T.home_lo;
-            res[r] = stash_lookup(T, home, B.want[r] & R_MASK, miss);
-        }
+    for (uint32_t d = 1; d <= MAX_DISP && __any(pend != 0u); d++) {
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (pend & (1u << (b * 4 + r))) B[b].e[r] = __builtin_nontemporal_load(bucket_ptr(T, B[b].l[r] + d, j));  // halo keeps it in range
+        uint32_t next = 0;
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (pend & (1u << (b * 4 + r))) {
+                    uint32_t val;
+                    uint32_t f = eval_bucket(B[b].e[r], (B[b].want[r] & R_MASK) + (d << R_BITS), j, val);
+                    if (f & 1u) res[b][r] = val;
+                    next |= ((f & 3u) == 2u ? 1u : 0u) << (b * 4 + r);
+                }
+        pend = next;
     }
+    if (pend && T.n_stash) {  // chain exhausted through flagged buckets
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (pend & (1u << (b * 4 + r))) res[b][r] = stash_lookup(T, B[b].l[r] + T.home_lo, B[b].want[r] & R_MASK, miss);
+    }
+    (void)found;
+}
+__device__ __forceinline__ void probe_eval(const TableView& T, ProbeBatch& B, uint32_t miss, uint32_t lane, uint32_t (&res)[4]) {
+    ProbeBatch (&arr)[1] = reinterpret_cast<ProbeBatch (&)[1]>(B);
+    uint32_t (&r1)[1][4] = reinterpret_cast<uint32_t (&)[1][4]>(res);
+    probe_eval_multi<1>(T, arr, miss, lane, r1);
 }
 __device__ __forceinline__ void wave_probe64_vals(const TableView& T, uint32_t local, uint32_t tagv, uint32_t miss,
                                                   uint32_t lane, uint32_t (&res)[4]) {
