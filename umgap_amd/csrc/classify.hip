@@ -105,7 +105,9 @@ constexpr uint32_t STRIP = 1024;  // taxa per wave held in LDS between the stage
 // A wave owns a GROUP of G = min(STRIP / stride, 64 / frags) reads at a time: all their keys are
 // probed (chunks of 64, two chunks in flight) into the LDS strip, seedextend then runs on all
 // G * frags fragments at once (one lane each), and the G reads are aggregated one after another.
-__global__ __launch_bounds__(256) void k_classify9(TableView T, TaxView V, int method, const uint64_t* __restrict__ keys,
+// 94 VGPRs would allow 5 waves/SIMD; 4 measured faster (18.8 vs 19.6 ms): the request rate is the ceiling and a fifth
+// wave only adds contention.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_classify9(TableView T, TaxView V, int method, const uint64_t* __restrict__ keys,
                                                    size_t n_reads, uint32_t stride, uint32_t frags, uint32_t min_seed, uint32_t max_gap,
                                                    float lower_bound, uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status) {
     __shared__ uint32_t lds_taxa[4][STRIP], lds_keys[4][256], lds_cnt[4][256];
@@ -330,7 +332,7 @@ extern "C" int umgap_classify9_dev(umgap_index* ix, umgap_taxonomy* tx, int meth
     if (fragments_per_read && G * fragments_per_read > 64) G = 64 / fragments_per_read;
     size_t groups = (n_reads + G - 1) / G;
     size_t g = (groups + 3) / 4;
-    if (g > 256 * 8) g = 256 * 8;
+    if (g > 256 * 8) g = 256 * 8;     // measured: 8 workgroups per CU (two resident rounds) beats 4 and 16
     hipLaunchKernelGGL(k_classify9, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, d_keys45, n_reads,
                        kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status);
     UMGAP_HIP(hipGetLastError());
