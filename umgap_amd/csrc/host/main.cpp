@@ -608,13 +608,56 @@ int cmd_taxa2agg(const std::vector<std::string>& args) {
     return 0;
 }
 
-// ---- seedextend (unranked mode on the device) -------------------------------------------------
+// ---- seedextend: the text filter (the fused pipeline runs it on the device) ---------------------------
+// -r <taxons.tsv>: TaxonList::score (src/taxon.rs:181-191) of a taxon = Rank::score (src/rank.rs:86-99) of its nearest
+// ancestor-or-self that is ranked or the root.  `self < &Rank::Species` is the first arm of Rank::score and PartialOrd is
+// None for NoRank, so every named rank above species scores 12 and everything else is None (=> the -p penalty).
+struct RankScores {
+    std::vector<int8_t> present, ranked_or_root;   // by id
+    std::vector<uint64_t> parent;
+    std::vector<uint8_t> rank;
+    std::vector<int16_t> memo;                     // -2 not computed, -1 None, else the score
+    explicit RankScores(const TaxonRows& rows) {
+        uint64_t max_id = 0;
+        for (uint64_t id : rows.id) max_id = std::max(max_id, id);
+        size_t len = (size_t)max_id + 1;            // src/taxon.rs:136-145
+        present.assign(len, 0); parent.assign(len, 0); rank.assign(len, 0); memo.assign(len, -2);
+        for (size_t i = 0; i < rows.id.size(); i++) { size_t id = (size_t)rows.id[i]; present[id] = 1; parent[id] = rows.parent[i]; rank[id] = rows.rank[i]; }
+        if (!present[0]) { present[0] = 1; parent[0] = 0; rank[0] = 0; }   // new_with_unknown(.., true), :149-155
+    }
+    // None = -1
+    int score(uint64_t index) {
+        uint64_t cur = index;
+        std::vector<uint64_t> path;
+        int res = -1;
+        for (size_t steps = 0;; steps++) {
+            if (cur >= present.size() || !present[cur]) { res = -1; break; }        // get() == None ends the walk
+            if (memo[cur] != -2) { res = memo[cur]; break; }
+            if (parent[cur] == cur || rank[cur] != 0) { res = (rank[cur] != 0 && rank[cur] < 27) ? 12 : -1; memo[cur] = (int16_t)res; break; }
+            if (steps > present.size()) throw CliError("taxonomy has a parent cycle without a ranked taxon");   // the reference would not terminate
+            path.push_back(cur);
+            cur = parent[cur];
+        }
+        for (uint64_t v : path) memo[v] = (int16_t)res;
+        return res;
+    }
+};
+
 int cmd_seedextend(const std::vector<std::string>& args) {
     Parsed p = parse_args(args, {{'s', "min-seed-size", true}, {'g', "max-gap-size", true}, {'r', "ranked", true}, {'p', "penalty", true}});
     uint64_t s = opt_usize(p, "min-seed-size", 2), g = opt_usize(p, "max-gap-size", 0);
-    (void)opt_usize(p, "penalty", 5);
-    if (p.has("ranked")) throw CliError("seedextend --ranked is outside the accelerated path (scripts/umgap-analyse.sh never uses it)");
+    uint64_t penalty = opt_usize(p, "penalty", 5);
     if (!p.positional.empty()) usage_error("Found argument '" + p.positional[0] + "' which wasn't expected, or isn't valid in this context");
+    std::optional<RankScores> ranks;
+    if (auto tf = p.get("ranked")) {
+        RankScores rs(read_taxa_file(*tf));
+        for (size_t id = 0; id < rs.present.size(); id++) (void)rs.score(id);   // memoise everything: workers only read
+        ranks.emplace(std::move(rs));
+    }
+    auto score_of = [&](uint64_t t) -> uint64_t {
+        if (t >= ranks->memo.size() || ranks->memo[t] < 0) return penalty;
+        return (uint64_t)ranks->memo[t];
+    };
     // host restatement of the record state machine for the text filter (the device kernels
     // umgap_seedextend_dev / umgap_classify9_dev serve the fused pipeline), block-parallel over
     // records.  src/commands/seedextend.rs:99-148
@@ -634,23 +677,19 @@ int cmd_seedextend(const std::vector<std::string>& args) {
             LineCursor lc{d + cuts[pi], d + cuts[pi + 1]};
             std::string_view line, header;
             std::vector<uint64_t> t;
+            std::vector<std::pair<size_t, size_t>> seeds;
             bool open = false;
             auto flush_record = [&]() {
                 if (!open) return;
                 open = false;
                 t.push_back(0);                                                   // :99
+                seeds.clear();
                 size_t start = 0, end = 1, same_tid = 1, same_max = 1;
                 uint64_t last = t[0];
-                const size_t mark = P.out.size();
-                P.out.push_back('>'); P.out.append(header); P.out.push_back('\n');
-                auto emit = [&](size_t a0, size_t e0) {
-                    if (a0 > e0 || e0 > t.size()) { P.panic = true; P.out.resize(mark); return; }
-                    for (size_t j = a0; j < e0; j++) { append_uint(P.out, t[j]); P.out.push_back('\n'); }
-                };
                 while (end < t.size()) {
                     if (last == t[end]) { same_tid++; end++; continue; }
                     if (last == 0 && same_tid > g) {
-                        if (same_max >= s) emit(start, end - same_tid);
+                        if (same_max >= s) seeds.emplace_back(start, end - same_tid);
                         start = end; last = t[end]; same_tid = 1; same_max = 1; end++;
                         continue;
                     }
@@ -660,7 +699,24 @@ int cmd_seedextend(const std::vector<std::string>& args) {
                 }
                 if (same_max >= s) {
                     if (last == 0) end -= same_tid;
-                    emit(start, end);
+                    seeds.emplace_back(start, end);
+                }
+                if (ranks && !seeds.empty()) {   // :150-163: only the best extended seed; max_by_key keeps the LAST maximum
+                    size_t best = 0;
+                    uint64_t best_score = 0;
+                    for (size_t i = 0; i < seeds.size(); i++) {
+                        uint64_t sc = 0;
+                        for (size_t j = seeds[i].first; j < seeds[i].second && j < t.size(); j++) sc += score_of(t[j]);
+                        if (i == 0 || sc >= best_score) { best = i; best_score = sc; }
+                    }
+                    seeds[0] = seeds[best];
+                    seeds.resize(1);
+                }
+                const size_t mark = P.out.size();
+                P.out.push_back('>'); P.out.append(header); P.out.push_back('\n');
+                for (auto& se : seeds) {
+                    if (se.first > se.second || se.second > t.size()) { P.panic = true; P.out.resize(mark); break; }   // taxons[start..end]
+                    for (size_t j = se.first; j < se.second; j++) { append_uint(P.out, t[j]); P.out.push_back('\n'); }
                 }
                 t.clear();
             };
