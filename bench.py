@@ -34,8 +34,8 @@ HBM_PEAK_GBPS = 8000.0         # MI355X HBM3E spec (MI355X_MICROARCH.md)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=["auto", "replica", "sharded"], default="auto")
     ap.add_argument("--pairs-per-step", type=int, default=int(os.environ.get("UMGAP_BENCH_PAIRS", 10_000_000)))
     ap.add_argument("--batches", type=int, default=5, help="resident batches (5 x 10 M = the 50 M-pair config)")
