@@ -294,6 +294,24 @@ def main():
         el = time.perf_counter() - t1
         out["with_seedextend"] = {"value": round(args.steps * B / el, 1), "unit": "pairs/s", "ms_per_step": round(1e3 * el / args.steps, 3),
                                   "pipeline": "probe -> seedextend -g1 -s3 (per read end) -> taxa2agg -l2 -a lca*, one fused kernel"}
+    if world == 1 and fused and not args.seedextend:
+        # the two 9-mer sensitivity pipelines of scripts/umgap-analyse.sh:277-288 through the fused kernel for the other
+        # aggregation strategies (same batches; reported next to the headline, not part of it)
+        others = {}
+        for name, kw in (("high_sensitivity: seedextend -g1 -s3 | taxa2agg -l1 -a hybrid -f 0.25", dict(method="tree", strategy="hybrid", factor=0.25, lower_bound=1.0, min_seed_size=3)),
+                         ("max_sensitivity: seedextend -g1 -s2 | taxa2agg -l1 -m rmq -a mrtl", dict(method="rmq", strategy="mrtl", lower_bound=1.0, min_seed_size=2))):
+            def o_step(i):
+                classify9_dev(w.index, w.taxonomy, keys[i % n_batches], B, KMERS, d_taxon, d_status, fragments_per_read=2, max_gap_size=1, **kw)
+            o_step(0)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            n_o = min(args.steps, 5)
+            for i in range(n_o):
+                o_step(i + 1)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t1
+            others[name] = {"value": round(n_o * B / el, 1), "unit": "pairs/s", "ms_per_step": round(1e3 * el / n_o, 3)}
+        out["other_pipelines"] = others
     if rank == 0 and world == 1 and not args.no_gather:
         # measured random-sector gather ceilings over the same table (SURVEY.md §8d second denominator)
         n = 1 << 28

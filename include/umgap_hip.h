@@ -210,6 +210,15 @@ int umgap_classify9_dev(umgap_index* ix, umgap_taxonomy* tx, int method, float l
                         uint32_t fragments_per_read, uint32_t min_seed_size, uint32_t max_gap_size,
                         uint32_t* d_out_taxon, uint32_t* d_out_status, void* stream);
 
+/* The same for every aggregation strategy of taxa2agg (MRTL, tree-hybrid = its default, rmq-hybrid;
+ * UMGAP_STRATEGY_LCA_STAR forwards to umgap_classify9_dev): the fused form of
+ * `prot2kmer2lca -o | seedextend | uniq -d / | taxa2agg -m M -a A -f F -l L` for the sensitivity
+ * pipelines (scripts/umgap-analyse.sh:277-288).  Ties as in umgap_aggregate (smallest preorder). */
+int umgap_classify9_strategy_dev(umgap_index* ix, umgap_taxonomy* tx, int method, int strategy, float factor,
+                                 float lower_bound, int ranked_only, const uint64_t* d_keys45, size_t n_reads,
+                                 uint32_t kmers_per_read, uint32_t fragments_per_read, uint32_t min_seed_size,
+                                 uint32_t max_gap_size, uint32_t* d_out_taxon, uint32_t* d_out_status, void* stream);
+
 /* Surface B of the same pipeline: the reads arrive as protein fragments (1 byte per residue, what
  * `prot2kmer2lca` reads, src/commands/prot2kmer2lca.rs:172-179): read r owns fragments
  * [r*F, (r+1)*F) of the CSR (d_bytes, d_frag_offsets[n_reads*F + 1]); every window of 9 residues of

@@ -499,6 +499,70 @@ def test_fused_classify_vs_oracle(api, torch_cuda, stride, n_pairs, with_seedext
     assert torch.equal(d_t, d_t2) and torch.equal(d_s, d_s2)
 
 
+@pytest.mark.parametrize("with_seedextend", [False, True])
+@pytest.mark.parametrize("method,strategy,factor,lb", [("tree", "hybrid", 0.25, 1.0), ("rmq", "mrtl", 0.25, 1.0), ("rmq", "hybrid", 0.5, 0.0),
+                                                        ("tree", "hybrid", 0.8, 2.0), ("rmq", "mrtl", 0.25, 5.0)])
+@pytest.mark.parametrize("stride,n_pairs", [(84, 20_001), (128, 2_001), (6, 999)])
+def test_fused_classify_other_strategies(api, torch_cuda, stride, n_pairs, method, strategy, factor, lb, with_seedextend):
+    """umgap_classify9_strategy_dev (probe -> [seedextend] -> MRTL / hybrid in one kernel, the sensitivity pipelines of
+    scripts/umgap-analyse.sh:277-288) against the oracle (tie sets) and, bit for bit, against the unfused device path."""
+    torch = torch_cuda
+    from umgap_amd.synth import ADD_B, MUL_A, SyntheticWorkload
+    n_tax, n_keys = 20_000, 1_000_000
+    w = SyntheticWorkload(n_tax=n_tax, n_keys=n_keys)
+    d_keys = w.reads(0, n_pairs, kmers_per_pair=stride)
+    d_t = torch.empty(n_pairs, dtype=torch.int32, device="cuda")
+    d_s = torch.empty(n_pairs, dtype=torch.int32, device="cuda")
+    api.classify9_dev(w.index, w.taxonomy, d_keys, n_pairs, stride, d_t, d_s, method=method, strategy=strategy, factor=factor, lower_bound=lb,
+                      fragments_per_read=2 if with_seedextend else 0, min_seed_size=2, max_gap_size=1)
+    d_hits = w.index.lookup9_dev(d_keys)
+    if with_seedextend:
+        api.seedextend_dev(d_hits, stride=stride // 2, n_records=2 * n_pairs, min_seed_size=2, max_gap_size=1)
+    d_t2, d_s2 = torch.empty_like(d_t), torch.empty_like(d_s)
+    w.taxonomy.aggregate_strided_dev(d_hits, stride, n_pairs, d_t2, d_s2, method=method, strategy=strategy, factor=factor, lower_bound=lb)
+    torch.cuda.synchronize()
+    assert torch.equal(d_t, d_t2) and torch.equal(d_s, d_s2)
+    agg = O.Aggregator(O.Taxonomy.from_arrays(w.ids, w.parents, w.valid, w.rank), method, strategy, factor=factor)
+    hits = d_hits.cpu().numpy().view(np.uint32)
+    offs = np.arange(n_pairs + 1, dtype=np.uint64) * stride
+    t, s = d_t.cpu().numpy().view(np.uint32), d_s.cpu().numpy().view(np.uint32)
+    nbad, bad, wt, ws = agg.taxa2agg_check(hits, offs, t, s, lower_bound=lb, nthreads=8)
+    assert nbad == 0, (bad, t[bad.astype(int)], wt[bad.astype(int)])
+    assert (s == 0).any()
+
+
+def test_fused_classify_other_strategies_many_distinct_taxa(api, torch_cuda):
+    """Reads with more than 64 distinct taxa among their 128 k-mers take the second launch (larger scratch)."""
+    torch = torch_cuda
+    from umgap_amd.api import Index, Taxonomy
+    from umgap_amd.synth import synthetic_taxonomy
+    ids, par, valid, rank = synthetic_taxonomy(5000, 8000, max_depth=12, seed=9)
+    tx = Taxonomy(ids, par, valid, rank)
+    rng = np.random.default_rng(3)
+    n_keys, stride, n_reads = 40_000, 128, 600
+    keys = rng.permutation(np.unique(rng.integers(0, 1 << 45, 2 * n_keys, dtype=np.uint64)))[:n_keys]
+    vals = rng.choice(ids, n_keys).astype(np.uint32)
+    ix = Index.build(keys, vals)
+    q = keys[rng.integers(0, n_keys, n_reads * stride)]            # all hits, ~128 distinct taxa per read
+    q[: 100 * stride] = keys[rng.integers(0, 40, 100 * stride)]   # the first 100 reads: few distinct taxa
+    d_keys = torch.from_numpy(q.view(np.int64)).cuda()
+    d_t = torch.empty(n_reads, dtype=torch.int32, device="cuda")
+    d_s = torch.empty_like(d_t)
+    d_t2, d_s2 = torch.empty_like(d_t), torch.empty_like(d_t)
+    for method, strategy in (("tree", "hybrid"), ("rmq", "mrtl"), ("rmq", "hybrid")):
+        api.classify9_dev(ix, tx, d_keys, n_reads, stride, d_t, d_s, method=method, strategy=strategy, factor=0.3, lower_bound=0.0)
+        d_hits = ix.lookup9_dev(d_keys)
+        tx.aggregate_strided_dev(d_hits, stride, n_reads, d_t2, d_s2, method=method, strategy=strategy, factor=0.3, lower_bound=0.0)
+        torch.cuda.synchronize()
+        assert torch.equal(d_t, d_t2) and torch.equal(d_s, d_s2)
+        hits = d_hits.cpu().numpy().view(np.uint32)
+        assert max(len(set(hits[r * stride:(r + 1) * stride].tolist())) for r in range(100, n_reads)) > 64
+        agg = O.Aggregator(O.Taxonomy.from_arrays(ids, par, valid, rank), method, strategy, factor=0.3)
+        offs = np.arange(n_reads + 1, dtype=np.uint64) * stride
+        nbad, bad, _, _ = agg.taxa2agg_check(hits, offs, d_t.cpu().numpy().view(np.uint32), d_s.cpu().numpy().view(np.uint32), lower_bound=0.0, nthreads=8)
+        assert nbad == 0, bad
+
+
 def test_synth_pipeline_small(api, torch_cuda):
     t, s = _pipeline_check(api, torch_cuda, n_tax=20_000, n_keys=1_000_000, n_pairs=20_000, with_seedextend=False)
     assert (s == 0).mean() > 0.9 and len(np.unique(t)) > 1000

@@ -96,6 +96,7 @@ def load():
         "umgap_aggregate_dev": (i32, [vp, i32, i32, f32, f32, i32, vp, vp, vp, sz, vp, vp, vp]),
         "umgap_aggregate_strided_dev": (i32, [vp, i32, i32, f32, f32, i32, vp, u32, sz, vp, vp, vp]),
         "umgap_classify9_dev": (i32, [vp, vp, i32, f32, i32, vp, sz, u32, u32, u32, u32, vp, vp, vp]),
+        "umgap_classify9_strategy_dev": (i32, [vp, vp, i32, i32, f32, f32, i32, vp, sz, u32, u32, u32, u32, vp, vp, vp]),
         "umgap_classify_prot9_dev": (i32, [vp, vp, i32, f32, i32, vp, vp, sz, u32, i32, u32, u32, vp, vp, vp]),
         "umgap_classify_records": (i32, [vp, vp, i32, i32, f32, f32, i32, vp, vp, sz, vp, sz, i32, u32, u32, vp, vp]),
         "umgap_index_build_windows9_dev": (i32, [vp, vp, vp, sz, u32, u64, dbl, i32, pp]),

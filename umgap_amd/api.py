@@ -326,11 +326,18 @@ class Taxonomy:
 
 
 def classify9_dev(index, taxonomy, d_keys45, n_reads, kmers_per_read, d_out_taxon, d_out_status, method="tree", lower_bound=0.0,
-                  ranked_only=False, fragments_per_read=0, min_seed_size=2, max_gap_size=0, stream=None):
-    """Fused probe -> [seedextend] -> LCA* over packed 9-mers (include/umgap_hip.h: umgap_classify9_dev)."""
-    check(_lib.load().umgap_classify9_dev(index._h, taxonomy._h, METHODS[method], lower_bound, int(ranked_only), _dev_ptr(d_keys45), n_reads,
-                                          kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, _dev_ptr(d_out_taxon),
-                                          _dev_ptr(d_out_status), _stream_ptr(stream)))
+                  ranked_only=False, fragments_per_read=0, min_seed_size=2, max_gap_size=0, stream=None, strategy="lca*", factor=0.25):
+    """Fused probe -> [seedextend] -> aggregate over packed 9-mers (include/umgap_hip.h: umgap_classify9_dev for LCA*,
+    umgap_classify9_strategy_dev for MRTL and the hybrids)."""
+    if strategy == "lca*":
+        check(_lib.load().umgap_classify9_dev(index._h, taxonomy._h, METHODS[method], lower_bound, int(ranked_only), _dev_ptr(d_keys45), n_reads,
+                                              kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, _dev_ptr(d_out_taxon),
+                                              _dev_ptr(d_out_status), _stream_ptr(stream)))
+    else:
+        check(_lib.load().umgap_classify9_strategy_dev(index._h, taxonomy._h, METHODS[method], STRATEGIES[strategy], factor, lower_bound,
+                                                       int(ranked_only), _dev_ptr(d_keys45), n_reads, kmers_per_read, fragments_per_read,
+                                                       min_seed_size, max_gap_size, _dev_ptr(d_out_taxon), _dev_ptr(d_out_status),
+                                                       _stream_ptr(stream)))
 
 
 def classify_prot9_dev(index, taxonomy, d_bytes, d_frag_offsets, n_reads, fragments_per_read, d_out_taxon, d_out_status, method="tree",

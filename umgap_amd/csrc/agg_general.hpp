@@ -1,0 +1,270 @@
+// agg_general.hpp -- the per-read body of the general aggregation (MRTL, tree-hybrid, rmq-hybrid), shared by
+// k_agg_general (aggregate_general.hip: hits in HBM) and k_classify9_general (classify.hip: hits in LDS).
+// Algorithms and reference citations: aggregate_general.hip.
+#pragma once
+#include "agg_common.hpp"
+
+namespace umgap {
+namespace agg {
+
+template <int CAP, int HCAP>
+struct Scratch {
+    uint32_t hkeys[HCAP], hcnt[HCAP];
+    uint32_t a_tax[CAP], a_slot[CAP];
+    float a_cnt[CAP];
+    uint32_t s_pre[CAP], s_last[CAP];
+    float s_cnt[CAP];
+    uint32_t b_pre[CAP], b_last[CAP];
+    float b_cnt[CAP];
+    uint32_t b_dep[CAP], b_adj[CAP], b_lca[CAP];
+};
+
+__device__ __forceinline__ void wave_sync() {  // LDS hand-off between lanes of one wave
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ uint64_t lanemask_lt(uint32_t lane) { return (1ull << lane) - 1ull; }
+__device__ __forceinline__ float wave_maxf(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { float w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+    return v;
+}
+
+// LCA of two list members by preorder index, u < v, u not an ancestor of v: binary lifting from v
+// to the highest ancestor that still starts after u; its parent is the LCA.
+__device__ __forceinline__ uint32_t lane_lca(const TaxView& V, uint32_t u, uint32_t v) {
+    uint32_t y = v;
+    for (int k = (int)V.up_levels - 1; k >= 0; k--) {
+        uint32_t c = V.up[(size_t)k * V.n_reach + y];
+        if (c > u) y = c;
+    }
+    return V.parent_pre[y];
+}
+
+// One read through count -> filter -> resolve -> sort -> strategy, by one wave with its scratch S (hash table clean on
+// entry and on exit).  rp / sp may point to global memory or to LDS (the fused kernel).  Returns false when the read has
+// more than CAP distinct taxa (nothing written; S clean).
+template <bool SCORED, int CAP, int HCAP>
+__device__ __forceinline__ bool general_read(const TaxView& V, Scratch<CAP, HCAP>& S, int method, int strategy, float factor, float lower_bound,
+                                             const uint32_t* rp, const float* sp, uint64_t n, uint32_t lane, uint32_t& res_taxon, uint32_t& res_status) {
+    // rmq::rtl walks `ancestors` like the tree aggregators (src/rmq/rtl.rs:42-49)
+    const bool tree_like = method != UMGAP_METHOD_RMQ || strategy == UMGAP_STRATEGY_MRTL;
+    res_taxon = 0;
+    res_status = UMGAP_READ_OK;
+    bool done = false;
+    {
+        // ---- 1. distinct taxa (a_tax) with their slots -----------------------------------
+        uint32_t nd = 0;
+        bool overflow = false;
+        for (uint64_t base = 0; base < n && !overflow; base += 64) {
+            uint64_t j = base + lane;
+            uint32_t t = j < n ? rp[j] : 0u;
+            bool lead = false, full = false;
+            uint32_t slot = 0;
+            if (t != 0) {  // src/commands/taxa2agg.rs:169 drops taxon 0
+                slot = (t * 0x9E3779B1u) >> (32 - __builtin_ctz(HCAP));
+                uint32_t probes = 0;
+                for (;;) {
+                    uint32_t old = atomicCAS(&S.hkeys[slot], 0u, t);
+                    if (old == 0u) { lead = true; break; }
+                    if (old == t) break;
+                    slot = (slot + 1) & (HCAP - 1);
+                    if (++probes == HCAP) { full = true; break; }
+                }
+                if (!SCORED && !full) atomicAdd(&S.hcnt[slot], 1u);
+            }
+            uint64_t lm = __ballot(lead);
+            uint32_t idx = nd + (uint32_t)__builtin_popcountll(lm & lanemask_lt(lane));
+            if (lead && idx < CAP) { S.a_tax[idx] = t; S.a_slot[idx] = slot; }
+            nd += (uint32_t)__builtin_popcountll(lm);
+            overflow = nd > CAP || __any(full);
+        }
+        wave_sync();
+        if (overflow) {
+            // give the table back clean; the caller hands the read to a pass with a larger scratch
+            for (uint32_t i = lane; i < HCAP; i += 64) { S.hkeys[i] = 0u; S.hcnt[i] = 0u; }
+            wave_sync();
+            return false;
+        }
+        // multiplicities, then clean the slots this read used
+        for (uint32_t e = lane; e < nd; e += 64) {
+            uint32_t slot = S.a_slot[e];
+            if (!SCORED) S.a_cnt[e] = (float)S.hcnt[slot];
+            S.hkeys[slot] = 0u;
+            S.hcnt[slot] = 0u;
+        }
+        if (SCORED) {
+            // scores are added in input order (agg::count): every lane scans the read for its taxa
+            for (uint32_t eb = 0; eb < nd; eb += 64) {
+                uint32_t e = eb + lane;
+                uint32_t mine = e < nd ? S.a_tax[e] : 0u;
+                float acc = 0.0f;
+                for (uint64_t j = 0; j < n; j++) {
+                    uint32_t tj = rp[j];
+                    float sj = sp[j];
+                    if (tj == mine) acc = __fadd_rn(acc, sj);
+                }
+                if (e < nd) S.a_cnt[e] = acc;
+            }
+        }
+        wave_sync();
+
+        // ---- 2. filter + resolve + compact the survivors ---------------------------------
+        uint32_t D = 0;
+        uint64_t errkey = NOERR;
+        for (uint32_t eb = 0; eb < nd; eb += 64) {
+            uint32_t e = eb + lane;
+            bool ok = e < nd && S.a_cnt[e] >= lower_bound;  // agg::filter
+            Hit h{NONE, NONE};
+            if (ok) h = resolve(V, tree_like, S.a_tax[e], errkey);
+            bool surv = ok && h.pre != NONE;
+            uint64_t m = __ballot(surv);
+            uint32_t idx = D + (uint32_t)__builtin_popcountll(m & lanemask_lt(lane));
+            if (surv) { S.s_pre[idx] = h.pre; S.s_last[idx] = h.last; S.s_cnt[idx] = S.a_cnt[e]; }
+            D += (uint32_t)__builtin_popcountll(m);
+        }
+        wave_sync();
+        if (__any(errkey != NOERR)) {
+            uint64_t ek = wave_min64(errkey);
+            res_status = ((ek >> 32) & 1) ? UMGAP_READ_PANIC : UMGAP_READ_UNKNOWN_TAXON;
+            res_taxon = (uint32_t)ek;
+            done = true;
+        } else if (D == 0) {
+            res_status = UMGAP_READ_EMPTY;  // literal "1" (src/commands/taxa2agg.rs:174-175)
+            res_taxon = 1;
+            done = true;
+        }
+
+        if (!done) {
+            // ---- 3. sort by preorder index (distinct taxa => distinct keys): rank by counting ----
+            for (uint32_t eb = 0; eb < D; eb += 64) {
+                uint32_t e = eb + lane;
+                uint32_t p = e < D ? S.s_pre[e] : 0u, rank = 0;
+                for (uint32_t f = 0; f < D; f++) rank += S.s_pre[f] < p;
+                if (e < D) { S.b_pre[rank] = p; S.b_last[rank] = S.s_last[e]; S.b_cnt[rank] = S.s_cnt[e]; }
+            }
+            wave_sync();
+            uint32_t ans = NONE;  // preorder index of the aggregate
+            if (strategy == UMGAP_STRATEGY_MRTL) {
+                // ---- MRTL ----
+                float best = -__builtin_inff();
+                uint32_t best_i = NONE;
+                for (uint32_t ib = 0; ib < D; ib += 64) {
+                    uint32_t i = ib + lane;
+                    if (i < D) {
+                        float score = S.b_cnt[i];
+                        uint32_t pi = S.b_pre[i];
+                        for (uint32_t j = i; j-- > 0;)
+                            if (S.b_last[j] >= pi) score = __fadd_rn(score, S.b_cnt[j]);  // ancestor, nearest first
+                        if (score > best) { best = score; best_i = i; }
+                    }
+                }
+                float m = wave_maxf(best);
+                uint32_t bi = wave_min(best == m ? best_i : NONE);
+                ans = S.b_pre[bi];
+            } else {
+                // adjacent LCAs (both hybrids)
+                for (uint32_t kb = 0; kb < D; kb += 64) {
+                    uint32_t k = kb + lane;
+                    if (k < D) S.b_dep[k] = V.depth[S.b_pre[k]];
+                    if (k + 1 < D) {
+                        uint32_t u = S.b_pre[k], v = S.b_pre[k + 1];
+                        uint32_t l = S.b_last[k] >= v ? u : lane_lca(V, u, v);
+                        S.b_lca[k] = l;
+                        S.b_adj[k] = V.depth[l];
+                    }
+                }
+                wave_sync();
+                if (method == UMGAP_METHOD_TREE && CAP <= 64 && !SCORED) {
+                    // ---- tree::mix, one lane per list element: every level of the greedy descent is three wave
+                    // reductions instead of two serial scans of the range.  Unscored counts are small integers, so
+                    // the children's values (Tree::aggregate) are exact differences of one prefix sum.
+                    const uint32_t k = lane;
+                    float pfx = k < D ? S.b_cnt[k] : 0.0f;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { float t = __shfl_up(pfx, o, 64); if (lane >= (uint32_t)o) pfx = __fadd_rn(pfx, t); }
+                    const uint32_t adj_k = k + 1 < D ? S.b_adj[k] : NONE;
+                    uint32_t i = 0, j = D - 1;
+                    float wcur = __shfl(pfx, (int)(D - 1), 64);
+                    for (;;) {
+                        if (i == j) { ans = S.b_pre[j]; break; }
+                        const bool inr = k >= i && k < j;
+                        const uint32_t m = wave_min(inr ? adj_k : NONE);
+                        if (S.b_dep[i] == m) { i++; continue; }  // chain hit: collapses into the node below
+                        const uint64_t eq = __ballot(inr && adj_k == m);
+                        const uint32_t node = S.b_lca[__builtin_ctzll(eq)];
+                        const uint64_t ends = eq | (1ull << j);              // a child ends at every cut and at j
+                        const bool is_end = (ends >> k) & 1ull;
+                        const uint64_t below = ends & lanemask_lt(k);
+                        const uint32_t st = below ? 64u - (uint32_t)__builtin_clzll(below) : i;   // where this child starts
+                        const float before_raw = __shfl(pfx, (int)((st - 1u) & 63u), 64);
+                        const float seg = is_end ? __fsub_rn(pfx, st ? before_raw : 0.0f) : -1.0f;
+                        const float best_w = wave_maxf(seg);
+                        const uint32_t best_e = wave_min(is_end && seg == best_w ? k : NONE);   // first maximum, like `wsum > best_w`
+                        const uint32_t best_s = (uint32_t)__shfl((int)st, (int)best_e, 64);
+                        if (__fdiv_rn(best_w, wcur) < factor) { ans = node; break; }  // src/tree/mix.rs:57-59
+                        wcur = best_w;
+                        i = best_s;
+                        j = best_e;
+                    }
+                } else if (method == UMGAP_METHOD_TREE) {
+                    // ---- tree::mix: greedy descent over the implicit induced tree (uniform code; scored reads, whose
+                    // f32 sums depend on the order, and the large-scratch pass) ----
+                    uint32_t i = 0, j = D - 1;
+                    float wcur = 0.0f;
+                    for (uint32_t k = 0; k < D; k++) wcur = __fadd_rn(wcur, S.b_cnt[k]);
+                    for (;;) {
+                        if (i == j) { ans = S.b_pre[j]; break; }
+                        uint32_t m = NONE, node = NONE;
+                        for (uint32_t k = i; k < j; k++)
+                            if (S.b_adj[k] < m) { m = S.b_adj[k]; node = S.b_lca[k]; }
+                        if (S.b_dep[i] == m) { i++; continue; }  // chain hit: collapses into the node below
+                        float best_w = -1.0f, wsum = 0.0f;
+                        uint32_t best_s = i, best_e = i, s = i;
+                        for (uint32_t k = i; k <= j; k++) {
+                            wsum = __fadd_rn(wsum, S.b_cnt[k]);
+                            if (k == j || S.b_adj[k] == m) {
+                                if (wsum > best_w) { best_w = wsum; best_s = s; best_e = k; }
+                                s = k + 1;
+                                wsum = 0.0f;
+                            }
+                        }
+                        if (__fdiv_rn(best_w, wcur) < factor) { ans = node; break; }  // src/tree/mix.rs:57-59
+                        wcur = best_w;
+                        i = best_s;
+                        j = best_e;
+                    }
+                } else {
+                    // ---- rmq::mix: weights over hits + adjacent LCAs ----
+                    const float one_minus = __fsub_rn(1.0f, factor);
+                    float best = -__builtin_inff();
+                    uint32_t best_p = NONE;
+                    const uint32_t n_cand = 2 * D - 1;
+                    for (uint32_t cb = 0; cb < n_cand; cb += 64) {
+                        uint32_t c = cb + lane;
+                        if (c < n_cand) {
+                            uint32_t pc = c < D ? S.b_pre[c] : S.b_lca[c - D];
+                            uint32_t lc = c < D ? S.b_last[c] : V.last_of_pre[pc];
+                            float lw = 0.0f, rw = 0.0f;
+                            for (uint32_t k = 0; k < D; k++) {
+                                uint32_t pk = S.b_pre[k];
+                                if (pc <= pk && pk <= lc) lw = __fadd_rn(lw, S.b_cnt[k]);          // hit below-or-at the candidate
+                                if (pk <= pc && pc <= S.b_last[k]) rw = __fadd_rn(rw, S.b_cnt[k]);  // hit above-or-at the candidate
+                            }
+                            float score = __fadd_rn(__fmul_rn(lw, factor), __fmul_rn(rw, one_minus));  // src/rmq/mix.rs:52-54
+                            if (score > best || (score == best && pc < best_p)) { best = score; best_p = pc; }
+                        }
+                    }
+                    float m = wave_maxf(best);
+                    ans = wave_min(best == m ? best_p : NONE);
+                }
+            }
+            res_taxon = V.snap_of_pre[ans];  // snapping[aggregate] (src/commands/taxa2agg.rs:178)
+            res_status = res_taxon == NONE ? UMGAP_READ_PANIC : UMGAP_READ_OK;
+        }
+    }
+    return true;
+}
+
+}  // namespace agg
+}  // namespace umgap

@@ -14,7 +14,7 @@
 // probe -> taxa into the wave's LDS strip -> seedextend on all the group's fragments in parallel
 // lanes -> per read: LDS hash-count, leaders gather {pre,last}, O(1) range-min LCA (aggregate.hip
 // has the commentary).
-#include "agg_common.hpp"
+#include "agg_general.hpp"
 #include "probe_common.hpp"
 
 using namespace umgap;
@@ -102,6 +102,37 @@ __device__ __forceinline__ void wave_lds_sync() {
 
 constexpr uint32_t STRIP = 1024;  // taxa per wave held in LDS between the stages (4 KB)
 
+// Probe stage of a group: keys kp[0..nk) (nk <= STRIP) -> taxa (0 = miss) in the wave's LDS strip; chunks of 64 keys,
+// two chunks (8 sectors per quad) in flight.
+__device__ __forceinline__ void probe_group_to_strip(const TableView& T, const uint64_t* __restrict__ kp, uint32_t nk, uint32_t* wtaxa, uint32_t lane) {
+    const uint32_t q = lane >> 2, j = lane & 3;
+    for (uint32_t c = 0; c * 64 < nk; c += 2) {
+        ProbeBatch B[2];
+        uint32_t res[2][4];
+        const bool two = (c + 1) * 64 < nk;
+        {
+            uint32_t i = c * 64 + lane, local = 0, tag = 0, valid = 0;
+            if (i < nk) valid = locate(T, __builtin_nontemporal_load(kp + i), local, tag) ? 1u : 0u;
+            probe_issue(T, local, tag | (valid << 31), lane, B[0]);
+        }
+        if (two) {
+            uint32_t i = (c + 1) * 64 + lane, local = 0, tag = 0, valid = 0;
+            if (i < nk) valid = locate(T, __builtin_nontemporal_load(kp + i), local, tag) ? 1u : 0u;
+            probe_issue(T, local, tag | (valid << 31), lane, B[1]);
+        } else probe_skip(B[1]);
+        probe_eval_multi<2>(T, B, 0u, lane, res);
+        if (j == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                uint32_t i0 = c * 64 + 16 * r + q, i1 = i0 + 64;
+                if (i0 < nk) wtaxa[i0] = res[0][r];
+                if (two && i1 < nk) wtaxa[i1] = res[1][r];
+            }
+        }
+    }
+}
+
+
 // A wave owns a GROUP of G = min(STRIP / stride, 64 / frags) reads at a time: all their keys are
 // probed (chunks of 64, two chunks in flight) into the LDS strip, seedextend then runs on all
 // G * frags fragments at once (one lane each), and the G reads are aggregated one after another.
@@ -111,7 +142,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
                                                    size_t n_reads, uint32_t stride, uint32_t frags, uint32_t min_seed, uint32_t max_gap,
                                                    float lower_bound, uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status) {
     __shared__ uint32_t lds_taxa[4][STRIP], lds_keys[4][256], lds_cnt[4][256];
-    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t* wtaxa = lds_taxa[wv];
     uint32_t* wkeys = lds_keys[wv];
     uint32_t* wcnt = lds_cnt[wv];
@@ -128,31 +159,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const uint32_t nr = (uint32_t)min((size_t)G, n_reads - r0);
         const uint32_t nk = nr * stride;                   // keys of this group (<= STRIP)
         const uint64_t* kp = keys + r0 * stride;
-        // ---- probe: chunks of 64 keys, two chunks (8 sectors per quad) in flight ----
-        for (uint32_t c = 0; c * 64 < nk; c += 2) {
-            ProbeBatch B[2];
-            uint32_t res[2][4];
-            const bool two = (c + 1) * 64 < nk;
-            {
-                uint32_t i = c * 64 + lane, local = 0, tag = 0, valid = 0;
-                if (i < nk) valid = locate(T, __builtin_nontemporal_load(kp + i), local, tag) ? 1u : 0u;
-                probe_issue(T, local, tag | (valid << 31), lane, B[0]);
-            }
-            if (two) {
-                uint32_t i = (c + 1) * 64 + lane, local = 0, tag = 0, valid = 0;
-                if (i < nk) valid = locate(T, __builtin_nontemporal_load(kp + i), local, tag) ? 1u : 0u;
-                probe_issue(T, local, tag | (valid << 31), lane, B[1]);
-            } else probe_skip(B[1]);
-            probe_eval_multi<2>(T, B, 0u, lane, res);
-            if (j == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    uint32_t i0 = c * 64 + 16 * r + q, i1 = i0 + 64;
-                    if (i0 < nk) wtaxa[i0] = res[0][r];
-                    if (two && i1 < nk) wtaxa[i1] = res[1][r];
-                }
-            }
-        }
+        probe_group_to_strip(T, kp, nk, wtaxa, lane);
         wave_lds_sync();
         // ---- seedextend per fragment (one lane per fragment, nr * frags <= 64) ----
         if (frags) {
@@ -167,6 +174,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             if (lane == 0) {
                 out_taxon[r0 + k] = res_taxon;
                 out_status[r0 + k] = res_status;
+            }
+        }
+        wave_lds_sync();
+    }
+}
+
+// The same fused pipeline for the other strategies -- MRTL, tree-hybrid (the `taxa2agg` default, used by the
+// high-sensitivity pipeline, scripts/umgap-analyse.sh:283-288) and rmq-hybrid: probe and seedextend as above, then every
+// read of the group goes through general_read (agg_general.hpp) with the LDS strip as its source.  A read with more
+// than CAP distinct taxa is deferred to a second launch over the `todo` list with a larger scratch (one read per group).
+template <int CAP, int HCAP>
+__global__ __launch_bounds__(256) void k_classify9_general(TableView T, TaxView V, int method, int strategy, float factor,
+                                                           const uint64_t* __restrict__ keys, size_t n_reads, uint32_t stride, uint32_t frags,
+                                                           uint32_t min_seed, uint32_t max_gap, float lower_bound,
+                                                           uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status,
+                                                           const uint32_t* __restrict__ todo, const uint32_t* __restrict__ todo_count,
+                                                           uint32_t* __restrict__ defer, uint32_t* __restrict__ defer_count) {
+    __shared__ uint32_t lds_taxa[4][STRIP];
+    __shared__ Scratch<CAP, HCAP> scratch[4];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t* wtaxa = lds_taxa[wv];
+    Scratch<CAP, HCAP>& S = scratch[wv];
+    for (uint32_t i = lane; i < HCAP; i += 64) { S.hkeys[i] = 0u; S.hcnt[i] = 0u; }
+    wave_lds_sync();
+    uint32_t G = STRIP / stride;
+    if (frags && G * frags > 64) G = 64 / frags;
+    if (todo) G = 1;
+    const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const size_t n_groups = todo ? (size_t)*todo_count : (n_reads + G - 1) / G;
+    for (size_t g = wave0; g < n_groups; g += nwaves) {
+        const size_t r0 = todo ? (size_t)todo[g] : g * G;
+        const uint32_t nr = todo ? 1u : (uint32_t)min((size_t)G, n_reads - r0);
+        const uint32_t nk = nr * stride;
+        probe_group_to_strip(T, keys + r0 * stride, nk, wtaxa, lane);
+        wave_lds_sync();
+        if (frags) {
+            const uint32_t flen = stride / frags;
+            if (lane < nr * frags) seedextend_lds(wtaxa + lane * flen, flen, min_seed, max_gap);
+            wave_lds_sync();
+        }
+        for (uint32_t k = 0; k < nr; k++) {
+            uint32_t res_taxon, res_status;
+            const bool ok = general_read<false, CAP, HCAP>(V, S, method, strategy, factor, lower_bound, wtaxa + k * stride, nullptr, stride, lane,
+                                                           res_taxon, res_status);
+            wave_lds_sync();
+            if (lane == 0) {
+                if (ok) { out_taxon[r0 + k] = res_taxon; out_status[r0 + k] = res_status; }
+                else if (defer) defer[atomicAdd(defer_count, 1u)] = (uint32_t)(r0 + k);
+                else { out_taxon[r0 + k] = 0; out_status[r0 + k] = UMGAP_READ_UNSUPPORTED; }
             }
         }
         wave_lds_sync();
@@ -335,6 +392,56 @@ extern "C" int umgap_classify9_dev(umgap_index* ix, umgap_taxonomy* tx, int meth
     if (g > 256 * 8) g = 256 * 8;     // measured: 8 workgroups per CU (two resident rounds) beats 4 and 16
     hipLaunchKernelGGL(k_classify9, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, d_keys45, n_reads,
                        kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status);
+    UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}
+
+extern "C" int umgap_classify9_strategy_dev(umgap_index* ix, umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound,
+                                            int ranked_only, const uint64_t* d_keys45, size_t n_reads, uint32_t kmers_per_read,
+                                            uint32_t fragments_per_read, uint32_t min_seed_size, uint32_t max_gap_size, uint32_t* d_out_taxon,
+                                            uint32_t* d_out_status, void* stream) {
+    if (strategy == UMGAP_STRATEGY_LCA_STAR)
+        return umgap_classify9_dev(ix, tx, method, lower_bound, ranked_only, d_keys45, n_reads, kmers_per_read, fragments_per_read, min_seed_size,
+                                   max_gap_size, d_out_taxon, d_out_status, stream);
+    if (!ix || !tx || (n_reads && (!d_keys45 || !d_out_taxon || !d_out_status))) return fail(UMGAP_ERR_INVALID, "umgap_classify9_strategy_dev: null argument");
+    if (ix->kind != 9) return fail(UMGAP_ERR_INVALID, "umgap_classify9_strategy_dev: needs a 9-mer index");
+    if (kmers_per_read == 0 || kmers_per_read > 128) return fail(UMGAP_ERR_INVALID, "umgap_classify9_strategy_dev: kmers_per_read must be in 1..128 (use lookup9 + aggregate for longer reads)");
+    if (fragments_per_read && (kmers_per_read % fragments_per_read) != 0) return fail(UMGAP_ERR_INVALID, "umgap_classify9_strategy_dev: kmers_per_read must be a multiple of fragments_per_read");
+    if (fragments_per_read > 64) return fail(UMGAP_ERR_INVALID, "umgap_classify9_strategy_dev: at most 64 fragments per read");
+    if (method != UMGAP_METHOD_TREE && method != UMGAP_METHOD_RMQ) return fail(UMGAP_ERR_INVALID, "unknown method");
+    if (strategy != UMGAP_STRATEGY_HYBRID && strategy != UMGAP_STRATEGY_MRTL) return fail(UMGAP_ERR_INVALID, "unknown strategy");
+    if (method == UMGAP_METHOD_TREE && strategy == UMGAP_STRATEGY_MRTL)
+        return fail(UMGAP_ERR_INVALID, "Invalid invocation: Tree and MaximumRootToLeafPath cannot be combined");  // src/commands/taxa2agg.rs:134-138
+    if (ix->device != tx->device) return fail(UMGAP_ERR_INVALID, "umgap_classify9_strategy_dev: index and taxonomy live on different devices");
+    if (n_reads >= 0xFFFFFFFFull) return fail(UMGAP_ERR_INVALID, "umgap_classify9_strategy_dev: at most 2^32 - 2 reads per call");
+    int rc = use_device(ix->device);
+    if (rc) return rc;
+    if (!n_reads) return UMGAP_OK;
+    size_t need = (n_reads + 1) * sizeof(uint32_t);
+    if (need > tx->d_defer_bytes) {
+        if (tx->d_defer) (void)hipFree(tx->d_defer);
+        tx->d_defer = nullptr;
+        tx->d_defer_bytes = 0;
+        hipError_t e = hipMalloc((void**)&tx->d_defer, need);
+        if (e != hipSuccess) return fail(UMGAP_ERR_NOMEM, std::string("hipMalloc(defer list): ") + hipGetErrorString(e));
+        tx->d_defer_bytes = need;
+    }
+    uint32_t* d_count = tx->d_defer;
+    uint32_t* d_list = tx->d_defer + 1;
+    hipStream_t s = (hipStream_t)stream;
+    UMGAP_HIP(hipMemsetAsync(d_count, 0, sizeof(uint32_t), s));
+    uint32_t G = 1024u / kmers_per_read;
+    if (fragments_per_read && G * fragments_per_read > 64) G = 64 / fragments_per_read;
+    size_t g = ((n_reads + G - 1) / G + 3) / 4;
+    if (g > 256 * 8) g = 256 * 8;
+    TaxView V = view_of(tx, ranked_only);
+    hipLaunchKernelGGL((k_classify9_general<64, 256>), dim3((unsigned)g), dim3(256), 0, s, ix->view, V, method, strategy, factor, d_keys45, n_reads, kmers_per_read,
+                       fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status, (const uint32_t*)nullptr,
+                       (const uint32_t*)nullptr, d_list, d_count);
+    // reads with more than 64 distinct taxa (at most 128: kmers_per_read <= 128)
+    hipLaunchKernelGGL((k_classify9_general<128, 512>), dim3(256), dim3(256), 0, s, ix->view, V, method, strategy, factor, d_keys45, n_reads, kmers_per_read,
+                       fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status, (const uint32_t*)d_list,
+                       (const uint32_t*)d_count, (uint32_t*)nullptr, (uint32_t*)nullptr);
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
 }
