@@ -184,13 +184,25 @@ __device__ __forceinline__ bool general_read(const TaxView& V, Scratch<CAP, HCAP
 #pragma unroll
                     for (int o = 1; o < 64; o <<= 1) { float t = __shfl_up(pfx, o, 64); if (lane >= (uint32_t)o) pfx = __fadd_rn(pfx, t); }
                     const uint32_t adj_k = k + 1 < D ? S.b_adj[k] : NONE;
+                    const uint32_t dep_k = k < D ? S.b_dep[k] : 0u;
                     uint32_t i = 0, j = D - 1;
                     float wcur = __shfl(pfx, (int)(D - 1), 64);
                     for (;;) {
-                        if (i == j) { ans = S.b_pre[j]; break; }
-                        const bool inr = k >= i && k < j;
-                        const uint32_t m = wave_min(inr ? adj_k : NONE);
-                        if (S.b_dep[i] == m) { i++; continue; }  // chain hit: collapses into the node below
+                        // Chain hits (elements that are the branching node of everything after them in the range collapse
+                        // into the node below, Tree::collapse) are skipped in one go: element k is one iff its depth equals
+                        // the minimum adjacent-LCA depth over [k, j), a suffix minimum; the first k that is not decides.
+                        bool inr = k >= i && k < j;
+                        uint32_t suf = inr ? adj_k : NONE;
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) {
+                            uint32_t t = (uint32_t)__shfl_down((int)suf, o, 64);
+                            if (lane + (uint32_t)o < 64) suf = t < suf ? t : suf;
+                        }
+                        const uint64_t branch = __ballot(inr && dep_k != suf);
+                        if (!branch) { ans = S.b_pre[j]; break; }            // a pure chain down to the last element
+                        i = (uint32_t)__builtin_ctzll(branch);
+                        const uint32_t m = (uint32_t)__shfl((int)suf, (int)i, 64);
+                        inr = k >= i && k < j;
                         const uint64_t eq = __ballot(inr && adj_k == m);
                         const uint32_t node = S.b_lca[__builtin_ctzll(eq)];
                         const uint64_t ends = eq | (1ull << j);              // a child ends at every cut and at j
