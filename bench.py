@@ -295,11 +295,12 @@ def main():
         out["with_seedextend"] = {"value": round(args.steps * B / el, 1), "unit": "pairs/s", "ms_per_step": round(1e3 * el / args.steps, 3),
                                   "pipeline": "probe -> seedextend -g1 -s3 (per read end) -> taxa2agg -l2 -a lca*, one fused kernel"}
     if world == 1 and fused and not args.seedextend:
-        # the two 9-mer sensitivity pipelines of scripts/umgap-analyse.sh:277-288 through the fused kernel for the other
-        # aggregation strategies (same batches; reported next to the headline, not part of it)
+        # the filter + aggregate stages of the two 9-mer sensitivity pipelines (scripts/umgap-analyse.sh:277-288) through the
+        # fused kernel for the other strategies, on the same batches (the script feeds them 6-frame translations, ~500 k-mers
+        # per pair, which go through umgap_classify_records); reported next to the headline, not part of it
         others = {}
-        for name, kw in (("high_sensitivity: seedextend -g1 -s3 | taxa2agg -l1 -a hybrid -f 0.25", dict(method="tree", strategy="hybrid", factor=0.25, lower_bound=1.0, min_seed_size=3)),
-                         ("max_sensitivity: seedextend -g1 -s2 | taxa2agg -l1 -m rmq -a mrtl", dict(method="rmq", strategy="mrtl", lower_bound=1.0, min_seed_size=2))):
+        for name, kw in (("hybrid: seedextend -g1 -s3 | taxa2agg -l1 -a hybrid -f 0.25 (stages of umgap-analyse.sh:283-288 on the benchmark's 84-k-mer pairs)", dict(method="tree", strategy="hybrid", factor=0.25, lower_bound=1.0, min_seed_size=3)),
+                         ("mrtl: seedextend -g1 -s2 | taxa2agg -l1 -m rmq -a mrtl (stages of umgap-analyse.sh:277-282 on the same pairs)", dict(method="rmq", strategy="mrtl", lower_bound=1.0, min_seed_size=2))):
             def o_step(i):
                 classify9_dev(w.index, w.taxonomy, keys[i % n_batches], B, KMERS, d_taxon, d_status, fragments_per_read=2, max_gap_size=1, **kw)
             o_step(0)
