@@ -739,3 +739,22 @@ def test_prot2kmer2agg_socket_server(world, proteome, tmp_path):
     assert out.startswith(b"Socket created, listening for connections.\n")
     assert out.count(b"Connection accepted. Processing...\n") == 3 and out.count(b"Connection finished succesfully.\n") == 2
     assert b"Connection died with an error: Unknown Taxon ID: %d\n" % proteome["missing"] in out
+
+
+def test_prot2kmer2lca_header_only_records(world):
+    """A record without sequence lines has the empty sequence (found by tools/fuzz_cli.py: it used to inherit the previous
+    record's first line)."""
+    k = world["kmers"][0]
+    fasta = (">a\n%sACD\n>empty\n>b\n%s\n>also empty\n\n>c\nACDEFGHIKLMN\n" % (k, k)).encode()
+    for flags in ([], ["-o"]):
+        rc, out, _ = run(["prot2kmer2lca"] + flags + [world["idx"]], fasta)
+        orc, oout, _ = O.run_cli(["prot2kmer2lca"] + flags + [world["idx_tsv"]], fasta)
+        assert rc == orc == 0 and out == oout and b"empty" not in out
+
+
+def test_differential_fuzz_device_commands():
+    """tools/fuzz_cli.py, a short fixed-seed run: random FASTA-like byte soup through the device-backed commands and the
+    fused command, product vs oracle (stdout and exit status)."""
+    p = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "fuzz_cli.py"), "30", "taxa2agg", "pept2lca", "prot2kmer2lca", "prot2kmer2agg"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, FUZZ_SEED="7"))
+    assert p.returncode == 0, p.stdout[-3000:]

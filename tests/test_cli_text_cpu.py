@@ -101,3 +101,10 @@ def test_text_filter_errors(taxonomy):
     assert rc == 1 and err.startswith(b"Error: ")
     rc, out, err = run(["uniq"], b"no header\n")
     assert rc == 1 and b"Expected > at beginning of fasta header." in err
+
+
+def test_differential_fuzz_text_filters(taxonomy):
+    """tools/fuzz_cli.py on the two text filters (fixed seed): random byte soup, product vs oracle."""
+    p = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "fuzz_cli.py"), "150", "seedextend", "uniq"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, FUZZ_SEED="3"))
+    assert p.returncode == 0, p.stdout[-3000:]

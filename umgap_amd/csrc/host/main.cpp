@@ -225,6 +225,7 @@ void parse_lookup_part(const char* d, size_t begin, size_t end, bool kmer_mode, 
             P.emit.push_back(1);
             have_rec = true;
             n_lines = 0;
+            seq1 = std::string_view();   // a record without sequence lines has the empty sequence, not its predecessor's
             scratch.clear();
             continue;
         }
