@@ -755,6 +755,7 @@ def test_prot2kmer2lca_header_only_records(world):
 def test_differential_fuzz_device_commands():
     """tools/fuzz_cli.py, a short fixed-seed run: random FASTA-like byte soup through the device-backed commands and the
     fused command, product vs oracle (stdout and exit status)."""
-    p = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "fuzz_cli.py"), "30", "taxa2agg", "pept2lca", "prot2kmer2lca", "prot2kmer2agg"],
+    p = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "fuzz_cli.py"), "20", "taxa2agg", "taxa2agg_scored", "pept2lca", "pept2lca_var", "prot2kmer2lca", "prot2tryp2lca",
+                        "prot2kmer2agg"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, FUZZ_SEED="7"))
     assert p.returncode == 0, p.stdout[-3000:]

@@ -58,9 +58,17 @@ def main():
         for k in kmers:
             f.write("%s\t%d\n" % (k, int(rng.choice(np.concatenate([ids, [499, 100000]])))))
     idx = os.path.join(work, "index.umgapix")
-    need_dev = any(c in ("taxa2agg", "pept2lca", "prot2kmer2lca", "prot2kmer2agg") for c in cmds)
+    peps = sorted({"".join(rng.choice(list(LETTERS), int(rng.integers(4, 14)))) + str(rng.choice(["K", "R"])) for _ in range(300)})
+    tryp_tsv = os.path.join(work, "tryptic.tsv")
+    with open(tryp_tsv, "w") as f:
+        for k in peps:
+            f.write("%s\t%d\n" % (k, int(rng.choice(ids))))
+    tryp = os.path.join(work, "tryptic.umgapix")
+    need_dev = any(c in ("taxa2agg", "taxa2agg_scored", "pept2lca", "pept2lca_var", "prot2tryp2lca", "prot2kmer2lca", "prot2kmer2agg") for c in cmds)
     if need_dev:
         with open(idx_tsv, "rb") as fi, open(idx, "wb") as fo:
+            subprocess.run([UMGAP, "buildindex"], stdin=fi, stdout=fo, check=True)
+        with open(tryp_tsv, "rb") as fi, open(tryp, "wb") as fo:
             subprocess.run([UMGAP, "buildindex"], stdin=fi, stdout=fo, check=True)
 
     def taxa_item(rng):
@@ -76,6 +84,24 @@ def main():
         if c < 0.8:
             return "".join(rng.choice(list(LETTERS + "*X"), int(rng.integers(0, 30)))).encode()
         return rng.choice([b"", b"ACDEFGHIk", b"ACD\xc3\xa9FGHIKLMNP", b"ACDEFGHI ", b">x"])
+
+    def scored_item(rng):
+        c = rng.random()
+        if c < 0.85:
+            return b"%d=%s" % (int(rng.choice(np.concatenate([ids[:20], [0, 0, 499]]))), rng.choice([b"1", b"0.5", b"2.25", b"1e-3", b"3", b"0.1"]))
+        return rng.choice([b"", b"5", b"5=", b"=1", b"5=1=2", b"5=abc", b"5=inf", b"5=-1"])
+
+    def tryp_pep_item(rng):
+        c = rng.random()
+        if c < 0.6:
+            return peps[int(rng.integers(0, len(peps)))].encode()
+        return "".join(rng.choice(list(LETTERS + "KR*"), int(rng.integers(0, 20)))).encode()
+
+    def tryp_prot_item(rng):
+        parts = []
+        for _ in range(int(rng.integers(0, 6))):
+            parts.append(peps[int(rng.integers(0, len(peps)))] if rng.random() < 0.6 else "".join(rng.choice(list(LETTERS + "KRP*"), int(rng.integers(0, 15)))))
+        return "".join(parts).encode()
 
     def prot_item(rng):
         n = int(rng.integers(0, 40))
@@ -99,6 +125,15 @@ def main():
             elif cmd == "taxa2agg":
                 flags = [["-a", "lca*", "-l", "2"], [], ["-m", "rmq", "-a", "mrtl"], ["-m", "rmq", "-a", "lca*"], ["-r", "-a", "lca*"], ["-m", "rmq", "-f", "0.6"]][int(rng.integers(0, 6))]
                 data, mine, theirs = soup(rng, taxa_item, int(rng.integers(0, 12))), ["taxa2agg"] + flags + [tsv], ["taxa2agg"] + flags + [tsv]
+            elif cmd == "taxa2agg_scored":
+                flags = [["-s"], ["-s", "-a", "lca*", "-l", "1.5"], ["-s", "-m", "rmq", "-a", "mrtl"], ["-s", "-m", "rmq", "-a", "lca*", "-l", "0.6"]][int(rng.integers(0, 4))]
+                data, mine, theirs = soup(rng, scored_item, int(rng.integers(0, 12))), ["taxa2agg"] + flags + [tsv], ["taxa2agg"] + flags + [tsv]
+            elif cmd == "pept2lca_var":
+                flags = [[], ["-o"], ["-o", "-c", "3"]][int(rng.integers(0, 3))]
+                data, mine, theirs = soup(rng, tryp_pep_item, int(rng.integers(0, 12))), ["pept2lca"] + flags + [tryp], ["pept2lca"] + flags + [tryp_tsv]
+            elif cmd == "prot2tryp2lca":
+                flags = [[], ["-o"], ["-l", "9", "-L", "45"], ["-o", "-l", "3", "-L", "12", "-c", "2"], ["-k", "AC"], ["-d", "W"]][int(rng.integers(0, 6))]
+                data, mine, theirs = soup(rng, tryp_prot_item, int(rng.integers(0, 12))), ["prot2tryp2lca"] + flags + [tryp], ["prot2tryp2lca"] + flags + [tryp_tsv]
             elif cmd == "pept2lca":
                 flags = [[], ["-o"], ["-o", "-c", "3"]][int(rng.integers(0, 3))]
                 data, mine, theirs = soup(rng, pep_item, int(rng.integers(0, 12))), ["pept2lca"] + flags + [idx], ["pept2lca"] + flags + [idx_tsv]
