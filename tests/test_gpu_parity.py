@@ -896,6 +896,63 @@ def test_classify_prot9_ragged_fragments(api, torch_cuda):
         assert nbad == 0, (F, bad)
 
 
+def test_classify_records_long_ragged_reads(api, torch_cuda):
+    """umgap_classify_records (host records in, one taxon per read out; what `umgap prot2kmer2agg` calls per block) on reads
+    the fused kernels do not take: 1..12 fragments of 9..700 residues (6-frame translations, whole proteins), every
+    strategy, with and without seedextend -- against the oracle stages."""
+    rng = np.random.default_rng(123)
+    letters = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    from umgap_amd.synth import synthetic_taxonomy
+    ids, par, valid, rank = synthetic_taxonomy(3000, 5000, max_depth=14, seed=21)
+    tx = api.Taxonomy(ids, par, valid, rank)
+    otx = O.Taxonomy.from_arrays(ids, par, valid, rank)
+    parent_of = dict(zip(ids.tolist(), par.tolist()))
+    proteins, table = [], {}
+    for _ in range(120):
+        prot = rng.choice(letters, int(rng.integers(60, 900))).tobytes()
+        t = int(rng.choice(ids))
+        proteins.append(prot)
+        for i in range(len(prot) - 8):
+            table.setdefault(prot[i:i + 9], parent_of[t] if (i // 11) % 4 == 3 else t)
+    kmers = sorted(table)
+    keys, _ = api.pack9_array(kmers)
+    ix = api.Index.build(keys, np.array([table[k] for k in kmers], np.uint32))
+    frags, read_frags = [], [0]
+    for r in range(400):
+        for _ in range(int(rng.integers(1, 13))):
+            prot = proteins[int(rng.integers(0, len(proteins)))]
+            a = int(rng.integers(0, max(1, len(prot) - 9)))
+            f = bytearray(prot[a:a + int(rng.integers(9, 700))])
+            for i in range(len(f)):
+                m = rng.random()
+                if m < 0.02:
+                    f[i] = int(rng.choice(letters))
+                elif m < 0.03:
+                    f[i] = ord("*")
+            if len(f) >= 9:
+                frags.append(bytes(f))
+        read_frags.append(len(frags))
+    assert max(len(f) for f in frags) > 300
+    for se in (False, True):
+        hits, roffs = [], [0]
+        for r in range(len(read_frags) - 1):
+            for f in frags[read_frags[r]:read_frags[r + 1]]:
+                h = np.array([table.get(f[i:i + 9], 0) for i in range(len(f) - 8)], np.uint32)
+                if se:
+                    kept = O.seedextend_record(h, 3, 1)
+                    h = kept
+                hits += h.tolist()
+            roffs.append(len(hits))
+        hits, roffs = np.array(hits, np.uint32), np.array(roffs, np.uint64)
+        for method, strategy, lb in (("tree", "lca*", 2.0), ("tree", "hybrid", 1.0), ("rmq", "mrtl", 1.0), ("rmq", "hybrid", 0.0), ("rmq", "lca*", 5.0)):
+            t, s = api.classify_records(ix, tx, frags, read_frags, method=method, strategy=strategy, factor=0.25, lower_bound=lb,
+                                        seedextend=se, min_seed_size=3, max_gap_size=1)
+            agg = O.Aggregator(otx, method, strategy, factor=0.25)
+            nbad, bad, wt, ws = agg.taxa2agg_check(hits, roffs, t, s, lower_bound=lb, nthreads=8)
+            assert nbad == 0, (se, method, strategy, bad, t[bad.astype(int)], wt[bad.astype(int)])
+            assert (s == 0).mean() > 0.5
+
+
 # ---------------------------------------------------------------------------------------------
 # BASELINE.json configs[2] at full size: 50 M pairs (5 x 10 M), 8 G-key table, size-independent properties
 # ---------------------------------------------------------------------------------------------
