@@ -107,6 +107,15 @@ int umgap_index_owner9_dev(const umgap_index* ix, const uint64_t* d_keys45, size
 int umgap_index_partition9_dev(const umgap_index* ix, const uint64_t* d_keys45, size_t n, uint32_t n_shards,
                                uint64_t cap, uint64_t* d_send, int64_t* d_perm, uint64_t* d_cursor,
                                uint32_t* d_overflow, void* stream);
+/* Incremental build from host chunks, for inputs that do not fit host memory (`umgap buildindex` streams a TSV
+ * of any size through it; src/commands/buildindex.rs:32-48): the table is sized for expected_keys at the given
+ * load, chunks are uploaded and inserted as they come, finish() reports duplicates / overflow and hands over the
+ * index (the builder is consumed).  The caller guarantees nothing about key order. */
+typedef struct umgap_index_builder umgap_index_builder;
+int umgap_index_builder_new(uint64_t expected_keys, double load_factor, int device, umgap_index_builder** out);
+int umgap_index_builder_add(umgap_index_builder* b, const uint64_t* keys45, const uint32_t* taxa, size_t n);
+int umgap_index_builder_finish(umgap_index_builder* b, umgap_index** out);
+void umgap_index_builder_free(umgap_index_builder* b);
 void umgap_index_free(umgap_index* ix);
 uint64_t umgap_index_num_keys(const umgap_index* ix);
 uint64_t umgap_index_num_buckets(const umgap_index* ix);

@@ -759,3 +759,32 @@ def test_differential_fuzz_device_commands():
                         "prot2kmer2agg"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, FUZZ_SEED="7"))
     assert p.returncode == 0, p.stdout[-3000:]
+
+
+@pytest.mark.parametrize("block,threads,piped", [(200, 3, True), (4096, 8, False), (1 << 20, 2, True)])
+def test_buildindex_streaming(tmp_path, block, threads, piped):
+    """buildindex is two block-parallel passes (count + check, then pack + insert through umgap_index_builder_*): the
+    result must not depend on block seams, thread ranges or whether stdin is a file (re-read) or a pipe (spooled)."""
+    rng = np.random.default_rng(block)
+    kmers = sorted({"".join(rng.choice(list(LETTERS), 9)) for _ in range(30_000)})
+    tsv = tmp_path / "big.tsv"
+    tsv.write_text("".join("%s\t%d\n" % (k, int(rng.integers(1, 1 << 31))) for k in kmers))
+    idx = tmp_path / "big.umgapix"
+    env = dict(os.environ, UMGAP_BLOCK_BYTES=str(block), UMGAP_THREADS=str(threads))
+    with open(idx, "wb") as fout:
+        if piped:
+            cat = subprocess.Popen(["cat", str(tsv)], stdout=subprocess.PIPE)
+            p = subprocess.run([UMGAP, "buildindex"], stdin=cat.stdout, stdout=fout, stderr=subprocess.PIPE, env=env)
+            cat.wait()
+        else:
+            with open(tsv, "rb") as fin:
+                p = subprocess.run([UMGAP, "buildindex"], stdin=fin, stdout=fout, stderr=subprocess.PIPE, env=env)
+    assert p.returncode == 0, p.stderr
+    rc, out, err = run(["printindex", str(idx)])
+    assert rc == 0 and out == tsv.read_bytes(), err
+    # order violations are found wherever the seam falls
+    lines = tsv.read_text().splitlines(keepends=True)
+    for at in (1, len(lines) // 2, len(lines) - 1):
+        for bad in (lines[:at] + [lines[at - 1]] + lines[at:], lines[:at - 1] + [lines[at], lines[at - 1]] + lines[at + 1:]):
+            p = subprocess.run([UMGAP, "buildindex"], input="".join(bad).encode(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+            assert p.returncode == 1 and (b"duplicate key" in p.stderr or b"out-of-order key" in p.stderr), p.stderr

@@ -59,14 +59,14 @@ class BlockReader {
             if (have == 0) return false;
             if (first_) {
                 // src/io/fasta.rs:44-49
-                if (buf_[0] != '>') { first_line_error_ = true; }
+                if (!lines_only_ && buf_[0] != '>') { first_line_error_ = true; }
                 first_ = false;
             }
             if (eof_) { data = buf_.data(); len = have; return true; }
             // last record start strictly inside the buffer
             size_t cut = 0;
             for (size_t p = have; p-- > 1;)
-                if (buf_[p] == '>' && buf_[p - 1] == '\n') { cut = p; break; }
+                if (buf_[p - 1] == '\n' && (lines_only_ || buf_[p] == '>')) { cut = p; break; }
             if (cut > 0) {
                 carry_off_ = cut;
                 carry_ = have - cut;
@@ -78,12 +78,14 @@ class BlockReader {
         }
     }
     bool first_line_error() const { return first_line_error_; }
+    // plain line-oriented input (TSV): blocks end at any newline, no FASTA header check
+    void lines_only() { lines_only_ = true; }
 
   private:
     FILE* f_;
     std::vector<char> buf_;
     size_t carry_ = 0, carry_off_ = 0;
-    bool eof_ = false, first_ = true, first_line_error_ = false;
+    bool eof_ = false, first_ = true, first_line_error_ = false, lines_only_ = false;
 };
 
 // Record-aligned split of a block into at most `parts` ranges [begin[i], begin[i+1]).
@@ -95,6 +97,21 @@ inline std::vector<size_t> split_records(const char* d, size_t len, unsigned par
         // advance to the next record start
         const char* q = (const char*)memchr(d + p, '\n', len - p);
         while (q && (size_t)(q - d) + 1 < len && q[1] != '>') q = (const char*)memchr(q + 1, '\n', len - (size_t)(q + 1 - d));
+        if (!q || (size_t)(q - d) + 1 >= len) break;
+        size_t s = (size_t)(q - d) + 1;
+        if (s > b.back()) b.push_back(s);
+    }
+    b.push_back(len);
+    return b;
+}
+
+// Line-aligned split of a block into at most `parts` ranges.
+inline std::vector<size_t> split_lines(const char* d, size_t len, unsigned parts) {
+    std::vector<size_t> b{0};
+    for (unsigned t = 1; t < parts; t++) {
+        size_t p = len * t / parts;
+        if (p <= b.back()) continue;
+        const char* q = (const char*)memchr(d + p, '\n', len - p);
         if (!q || (size_t)(q - d) + 1 >= len) break;
         size_t s = (size_t)(q - d) + 1;
         if (s > b.back()) b.push_back(s);

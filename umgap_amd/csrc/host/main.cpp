@@ -1135,39 +1135,124 @@ int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
     return 0;
 }
 
-// ---- buildindex: TSV (9-mer<TAB>taxon, sorted) on stdin -> UMGAPIX1 table on stdout ---------
-int cmd_buildindex(const std::vector<std::string>& args) {
-    Parsed p = parse_args(args, {{'l', "load-factor", true}});
-    float load = opt_f32(p, "load-factor", 0.0f);
-    LineSource ls(stdin);
-    std::string_view l;
+// ---- buildindex: TSV (key<TAB>taxon, sorted) on stdin -> UMGAPIX1 table on stdout (src/commands/buildindex.rs:32-48) ----
+// Two passes over the input, both block-parallel, host memory O(block) for a 9-mer index of any size:
+//   pass 1 counts the keys and checks what fst::MapBuilder::insert checks (strictly increasing keys) plus the field
+//          syntax; stdin is re-read if it is a seekable file, otherwise it is spooled to a temporary file on the way;
+//   pass 2 packs the 9-mers and streams them into the device table (umgap_index_builder_*).
+// If some key is not [A-Z]{9} the variable-length table is built instead (in memory: tryptic indexes are small).
+struct BuildPart {
+    size_t n = 0;
+    bool all9 = true;
+    std::string first, last;                 // first / last key of the range (order check across ranges)
+    std::optional<CliError> error;           // first error of the range
     std::vector<uint64_t> keys;
     std::vector<uint32_t> vals;
     StringBatch strs;
-    bool all9 = true;
-    std::string prev;
-    while (ls.next(l)) {
+};
+
+void parse_index_part(const char* d, size_t begin, size_t end, int pass, bool want_strings, BuildPart& P) {
+    LineCursor lc{d + begin, d + end};
+    std::string_view l, prev;
+    while (lc.next(l)) {
         if (l.empty()) continue;
         size_t tab = l.find('\t');
-        if (tab == std::string_view::npos || l.find('\t', tab + 1) != std::string_view::npos) throw CliError("CSV deserialize error: expected two fields");
+        if (tab == std::string_view::npos || l.find('\t', tab + 1) != std::string_view::npos) { P.error = CliError("CSV deserialize error: expected two fields"); return; }
         std::string_view k = l.substr(0, tab);
         uint64_t v;
-        try { v = parse_usize(l.substr(tab + 1)); } catch (CliError&) { throw CliError("CSV deserialize error: invalid integer"); }
-        // fst::MapBuilder::insert wants strictly increasing keys (src/commands/buildindex.rs:42)
-        if (!prev.empty() && !(std::string_view(prev) < k)) throw CliError(std::string(prev == k ? "Error inserting duplicate key: " : "Error inserting out-of-order key: ") + std::string(k));
-        prev.assign(k);
+        try { v = parse_usize(l.substr(tab + 1)); } catch (CliError&) { P.error = CliError("CSV deserialize error: invalid integer"); return; }
+        if (pass == 1) {
+            // fst::MapBuilder::insert wants strictly increasing keys (src/commands/buildindex.rs:42)
+            if (P.n && !(prev < k)) { P.error = CliError(std::string(prev == k ? "Error inserting duplicate key: " : "Error inserting out-of-order key: ") + std::string(k)); return; }
+            if (k.empty() || k.size() > 63) { P.error = CliError("key '" + std::string(k) + "': keys must be 1..63 bytes long"); return; }
+            if (v > 0xFFFFFFFFull) { P.error = CliError("taxon id does not fit 32 bits"); return; }
+            if (P.n == 0) P.first.assign(k);
+            prev = k;
+        }
         uint64_t key = 0;
-        if (k.size() != 9 || !umgap_pack9(k.data(), &key)) all9 = false;
-        if (k.empty() || k.size() > 63) throw CliError("key '" + std::string(k) + "': keys must be 1..63 bytes long");
-        if (v > 0xFFFFFFFFull) throw CliError("taxon id does not fit 32 bits");
-        keys.push_back(key);
-        strs.add(k);
-        vals.push_back((uint32_t)v);
+        const bool nine = k.size() == 9 && umgap_pack9(k.data(), &key);
+        if (!nine) P.all9 = false;
+        if (pass == 2) {
+            if (want_strings) { P.strs.add(k); P.vals.push_back((uint32_t)v); }
+            else { P.keys.push_back(key); P.vals.push_back((uint32_t)v); }
+        }
+        P.n++;
     }
-    // every key [A-Z]{9} => the packed 9-mer table; anything else => the variable-length table
+    if (pass == 1 && P.n) P.last.assign(prev);
+}
+
+int cmd_buildindex(const std::vector<std::string>& args) {
+    Parsed p = parse_args(args, {{'l', "load-factor", true}});
+    float load = opt_f32(p, "load-factor", 0.0f);
+    const unsigned T = worker_count();
+    // pass 1 (spooling unless stdin can be rewound)
+    const bool seekable = lseek(fileno(stdin), 0, SEEK_CUR) != (off_t)-1;
+    FILE* spool = nullptr;
+    if (!seekable) {
+        spool = tmpfile();
+        if (!spool) throw CliError(std::string("cannot create a temporary file for the second pass: ") + strerror(errno));
+    }
+    size_t n_keys = 0;
+    bool all9 = true;
+    std::string last_key;
+    bool have_last = false;
+    {
+        BlockReader blocks(stdin);
+        blocks.lines_only();
+        const char* d;
+        size_t len;
+        while (blocks.next(d, len)) {
+            if (spool && fwrite(d, 1, len, spool) != len) throw CliError(std::string("writing the temporary file: ") + strerror(errno));
+            std::vector<size_t> cuts = split_lines(d, len, T);
+            const size_t np = cuts.size() - 1;
+            std::vector<BuildPart> parts(np);
+            parallel_for(np, [&](size_t i) { parse_index_part(d, cuts[i], cuts[i + 1], 1, false, parts[i]); });
+            for (size_t i = 0; i < np; i++) {
+                BuildPart& P = parts[i];
+                if (P.n && have_last && !(std::string_view(last_key) < std::string_view(P.first)))
+                    throw CliError(std::string(last_key == P.first ? "Error inserting duplicate key: " : "Error inserting out-of-order key: ") + P.first);
+                if (P.error) throw *P.error;
+                if (P.n) { last_key = P.last; have_last = true; }
+                n_keys += P.n;
+                all9 = all9 && P.all9;
+            }
+        }
+    }
+    FILE* in2 = stdin;
+    if (spool) { fflush(spool); rewind(spool); in2 = spool; }
+    else if (fseeko(stdin, 0, SEEK_SET) != 0) throw CliError("cannot rewind the input for the second pass");
+    else clearerr(stdin);
+    // pass 2
     umgap_index* ix = nullptr;
-    if (all9) LIB(umgap_index_build9(keys.data(), vals.data(), keys.size(), load, 0, &ix));
-    else LIB(umgap_index_build_var(strs.bytes.data(), strs.offsets.data(), vals.data(), vals.size(), load, 0, &ix));
+    BlockReader blocks(in2);
+    blocks.lines_only();
+    const char* d;
+    size_t len;
+    if (all9) {
+        umgap_index_builder* b = nullptr;
+        LIB(umgap_index_builder_new(n_keys, load, 0, &b));
+        try {
+            while (blocks.next(d, len)) {
+                std::vector<size_t> cuts = split_lines(d, len, T);
+                const size_t np = cuts.size() - 1;
+                std::vector<BuildPart> parts(np);
+                parallel_for(np, [&](size_t i) { parse_index_part(d, cuts[i], cuts[i + 1], 2, false, parts[i]); });
+                for (size_t i = 0; i < np; i++) LIB(umgap_index_builder_add(b, parts[i].keys.data(), parts[i].vals.data(), parts[i].keys.size()));
+            }
+            LIB(umgap_index_builder_finish(b, &ix));
+        } catch (...) { umgap_index_builder_free(b); throw; }
+    } else {
+        StringBatch strs;
+        std::vector<uint32_t> vals;
+        while (blocks.next(d, len)) {
+            BuildPart P;
+            parse_index_part(d, 0, len, 2, true, P);
+            for (size_t i = 0; i < P.strs.size(); i++) strs.add(std::string_view((const char*)P.strs.bytes.data() + P.strs.offsets[i], P.strs.offsets[i + 1] - P.strs.offsets[i]));
+            vals.insert(vals.end(), P.vals.begin(), P.vals.end());
+        }
+        LIB(umgap_index_build_var(strs.bytes.data(), strs.offsets.data(), vals.data(), vals.size(), load, 0, &ix));
+    }
+    if (spool) fclose(spool);
     LIB(umgap_index_save(ix, "/dev/stdout"));
     umgap_index_free(ix);
     return 0;

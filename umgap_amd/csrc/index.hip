@@ -564,6 +564,111 @@ int umgap_index_build9(const uint64_t* keys, const uint32_t* taxa, size_t n, dou
     return rc;
 }
 
+// ---- incremental build from host chunks (umgap buildindex streams a TSV of any size through this) ----
+}  // extern "C"
+struct umgap_index_builder {
+    umgap_index* ix = nullptr;
+    BuildFlags* d_flags = nullptr;
+    uint64_t* d_stash = nullptr;
+    uint64_t n_added = 0;
+    void* h_stage[2] = {nullptr, nullptr};
+    void* d_stage[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+    size_t cap = 0;
+    int slot = 0;
+};
+extern "C" {
+
+void umgap_index_builder_free(umgap_index_builder* b) {
+    if (!b) return;
+    if (b->ix) { (void)use_device(b->ix->device); (void)hipStreamSynchronize(b->ix->stream); }
+    for (int i = 0; i < 2; i++) {
+        if (b->h_stage[i]) (void)hipHostFree(b->h_stage[i]);
+        if (b->d_stage[i]) (void)hipFree(b->d_stage[i]);
+        if (b->done[i]) (void)hipEventDestroy(b->done[i]);
+    }
+    if (b->d_flags) (void)hipFree(b->d_flags);
+    if (b->d_stash) (void)hipFree(b->d_stash);
+    if (b->ix) umgap_index_free(b->ix);
+    delete b;
+}
+
+int umgap_index_builder_new(uint64_t expected_keys, double load, int device, umgap_index_builder** out) {
+    if (!out) return fail(UMGAP_ERR_INVALID, "umgap_index_builder_new: null argument");
+    umgap_index_builder* b = new umgap_index_builder();
+    int rc = new_handle(device, &b->ix);
+    if (rc) { delete b; return rc; }
+    auto bail = [&](int code) { umgap_index_builder_free(b); return code; };
+    rc = alloc_table(b->ix, choose_m(expected_keys, load), 0, 1);
+    if (rc) return bail(rc);
+    if (hipMalloc((void**)&b->d_flags, sizeof(BuildFlags)) != hipSuccess || hipMalloc((void**)&b->d_stash, (size_t)STASH_CAP * 16) != hipSuccess)
+        return bail(fail(UMGAP_ERR_NOMEM, "umgap_index_builder_new: hipMalloc failed"));
+    size_t nslots = (size_t)b->ix->view.n_resident * SLOTS;
+    hipLaunchKernelGGL(k_fill, dim3(grid_for(nslots)), dim3(256), 0, b->ix->stream, b->ix->d_slots, nslots, EMPTY_SLOT);
+    if (hipMemsetAsync(b->d_flags, 0, sizeof(BuildFlags), b->ix->stream) != hipSuccess) return bail(fail(UMGAP_ERR_DEVICE, "umgap_index_builder_new: memset failed"));
+    b->cap = 4u << 20;   // keys per staging slot: 32 MiB of keys + 16 MiB of taxa
+    for (int i = 0; i < 2; i++) {
+        if (hipHostMalloc(&b->h_stage[i], b->cap * 12, hipHostMallocDefault) != hipSuccess || hipMalloc(&b->d_stage[i], b->cap * 12) != hipSuccess ||
+            hipEventCreateWithFlags(&b->done[i], hipEventDisableTiming) != hipSuccess)
+            return bail(fail(UMGAP_ERR_NOMEM, "umgap_index_builder_new: staging allocation failed"));
+    }
+    *out = b;
+    return UMGAP_OK;
+}
+
+int umgap_index_builder_add(umgap_index_builder* b, const uint64_t* keys45, const uint32_t* taxa, size_t n) {
+    if (!b || !b->ix || (n && (!keys45 || !taxa))) return fail(UMGAP_ERR_INVALID, "umgap_index_builder_add: null argument");
+    int rc = use_device(b->ix->device);
+    if (rc) return rc;
+    umgap_index* x = b->ix;
+    for (size_t off = 0; off < n; off += b->cap, b->slot ^= 1) {
+        const int s = b->slot;
+        const size_t len = std::min(b->cap, n - off);
+        if (b->busy[s]) { UMGAP_HIP(hipEventSynchronize(b->done[s])); b->busy[s] = false; }
+        uint64_t* hk = (uint64_t*)b->h_stage[s];
+        uint32_t* hv = (uint32_t*)((char*)b->h_stage[s] + b->cap * 8);
+        memcpy(hk, keys45 + off, len * 8);
+        memcpy(hv, taxa + off, len * 4);
+        uint64_t* dk = (uint64_t*)b->d_stage[s];
+        uint32_t* dv = (uint32_t*)((char*)b->d_stage[s] + b->cap * 8);
+        UMGAP_HIP(hipMemcpyAsync(dk, hk, len * 8, hipMemcpyHostToDevice, x->stream));
+        UMGAP_HIP(hipMemcpyAsync(dv, hv, len * 4, hipMemcpyHostToDevice, x->stream));
+        hipLaunchKernelGGL(k_insert, dim3(grid_for(len)), dim3(256), 0, x->stream, x->d_slots, x->view.m, x->view.nb, x->view.home_lo, x->view.home_hi,
+                           (const uint64_t*)dk, (const uint32_t*)dv, len, b->d_flags, b->d_stash);
+        UMGAP_HIP(hipEventRecord(b->done[s], x->stream));
+        b->busy[s] = true;
+    }
+    b->n_added += n;
+    return UMGAP_OK;
+}
+
+int umgap_index_builder_finish(umgap_index_builder* b, umgap_index** out) {
+    if (!b || !b->ix || !out) return fail(UMGAP_ERR_INVALID, "umgap_index_builder_finish: null argument");
+    int rc = use_device(b->ix->device);
+    if (rc) return rc;
+    umgap_index* x = b->ix;
+    BuildFlags h{};
+    hipError_t e = hipMemcpyAsync(&h, b->d_flags, sizeof(h), hipMemcpyDeviceToHost, x->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(x->stream);
+    if (e != hipSuccess) return fail(UMGAP_ERR_DEVICE, std::string("index build: ") + hipGetErrorString(e));
+    if (h.bad_key) return fail(UMGAP_ERR_BUILD, "index build: " + std::to_string(h.bad_key) + " keys are not 45-bit packed 9-mers");
+    if (h.duplicate) return fail(UMGAP_ERR_BUILD, "index build: " + std::to_string(h.duplicate) + " duplicate keys (keys must be distinct, cf. fst::MapBuilder::insert)");
+    if (h.too_full) return fail(UMGAP_ERR_BUILD, "index build: table too full (more keys than announced?)");
+    std::vector<uint64_t> raw(2 * (size_t)h.n_stash);
+    if (h.n_stash && hipMemcpy(raw.data(), b->d_stash, raw.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(UMGAP_ERR_DEVICE, "index build: stash copy failed");
+    std::vector<std::pair<uint64_t, uint64_t>> entries(h.n_stash);
+    for (size_t i = 0; i < h.n_stash; i++) entries[i] = {raw[2 * i], raw[2 * i + 1]};
+    rc = set_stash(x, entries);
+    if (!rc) rc = finish_halo(x);
+    if (rc) return rc;
+    x->n_keys = b->n_added;
+    *out = x;
+    b->ix = nullptr;
+    umgap_index_builder_free(b);
+    return UMGAP_OK;
+}
+
 int umgap_synth_index_build(uint64_t n_keys, const uint32_t* d_taxon_of_row, uint64_t n_tax, uint64_t a, uint64_t b,
                             double load, int device, umgap_index** out) {
     return umgap_synth_index_build_shard(n_keys, d_taxon_of_row, n_tax, a, b, load, device, 0, 1, out);
