@@ -105,7 +105,7 @@ int umgap_index_owner9_dev(const umgap_index* ix, const uint64_t* d_keys45, size
  * d_cursor[n_shards] and *d_overflow) and records in d_perm[i] where key i went, so that the
  * returned taxa can be gathered back.  *d_overflow != 0 afterwards = some region exceeded cap. */
 int umgap_index_partition9_dev(const umgap_index* ix, const uint64_t* d_keys45, size_t n, uint32_t n_shards,
-                               uint64_t cap, uint64_t* d_send, int64_t* d_perm, uint64_t* d_cursor,
+                               uint64_t cap, uint64_t* d_send, int32_t* d_perm, uint64_t* d_cursor,
                                uint32_t* d_overflow, void* stream);
 /* Incremental build from host chunks, for inputs that do not fit host memory (`umgap buildindex` streams a TSV
  * of any size through it; src/commands/buildindex.rs:32-48): the table is sized for expected_keys at the given

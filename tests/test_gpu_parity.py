@@ -596,7 +596,7 @@ def test_sharded_components_single_gpu(api, torch_cuda, n_shards):
     K = keys.numel()
     cap = int(K / n_shards * 1.2) + 4096
     send = torch.full((n_shards * cap,), -1, dtype=torch.int64, device="cuda")
-    perm = torch.empty(K, dtype=torch.int64, device="cuda")
+    perm = torch.empty(K, dtype=torch.int32, device="cuda")
     cursor = torch.zeros(n_shards, dtype=torch.int64, device="cuda")
     overflow = torch.zeros(1, dtype=torch.int32, device="cuda")
     _lib.check(_lib.load().umgap_index_partition9_dev(shards[0]._h, _dev_ptr(keys), K, n_shards, cap, _dev_ptr(send), _dev_ptr(perm),

@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void k_insert_windows(uint64_t* __restrict__ s
 constexpr int PART_PER_THREAD = 16;
 __global__ __launch_bounds__(256) void k_partition(const uint64_t* __restrict__ keys, size_t n, uint32_t m, uint32_t nb,
                                                    uint32_t n_shards, uint64_t cap, uint64_t* __restrict__ send,
-                                                   int64_t* __restrict__ perm, unsigned long long* __restrict__ cursor,
+                                                   int32_t* __restrict__ perm, unsigned long long* __restrict__ cursor,
                                                    uint32_t* __restrict__ overflow) {
     __shared__ uint32_t cnt[64];
     __shared__ unsigned long long base[64];
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void k_partition(const uint64_t* __restrict__ 
             size_t i = t0 + (size_t)k * blockDim.x + threadIdx.x;
             if (own[k] != 0xFFFFFFFFu) {
                 uint64_t pos = base[own[k]] + lpos[k];
-                if (pos < cap) { send[(size_t)own[k] * cap + pos] = key[k]; perm[i] = (int64_t)((size_t)own[k] * cap + pos); }
+                if (pos < cap) { send[(size_t)own[k] * cap + pos] = key[k]; perm[i] = (int32_t)((size_t)own[k] * cap + pos); }
                 else { perm[i] = 0; atomicExch(overflow, 1u); }
             }
         }
@@ -897,7 +897,8 @@ int umgap_index_build_windows9_dev(const uint8_t* d_bytes, const uint64_t* d_off
 }
 
 int umgap_index_partition9_dev(const umgap_index* ix, const uint64_t* d_keys, size_t n, uint32_t n_shards, uint64_t cap,
-                               uint64_t* d_send, int64_t* d_perm, uint64_t* d_cursor, uint32_t* d_overflow, void* stream) {
+                               uint64_t* d_send, int32_t* d_perm, uint64_t* d_cursor, uint32_t* d_overflow, void* stream) {
+    if ((uint64_t)n_shards * cap > 0x7FFFFFFFull) return fail(UMGAP_ERR_INVALID, "umgap_index_partition9_dev: n_shards * cap must fit 31 bits (cut the batch into pieces)");
     if (!ix || !n_shards || n_shards > 64 || (n && (!d_keys || !d_send || !d_perm)) || !d_cursor || !d_overflow) return fail(UMGAP_ERR_INVALID, "umgap_index_partition9_dev: bad argument");
     int rc = use_device(ix->device);
     if (rc) return rc;

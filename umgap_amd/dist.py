@@ -72,7 +72,7 @@ class ShardedLookup:
         n = self.cap * world
         nbuf = 2 if self.chunks > 1 else 1
         self.buf = [dict(send_keys=ops.empty(n, torch.int64), recv_keys=ops.empty(n, torch.int64), recv_taxa=ops.empty(n, torch.int32),
-                         back_taxa=ops.empty(n, torch.int32), perm=ops.empty(per, torch.int64), cursor=ops.empty(world, torch.int64),
+                         back_taxa=ops.empty(n, torch.int32), perm=ops.empty(per, torch.int32), cursor=ops.empty(world, torch.int64),
                          overflow=ops.empty(1, torch.int32)) for _ in range(nbuf)]
         self.side = ops.streams(2) if self.chunks > 1 else None
 
