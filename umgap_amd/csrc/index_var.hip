@@ -117,33 +117,67 @@ __global__ __launch_bounds__(256) void k_lookup_var(const uint8_t* __restrict__ 
             uint64_t l64 = qoff[i + 1] - o;
             if (l64 >= 1 && l64 <= VAR_MAX_LEN) { len = (uint32_t)l64; h = hash_bytes(qbytes + o, len); valid = 1; }
         }
-        uint32_t res[4];
+        // Three phases so that the four rounds overlap their memory round trips (walking each round to its end before
+        // the next started, as the first version did, kept 16 requests per wave in flight; +6 %.  Fetching all words of
+        // a key in one go for hashing / comparison instead of word by word was tried and lost: it doubles the L1
+        // accesses, and the vector cache's tag rate is the other bound of this kernel):
+        //   1. the home buckets of the 4 rounds (4 loads in flight per quad);
+        //   2. the first 8 key bytes in the heap of every slot whose tag and length agree (default cache policy: the
+        //      line stays close for phase 3), together with the query's first word;
+        //   3. full comparison, then the rare displacement chain / stash.
+        uint32_t res[4], v[4], ln[4], want[4];
+        uint64_t hq[4], bucket[4];
+        const uint8_t* qp[4];
+        u32x4 e[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             int src = 16 * r + (int)q;
-            uint32_t v = (uint32_t)__shfl((int)valid, src, 64);
+            v[r] = (uint32_t)__shfl((int)valid, src, 64);
             uint32_t hl = (uint32_t)__shfl((int)(uint32_t)h, src, 64), hh = (uint32_t)__shfl((int)(uint32_t)(h >> 32), src, 64);
             uint32_t ol = (uint32_t)__shfl((int)(uint32_t)o, src, 64), oh = (uint32_t)__shfl((int)(uint32_t)(o >> 32), src, 64);
-            uint32_t ln = (uint32_t)__shfl((int)len, src, 64);
-            uint64_t hq = ((uint64_t)hh << 32) | hl;
-            const uint8_t* qp = qbytes + (((uint64_t)oh << 32) | ol);
+            ln[r] = (uint32_t)__shfl((int)len, src, 64);
+            hq[r] = ((uint64_t)hh << 32) | hl;
+            qp[r] = qbytes + (((uint64_t)oh << 32) | ol);
+            bucket[r] = __umul64hi(hq[r], T.nb);
+            want[r] = ((uint32_t)hq[r] & 0x01FFFFFFu) | (ln[r] << 25);
+            e[r] = v[r] ? __builtin_nontemporal_load(T.slots + bucket[r] * VAR_SLOTS + j) : u32x4{0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu};
+        }
+        uint64_t hw[4], qw[4];
+        bool cand[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint64_t off = ((uint64_t)e[r].w << 32) | e[r].z;
+            cand[r] = v[r] && off != VAR_EMPTY && (e[r].x & 0x7FFFFFFFu) == want[r];
+            hw[r] = qw[r] = 0;
+            if (cand[r] && ln[r] >= 8) {
+                hw[r] = *reinterpret_cast<const u64_unaligned*>(T.heap + off);
+                qw[r] = *reinterpret_cast<const u64_unaligned*>(qp[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
             uint32_t r_out = miss;
-            if (v) {  // quad-uniform
-                uint64_t bucket = __umul64hi(hq, T.nb);
-                uint32_t want = ((uint32_t)hq & 0x01FFFFFFu) | (ln << 25);
-                bool found = false, go = true;
-                for (uint32_t d = 0; go && d <= VAR_MAX_DISP; d++) {
-                    u32x4 e = __builtin_nontemporal_load(T.slots + (bucket + d) * VAR_SLOTS + j);
-                    uint64_t off = ((uint64_t)e.w << 32) | e.z;
-                    uint32_t val = 0, hit = 0;
-                    if (off != VAR_EMPTY && (e.x & 0x7FFFFFFFu) == want && bytes_equal(T.heap + off, qp, ln)) { hit = 1; val = e.y; }
-                    uint32_t ovf = (j == 0) ? (e.x >> 31) : 0u;
-                    uint32_t f = quad_or(hit | (ovf << 1));
+            if (v[r]) {  // quad-uniform
+                const uint64_t off = ((uint64_t)e[r].w << 32) | e[r].z;
+                uint32_t val = 0, hit = 0;
+                if (cand[r] && hw[r] == qw[r] && bytes_equal(T.heap + off, qp[r], ln[r])) { hit = 1; val = e[r].y; }
+                uint32_t ovf = (j == 0) ? (e[r].x >> 31) : 0u;
+                uint32_t f = quad_or(hit | (ovf << 1));
+                val = quad_or(val);
+                bool found = f & 1u, go = !found && (f & 2u);
+                if (found) r_out = val;
+                for (uint32_t d = 1; go && d <= VAR_MAX_DISP; d++) {   // home bucket overflowed at build time: walk on
+                    u32x4 ed = __builtin_nontemporal_load(T.slots + (bucket[r] + d) * VAR_SLOTS + j);
+                    uint64_t offd = ((uint64_t)ed.w << 32) | ed.z;
+                    val = 0; hit = 0;
+                    if (offd != VAR_EMPTY && (ed.x & 0x7FFFFFFFu) == want[r] && bytes_equal(T.heap + offd, qp[r], ln[r])) { hit = 1; val = ed.y; }
+                    ovf = (j == 0) ? (ed.x >> 31) : 0u;
+                    f = quad_or(hit | (ovf << 1));
                     val = quad_or(val);
                     if (f & 1u) { r_out = val; found = true; go = false; }
                     else if (!(f & 2u)) go = false;
                 }
-                if (!found && go == true && T.n_stash) r_out = var_stash_lookup(T, hq, qp, ln, miss);  // chain exhausted
+                if (!found && go && T.n_stash) r_out = var_stash_lookup(T, hq[r], qp[r], ln[r], miss);  // chain exhausted
             }
             res[r] = r_out;
         }
@@ -205,10 +239,10 @@ __global__ void k_selfcheck_var(const uint32_t* __restrict__ got, const uint32_t
         if (got[i] != want[i]) atomicAdd(&flags->mismatch, 1ull);
 }
 
-inline int grid_for(size_t n) {
+inline int grid_for(size_t n, size_t per_cu = 8) {
     size_t g = (n + 255) / 256;
     if (g < 1) g = 1;
-    if (g > 256 * 8) g = 256 * 8;
+    if (g > 256 * per_cu) g = 256 * per_cu;
     return (int)g;
 }
 
@@ -295,7 +329,8 @@ int var_build(umgap_var_index** out, uint8_t* d_heap, uint64_t heap_bytes, const
 }
 
 int var_lookup_dev(const umgap_var_index* v, const uint8_t* d_bytes, const uint64_t* d_off, size_t n, uint32_t miss, uint32_t* d_out, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(k_lookup_var, dim3(grid_for(n)), dim3(256), 0, s, d_bytes, d_off, n, miss, d_out, v->view());
+    // 85 VGPRs = 5 waves/SIMD = 5 workgroups per CU: a grid of whole resident rounds (no half-empty tail round)
+    if (n) hipLaunchKernelGGL(k_lookup_var, dim3(grid_for(n, 10)), dim3(256), 0, s, d_bytes, d_off, n, miss, d_out, v->view());
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
 }
