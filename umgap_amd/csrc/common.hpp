@@ -37,10 +37,10 @@ int use_device(int device);
 //   bucket it skipped carries the overflow flag, so a probe walks on only past flagged buckets:
 //   a hit or a miss costs ONE 64-byte sector unless the home bucket overflowed at build time.
 //   (bucket, d, R) determines h, hence the key: exact match, no false positives.
-//   The very few keys (~1e-5 at load 0.6) whose chain would exceed MAX_DISP live in the STASH: a
+//   The very few keys (~1e-5 at load 0.6, fewer at the default 0.5) whose chain would exceed MAX_DISP live in the STASH: a
 //   sorted array of (home bucket << 28 | R) -> taxon, binary-searched only by probes that walked
-//   the whole chain through flagged buckets.  This keeps the load factor (13.3 B/key at 0.6)
-//   independent of the table size.
+//   the whole chain through flagged buckets.  This keeps the load factor (default 0.5 = 16 B/key: 2.3 % of the
+//   buckets overflow, 1.014 requests per lookup; 0.6 = 13.3 B/key: 6.6 %, 1.044) independent of the table size.
 // ---------------------------------------------------------------------------------------------
 static constexpr uint64_t MASK45 = (1ull << 45) - 1;
 static constexpr uint32_t R_BITS = 28;
