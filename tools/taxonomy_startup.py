@@ -12,7 +12,9 @@ for name, cmd in (("taxa2agg_lca", [UMGAP, "taxa2agg", "-a", "lca*", tsv]), ("ta
     best = 1e9
     for _ in range(3):
         t0 = time.perf_counter()
-        subprocess.run(cmd, input=b"", stdout=subprocess.DEVNULL, check=True, env=dict(os.environ, UMGAP_TIMING="1"))
+        pr = subprocess.run(cmd, input=b"", stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, check=True, env=dict(os.environ, UMGAP_TIMING="1"))
         best = min(best, time.perf_counter() - t0)
+        if pr.stderr.strip():
+            res[name + "_phases"] = pr.stderr.decode().strip().splitlines()[-1]
     res[name + "_s"] = round(best, 3)
 print(json.dumps(res))

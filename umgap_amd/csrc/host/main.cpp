@@ -462,7 +462,11 @@ int cmd_prot2kmer2lca(const std::vector<std::string>& args) {
 
 // ---- taxa2agg ------------------------------------------------------------------------------------
 umgap_taxonomy* load_taxonomy(const std::string& path) {
-    TaxonRows rows = read_taxa_file(path);
+    const bool timing = getenv("UMGAP_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    TaxonRows rows = read_taxa_file_parallel(path);
+    const double t1 = now();
     std::vector<uint32_t> id(rows.id.size()), parent(rows.id.size());
     for (size_t i = 0; i < rows.id.size(); i++) {
         if (rows.id[i] >= 0xFFFFFFFFull || rows.parent[i] >= 0xFFFFFFFFull) throw CliError("taxon id >= 2^32-1 is not supported");
@@ -471,6 +475,7 @@ umgap_taxonomy* load_taxonomy(const std::string& path) {
     }
     umgap_taxonomy* tx = nullptr;
     int rc = umgap_taxonomy_create(id.data(), parent.data(), rows.valid.data(), rows.rank.data(), id.size(), 0, &tx);
+    if (timing) fprintf(stderr, "taxonomy: parse %.3f s, create (host tables + upload, includes HIP start-up when first) %.3f s\n", t1 - t0, now() - t1);
     if (rc == UMGAP_ERR_PANIC) throw CliPanic(umgap_last_error());
     if (rc) lib_fail(rc);
     return tx;
@@ -651,7 +656,7 @@ int cmd_seedextend(const std::vector<std::string>& args) {
     if (!p.positional.empty()) usage_error("Found argument '" + p.positional[0] + "' which wasn't expected, or isn't valid in this context");
     std::optional<RankScores> ranks;
     if (auto tf = p.get("ranked")) {
-        RankScores rs(read_taxa_file(*tf));
+        RankScores rs(read_taxa_file_parallel(*tf));
         for (size_t id = 0; id < rs.present.size(); id++) (void)rs.score(id);   // memoise everything: workers only read
         ranks.emplace(std::move(rs));
     }
