@@ -796,7 +796,10 @@ int umgap_index_open_shard(const char* path, uint32_t device_mask, uint32_t shar
     // body [lo, hi) then the halo (wraps to bucket 0 for the last shard).  The ~100 GB body is pulled in by several
     // threads, each with its own pinned buffer and stream: pread (page cache or NVMe queue depth) of one chunk overlaps
     // the uploads of the others (a single read-then-copy loop tops out near 4 GB/s).
-    const size_t chunk = 32u << 20;
+    // pinned staging per loader thread: 32 MiB for the big tables, less for small ones (pinning memory is not free and
+    // the command-line tools open an index per invocation)
+    const size_t body_bytes = (size_t)(hi - lo) * 64;
+    const size_t chunk = std::min<size_t>(32u << 20, std::max<size_t>(1u << 20, (body_bytes / 32 + 4095) & ~(size_t)4095));
     const int fd = fileno(f);
     std::atomic<bool> ok{true};
     auto load_range = [&](uint64_t first_bucket, uint64_t count, size_t dst_bucket, unsigned n_threads) {
