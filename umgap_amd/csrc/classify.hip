@@ -256,6 +256,7 @@ __global__ __launch_bounds__(256, 4) void k_classify_prot9(TableView T, TaxView 
     uint32_t* wfstart = lds_fstart[wv];
     uint32_t* wfwin = lds_fwin[wv];
     uint32_t* wfbyte = lds_fbyte[wv];
+    uint32_t* wowner = lds_taxa[wv];   // the strip is dead until the first probe results arrive: its head holds the lane -> run table
 #pragma unroll
     for (int i = 0; i < 4; i++) { wkeys[lane + 64 * i] = 0u; wcnt[lane + 64 * i] = 0u; }
     const bool tree_like = method != UMGAP_METHOD_RMQ;
@@ -313,40 +314,71 @@ __global__ __launch_bounds__(256, 4) void k_classify_prot9(TableView T, TaxView 
             for (uint32_t i = lane; i < nb_lo; i += 64) wbytes[k * PROT_MAX_BYTES + i] = gp[i];
         }
         wave_lds_sync();
-        // ---- probe: the group's windows as one flat list, chunks of 128 (two batches in flight) ----
-        for (uint32_t c = 0; c < W; c += 128) {
+        // ---- probe: every lane walks a run of R consecutive windows of ONE fragment with a rolling key ----
+        // (one LDS byte and a shift per window instead of nine bytes and a search for the owning fragment; batch t = the
+        // t-th window of every lane; runs never cross a fragment because lanes are dealt out per fragment.)
+        uint32_t R = (W + 63) / 64, my_lanes, lanes_incl, n_lanes;
+        if (R == 0) R = 1;
+        for (;;) {   // smallest run length whose lanes fit the wave (wave-uniform loop; usually 1-2 trips)
+            my_lanes = (my_win + R - 1) / R;
+            lanes_incl = my_lanes;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { uint32_t t = (uint32_t)__shfl_up((int)lanes_incl, o, 64); if (lane >= (uint32_t)o) lanes_incl += t; }
+            n_lanes = (uint32_t)__shfl((int)lanes_incl, 63, 64);
+            if (n_lanes <= 64) break;
+            R++;
+        }
+        {
+            const uint32_t first_lane = lanes_incl - my_lanes;
+            for (uint32_t x = 0; x < my_lanes; x++) wowner[first_lane + x] = lane | (x << 8);   // fragment id, run number
+        }
+        wave_lds_sync();
+        uint32_t run_cnt = 0, sb = 0, poison = 0, bo = 0;
+        uint64_t key = 0;
+        if (lane < n_lanes) {
+            const uint32_t ow = wowner[lane], f = ow & 0xFFu, w0 = (ow >> 8) * R;
+            const uint32_t fw = wfwin[f];
+            run_cnt = fw - w0 < R ? fw - w0 : R;
+            sb = wfstart[f] + w0;
+            bo = wfbyte[f] + w0;
+        }
+        wave_lds_sync();   // the table is read; the strip may be written now
+        for (uint32_t t = 0; t < R; t += 2) {
             ProbeBatch B[2];
             uint32_t pr[2][4];
-            const bool two = c + 64 < W;
+            const bool two = t + 1 < R;
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 if (h == 1 && !two) { probe_skip(B[1]); break; }   // wave-uniform
-                const uint32_t gw = c + 64 * h + lane;
+                const uint32_t tt = t + h;
+                const bool active = tt < run_cnt;
                 uint32_t valid = 0, loc = 0, tg = 0;
-                if (gw < W) {
-                    // the fragment that owns window gw: the last one whose first window is <= gw
-                    uint32_t lo = 0, hi = nfr;
-                    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (wfstart[mid] <= gw) lo = mid; else hi = mid; }
-                    const uint8_t* sp = wbytes + wfbyte[lo] + (gw - wfstart[lo]);
-                    uint64_t key = 0;
-                    bool okc = true;
+                if (tt == 0) {            // wave-uniform: the first window of every run is read whole
+                    if (active) {
 #pragma unroll
-                    for (int ch9 = 0; ch9 < 9; ch9++) {
-                        uint32_t ch = sp[ch9];
-                        okc = okc && (ch >= 'A' && ch <= 'Z');
-                        key = (key << 5) | ((ch - 'A') & 31u);
+                        for (int c9 = 0; c9 < 9; c9++) {
+                            const uint32_t code = (uint32_t)wbytes[bo + c9] - 'A';
+                            if (code >= 26u) poison = c9 + 1;             // that many windows, this one included, hold the byte
+                            key = (key << 5) | (code & 31u);
+                        }
                     }
-                    valid = (okc && locate(T, key, loc, tg)) ? 1u : 0u;
+                } else if (active) {      // the next residue enters, the oldest leaves
+                    const uint32_t code = (uint32_t)wbytes[bo + tt + 8] - 'A';
+                    key = ((key << 5) | (code & 31u)) & MASK45;
+                    poison = code >= 26u ? 9u : (poison ? poison - 1u : 0u);
                 }
+                if (active && poison == 0) valid = locate(T, key, loc, tg) ? 1u : 0u;
                 probe_issue(T, loc, tg | (valid << 31), lane, B[h]);
             }
             probe_eval_multi<2>(T, B, 0u, lane, pr);
-            if (j == 0) {
+            // the result of round x belongs to the window of lane 16x + q: fetch its strip position (every lane shuffles)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const uint32_t sidx = (t + h < run_cnt) ? sb + t + h : NONE;
 #pragma unroll
                 for (int x = 0; x < 4; x++) {
-                    const uint32_t i0 = c + 16 * x + q, i1 = i0 + 64;
-                    if (i0 < W) wtaxa[i0] = pr[0][x];
-                    if (two && i1 < W) wtaxa[i1] = pr[1][x];
+                    const uint32_t dst = (uint32_t)__shfl((int)sidx, 16 * x + (int)q, 64);
+                    if (j == 0 && dst != NONE && (h == 0 || two)) wtaxa[dst] = pr[h][x];
                 }
             }
         }
