@@ -5,7 +5,7 @@
 // leave the CU.  Reference code per stage: src/commands/pept2lca.rs:93 (get), src/commands/
 // seedextend.rs:99-148, src/commands/taxa2agg.rs:161-180 + src/tree/lca.rs:32-40.
 //
-// Why fuse: the probe is bound by the chip's random-request rate (~40 G 64-byte requests/s, see
+// Why fuse: the probe is bound by the chip's random-request rate (~50 G 64-byte requests/s, see
 // DESIGN.md) and leaves the ALUs idle; the aggregate is instruction/latency bound.  In one kernel
 // the aggregate of some waves runs under the memory waits of the others, and the 4 B/hit round
 // trip through HBM disappears.
@@ -13,7 +13,8 @@
 // A wave owns a group of reads at a time (stride = k-mers per read, 84 -> 12 reads = 1008 keys):
 // probe -> taxa into the wave's LDS strip -> seedextend on all the group's fragments in parallel
 // lanes -> per read: LDS hash-count, leaders gather {pre,last}, O(1) range-min LCA (aggregate.hip
-// has the commentary).
+// has the commentary).  k_classify9_general is the same pipeline for MRTL and the hybrids, k_classify_prot9 takes the
+// reads as protein fragments (rolling keys from LDS) instead of packed k-mers.
 #include "agg_general.hpp"
 #include "probe_common.hpp"
 
