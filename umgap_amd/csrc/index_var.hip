@@ -119,8 +119,8 @@ __global__ __launch_bounds__(256) void k_lookup_var(const uint8_t* __restrict__ 
         }
         // Three phases so that the four rounds overlap their memory round trips (walking each round to its end before
         // the next started, as the first version did, kept 16 requests per wave in flight; +6 %.  Fetching all words of
-        // a key in one go for hashing / comparison instead of word by word was tried and lost: it doubles the L1
-        // accesses, and the vector cache's tag rate is the other bound of this kernel):
+        // a key in one go for hashing / comparison instead of word by word was tried twice (always 8 clamped words; predicated
+        // words) and did not pay: the first doubles the cache accesses, both cost registers and with them a resident wave):
         //   1. the home buckets of the 4 rounds (4 loads in flight per quad);
         //   2. the first 8 key bytes in the heap of every slot whose tag and length agree (default cache policy: the
         //      line stays close for phase 3), together with the query's first word;
@@ -329,8 +329,14 @@ int var_build(umgap_var_index** out, uint8_t* d_heap, uint64_t heap_bytes, const
 }
 
 int var_lookup_dev(const umgap_var_index* v, const uint8_t* d_bytes, const uint64_t* d_off, size_t n, uint32_t miss, uint32_t* d_out, hipStream_t s) {
-    // 85 VGPRs = 5 waves/SIMD = 5 workgroups per CU: a grid of whole resident rounds (no half-empty tail round)
-    if (n) hipLaunchKernelGGL(k_lookup_var, dim3(grid_for(n, 10)), dim3(256), 0, s, d_bytes, d_off, n, miss, d_out, v->view());
+    // a grid of whole resident rounds (two of them): with a partial last round the kernel measured 16 % slower
+    static int per_cu = 0;
+    if (!per_cu) {
+        int b = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_lookup_var, 256, 0) != hipSuccess || b < 1) b = 4;
+        per_cu = 2 * b;
+    }
+    if (n) hipLaunchKernelGGL(k_lookup_var, dim3(grid_for(n, (size_t)per_cu)), dim3(256), 0, s, d_bytes, d_off, n, miss, d_out, v->view());
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
 }
