@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--seedextend", action="store_true", help="insert seedextend -g1 -s3 per fragment between lookup and aggregate")
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (process group, barriers, sharded extra) even with one rank")
     ap.add_argument("--unfused", action="store_true", help="run lookup and aggregate as separate kernels (hits through HBM)")
+    ap.add_argument("--no-bind", action="store_true", help="keep taxon ids in the table (the fused kernel then gathers {pre,last} by id)")
     return ap.parse_args()
 
 
@@ -198,6 +199,14 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     fused = not args.unfused and not sharded_mode
+    # the table is bound to the taxonomy for the fused LCA* kernel (values = preorder interval codes: no by-id gathers);
+    # a one-time in-place pass, undone before the kernels that want taxon ids
+    t_bind = None
+    if fused and not args.no_bind:
+        tb = time.perf_counter()
+        w.index.bind(w.taxonomy)
+        torch.cuda.synchronize()
+        t_bind = time.perf_counter() - tb
 
     def step(i, timed_idx=None):
         k = keys[i % n_batches]
@@ -263,7 +272,8 @@ def main():
                                    n_batches, B, " + seedextend -g1 -s3" if args.seedextend else "", " (one fused kernel)" if fused else ""),
                    "pairs_per_step_per_gpu": B, "n_keys": args.n_keys, "n_tax": args.n_tax,
                    "table_GB": round(w.index.table_bytes / 1e9, 2), "load_factor": args.load_factor,
-                   "parallelism": ("1 GPU" if world == 1 else "%s x%d" % (mode, world)), "setup_s": round(t_setup, 1)},
+                   "parallelism": ("1 GPU" if world == 1 else "%s x%d" % (mode, world)), "setup_s": round(t_setup, 1),
+                   "table_bound_to_taxonomy": t_bind is not None, "bind_s": None if t_bind is None else round(t_bind, 3)},
         "roofline": {"bound": "hbm", "kernel": "k_classify9" if fused else "k_lookup9", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(kernel_ms, 3),
@@ -294,6 +304,8 @@ def main():
         el = time.perf_counter() - t1
         out["with_seedextend"] = {"value": round(args.steps * B / el, 1), "unit": "pairs/s", "ms_per_step": round(1e3 * el / args.steps, 3),
                                   "pipeline": "probe -> seedextend -g1 -s3 (per read end) -> taxa2agg -l2 -a lca*, one fused kernel"}
+    if w.index is not None and w.index.bound:
+        w.index.unbind(w.taxonomy)          # the kernels below want taxon ids
     if world == 1 and fused and not args.seedextend:
         # the filter + aggregate stages of the two 9-mer sensitivity pipelines (scripts/umgap-analyse.sh:277-288) through the
         # fused kernel for the other strategies, on the same batches (the script feeds them 6-frame translations, ~500 k-mers

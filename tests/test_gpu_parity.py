@@ -563,6 +563,70 @@ def test_fused_classify_other_strategies_many_distinct_taxa(api, torch_cuda):
         assert nbad == 0, bad
 
 
+@pytest.mark.parametrize("stride,n_pairs,lb", [(84, 30_001, 2.0), (84, 10_000, 1.0), (128, 3_001, 0.0), (42, 5_000, 3.0), (7, 1_000, 1.0)])
+def test_bound_table_classify_is_bit_identical(api, torch_cuda, stride, n_pairs, lb):
+    """umgap_index_bind_taxonomy rewrites the table values into {preorder, subtree-size code}; the fused kernel then skips
+    the by-id gathers.  Same answers, bit for bit, as the unbound kernel (which is checked against the oracle above), with
+    and without seedextend, for both methods and -r; plain lookups are refused while bound; unbinding restores the ids."""
+    torch = torch_cuda
+    from umgap_amd import UmgapError
+    from umgap_amd.synth import SyntheticWorkload
+    w = SyntheticWorkload(n_tax=60_000, n_keys=2_000_000, max_depth=30)
+    d_keys = w.reads(0, n_pairs, kmers_per_pair=stride)
+    want_hits = w.index.lookup9_dev(d_keys).clone()
+    outs = {}
+    cases = [(m, r, f) for m in ("tree", "rmq") for r in (False, True) for f in ((0, 2) if stride % 2 == 0 else (0,))]
+    for m, r, f in cases:
+        d_t = torch.empty(n_pairs, dtype=torch.int32, device="cuda"); d_s = torch.empty_like(d_t)
+        api.classify9_dev(w.index, w.taxonomy, d_keys, n_pairs, stride, d_t, d_s, method=m, lower_bound=lb, ranked_only=r,
+                          fragments_per_read=f, min_seed_size=2, max_gap_size=1)
+        outs[(m, r, f)] = (d_t, d_s)
+    w.index.bind(w.taxonomy)
+    assert w.index.bound
+    try:
+        for m, r, f in cases:
+            d_t = torch.empty(n_pairs, dtype=torch.int32, device="cuda"); d_s = torch.empty_like(d_t)
+            api.classify9_dev(w.index, w.taxonomy, d_keys, n_pairs, stride, d_t, d_s, method=m, lower_bound=lb, ranked_only=r,
+                              fragments_per_read=f, min_seed_size=2, max_gap_size=1)
+            torch.cuda.synchronize()
+            assert torch.equal(d_t, outs[(m, r, f)][0]) and torch.equal(d_s, outs[(m, r, f)][1]), (m, r, f)
+        with pytest.raises(UmgapError):
+            w.index.lookup9_dev(d_keys)
+        with pytest.raises(UmgapError):
+            w.index.bind(w.taxonomy)
+    finally:
+        w.index.unbind(w.taxonomy)
+    assert not w.index.bound
+    assert torch.equal(w.index.lookup9_dev(d_keys), want_hits)
+    assert (outs[("tree", False, 0)][1] == 0).any()
+
+
+def test_bind_refuses_values_outside_the_taxonomy(api, torch_cuda):
+    """A table value that is not a reachable taxon has no interval: binding is refused and the table is left untouched."""
+    from umgap_amd import UmgapError
+    ids = np.arange(1, 40, dtype=np.uint32)
+    par = np.maximum(1, ids // 2).astype(np.uint32)
+    par[0] = 1
+    tx = api.Taxonomy(ids, par)
+    rng = np.random.default_rng(1)
+    keys = np.unique(rng.integers(0, 1 << 45, 5000, dtype=np.uint64))
+    vals = rng.choice(ids, len(keys)).astype(np.uint32)
+    vals[17] = 7_000_001
+    ix = api.Index.build(keys, vals)
+    with pytest.raises(UmgapError):
+        ix.bind(tx)
+    assert not ix.bound
+    import torch
+    got = ix.lookup9_dev(torch.from_numpy(keys.view(np.int64)).cuda()).cpu().numpy().view(np.uint32)
+    assert (got == vals).all()
+    vals[17] = 3
+    ix2 = api.Index.build(keys, vals)
+    ix2.bind(tx)
+    ix2.unbind(tx)
+    got = ix2.lookup9_dev(torch.from_numpy(keys.view(np.int64)).cuda()).cpu().numpy().view(np.uint32)
+    assert (got == vals).all()
+
+
 def test_synth_pipeline_small(api, torch_cuda):
     t, s = _pipeline_check(api, torch_cuda, n_tax=20_000, n_keys=1_000_000, n_pairs=20_000, with_seedextend=False)
     assert (s == 0).mean() > 0.9 and len(np.unique(t)) > 1000
@@ -850,6 +914,14 @@ def test_fused_classify_prot9_vs_oracle(api, torch_cuda, with_seedextend):
     nbad, bad, wt, ws = agg.taxa2agg_check(hits, offs, t, s, lower_bound=2.0, nthreads=8)
     assert nbad == 0, (bad, t[bad.astype(int)], s[bad.astype(int)], wt[bad.astype(int)])
     assert (s == 0).mean() > 0.5
+    # the same launch on the table bound to the taxonomy: bit-identical
+    ix.bind(w.taxonomy)
+    d_t2, d_s2 = torch.empty_like(d_t), torch.empty_like(d_s)
+    api.classify_prot9_dev(ix, w.taxonomy, reads, roffs, n_reads, F, d_t2, d_s2, method="tree", lower_bound=2.0, seedextend=with_seedextend,
+                           min_seed_size=3, max_gap_size=1)
+    torch.cuda.synchronize()
+    ix.unbind(w.taxonomy)
+    assert torch.equal(d_t, d_t2) and torch.equal(d_s, d_s2)
 
 
 def test_classify_prot9_ragged_fragments(api, torch_cuda):

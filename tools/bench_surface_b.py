@@ -43,6 +43,8 @@ d_t = torch.empty(n_pairs, dtype=torch.int32, device=dev)
 d_s = torch.empty_like(d_t)
 res = {"n_proteome_fragments": n_frag, "index_keys": n_frag * (flen - 8), "table_GB": round(ix.table_bytes / 1e9, 2), "pairs_per_step": n_pairs,
        "input_bytes_per_pair": F * flen + (F * 8), "setup_s": round(setup, 1)}
+ix.bind(w.taxonomy)     # values = preorder interval codes: the aggregate stage gathers nothing by id
+res["table_bound_to_taxonomy"] = True
 for name, se in (("classify_prot9", False), ("classify_prot9_seedextend", True)):
     classify_prot9_dev(ix, w.taxonomy, batches[0], roffs, n_pairs, F, d_t, d_s, method="tree", lower_bound=2.0, seedextend=se, min_seed_size=3, max_gap_size=1)
     torch.cuda.synchronize()

@@ -160,6 +160,17 @@ class Index:
     def save(self, path):
         check(_lib.load().umgap_index_save(self._h, str(path).encode()))
 
+    def bind(self, taxonomy):
+        """Rewrite the table values into {preorder, subtree size} codes of `taxonomy` (umgap_index_bind_taxonomy)."""
+        check(_lib.load().umgap_index_bind_taxonomy(self._h, taxonomy._h))
+
+    def unbind(self, taxonomy):
+        check(_lib.load().umgap_index_unbind_taxonomy(self._h, taxonomy._h))
+
+    @property
+    def bound(self):
+        return bool(_lib.load().umgap_index_is_bound(self._h))
+
     def close(self):
         if self._h:
             _lib.load().umgap_index_free(self._h)

@@ -1,0 +1,108 @@
+// bind.hip — binding a 9-mer table to a taxonomy: the slot values (and the stash's) are rewritten in place from NCBI
+// taxon ids to the {preorder index, subtree size code} of bound.hpp, and back.  See bound.hpp for why.
+#include "bound.hpp"
+#include "common.hpp"
+#include "taxonomy.hpp"
+
+using namespace umgap;
+
+namespace {
+
+constexpr uint64_t EMPTY64 = ~0ull;
+
+// dry run: values that have no interval (id beyond the list, absent or unreachable taxon, or 0)
+__global__ __launch_bounds__(256) void k_bind_check(const uint64_t* __restrict__ slots, size_t nslots, const uint32_t* __restrict__ stash_vals,
+                                                    uint32_t n_stash, const uint2* __restrict__ by_id, uint32_t len, unsigned long long* bad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    unsigned long long mine = 0;
+    for (size_t k = i; k < nslots + n_stash; k += stride) {
+        uint32_t t;
+        if (k < nslots) { uint64_t s = slots[k]; if (s == EMPTY64) continue; t = (uint32_t)(s >> 32); }
+        else t = stash_vals[k - nslots];
+        if (t >= len || by_id[t].x == UMGAP_NONE) mine++;
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+
+__global__ __launch_bounds__(256) void k_bind(uint64_t* __restrict__ slots, size_t nslots, uint32_t* __restrict__ stash_vals, uint32_t n_stash,
+                                              const uint2* __restrict__ by_id) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = i; k < nslots + n_stash; k += stride) {
+        if (k < nslots) {
+            uint64_t s = slots[k];
+            if (s == EMPTY64) continue;
+            uint2 pl = by_id[(uint32_t)(s >> 32)];
+            slots[k] = ((uint64_t)bound::encode(pl.x, pl.y - pl.x) << 32) | (s & 0xFFFFFFFFull);
+        } else {
+            uint2 pl = by_id[stash_vals[k - nslots]];
+            stash_vals[k - nslots] = bound::encode(pl.x, pl.y - pl.x);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_unbind(uint64_t* __restrict__ slots, size_t nslots, uint32_t* __restrict__ stash_vals, uint32_t n_stash,
+                                                const uint32_t* __restrict__ id_of_pre) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = i; k < nslots + n_stash; k += stride) {
+        if (k < nslots) {
+            uint64_t s = slots[k];
+            if (s == EMPTY64) continue;
+            slots[k] = ((uint64_t)id_of_pre[bound::pre_of((uint32_t)(s >> 32))] << 32) | (s & 0xFFFFFFFFull);
+        } else {
+            stash_vals[k - nslots] = id_of_pre[bound::pre_of(stash_vals[k - nslots])];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int umgap_index_is_bound(const umgap_index* ix) { return ix && ix->bound_to ? 1 : 0; }
+
+int umgap_index_bind_taxonomy(umgap_index* ix, umgap_taxonomy* tx) {
+    if (!ix || !tx) return fail(UMGAP_ERR_INVALID, "umgap_index_bind_taxonomy: null argument");
+    if (ix->kind != 9) return fail(UMGAP_ERR_INVALID, "umgap_index_bind_taxonomy: only the 9-mer table can be bound");
+    if (ix->bound_to) return fail(UMGAP_ERR_INVALID, "umgap_index_bind_taxonomy: the index is already bound");
+    if (ix->device != tx->device) return fail(UMGAP_ERR_INVALID, "umgap_index_bind_taxonomy: index and taxonomy live on different devices");
+    if (tx->n_reach > bound::MAX_REACH) return fail(UMGAP_ERR_INVALID, "umgap_index_bind_taxonomy: more than 2^22 - 2 reachable taxa");
+    int rc = use_device(ix->device);
+    if (rc) return rc;
+    const size_t nslots = (size_t)ix->view.n_resident * SLOTS;
+    unsigned long long* d_bad = nullptr;
+    UMGAP_HIP(hipMalloc((void**)&d_bad, sizeof(unsigned long long)));
+    hipError_t e = hipMemsetAsync(d_bad, 0, sizeof(unsigned long long), ix->stream);
+    unsigned long long bad = 0;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_bind_check, dim3(256 * 8), dim3(256), 0, ix->stream, ix->d_slots, nslots, ix->d_stash_vals, ix->n_stash, tx->d_by_id, tx->len, d_bad);
+        e = hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, ix->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+    (void)hipFree(d_bad);
+    if (e != hipSuccess) return fail(UMGAP_ERR_DEVICE, std::string("umgap_index_bind_taxonomy: ") + hipGetErrorString(e));
+    if (bad) return fail(UMGAP_ERR_BUILD, "umgap_index_bind_taxonomy: " + std::to_string(bad) + " table values are not taxa of this taxonomy (the unbound kernels report them per read)");
+    hipLaunchKernelGGL(k_bind, dim3(256 * 8), dim3(256), 0, ix->stream, ix->d_slots, nslots, ix->d_stash_vals, ix->n_stash, tx->d_by_id);
+    UMGAP_HIP(hipGetLastError());
+    UMGAP_HIP(hipStreamSynchronize(ix->stream));
+    ix->bound_to = tx;
+    return UMGAP_OK;
+}
+
+int umgap_index_unbind_taxonomy(umgap_index* ix, umgap_taxonomy* tx) {
+    if (!ix || !tx) return fail(UMGAP_ERR_INVALID, "umgap_index_unbind_taxonomy: null argument");
+    if (!ix->bound_to) return UMGAP_OK;
+    if (ix->bound_to != tx) return fail(UMGAP_ERR_INVALID, "umgap_index_unbind_taxonomy: bound to another taxonomy");
+    int rc = use_device(ix->device);
+    if (rc) return rc;
+    const size_t nslots = (size_t)ix->view.n_resident * SLOTS;
+    hipLaunchKernelGGL(k_unbind, dim3(256 * 8), dim3(256), 0, ix->stream, ix->d_slots, nslots, ix->d_stash_vals, ix->n_stash, tx->d_id_of_pre);
+    UMGAP_HIP(hipGetLastError());
+    UMGAP_HIP(hipStreamSynchronize(ix->stream));
+    ix->bound_to = nullptr;
+    return UMGAP_OK;
+}
+
+}  // extern "C"

@@ -16,6 +16,7 @@
 // has the commentary).  k_classify9_general is the same pipeline for MRTL and the hybrids, k_classify_prot9 takes the
 // reads as protein fragments (rolling keys from LDS) instead of packed k-mers.
 #include "agg_general.hpp"
+#include "bound.hpp"
 #include "probe_common.hpp"
 
 using namespace umgap;
@@ -96,6 +97,37 @@ __device__ __forceinline__ void lca_star_from_lds(const TaxView& V, bool tree_li
     }
 }
 
+// The same for a table BOUND to the taxonomy (bound.hpp): the strip holds {pre + 1, size code} instead of taxon ids, so
+// no by-id gather is needed; only a survivor whose subtree end falls inside the code's rounding gap fetches it.
+__device__ __forceinline__ void lca_star_bound_from_lds(const TaxView& V, const uint32_t* rt, uint32_t n, float lower_bound,
+                                                        uint32_t* wkeys, uint32_t* wcnt, uint32_t lane, uint32_t& res_taxon, uint32_t& res_status) {
+    uint32_t t0 = lane < n ? rt[lane] : 0u, t1 = 64 + lane < n ? rt[64 + lane] : 0u;
+    bool keep0, keep1;
+    float c0, c1;
+    lds_count(wkeys, wcnt, t0, t1, lower_bound, keep0, keep1, c0, c1);
+    if (!__any(keep0 || keep1)) {
+        res_status = UMGAP_READ_EMPTY;   // literal "1" (src/commands/taxa2agg.rs:174-175)
+        res_taxon = 1;
+        return;
+    }
+    const uint32_t p0 = keep0 ? bound::pre_of(t0) : 0u, p1 = keep1 ? bound::pre_of(t1) : 0u;
+    const uint32_t M = wave_max(max(p0, p1));
+    auto not_ancestor_of_M = [&](uint32_t v, uint32_t p) -> bool {   // last[x] < pre[M] ?
+        uint32_t lo, hi;
+        bound::size_bounds(v, lo, hi);
+        if (M > p + hi) return true;
+        if (M <= p + lo) return false;
+        return V.last_of_pre[p] < M;                                  // inside the rounding gap: the exact subtree end
+    };
+    uint32_t hp = NONE;
+    if (keep0 && not_ancestor_of_M(t0, p0)) hp = p0;
+    if (keep1 && not_ancestor_of_M(t1, p1)) hp = min(hp, p1);
+    hp = wave_min(hp);
+    if (hp != NONE) res_taxon = V.psnap_of_pre[wave_argmin_depth(V, hp + 1, M, lane)];
+    else res_taxon = V.snap_of_pre[M];
+    res_status = res_taxon == NONE ? UMGAP_READ_PANIC : UMGAP_READ_OK;
+}
+
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -139,6 +171,7 @@ __device__ __forceinline__ void probe_group_to_strip(const TableView& T, const u
 // G * frags fragments at once (one lane each), and the G reads are aggregated one after another.
 // 94 VGPRs would allow 5 waves/SIMD; 4 measured faster (18.8 vs 19.6 ms): the request rate is the ceiling and a fifth
 // wave only adds contention.
+template <bool BOUND>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_classify9(TableView T, TaxView V, int method, const uint64_t* __restrict__ keys,
                                                    size_t n_reads, uint32_t stride, uint32_t frags, uint32_t min_seed, uint32_t max_gap,
                                                    float lower_bound, uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status) {
@@ -171,7 +204,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         // ---- aggregate each read of the group ----
         for (uint32_t k = 0; k < nr; k++) {
             uint32_t res_taxon, res_status;
-            lca_star_from_lds(V, tree_like, wtaxa + k * stride, stride, lower_bound, wkeys, wcnt, lane, res_taxon, res_status);
+            if (BOUND) lca_star_bound_from_lds(V, wtaxa + k * stride, stride, lower_bound, wkeys, wcnt, lane, res_taxon, res_status);
+            else lca_star_from_lds(V, tree_like, wtaxa + k * stride, stride, lower_bound, wkeys, wcnt, lane, res_taxon, res_status);
             if (lane == 0) {
                 out_taxon[r0 + k] = res_taxon;
                 out_status[r0 + k] = res_status;
@@ -242,6 +276,7 @@ __global__ __launch_bounds__(256) void k_classify9_general(TableView T, TaxView 
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t PROT_MAX_FRAGS = 16, PROT_MAX_BYTES = 384, PROT_MAX_WINDOWS = 128, PROT_GROUP = STRIP / PROT_MAX_WINDOWS;  // 8 reads
 
+template <bool BOUND>
 __global__ __launch_bounds__(256, 4) void k_classify_prot9(TableView T, TaxView V, int method, const uint8_t* __restrict__ bytes,
                                                         const uint64_t* __restrict__ foff, size_t n_reads, uint32_t F, uint32_t do_seed,
                                                         uint32_t min_seed, uint32_t max_gap, float lower_bound,
@@ -393,7 +428,10 @@ __global__ __launch_bounds__(256, 4) void k_classify_prot9(TableView T, TaxView 
         for (uint32_t k = 0; k < nr; k++) {
             const uint32_t total = lds_total[wv][k];
             uint32_t res_taxon = 0, res_status = 4u;   // UMGAP_READ_UNSUPPORTED: use lookup_prot9 + aggregate for such reads
-            if (total != 0xFFFFFFFFu) lca_star_from_lds(V, tree_like, wtaxa + wfstart[k * F], total, lower_bound, wkeys, wcnt, lane, res_taxon, res_status);
+            if (total != 0xFFFFFFFFu) {
+                if (BOUND) lca_star_bound_from_lds(V, wtaxa + wfstart[k * F], total, lower_bound, wkeys, wcnt, lane, res_taxon, res_status);
+                else lca_star_from_lds(V, tree_like, wtaxa + wfstart[k * F], total, lower_bound, wkeys, wcnt, lane, res_taxon, res_status);
+            }
             if (lane == 0) {
                 out_taxon[r0 + k] = res_taxon;
                 out_status[r0 + k] = res_status;
@@ -423,8 +461,13 @@ extern "C" int umgap_classify9_dev(umgap_index* ix, umgap_taxonomy* tx, int meth
     size_t groups = (n_reads + G - 1) / G;
     size_t g = (groups + 3) / 4;
     if (g > 256 * 8) g = 256 * 8;     // measured: 8 workgroups per CU (two resident rounds) beats 4 and 16
-    hipLaunchKernelGGL(k_classify9, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, d_keys45, n_reads,
-                       kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status);
+    if (ix->bound_to && ix->bound_to != tx) return fail(UMGAP_ERR_INVALID, "umgap_classify9_dev: the index is bound to another taxonomy");
+    if (ix->bound_to)
+        hipLaunchKernelGGL(k_classify9<true>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, d_keys45, n_reads,
+                           kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status);
+    else
+        hipLaunchKernelGGL(k_classify9<false>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, d_keys45, n_reads,
+                           kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status);
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
 }
@@ -437,6 +480,7 @@ extern "C" int umgap_classify9_strategy_dev(umgap_index* ix, umgap_taxonomy* tx,
         return umgap_classify9_dev(ix, tx, method, lower_bound, ranked_only, d_keys45, n_reads, kmers_per_read, fragments_per_read, min_seed_size,
                                    max_gap_size, d_out_taxon, d_out_status, stream);
     if (!ix || !tx || (n_reads && (!d_keys45 || !d_out_taxon || !d_out_status))) return fail(UMGAP_ERR_INVALID, "umgap_classify9_strategy_dev: null argument");
+    if (ix->bound_to) return fail(UMGAP_ERR_INVALID, "the index is bound to a taxonomy (umgap_index_bind_taxonomy): its values are interval codes, not taxon ids; unbind it first");
     if (ix->kind != 9) return fail(UMGAP_ERR_INVALID, "umgap_classify9_strategy_dev: needs a 9-mer index");
     if (kmers_per_read == 0 || kmers_per_read > 128) return fail(UMGAP_ERR_INVALID, "umgap_classify9_strategy_dev: kmers_per_read must be in 1..128 (use lookup9 + aggregate for longer reads)");
     if (fragments_per_read && (kmers_per_read % fragments_per_read) != 0) return fail(UMGAP_ERR_INVALID, "umgap_classify9_strategy_dev: kmers_per_read must be a multiple of fragments_per_read");
@@ -484,6 +528,7 @@ extern "C" int umgap_classify_prot9_dev(umgap_index* ix, umgap_taxonomy* tx, int
                                         int seedextend, uint32_t min_seed_size, uint32_t max_gap_size, uint32_t* d_out_taxon,
                                         uint32_t* d_out_status, void* stream) {
     if (!ix || !tx || (n_reads && (!d_bytes || !d_frag_offsets || !d_out_taxon || !d_out_status))) return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: null argument");
+    if (ix->bound_to && ix->bound_to != tx) return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: the index is bound to another taxonomy");
     if (ix->kind != 9) return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: needs a 9-mer index");
     if (fragments_per_read == 0 || fragments_per_read > PROT_MAX_FRAGS) return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: fragments_per_read must be in 1..16");
     if (method != UMGAP_METHOD_TREE && method != UMGAP_METHOD_RMQ) return fail(UMGAP_ERR_INVALID, "unknown method");
@@ -495,8 +540,12 @@ extern "C" int umgap_classify_prot9_dev(umgap_index* ix, umgap_taxonomy* tx, int
     if (G * fragments_per_read > 64) G = 64 / fragments_per_read;
     size_t g = ((n_reads + G - 1) / G + 3) / 4;
     if (g > 256 * 8) g = 256 * 8;
-    hipLaunchKernelGGL(k_classify_prot9, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, d_bytes,
-                       d_frag_offsets, n_reads, fragments_per_read, seedextend ? 1u : 0u, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status);
+    if (ix->bound_to)
+        hipLaunchKernelGGL(k_classify_prot9<true>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, d_bytes,
+                           d_frag_offsets, n_reads, fragments_per_read, seedextend ? 1u : 0u, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status);
+    else
+        hipLaunchKernelGGL(k_classify_prot9<false>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, d_bytes,
+                           d_frag_offsets, n_reads, fragments_per_read, seedextend ? 1u : 0u, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status);
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
 }

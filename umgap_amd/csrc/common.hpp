@@ -118,4 +118,7 @@ struct umgap_index {
     void* h_stage[2] = {nullptr, nullptr};
     void* d_stage[2] = {nullptr, nullptr};
     size_t stage_cap = 0;  // keys per staging buffer
+    // non-null: the slot values are not taxon ids but codes bound to that taxonomy (bound.hpp); only the bound
+    // fused kernel understands them
+    const void* bound_to = nullptr;
 };

@@ -715,6 +715,7 @@ int umgap_index_device(const umgap_index* ix) { return ix ? ix->device : -1; }
 
 int umgap_index_save(const umgap_index* ix, const char* path) {
     if (!ix || !path) return fail(UMGAP_ERR_INVALID, "umgap_index_save: null argument");
+    if (ix->bound_to) return fail(UMGAP_ERR_INVALID, "the index is bound to a taxonomy (umgap_index_bind_taxonomy): its values are interval codes, not taxon ids; unbind it first");
     if (ix->kind == 2) {
         int rcv = use_device(ix->device);
         if (rcv) return rcv;
@@ -913,6 +914,7 @@ int umgap_index_partition9_dev(const umgap_index* ix, const uint64_t* d_keys, si
 
 int umgap_index_lookup9_dev(umgap_index* ix, const uint64_t* d_keys, size_t n, uint32_t miss, uint32_t* d_out, void* stream) {
     if (!ix || (n && (!d_keys || !d_out))) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup9_dev: null argument");
+    if (ix->bound_to) return fail(UMGAP_ERR_INVALID, "the index is bound to a taxonomy (umgap_index_bind_taxonomy): its values are interval codes, not taxon ids; unbind it first");
     if (ix->kind != 9) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup9_dev: not a 9-mer index");
     int rc = use_device(ix->device);
     if (rc) return rc;
@@ -924,6 +926,7 @@ int umgap_index_lookup9_dev(umgap_index* ix, const uint64_t* d_keys, size_t n, u
 // measurement-only entry: the lane-per-key variant
 int umgap_index_lookup9_lane_dev(umgap_index* ix, const uint64_t* d_keys, size_t n, uint32_t miss, uint32_t* d_out, void* stream) {
     if (!ix || (n && (!d_keys || !d_out))) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup9_lane_dev: null argument");
+    if (ix->bound_to) return fail(UMGAP_ERR_INVALID, "the index is bound to a taxonomy (umgap_index_bind_taxonomy): its values are interval codes, not taxon ids; unbind it first");
     int rc = use_device(ix->device);
     if (rc) return rc;
     if (n) hipLaunchKernelGGL(k_lookup9_lane, dim3(grid_for(n, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, d_keys, n, miss, d_out, ix->view);
@@ -934,6 +937,7 @@ int umgap_index_lookup9_lane_dev(umgap_index* ix, const uint64_t* d_keys, size_t
 int umgap_index_lookup_prot9_dev(umgap_index* ix, const uint8_t* d_bytes, const uint64_t* d_offsets, const uint64_t* d_out_offsets,
                                  size_t n_prot, uint32_t miss, uint32_t* d_out, void* stream) {
     if (!ix || (n_prot && (!d_bytes || !d_offsets || !d_out_offsets || !d_out))) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup_prot9_dev: null argument");
+    if (ix->bound_to) return fail(UMGAP_ERR_INVALID, "the index is bound to a taxonomy (umgap_index_bind_taxonomy): its values are interval codes, not taxon ids; unbind it first");
     int rc = use_device(ix->device);
     if (rc) return rc;
     if (!n_prot) return UMGAP_OK;
@@ -947,6 +951,7 @@ int umgap_index_lookup_prot9_dev(umgap_index* ix, const uint8_t* d_bytes, const 
 
 int umgap_index_lookup9(umgap_index* ix, const uint64_t* keys, size_t n, uint32_t miss, uint32_t* out) {
     if (!ix || (n && (!keys || !out))) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup9: null argument");
+    if (ix->bound_to) return fail(UMGAP_ERR_INVALID, "the index is bound to a taxonomy (umgap_index_bind_taxonomy): its values are interval codes, not taxon ids; unbind it first");
     if (ix->kind != 9) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup9: not a 9-mer index");
     int rc = use_device(ix->device);
     if (rc) return rc;
@@ -1005,6 +1010,7 @@ inline uint64_t unmix45(uint64_t h) {    // inverse of mix45 (common.hpp)
 
 int umgap_index_dump9(const umgap_index* ix, uint64_t* keys45, uint32_t* taxa, size_t cap, size_t* n_out) {
     if (!ix || ix->kind != 9 || !n_out) return fail(UMGAP_ERR_INVALID, "umgap_index_dump9: not a 9-mer index");
+    if (ix->bound_to) return fail(UMGAP_ERR_INVALID, "the index is bound to a taxonomy (umgap_index_bind_taxonomy): its values are interval codes, not taxon ids; unbind it first");
     if (ix->view.home_lo != 0 || ix->view.home_hi != ix->view.nb) return fail(UMGAP_ERR_INVALID, "umgap_index_dump9: handle holds a shard");
     int rc = use_device(ix->device);
     if (rc) return rc;

@@ -17,6 +17,7 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
                                       uint32_t max_gap_size, uint32_t* out_taxon, uint32_t* out_status) {
     if (!ix || !tx || (n_reads && (!read_frags || !out_taxon || !out_status)) || (n_fragments && !frag_offsets))
         return fail(UMGAP_ERR_INVALID, "umgap_classify_records: null argument");
+    if (ix->bound_to) return fail(UMGAP_ERR_INVALID, "the index is bound to a taxonomy (umgap_index_bind_taxonomy): its values are interval codes, not taxon ids; unbind it first");
     if (ix->kind != 9) return fail(UMGAP_ERR_INVALID, "umgap_classify_records: not a 9-mer index");
     if (ix->device != tx->device) return fail(UMGAP_ERR_INVALID, "umgap_classify_records: index and taxonomy live on different devices");
     if (!n_reads) return UMGAP_OK;
