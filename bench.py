@@ -304,8 +304,6 @@ def main():
         el = time.perf_counter() - t1
         out["with_seedextend"] = {"value": round(args.steps * B / el, 1), "unit": "pairs/s", "ms_per_step": round(1e3 * el / args.steps, 3),
                                   "pipeline": "probe -> seedextend -g1 -s3 (per read end) -> taxa2agg -l2 -a lca*, one fused kernel"}
-    if w.index is not None and w.index.bound:
-        w.index.unbind(w.taxonomy)          # the kernels below want taxon ids
     if world == 1 and fused and not args.seedextend:
         # the filter + aggregate stages of the two 9-mer sensitivity pipelines (scripts/umgap-analyse.sh:277-288) through the
         # fused kernel for the other strategies, on the same batches (the script feeds them 6-frame translations, ~500 k-mers
@@ -325,6 +323,8 @@ def main():
             el = time.perf_counter() - t1
             others[name] = {"value": round(n_o * B / el, 1), "unit": "pairs/s", "ms_per_step": round(1e3 * el / n_o, 3)}
         out["other_pipelines"] = others
+    if w.index is not None and w.index.bound:
+        w.index.unbind(w.taxonomy)          # what follows (sharded mode) wants taxon ids
     if rank == 0 and world == 1 and not args.no_gather:
         # measured random-sector gather ceilings over the same table (SURVEY.md §8d second denominator)
         n = 1 << 28

@@ -529,6 +529,14 @@ def test_fused_classify_other_strategies(api, torch_cuda, stride, n_pairs, metho
     nbad, bad, wt, ws = agg.taxa2agg_check(hits, offs, t, s, lower_bound=lb, nthreads=8)
     assert nbad == 0, (bad, t[bad.astype(int)], wt[bad.astype(int)])
     assert (s == 0).any()
+    # and on the table bound to the taxonomy (interval codes instead of ids): bit-identical
+    w.index.bind(w.taxonomy)
+    d_t3, d_s3 = torch.empty_like(d_t), torch.empty_like(d_s)
+    api.classify9_dev(w.index, w.taxonomy, d_keys, n_pairs, stride, d_t3, d_s3, method=method, strategy=strategy, factor=factor, lower_bound=lb,
+                      fragments_per_read=2 if with_seedextend else 0, min_seed_size=2, max_gap_size=1)
+    torch.cuda.synchronize()
+    w.index.unbind(w.taxonomy)
+    assert torch.equal(d_t, d_t3) and torch.equal(d_s, d_s3)
 
 
 def test_fused_classify_other_strategies_many_distinct_taxa(api, torch_cuda):

@@ -3,6 +3,7 @@
 // Algorithms and reference citations: aggregate_general.hip.
 #pragma once
 #include "agg_common.hpp"
+#include "bound.hpp"
 
 namespace umgap {
 namespace agg {
@@ -44,7 +45,9 @@ __device__ __forceinline__ uint32_t lane_lca(const TaxView& V, uint32_t u, uint3
 // One read through count -> filter -> resolve -> sort -> strategy, by one wave with its scratch S (hash table clean on
 // entry and on exit).  rp / sp may point to global memory or to LDS (the fused kernel).  Returns false when the read has
 // more than CAP distinct taxa (nothing written; S clean).
-template <bool SCORED, int CAP, int HCAP>
+// BOUND: the taxa are the interval codes of a table bound to the taxonomy (bound.hpp): {pre, last} come from the code
+// itself when the subtree is smaller than 32 nodes (exact size), from one 4-byte gather otherwise; nothing can be unknown.
+template <bool SCORED, int CAP, int HCAP, bool BOUND = false>
 __device__ __forceinline__ bool general_read(const TaxView& V, Scratch<CAP, HCAP>& S, int method, int strategy, float factor, float lower_bound,
                                              const uint32_t* rp, const float* sp, uint64_t n, uint32_t lane, uint32_t& res_taxon, uint32_t& res_status) {
     // rmq::rtl walks `ancestors` like the tree aggregators (src/rmq/rtl.rs:42-49)
@@ -116,7 +119,14 @@ __device__ __forceinline__ bool general_read(const TaxView& V, Scratch<CAP, HCAP
             uint32_t e = eb + lane;
             bool ok = e < nd && S.a_cnt[e] >= lower_bound;  // agg::filter
             Hit h{NONE, NONE};
-            if (ok) h = resolve(V, tree_like, S.a_tax[e], errkey);
+            if (ok) {
+                if (BOUND) {
+                    uint32_t lo, hi;
+                    bound::size_bounds(S.a_tax[e], lo, hi);
+                    h.pre = bound::pre_of(S.a_tax[e]);
+                    h.last = lo == hi ? h.pre + lo : V.last_of_pre[h.pre];
+                } else h = resolve(V, tree_like, S.a_tax[e], errkey);
+            }
             bool surv = ok && h.pre != NONE;
             uint64_t m = __ballot(surv);
             uint32_t idx = D + (uint32_t)__builtin_popcountll(m & lanemask_lt(lane));

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // high-sensitivity pipeline, scripts/umgap-analyse.sh:283-288) and rmq-hybrid: probe and seedextend as above, then every
 // read of the group goes through general_read (agg_general.hpp) with the LDS strip as its source.  A read with more
 // than CAP distinct taxa is deferred to a second launch over the `todo` list with a larger scratch (one read per group).
-template <int CAP, int HCAP>
+template <int CAP, int HCAP, bool BOUND>
 __global__ __launch_bounds__(256) void k_classify9_general(TableView T, TaxView V, int method, int strategy, float factor,
                                                            const uint64_t* __restrict__ keys, size_t n_reads, uint32_t stride, uint32_t frags,
                                                            uint32_t min_seed, uint32_t max_gap, float lower_bound,
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void k_classify9_general(TableView T, TaxView 
         }
         for (uint32_t k = 0; k < nr; k++) {
             uint32_t res_taxon, res_status;
-            const bool ok = general_read<false, CAP, HCAP>(V, S, method, strategy, factor, lower_bound, wtaxa + k * stride, nullptr, stride, lane,
+            const bool ok = general_read<false, CAP, HCAP, BOUND>(V, S, method, strategy, factor, lower_bound, wtaxa + k * stride, nullptr, stride, lane,
                                                            res_taxon, res_status);
             wave_lds_sync();
             if (lane == 0) {
@@ -480,7 +480,7 @@ extern "C" int umgap_classify9_strategy_dev(umgap_index* ix, umgap_taxonomy* tx,
         return umgap_classify9_dev(ix, tx, method, lower_bound, ranked_only, d_keys45, n_reads, kmers_per_read, fragments_per_read, min_seed_size,
                                    max_gap_size, d_out_taxon, d_out_status, stream);
     if (!ix || !tx || (n_reads && (!d_keys45 || !d_out_taxon || !d_out_status))) return fail(UMGAP_ERR_INVALID, "umgap_classify9_strategy_dev: null argument");
-    if (ix->bound_to) return fail(UMGAP_ERR_INVALID, "the index is bound to a taxonomy (umgap_index_bind_taxonomy): its values are interval codes, not taxon ids; unbind it first");
+    if (ix->bound_to && ix->bound_to != tx) return fail(UMGAP_ERR_INVALID, "umgap_classify9_strategy_dev: the index is bound to another taxonomy");
     if (ix->kind != 9) return fail(UMGAP_ERR_INVALID, "umgap_classify9_strategy_dev: needs a 9-mer index");
     if (kmers_per_read == 0 || kmers_per_read > 128) return fail(UMGAP_ERR_INVALID, "umgap_classify9_strategy_dev: kmers_per_read must be in 1..128 (use lookup9 + aggregate for longer reads)");
     if (fragments_per_read && (kmers_per_read % fragments_per_read) != 0) return fail(UMGAP_ERR_INVALID, "umgap_classify9_strategy_dev: kmers_per_read must be a multiple of fragments_per_read");
@@ -512,13 +512,16 @@ extern "C" int umgap_classify9_strategy_dev(umgap_index* ix, umgap_taxonomy* tx,
     size_t g = ((n_reads + G - 1) / G + 3) / 4;
     if (g > 256 * 8) g = 256 * 8;
     TaxView V = view_of(tx, ranked_only);
-    hipLaunchKernelGGL((k_classify9_general<64, 256>), dim3((unsigned)g), dim3(256), 0, s, ix->view, V, method, strategy, factor, d_keys45, n_reads, kmers_per_read,
-                       fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status, (const uint32_t*)nullptr,
-                       (const uint32_t*)nullptr, d_list, d_count);
-    // reads with more than 64 distinct taxa (at most 128: kmers_per_read <= 128)
-    hipLaunchKernelGGL((k_classify9_general<128, 512>), dim3(256), dim3(256), 0, s, ix->view, V, method, strategy, factor, d_keys45, n_reads, kmers_per_read,
-                       fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status, (const uint32_t*)d_list,
-                       (const uint32_t*)d_count, (uint32_t*)nullptr, (uint32_t*)nullptr);
+    // first pass, then the reads with more than 64 distinct taxa (at most 128: kmers_per_read <= 128)
+#define UMGAP_LAUNCH_GENERAL(BOUND)                                                                                                              \
+    hipLaunchKernelGGL((k_classify9_general<64, 256, BOUND>), dim3((unsigned)g), dim3(256), 0, s, ix->view, V, method, strategy, factor, d_keys45,      \
+                       n_reads, kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status,           \
+                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_list, d_count);                                                       \
+    hipLaunchKernelGGL((k_classify9_general<128, 512, BOUND>), dim3(256), dim3(256), 0, s, ix->view, V, method, strategy, factor, d_keys45, n_reads, \
+                       kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status,                    \
+                       (const uint32_t*)d_list, (const uint32_t*)d_count, (uint32_t*)nullptr, (uint32_t*)nullptr)
+    if (ix->bound_to) { UMGAP_LAUNCH_GENERAL(true); } else { UMGAP_LAUNCH_GENERAL(false); }
+#undef UMGAP_LAUNCH_GENERAL
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
 }
