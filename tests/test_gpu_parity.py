@@ -1081,3 +1081,11 @@ def test_full_size_50M_pairs_properties(api, torch_cuda):
         del keys, hits
     assert hist[0] > 0.9 * 5 * B and hist[2] == 0 and hist[3] == 0
     assert len(distinct) > 50_000      # the answers are spread over the taxonomy, not degenerate
+    # (4) the table bound to the 2.5 M-taxon taxonomy (how bench.py runs the kernel): bit-identical on a whole batch
+    keys = w.reads(4 * B, B)
+    api.classify9_dev(w.index, w.taxonomy, keys, B, KMERS_PER_PAIR, d_t, d_s, method="tree", lower_bound=1.0, fragments_per_read=2, min_seed_size=3, max_gap_size=1)
+    w.index.bind(w.taxonomy)
+    api.classify9_dev(w.index, w.taxonomy, keys, B, KMERS_PER_PAIR, d_t2, d_s2, method="tree", lower_bound=1.0, fragments_per_read=2, min_seed_size=3, max_gap_size=1)
+    torch.cuda.synchronize()
+    w.index.unbind(w.taxonomy)
+    assert torch.equal(d_t, d_t2) and torch.equal(d_s, d_s2)
