@@ -15,6 +15,10 @@
  *                                      record loop src/commands/taxa2agg.rs:161-180)
  *                                                                         -> umgap_aggregate[_dev]
  *   seedextend record state machine    src/commands/seedextend.rs:99-148  -> umgap_seedextend_dev
+ *   the four 9-mer stages of scripts/umgap-analyse.sh:257-310 in one call (hits never leave the device)
+ *                                                                         -> umgap_classify9[_strategy]_dev,
+ *                                                                            umgap_classify_prot9_dev,
+ *                                                                            umgap_classify_records (host records)
  *
  * Conventions
  *   - every function returns UMGAP_OK (0) or a negative UMGAP_ERR_* code; the message is in the
@@ -81,7 +85,8 @@ void umgap_unpack9(uint64_t key45, char* nine_bytes);
 
 /* ---- index: 9-mer -> taxon table resident in HBM --------------------------------------- */
 /* Builds a table on `device` from host arrays (keys distinct, any order).  load_factor in
- * (0,1): filled fraction of the 8-slot buckets (0 selects the default 0.5 = 16 B per key: 2.3 % of the buckets overflow, 6.6 % at 0.6). */
+ * (0,1): filled fraction of the 8-slot buckets (0 selects the default 0.5 = 16 B per key: 2.3 % of
+ * the buckets overflow; 6.6 % at 0.6). */
 int umgap_index_build9(const uint64_t* keys45, const uint32_t* taxa, size_t n, double load_factor,
                        int device, umgap_index** out);
 /* Same, key/value arrays already in device memory (on `device`). */
