@@ -609,6 +609,55 @@ def test_bound_table_classify_is_bit_identical(api, torch_cuda, stride, n_pairs,
     assert (outs[("tree", False, 0)][1] == 0).any()
 
 
+@pytest.mark.parametrize("shape", ["caterpillar", "broom", "random", "binary"])
+def test_bound_table_adversarial_tree_shapes(api, torch_cuda, shape):
+    """The 10-bit subtree-size code is exact below 32 and rounded above: trees whose subtree sizes sit around the
+    rounding boundaries (long chains with side leaves, brooms, complete binary trees) hit the 'exact last' path often.
+    Bound vs unbound vs oracle, reads = small random sets of taxa."""
+    torch = torch_cuda
+    rng = np.random.default_rng({"caterpillar": 1, "broom": 2, "random": 3, "binary": 4}[shape])
+    n = 6000
+    ids = np.arange(1, n + 1, dtype=np.uint32)
+    par = np.ones(n, np.uint32)
+    if shape == "caterpillar":      # a spine with a leaf hanging off every spine node
+        for i in range(1, n):
+            par[i] = (i - 1 if i % 2 == 0 else i) if i > 1 else 1
+            par[i] = max(1, (i // 2) * 2 - 1) if i % 2 == 0 else max(1, i - 2)
+    elif shape == "broom":          # a long handle, then a wide fan
+        for i in range(1, n):
+            par[i] = i if i < 3000 else 3000
+    elif shape == "binary":
+        for i in range(1, n):
+            par[i] = (i + 1) // 2
+    else:
+        for i in range(1, n):
+            par[i] = int(rng.integers(max(1, i - 50), i + 1))
+    par[0] = 1
+    tx = api.Taxonomy(ids, par)
+    keys = np.arange(1000, 1000 + n, dtype=np.uint64) * np.uint64(7919)
+    ix = api.Index.build(keys, ids)
+    n_reads, stride = 4000, 8
+    pick = rng.integers(0, n, (n_reads, stride))
+    pick[:, 4:] = pick[:, :4]                       # every taxon twice, so -l 2 keeps them
+    q = keys[pick.reshape(-1)]
+    d_keys = torch.from_numpy(q.view(np.int64)).cuda()
+    agg = O.Aggregator(O.Taxonomy.from_arrays(ids, par), "tree", "lca*")
+    offs = np.arange(n_reads + 1, dtype=np.uint64) * stride
+    hits = ids[pick.reshape(-1)]
+    res = {}
+    for bound in (False, True):
+        if bound:
+            ix.bind(tx)
+        d_t = torch.empty(n_reads, dtype=torch.int32, device="cuda"); d_s = torch.empty_like(d_t)
+        api.classify9_dev(ix, tx, d_keys, n_reads, stride, d_t, d_s, method="tree", lower_bound=2.0)
+        torch.cuda.synchronize()
+        res[bound] = (d_t.cpu().numpy().view(np.uint32), d_s.cpu().numpy().view(np.uint32))
+    ix.unbind(tx)
+    assert (res[False][0] == res[True][0]).all() and (res[False][1] == res[True][1]).all()
+    nbad, bad, _, _ = agg.taxa2agg_check(hits, offs, res[True][0], res[True][1], lower_bound=2.0, nthreads=8)
+    assert nbad == 0, bad
+
+
 def test_bind_refuses_values_outside_the_taxonomy(api, torch_cuda):
     """A table value that is not a reachable taxon has no interval: binding is refused and the table is left untouched."""
     from umgap_amd import UmgapError
