@@ -31,15 +31,33 @@ __device__ __forceinline__ float wave_maxf(float v) {
     return v;
 }
 
-// LCA of two list members by preorder index, u < v, u not an ancestor of v: binary lifting from v
-// to the highest ancestor that still starts after u; its parent is the LCA.
-__device__ __forceinline__ uint32_t lane_lca(const TaxView& V, uint32_t u, uint32_t v) {
-    uint32_t y = v;
-    for (int k = (int)V.up_levels - 1; k >= 0; k--) {
-        uint32_t c = V.up[(size_t)k * V.n_reach + y];
-        if (c > u) y = c;
+// Packed (depth << 32 | position) of a shallowest node with preorder index in [lo, hi], lo <= hi, for ONE lane: the two
+// 8-blocks at the ends are read whole (two aligned 16-byte loads each) and scanned in registers, the blocks in between
+// come from the 8-block sparse table; every load is independent of the others (one round trip).  The first version walked
+// a binary-lifting table: seven dependent gathers per LCA, as many random requests per read as the probes themselves.
+typedef uint32_t agg_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint64_t lane_argmin_depth(const TaxView& V, uint32_t lo, uint32_t hi) {
+    const uint32_t bl = lo >> 3, bh = hi >> 3;
+    const agg_u32x4* d4 = reinterpret_cast<const agg_u32x4*>(V.depth);
+    const agg_u32x4 a0 = d4[2 * (size_t)bl], a1 = d4[2 * (size_t)bl + 1];
+    agg_u32x4 b0 = a0, b1 = a1;
+    if (bh != bl) { b0 = d4[2 * (size_t)bh]; b1 = d4[2 * (size_t)bh + 1]; }
+    uint64_t e0 = ~0ull, e1 = ~0ull;
+    if (bh > bl + 1) {
+        const uint32_t len = bh - bl - 1, k = 31u - (uint32_t)__builtin_clz(len);
+        e0 = V.sparse8[(size_t)k * V.n_blocks8 + bl + 1];
+        e1 = V.sparse8[(size_t)k * V.n_blocks8 + bh - (1u << k)];
     }
-    return V.parent_pre[y];
+    uint64_t best = e0 < e1 ? e0 : e1;
+    const uint32_t da[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, db[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (uint32_t i = 0; i < 8; i++) {
+        const uint32_t pa = bl * 8 + i, pb = bh * 8 + i;
+        const uint64_t ca = ((uint64_t)da[i] << 32) | pa, cb = ((uint64_t)db[i] << 32) | pb;
+        if (pa >= lo && pa <= hi && ca < best) best = ca;
+        if (pb >= lo && pb <= hi && cb < best) best = cb;
+    }
+    return best;
 }
 
 // One read through count -> filter -> resolve -> sort -> strategy, by one wave with its scratch S (hash table clean on
@@ -176,12 +194,16 @@ __device__ __forceinline__ bool general_read(const TaxView& V, Scratch<CAP, HCAP
                 // adjacent LCAs (both hybrids)
                 for (uint32_t kb = 0; kb < D; kb += 64) {
                     uint32_t k = kb + lane;
-                    if (k < D) S.b_dep[k] = V.depth[S.b_pre[k]];
+                    uint32_t du = 0;
+                    if (k < D) { du = V.depth[S.b_pre[k]]; S.b_dep[k] = du; }
                     if (k + 1 < D) {
-                        uint32_t u = S.b_pre[k], v = S.b_pre[k + 1];
-                        uint32_t l = S.b_last[k] >= v ? u : lane_lca(V, u, v);
-                        S.b_lca[k] = l;
-                        S.b_adj[k] = V.depth[l];
+                        const uint32_t u = S.b_pre[k], v = S.b_pre[k + 1];
+                        if (S.b_last[k] >= v) { S.b_lca[k] = u; S.b_adj[k] = du; }      // u is an ancestor of v
+                        else {   // LCA = parent of a shallowest node in (pre[u], pre[v]]; its depth is that node's minus one
+                            const uint64_t m = lane_argmin_depth(V, u + 1, v);
+                            S.b_lca[k] = V.parent_pre[(uint32_t)m];
+                            S.b_adj[k] = (uint32_t)(m >> 32) - 1u;
+                        }
                     }
                 }
                 wave_sync();

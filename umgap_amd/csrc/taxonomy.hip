@@ -174,17 +174,25 @@ int umgap_taxonomy_create(const uint32_t* id, const uint32_t* parent, const uint
             sparse[(size_t)k * n_blocks + b] = std::min(sparse[(size_t)(k - 1) * n_blocks + b], sparse[(size_t)(k - 1) * n_blocks + b + (1u << (k - 1))]);
     tx->n_blocks = n_blocks;
     tx->n_levels = n_levels;
-    // subtree ends by pre and the binary-lifting table (2^k-th ancestor, root maps to itself)
+    // subtree ends by pre, and a second sparse table over blocks of 8 for the per-lane LCA of the hybrid aggregators
+    // (agg_general.hpp: two aligned 32-byte depth blocks + two table entries, all independent loads)
     std::vector<uint32_t> last_of_pre(counter);
-    uint32_t max_depth = 0;
-    for (uint32_t p = 0; p < counter; p++) { last_of_pre[p] = tx->h_last[id_of_pre[p]]; max_depth = std::max(max_depth, depth_of_pre[p]); }
-    uint32_t up_levels = 1;
-    while ((1u << up_levels) <= max_depth) up_levels++;
-    std::vector<uint32_t> up((size_t)up_levels * counter);
-    for (uint32_t p = 0; p < counter; p++) up[p] = parent_pre[p];
-    for (uint32_t k = 1; k < up_levels; k++)
-        for (uint32_t p = 0; p < counter; p++) up[(size_t)k * counter + p] = up[(size_t)(k - 1) * counter + up[(size_t)(k - 1) * counter + p]];
-    tx->up_levels = up_levels;
+    for (uint32_t p = 0; p < counter; p++) last_of_pre[p] = tx->h_last[id_of_pre[p]];
+    const uint32_t n_blocks8 = (counter + 7) / 8;
+    uint32_t n_levels8 = 1;
+    while ((1u << n_levels8) <= n_blocks8) n_levels8++;
+    std::vector<uint64_t> sparse8((size_t)n_levels8 * n_blocks8, ~0ull);
+    for (uint32_t b8 = 0; b8 < n_blocks8; b8++) {
+        uint64_t best = ~0ull;
+        for (uint32_t p = b8 * 8; p < counter && p < b8 * 8 + 8; p++) best = std::min(best, ((uint64_t)depth_of_pre[p] << 32) | p);
+        sparse8[b8] = best;
+    }
+    for (uint32_t k = 1; k < n_levels8; k++)
+        for (uint32_t b8 = 0; b8 + (1u << k) <= n_blocks8; b8++)
+            sparse8[(size_t)k * n_blocks8 + b8] = std::min(sparse8[(size_t)(k - 1) * n_blocks8 + b8], sparse8[(size_t)(k - 1) * n_blocks8 + b8 + (1u << (k - 1))]);
+    tx->n_blocks8 = n_blocks8;
+    tx->n_levels8 = n_levels8;
+    depth_of_pre.resize((size_t)n_blocks8 * 8, NONE);   // whole 8-blocks on the device (the per-lane scan loads them as 2 x 16 B)
 
     int rc = use_device(device);
     if (rc) { delete tx; return rc; }
@@ -205,7 +213,7 @@ int umgap_taxonomy_create(const uint32_t* id, const uint32_t* parent, const uint
     if (!rc) rc = upload(&tx->d_psnap_of_pre[1], psnap_pre[1]);
     if (!rc) rc = upload(&tx->d_sparse, sparse);
     if (!rc) rc = upload(&tx->d_last_of_pre, last_of_pre);
-    if (!rc) rc = upload(&tx->d_up, up);
+    if (!rc) rc = upload(&tx->d_sparse8, sparse8);
     if (rc) { umgap_taxonomy_free(tx); return rc; }
     *out = tx;
     return UMGAP_OK;
@@ -216,7 +224,7 @@ void umgap_taxonomy_free(umgap_taxonomy* tx) {
     (void)hipSetDevice(tx->device);
     void* ptrs[] = {tx->d_by_id, tx->d_err_kind, tx->d_err_payload, tx->d_err_dist, tx->d_parent_pre, tx->d_depth,
                     tx->d_id_of_pre, tx->d_snap_of_pre[0], tx->d_snap_of_pre[1], tx->d_psnap_of_pre[0], tx->d_psnap_of_pre[1],
-                    tx->d_sparse, tx->d_last_of_pre, tx->d_up, tx->d_stage, tx->d_defer};
+                    tx->d_sparse, tx->d_last_of_pre, tx->d_sparse8, tx->d_stage, tx->d_defer};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (tx->stream) (void)hipStreamDestroy(tx->stream);

@@ -44,8 +44,8 @@ struct umgap_taxonomy {
     uint64_t* d_sparse = nullptr;                     // [levels][n_blocks] packed (depth << 32 | pos) block-range minima
     uint32_t n_blocks = 0, n_levels = 0;
     uint32_t* d_last_of_pre = nullptr;                // subtree end by pre
-    uint32_t* d_up = nullptr;                         // [up_levels][n_reach]: 2^k-th ancestor by pre (binary lifting, per-lane LCA)
-    uint32_t up_levels = 0;
+    uint64_t* d_sparse8 = nullptr;                    // [levels8][n_blocks8] packed (depth << 32 | pos) minima over 8-blocks: per-lane O(1) LCA
+    uint32_t n_blocks8 = 0, n_levels8 = 0;
     hipStream_t stream = nullptr;
     // staging for the host-pointer umgap_aggregate
     void* d_stage = nullptr;
@@ -68,12 +68,12 @@ struct TaxView {
     const uint32_t* psnap_of_pre;  // chosen by ranked_only
     const uint64_t* sparse;
     const uint32_t* last_of_pre;
-    const uint32_t* up;
-    uint32_t len, n_reach, n_blocks, up_levels;
+    const uint64_t* sparse8;
+    uint32_t len, n_reach, n_blocks, n_blocks8;
 };
 inline TaxView view_of(const umgap_taxonomy* tx, int ranked_only) {
     return TaxView{tx->d_by_id, tx->d_err_kind, tx->d_err_payload, tx->d_err_dist, tx->d_parent_pre, tx->d_depth, tx->d_id_of_pre,
                    tx->d_snap_of_pre[ranked_only ? 1 : 0], tx->d_psnap_of_pre[ranked_only ? 1 : 0], tx->d_sparse,
-                   tx->d_last_of_pre, tx->d_up, tx->len, tx->n_reach, tx->n_blocks, tx->up_levels};
+                   tx->d_last_of_pre, tx->d_sparse8, tx->len, tx->n_reach, tx->n_blocks, tx->n_blocks8};
 }
 }  // namespace umgap
