@@ -204,7 +204,10 @@ int umgap_aggregate_strided_dev(umgap_taxonomy* tx, int method, int strategy, fl
 /* In place per record r = taxa[offsets[r]..offsets[r+1]): taxa outside every extended seed
  * are overwritten with 0 (a dropped taxon and a 0 are equivalent for taxa2agg, which discards
  * zeros, src/commands/taxa2agg.rs:169).  kept[r] (nullable) receives the number of taxa the
- * reference's seedextend would print for the record. */
+ * reference's seedextend would print for the record, or UMGAP_NONE where the reference panics
+ * (exit 101): a seed sliced with start > end (src/commands/seedextend.rs:169-173), which needs
+ * min_seed_size < 2 and a leading run of misses; such a record is zeroed entirely.  The fused
+ * kernels below report the same case as UMGAP_READ_PANIC for the read. */
 int umgap_seedextend_dev(const uint64_t* d_offsets, size_t n_records, uint32_t min_seed_size,
                          uint32_t max_gap_size, uint32_t* d_taxa, uint32_t* d_kept, int device,
                          void* stream);
@@ -263,11 +266,19 @@ int umgap_classify_prot9_dev(umgap_index* ix, umgap_taxonomy* tx, int method, fl
  * looked up (miss = 0 as with -o), seedextend (unranked, src/commands/seedextend.rs:99-148) runs per
  * fragment when `seedextend` != 0, and the read's surviving hits are aggregated exactly as
  * umgap_aggregate does (any method / strategy; out_status as there).  Reads of any length. */
+/* out_status additionally takes UMGAP_READ_PANIC for a read holding a fragment on which the reference's seedextend would
+ * panic (a seed sliced with start > end, src/commands/seedextend.rs:169-173; only with min_seed_size < 2).  The block is
+ * processed in chunks of whole reads, chunk c+1 uploading while chunk c computes; pass arrays from umgap_host_alloc for
+ * full-rate asynchronous copies (pageable memory works, the copies then block). */
 int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int method, int strategy, float factor,
                            float lower_bound, int ranked_only, const uint8_t* bytes,
                            const uint64_t* frag_offsets, size_t n_fragments, const uint64_t* read_frags,
                            size_t n_reads, int seedextend, uint32_t min_seed_size, uint32_t max_gap_size,
                            uint32_t* out_taxon, uint32_t* out_status);
+
+/* Page-locked host memory for the arrays passed to the host-pointer entry points (any size; free with umgap_host_free). */
+int umgap_host_alloc(size_t bytes, void** out);
+void umgap_host_free(void* p);
 
 /* ---- measurement helpers (bench.py; not part of the reference surface) ------------------- */
 /* Lane-per-key probe variant of umgap_index_lookup9_dev, kept for the A/B in DESIGN.md. */

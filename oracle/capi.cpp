@@ -235,14 +235,19 @@ size_t orc_taxa2agg_check(void* h, int ranked, float lower_bound, const uint32_t
 }
 
 // ---- seedextend on arrays (src/commands/seedextend.rs:99-148), for device parity ----------
-// in: taxa of one record (without the appended sentinel); out: kept taxa; returns count
+// in: taxa of one record (without the appended sentinel); out: kept taxa; returns count, or (size_t)-1 where the
+// reference panics (a seed sliced with start > end, src/commands/seedextend.rs:169-173)
 size_t orc_seedextend_record(const uint32_t* taxa, size_t n, size_t min_seed_size, size_t max_gap_size,
                              uint32_t* out) {
     std::ostringstream in_s, out_s;
     in_s << ">r\n";
     for (size_t i = 0; i < n; i++) in_s << taxa[i] << "\n";
     std::istringstream is(in_s.str());
-    seedextend(is, out_s, min_seed_size, max_gap_size, nullptr, 5);
+    try {
+        seedextend(is, out_s, min_seed_size, max_gap_size, nullptr, 5);
+    } catch (const Panic&) {
+        return (size_t)-1;
+    }
     std::istringstream os(out_s.str());
     std::string line;
     size_t k = 0;

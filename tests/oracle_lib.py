@@ -286,10 +286,13 @@ class RMQ:
 
 
 def seedextend_record(taxa, min_seed_size=2, max_gap_size=0):
+    """Kept taxa of one record, or None where the reference panics (src/commands/seedextend.rs:169-173)."""
     taxa = np.ascontiguousarray(taxa, dtype=np.uint32)
     out = np.zeros(len(taxa) + 1, np.uint32)
     n = lib().orc_seedextend_record(_p(taxa, C.c_uint32), C.c_size_t(len(taxa)), C.c_size_t(min_seed_size),
                                     C.c_size_t(max_gap_size), _p(out, C.c_uint32))
+    if n == C.c_size_t(-1).value:
+        return None
     return out[:n]
 
 

@@ -165,6 +165,84 @@ def test_taxa2agg_error_paths(world):
     assert rc == 1 and b"Failed opening taxon file." in err
 
 
+# Display strings of the reference's taxon ErrorKind values (src/taxon.rs:394-406): Msg carries the bail! text of
+# src/taxon.rs:93 / :110; InvalidID is a foreign link to std::num::ParseIntError and UnknownRank to strum::ParseError, whose
+# Display texts are those of Rust's std and of strum 0.x.  quick_main! (src/main.rs:8) prints "Error: <display>", exit 1.
+TAXON_ERROR_TEXT = {
+    "hello world": b"Taxon requires five fields",
+    "a\troot\tno_rank\t1\t\x00": b"invalid digit found in string",
+    "1\troot\tno_rank\t1\t\x00": b"Matching variant not found",
+    "1\troot\tno rank\t#\t\x00": b"invalid digit found in string",
+    "1\troot\tno rank\t\t\x00": b"cannot parse integer from empty string",
+    "1\troot\tno rank\t7\thello": b"Couldn't parse the valid byte",
+}
+TAXON_ERROR_KIND = {b"Taxon requires five fields": "Msg", b"Couldn't parse the valid byte": "Msg", b"invalid digit found in string": "InvalidID",
+                    b"cannot parse integer from empty string": "InvalidID", b"Matching variant not found": "UnknownRank"}
+
+
+@pytest.fixture(scope="module")
+def proteome_small(fixture_tsv, tmp_path_factory):
+    """(index with the single 9-mer ACDEFGHIK -> taxon 2, the reference's fixture taxonomy, the 9-mer, a residue that makes misses)."""
+    d = tmp_path_factory.mktemp("small")
+    idx = str(d / "one.umgapix")
+    p = subprocess.run([UMGAP, "buildindex"], input=b"ACDEFGHIK\t2\n", stdout=open(idx, "wb"), stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr
+    return idx, fixture_tsv, "ACDEFGHIK", "W"
+
+
+def test_taxon_parsing_vectors_through_the_command(golden, tmp_path):
+    """The reference's own taxon-parsing vectors (src/taxon.rs:417-429) fed to the PRODUCT's TSV parser: each line is the
+    whole taxons.tsv of a `umgap taxa2agg` run (src/commands/taxa2agg.rs:104 reads it with read_taxa_file, src/taxon.rs:118-128)."""
+    g = golden["taxon_parsing"]
+    assert len(g["err"]) == 6 and len(g["ok"]) == 4
+    for i, (line, kind) in enumerate(g["err"]):
+        tsv = tmp_path / ("err%d.tsv" % i)
+        tsv.write_bytes(line.encode("latin1") + b"\n")
+        want = TAXON_ERROR_TEXT[line]
+        assert TAXON_ERROR_KIND[want] == kind            # the message belongs to the ErrorKind the reference's test names
+        rc, out, err = run(["taxa2agg", str(tsv)], b">r\n1\n")
+        assert rc == 1 and out == b"" and err == b"Error: " + want + b"\n", (line, rc, err)
+        orc, oout, oerr = O.run_cli(["taxa2agg", str(tsv)], b">r\n1\n")
+        assert (orc, oout, oerr) == (rc, out, err)
+    for i, (line, (tid, name, rank, parent, valid)) in enumerate(g["ok"] + [[g["doctest"]["line"], g["doctest"]["want"]]]):
+        tsv = tmp_path / ("ok%d.tsv" % i)
+        tsv.write_bytes(line.encode("latin1") + b"\n")
+        for flags in ([], ["-r"]):
+            rc, out, err = run(["taxa2agg"] + flags + [str(tsv)], b">r\n%d\n" % tid)
+            if parent == tid:
+                # a one-taxon tree: the line parsed, it is its own root (src/taxon.rs:224-247) and the root snaps to itself
+                # whatever its valid / rank fields say (filter_ancestors is seeded with Some(root), :279)
+                assert rc == 0 and out == b">r\n%d\n" % tid, (line, flags, rc, out, err)
+            else:
+                # parent != id: parsed, but no taxon is its own parent => `expect("There's no root!")` panics (:243), exit 101
+                assert rc == 101 and out == b"" and b"There's no root!" in err, (line, flags, rc, err)
+            assert O.run_cli(["taxa2agg"] + flags + [str(tsv)], b">r\n%d\n" % tid)[:2] == (rc, out)
+
+
+def test_seedextend_slice_panic_exit_101(world, proteome_small):
+    """src/commands/seedextend.rs:130-134 + :143-148, sliced at :169-173: with -g1 -s1 the record [0, 5] leaves the scanner
+    with start = 2 and end = 1 => `taxons[2..1]` panics, exit 101, nothing of the record is printed (derived by hand from the
+    reference source; the oracle agrees).  Both the text filter and the fused command reproduce it."""
+    rc, out, err = run(["seedextend", "-g1", "-s1"], b">a\n7\n7\n>b\n0\n5\n>c\n7\n")
+    assert rc == 101 and out == b">a\n7\n7\n", (rc, out, err)
+    assert O.run_cli(["seedextend", "-g1", "-s1"], b">a\n7\n7\n>b\n0\n5\n>c\n7\n")[:2] == (101, b">a\n7\n7\n")
+    # without the leading miss nothing panics
+    rc, out, _ = run(["seedextend", "-g1", "-s1"], b">b\n5\n0\n")
+    assert rc == 0 and out == b">b\n5\n"
+    # fused command: a fragment whose first window misses and whose second window hits gives seedextend the record [0, x]
+    idx, tsv, hit, miss = proteome_small
+    frag = miss[0] + hit                      # 10 residues: window 0 = miss[0] + hit[:8] (absent), window 1 = hit
+    fasta = (">ok/1\n%s\n>bad/1\n%s\n>after/1\n%s\n" % (hit, frag, hit)).encode()
+    stages = [["prot2kmer2lca", "-o", idx], ["seedextend", "-g1", "-s1"], ["uniq", "-d", "/"], ["taxa2agg", "-l1", "-a", "lca*", tsv]]
+    data, rcs = fasta, []
+    for st in stages:
+        rc, data, _ = run(st, data)
+        rcs.append(rc)
+    assert rcs == [0, 101, 0, 0]              # the reference's pipe: seedextend dies, its readers see EOF after record `ok`
+    rc, out, err = run(["prot2kmer2agg", "-g1", "-s1", "-d", "/", "-l1", "-a", "lca*", idx, tsv], fasta)
+    assert rc == 101 and out == data, (rc, out, data, err)
+
+
 def test_text_filters_match_oracle(world, golden):
     g = golden["text_examples"]
     rc, out, _ = run(["uniq"] + g["uniq"]["args"], g["uniq"]["stdin"].encode())
@@ -393,7 +471,7 @@ def test_config1_testdata_plumbing(tryptic, world, golden):
     (scripts/umgap-analyse.sh:295-298; 6-frame translation stands in for FGSpp, which is not available): plumbing only --
     headers survive, the two ends are joined by `uniq -d /`, one taxon per read pair, identical to the oracle."""
     import json as _json
-    with open(os.path.join(ROOT, "tests", "golden", "testdata_A_first25.json")) as f:
+    with open(os.path.join(ROOT, "tests", "golden", "testdata_A.json")) as f:
         td = _json.load(f)
     recs = []
     for a, b in zip(td["A1"], td["A2"]):
@@ -415,7 +493,8 @@ def test_config1_testdata_plumbing(tryptic, world, golden):
     assert mine == ref
     lines = mine.decode().split("\n")
     headers = [l[1:] for l in lines if l.startswith(">")]
-    assert headers == [a["header"][:-2] for a in td["A1"]]        # 25 pairs -> 25 records, header cut at '/'
+    assert len(td["A1"]) == 100
+    assert headers == [a["header"][:-2] for a in td["A1"]]        # 100 pairs -> 100 records, header cut at '/'
     assert all(l.isdigit() for l in lines if l and not l.startswith(">"))
 
 

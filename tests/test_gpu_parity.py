@@ -416,6 +416,39 @@ def test_seedextend_vs_oracle(api, torch_cuda):
             assert mine[mine != 0].tolist() == want[want != 0].tolist(), (i, r.tolist(), want, mine)
 
 
+def test_seedextend_panic_cases_vs_oracle(api, torch_cuda):
+    """--min-seed-size 0/1: a leading run of misses makes the reference slice a seed with start > end
+    (src/commands/seedextend.rs:130-134 then :143-148 / :118, sliced at :169-173) and panic; the device kernel reports
+    exactly those records with kept == NONE and prints nothing of them."""
+    torch = torch_cuda
+    rng = np.random.default_rng(18)
+    recs = [np.array([0, 5], np.uint32), np.array([0, 0, 7], np.uint32), np.array([0], np.uint32), np.array([], np.uint32)]
+    for _ in range(3000):
+        n = int(rng.integers(0, 12))
+        recs.append(rng.choice(np.array([0, 0, 0, 5, 5, 7], np.uint32), n))
+    taxa, offs = _csr([r.tolist() for r in recs])
+    n_panics = 0
+    for (s, g) in ((1, 1), (0, 1), (1, 0), (1, 2), (0, 0), (2, 1)):
+        d_taxa = torch.from_numpy(taxa.view(np.int32).copy()).cuda()
+        d_offs = torch.from_numpy(offs.view(np.int64)).cuda()
+        d_kept = torch.zeros(len(recs), dtype=torch.int32, device="cuda")
+        api.seedextend_dev(d_taxa, d_offsets=d_offs, min_seed_size=s, max_gap_size=g, d_kept=d_kept)
+        torch.cuda.synchronize()
+        got = d_taxa.cpu().numpy().view(np.uint32)
+        kept = d_kept.cpu().numpy().view(np.uint32)
+        for i, r in enumerate(recs):
+            want = O.seedextend_record(r, s, g)
+            mine = got[int(offs[i]):int(offs[i + 1])]
+            if want is None:
+                n_panics += 1
+                assert kept[i] == 0xFFFFFFFF and not mine.any(), (s, g, r.tolist(), kept[i], mine)
+            else:
+                assert kept[i] == len(want), (s, g, r.tolist(), want, mine)
+                assert mine[mine != 0].tolist() == want[want != 0].tolist(), (s, g, r.tolist(), want, mine)
+    assert n_panics > 50     # the case is exercised; [0, 5] with -g1 -s1 is the hand-derived one
+    assert O.seedextend_record(np.array([0, 5], np.uint32), 1, 1) is None
+
+
 # ---------------------------------------------------------------------------------------------
 # the synthetic 9-mer high-precision pipeline: lookup -> (seedextend) -> LCA* with -l 2
 # ---------------------------------------------------------------------------------------------
@@ -497,6 +530,41 @@ def test_fused_classify_vs_oracle(api, torch_cuda, stride, n_pairs, with_seedext
     w.taxonomy.aggregate_strided_dev(d_hits, stride, n_pairs, d_t2, d_s2, method="tree", strategy="lca*", lower_bound=2.0)
     torch.cuda.synchronize()
     assert torch.equal(d_t, d_t2) and torch.equal(d_s, d_s2)
+
+
+@pytest.mark.parametrize("method,strategy", [("tree", "lca*"), ("tree", "hybrid"), ("rmq", "mrtl")])
+def test_fused_classify_seedextend_panic_status(api, torch_cuda, method, strategy):
+    """--min-seed-size 1: where the reference's seedextend would panic on a fragment (src/commands/seedextend.rs:169-173,
+    exit 101) the fused kernels report UMGAP_READ_PANIC for the read; every other read is aggregated as usual."""
+    torch = torch_cuda
+    from umgap_amd.synth import ADD_B, MUL_A, SyntheticWorkload
+    n_tax, n_keys, stride, n_pairs = 20_000, 1_000_000, 12, 6_000
+    w = SyntheticWorkload(n_tax=n_tax, n_keys=n_keys)
+    d_keys = w.reads(0, n_pairs, kmers_per_pair=stride)
+    d_t = torch.empty(n_pairs, dtype=torch.int32, device="cuda")
+    d_s = torch.empty(n_pairs, dtype=torch.int32, device="cuda")
+    api.classify9_dev(w.index, w.taxonomy, d_keys, n_pairs, stride, d_t, d_s, method=method, strategy=strategy, factor=0.25, lower_bound=1.0,
+                      fragments_per_read=2, min_seed_size=1, max_gap_size=1)
+    torch.cuda.synchronize()
+    keys = d_keys.cpu().numpy().view(np.uint64)
+    hits = O.synth_lookup9(O.SynthIndexParams(n_keys, n_tax, MUL_A, ADD_B), w.taxon_of_row, keys, 0)
+    half = stride // 2
+    t, s = d_t.cpu().numpy().view(np.uint32), d_s.cpu().numpy().view(np.uint32)
+    panics, ok_reads, ok_rows = 0, [], []
+    for r in range(n_pairs):
+        frs = [O.seedextend_record(hits[(2 * r + f) * half:(2 * r + f + 1) * half], 1, 1) for f in (0, 1)]
+        if any(f is None for f in frs):
+            panics += 1
+            assert s[r] == 3 and t[r] == 0, (r, s[r], t[r])
+        else:
+            ok_reads.append(r)
+            ok_rows.append(np.concatenate(frs).tolist())
+    assert panics > 20 and len(ok_reads) > 1000, (panics, len(ok_reads))
+    taxa, offs = _csr(ok_rows)
+    agg = O.Aggregator(O.Taxonomy.from_arrays(w.ids, w.parents, w.valid, w.rank), method, strategy, 0.25)
+    idx = np.array(ok_reads)
+    nbad, bad, _, _ = agg.taxa2agg_check(taxa, offs, t[idx].copy(), s[idx].copy(), lower_bound=1.0, nthreads=8)
+    assert nbad == 0, bad
 
 
 @pytest.mark.parametrize("with_seedextend", [False, True])
@@ -785,6 +853,22 @@ def test_pept2lca_doc_example_tryptic(api):
     ix = api.Index.build_var([b"AAALTER", b"ENFVYLAK"], np.array([2, 3398], np.uint32))
     assert ix.lookup_var([b"AAALTER", b"ENFVYLAK"]).tolist() == [2, 3398]
     assert ix.lookup_var([b"NOTATRYPTICPEPTIDE", b"ENFVYLAK"], miss_value=0).tolist() == [0, 3398]
+
+
+def test_fused_kernels_refuse_a_var_index(api, torch_cuda):
+    """A variable-length (kind 2) handle carries no 9-mer table: every fused 9-mer entry point must answer
+    UMGAP_ERR_INVALID instead of probing whatever its view holds."""
+    torch = torch_cuda
+    from umgap_amd.synth import SyntheticWorkload
+    w = SyntheticWorkload(n_tax=2_000, n_keys=10_000)
+    ix = api.Index.build_var([b"AAALTER", b"ENFVYLAK"], np.array([2, 3398], np.uint32))
+    d_keys = torch.zeros(84 * 4, dtype=torch.int64, device="cuda")
+    d_t = torch.empty(4, dtype=torch.int32, device="cuda")
+    d_s = torch.empty(4, dtype=torch.int32, device="cuda")
+    for strategy, method in (("lca*", "tree"), ("hybrid", "tree"), ("mrtl", "rmq")):
+        with pytest.raises(api.UmgapError) as e:
+            api.classify9_dev(ix, w.taxonomy, d_keys, 4, 84, d_t, d_s, method=method, strategy=strategy)
+        assert e.value.code == -1 and "9-mer index" in e.value.message
 
 
 # ---------------------------------------------------------------------------------------------

@@ -1,6 +1,9 @@
 """Pins the CPU oracle against every golden vector the reference's unit tests hold for the
 pept2lca -> taxa2agg path.  CPU only."""
 import itertools
+import os
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -18,12 +21,25 @@ def large(large_tsv):
     return O.Taxonomy.from_tsv(large_tsv)
 
 
+# the committed vectors are what the reference's sources hold (checked wherever the reference tree is present:
+# the build container; the GPU box has only the JSON)
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="the reference tree is not on this machine")
+def test_golden_vectors_are_the_references():
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_reference_vectors.py")
+    r = subprocess.run([sys.executable, script, "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr + r.stdout
+
+
+# the reference's taxon ErrorKind names (src/taxon.rs:394-406) -> the oracle's flat error kinds
+TAXON_ERRKIND = {"Msg": "Msg", "InvalidID": "ParseInt", "UnknownRank": "UnknownRank"}
+
+
 # --- src/taxon.rs:417-429 + doctest :77-88 ---------------------------------------------------
 def test_taxon_parsing(golden):
     for line, want in golden["taxon_parsing"]["ok"]:
         assert list(O.parse_taxon(line.encode("latin1"))) == want
     for line, kind in golden["taxon_parsing"]["err"]:
-        assert O.parse_taxon(line.encode("latin1")) == kind
+        assert O.parse_taxon(line.encode("latin1")) == TAXON_ERRKIND[kind]
     d = golden["taxon_parsing"]["doctest"]
     assert list(O.parse_taxon(d["line"].encode("latin1"))) == d["want"]
 

@@ -106,6 +106,8 @@ def load():
         "umgap_index_unbind_taxonomy": (i32, [vp, vp]),
         "umgap_index_is_bound": (i32, [vp]),
         "umgap_classify_records": (i32, [vp, vp, i32, i32, f32, f32, i32, vp, vp, sz, vp, sz, i32, u32, u32, vp, vp]),
+        "umgap_host_alloc": (i32, [sz, pp]),
+        "umgap_host_free": (None, [vp]),
         "umgap_index_build_windows9_dev": (i32, [vp, vp, vp, sz, u32, u64, dbl, i32, pp]),
         "umgap_synth_prot_reads_dev": (i32, [vp, u64, u32, u64, u64, sz, u32, u32, vp, i32, vp]),
         "umgap_seedextend_dev": (i32, [vp, sz, u32, u32, vp, vp, i32, vp]),

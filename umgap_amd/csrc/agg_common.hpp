@@ -98,9 +98,16 @@ __device__ __forceinline__ Hit resolve(const TaxView& V, bool tree_like, uint32_
 }
 
 
+// wave-level hand-off through LDS: a fence so the compiler keeps the LDS operations on either side in program order,
+// and the (free on wave64) wave barrier that re-converges the lanes of a divergent region before the next phase
+__device__ __forceinline__ void lds_phase() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 // Unscored stage 1 through the wave's private LDS hash table (keys[256] all 0 = empty, cnt[256] all
-// 0 on entry and on exit).  One wave executes in lockstep and the LDS serves its instructions in
-// order, so every lane's ds_add has landed before any leader reads its counter back.
+// 0 on entry and on exit).  The three phases -- every lane's ds_add, the leaders' read-back, the key clear -- are
+// separated by lds_phase(): the LDS serves one wave's instructions in order, the fence keeps them in this order.
 __device__ __forceinline__ void lds_count(uint32_t* keys, uint32_t* cnt, uint32_t t0, uint32_t t1, float lower_bound,
                                           bool& keep0, bool& keep1, float& cnt0, float& cnt1) {
     uint32_t slot0 = 0, slot1 = 0;
@@ -127,6 +134,7 @@ __device__ __forceinline__ void lds_count(uint32_t* keys, uint32_t* cnt, uint32_
     }
     keep0 = keep1 = false;
     cnt0 = cnt1 = 0.0f;
+    lds_phase();
     if (lead0) {
         cnt0 = (float)atomicExch(&cnt[slot0], 0u);  // read the multiplicity and reset the slot
         keep0 = cnt0 >= lower_bound;                // agg::filter keeps freq >= lower_bound
@@ -135,7 +143,8 @@ __device__ __forceinline__ void lds_count(uint32_t* keys, uint32_t* cnt, uint32_
         cnt1 = (float)atomicExch(&cnt[slot1], 0u);
         keep1 = cnt1 >= lower_bound;
     }
-    // every leader has read its counter before any key is cleared (lockstep), so no slot is reused early
+    // every leader has read its counter before any key is cleared, so no slot is reused early
+    lds_phase();
     if (lead0) atomicExch(&keys[slot0], 0u);
     if (lead1) atomicExch(&keys[slot1], 0u);
 }

@@ -206,17 +206,10 @@ int launch(umgap_taxonomy* tx, int method, int strategy, float factor, float low
         if (d_scores) hipLaunchKernelGGL(k_agg_lca<true>, grid, block, 0, stream, V, method, d_taxa, d_scores, d_offsets, stride, n_reads, lower_bound, d_out_taxon, d_out_status);
         else hipLaunchKernelGGL(k_agg_lca<false>, grid, block, 0, stream, V, method, d_taxa, d_scores, d_offsets, stride, n_reads, lower_bound, d_out_taxon, d_out_status);
     } else {
-        size_t need = (n_reads + 1) * sizeof(uint32_t);
-        if (need > tx->d_defer_bytes) {
-            if (tx->d_defer) (void)hipFree(tx->d_defer);
-            tx->d_defer = nullptr;
-            tx->d_defer_bytes = 0;
-            hipError_t e = hipMalloc((void**)&tx->d_defer, need);
-            if (e != hipSuccess) return fail(UMGAP_ERR_NOMEM, std::string("hipMalloc(aggregate defer list): ") + hipGetErrorString(e));
-            tx->d_defer_bytes = need;
-        }
+        uint32_t* d_defer = defer_list_for(tx, stream, (n_reads + 1) * sizeof(uint32_t));
+        if (!d_defer) return UMGAP_ERR_NOMEM;
         return launch_general(V, method, strategy, factor, lower_bound, d_taxa, d_scores, d_offsets, stride, n_reads, d_out_taxon,
-                              d_out_status, tx->d_defer, stream);
+                              d_out_status, d_defer, stream);
     }
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;

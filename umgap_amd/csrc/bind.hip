@@ -71,6 +71,9 @@ int umgap_index_bind_taxonomy(umgap_index* ix, umgap_taxonomy* tx) {
     if (tx->n_reach > bound::MAX_REACH) return fail(UMGAP_ERR_INVALID, "umgap_index_bind_taxonomy: more than 2^22 - 2 reachable taxa");
     int rc = use_device(ix->device);
     if (rc) return rc;
+    // the slots are rewritten in place: nothing launched earlier on ANY stream of this device (a classify on the
+    // caller's stream, say) may still be probing them
+    UMGAP_HIP(hipDeviceSynchronize());
     const size_t nslots = (size_t)ix->view.n_resident * SLOTS;
     unsigned long long* d_bad = nullptr;
     UMGAP_HIP(hipMalloc((void**)&d_bad, sizeof(unsigned long long)));
@@ -88,6 +91,7 @@ int umgap_index_bind_taxonomy(umgap_index* ix, umgap_taxonomy* tx) {
     UMGAP_HIP(hipGetLastError());
     UMGAP_HIP(hipStreamSynchronize(ix->stream));
     ix->bound_to = tx;
+    tx->bound_indexes.push_back(ix);
     return UMGAP_OK;
 }
 
@@ -97,11 +101,14 @@ int umgap_index_unbind_taxonomy(umgap_index* ix, umgap_taxonomy* tx) {
     if (ix->bound_to != tx) return fail(UMGAP_ERR_INVALID, "umgap_index_unbind_taxonomy: bound to another taxonomy");
     int rc = use_device(ix->device);
     if (rc) return rc;
+    UMGAP_HIP(hipDeviceSynchronize());   // as in bind: no kernel of any stream may be reading the slots
     const size_t nslots = (size_t)ix->view.n_resident * SLOTS;
     hipLaunchKernelGGL(k_unbind, dim3(256 * 8), dim3(256), 0, ix->stream, ix->d_slots, nslots, ix->d_stash_vals, ix->n_stash, tx->d_id_of_pre);
     UMGAP_HIP(hipGetLastError());
     UMGAP_HIP(hipStreamSynchronize(ix->stream));
     ix->bound_to = nullptr;
+    for (size_t i = 0; i < tx->bound_indexes.size(); i++)
+        if (tx->bound_indexes[i] == ix) { tx->bound_indexes.erase(tx->bound_indexes.begin() + (long)i); break; }
     return UMGAP_OK;
 }
 

@@ -31,15 +31,18 @@ namespace {
 // move, "don't start with a missing taxon" (src/commands/seedextend.rs:130-134), merely skips
 // element `end` and restarts right after it -- so the next element is prefetched while the
 // current one is processed (the LDS read latency is the cost of this stage).
-__device__ __forceinline__ void seedextend_lds(uint32_t* t, uint32_t n, uint32_t min_seed, uint32_t max_gap) {
+// Returns true when the reference would panic on the record: a seed with start > end, sliced at src/commands/seedextend.rs:169-173
+// (only reachable with --min-seed-size < 2).
+__device__ __forceinline__ bool seedextend_lds(uint32_t* t, uint32_t n, uint32_t min_seed, uint32_t max_gap) {
     uint32_t cursor = 0;
+    bool panicked = false;
     auto emit = [&](uint32_t s, uint32_t e) {   // seeds.push((s, e)): everything before s and after the last e is dropped
+        if (s > e) { panicked = true; return; }
         if (e > n) e = n;
-        if (s > e) s = e;
         for (uint32_t i = cursor; i < s; i++) t[i] = 0;
         cursor = e > cursor ? e : cursor;
     };
-    if (n == 0) return;
+    if (n == 0) return false;
     uint32_t start = 0, last_tid = t[0], same_tid = 1, same_max = 1;
     uint32_t nxt = n > 1 ? t[1] : 0u;
     for (uint32_t end = 1; end <= n; end++) {
@@ -61,6 +64,7 @@ __device__ __forceinline__ void seedextend_lds(uint32_t* t, uint32_t n, uint32_t
         emit(start, end);
     }
     for (uint32_t i = cursor; i < n; i++) t[i] = 0;
+    return panicked;
 }
 
 // LCA* of one read whose taxa sit in LDS at rt[0..n) (n <= 128), shared by both fused kernels.
@@ -196,9 +200,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         probe_group_to_strip(T, kp, nk, wtaxa, lane);
         wave_lds_sync();
         // ---- seedextend per fragment (one lane per fragment, nr * frags <= 64) ----
+        uint64_t se_panic = 0;   // lanes (= fragments) on which the reference's seedextend panics
         if (frags) {
             const uint32_t flen = stride / frags;
-            if (lane < nr * frags) seedextend_lds(wtaxa + lane * flen, flen, min_seed, max_gap);
+            bool pk = false;
+            if (lane < nr * frags) pk = seedextend_lds(wtaxa + lane * flen, flen, min_seed, max_gap);
+            se_panic = __ballot(pk);
             wave_lds_sync();
         }
         // ---- aggregate each read of the group ----
@@ -206,6 +213,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             uint32_t res_taxon, res_status;
             if (BOUND) lca_star_bound_from_lds(V, wtaxa + k * stride, stride, lower_bound, wkeys, wcnt, lane, res_taxon, res_status);
             else lca_star_from_lds(V, tree_like, wtaxa + k * stride, stride, lower_bound, wkeys, wcnt, lane, res_taxon, res_status);
+            if (se_panic && ((se_panic >> (k * frags)) & ((frags >= 64 ? 0ull : (1ull << frags)) - 1ull))) { res_taxon = 0; res_status = UMGAP_READ_PANIC; }
             if (lane == 0) {
                 out_taxon[r0 + k] = res_taxon;
                 out_status[r0 + k] = res_status;
@@ -245,15 +253,19 @@ __global__ __launch_bounds__(256) void k_classify9_general(TableView T, TaxView 
         const uint32_t nk = nr * stride;
         probe_group_to_strip(T, keys + r0 * stride, nk, wtaxa, lane);
         wave_lds_sync();
+        uint64_t se_panic = 0;
         if (frags) {
             const uint32_t flen = stride / frags;
-            if (lane < nr * frags) seedextend_lds(wtaxa + lane * flen, flen, min_seed, max_gap);
+            bool pk = false;
+            if (lane < nr * frags) pk = seedextend_lds(wtaxa + lane * flen, flen, min_seed, max_gap);
+            se_panic = __ballot(pk);
             wave_lds_sync();
         }
         for (uint32_t k = 0; k < nr; k++) {
             uint32_t res_taxon, res_status;
-            const bool ok = general_read<false, CAP, HCAP, BOUND>(V, S, method, strategy, factor, lower_bound, wtaxa + k * stride, nullptr, stride, lane,
-                                                           res_taxon, res_status);
+            bool ok = general_read<false, CAP, HCAP, BOUND>(V, S, method, strategy, factor, lower_bound, wtaxa + k * stride, nullptr, stride, lane,
+                                                     res_taxon, res_status);
+            if (se_panic && ((se_panic >> (k * frags)) & ((frags >= 64 ? 0ull : (1ull << frags)) - 1ull))) { ok = true; res_taxon = 0; res_status = UMGAP_READ_PANIC; }
             wave_lds_sync();
             if (lane == 0) {
                 if (ok) { out_taxon[r0 + k] = res_taxon; out_status[r0 + k] = res_status; }
@@ -420,8 +432,11 @@ __global__ __launch_bounds__(256, 4) void k_classify_prot9(TableView T, TaxView 
         }
         wave_lds_sync();
         // ---- seedextend: all fragments of the group at once, one lane each ----
+        uint64_t se_panic = 0;
         if (do_seed) {
-            if (lane < nfr && my_win) seedextend_lds(wtaxa + my_start, my_win, min_seed, max_gap);
+            bool pk = false;
+            if (lane < nfr && my_win) pk = seedextend_lds(wtaxa + my_start, my_win, min_seed, max_gap);
+            se_panic = __ballot(pk);
             wave_lds_sync();
         }
         // ---- aggregate ----
@@ -432,6 +447,7 @@ __global__ __launch_bounds__(256, 4) void k_classify_prot9(TableView T, TaxView 
                 if (BOUND) lca_star_bound_from_lds(V, wtaxa + wfstart[k * F], total, lower_bound, wkeys, wcnt, lane, res_taxon, res_status);
                 else lca_star_from_lds(V, tree_like, wtaxa + wfstart[k * F], total, lower_bound, wkeys, wcnt, lane, res_taxon, res_status);
             }
+            if (se_panic && ((se_panic >> (k * F)) & ((1ull << F) - 1ull))) { res_taxon = 0; res_status = UMGAP_READ_PANIC; }
             if (lane == 0) {
                 out_taxon[r0 + k] = res_taxon;
                 out_status[r0 + k] = res_status;
@@ -452,6 +468,7 @@ extern "C" int umgap_classify9_dev(umgap_index* ix, umgap_taxonomy* tx, int meth
     if (fragments_per_read && (kmers_per_read % fragments_per_read) != 0) return fail(UMGAP_ERR_INVALID, "umgap_classify9_dev: kmers_per_read must be a multiple of fragments_per_read");
     if (fragments_per_read > 64) return fail(UMGAP_ERR_INVALID, "umgap_classify9_dev: at most 64 fragments per read");
     if (method != UMGAP_METHOD_TREE && method != UMGAP_METHOD_RMQ) return fail(UMGAP_ERR_INVALID, "unknown method");
+    if (ix->kind != 9) return fail(UMGAP_ERR_INVALID, "umgap_classify9_dev: needs a 9-mer index");
     if (ix->device != tx->device) return fail(UMGAP_ERR_INVALID, "umgap_classify9_dev: index and taxonomy live on different devices");
     int rc = use_device(ix->device);
     if (rc) return rc;
@@ -494,18 +511,11 @@ extern "C" int umgap_classify9_strategy_dev(umgap_index* ix, umgap_taxonomy* tx,
     int rc = use_device(ix->device);
     if (rc) return rc;
     if (!n_reads) return UMGAP_OK;
-    size_t need = (n_reads + 1) * sizeof(uint32_t);
-    if (need > tx->d_defer_bytes) {
-        if (tx->d_defer) (void)hipFree(tx->d_defer);
-        tx->d_defer = nullptr;
-        tx->d_defer_bytes = 0;
-        hipError_t e = hipMalloc((void**)&tx->d_defer, need);
-        if (e != hipSuccess) return fail(UMGAP_ERR_NOMEM, std::string("hipMalloc(defer list): ") + hipGetErrorString(e));
-        tx->d_defer_bytes = need;
-    }
-    uint32_t* d_count = tx->d_defer;
-    uint32_t* d_list = tx->d_defer + 1;
     hipStream_t s = (hipStream_t)stream;
+    uint32_t* d_defer = defer_list_for(tx, s, (n_reads + 1) * sizeof(uint32_t));
+    if (!d_defer) return UMGAP_ERR_NOMEM;
+    uint32_t* d_count = d_defer;
+    uint32_t* d_list = d_defer + 1;
     UMGAP_HIP(hipMemsetAsync(d_count, 0, sizeof(uint32_t), s));
     uint32_t G = 1024u / kmers_per_read;
     if (fragments_per_read && G * fragments_per_read > 64) G = 64 / fragments_per_read;

@@ -918,13 +918,42 @@ void parse_fuse_part(const char* d, size_t begin, size_t end, const std::optiona
 }
 
 // one block's worth of reads, self-contained (nothing points into the block buffer)
+// Grow-only array in page-locked host memory (umgap_host_alloc): what umgap_classify_records copies from / to at full
+// PCIe rate and without blocking the calling thread.  resize() keeps no old contents.
+template <class T>
+struct PinnedVec {
+    T* p = nullptr;
+    size_t n = 0, cap = 0;
+    PinnedVec() = default;
+    PinnedVec(const PinnedVec&) = delete;
+    PinnedVec& operator=(const PinnedVec&) = delete;
+    ~PinnedVec() { umgap_host_free(p); }
+    void resize(size_t m) {
+        if (m > cap) {
+            umgap_host_free(p);
+            p = nullptr;
+            cap = 0;
+            void* q = nullptr;
+            const size_t want = m + m / 4 + 1024;
+            if (umgap_host_alloc(want * sizeof(T), &q) != UMGAP_OK) throw CliError(umgap_last_error());
+            p = (T*)q;
+            cap = want;
+        }
+        n = m;
+    }
+    T* data() { return p; }
+    T* begin() { return p; }
+    size_t size() const { return n; }
+    T& operator[](size_t i) { return p[i]; }
+};
+
 struct FuseJob {
-    std::vector<uint8_t> bytes;
-    std::vector<uint64_t> frag_off, read_frags;
+    PinnedVec<uint8_t> bytes;
+    PinnedVec<uint64_t> frag_off, read_frags;
     std::string hdrs;                 // the reads' headers, back to back
     std::vector<uint64_t> hdr_end;    // n_reads + 1
     size_t n_reads = 0;
-    std::vector<uint32_t> out_taxon, out_status;
+    PinnedVec<uint32_t> out_taxon, out_status;
 };
 
 int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
@@ -935,8 +964,8 @@ int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
     uint64_t s = opt_usize(p, "min-seed-size", 2), g = opt_usize(p, "max-gap-size", 0);
     bool se = !p.has("no-seedextend");
     // with -s 0 / -s 1 the reference's seedextend can panic on a leading run of misses (slice start > end,
-    // src/commands/seedextend.rs:118,145); the device kernel has no such state, so those values stay with the separate command
-    if (se && s < 2) throw CliError("prot2kmer2agg needs --min-seed-size >= 2 (use the separate seedextend command below that)");
+    // src/commands/seedextend.rs:118,145 sliced at :169-173): the device reports such reads with UMGAP_READ_PANIC and the
+    // command exits 101 after printing the reads before it, like the reference's pipe does
     if (s > 0xFFFFFFFFull || g > 0xFFFFFFFFull) throw CliError("seed / gap size out of range");
     auto delim = p.get("delimiter");
     std::string m = p.get("method").value_or("tree"), a = p.get("aggregate").value_or("hybrid");

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "probe_common.hpp"
+#include "taxonomy.hpp"
 
 namespace umgap {
 void var_free(umgap_var_index* v);
@@ -365,6 +366,44 @@ __global__ __launch_bounds__(256) void k_gather_mlp(const uint64_t* __restrict__
     if (t < n) out[t] = acc;
 }
 
+// the same 64-byte quad gather, 8 in flight per lane, with the load's cache-policy bits spelled out (gfx950: sc0, sc1, nt):
+// does any policy move the random-sector ceiling?  Loads are inline asm, so the wait is explicit.
+template <int POL>
+__device__ __forceinline__ u32x4 load_policy(const u32x4* p) {
+    u32x4 v;
+    if constexpr (POL == 0) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    else if constexpr (POL == 1) asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(v) : "v"(p) : "memory");
+    else if constexpr (POL == 2) asm volatile("global_load_dwordx4 %0, %1, off sc0" : "=v"(v) : "v"(p) : "memory");
+    else if constexpr (POL == 3) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+    else if constexpr (POL == 4) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
+    else if constexpr (POL == 5) asm volatile("global_load_dwordx4 %0, %1, off sc0 nt" : "=v"(v) : "v"(p) : "memory");
+    else if constexpr (POL == 6) asm volatile("global_load_dwordx4 %0, %1, off sc1 nt" : "=v"(v) : "v"(p) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1 nt" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <int POL>
+__global__ __launch_bounds__(256) void k_gather_policy(const uint64_t* __restrict__ slots, uint32_t nb, size_t n, uint32_t* __restrict__ out) {
+    constexpr int LANES = 4, U = 8;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = ((size_t)gridDim.x * blockDim.x) / LANES;
+    const uint32_t j = threadIdx.x % LANES;
+    uint32_t acc = 0;
+    for (size_t i = t / LANES; i < n; i += stride * U) {
+        u32x4 e[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            size_t ii = i + (size_t)u * stride;
+            uint64_t h = mix45(ii * 0x9E3779B97F4A7C15ull >> 19);
+            uint32_t bucket = __umulhi((uint32_t)h, nb);
+            e[u] = load_policy<POL>(reinterpret_cast<const u32x4*>(slots) + ((size_t)bucket * 4 + j));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < U; u++) acc ^= e[u].x ^ e[u].y ^ e[u].z ^ e[u].w;
+    }
+    if (t < n) out[t] = acc;
+}
+
 __global__ void k_fill(uint64_t* p, size_t n, uint64_t v) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -696,6 +735,11 @@ int umgap_synth_index_build_shard(uint64_t n_keys, const uint32_t* d_taxon_of_ro
 void umgap_index_free(umgap_index* ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
+    if (ix->bound_to) {   // leave the taxonomy's registry (bind.hip); the values die with the table
+        auto& v = ((umgap_taxonomy*)ix->bound_to)->bound_indexes;
+        for (size_t i = 0; i < v.size(); i++)
+            if (v[i] == ix) { v.erase(v.begin() + (long)i); break; }
+    }
     if (ix->var) var_free(ix->var);
     if (ix->d_slots) (void)hipFree(ix->d_slots);
     if (ix->d_stash_keys) (void)hipFree(ix->d_stash_keys);
@@ -1053,6 +1097,20 @@ int umgap_bench_gather_dev(umgap_index* ix, size_t n, uint32_t bytes_per_probe, 
     hipStream_t s = (hipStream_t)stream;
     uint32_t nb = ix->view.n_resident;
     int g = 256 * 8;
+    if (bytes_per_probe >> 28) {   // bits 28+: 1 + cache-policy variant of the 64-byte, 8-in-flight gather (k_gather_policy)
+        switch ((bytes_per_probe >> 28) - 1) {
+            case 0: hipLaunchKernelGGL(k_gather_policy<0>, dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out); break;
+            case 1: hipLaunchKernelGGL(k_gather_policy<1>, dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out); break;
+            case 2: hipLaunchKernelGGL(k_gather_policy<2>, dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out); break;
+            case 3: hipLaunchKernelGGL(k_gather_policy<3>, dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out); break;
+            case 4: hipLaunchKernelGGL(k_gather_policy<4>, dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out); break;
+            case 5: hipLaunchKernelGGL(k_gather_policy<5>, dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out); break;
+            case 6: hipLaunchKernelGGL(k_gather_policy<6>, dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out); break;
+            default: hipLaunchKernelGGL(k_gather_policy<7>, dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out); break;
+        }
+        UMGAP_HIP(hipGetLastError());
+        return UMGAP_OK;
+    }
     if (bytes_per_probe >> 16) {   // bits 16+: that many probes in flight per lane, no store per probe (pure random-read rate)
         const uint32_t fl = bytes_per_probe >> 16, bytes = bytes_per_probe & 0xFFFFu;
         if (bytes == 64 && fl == 2) hipLaunchKernelGGL((k_gather_mlp<4, 2>), dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out);

@@ -26,15 +26,14 @@ int use_device(int device) {
 
 }  // namespace umgap
 
+#include "seedextend.hpp"
+
 using namespace umgap;
 
 namespace {
 
 // ---------------------------------------------------------------------------------------------
-// seedextend, unranked mode: src/commands/seedextend.rs:99-148 restated per record, in place.
-// The reference appends a 0 sentinel (:99) and collects (start, end) seeds; here everything
-// outside the seeds is overwritten with 0 (taxa2agg drops zeros, src/commands/taxa2agg.rs:169).
-// One lane per record (records are short: <= a few hundred items).
+// seedextend, unranked mode (seedextend.hpp has the per-record state machine), in place, one lane per record.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_seedextend(const uint64_t* __restrict__ offsets, uint32_t stride, size_t n_records,
                                                     uint32_t min_seed, uint32_t max_gap, uint32_t* __restrict__ taxa,
@@ -44,47 +43,21 @@ __global__ __launch_bounds__(256) void k_seedextend(const uint64_t* __restrict__
     for (; r < n_records; r += step) {
         uint64_t off = offsets ? offsets[r] : (uint64_t)r * stride;
         uint32_t n = offsets ? (uint32_t)(offsets[r + 1] - off) : stride;
-        uint32_t* t = taxa + off;
-        auto at = [&](uint32_t i) -> uint32_t { return i < n ? t[i] : 0u; };  // index n = the sentinel
-        const uint32_t len = n + 1;
-        uint32_t cursor = 0, nkept = 0;
-        auto emit = [&](uint32_t s, uint32_t e) {  // seeds.push((s, e)); slices are clamped like taxons[s..e]
-            if (e > n) e = n;                      // the sentinel itself is never stored
-            if (s > e) s = e;
-            for (uint32_t i = cursor; i < s; i++) t[i] = 0;
-            nkept += e - s;
-            cursor = e > cursor ? e : cursor;
-        };
-        uint32_t start = 0, end = 1;
-        uint32_t last_tid = at(start), same_tid = 1, same_max = 1;
-        while (end < len) {
-            uint32_t cur = at(end);
-            if (last_tid == cur) { same_tid += 1; end += 1; continue; }                 // :109-113
-            if (last_tid == 0 && same_tid > max_gap) {                                  // :116-127
-                if (same_max >= min_seed) emit(start, end - same_tid);
-                start = end;
-                last_tid = cur;
-                same_tid = 1;
-                same_max = 1;
-                end += 1;
-                continue;
-            }
-            if (last_tid == 0 && (end - start) == same_tid) {                           // :130-134
-                end += 1;
-                start = end;
-                continue;
-            }
-            if (last_tid != 0) same_max = same_max > same_tid ? same_max : same_tid;    // :137-139
-            last_tid = cur;
-            same_tid = 1;
-            end += 1;
-        }
-        if (same_max >= min_seed) {                                                     // :143-148
-            if (last_tid == 0) end -= same_tid;
-            emit(start, end);
-        }
-        for (uint32_t i = cursor; i < n; i++) t[i] = 0;
-        if (kept) kept[r] = nkept;
+        const uint32_t k = seedextend_record(taxa + off, n, min_seed, max_gap);
+        if (kept) kept[r] = k;
+    }
+}
+
+// Reads that hold a fragment on which seedextend panicked (kept == UMGAP_NONE) get status UMGAP_READ_PANIC: in the
+// reference's pipe the seedextend process dies at that record (exit 101) and nothing after it is printed.
+__global__ __launch_bounds__(256) void k_mark_seed_panics(const uint32_t* __restrict__ kept, const uint64_t* __restrict__ read_frags, size_t n_reads,
+                                                          uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status) {
+    size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; r < n_reads; r += step) {
+        bool pk = false;
+        for (uint64_t f = read_frags[r]; f < read_frags[r + 1]; f++) pk = pk || kept[f] == UMGAP_NONE;
+        if (pk) { out_taxon[r] = 0; out_status[r] = UMGAP_READ_PANIC; }
     }
 }
 
@@ -207,6 +180,18 @@ inline int grid_for(size_t n) {
 }
 
 }  // namespace
+
+namespace umgap {
+int mark_seedextend_panics(const uint32_t* d_kept, const uint64_t* d_read_frags, size_t n_reads, uint32_t* d_out_taxon, uint32_t* d_out_status,
+                           hipStream_t stream) {
+    if (!n_reads) return UMGAP_OK;
+    size_t g = (n_reads + 255) / 256;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_mark_seed_panics, dim3((unsigned)g), dim3(256), 0, stream, d_kept, d_read_frags, n_reads, d_out_taxon, d_out_status);
+    UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}
+}  // namespace umgap
 
 extern "C" {
 

@@ -6,10 +6,161 @@
 // consecutive fragments `uniq` would merge (src/commands/uniq.rs:66-79); the per-window hits stay in
 // HBM between the probe, seedextend (src/commands/seedextend.rs:99-148, in place) and the per-read
 // aggregate (src/commands/taxa2agg.rs:160-180).  Only one taxon + status per read travels back.
-#include "common.hpp"
+//
+// Shape of the call (round 2): nothing is rebuilt on the host.  The block is cut into chunks of whole reads
+// (~32 MB of residues); chunk c+1 is uploaded straight from the caller's arrays (pin them with umgap_host_alloc
+// for full PCIe rate) on one stream while chunk c runs on the other.  On the device the hit of the window that
+// STARTS at byte b lives at hits[b] -- fragment f owns hits[off[f] .. off[f+1]), its last 8 positions (no window
+// starts there) stay 0, which taxa2agg drops (src/commands/taxa2agg.rs:169) -- so no window prefix sums are needed:
+//   k_frag_prepare   fragment -> {start, length} (validated) + the tail positions marked in a bitmap
+//   k_lookup_bytes9  every unmarked byte position: 9 residues packed from LDS -> quad probe -> hits[b]
+//   k_seedextend_frags / k_read_offsets / the aggregate kernels / k_mark_seed_panics
+#include "probe_common.hpp"
+#include "seedextend.hpp"
 #include "taxonomy.hpp"
 
+#include <algorithm>
+#include <vector>
+
+namespace umgap {
+int mark_seedextend_panics(const uint32_t* d_kept, const uint64_t* d_read_frags, size_t n_reads, uint32_t* d_out_taxon, uint32_t* d_out_status,
+                           hipStream_t stream);
+}
+
 using namespace umgap;
+using namespace umgap::probe;
+
+namespace {
+
+// fragment f of the chunk (global fragment f0 + f): start/length relative to the chunk's first byte, checked against the
+// chunk (a decreasing or overrunning offset raises *bad and empties the fragment); its last min(len, 8) byte positions
+// start no window: marked in `tails` (bit b of word b / 32).
+__global__ __launch_bounds__(256) void k_frag_prepare(const uint64_t* __restrict__ off, size_t n_frag, uint64_t base, uint32_t chunk_bytes,
+                                                      uint32_t* __restrict__ fstart, uint32_t* __restrict__ flen, uint32_t* __restrict__ tails,
+                                                      uint32_t* __restrict__ bad) {
+    size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; f < n_frag; f += step) {
+        const uint64_t a = off[f], b = off[f + 1];
+        uint32_t s = 0, l = 0;
+        if (a < base || b < a || b - base > chunk_bytes) atomicExch(bad, 1u);
+        else { s = (uint32_t)(a - base); l = (uint32_t)(b - a); }
+        fstart[f] = s;
+        flen[f] = l;
+        const uint32_t t0 = l > 8 ? s + l - 8 : s, t1 = s + l;    // [t0, t1): at most 8 bits, at most two words
+        if (t1 > t0) {
+            const uint32_t w0 = t0 >> 5, w1 = (t1 - 1) >> 5;
+            const uint32_t lo = 0xFFFFFFFFu << (t0 & 31), hi = 0xFFFFFFFFu >> (31 - ((t1 - 1) & 31));
+            if (w0 == w1) atomicOr(&tails[w0], lo & hi);
+            else { atomicOr(&tails[w0], lo); atomicOr(&tails[w1], hi); }
+        }
+    }
+}
+
+// hits[b] = value of the 9-mer bytes[b .. b+9) (0 = miss; windows holding a byte outside 'A'..'Z' miss,
+// src/commands/prot2kmer2lca.rs:172-179 + the packing convention of include/umgap_hip.h) for every position that starts
+// a window, 0 elsewhere.  A wave takes 128 consecutive positions per step: their 136 bytes are staged in the wave's LDS
+// strip, two probe batches of 64 go out back to back (8 sectors in flight per quad), results land coalesced.
+__global__ __launch_bounds__(256) void k_lookup_bytes9(TableView T, const uint8_t* __restrict__ bytes, const uint32_t* __restrict__ tails,
+                                                       uint32_t n_bytes, uint32_t* __restrict__ hits) {
+    __shared__ uint8_t lds[4][144];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
+    uint8_t* wb = lds[wv];
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t p0 = wave * 128; p0 < n_bytes; p0 += nwaves * 128) {
+        // stage bytes [p0, p0 + 136)
+        for (uint32_t i = lane; i < 136; i += 64) wb[i] = p0 + i < n_bytes ? bytes[p0 + i] : (uint8_t)0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t tw0 = tails[(p0 >> 5) + (lane >> 5)], tw1 = p0 + 64 < n_bytes ? tails[((p0 + 64) >> 5) + (lane >> 5)] : 0xFFFFFFFFu;
+        ProbeBatch B[2];
+        uint32_t res[2][4];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t p = p0 + 64 * h + lane;
+            const bool starts = p < n_bytes && !(((h ? tw1 : tw0) >> (lane & 31)) & 1u);
+            uint64_t key = 0;
+            bool ok = starts;
+#pragma unroll
+            for (int c = 0; c < 9; c++) {
+                const uint32_t code = (uint32_t)wb[64 * h + lane + c] - 'A';
+                ok = ok && code < 26u;
+                key = (key << 5) | (code & 31u);
+            }
+            uint32_t local = 0, tag = 0, valid = 0;
+            if (ok) valid = locate(T, key, local, tag) ? 1u : 0u;
+            probe_issue(T, local, tag | (valid << 31), lane, B[h]);
+        }
+        probe_eval_multi<2>(T, B, 0u, lane, res);
+        if (j == 0) {
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t p = p0 + 64 * h + 16 * r + q;
+                    if (p < n_bytes) hits[p] = res[h][r];
+                }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// seedextend per fragment over its windows hits[start .. start + len - 8) (one lane per fragment, as k_seedextend)
+__global__ __launch_bounds__(256) void k_seedextend_frags(const uint32_t* __restrict__ fstart, const uint32_t* __restrict__ flen, size_t n_frag,
+                                                          uint32_t min_seed, uint32_t max_gap, uint32_t* __restrict__ hits, uint32_t* __restrict__ kept) {
+    size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; f < n_frag; f += step) {
+        const uint32_t l = flen[f];
+        // a fragment without windows is an empty record: the state machine over [sentinel] emits nothing (and cannot panic)
+        const uint32_t k = l > 8 ? seedextend_record(hits + fstart[f], l - 8, min_seed, max_gap) : 0u;
+        if (kept) kept[f] = k;
+    }
+}
+
+// read r of the chunk owns hits[roff[r] .. roff[r+1]); rf = the chunk's slice of read_frags (n_reads + 1 entries, global
+// fragment numbers), checked to be non-decreasing and inside the chunk's fragments [f0, f0 + n_frag]
+__global__ __launch_bounds__(256) void k_read_offsets(const uint64_t* __restrict__ rf, size_t n_reads, uint64_t f0, size_t n_frag,
+                                                      const uint32_t* __restrict__ fstart, uint32_t chunk_bytes, uint64_t* __restrict__ roff,
+                                                      uint64_t* __restrict__ rfrag_local, uint32_t* __restrict__ bad) {
+    size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; r <= n_reads; r += step) {
+        const uint64_t g = rf[r];
+        uint64_t f = 0;
+        if (g < f0 || g - f0 > n_frag || (r && g < rf[r - 1])) atomicExch(bad, 1u);
+        else f = g - f0;
+        roff[r] = f == n_frag ? (uint64_t)chunk_bytes : (uint64_t)fstart[f];
+        rfrag_local[r] = f;
+    }
+}
+
+struct Slot {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    uint8_t* bytes = nullptr;
+    uint64_t *off = nullptr, *rf = nullptr, *roff = nullptr, *rfl = nullptr;
+    uint32_t *fstart = nullptr, *flen = nullptr, *tails = nullptr, *hits = nullptr, *kept = nullptr, *ot = nullptr, *os = nullptr, *bad = nullptr;
+};
+
+inline size_t pad256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+}  // namespace
+
+// pinned host memory for the arrays handed to the host-pointer entry points (full-rate, truly asynchronous PCIe copies)
+extern "C" int umgap_host_alloc(size_t bytes, void** out) {
+    if (!out) return fail(UMGAP_ERR_INVALID, "umgap_host_alloc: null argument");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(UMGAP_ERR_DEVICE, "umgap_host_alloc: no usable GPU");
+    hipError_t e = hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocPortable);
+    if (e != hipSuccess) { *out = nullptr; return fail(UMGAP_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
+    return UMGAP_OK;
+}
+extern "C" void umgap_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
 
 extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound,
                                       int ranked_only, const uint8_t* bytes, const uint64_t* frag_offsets, size_t n_fragments,
@@ -20,60 +171,128 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
     if (ix->bound_to) return fail(UMGAP_ERR_INVALID, "the index is bound to a taxonomy (umgap_index_bind_taxonomy): its values are interval codes, not taxon ids; unbind it first");
     if (ix->kind != 9) return fail(UMGAP_ERR_INVALID, "umgap_classify_records: not a 9-mer index");
     if (ix->device != tx->device) return fail(UMGAP_ERR_INVALID, "umgap_classify_records: index and taxonomy live on different devices");
+    if (method != UMGAP_METHOD_TREE && method != UMGAP_METHOD_RMQ) return fail(UMGAP_ERR_INVALID, "unknown method");
+    if (strategy < 0 || strategy > 2) return fail(UMGAP_ERR_INVALID, "unknown strategy");
+    if (method == UMGAP_METHOD_TREE && strategy == UMGAP_STRATEGY_MRTL)
+        return fail(UMGAP_ERR_INVALID, "Invalid invocation: Tree and MaximumRootToLeafPath cannot be combined");  // src/commands/taxa2agg.rs:134-138
     if (!n_reads) return UMGAP_OK;
     if (read_frags[0] != 0 || read_frags[n_reads] != n_fragments) return fail(UMGAP_ERR_INVALID, "umgap_classify_records: read_frags must cover [0, n_fragments]");
     int rc = use_device(tx->device);
     if (rc) return rc;
-    const uint64_t base = n_fragments ? frag_offsets[0] : 0, n_bytes = n_fragments ? frag_offsets[n_fragments] - base : 0;
+    const uint64_t base = n_fragments ? frag_offsets[0] : 0;
+    if (n_fragments && frag_offsets[n_fragments] < base) return fail(UMGAP_ERR_INVALID, "umgap_classify_records: frag_offsets must not decrease");
+    const uint64_t n_bytes = n_fragments ? frag_offsets[n_fragments] - base : 0;
     if (n_bytes && !bytes) return fail(UMGAP_ERR_INVALID, "umgap_classify_records: null bytes");
-    // window CSR: fragment f owns hits [win[f], win[f+1]), read r owns [rwin[r], rwin[r+1])
-    std::vector<uint64_t> rel(n_fragments + 1), win(n_fragments + 1), rwin(n_reads + 1);
-    win[0] = 0;
-    rel[0] = 0;
-    for (size_t f = 0; f < n_fragments; f++) {
-        if (frag_offsets[f + 1] < frag_offsets[f]) return fail(UMGAP_ERR_INVALID, "umgap_classify_records: frag_offsets must not decrease");
-        uint64_t len = frag_offsets[f + 1] - frag_offsets[f];
-        rel[f + 1] = frag_offsets[f + 1] - base;
-        win[f + 1] = win[f] + (len >= 9 ? len - 8 : 0);
+
+    // ---- chunk plan: whole reads, at most CH residues / FH fragments / RH reads each (a single read may exceed them) ----
+    const uint64_t CH = 32ull << 20;
+    const size_t FH = 4u << 20, RH = 2u << 20;
+    auto frag_of = [&](size_t r) -> uint64_t { uint64_t f = read_frags[r]; return f > n_fragments ? n_fragments : f; };
+    auto byte_of = [&](size_t r) -> uint64_t { uint64_t o = frag_offsets[frag_of(r)]; return o < base ? 0 : std::min(o - base, n_bytes); };
+    std::vector<size_t> cuts{0};
+    while (cuts.back() < n_reads) {
+        const size_t r0 = cuts.back();
+        size_t lo = r0 + 1, hi = std::min(n_reads, r0 + RH);   // largest r1 in [lo, hi] within the budgets (monotone if the input is sane)
+        const uint64_t b0 = byte_of(r0), f0 = frag_of(r0);
+        auto fits = [&](size_t r1) { uint64_t b = byte_of(r1), f = frag_of(r1); return b >= b0 && b - b0 <= CH && f >= f0 && f - f0 <= FH; };
+        while (lo < hi) {
+            size_t mid = lo + (hi - lo + 1) / 2;
+            if (fits(mid)) lo = mid; else hi = mid - 1;
+        }
+        cuts.push_back(lo);
     }
-    for (size_t r = 0; r <= n_reads; r++) {
-        if (read_frags[r] > n_fragments || (r && read_frags[r] < read_frags[r - 1])) return fail(UMGAP_ERR_INVALID, "umgap_classify_records: bad read_frags");
-        rwin[r] = win[read_frags[r]];
+    uint64_t max_b = 0;
+    size_t max_f = 0, max_r = 0;
+    for (size_t c = 0; c + 1 < cuts.size(); c++) {
+        const uint64_t b0 = byte_of(cuts[c]), b1 = byte_of(cuts[c + 1]), f0 = frag_of(cuts[c]), f1 = frag_of(cuts[c + 1]);
+        if (b1 < b0 || f1 < f0) return fail(UMGAP_ERR_INVALID, "umgap_classify_records: offsets must not decrease");
+        if (b1 - b0 >= 0xFFFFFF00ull) return fail(UMGAP_ERR_INVALID, "umgap_classify_records: a single read holds 4 GiB of residues or more");
+        max_b = std::max(max_b, b1 - b0);
+        max_f = std::max<size_t>(max_f, f1 - f0);
+        max_r = std::max(max_r, cuts[c + 1] - cuts[c]);
     }
-    const uint64_t n_win = win[n_fragments];
-    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t b_bytes = pad(n_bytes + 16), b_off = pad((n_fragments + 1) * 8), b_roff = pad((n_reads + 1) * 8), b_hits = pad(n_win * 4 + 16),
-                 b_out = pad(n_reads * 4);
-    const size_t need = b_bytes + 2 * b_off + b_roff + b_hits + 2 * b_out;
+    const bool want_kept = seedextend && min_seed_size < 2;   // the only settings under which the reference's seedextend can panic
+
+    // ---- device staging: two slots inside the taxonomy handle's staging block ----
+    const size_t b_bytes = pad256(max_b + 160), b_off = pad256((max_f + 1) * 8), b_rf = pad256((max_r + 1) * 8), b_f32 = pad256((max_f + 1) * 4),
+                 b_tails = pad256((max_b / 32 + 8) * 4), b_hits = pad256((max_b + 16) * 4), b_out = pad256(max_r * 4 + 4);
+    const size_t per_slot = b_bytes + b_off + 3 * b_rf + 2 * b_f32 + b_tails + b_hits + (want_kept ? b_f32 : 0) + 2 * b_out + 256;
+    const size_t need = 2 * per_slot;
     if (need > tx->d_stage_bytes) {
         if (tx->d_stage) (void)hipFree(tx->d_stage);
         tx->d_stage = nullptr;
         tx->d_stage_bytes = 0;
-        hipError_t e = hipMalloc(&tx->d_stage, need + need / 4);
+        hipError_t e = hipMalloc(&tx->d_stage, need + need / 8);
         if (e != hipSuccess) return fail(UMGAP_ERR_NOMEM, std::string("hipMalloc(record staging): ") + hipGetErrorString(e));
-        tx->d_stage_bytes = need + need / 4;
+        tx->d_stage_bytes = need + need / 8;
     }
-    char* p = (char*)tx->d_stage;
-    uint8_t* d_bytes = (uint8_t*)p; p += b_bytes;
-    uint64_t* d_off = (uint64_t*)p; p += b_off;
-    uint64_t* d_win = (uint64_t*)p; p += b_off;
-    uint64_t* d_rwin = (uint64_t*)p; p += b_roff;
-    uint32_t* d_hits = (uint32_t*)p; p += b_hits;
-    uint32_t* d_ot = (uint32_t*)p; p += b_out;
-    uint32_t* d_os = (uint32_t*)p;
-    hipStream_t s = tx->stream;
-    if (n_bytes) UMGAP_HIP(hipMemcpyAsync(d_bytes, bytes + base, n_bytes, hipMemcpyHostToDevice, s));
-    UMGAP_HIP(hipMemcpyAsync(d_off, rel.data(), (n_fragments + 1) * 8, hipMemcpyHostToDevice, s));
-    UMGAP_HIP(hipMemcpyAsync(d_win, win.data(), (n_fragments + 1) * 8, hipMemcpyHostToDevice, s));
-    UMGAP_HIP(hipMemcpyAsync(d_rwin, rwin.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, s));
-    if (n_win) {
-        rc = umgap_index_lookup_prot9_dev(ix, d_bytes, d_off, d_win, n_fragments, 0u, d_hits, s);
-        if (!rc && seedextend) rc = umgap_seedextend_dev(d_win, n_fragments, min_seed_size, max_gap_size, d_hits, nullptr, tx->device, s);
+    Slot S[2];
+    S[0].stream = tx->stream;
+    hipError_t e = hipSuccess;
+    if (!tx->stream2) e = hipStreamCreateWithFlags(&tx->stream2, hipStreamNonBlocking);
+    if (e != hipSuccess) return fail(UMGAP_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    S[1].stream = tx->stream2;
+    if (!tx->h_flags) e = hipHostMalloc((void**)&tx->h_flags, 2 * sizeof(uint32_t), hipHostMallocDefault);
+    if (e != hipSuccess) { tx->h_flags = nullptr; return fail(UMGAP_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
+    volatile uint32_t* h_bad = tx->h_flags;
+    h_bad[0] = h_bad[1] = 0;
+    for (int k = 0; k < 2; k++) {
+        char* p = (char*)tx->d_stage + (size_t)k * per_slot;
+        S[k].bytes = (uint8_t*)p; p += b_bytes;
+        S[k].off = (uint64_t*)p; p += b_off;
+        S[k].rf = (uint64_t*)p; p += b_rf;
+        S[k].roff = (uint64_t*)p; p += b_rf;
+        S[k].rfl = (uint64_t*)p; p += b_rf;
+        S[k].fstart = (uint32_t*)p; p += b_f32;
+        S[k].flen = (uint32_t*)p; p += b_f32;
+        S[k].tails = (uint32_t*)p; p += b_tails;
+        S[k].hits = (uint32_t*)p; p += b_hits;
+        if (want_kept) { S[k].kept = (uint32_t*)p; p += b_f32; }
+        S[k].ot = (uint32_t*)p; p += b_out;
+        S[k].os = (uint32_t*)p; p += b_out;
+        S[k].bad = (uint32_t*)p;
     }
-    if (!rc) rc = umgap_aggregate_dev(tx, method, strategy, factor, lower_bound, ranked_only, d_hits, nullptr, d_rwin, n_reads, d_ot, d_os, s);
-    if (rc) { (void)hipStreamSynchronize(s); return rc; }
-    UMGAP_HIP(hipMemcpyAsync(out_taxon, d_ot, n_reads * 4, hipMemcpyDeviceToHost, s));
-    UMGAP_HIP(hipMemcpyAsync(out_status, d_os, n_reads * 4, hipMemcpyDeviceToHost, s));
-    UMGAP_HIP(hipStreamSynchronize(s));
+    TableView T = ix->view;
+    rc = UMGAP_OK;
+    for (size_t c = 0; c + 1 < cuts.size() && rc == UMGAP_OK; c++) {
+        Slot& L = S[c & 1];
+        hipStream_t s = L.stream;
+        const size_t r0 = cuts[c], nr = cuts[c + 1] - r0;
+        const uint64_t f0 = frag_of(r0), nf = frag_of(cuts[c + 1]) - f0;
+        const uint64_t b0 = byte_of(r0), nb = byte_of(cuts[c + 1]) - b0;
+        // slot reuse is ordered by its stream: chunk c-2's copies back were enqueued there before anything below
+        UMGAP_HIP(hipMemsetAsync(L.bad, 0, 4, s));
+        UMGAP_HIP(hipMemsetAsync(L.tails, 0, (nb / 32 + 8) * 4, s));
+        if (nb) UMGAP_HIP(hipMemcpyAsync(L.bytes, bytes + base + b0, nb, hipMemcpyHostToDevice, s));
+        UMGAP_HIP(hipMemsetAsync(L.bytes + nb, 0, 144, s));   // the packer may look 8 bytes past the chunk
+        if (nf) UMGAP_HIP(hipMemcpyAsync(L.off, frag_offsets + f0, (nf + 1) * 8, hipMemcpyHostToDevice, s));
+        UMGAP_HIP(hipMemcpyAsync(L.rf, read_frags + r0, (nr + 1) * 8, hipMemcpyHostToDevice, s));
+        const unsigned gf = (unsigned)std::min<size_t>((nf + 255) / 256 + 1, 2048), gr = (unsigned)std::min<size_t>((nr + 256) / 256 + 1, 2048);
+        if (nf) hipLaunchKernelGGL(k_frag_prepare, dim3(gf), dim3(256), 0, s, L.off, (size_t)nf, base + b0, (uint32_t)nb, L.fstart, L.flen, L.tails, L.bad);
+        if (nb) {
+            const unsigned gb = (unsigned)std::min<uint64_t>((nb + 511) / 512, 2048);
+            hipLaunchKernelGGL(k_lookup_bytes9, dim3(gb), dim3(256), 0, s, T, L.bytes, L.tails, (uint32_t)nb, L.hits);
+        }
+        if (seedextend && nf)
+            hipLaunchKernelGGL(k_seedextend_frags, dim3(gf), dim3(256), 0, s, L.fstart, L.flen, (size_t)nf, min_seed_size, max_gap_size, L.hits, L.kept);
+        hipLaunchKernelGGL(k_read_offsets, dim3(gr), dim3(256), 0, s, L.rf, nr, f0, (size_t)nf, L.fstart, (uint32_t)nb, L.roff, L.rfl, L.bad);
+        UMGAP_HIP(hipGetLastError());
+        rc = umgap_aggregate_dev(tx, method, strategy, factor, lower_bound, ranked_only, L.hits, nullptr, L.roff, nr, L.ot, L.os, s);
+        if (!rc && want_kept && nf) rc = mark_seedextend_panics(L.kept, L.rfl, nr, L.ot, L.os, s);
+        if (rc) break;
+        UMGAP_HIP(hipMemcpyAsync(out_taxon + r0, L.ot, nr * 4, hipMemcpyDeviceToHost, s));
+        UMGAP_HIP(hipMemcpyAsync(out_status + r0, L.os, nr * 4, hipMemcpyDeviceToHost, s));
+        UMGAP_HIP(hipMemcpyAsync(tx->h_flags + (c & 1), L.bad, 4, hipMemcpyDeviceToHost, s));
+        // before this slot is refilled (chunk c+2) the host must have seen its flag: wait for chunk c-1 now, which also
+        // keeps at most two chunks in flight
+        if (c >= 1) {
+            UMGAP_HIP(hipStreamSynchronize(S[(c - 1) & 1].stream));
+            if (h_bad[(c - 1) & 1]) { rc = fail(UMGAP_ERR_INVALID, "umgap_classify_records: frag_offsets / read_frags are not non-decreasing offsets into the block"); break; }
+        }
+    }
+    hipError_t e0 = hipStreamSynchronize(S[0].stream), e1 = hipStreamSynchronize(S[1].stream);
+    if (rc) return rc;
+    if (e0 != hipSuccess || e1 != hipSuccess) return fail(UMGAP_ERR_DEVICE, std::string("umgap_classify_records: ") + hipGetErrorString(e0 != hipSuccess ? e0 : e1));
+    if (h_bad[0] || h_bad[1]) return fail(UMGAP_ERR_INVALID, "umgap_classify_records: frag_offsets / read_frags are not non-decreasing offsets into the block");
     return UMGAP_OK;
 }

@@ -219,15 +219,45 @@ int umgap_taxonomy_create(const uint32_t* id, const uint32_t* parent, const uint
     return UMGAP_OK;
 }
 
+}  // extern "C"
+
+namespace umgap {
+uint32_t* defer_list_for(umgap_taxonomy* tx, hipStream_t stream, size_t bytes) {
+    std::lock_guard<std::mutex> g(tx->defer_mutex);
+    umgap_taxonomy::DeferList& L = tx->defer_lists[stream];
+    if (bytes > L.bytes) {
+        if (L.d) (void)hipFree(L.d);
+        L.d = nullptr;
+        L.bytes = 0;
+        hipError_t e = hipMalloc((void**)&L.d, bytes);
+        if (e != hipSuccess) { fail(UMGAP_ERR_NOMEM, std::string("hipMalloc(deferred-read list): ") + hipGetErrorString(e)); L.d = nullptr; return nullptr; }
+        L.bytes = bytes;
+    }
+    return L.d;
+}
+}  // namespace umgap
+
+extern "C" {
+
 void umgap_taxonomy_free(umgap_taxonomy* tx) {
     if (!tx) return;
     (void)hipSetDevice(tx->device);
+    // an index still bound to this taxonomy gets its taxon ids back first (its bound_to must not dangle)
+    while (!tx->bound_indexes.empty()) {
+        umgap_index* ix = tx->bound_indexes.back();
+        if (umgap_index_unbind_taxonomy(ix, tx) != UMGAP_OK) { ix->bound_to = nullptr; tx->bound_indexes.pop_back(); }
+    }
+    (void)hipDeviceSynchronize();
     void* ptrs[] = {tx->d_by_id, tx->d_err_kind, tx->d_err_payload, tx->d_err_dist, tx->d_parent_pre, tx->d_depth,
                     tx->d_id_of_pre, tx->d_snap_of_pre[0], tx->d_snap_of_pre[1], tx->d_psnap_of_pre[0], tx->d_psnap_of_pre[1],
-                    tx->d_sparse, tx->d_last_of_pre, tx->d_sparse8, tx->d_stage, tx->d_defer};
+                    tx->d_sparse, tx->d_last_of_pre, tx->d_sparse8, tx->d_stage};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    for (auto& kv : tx->defer_lists)
+        if (kv.second.d) (void)hipFree(kv.second.d);
     if (tx->stream) (void)hipStreamDestroy(tx->stream);
+    if (tx->stream2) (void)hipStreamDestroy(tx->stream2);
+    if (tx->h_flags) (void)hipHostFree(tx->h_flags);
     delete tx;
 }
 

@@ -21,6 +21,8 @@
 //
 // ~22 B per taxon (2.5 M taxa: ~55 MB): resident in the 256 MiB Infinity Cache, top levels in L2.
 #pragma once
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "common.hpp"
@@ -47,15 +49,26 @@ struct umgap_taxonomy {
     uint64_t* d_sparse8 = nullptr;                    // [levels8][n_blocks8] packed (depth << 32 | pos) minima over 8-blocks: per-lane O(1) LCA
     uint32_t n_blocks8 = 0, n_levels8 = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;     // second lane of umgap_classify_records (chunk c+1 uploads while chunk c computes)
+    uint32_t* h_flags = nullptr;       // pinned: per-lane "bad offsets" flags of umgap_classify_records
     // staging for the host-pointer umgap_aggregate
     void* d_stage = nullptr;
     size_t d_stage_bytes = 0;
-    // deferred-read list of the general aggregation (aggregate_general.hip)
-    uint32_t* d_defer = nullptr;
-    size_t d_defer_bytes = 0;
+    // deferred-read lists of the general aggregation (aggregate_general.hip), ONE PER STREAM: launches on one stream are
+    // ordered and may share a list, launches on different streams may overlap and must not (umgap::defer_list_for)
+    struct DeferList { uint32_t* d = nullptr; size_t bytes = 0; };
+    std::map<hipStream_t, DeferList> defer_lists;
+    std::mutex defer_mutex;
+    // indexes whose values are currently bound to this taxonomy (bind.hip): unbound again by umgap_taxonomy_free,
+    // dropped from the list by umgap_index_free
+    std::vector<umgap_index*> bound_indexes;
 };
 
 namespace umgap {
+// The calling stream's deferred-read list, at least `bytes` long (grown with hipFree + hipMalloc, which wait for the
+// device, so a launch still using the old list has finished).  nullptr + error set on failure.
+uint32_t* defer_list_for(umgap_taxonomy* tx, hipStream_t stream, size_t bytes);
+
 struct TaxView {
     const uint2* by_id;
     const uint8_t* err_kind;
