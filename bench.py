@@ -9,17 +9,22 @@ BASELINE.json configs[2]: 50 M synthetic 150-bp pairs (84 9-mers each) against t
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: reads are independent units, so by default every rank holds a replica of the table and
-classifies its own reads with no data-path collective (weak scaling).  The north star's sharded
-mode (index sharded by bucket range, keys / hits exchanged with RCCL all-to-all over xGMI) is
-then measured too and reported under "sharded" in the same line (`--mode sharded` makes it the
-headline instead; `--mode replica` skips it).
-Prints ONE JSON line on rank 0 (contract: see the driver's prompt; DESIGN.md "Measurement").
+`python bench.py --gpus N` without RANK in the environment starts its N ranks itself (one process per
+GPU, rendezvous on 127.0.0.1) BEFORE anything touches the GPU and exits with their status.
+
+N > 1 (or --force-dist): reads are independent units, so the headline `value` is the replica mode --
+every rank holds the table and classifies its own reads with no data-path collective (weak scaling).
+The north star's sharded mode (index sharded by bucket range, k-mers and hits exchanged over RCCL inside
+libumgap_hip.so: umgap_sharded_classify9_dev) is measured in the same run and reported under "sharded"
+(`--mode sharded` makes it the headline, `--mode replica` skips it).  "ranks_seen" comes from an RCCL
+all-reduce.  Prints ONE JSON line on rank 0 (contract: the driver's prompt; DESIGN.md "Measurement").
+`--rehearse-cpu` runs the launch / rendezvous / reduction plumbing on CPU over gloo (CI).
 """
 import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -28,7 +33,9 @@ sys.path.insert(0, ROOT)
 BYTES_PER_LOOKUP = 76          # 64 B bucket + 8 B key + 4 B taxon          
 KMERS = 84
 BYTES_PER_PAIR = KMERS * BYTES_PER_LOOKUP + KMERS * 4 + 4   # 6724: + hits re-read by aggregate + result
+BYTES_PER_PAIR_FUSED = KMERS * (64 + 8) + 4                 # 6052: what the fused kernel must move (hits never leave the CU)
 HBM_PEAK_GBPS = 8000.0         # MI355X HBM3E spec (MI355X_MICROARCH.md)
+METRIC = "paired reads/sec classified (9-mer high-precision)"
 
 
 def parse():
@@ -42,13 +49,46 @@ def parse():
     ap.add_argument("--n-keys", type=int, default=int(os.environ.get("UMGAP_BENCH_KEYS", 8_000_000_000)))
     ap.add_argument("--n-tax", type=int, default=2_500_000)
     ap.add_argument("--load-factor", type=float, default=0.5)
+    ap.add_argument("--pieces", type=int, default=8, help="pipelined pieces of a sharded step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only: no seedextend / other pipelines / workload sweep / end-to-end legs")
+    ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--seedextend", action="store_true", help="insert seedextend -g1 -s3 per fragment between lookup and aggregate")
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (process group, barriers, sharded extra) even with one rank")
     ap.add_argument("--unfused", action="store_true", help="run lookup and aggregate as separate kernels (hits through HBM)")
     ap.add_argument("--no-bind", action="store_true", help="keep taxon ids in the table (the fused kernel then gathers {pre,last} by id)")
+    ap.add_argument("--rehearse-cpu", action="store_true", help="CPU/gloo rehearsal of the multi-rank plumbing (no GPU, no kernels)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds before self-launched ranks are killed")
     return ap.parse_args()
+
+
+def rehearse_cpu(args):
+    """The N-rank plumbing of this file without a GPU: rendezvous, ranks_seen, the unique-id hand-off, barriers, max over
+    ranks, one JSON line from rank 0.  tests/test_dist_gloo.py runs it at world 2."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29517")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    seen = torch.ones(1, dtype=torch.int64)
+    dist.all_reduce(seen)
+    box = [bytes(range(128)) if rank == 0 else None]       # stands in for umgap_comm_unique_id()
+    dist.broadcast_object_list(box, src=0)
+    assert box[0] == bytes(range(128))
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.001 * (1 + rank))                     # ranks differ: the max over ranks is rank world-1's time
+    dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": METRIC, "value": None, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(1e3 * float(t.item()) / max(1, args.steps), 3), "rehearsal": "cpu/gloo: plumbing only, nothing measured",
+                          "ranks_seen": int(seen.item())}), flush=True)
+    dist.destroy_process_group()
 
 
 def cpu_baseline(n_tax, ids, parents, valid, rank, taxonomy_handle, d_taxon_of_row, d_row_of_id, device):
@@ -79,9 +119,14 @@ def cpu_baseline(n_tax, ids, parents, valid, rank, taxonomy_handle, d_taxon_of_r
                                                   synth.MUL_A, synth.ADD_B, synth.SEED_READS, 0, n_pairs, KMERS, _dev_ptr(d_keys), _stream_ptr(None)))
     torch.cuda.synchronize()
     q = d_keys.cpu().numpy().view(np.uint64)
+    # lookup stage: all cores (rayon in the reference).  The sample is looked up `reps` times inside ONE threaded call, so
+    # that starting `cores` threads (tens of ms at 256 threads) does not pass for lookup time
+    reps = 8
+    qq = np.tile(q, reps)
     t0 = time.perf_counter()
-    hits = cpu_index.lookup9(q, 0, nthreads=cores)       # lookup stage: all cores (rayon in the reference)
-    t_lookup = time.perf_counter() - t0
+    hits = cpu_index.lookup9(qq, 0, nthreads=cores)[: len(q)]
+    t_lookup = (time.perf_counter() - t0) / reps
+    del qq
     agg = O.Aggregator(O.Taxonomy.from_arrays(ids, parents, valid, rank), "tree", "lca*")
     offs = np.arange(n_pairs + 1, dtype=np.uint64) * KMERS
     t0 = time.perf_counter()
@@ -92,66 +137,92 @@ def cpu_baseline(n_tax, ids, parents, valid, rank, taxonomy_handle, d_taxon_of_r
     import shutil
     have_ref = bool(shutil.which("cargo")) or bool(shutil.which("rustc"))
     return {"value": round(value, 1), "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": "restated CPU baseline (not the Rust binary: %s on this box); %d pairs (%d lookups) vs a %d-key sorted-array index; "
-                      "lookup on %d threads %.2fs, LCA* -l2 on 1 thread %.2fs; pipelined stages => rate of the slower one" % (
+            "sample": "restated CPU baseline (not the Rust binary: %s on this box), kernel path only (no text): %d pairs (%d lookups) vs a %d-key "
+                      "sorted-array index; lookup on %d threads %.3f s per sample (%.1f M lookups/s, %d passes in one threaded call), LCA* -l2 on 1 "
+                      "thread %.2f s; pipelined stages => rate of the slower one" % (
                           "a Rust toolchain exists but the reference sources do not travel" if have_ref else "no cargo/rustc",
-                          n_pairs, n_pairs * KMERS, n_cpu_keys, cores, t_lookup, t_agg)}
+                          n_pairs, n_pairs * KMERS, n_cpu_keys, cores, t_lookup, n_pairs * KMERS / t_lookup / 1e6, reps, t_agg)}
 
 
-def sharded_extra(args, w, keys, rank, world, local_rank, device, B, d_hits, d_taxon, d_status, main_out):
-    """The north star's sharded-index mode, measured after the headline run.  A watchdog prints the
-    headline line and exits if a collective stalls, so this section can never cost the main result."""
-    import threading
+class Watchdog:
+    """A collective that stalls must not pass for success: prints what there is and exits non-zero."""
 
+    def __init__(self, seconds, rank, line):
+        self.t = threading.Timer(seconds, self.bail)
+        self.t.daemon = True
+        self.rank, self.line, self.seconds = rank, line, seconds
+
+    def bail(self):
+        if self.rank == 0:
+            self.line["sharded"] = {"error": "timed out after %d s" % self.seconds}
+            print(json.dumps(self.line), flush=True)
+        os._exit(3)
+
+    def __enter__(self):
+        self.t.start()
+        return self
+
+    def __exit__(self, *a):
+        self.t.cancel()
+
+
+def sharded_section(args, w, keys, rank, world, device, B, d_taxon, d_status, want_first):
+    """One sharded step = umgap_sharded_classify9_dev over the rank's B pairs (pack -> RCCL exchange -> probe on the owner ->
+    RCCL exchange back -> gather + LCA*), `pieces` pipelined pieces; checked bit for bit against the replica's answers."""
     import torch
     import torch.distributed as dist
     from umgap_amd import synth
     from umgap_amd.api import Index
-    from umgap_amd.dist import GpuOps, ShardedLookup
+    from umgap_amd.dist import Comm, Sharded
+    if w.index is not None:     # the replica has done its job: its HBM goes to the shard and the exchange buffers
+        w.index.close()
+        w.index = None
+    torch.cuda.empty_cache()
+    shard = Index.synthetic(args.n_keys, w.d_taxon_of_row, synth.MUL_A, synth.ADD_B, args.load_factor, rank, world)
+    comm = Comm.from_torch_distributed(device.index or 0)
+    per_piece = -(-B // args.pieces)
+    sh = Sharded(shard, w.taxonomy, comm, per_piece * args.pieces * KMERS, pieces=args.pieces)
+    steps = max(2, min(5, args.steps))
 
-    def bail():
-        if rank == 0:
-            main_out["sharded"] = {"error": "timed out after 180 s"}
-            print(json.dumps(main_out), flush=True)
-        os._exit(0)
+    def one(i):
+        sh.classify9(keys[i % len(keys)], B, KMERS, d_taxon, d_status, method="tree", strategy="lca*", lower_bound=2.0)
 
-    dog = threading.Timer(180.0, bail)
-    dog.daemon = True
-    dog.start()
-    try:
-        if w.index is not None:     # the replica has done its job: its HBM goes to the shard and the exchange buffers
-            w.index.close()
-            w.index = None
-        shard = Index.synthetic(args.n_keys, w.d_taxon_of_row, synth.MUL_A, synth.ADD_B, args.load_factor, rank, world)
-        sl = ShardedLookup(GpuOps(shard, device), rank, world, B * KMERS, chunks=4)
-        steps = max(2, min(3, args.steps))
-
-        def one(i):
-            sl.lookup(keys[i % len(keys)], d_hits)
-            w.taxonomy.aggregate_strided_dev(d_hits, KMERS, B, d_taxon, d_status, method="tree", strategy="lca*", lower_bound=2.0)
-
-        one(0)
-        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            one(i + 1)
-        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        sl.check_overflow()
-        st = d_status.cpu().numpy()
-        assert ((st == 0) | (st == 1)).all()
-        res = {"value": round(world * steps * B / float(el.item()), 1), "unit": "pairs/s", "steps": steps,
-               "ms_per_step": round(1e3 * float(el.item()) / steps, 3), "shard_table_GB": round(shard.table_bytes / 1e9, 2),
-               "exchange": "all_to_all_single: 8 B/key out, 4 B/key back, %d keys per rank per step, 4 pieces over 2 streams" % (B * KMERS)}
-    except Exception as e:  # noqa: BLE001
-        res = {"error": "%s: %s" % (type(e).__name__, e)}
-    dog.cancel()
+    one(0)
+    sh.check()
+    same = bool(torch.equal(d_taxon, want_first[0]) and torch.equal(d_status, want_first[1]))
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(i + 1)
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    sh.check()
+    ok = torch.tensor([int(same)], device=device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    out_b, back_b = sh.wire_bytes_per_step_and_peer()
+    res = {"value": round(world * steps * B / float(el.item()), 1), "unit": "pairs/s", "steps": steps,
+           "ms_per_step": round(1e3 * float(el.item()) / steps, 3), "shard_table_GB": round(shard.table_bytes / 1e9, 2),
+           "probe_kernel_ms_first_piece": round(sh.probe_ms(), 3), "pieces": sh.pieces, "value_bytes": sh.value_bytes,
+           "bit_identical_to_replica": bool(ok.item()),
+           "exchange": "RCCL send/recv groups inside libumgap_hip.so: 6 B per k-mer out, %d B per hit back; per step and peer %.1f MB out + %.1f MB back "
+                       "(%d k-mers per rank and step, %d pieces over 3 streams)" % (sh.value_bytes, out_b / 1e6, back_b / 1e6, B * KMERS, sh.pieces)}
+    sh.close()
+    comm.close()
     return res
 
 
 def main():
     args = parse()
+    if "RANK" not in os.environ and args.gpus > 1:
+        # self-launch: one fresh process per rank, started before this process has touched the GPU
+        from umgap_amd.dist import spawn_ranks
+        rc = spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, timeout=args.launch_timeout)
+        if rc:
+            sys.stderr.write("bench.py: a rank failed or stalled (exit status %d)\n" % rc)
+        sys.exit(rc)
+    if args.rehearse_cpu:
+        return rehearse_cpu(args)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -159,17 +230,20 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+    if world != args.gpus and rank == 0:
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d; running %d ranks\n" % (args.gpus, world, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     multi = world > 1 or args.force_dist
+    ranks_seen = 1
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        seen = torch.ones(1, dtype=torch.int64, device=device)
+        dist.all_reduce(seen)                       # RCCL: every rank is really there
+        ranks_seen = int(seen.item())
     mode = args.mode
     if mode == "auto":
         mode = "replica"
@@ -177,28 +251,24 @@ def main():
     from umgap_amd import synth
     from umgap_amd.api import classify9_dev, seedextend_dev
     t_setup = time.perf_counter()
-    sharded_mode = mode == "sharded" and world > 1
-    w = synth.SyntheticWorkload(n_tax=args.n_tax, n_keys=args.n_keys, id_space=int(args.n_tax * 1.4), load_factor=args.load_factor,
-                                device=local_rank, shard=rank if sharded_mode else 0, n_shards=world if sharded_mode else 1)
+    w = synth.SyntheticWorkload(n_tax=args.n_tax, n_keys=args.n_keys, id_space=int(args.n_tax * 1.4), load_factor=args.load_factor, device=local_rank)
     torch.cuda.synchronize()
     B = args.pairs_per_step
     n_batches = max(1, min(args.batches, args.steps + args.warmup))
     # every rank owns different pairs: rank r, batch b -> pairs [(r*n_batches + b) * B, +B)
     keys = [w.reads((rank * n_batches + b) * B, B) for b in range(n_batches)]
-    d_hits = torch.empty(B * KMERS, dtype=torch.int32, device=device)
+    d_hits = torch.empty(B * KMERS, dtype=torch.int32, device=device) if args.unfused else None
     d_taxon = torch.empty(B, dtype=torch.int32, device=device)
     d_status = torch.empty(B, dtype=torch.int32, device=device)
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
 
-    sharded = None
-    if sharded_mode:
-        from umgap_amd.dist import GpuOps, ShardedLookup
-        sharded = ShardedLookup(GpuOps(w.index, device), rank, world, B * KMERS, chunks=4)
-
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-
-    fused = not args.unfused and not sharded_mode
+    fused = not args.unfused
+    # the answers of batch 0 on the plain (unbound) table: what every later variant must reproduce bit for bit
+    classify9_dev(w.index, w.taxonomy, keys[0], B, KMERS, d_taxon, d_status, method="tree", lower_bound=2.0)
+    torch.cuda.synchronize()
+    want_first = (d_taxon.clone(), d_status.clone())
     # the table is bound to the taxonomy for the fused LCA* kernel (values = preorder interval codes: no by-id gathers);
     # a one-time in-place pass, undone before the kernels that want taxon ids
     t_bind = None
@@ -210,22 +280,17 @@ def main():
 
     def step(i, timed_idx=None):
         k = keys[i % n_batches]
+        if timed_idx is not None:
+            ev[timed_idx][0].record()
         if fused:
-            if timed_idx is not None:
-                ev[timed_idx][0].record()
             classify9_dev(w.index, w.taxonomy, k, B, KMERS, d_taxon, d_status, method="tree", lower_bound=2.0,
                           fragments_per_read=2 if args.seedextend else 0, min_seed_size=3, max_gap_size=1)
             if timed_idx is not None:
                 ev[timed_idx][1].record()
             return
-        if sharded is None:
-            if timed_idx is not None:
-                ev[timed_idx][0].record()
-            w.index.lookup9_dev(k, d_hits, miss_value=0)
-            if timed_idx is not None:
-                ev[timed_idx][1].record()
-        else:
-            sharded.lookup(k, d_hits, ev[timed_idx] if timed_idx is not None else None)
+        w.index.lookup9_dev(k, d_hits, miss_value=0)
+        if timed_idx is not None:
+            ev[timed_idx][1].record()
         if args.seedextend:
             seedextend_dev(d_hits, stride=KMERS // 2, n_records=2 * B, min_seed_size=3, max_gap_size=1)
         w.taxonomy.aggregate_strided_dev(d_hits, KMERS, B, d_taxon, d_status, method="tree", strategy="lca*", lower_bound=2.0)
@@ -249,11 +314,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    if sharded is not None:
-        sharded.check_overflow()
-    # sanity on the last batch: statuses are OK/EMPTY only and the answers are not degenerate
+    # sanity on the last batch: statuses are OK/EMPTY only; and batch 0 through the timed configuration equals the plain one
     st = d_status.cpu().numpy()
     assert ((st == 0) | (st == 1)).all(), "unexpected per-read status in the bench output"
+    bit_exact = None
+    if not args.seedextend:
+        step(0)
+        torch.cuda.synchronize()
+        bit_exact = bool(torch.equal(d_taxon, want_first[0]) and torch.equal(d_status, want_first[1]))
+        assert bit_exact, "the timed kernel's answers differ from the plain table's"
 
     kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
     lookups = B * KMERS
@@ -263,23 +332,27 @@ def main():
     value = world * args.steps * B / elapsed
 
     out = {
-        "metric": "paired reads/sec classified (9-mer high-precision)", "value": round(value, 1), "unit": "pairs/s",
+        "metric": METRIC, "value": round(value, 1), "unit": "pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64 keys / u32 taxa (integer, no MFMA)",
-        "data": "synthetic",
+        "data": "synthetic", "ranks_seen": ranks_seen,
         "config": {"workload": "BASELINE.json configs[2]: synthetic 150 bp paired reads (84 packed 9-mers per pair), "
                                "%d resident batches x %d pairs per GPU; lookup%s + taxa2agg -l2 -a lca*%s" % (
                                    n_batches, B, " + seedextend -g1 -s3" if args.seedextend else "", " (one fused kernel)" if fused else ""),
                    "pairs_per_step_per_gpu": B, "n_keys": args.n_keys, "n_tax": args.n_tax,
                    "table_GB": round(w.index.table_bytes / 1e9, 2), "load_factor": args.load_factor,
-                   "parallelism": ("1 GPU" if world == 1 else "%s x%d" % (mode, world)), "setup_s": round(t_setup, 1),
-                   "table_bound_to_taxonomy": t_bind is not None, "bind_s": None if t_bind is None else round(t_bind, 3)},
+                   "parallelism": ("1 GPU" if world == 1 else "replica x%d (table on every GPU, reads split, no data-path collective)" % world),
+                   "setup_s": round(t_setup, 1), "table_bound_to_taxonomy": t_bind is not None, "bind_s": None if t_bind is None else round(t_bind, 3),
+                   "parity": {"answers_bit_identical_to_unbound_table": bit_exact,
+                              "lookup_parity": "contract-only: fst::Map::get is third-party and no reference test touches it (DESIGN.md §2); "
+                                               "aggregation pinned by the reference's golden vectors"}},
         "roofline": {"bound": "hbm", "kernel": "k_classify9" if fused else "k_lookup9", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None, "traffic_source": None,
                      "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(kernel_ms, 3),
+                     "frac_on_fused_bytes": round(B * BYTES_PER_PAIR_FUSED / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if fused and kernel_ms > 0 else None,
                      "whole_path_frac": round(value / world * BYTES_PER_PAIR / 1e9 / HBM_PEAK_GBPS, 4)},
     }
-    # PMC-derived traffic, if a profile of this round has been committed (profiles/traffic.json)
+    # PMC-derived traffic: NOT measured in this run -- read back from the committed profile of the same kernel and sizes
     tp = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tp):
         try:
@@ -287,9 +360,11 @@ def main():
             if (tj.get("pairs_per_step") == B and tj.get("n_keys") == args.n_keys and tj.get("kernel") == out["roofline"]["kernel"]
                     and tj.get("load_factor", args.load_factor) == args.load_factor):
                 out["roofline"]["traffic"] = tj["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE + WRITE_SIZE of %s, tag %s; not re-measured in this run)" % (tj.get("kernel"), tj.get("tag"))
         except Exception:
             pass
-    if world == 1 and fused and not args.seedextend:
+    extras = world == 1 and fused and not args.seedextend and not args.no_extras
+    if extras:
         # the full high-precision pipeline: seedextend -g1 -s3 per fragment between probe and aggregate
         # (scripts/umgap-analyse.sh:302), same batches, same kernel with the stage switched on
         def se_step(i):
@@ -304,7 +379,6 @@ def main():
         el = time.perf_counter() - t1
         out["with_seedextend"] = {"value": round(args.steps * B / el, 1), "unit": "pairs/s", "ms_per_step": round(1e3 * el / args.steps, 3),
                                   "pipeline": "probe -> seedextend -g1 -s3 (per read end) -> taxa2agg -l2 -a lca*, one fused kernel"}
-    if world == 1 and fused and not args.seedextend:
         # the filter + aggregate stages of the two 9-mer sensitivity pipelines (scripts/umgap-analyse.sh:277-288) through the
         # fused kernel for the other strategies, on the same batches (the script feeds them 6-frame translations, ~500 k-mers
         # per pair, which go through umgap_classify_records); reported next to the headline, not part of it
@@ -323,8 +397,43 @@ def main():
             el = time.perf_counter() - t1
             others[name] = {"value": round(n_o * B / el, 1), "unit": "pairs/s", "ms_per_step": round(1e3 * el / n_o, 3)}
         out["other_pipelines"] = others
+        # sensitivity of the headline to the read mix: the share of k-mers with unrelated
+        # taxa decides how many reads need the range-minimum LCA; -l 1 keeps every singleton.  Each leg: one batch generated
+        # with that mix, timed on the bound table, and checked bit for bit against the unbound kernel afterwards.
+        sweep, sweep_keys = {}, {}
+        legs = (("unrelated 10 % (headline mix: 60 % on the root path, 30 % misses)", 60, 10, 2.0), ("unrelated 30 % (40 % path)", 40, 30, 2.0),
+                ("unrelated 50 % (20 % path)", 20, 50, 2.0), ("unrelated 10 %, -l 1", 60, 10, 1.0), ("unrelated 50 %, -l 1", 20, 50, 1.0))
+        n_s = min(args.steps, 5)
+        kbuf = torch.empty(B * KMERS, dtype=torch.int64, device=device)
+        got = {}
+        for name, pp, up, lb in legs:
+            if (pp, up) != sweep_keys.get("mix"):
+                w.reads(900_000_000, B, d_keys=kbuf, path_percent=pp, unrelated_percent=up)
+                sweep_keys["mix"] = (pp, up)
+            classify9_dev(w.index, w.taxonomy, kbuf, B, KMERS, d_taxon, d_status, method="tree", lower_bound=lb)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n_s):
+                classify9_dev(w.index, w.taxonomy, kbuf, B, KMERS, d_taxon, d_status, method="tree", lower_bound=lb)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t1
+            got[name] = (d_taxon.clone(), d_status.clone())
+            sweep[name] = {"value": round(n_s * B / el, 1), "unit": "pairs/s", "ms_per_step": round(1e3 * el / n_s, 3),
+                           "classified_below_root": round(float(((d_status == 0) & (d_taxon != 1)).float().mean().item()), 3)}
+        out["workload_sweep"] = sweep
     if w.index is not None and w.index.bound:
-        w.index.unbind(w.taxonomy)          # what follows (sharded mode) wants taxon ids
+        w.index.unbind(w.taxonomy)          # what follows wants taxon ids
+    if extras:
+        # bit-exact check of the sweep legs after the timed region: the unbound kernel on the same batches
+        sweep_keys.clear()
+        for name, pp, up, lb in legs:
+            if (pp, up) != sweep_keys.get("mix"):
+                w.reads(900_000_000, B, d_keys=kbuf, path_percent=pp, unrelated_percent=up)
+                sweep_keys["mix"] = (pp, up)
+            classify9_dev(w.index, w.taxonomy, kbuf, B, KMERS, d_taxon, d_status, method="tree", lower_bound=lb)
+            torch.cuda.synchronize()
+            sweep[name]["bit_identical_to_unbound_kernel"] = bool(torch.equal(d_taxon, got[name][0]) and torch.equal(d_status, got[name][1]))
+        del kbuf, got
     if rank == 0 and world == 1 and not args.no_gather:
         # measured random-sector gather ceilings over the same table (SURVEY.md §8d second denominator)
         n = 1 << 28
@@ -343,10 +452,31 @@ def main():
         del d_out
         out["roofline"]["measured_gather_GBps"] = ceil
         out["roofline"]["frac_of_measured_64B_gather"] = round(lookups * 64 / (kernel_ms * 1e-3) / 1e9 / ceil["64"], 4)
-    if multi and args.mode == "auto":
-        out["sharded"] = sharded_extra(args, w, keys, rank, world, local_rank, device, B, d_hits, d_taxon, d_status, out)
+    if multi and args.mode != "replica":
+        with Watchdog(300, rank, out):
+            try:
+                out["sharded"] = sharded_section(args, w, keys, rank, world, device, B, d_taxon, d_status, want_first)
+            except Exception as e:  # noqa: BLE001
+                out["sharded"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if args.mode == "sharded" and "value" in out["sharded"]:
+            out["replica"] = {"value": out["value"], "ms_per_step": out["ms_per_step"]}
+            out["value"], out["ms_per_step"] = out["sharded"]["value"], out["sharded"]["ms_per_step"]
+            out["config"]["parallelism"] = "sharded x%d (bucket-range shards, RCCL exchange)" % world
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.n_tax, w.ids, w.parents, w.valid, w.rank, w.taxonomy._h, w.d_taxon_of_row, w.d_row_of_id, device)
+    if rank == 0 and world == 1 and extras and not args.no_end_to_end and os.path.exists(os.path.join(ROOT, "umgap_amd", "bin", "umgap")):
+        # text in -> text out through the unchanged script's chain, beside the oracle's same four stages (tools/end_to_end.py)
+        if w.index is not None:
+            w.index.close()
+            w.index = None
+        del keys
+        torch.cuda.empty_cache()
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import end_to_end
+            out["end_to_end"], out["cpu_baseline_end_to_end"] = end_to_end.run()
+        except Exception as e:  # noqa: BLE001
+            out["end_to_end"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if multi:

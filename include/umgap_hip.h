@@ -276,6 +276,53 @@ int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int method, int 
                            size_t n_reads, int seedextend, uint32_t min_seed_size, uint32_t max_gap_size,
                            uint32_t* out_taxon, uint32_t* out_status);
 
+/* ---- the index sharded over the GPUs of one node (BASELINE.json north_star; replaces the single resident
+ * `umgap prot2kmer2lca -m -o -s <socket>` server of scripts/umgap-analyse.sh:257-264) ----------------------------------
+ * One rank per GPU (a process, or a thread of one process).  Rank r holds shard r of n (umgap_index_open_shard,
+ * umgap_index_set_shard, umgap_synth_index_build_shard) and a replica of the taxonomy, classifies its own reads and
+ * exchanges k-mers / hits with the other ranks over RCCL (xGMI): 6 bytes per k-mer out, 3 bytes per hit back (4 when a
+ * value of the table needs them).  See DESIGN.md "Multi-GPU" for the pipeline and the bytes per step and peer.
+ *
+ * Communicator: rank 0 calls umgap_comm_unique_id and hands the 128 bytes to every rank (any channel: a file, MPI,
+ * torch.distributed); every rank then calls umgap_comm_init_rank (collective).  RCCL is resolved at run time (dlopen of
+ * librccl.so.1), so nothing here is needed to load the library for single-GPU use.  umgap_comm_init_local creates all
+ * `world` ranks of a communicator whose exchange is device-to-device copies on ONE GPU, for rehearsing the N-rank
+ * protocol where a single GPU is at hand: each rank must then be driven from its own host thread. */
+typedef struct umgap_comm umgap_comm;
+typedef struct umgap_sharded umgap_sharded;
+int umgap_comm_unique_id(uint8_t* id128);
+int umgap_comm_init_rank(const uint8_t* id128, int world, int rank, int device, umgap_comm** out);
+int umgap_comm_init_local(int world, int device, umgap_comm** out_ranks /* world handles */);
+int umgap_comm_world(const umgap_comm* c);
+int umgap_comm_rank(const umgap_comm* c);
+void umgap_comm_free(umgap_comm* c);
+/* The sharded table of one rank: `shard` must be shard rank-of-world of the communicator; `tx` (nullable) is needed by
+ * umgap_sharded_classify9_dev.  max_keys_per_call bounds one call; it is cut into `pieces` (0 = 8) pipelined pieces of
+ * whole reads, so make it a multiple of pieces * kmers_per_read.  slack (0.03 if out of range): head room of the
+ * fixed-size exchange regions over the mean.  Collective (the ranks agree on the value width).  Borrowed handles must
+ * outlive the group. */
+int umgap_sharded_create(umgap_index* shard, umgap_taxonomy* tx, umgap_comm* comm, uint64_t max_keys_per_call,
+                         uint32_t pieces, double slack, umgap_sharded** out);
+void umgap_sharded_free(umgap_sharded* sh);
+uint32_t umgap_sharded_value_bytes(const umgap_sharded* sh);  /* 3 or 4 */
+uint64_t umgap_sharded_region_slots(const umgap_sharded* sh); /* slots per peer and piece: a peer receives 6 x this out, value_bytes x this back */
+uint32_t umgap_sharded_pieces(const umgap_sharded* sh);
+/* get() over the whole sharded table: as umgap_index_lookup9_dev.  Collective: every rank calls it the same number of
+ * times (n may differ, 0 included); enqueues on internal streams ordered after `stream` and joins them back into it. */
+int umgap_sharded_lookup9_dev(umgap_sharded* sh, const uint64_t* d_keys45, size_t n, uint32_t miss_value,
+                              uint32_t* d_out_taxa, void* stream);
+/* The fused 9-mer pipeline over the sharded table: as umgap_classify9_dev / umgap_classify9_strategy_dev (any strategy),
+ * results bit-identical to theirs on a whole table.  Collective like the lookup. */
+int umgap_sharded_classify9_dev(umgap_sharded* sh, int method, int strategy, float factor, float lower_bound,
+                                int ranked_only, const uint64_t* d_keys45, size_t n_reads, uint32_t kmers_per_read,
+                                uint32_t fragments_per_read, uint32_t min_seed_size, uint32_t max_gap_size,
+                                uint32_t* d_out_taxon, uint32_t* d_out_status, void* stream);
+/* Waits for the device and reports (UMGAP_ERR_BUILD) whether an exchange region overflowed in any call since the last
+ * check -- the affected k-mers were answered with a miss, so those calls' results are not to be used. */
+int umgap_sharded_check(umgap_sharded* sh);
+/* Duration of the local probe kernel of the first piece of the last call (measurement: bench.py's roofline). */
+int umgap_sharded_probe_ms(umgap_sharded* sh, float* ms);
+
 /* Page-locked host memory for the arrays passed to the host-pointer entry points (any size; free with umgap_host_free). */
 int umgap_host_alloc(size_t bytes, void** out);
 void umgap_host_free(void* p);
@@ -287,7 +334,9 @@ int umgap_index_lookup9_lane_dev(umgap_index* ix, const uint64_t* d_keys45, size
 /* Random-sector gather microbenchmark over the index table: each of n probes reads bytes_per_probe
  * (16..256) bytes at a bucket chosen by a hash of its index; out receives a checksum per probe.
  * bytes_per_probe | (k << 16) selects the pure-read form: k probes in flight per lane and one store per
- * lane at the end instead of one per probe (d_out still needs n entries). */
+ * lane at the end instead of one per probe (d_out still needs n entries).  Bits 24-27: footprint shift (the probes stay
+ * inside the first num_buckets >> shift buckets); bits 28-30: 1 + cache-policy variant (sc0 / sc1 / nt combinations) of
+ * the 64-byte, 8-in-flight form.  tools/ceiling_probe.py drives them. */
 int umgap_bench_gather_dev(umgap_index* ix, size_t n, uint32_t bytes_per_probe, uint32_t* d_out, void* stream);
 /* Synthetic workload generators (DESIGN.md "Synthetic workload"), all on device. */
 int umgap_synth_index_build(uint64_t n_keys, const uint32_t* d_taxon_of_row, uint64_t n_tax,
@@ -309,6 +358,13 @@ int umgap_index_build_windows9_dev(const uint8_t* d_bytes, const uint64_t* d_off
 int umgap_synth_prot_reads_dev(const uint8_t* d_proteome, uint64_t n_proteome_fragments, uint32_t fragment_len,
                                uint64_t seed, uint64_t first_read, size_t n_reads, uint32_t fragments_per_read,
                                uint32_t mutations_per_mille, uint8_t* d_out, int device, void* stream);
+/* Reads of the benchmark: per pair, path_percent of the k-mers are members whose taxon lies on the root path of the pair's
+ * source taxon, unrelated_percent are members with unrelated taxa (slot pairs share one), the rest are non-members (1 % of
+ * all k-mers carry an 'X').  umgap_synth_reads9_dev is the 60 / 10 mix of the headline; bench.py's workload_sweep varies it. */
+int umgap_synth_reads9_mix_dev(const umgap_taxonomy* tx, const uint32_t* d_taxon_of_row, const uint32_t* d_row_of_id,
+                               uint64_t n_tax, uint64_t n_keys, uint64_t mul_a, uint64_t add_b, uint64_t seed,
+                               uint64_t first_pair, uint64_t n_pairs, uint32_t kmers_per_pair, uint32_t path_percent,
+                               uint32_t unrelated_percent, uint64_t* d_keys45, void* stream);
 int umgap_synth_reads9_dev(const umgap_taxonomy* tx, const uint32_t* d_taxon_of_row,
                            const uint32_t* d_row_of_id, uint64_t n_tax, uint64_t n_keys, uint64_t mul_a,
                            uint64_t add_b, uint64_t seed, uint64_t first_pair, uint64_t n_pairs,

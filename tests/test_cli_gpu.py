@@ -225,7 +225,7 @@ def test_seedextend_slice_panic_exit_101(world, proteome_small):
     reference source; the oracle agrees).  Both the text filter and the fused command reproduce it."""
     rc, out, err = run(["seedextend", "-g1", "-s1"], b">a\n7\n7\n>b\n0\n5\n>c\n7\n")
     assert rc == 101 and out == b">a\n7\n7\n", (rc, out, err)
-    assert O.run_cli(["seedextend", "-g1", "-s1"], b">a\n7\n7\n>b\n0\n5\n>c\n7\n")[:2] == (101, b">a\n7\n7\n")
+    assert O.run_cli(["seedextend", "-g", "1", "-s", "1"], b">a\n7\n7\n>b\n0\n5\n>c\n7\n")[:2] == (101, b">a\n7\n7\n")
     # without the leading miss nothing panics
     rc, out, _ = run(["seedextend", "-g1", "-s1"], b">b\n5\n0\n")
     assert rc == 0 and out == b">b\n5\n"

@@ -1,95 +1,58 @@
-"""The N > 1 path on CPU: two gloo ranks run the sharded-lookup exchange (partition -> all-to-all
-keys -> local probe -> all-to-all taxa -> gather) with numpy stand-ins for the two HIP kernels.
-What is under test is the distributed plumbing of umgap_amd/dist.py (routing, fixed-capacity
-regions, padding, permutation), which is identical on the GPU box."""
+"""The N > 1 plumbing on CPU (world size 2, gloo).  The data path of the sharded mode lives in libumgap_hip.so
+(umgap_amd/csrc/shard.hip: RCCL send/recv groups) and is checked on the GPU with all ranks on one card
+(tests/test_gpu_parity.py::test_sharded_table_*); what can and must work without a GPU is everything around it:
+`python bench.py --gpus 2` starting its own ranks before touching the GPU, the rendezvous on 127.0.0.1, ranks_seen,
+the hand-off of rank 0's unique id, barriers, the max over ranks, ONE JSON line from rank 0, and a non-zero exit when a
+rank fails or stalls."""
+import json
 import os
-import socket
+import subprocess
+import sys
+import textwrap
 
-import numpy as np
-import torch
-import torch.distributed as dist
-import torch.multiprocessing as mp
-
-from umgap_amd.dist import ShardedLookup
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-class CpuOps:
-    """Owner = key mod world; each rank answers only the keys it owns from a dict."""
-
-    def __init__(self, rank, world, table):
-        self.rank, self.world = rank, world
-        self.table = {k: v for k, v in table.items() if k % world == rank}
-
-    def empty(self, n, dtype):
-        return torch.empty(n, dtype=dtype)
-
-    def partition(self, keys, n_shards, cap, send, perm, cursor, overflow):
-        send.fill_(-1)
-        cursor.zero_()
-        overflow.zero_()
-        k = keys.numpy()
-        for i, key in enumerate(k):
-            o = int(key) % n_shards
-            pos = int(cursor[o])
-            if pos < cap:
-                send[o * cap + pos] = int(key)
-                perm[i] = o * cap + pos
-            else:
-                perm[i] = 0
-                overflow[0] = 1
-            cursor[o] += 1
-
-    def lookup(self, keys, out):
-        k = keys.numpy()
-        out.copy_(torch.tensor([self.table.get(int(x), 0) if x >= 0 else 0 for x in k], dtype=torch.int32))
+def test_bench_self_launch_world2_gloo():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--rehearse-cpu"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                      # rank 0 only
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["steps"] == 3 and j["value"] is None and "rehearsal" in j
+    assert j["ms_per_step"] >= 2.0                     # the max over ranks: rank 1 sleeps 2 ms per step, rank 0 only 1
 
 
-def _worker(rank, world, port, n_keys, results):
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    rng = np.random.default_rng(1234)
-    universe = rng.choice(1 << 40, 5000, replace=False)
-    table = {int(k): int(v) for k, v in zip(universe, rng.integers(1, 1 << 30, len(universe)))}
-    rng_r = np.random.default_rng(100 + rank)
-    # each rank owns different reads: a mix of members and strangers, ragged vs the region size
-    mine = np.concatenate([rng_r.choice(universe, n_keys - n_keys // 3), rng_r.integers(1 << 41, 1 << 42, n_keys // 3)])
-    rng_r.shuffle(mine)
-    sl = ShardedLookup(CpuOps(rank, world, table), rank, world, n_keys, slack=0.5)
-    hits = torch.empty(n_keys, dtype=torch.int32)
-    for _ in range(2):  # buffers are reused across steps
-        sl.lookup(torch.from_numpy(mine.astype(np.int64)), hits)
-    sl.check_overflow()
-    want = np.array([table.get(int(k), 0) for k in mine], np.int32)
-    ok = bool((hits.numpy() == want).all()) and bool((want != 0).any())
-    # a skewed batch must trip the overflow check instead of silently dropping keys
-    skew = torch.from_numpy(np.full(n_keys, int(universe[0]) // world * world, np.int64))
-    tight = ShardedLookup(CpuOps(rank, world, table), rank, world, n_keys, slack=0.0)
-    tight.cap = n_keys // world   # regions too small for a batch that goes to one owner
-    tight.lookup(skew, hits)
-    try:
-        tight.check_overflow()
-        tripped = False
-    except RuntimeError:
-        tripped = True
-    flag = torch.tensor([int(ok), int(tripped)])
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-    if rank == 0:
-        results.put(flag.tolist())
-    dist.destroy_process_group()
+def test_spawn_ranks_reports_failure_and_stall(tmp_path):
+    from umgap_amd.dist import spawn_ranks
+    bad = tmp_path / "bad.py"
+    bad.write_text(textwrap.dedent("""
+        import os, sys
+        sys.exit(7 if os.environ["RANK"] == "1" else 0)
+    """))
+    assert spawn_ranks(str(bad), [], 2, timeout=60) == 7
+    hang = tmp_path / "hang.py"
+    hang.write_text(textwrap.dedent("""
+        import os, time
+        assert os.environ["WORLD_SIZE"] == "3" and os.environ["MASTER_ADDR"] == "127.0.0.1"
+        time.sleep(600 if os.environ["RANK"] == "2" else 0)
+    """))
+    assert spawn_ranks(str(hang), [], 3, timeout=3) != 0      # the stalled rank is killed and reported
 
 
-def test_sharded_lookup_world2_gloo():
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    results = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, 3001, results)) for r in range(2)]
-    for p in procs:
-        p.start()
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
-    ok, tripped = results.get(timeout=10)
-    assert ok == 1 and tripped == 1
+def test_owner_ranges_cover_the_table_once():
+    """Shard r of n owns the home buckets [nb*r/n, nb*(r+1)/n) (alloc_table in index.hip = owner_of_bucket in shard.hip):
+    a partition of [0, nb) for every n, so every key has exactly one owner."""
+    for nb in (1 << 17, 3 << 17, 12345 << 17):
+        for n in (1, 2, 3, 5, 8):
+            edges = [nb * r // n for r in range(n + 1)]
+            assert edges[0] == 0 and edges[-1] == nb and all(a < b for a, b in zip(edges, edges[1:]))
+            for b in (0, 1, nb // 3, nb // 2, nb - 1) + tuple(e for e in edges[1:-1]) + tuple(e - 1 for e in edges[1:]):
+                s = b * n // nb
+                while nb * s // n > b:
+                    s -= 1
+                while nb * (s + 1) // n <= b:
+                    s += 1
+                assert edges[s] <= b < edges[s + 1]

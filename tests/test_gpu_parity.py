@@ -947,32 +947,163 @@ def test_device_pointer_variants(api, torch_cuda):
         assert (dt.cpu().numpy().view(np.uint32) == t).all() and (ds.cpu().numpy().view(np.uint32) == s).all()
 
 
-def test_sharded_lookup_pipelined_nccl_world1(api, torch_cuda):
-    """umgap_amd.dist.ShardedLookup with the two-stream pipelining, on a world-size-1 RCCL group: the stream
-    fork/join and buffer reuse must give the same hits as the plain probe."""
+def _run_ranks(world, fn):
+    """Drives `fn(rank)` from one host thread per rank (the local communicator's exchange blocks until every rank has
+    arrived); re-raises the first failure."""
+    import threading
+    errs = [None] * world
+
+    def body(r):
+        try:
+            fn(r)
+        except BaseException as e:  # noqa: BLE001
+            errs[r] = e
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(300)
+        assert not t.is_alive(), "a rank is stuck in the exchange"
+    for e in errs:
+        if e is not None:
+            raise e
+
+
+@pytest.mark.parametrize("world,pieces", [(1, 1), (2, 3), (3, 8), (8, 4)])
+def test_sharded_table_local_ranks_match_whole_table(api, torch_cuda, world, pieces):
+    """The N-rank sharded path of the C ABI (pack 6-byte keys -> exchange -> probe on the owner -> 3-byte values back ->
+    gather + [seedextend] + aggregate), all ranks on this one GPU through the local communicator: every rank's answers are
+    bit-identical to the whole-table kernels, for the plain get() and for the fused pipeline with every strategy."""
     torch = torch_cuda
-    import torch.distributed as dist
-    from umgap_amd.dist import GpuOps, ShardedLookup
+    from umgap_amd.dist import Comm, Sharded
+    from umgap_amd.synth import ADD_B, MUL_A, SyntheticWorkload
+    n_tax, n_keys, stride = 20_000, 1_500_000, 84
+    w = SyntheticWorkload(n_tax=n_tax, n_keys=n_keys)
+    n_reads = [4001 + 173 * r for r in range(world)]                       # ragged: every rank owns a different number of reads
+    max_keys = (max(n_reads) + pieces) // pieces * pieces * stride
+    keys = [w.reads(10_000 * r, n_reads[r], kmers_per_pair=stride) for r in range(world)]
+    want_hits = [w.index.lookup9_dev(k, miss_value=0).clone() for k in keys]
+    modes = [("tree", "lca*", 0, 2.0), ("tree", "lca*", 2, 2.0), ("tree", "hybrid", 2, 1.0), ("rmq", "mrtl", 2, 1.0), ("rmq", "hybrid", 0, 0.0)]
+    want = {}
+    for r in range(world):
+        for m in modes:
+            t = torch.empty(n_reads[r], dtype=torch.int32, device="cuda")
+            s = torch.empty_like(t)
+            api.classify9_dev(w.index, w.taxonomy, keys[r], n_reads[r], stride, t, s, method=m[0], strategy=m[1], factor=0.25, lower_bound=m[3],
+                              fragments_per_read=m[2], min_seed_size=3, max_gap_size=1)
+            want[(r, m)] = (t, s)
+    torch.cuda.synchronize()
+    shards = [api.Index.synthetic(n_keys, w.d_taxon_of_row, MUL_A, ADD_B, 0.0, r, world) for r in range(world)]
+    comms = Comm.local(world)
+    got_hits = [torch.full_like(want_hits[r], -7) for r in range(world)]
+    got = {}
+
+    def rank_body(r):
+        torch.cuda.set_device(0)
+        sh = Sharded(shards[r], w.taxonomy, comms[r], max_keys, pieces=pieces)
+        assert sh.value_bytes == 3 and sh.pieces == pieces
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            for _ in range(2):                                              # buffer sets are reused across calls
+                sh.lookup9(keys[r], got_hits[r], miss_value=0, stream=st)
+            for m in modes:
+                t = torch.full((n_reads[r],), -1, dtype=torch.int32, device="cuda")
+                s = torch.full_like(t, -1)
+                sh.classify9(keys[r], n_reads[r], stride, t, s, method=m[0], strategy=m[1], factor=0.25, lower_bound=m[3], fragments_per_read=m[2],
+                             min_seed_size=3, max_gap_size=1, stream=st)
+                got[(r, m)] = (t, s)
+        st.synchronize()
+        sh.check()
+        sh.close()
+
+    _run_ranks(world, rank_body)
+    torch.cuda.synchronize()
+    for r in range(world):
+        assert torch.equal(got_hits[r], want_hits[r]), (world, r)
+        assert (want_hits[r] != 0).float().mean().item() > 0.5
+        for m in modes:
+            assert torch.equal(got[(r, m)][1], want[(r, m)][1]), (world, r, m, "status")
+            assert torch.equal(got[(r, m)][0], want[(r, m)][0]), (world, r, m, "taxon")
+
+
+def test_sharded_table_wide_values_and_overflow(api, torch_cuda):
+    """Values that need 4 bytes switch the return format; a region that overflows is reported by check() (sticky over
+    several calls) and its keys are answered with a miss, never with another key's value."""
+    torch = torch_cuda
+    from umgap_amd.dist import Comm, Sharded
+    rng = np.random.default_rng(77)
+    keys = np.unique(rng.integers(0, 1 << 45, 200_000, dtype=np.uint64))
+    vals = rng.integers(1 << 24, 1 << 32, len(keys), dtype=np.uint64).astype(np.uint32)
+    vals[vals == 0xFFFFFFFF] = 5
+    world = 2
+    whole = api.Index.build(keys, vals)
+    q = np.concatenate([keys[:60_000], rng.integers(0, 1 << 45, 20_000, dtype=np.uint64), np.array([1 << 45, (1 << 64) - 1], np.uint64)])
+    d_q = torch.from_numpy(q.view(np.int64)).cuda()
+    want = whole.lookup9_dev(d_q, miss_value=9).clone()
+    shards = []
+    for r in range(world):
+        ix = api.Index.build(keys, vals)
+        ix.set_shard(r, world)
+        shards.append(ix)
+    comms = Comm.local(world)
+    outs = [torch.empty(len(q), dtype=torch.int32, device="cuda") for _ in range(world)]
+    tripped = [False] * world
+
+    def rank_body(r):
+        torch.cuda.set_device(0)
+        sh = Sharded(shards[r], None, comms[r], len(q), pieces=2)
+        assert sh.value_bytes == 4
+        st = torch.cuda.Stream()
+        sh.lookup9(d_q, outs[r], miss_value=9, stream=st)
+        sh.check()
+        # a batch that goes to ONE owner overflows its region: flagged, and still flagged after a clean call
+        skew = d_q[:1].repeat(len(q))
+        o2 = torch.empty(len(q), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        sh.lookup9(skew, o2, miss_value=9, stream=st)
+        sh.lookup9(d_q, outs[r], miss_value=9, stream=st)
+        try:
+            sh.check()
+        except api.UmgapError as e:
+            tripped[r] = "overflowed" in e.message
+        v = o2.cpu().numpy().view(np.uint32)
+        assert set(np.unique(v).tolist()) <= {9, int(want[0].item()) & 0xFFFFFFFF}      # the right value or a miss, nothing else
+        sh.check()                                                                      # the flag is cleared by the report
+        sh.close()
+
+    _run_ranks(world, rank_body)
+    torch.cuda.synchronize()
+    for r in range(world):
+        assert torch.equal(outs[r], want)
+    assert all(tripped)
+
+
+def test_sharded_table_rccl_world1(api, torch_cuda):
+    """The RCCL transport (ncclSend/ncclRecv groups resolved with dlopen) on a one-rank communicator: a self-exchange,
+    which is all a one-GPU box can run; the N-rank protocol itself is covered by the local ranks above."""
+    torch = torch_cuda
+    from umgap_amd.dist import Comm, Sharded
     from umgap_amd.synth import SyntheticWorkload
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        w = SyntheticWorkload(n_tax=5000, n_keys=600_000)
-        keys = w.reads(0, 5001)
-        want = w.index.lookup9_dev(keys).clone()
-        dev = torch.device("cuda", 0)
-        for chunks in (1, 4, 5):
-            sl = ShardedLookup(GpuOps(w.index, dev), 0, 1, keys.numel(), chunks=chunks)
-            hits = torch.empty(keys.numel(), dtype=torch.int32, device=dev)
-            for _ in range(3):
-                hits.fill_(-7)
-                sl.lookup(keys, hits)
-            torch.cuda.synchronize()
-            sl.check_overflow()
-            assert torch.equal(hits, want), chunks
-    finally:
-        dist.destroy_process_group()
+    w = SyntheticWorkload(n_tax=5000, n_keys=600_000)
+    n_reads, stride = 5001, 84
+    keys = w.reads(0, n_reads)
+    want_hits = w.index.lookup9_dev(keys).clone()
+    t0 = torch.empty(n_reads, dtype=torch.int32, device="cuda")
+    s0 = torch.empty_like(t0)
+    api.classify9_dev(w.index, w.taxonomy, keys, n_reads, stride, t0, s0, method="tree", lower_bound=2.0, fragments_per_read=2, min_seed_size=3, max_gap_size=1)
+    comm = Comm.init_rank(Comm.unique_id(), 1, 0, 0)
+    assert comm.world == 1 and comm.rank == 0
+    sh = Sharded(w.index, w.taxonomy, comm, (n_reads + 4) // 5 * 5 * stride, pieces=5)
+    hits = torch.full_like(want_hits, -7)
+    t1, s1 = torch.full_like(t0, -1), torch.full_like(s0, -1)
+    for _ in range(3):
+        sh.lookup9(keys, hits)
+        sh.classify9(keys, n_reads, stride, t1, s1, method="tree", lower_bound=2.0, fragments_per_read=2, min_seed_size=3, max_gap_size=1)
+    sh.check()
+    assert torch.equal(hits, want_hits) and torch.equal(t1, t0) and torch.equal(s1, s0)
+    assert sh.probe_ms() > 0
+    sh.close()
+    comm.close()
 
 
 # ---------------------------------------------------------------------------------------------

@@ -4,7 +4,8 @@
    policy   : the same with every sc0/sc1/nt cache-policy combination (k_gather_policy<0..7>)
    classify : the fused headline kernel on one 10 M-pair batch
 Run plain it prints the rates; run under `rocprofv3 --pmc ...` (tools/pmc_ceiling.sh) the same launches carry counters.
-    python tools/ceiling_probe.py [gather|policy|classify|all] [n_keys]"""
+   footprint: the gather confined to 1/8 ... 1/16384 of the table
+    python tools/ceiling_probe.py [gather|policy|footprint|classify|all] [n_keys]"""
 import json
 import os
 import sys
@@ -40,6 +41,12 @@ if what in ("gather", "all"):
     res["gather64_inflight8_Greq_per_s"] = round(n / ms / 1e6, 2)
     ms = timed(lambda: w.index.bench_gather_dev(n, 128 | (4 << 16), d_out))
     res["gather128_inflight4_Greq_per_s"] = round(n / ms / 1e6, 2)
+if what in ("footprint", "all"):
+    # the same gather confined to the first table_bytes >> shift bytes: where does the rate leave the 50 G/s plateau?
+    res["footprint_Greq_per_s"] = {}
+    for shift in (0, 3, 6, 8, 10, 12, 14):
+        ms = timed(lambda: w.index.bench_gather_dev(n, 64 | (8 << 16) | (shift << 24), d_out))
+        res["footprint_Greq_per_s"]["%.4g MB" % (w.index.table_bytes / 2 ** shift / 1e6)] = round(n / ms / 1e6, 2)
 if what in ("policy", "all"):
     names = ["none", "nt", "sc0", "sc1", "sc0 sc1", "sc0 nt", "sc1 nt", "sc0 sc1 nt"]
     res["policy_Greq_per_s"] = {}

@@ -106,6 +106,21 @@ def load():
         "umgap_index_unbind_taxonomy": (i32, [vp, vp]),
         "umgap_index_is_bound": (i32, [vp]),
         "umgap_classify_records": (i32, [vp, vp, i32, i32, f32, f32, i32, vp, vp, sz, vp, sz, i32, u32, u32, vp, vp]),
+        "umgap_comm_unique_id": (i32, [vp]),
+        "umgap_comm_init_rank": (i32, [vp, i32, i32, i32, pp]),
+        "umgap_comm_init_local": (i32, [i32, i32, pp]),
+        "umgap_comm_world": (i32, [vp]),
+        "umgap_comm_rank": (i32, [vp]),
+        "umgap_comm_free": (None, [vp]),
+        "umgap_sharded_create": (i32, [vp, vp, vp, u64, u32, dbl, pp]),
+        "umgap_sharded_free": (None, [vp]),
+        "umgap_sharded_value_bytes": (u32, [vp]),
+        "umgap_sharded_region_slots": (u64, [vp]),
+        "umgap_sharded_pieces": (u32, [vp]),
+        "umgap_sharded_lookup9_dev": (i32, [vp, vp, sz, u32, vp, vp]),
+        "umgap_sharded_classify9_dev": (i32, [vp, i32, i32, f32, f32, i32, vp, sz, u32, u32, u32, u32, vp, vp, vp]),
+        "umgap_sharded_check": (i32, [vp]),
+        "umgap_sharded_probe_ms": (i32, [vp, C.POINTER(C.c_float)]),
         "umgap_host_alloc": (i32, [sz, pp]),
         "umgap_host_free": (None, [vp]),
         "umgap_index_build_windows9_dev": (i32, [vp, vp, vp, sz, u32, u64, dbl, i32, pp]),
@@ -117,6 +132,7 @@ def load():
         "umgap_synth_index_build_shard": (i32, [u64, vp, u64, u64, u64, dbl, i32, u32, u32, pp]),
         "umgap_synth_peptides_dev": (i32, [u64, sz, u64, vp, vp, i32, vp]),
         "umgap_synth_reads9_dev": (i32, [vp, vp, vp, u64, u64, u64, u64, u64, u64, u64, u32, vp, vp]),
+        "umgap_synth_reads9_mix_dev": (i32, [vp, vp, vp, u64, u64, u64, u64, u64, u64, u64, u32, u32, u32, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError if the build is stale

@@ -18,6 +18,7 @@
 #include "agg_general.hpp"
 #include "bound.hpp"
 #include "probe_common.hpp"
+#include "shard_wire.hpp"
 
 using namespace umgap;
 using namespace umgap::agg;
@@ -170,15 +171,31 @@ __device__ __forceinline__ void probe_group_to_strip(const TableView& T, const u
 }
 
 
+// Sharded mode (shard.hip): the hits of a group were looked up by the shards that own the keys and came back over the
+// exchange; key i of the batch sits at slot perm[i] of the returned buffer (NOSLOT: the key was not representable or its
+// send region overflowed => miss), 3 or 4 bytes per slot (shard_wire.hpp), all-ones = miss.
+__device__ __forceinline__ void gather_group_to_strip(const HitSource& H, size_t first_key, uint32_t nk, uint32_t* wtaxa, uint32_t lane) {
+    const uint32_t* pp = H.perm + first_key;
+    for (uint32_t i0 = 0; i0 < nk; i0 += 256) {     // four independent perm loads, then four independent gathers, per lane
+        uint32_t slot[4], val[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t i = i0 + 64 * u + lane; slot[u] = i < nk ? __builtin_nontemporal_load(pp + i) : wire::NOSLOT; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) val[u] = slot[u] == wire::NOSLOT ? 0u : wire::load_value(H.ret, slot[u], H.value_bytes);
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t i = i0 + 64 * u + lane; if (i < nk) wtaxa[i] = val[u]; }
+    }
+}
+
 // A wave owns a GROUP of G = min(STRIP / stride, 64 / frags) reads at a time: all their keys are
 // probed (chunks of 64, two chunks in flight) into the LDS strip, seedextend then runs on all
 // G * frags fragments at once (one lane each), and the G reads are aggregated one after another.
 // 94 VGPRs would allow 5 waves/SIMD; 4 measured faster (18.8 vs 19.6 ms): the request rate is the ceiling and a fifth
 // wave only adds contention.
-template <bool BOUND>
+template <bool BOUND, bool GATHER>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_classify9(TableView T, TaxView V, int method, const uint64_t* __restrict__ keys,
                                                    size_t n_reads, uint32_t stride, uint32_t frags, uint32_t min_seed, uint32_t max_gap,
-                                                   float lower_bound, uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status) {
+                                                   float lower_bound, uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status, HitSource H) {
     __shared__ uint32_t lds_taxa[4][STRIP], lds_keys[4][256], lds_cnt[4][256];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t* wtaxa = lds_taxa[wv];
@@ -196,8 +213,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const size_t r0 = g * G;
         const uint32_t nr = (uint32_t)min((size_t)G, n_reads - r0);
         const uint32_t nk = nr * stride;                   // keys of this group (<= STRIP)
-        const uint64_t* kp = keys + r0 * stride;
-        probe_group_to_strip(T, kp, nk, wtaxa, lane);
+        if (GATHER) gather_group_to_strip(H, r0 * stride, nk, wtaxa, lane);
+        else probe_group_to_strip(T, keys + r0 * stride, nk, wtaxa, lane);
         wave_lds_sync();
         // ---- seedextend per fragment (one lane per fragment, nr * frags <= 64) ----
         uint64_t se_panic = 0;   // lanes (= fragments) on which the reference's seedextend panics
@@ -227,13 +244,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // high-sensitivity pipeline, scripts/umgap-analyse.sh:283-288) and rmq-hybrid: probe and seedextend as above, then every
 // read of the group goes through general_read (agg_general.hpp) with the LDS strip as its source.  A read with more
 // than CAP distinct taxa is deferred to a second launch over the `todo` list with a larger scratch (one read per group).
-template <int CAP, int HCAP, bool BOUND>
+template <int CAP, int HCAP, bool BOUND, bool GATHER>
 __global__ __launch_bounds__(256) void k_classify9_general(TableView T, TaxView V, int method, int strategy, float factor,
                                                            const uint64_t* __restrict__ keys, size_t n_reads, uint32_t stride, uint32_t frags,
                                                            uint32_t min_seed, uint32_t max_gap, float lower_bound,
                                                            uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status,
                                                            const uint32_t* __restrict__ todo, const uint32_t* __restrict__ todo_count,
-                                                           uint32_t* __restrict__ defer, uint32_t* __restrict__ defer_count) {
+                                                           uint32_t* __restrict__ defer, uint32_t* __restrict__ defer_count, HitSource H) {
     __shared__ uint32_t lds_taxa[4][STRIP];
     __shared__ Scratch<CAP, HCAP> scratch[4];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -251,7 +268,8 @@ __global__ __launch_bounds__(256) void k_classify9_general(TableView T, TaxView 
         const size_t r0 = todo ? (size_t)todo[g] : g * G;
         const uint32_t nr = todo ? 1u : (uint32_t)min((size_t)G, n_reads - r0);
         const uint32_t nk = nr * stride;
-        probe_group_to_strip(T, keys + r0 * stride, nk, wtaxa, lane);
+        if (GATHER) gather_group_to_strip(H, r0 * stride, nk, wtaxa, lane);
+        else probe_group_to_strip(T, keys + r0 * stride, nk, wtaxa, lane);
         wave_lds_sync();
         uint64_t se_panic = 0;
         if (frags) {
@@ -459,6 +477,41 @@ __global__ __launch_bounds__(256, 4) void k_classify_prot9(TableView T, TaxView 
 
 }  // namespace
 
+namespace umgap {
+// seedextend + aggregate of reads whose hits came back over the exchange (shard.hip): the fused kernels with the probe stage
+// replaced by a gather through `perm`.  Same argument rules as umgap_classify9[_strategy]_dev, checked by the caller.
+int launch_classify9_from_hits(umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound, int ranked_only, const HitSource& H,
+                               size_t n_reads, uint32_t kmers_per_read, uint32_t fragments_per_read, uint32_t min_seed_size, uint32_t max_gap_size,
+                               uint32_t* d_out_taxon, uint32_t* d_out_status, hipStream_t s) {
+    if (!n_reads) return UMGAP_OK;
+    uint32_t G = 1024u / kmers_per_read;
+    if (fragments_per_read && G * fragments_per_read > 64) G = 64 / fragments_per_read;
+    size_t g = ((n_reads + G - 1) / G + 3) / 4;
+    if (g > 256 * 8) g = 256 * 8;
+    TaxView V = view_of(tx, ranked_only);
+    const TableView none{};
+    if (strategy == UMGAP_STRATEGY_LCA_STAR) {
+        hipLaunchKernelGGL((k_classify9<false, true>), dim3((unsigned)g), dim3(256), 0, s, none, V, method, (const uint64_t*)nullptr, n_reads, kmers_per_read,
+                           fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status, H);
+    } else {
+        if (n_reads >= 0xFFFFFFFFull) return fail(UMGAP_ERR_INVALID, "at most 2^32 - 2 reads per call");
+        uint32_t* d_defer = defer_list_for(tx, s, (n_reads + 1) * sizeof(uint32_t));
+        if (!d_defer) return UMGAP_ERR_NOMEM;
+        uint32_t* d_count = d_defer;
+        uint32_t* d_list = d_defer + 1;
+        UMGAP_HIP(hipMemsetAsync(d_count, 0, sizeof(uint32_t), s));
+        hipLaunchKernelGGL((k_classify9_general<64, 256, false, true>), dim3((unsigned)g), dim3(256), 0, s, none, V, method, strategy, factor, (const uint64_t*)nullptr,
+                           n_reads, kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status,
+                           (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_list, d_count, H);
+        hipLaunchKernelGGL((k_classify9_general<128, 512, false, true>), dim3(256), dim3(256), 0, s, none, V, method, strategy, factor, (const uint64_t*)nullptr,
+                           n_reads, kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status,
+                           (const uint32_t*)d_list, (const uint32_t*)d_count, (uint32_t*)nullptr, (uint32_t*)nullptr, H);
+    }
+    UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}
+}  // namespace umgap
+
 extern "C" int umgap_classify9_dev(umgap_index* ix, umgap_taxonomy* tx, int method, float lower_bound, int ranked_only,
                                    const uint64_t* d_keys45, size_t n_reads, uint32_t kmers_per_read, uint32_t fragments_per_read,
                                    uint32_t min_seed_size, uint32_t max_gap_size, uint32_t* d_out_taxon, uint32_t* d_out_status,
@@ -480,11 +533,11 @@ extern "C" int umgap_classify9_dev(umgap_index* ix, umgap_taxonomy* tx, int meth
     if (g > 256 * 8) g = 256 * 8;     // measured: 8 workgroups per CU (two resident rounds) beats 4 and 16
     if (ix->bound_to && ix->bound_to != tx) return fail(UMGAP_ERR_INVALID, "umgap_classify9_dev: the index is bound to another taxonomy");
     if (ix->bound_to)
-        hipLaunchKernelGGL(k_classify9<true>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, d_keys45, n_reads,
-                           kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status);
+        hipLaunchKernelGGL((k_classify9<true, false>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, d_keys45, n_reads,
+                           kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status, HitSource{});
     else
-        hipLaunchKernelGGL(k_classify9<false>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, d_keys45, n_reads,
-                           kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status);
+        hipLaunchKernelGGL((k_classify9<false, false>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, d_keys45, n_reads,
+                           kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status, HitSource{});
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
 }
@@ -524,12 +577,12 @@ extern "C" int umgap_classify9_strategy_dev(umgap_index* ix, umgap_taxonomy* tx,
     TaxView V = view_of(tx, ranked_only);
     // first pass, then the reads with more than 64 distinct taxa (at most 128: kmers_per_read <= 128)
 #define UMGAP_LAUNCH_GENERAL(BOUND)                                                                                                              \
-    hipLaunchKernelGGL((k_classify9_general<64, 256, BOUND>), dim3((unsigned)g), dim3(256), 0, s, ix->view, V, method, strategy, factor, d_keys45,      \
+    hipLaunchKernelGGL((k_classify9_general<64, 256, BOUND, false>), dim3((unsigned)g), dim3(256), 0, s, ix->view, V, method, strategy, factor, d_keys45, \
                        n_reads, kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status,           \
-                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_list, d_count);                                                       \
-    hipLaunchKernelGGL((k_classify9_general<128, 512, BOUND>), dim3(256), dim3(256), 0, s, ix->view, V, method, strategy, factor, d_keys45, n_reads, \
+                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_list, d_count, HitSource{});                                          \
+    hipLaunchKernelGGL((k_classify9_general<128, 512, BOUND, false>), dim3(256), dim3(256), 0, s, ix->view, V, method, strategy, factor, d_keys45, n_reads, \
                        kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status,                    \
-                       (const uint32_t*)d_list, (const uint32_t*)d_count, (uint32_t*)nullptr, (uint32_t*)nullptr)
+                       (const uint32_t*)d_list, (const uint32_t*)d_count, (uint32_t*)nullptr, (uint32_t*)nullptr, HitSource{})
     if (ix->bound_to) { UMGAP_LAUNCH_GENERAL(true); } else { UMGAP_LAUNCH_GENERAL(false); }
 #undef UMGAP_LAUNCH_GENERAL
     UMGAP_HIP(hipGetLastError());

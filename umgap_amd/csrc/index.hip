@@ -1095,7 +1095,10 @@ int umgap_bench_gather_dev(umgap_index* ix, size_t n, uint32_t bytes_per_probe, 
     int rc = use_device(ix->device);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    uint32_t nb = ix->view.n_resident;
+    // bits 24-27: footprint shift -- the probes are confined to the first n_resident >> shift buckets (TLB / cache reach experiments)
+    uint32_t nb = ix->view.n_resident >> ((bytes_per_probe >> 24) & 0xFu);
+    if (nb < 16) nb = 16;
+    bytes_per_probe &= ~(0xFu << 24);
     int g = 256 * 8;
     if (bytes_per_probe >> 28) {   // bits 28+: 1 + cache-policy variant of the 64-byte, 8-in-flight gather (k_gather_policy)
         switch ((bytes_per_probe >> 28) - 1) {
@@ -1112,7 +1115,7 @@ int umgap_bench_gather_dev(umgap_index* ix, size_t n, uint32_t bytes_per_probe, 
         return UMGAP_OK;
     }
     if (bytes_per_probe >> 16) {   // bits 16+: that many probes in flight per lane, no store per probe (pure random-read rate)
-        const uint32_t fl = bytes_per_probe >> 16, bytes = bytes_per_probe & 0xFFFFu;
+        const uint32_t fl = (bytes_per_probe >> 16) & 0xFFu, bytes = bytes_per_probe & 0xFFFFu;
         if (bytes == 64 && fl == 2) hipLaunchKernelGGL((k_gather_mlp<4, 2>), dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out);
         else if (bytes == 64 && fl == 4) hipLaunchKernelGGL((k_gather_mlp<4, 4>), dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out);
         else if (bytes == 64 && fl == 8) hipLaunchKernelGGL((k_gather_mlp<4, 8>), dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out);

@@ -87,7 +87,8 @@ __device__ __forceinline__ uint64_t synth_key(uint64_t i, uint64_t a, uint64_t b
 __global__ __launch_bounds__(256) void k_synth_reads(TaxView V, const uint32_t* __restrict__ taxon_of_row,
                                                      const uint32_t* __restrict__ row_of_id, uint64_t n_tax, uint64_t n_keys,
                                                      uint64_t a, uint64_t b, uint64_t seed, uint64_t first_pair,
-                                                     uint64_t n_pairs, uint32_t kpp, uint64_t* __restrict__ keys) {
+                                                     uint64_t n_pairs, uint32_t kpp, uint32_t path_pct, uint32_t unrel_pct,
+                                                     uint64_t* __restrict__ keys) {
     const uint64_t M = 512000000000ull;
     uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(256) void k_synth_reads(TaxView V, const uint32_t* 
         uint64_t rj = splitmix64(r0 + (uint64_t)(j + 1) * 0xD1B54A32D192ED03ull);
         uint32_t cls = (uint32_t)(rj % 100);
         uint64_t member = ~0ull;
-        if (cls < 60) {
+        if (cls < path_pct) {
             // member whose taxon lies on the source's root path: half the time the source itself
             uint32_t pre = V.by_id[taxon_of_row[s]].x;
             uint32_t depth = V.depth[pre];
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void k_synth_reads(TaxView V, const uint32_t* 
                 uint64_t cnt = (n_keys - ra + n_tax - 1) / n_tax;
                 member = ra + n_tax * ((rj >> 20) % cnt);
             }
-        } else if (cls < 70) {
+        } else if (cls < path_pct + unrel_pct) {
             // unrelated member; slots j and j^1 share it, so some unrelated taxa occur twice and
             // survive `-l 2`
             uint64_t rp = splitmix64(r0 + (uint64_t)((j >> 1) + 1) * 0xA24BAED4963EE407ull);
@@ -243,17 +244,24 @@ int umgap_synth_prot_reads_dev(const uint8_t* d_proteome, uint64_t n_proteome_fr
     return UMGAP_OK;
 }
 
-int umgap_synth_reads9_dev(const umgap_taxonomy* tx, const uint32_t* d_taxon_of_row, const uint32_t* d_row_of_id, uint64_t n_tax,
-                           uint64_t n_keys, uint64_t a, uint64_t b, uint64_t seed, uint64_t first_pair, uint64_t n_pairs,
-                           uint32_t kmers_per_pair, uint64_t* d_keys45, void* stream) {
+int umgap_synth_reads9_mix_dev(const umgap_taxonomy* tx, const uint32_t* d_taxon_of_row, const uint32_t* d_row_of_id, uint64_t n_tax,
+                               uint64_t n_keys, uint64_t a, uint64_t b, uint64_t seed, uint64_t first_pair, uint64_t n_pairs,
+                               uint32_t kmers_per_pair, uint32_t path_percent, uint32_t unrelated_percent, uint64_t* d_keys45, void* stream) {
     if (!tx || !d_taxon_of_row || !d_row_of_id || !d_keys45 || !n_tax || !n_keys || !kmers_per_pair) return fail(UMGAP_ERR_INVALID, "umgap_synth_reads9_dev: bad argument");
     if (n_keys >= 512000000000ull) return fail(UMGAP_ERR_INVALID, "umgap_synth_reads9_dev: n_keys must be < 20^9");
+    if (path_percent + unrelated_percent > 99) return fail(UMGAP_ERR_INVALID, "umgap_synth_reads9_mix_dev: path + unrelated must leave at least 1 % of misses");
     int rc = use_device(tx->device);
     if (rc) return rc;
     TaxView V = view_of(tx, 0);
-    if (n_pairs) hipLaunchKernelGGL(k_synth_reads, dim3(grid_for(n_pairs * kmers_per_pair)), dim3(256), 0, (hipStream_t)stream, V, d_taxon_of_row, d_row_of_id, n_tax, n_keys, a, b % 512000000000ull, seed, first_pair, n_pairs, kmers_per_pair, d_keys45);
+    if (n_pairs) hipLaunchKernelGGL(k_synth_reads, dim3(grid_for(n_pairs * kmers_per_pair)), dim3(256), 0, (hipStream_t)stream, V, d_taxon_of_row, d_row_of_id, n_tax, n_keys, a, b % 512000000000ull, seed, first_pair, n_pairs, kmers_per_pair, path_percent, unrelated_percent, d_keys45);
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
+}
+
+int umgap_synth_reads9_dev(const umgap_taxonomy* tx, const uint32_t* d_taxon_of_row, const uint32_t* d_row_of_id, uint64_t n_tax,
+                           uint64_t n_keys, uint64_t a, uint64_t b, uint64_t seed, uint64_t first_pair, uint64_t n_pairs,
+                           uint32_t kmers_per_pair, uint64_t* d_keys45, void* stream) {
+    return umgap_synth_reads9_mix_dev(tx, d_taxon_of_row, d_row_of_id, n_tax, n_keys, a, b, seed, first_pair, n_pairs, kmers_per_pair, 60, 10, d_keys45, stream);
 }
 
 }  // extern "C"

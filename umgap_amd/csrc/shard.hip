@@ -1,0 +1,684 @@
+// shard.hip — the 9-mer index sharded by bucket range over the GPUs of one node, behind the C ABI (round 2).
+//
+// What it replaces: scripts/umgap-analyse.sh:257-264 keeps ONE `umgap prot2kmer2lca -m -o -s <socket>` process holding the
+// whole ~100 GB index and every sample streams its peptides through that socket.  Here rank r (one process per GPU, or one
+// thread per GPU inside `umgap`) holds the home buckets [nb*r/N, nb*(r+1)/N) (+ halo) in its HBM, classifies its OWN reads and
+// asks the owners for the k-mers it does not hold:
+//
+//   pack      keys -> N regions by owner shard, 6 bytes per key (shard_wire.hpp), + perm[i] = slot of key i   k_shard_pack
+//   exchange  all-to-all of the regions over RCCL send/recv groups (xGMI)                                      comm_alltoall
+//   probe     the received keys against the local shard (the quad probe of probe_common.hpp), 3 or 4 B/value  k_shard_probe
+//   exchange  all-to-all of the values back
+//   classify  gather the hits of each read through perm into LDS -> [seedextend] -> aggregate                  classify.hip (GATHER)
+//
+// A batch is cut into pieces of whole reads that run as a software pipeline over three buffer sets, each with its own
+// stream: while piece t is packed and its keys travel, piece t-1 is probed and piece t-2 is aggregated.  The exchanges are
+// issued in the order A(0) A(1) R(0) A(2) R(1) ... on every rank (RCCL runs one communicator's operations in issue
+// order), so a return exchange never waits behind the key exchange of the piece after it.  Regions have a fixed capacity
+// (the mixer spreads keys evenly: expected K/N per region, `slack` on top), which keeps every message the same size on
+// every rank with no host round trip; a key that does not fit raises a sticky flag (umgap_sharded_check) and is answered
+// with a miss.  Reads never move; the taxonomy is replicated.
+//
+// Transports: RCCL (librccl.so.1 resolved at run time with dlopen, so the library loads without it; inside a PyTorch
+// process that is PyTorch's own copy) and a LOCAL hub -- all ranks are threads of one process on one GPU, the all-to-all is
+// device-to-device copies ordered with events -- which lets the whole N-rank protocol be checked on a single-GPU box.
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <condition_variable>
+#include <mutex>
+#include <vector>
+
+#include "probe_common.hpp"
+#include "shard_wire.hpp"
+#include "taxonomy.hpp"
+
+namespace umgap {
+int launch_classify9_from_hits(umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound, int ranked_only, const HitSource& H,
+                               size_t n_reads, uint32_t kmers_per_read, uint32_t fragments_per_read, uint32_t min_seed_size, uint32_t max_gap_size,
+                               uint32_t* d_out_taxon, uint32_t* d_out_status, hipStream_t s);
+}
+
+using namespace umgap;
+using namespace umgap::probe;
+
+// ------------------------------------------------------------------------------------------------------------------
+// RCCL, bound at run time
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+
+Rccl* rccl() {
+    static Rccl R;
+    static std::once_flag once;
+    std::call_once(once, []() {
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            R.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (R.lib) break;
+        }
+        if (!R.lib) { R.error = std::string("RCCL is not loadable: ") + dlerror(); return; }
+        auto sym = [&](const char* n) -> void* {
+            void* p = dlsym(R.lib, n);
+            if (!p && R.error.empty()) R.error = std::string("RCCL lacks ") + n;
+            return p;
+        };
+        R.GetUniqueId = (decltype(R.GetUniqueId))sym("ncclGetUniqueId");
+        R.CommInitRank = (decltype(R.CommInitRank))sym("ncclCommInitRank");
+        R.CommDestroy = (decltype(R.CommDestroy))sym("ncclCommDestroy");
+        R.GroupStart = (decltype(R.GroupStart))sym("ncclGroupStart");
+        R.GroupEnd = (decltype(R.GroupEnd))sym("ncclGroupEnd");
+        R.Send = (decltype(R.Send))sym("ncclSend");
+        R.Recv = (decltype(R.Recv))sym("ncclRecv");
+        R.AllReduce = (decltype(R.AllReduce))sym("ncclAllReduce");
+        R.GetErrorString = (decltype(R.GetErrorString))sym("ncclGetErrorString");
+    });
+    return &R;
+}
+
+#define UMGAP_NCCL(expr)                                                                                          \
+    do {                                                                                                          \
+        ncclResult_t r__ = (expr);                                                                                \
+        if (r__ != ncclSuccess) return ::umgap::fail(UMGAP_ERR_DEVICE, std::string(#expr) + ": " + rccl()->GetErrorString(r__)); \
+    } while (0)
+
+// all ranks of a LOCAL communicator: threads of this process sharing one GPU
+struct LocalHub {
+    int world = 0, device = 0, refs = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int arrived = 0;
+    uint64_t generation = 0;
+    std::vector<const void*> send;
+    std::vector<hipEvent_t> ready, done;
+    std::vector<uint32_t> vals;
+    void barrier() {
+        std::unique_lock<std::mutex> lk(m);
+        const uint64_t g = generation;
+        if (++arrived == world) { arrived = 0; generation++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return generation != g; });
+    }
+};
+
+}  // namespace
+
+struct umgap_comm {
+    int world = 1, rank = 0, device = 0;
+    ncclComm_t nccl = nullptr;   // RCCL transport
+    LocalHub* hub = nullptr;     // local transport
+};
+
+namespace {
+
+// every rank sends `bytes` to every rank (its own share included): recv region p <- rank p's send region `rank`
+int comm_alltoall(umgap_comm* c, const void* send, void* recv, size_t bytes, hipStream_t s) {
+    if (c->hub) {
+        LocalHub& H = *c->hub;
+        H.send[c->rank] = send;
+        UMGAP_HIP(hipEventRecord(H.ready[c->rank], s));
+        H.barrier();
+        for (int p = 0; p < c->world; p++) {
+            UMGAP_HIP(hipStreamWaitEvent(s, H.ready[p], 0));
+            UMGAP_HIP(hipMemcpyAsync((char*)recv + (size_t)p * bytes, (const char*)H.send[p] + (size_t)c->rank * bytes, bytes, hipMemcpyDeviceToDevice, s));
+        }
+        UMGAP_HIP(hipEventRecord(H.done[c->rank], s));
+        H.barrier();
+        for (int p = 0; p < c->world; p++) UMGAP_HIP(hipStreamWaitEvent(s, H.done[p], 0));   // a send buffer is rewritten only after every rank has read it
+        H.barrier();   // nobody re-records an event before every wait on it is enqueued
+        return UMGAP_OK;
+    }
+    Rccl* R = rccl();
+    UMGAP_NCCL(R->GroupStart());
+    for (int p = 0; p < c->world; p++) {
+        UMGAP_NCCL(R->Send((const char*)send + (size_t)p * bytes, bytes, ncclUint8, p, c->nccl, s));
+        UMGAP_NCCL(R->Recv((char*)recv + (size_t)p * bytes, bytes, ncclUint8, p, c->nccl, s));
+    }
+    UMGAP_NCCL(R->GroupEnd());
+    return UMGAP_OK;
+}
+
+// max over all ranks of a host value (set-up time only; synchronises)
+int comm_max_u32(umgap_comm* c, uint32_t* v) {
+    if (c->hub) {
+        LocalHub& H = *c->hub;
+        H.vals[c->rank] = *v;
+        H.barrier();
+        uint32_t m = 0;
+        for (uint32_t x : H.vals) m = x > m ? x : m;
+        H.barrier();
+        *v = m;
+        return UMGAP_OK;
+    }
+    uint32_t* d = nullptr;
+    UMGAP_HIP(hipMalloc((void**)&d, 4));
+    hipError_t e = hipMemcpy(d, v, 4, hipMemcpyHostToDevice);
+    ncclResult_t r = ncclSuccess;
+    if (e == hipSuccess) r = rccl()->AllReduce(d, d, 1, ncclUint32, ncclMax, c->nccl, nullptr);
+    if (e == hipSuccess && r == ncclSuccess) e = hipStreamSynchronize(nullptr);
+    if (e == hipSuccess && r == ncclSuccess) e = hipMemcpy(v, d, 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (r != ncclSuccess) return fail(UMGAP_ERR_DEVICE, std::string("ncclAllReduce: ") + rccl()->GetErrorString(r));
+    if (e != hipSuccess) return fail(UMGAP_ERR_DEVICE, std::string("comm_max_u32: ") + hipGetErrorString(e));
+    return UMGAP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t owner_of_bucket(uint32_t b, uint32_t nb, uint32_t world) {
+    // shard s owns home buckets [nb*s/world, nb*(s+1)/world)   (alloc_table in index.hip)
+    uint32_t s = (uint32_t)(((uint64_t)b * world) / nb);
+    while ((uint64_t)nb * s / world > b) s--;
+    while ((uint64_t)nb * (s + 1) / world <= b) s++;
+    return s;
+}
+
+// keys -> per-owner regions of `send` (6 bytes per key: h = mix45(key) split 32 + 16) and perm[i] = owner * cap + position.
+// A workgroup handles a tile of 4096 keys: positions inside the tile come from LDS counters (one ds_add per wave and
+// owner), then ONE global atomic per owner reserves the tile's range, so a tile's keys for one owner are contiguous and
+// the later gather through perm stays cache friendly.  Keys with bits above 45 (not a packed 9-mer) are not sent.
+constexpr int PACK_PER_THREAD = 16;
+__global__ __launch_bounds__(256) void k_shard_pack(const uint64_t* __restrict__ keys, size_t n, uint32_t m, uint32_t nb, uint32_t world,
+                                                    uint64_t cap, uint8_t* __restrict__ send, uint32_t* __restrict__ perm,
+                                                    unsigned long long* __restrict__ cursor, uint32_t* __restrict__ overflow) {
+    __shared__ uint32_t cnt[64];
+    __shared__ unsigned long long base[64];
+    const uint32_t lane = threadIdx.x & 63;
+    const size_t tile = (size_t)blockDim.x * PACK_PER_THREAD;
+    for (size_t t0 = (size_t)blockIdx.x * tile; t0 < n; t0 += (size_t)gridDim.x * tile) {
+        if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+        __syncthreads();
+        uint64_t h[PACK_PER_THREAD];
+        uint32_t own[PACK_PER_THREAD], lpos[PACK_PER_THREAD];
+#pragma unroll
+        for (int k = 0; k < PACK_PER_THREAD; k++) {
+            const size_t i = t0 + (size_t)k * blockDim.x + threadIdx.x;
+            own[k] = 0xFFFFFFFFu;
+            h[k] = 0;
+            lpos[k] = 0;
+            if (i < n) {
+                const uint64_t key = __builtin_nontemporal_load(keys + i);
+                if ((key >> 45) == 0) {
+                    h[k] = mix45(key);
+                    const uint32_t a = (uint32_t)(h[k] >> R_BITS), r = (uint32_t)h[k] & R_MASK;
+                    own[k] = owner_of_bucket(a * m + (uint32_t)(((uint64_t)r * m) >> R_BITS), nb, world);
+                }
+            }
+            for (uint32_t o = 0; o < world; o++) {     // wave-aggregated LDS reservation
+                const uint64_t mask = __ballot(own[k] == o);
+                if (!mask) continue;
+                const uint32_t leader = (uint32_t)__builtin_ctzll(mask);
+                uint32_t wbase = 0;
+                if (lane == leader) wbase = atomicAdd(&cnt[o], (uint32_t)__builtin_popcountll(mask));
+                wbase = (uint32_t)__shfl((int)wbase, (int)leader, 64);
+                if (own[k] == o) lpos[k] = wbase + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < world) base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], (unsigned long long)cnt[threadIdx.x]) : 0ull;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PACK_PER_THREAD; k++) {
+            const size_t i = t0 + (size_t)k * blockDim.x + threadIdx.x;
+            if (i >= n) continue;
+            uint32_t slot = wire::NOSLOT;
+            if (own[k] != 0xFFFFFFFFu) {
+                const uint64_t pos = base[own[k]] + lpos[k];
+                if (pos < cap) {
+                    uint8_t* region = send + (size_t)own[k] * cap * 6;
+                    reinterpret_cast<uint32_t*>(region)[pos] = (uint32_t)h[k];
+                    reinterpret_cast<uint16_t*>(region + cap * 4)[pos] = (uint16_t)(h[k] >> 32);
+                    slot = (uint32_t)((uint64_t)own[k] * cap + pos);
+                } else {
+                    atomicExch(overflow, 1u);   // sticky: umgap_sharded_check reports it; the key is answered with a miss
+                }
+            }
+            perm[i] = slot;
+        }
+        __syncthreads();
+    }
+}
+
+// the unused tail of every region carries "no key"
+__global__ __launch_bounds__(256) void k_shard_pad(uint8_t* __restrict__ send, const unsigned long long* __restrict__ cursor, uint64_t cap) {
+    const uint32_t o = blockIdx.y;
+    uint16_t* hi = reinterpret_cast<uint16_t*>(send + (size_t)o * cap * 6 + cap * 4);
+    const unsigned long long filled = cursor[o] < cap ? cursor[o] : cap;
+    for (uint64_t i = filled + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) hi[i] = (uint16_t)wire::HI_NOKEY;
+}
+
+// received keys (world regions x cap slots) -> one value per slot.  A wave takes 128 consecutive slots (cap is a multiple
+// of 128, so they share a region): two probe batches in flight, results gathered into packed words and stored coalesced.
+template <int VB>
+__global__ __launch_bounds__(256) void k_shard_probe(TableView T, const uint8_t* __restrict__ recv, uint64_t cap, uint64_t n_slots, uint32_t* __restrict__ ret) {
+    const uint32_t lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    constexpr uint32_t MISS = VB == 3 ? 0xFFFFFFu : 0xFFFFFFFFu;
+    for (uint64_t s0 = wave * 128; s0 < n_slots; s0 += nwaves * 128) {
+        const uint64_t region = s0 / cap, pos0 = s0 - region * cap;
+        const uint8_t* rb = recv + region * cap * 6;
+        const uint32_t* lo = reinterpret_cast<const uint32_t*>(rb) + pos0;
+        const uint16_t* hi = reinterpret_cast<const uint16_t*>(rb + cap * 4) + pos0;
+        ProbeBatch B[2];
+        uint32_t res[2][4];
+#pragma unroll
+        for (int b = 0; b < 2; b++) {
+            const uint32_t l = __builtin_nontemporal_load(lo + 64 * b + lane);
+            const uint32_t hh = __builtin_nontemporal_load(hi + 64 * b + lane);
+            uint32_t local = 0, tag = 0, valid = 0;
+            if (hh < (1u << 13)) {
+                const uint64_t h = ((uint64_t)hh << 32) | l;
+                const uint32_t a = (uint32_t)(h >> R_BITS);
+                tag = (uint32_t)h & R_MASK;
+                const uint32_t bkt = a * T.m + (uint32_t)(((uint64_t)tag * T.m) >> R_BITS);
+                local = bkt - T.home_lo;
+                valid = (bkt >= T.home_lo && bkt < T.home_hi) ? 1u : 0u;   // a key this shard does not own is a miss
+            }
+            probe_issue(T, local, tag | (valid << 31), lane, B[b]);
+        }
+        probe_eval_multi<2>(T, B, MISS, lane, res);
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint64_t s = s0 + 64 * b + 16 * r;          // slot of quad 0 of this round
+                if (VB == 4) {
+                    if (j == 0) ret[s + q] = res[b][r];
+                } else {
+                    // four 24-bit values -> three words: quad i = q & 3 of a group of four builds word i from its value and the next quad's
+                    const uint32_t t = res[b][r] & 0xFFFFFFu, tn = (uint32_t)__shfl_down((int)t, 4, 64);
+                    const uint32_t i = q & 3;
+                    const uint32_t w = i == 0 ? (t | (tn << 24)) : (i == 1 ? ((t >> 8) | (tn << 16)) : ((t >> 16) | (tn << 8)));
+                    if (j == 0 && i < 3) ret[(s >> 2) * 3 + (q >> 2) * 3 + i] = w;
+                }
+            }
+    }
+}
+
+// the plain sharded get(): out[i] = value of key i (perm order undone), or miss_value
+__global__ __launch_bounds__(256) void k_shard_unpermute(HitSource H, size_t n, uint32_t miss_value, uint32_t* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    const uint32_t mr = wire::miss_raw(H.value_bytes);
+    for (; i < n; i += step) {
+        const uint32_t slot = H.perm[i];
+        uint32_t v = mr;
+        if (slot != wire::NOSLOT) v = wire::load_raw(H.ret, slot, H.value_bytes);
+        out[i] = v == mr ? miss_value : v;
+    }
+}
+
+// largest value stored in the shard (decides 3- or 4-byte values on the wire)
+__global__ __launch_bounds__(256) void k_max_value(const uint64_t* __restrict__ slots, size_t n_slots, const uint32_t* __restrict__ stash_vals,
+                                                   uint32_t n_stash, uint32_t* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    uint32_t m = 0;
+    for (size_t k = i; k < n_slots + n_stash; k += step) {
+        uint32_t v;
+        if (k < n_slots) { const uint64_t s = slots[k]; if (s == EMPTY_SLOT) continue; v = (uint32_t)(s >> 32); }
+        else v = stash_vals[k - n_slots];
+        m = v > m ? v : m;
+    }
+    if (m) atomicMax(out, m);
+}
+
+constexpr int NSETS = 3;
+
+struct BufSet {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+    uint8_t *send_keys = nullptr, *recv_keys = nullptr;
+    uint32_t *ret_send = nullptr, *ret_recv = nullptr, *perm = nullptr;
+    unsigned long long* cursor = nullptr;
+};
+
+}  // namespace
+
+struct umgap_sharded {
+    umgap_index* ix = nullptr;
+    umgap_taxonomy* tx = nullptr;
+    umgap_comm* comm = nullptr;
+    int device = 0;
+    uint64_t max_keys = 0, piece_keys = 0, cap = 0;
+    uint32_t pieces = 1, value_bytes = 4;
+    void* block = nullptr;
+    size_t block_bytes = 0;
+    BufSet set[NSETS];
+    uint32_t* d_overflow = nullptr;
+    hipEvent_t ev_in = nullptr, ev_probe0 = nullptr, ev_probe1 = nullptr;
+    bool probe_timed = false;
+};
+
+namespace {
+
+int sharded_args_ok(umgap_sharded* sh, const char* who) {
+    if (!sh) return fail(UMGAP_ERR_INVALID, std::string(who) + ": null handle");
+    return use_device(sh->device);
+}
+
+// one piece, first half: pack -> pad -> key exchange -> local probe, all on the set's stream
+int piece_out(umgap_sharded* sh, BufSet& S, const uint64_t* d_keys, size_t nk, bool time_probe) {
+    const uint32_t W = (uint32_t)sh->comm->world;
+    const TableView& T = sh->ix->view;
+    hipStream_t s = S.stream;
+    UMGAP_HIP(hipMemsetAsync(S.cursor, 0, W * sizeof(unsigned long long), s));
+    const size_t tile = 256 * PACK_PER_THREAD;
+    unsigned g = (unsigned)std::min<size_t>((nk + tile - 1) / tile, 2048);
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(k_shard_pack, dim3(g), dim3(256), 0, s, d_keys, nk, T.m, T.nb, W, sh->cap, S.send_keys, S.perm, S.cursor, sh->d_overflow);
+    hipLaunchKernelGGL(k_shard_pad, dim3(64, W), dim3(256), 0, s, S.send_keys, S.cursor, sh->cap);
+    UMGAP_HIP(hipGetLastError());
+    int rc = comm_alltoall(sh->comm, S.send_keys, S.recv_keys, (size_t)sh->cap * 6, s);
+    if (rc) return rc;
+    const uint64_t n_slots = sh->cap * W;
+    unsigned gp = (unsigned)std::min<uint64_t>((n_slots / 128 + 3) / 4, 256 * 8);
+    if (gp < 1) gp = 1;
+    if (time_probe) UMGAP_HIP(hipEventRecord(sh->ev_probe0, s));
+    if (sh->value_bytes == 3) hipLaunchKernelGGL(k_shard_probe<3>, dim3(gp), dim3(256), 0, s, T, S.recv_keys, sh->cap, n_slots, S.ret_send);
+    else hipLaunchKernelGGL(k_shard_probe<4>, dim3(gp), dim3(256), 0, s, T, S.recv_keys, sh->cap, n_slots, S.ret_send);
+    UMGAP_HIP(hipGetLastError());
+    if (time_probe) { UMGAP_HIP(hipEventRecord(sh->ev_probe1, s)); sh->probe_timed = true; }
+    return UMGAP_OK;
+}
+
+int piece_back(umgap_sharded* sh, BufSet& S) {
+    return comm_alltoall(sh->comm, S.ret_send, S.ret_recv, (size_t)sh->cap * sh->value_bytes, S.stream);
+}
+
+int fork_streams(umgap_sharded* sh, hipStream_t caller) {
+    UMGAP_HIP(hipEventRecord(sh->ev_in, caller));
+    for (auto& S : sh->set) UMGAP_HIP(hipStreamWaitEvent(S.stream, sh->ev_in, 0));
+    return UMGAP_OK;
+}
+int join_streams(umgap_sharded* sh, hipStream_t caller) {
+    for (auto& S : sh->set) {
+        UMGAP_HIP(hipEventRecord(S.done, S.stream));
+        UMGAP_HIP(hipStreamWaitEvent(caller, S.done, 0));
+    }
+    return UMGAP_OK;
+}
+
+}  // namespace
+
+// ==================================================================================================================
+// C ABI
+// ==================================================================================================================
+extern "C" {
+
+int umgap_comm_unique_id(uint8_t* id128) {
+    if (!id128) return fail(UMGAP_ERR_INVALID, "umgap_comm_unique_id: null argument");
+    Rccl* R = rccl();
+    if (!R->error.empty()) return fail(UMGAP_ERR_DEVICE, R->error);
+    ncclUniqueId id;
+    UMGAP_NCCL(R->GetUniqueId(&id));
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(id128, &id, sizeof(id));
+    return UMGAP_OK;
+}
+
+int umgap_comm_init_rank(const uint8_t* id128, int world, int rank, int device, umgap_comm** out) {
+    if (!id128 || !out) return fail(UMGAP_ERR_INVALID, "umgap_comm_init_rank: null argument");
+    if (world < 1 || world > 64 || rank < 0 || rank >= world) return fail(UMGAP_ERR_INVALID, "umgap_comm_init_rank: need 0 <= rank < world <= 64");
+    int rc = use_device(device);
+    if (rc) return rc;
+    Rccl* R = rccl();
+    if (!R->error.empty()) return fail(UMGAP_ERR_DEVICE, R->error);
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    umgap_comm* c = new umgap_comm();
+    c->world = world;
+    c->rank = rank;
+    c->device = device;
+    ncclResult_t r = R->CommInitRank(&c->nccl, world, id, rank);
+    if (r != ncclSuccess) { delete c; return fail(UMGAP_ERR_DEVICE, std::string("ncclCommInitRank: ") + R->GetErrorString(r)); }
+    *out = c;
+    return UMGAP_OK;
+}
+
+int umgap_comm_init_local(int world, int device, umgap_comm** out_ranks) {
+    if (!out_ranks) return fail(UMGAP_ERR_INVALID, "umgap_comm_init_local: null argument");
+    if (world < 1 || world > 64) return fail(UMGAP_ERR_INVALID, "umgap_comm_init_local: need 1 <= world <= 64");
+    int rc = use_device(device);
+    if (rc) return rc;
+    LocalHub* H = new LocalHub();
+    H->world = world;
+    H->device = device;
+    H->refs = world;
+    H->send.assign(world, nullptr);
+    H->vals.assign(world, 0);
+    H->ready.assign(world, nullptr);
+    H->done.assign(world, nullptr);
+    for (int r = 0; r < world; r++) {
+        if (hipEventCreateWithFlags(&H->ready[r], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&H->done[r], hipEventDisableTiming) != hipSuccess) {
+            delete H;
+            return fail(UMGAP_ERR_DEVICE, "umgap_comm_init_local: hipEventCreate failed");
+        }
+    }
+    for (int r = 0; r < world; r++) {
+        umgap_comm* c = new umgap_comm();
+        c->world = world;
+        c->rank = r;
+        c->device = device;
+        c->hub = H;
+        out_ranks[r] = c;
+    }
+    return UMGAP_OK;
+}
+
+int umgap_comm_world(const umgap_comm* c) { return c ? c->world : 0; }
+int umgap_comm_rank(const umgap_comm* c) { return c ? c->rank : -1; }
+
+void umgap_comm_free(umgap_comm* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->nccl) (void)rccl()->CommDestroy(c->nccl);
+    if (c->hub) {
+        bool last;
+        { std::lock_guard<std::mutex> g(c->hub->m); last = --c->hub->refs == 0; }
+        if (last) {
+            for (auto e : c->hub->ready) if (e) (void)hipEventDestroy(e);
+            for (auto e : c->hub->done) if (e) (void)hipEventDestroy(e);
+            delete c->hub;
+        }
+    }
+    delete c;
+}
+
+int umgap_sharded_create(umgap_index* shard, umgap_taxonomy* tx, umgap_comm* comm, uint64_t max_keys_per_call, uint32_t pieces, double slack,
+                         umgap_sharded** out) {
+    if (!shard || !comm || !out) return fail(UMGAP_ERR_INVALID, "umgap_sharded_create: null argument");
+    if (shard->kind != 9) return fail(UMGAP_ERR_INVALID, "umgap_sharded_create: needs a 9-mer index");
+    if (shard->bound_to) return fail(UMGAP_ERR_INVALID, "umgap_sharded_create: the index is bound to a taxonomy; shards exchange taxon ids");
+    if (shard->device != comm->device || (tx && tx->device != shard->device)) return fail(UMGAP_ERR_INVALID, "umgap_sharded_create: index, taxonomy and communicator must live on one device");
+    const uint32_t W = (uint32_t)comm->world, nb = shard->view.nb;
+    const uint32_t lo = (uint32_t)((uint64_t)nb * comm->rank / W), hi = (uint32_t)((uint64_t)nb * (comm->rank + 1) / W);
+    if (shard->view.home_lo != lo || shard->view.home_hi != hi)
+        return fail(UMGAP_ERR_INVALID, "umgap_sharded_create: the index handle is not shard " + std::to_string(comm->rank) + " of " + std::to_string(W) +
+                                           " (open it with umgap_index_open_shard / umgap_index_set_shard)");
+    if (max_keys_per_call == 0) return fail(UMGAP_ERR_INVALID, "umgap_sharded_create: max_keys_per_call must be positive");
+    if (pieces == 0) pieces = 8;
+    if (pieces > 64) pieces = 64;
+    if (!(slack >= 0.0) || slack > 4.0) slack = 0.03;
+    int rc = use_device(shard->device);
+    if (rc) return rc;
+    umgap_sharded* sh = new umgap_sharded();
+    sh->ix = shard;
+    sh->tx = tx;
+    sh->comm = comm;
+    sh->device = shard->device;
+    sh->max_keys = max_keys_per_call;
+    sh->pieces = pieces;
+    sh->piece_keys = (max_keys_per_call + pieces - 1) / pieces;
+    // a region receives piece_keys / W keys on average; binomial spread ~ sqrt of that, so slack + 8 sigma + one tile
+    const double mean = (double)sh->piece_keys / W;
+    uint64_t cap = (uint64_t)(mean * (1.0 + slack) + 8.0 * std::sqrt(mean + 1.0)) + 4096;
+    cap = (cap + 127) & ~(uint64_t)127;
+    if (cap * W >= 0xFFFFFFFFull) { delete sh; return fail(UMGAP_ERR_INVALID, "umgap_sharded_create: piece too large (raise `pieces`)"); }
+    sh->cap = cap;
+    // 3-byte values when every value on every shard fits (all-ones is the miss marker)
+    uint32_t* d_max = nullptr;
+    hipError_t e = hipMalloc((void**)&d_max, 4);
+    uint32_t vmax = 0;
+    if (e == hipSuccess) e = hipMemset(d_max, 0, 4);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_max_value, dim3(256 * 8), dim3(256), 0, nullptr, shard->d_slots, (size_t)shard->view.n_resident * SLOTS, shard->d_stash_vals, shard->n_stash, d_max);
+        e = hipMemcpy(&vmax, d_max, 4, hipMemcpyDeviceToHost);
+    }
+    if (d_max) (void)hipFree(d_max);
+    if (e != hipSuccess) { delete sh; return fail(UMGAP_ERR_DEVICE, std::string("umgap_sharded_create: ") + hipGetErrorString(e)); }
+    rc = comm_max_u32(comm, &vmax);
+    if (rc) { delete sh; return rc; }
+    sh->value_bytes = vmax < 0xFFFFFFu ? 3 : 4;
+    // one block: per set {send keys, recv keys, values out, values back, perm, cursor}
+    auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_keys = pad(cap * W * 6), b_vals = pad(cap * W * 4 + 64), b_perm = pad(sh->piece_keys * 4), b_cur = pad(W * 8);
+    const size_t per_set = 2 * b_keys + 2 * b_vals + b_perm + b_cur;
+    sh->block_bytes = NSETS * per_set + 256;
+    e = hipMalloc(&sh->block, sh->block_bytes);
+    if (e != hipSuccess) { delete sh; return fail(UMGAP_ERR_NOMEM, std::string("umgap_sharded_create: hipMalloc of the exchange buffers (") + std::to_string(sh->block_bytes >> 20) + " MiB): " + hipGetErrorString(e)); }
+    char* p = (char*)sh->block;
+    for (auto& S : sh->set) {
+        S.send_keys = (uint8_t*)p; p += b_keys;
+        S.recv_keys = (uint8_t*)p; p += b_keys;
+        S.ret_send = (uint32_t*)p; p += b_vals;
+        S.ret_recv = (uint32_t*)p; p += b_vals;
+        S.perm = (uint32_t*)p; p += b_perm;
+        S.cursor = (unsigned long long*)p; p += b_cur;
+        if (hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&S.done, hipEventDisableTiming) != hipSuccess) {
+            umgap_sharded_free(sh);
+            return fail(UMGAP_ERR_DEVICE, "umgap_sharded_create: stream / event creation failed");
+        }
+    }
+    sh->d_overflow = (uint32_t*)p;
+    e = hipMemset(sh->d_overflow, 0, 4);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&sh->ev_in, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreate(&sh->ev_probe0);
+    if (e == hipSuccess) e = hipEventCreate(&sh->ev_probe1);
+    if (e != hipSuccess) { umgap_sharded_free(sh); return fail(UMGAP_ERR_DEVICE, std::string("umgap_sharded_create: ") + hipGetErrorString(e)); }
+    *out = sh;
+    return UMGAP_OK;
+}
+
+void umgap_sharded_free(umgap_sharded* sh) {
+    if (!sh) return;
+    (void)hipSetDevice(sh->device);
+    (void)hipDeviceSynchronize();
+    for (auto& S : sh->set) {
+        if (S.stream) (void)hipStreamDestroy(S.stream);
+        if (S.done) (void)hipEventDestroy(S.done);
+    }
+    if (sh->ev_in) (void)hipEventDestroy(sh->ev_in);
+    if (sh->ev_probe0) (void)hipEventDestroy(sh->ev_probe0);
+    if (sh->ev_probe1) (void)hipEventDestroy(sh->ev_probe1);
+    if (sh->block) (void)hipFree(sh->block);
+    delete sh;
+}
+
+uint32_t umgap_sharded_value_bytes(const umgap_sharded* sh) { return sh ? sh->value_bytes : 0; }
+uint64_t umgap_sharded_region_slots(const umgap_sharded* sh) { return sh ? sh->cap : 0; }
+uint32_t umgap_sharded_pieces(const umgap_sharded* sh) { return sh ? sh->pieces : 0; }
+
+int umgap_sharded_lookup9_dev(umgap_sharded* sh, const uint64_t* d_keys45, size_t n, uint32_t miss_value, uint32_t* d_out_taxa, void* stream) {
+    int rc = sharded_args_ok(sh, "umgap_sharded_lookup9_dev");
+    if (rc) return rc;
+    if (n && (!d_keys45 || !d_out_taxa)) return fail(UMGAP_ERR_INVALID, "umgap_sharded_lookup9_dev: null argument");
+    if (n > sh->max_keys) return fail(UMGAP_ERR_INVALID, "umgap_sharded_lookup9_dev: more keys than the max_keys_per_call the group was created with");
+    hipStream_t caller = (hipStream_t)stream;
+    // every rank takes part in every exchange, even with nothing to look up: the piece count is fixed
+    const size_t per = sh->piece_keys, np = sh->pieces;
+    if ((rc = fork_streams(sh, caller))) return rc;
+    for (size_t t = 0; t <= np; t++) {
+        if (t < np) {
+            const size_t lo = std::min(n, t * per), hi = std::min(n, (t + 1) * per);
+            if ((rc = piece_out(sh, sh->set[t % NSETS], d_keys45 + lo, hi - lo, t == 0))) return rc;
+        }
+        if (t >= 1) {
+            const size_t c = t - 1, lo = std::min(n, c * per), hi = std::min(n, (c + 1) * per);
+            BufSet& S = sh->set[c % NSETS];
+            if ((rc = piece_back(sh, S))) return rc;
+            if (hi > lo) {
+                unsigned g = (unsigned)std::min<size_t>((hi - lo + 255) / 256, 2048);
+                hipLaunchKernelGGL(k_shard_unpermute, dim3(g), dim3(256), 0, S.stream, HitSource{S.ret_recv, S.perm, sh->value_bytes}, hi - lo, miss_value, d_out_taxa + lo);
+                UMGAP_HIP(hipGetLastError());
+            }
+        }
+    }
+    return join_streams(sh, caller);
+}
+
+int umgap_sharded_classify9_dev(umgap_sharded* sh, int method, int strategy, float factor, float lower_bound, int ranked_only,
+                                const uint64_t* d_keys45, size_t n_reads, uint32_t kmers_per_read, uint32_t fragments_per_read,
+                                uint32_t min_seed_size, uint32_t max_gap_size, uint32_t* d_out_taxon, uint32_t* d_out_status, void* stream) {
+    int rc = sharded_args_ok(sh, "umgap_sharded_classify9_dev");
+    if (rc) return rc;
+    if (!sh->tx) return fail(UMGAP_ERR_INVALID, "umgap_sharded_classify9_dev: the group was created without a taxonomy");
+    if (n_reads && (!d_keys45 || !d_out_taxon || !d_out_status)) return fail(UMGAP_ERR_INVALID, "umgap_sharded_classify9_dev: null argument");
+    if (kmers_per_read == 0 || kmers_per_read > 128) return fail(UMGAP_ERR_INVALID, "umgap_sharded_classify9_dev: kmers_per_read must be in 1..128");
+    if (fragments_per_read && (kmers_per_read % fragments_per_read) != 0) return fail(UMGAP_ERR_INVALID, "umgap_sharded_classify9_dev: kmers_per_read must be a multiple of fragments_per_read");
+    if (fragments_per_read > 64) return fail(UMGAP_ERR_INVALID, "umgap_sharded_classify9_dev: at most 64 fragments per read");
+    if (method != UMGAP_METHOD_TREE && method != UMGAP_METHOD_RMQ) return fail(UMGAP_ERR_INVALID, "unknown method");
+    if (strategy < 0 || strategy > 2) return fail(UMGAP_ERR_INVALID, "unknown strategy");
+    if (method == UMGAP_METHOD_TREE && strategy == UMGAP_STRATEGY_MRTL)
+        return fail(UMGAP_ERR_INVALID, "Invalid invocation: Tree and MaximumRootToLeafPath cannot be combined");  // src/commands/taxa2agg.rs:134-138
+    if ((uint64_t)n_reads * kmers_per_read > sh->max_keys) return fail(UMGAP_ERR_INVALID, "umgap_sharded_classify9_dev: more keys than the max_keys_per_call the group was created with");
+    hipStream_t caller = (hipStream_t)stream;
+    const size_t per = sh->piece_keys / kmers_per_read, np = sh->pieces;   // whole reads per piece
+    if (per == 0) return fail(UMGAP_ERR_INVALID, "umgap_sharded_classify9_dev: a piece cannot hold one read (lower `pieces`)");
+    if ((uint64_t)per * np < n_reads) return fail(UMGAP_ERR_INVALID, "umgap_sharded_classify9_dev: the reads do not fit the pieces (create the group with a max_keys_per_call that is a multiple of pieces * kmers_per_read)");
+    if ((rc = fork_streams(sh, caller))) return rc;
+    for (size_t t = 0; t <= np; t++) {
+        if (t < np) {
+            const size_t lo = std::min(n_reads, t * per), hi = std::min(n_reads, (t + 1) * per);
+            if ((rc = piece_out(sh, sh->set[t % NSETS], d_keys45 + lo * kmers_per_read, (hi - lo) * kmers_per_read, t == 0))) return rc;
+        }
+        if (t >= 1) {
+            const size_t c = t - 1, lo = std::min(n_reads, c * per), hi = std::min(n_reads, (c + 1) * per);
+            BufSet& S = sh->set[c % NSETS];
+            if ((rc = piece_back(sh, S))) return rc;
+            rc = launch_classify9_from_hits(sh->tx, method, strategy, factor, lower_bound, ranked_only, HitSource{S.ret_recv, S.perm, sh->value_bytes}, hi - lo,
+                                            kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, d_out_taxon + lo, d_out_status + lo, S.stream);
+            if (rc) return rc;
+        }
+    }
+    return join_streams(sh, caller);
+}
+
+int umgap_sharded_check(umgap_sharded* sh) {
+    int rc = sharded_args_ok(sh, "umgap_sharded_check");
+    if (rc) return rc;
+    UMGAP_HIP(hipDeviceSynchronize());
+    uint32_t ov = 0;
+    UMGAP_HIP(hipMemcpy(&ov, sh->d_overflow, 4, hipMemcpyDeviceToHost));
+    if (ov) {
+        UMGAP_HIP(hipMemset(sh->d_overflow, 0, 4));
+        return fail(UMGAP_ERR_BUILD, "sharded lookup: a send region overflowed its capacity since the last check (those keys were answered with a miss); raise `slack`");
+    }
+    return UMGAP_OK;
+}
+
+int umgap_sharded_probe_ms(umgap_sharded* sh, float* ms) {
+    if (!sh || !ms) return fail(UMGAP_ERR_INVALID, "umgap_sharded_probe_ms: null argument");
+    if (!sh->probe_timed) return fail(UMGAP_ERR_INVALID, "umgap_sharded_probe_ms: no call yet");
+    int rc = use_device(sh->device);
+    if (rc) return rc;
+    UMGAP_HIP(hipEventSynchronize(sh->ev_probe1));
+    UMGAP_HIP(hipEventElapsedTime(ms, sh->ev_probe0, sh->ev_probe1));
+    return UMGAP_OK;
+}
+
+}  // extern "C"

@@ -1,114 +1,171 @@
-"""Sharded multi-GPU lookup (BASELINE.json north_star): one process per GPU, the
-index sharded by bucket range, read keys / hits exchanged with torch.distributed all-to-all
-(backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU tests).
+"""Multi-GPU harness over the C ABI's sharded index (include/umgap_hip.h "the index sharded over the GPUs of one
+node"; SURVEY.md §8e, BASELINE.json north_star).  The exchange itself -- RCCL send/recv groups over xGMI, 6 bytes per
+k-mer out and 3 per hit back, pipelined pieces -- lives in libumgap_hip.so (umgap_amd/csrc/shard.hip); this module only
+creates the communicator and wraps the handles.  torch.distributed is used for what the bench contract asks of it
+(rendezvous, barrier, max-over-ranks of the elapsed time) and to hand rank 0's RCCL unique id to the other ranks.
 
-Per step on every rank (B local pairs, K = 84 B keys):
-    partition : keys -> N regions of `cap` slots by owner shard (HIP kernel: LDS counters per 4096-key tile,
-                one global atomic per owner and tile)
-    exchange  : all_to_all_single(keys)          8 B per key, each rank sends ~K/N to every peer
-    probe     : local table shard (the same quad-probe kernel)
-    exchange  : all_to_all_single(taxa)          4 B per key back
-    gather    : hits[i] = returned[perm[i]]
-Regions have a fixed capacity (keys are spread by a bijective mixer, so every region receives
-K/N +- a few sigma); unused slots carry an invalid key that the probe answers with a miss, which
-keeps both collectives equal-split and free of any host synchronisation.  The reads themselves are
-never exchanged: each rank aggregates the reads it owns (no data-path collective after the hits).
+    Comm.from_torch_distributed()      one rank per process, RCCL (GPU box)
+    Comm.local(world)                  all ranks in this process on one GPU: rehearsal of the N-rank protocol
+    Sharded(shard_index, taxonomy, comm, max_keys, pieces)   .lookup9 / .classify9 / .check
 """
 import ctypes as C
+import os
+import subprocess
+import sys
+
+from . import _lib
+from ._lib import check
+
+UNIQUE_ID_BYTES = 128
 
 
-class GpuOps:
-    """The device side of one rank: HIP kernels through the C ABI, buffers as torch CUDA tensors."""
+class Comm:
+    def __init__(self, handle, transport):
+        self._h = C.c_void_p(handle)
+        self.transport = transport
 
-    def __init__(self, index, device):
-        import torch
-        self.torch = torch
-        self.index = index
-        self.device = device
+    @property
+    def world(self):
+        return _lib.load().umgap_comm_world(self._h)
 
-    def empty(self, n, dtype):
-        return self.torch.empty(n, dtype=dtype, device=self.device)
+    @property
+    def rank(self):
+        return _lib.load().umgap_comm_rank(self._h)
 
-    def partition(self, keys, n_shards, cap, send, perm, cursor, overflow):
-        from . import _lib
-        from .api import _dev_ptr, _stream_ptr
-        send.fill_(-1)      # invalid key (bits above 45 set): answered with a miss
-        cursor.zero_()
-        overflow.zero_()
-        _lib.check(_lib.load().umgap_index_partition9_dev(self.index._h, _dev_ptr(keys), keys.numel(), n_shards, cap, _dev_ptr(send),
-                                                          _dev_ptr(perm), _dev_ptr(cursor), _dev_ptr(overflow), _stream_ptr(None)))
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * UNIQUE_ID_BYTES)()
+        check(_lib.load().umgap_comm_unique_id(buf))
+        return bytes(buf)
 
-    def lookup(self, keys, out):
-        self.index.lookup9_dev(keys, out, miss_value=0)
+    @classmethod
+    def init_rank(cls, unique_id, world, rank, device):
+        assert len(unique_id) == UNIQUE_ID_BYTES
+        buf = (C.c_uint8 * UNIQUE_ID_BYTES).from_buffer_copy(unique_id)
+        h = C.c_void_p()
+        check(_lib.load().umgap_comm_init_rank(buf, world, rank, device, C.byref(h)))
+        return cls(h.value, "rccl")
 
-    # two side streams: chunk c+1's partition / probe run while chunk c's all-to-all is on the wire
-    def streams(self, n):
-        return [self.torch.cuda.Stream(device=self.device) for _ in range(n)]
-
-    def stream_ctx(self, s):
-        return self.torch.cuda.stream(s)
-
-    def fork(self, side):
-        side.wait_stream(self.torch.cuda.current_stream())
-
-    def join(self, side):
-        self.torch.cuda.current_stream().wait_stream(side)
-
-
-class ShardedLookup:
-    """lookup(keys) -> hits across `world` ranks, each owning one shard of the table."""
-
-    def __init__(self, ops, rank, world, max_keys, slack=0.02, chunks=1):
-        """chunks > 1 (GPU only): the batch is cut into that many pieces that alternate over two side
-        streams, so the exchange of one piece overlaps the partition / probe / gather of the next."""
-        import torch
+    @classmethod
+    def from_torch_distributed(cls, device):
+        """Collective over the default process group: rank 0 draws the RCCL unique id, everybody gets it."""
         import torch.distributed as dist
-        self.torch, self.dist = torch, dist
-        self.ops, self.rank, self.world = ops, rank, world
-        self.chunks = max(1, int(chunks)) if hasattr(ops, "streams") else 1
-        self.max_keys = max_keys
-        per = -(-max_keys // self.chunks)
-        self.cap = int(per / world * (1.0 + slack)) + 4096
-        n = self.cap * world
-        nbuf = 2 if self.chunks > 1 else 1
-        self.buf = [dict(send_keys=ops.empty(n, torch.int64), recv_keys=ops.empty(n, torch.int64), recv_taxa=ops.empty(n, torch.int32),
-                         back_taxa=ops.empty(n, torch.int32), perm=ops.empty(per, torch.int32), cursor=ops.empty(world, torch.int64),
-                         overflow=ops.empty(1, torch.int32)) for _ in range(nbuf)]
-        self.side = ops.streams(2) if self.chunks > 1 else None
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [cls.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls.init_rank(box[0], world, rank, device)
 
-    def _one(self, b, keys, hits, events=None):
-        perm = b["perm"][: keys.numel()]
-        self.ops.partition(keys, self.world, self.cap, b["send_keys"], perm, b["cursor"], b["overflow"])
-        self.dist.all_to_all_single(b["recv_keys"], b["send_keys"])
-        if events is not None:
-            events[0].record()
-        self.ops.lookup(b["recv_keys"], b["recv_taxa"])
-        if events is not None:
-            events[1].record()
-        self.dist.all_to_all_single(b["back_taxa"], b["recv_taxa"])
-        self.torch.index_select(b["back_taxa"], 0, perm, out=hits)
+    @classmethod
+    def local(cls, world, device=0):
+        """All `world` ranks at once (one GPU, device-to-device exchange); drive each from its own thread."""
+        arr = (C.c_void_p * world)()
+        check(_lib.load().umgap_comm_init_local(world, device, arr))
+        return [cls(arr[r], "local") for r in range(world)]
 
-    def lookup(self, keys, hits, events=None):
-        """keys int64[K] -> hits int32[K] (0 = miss).  `events` = (start, end) timing events around
-        the local probe kernel of the (first) piece, recorded on the stream it runs on."""
-        K = keys.numel()
-        if self.chunks == 1:
-            self._one(self.buf[0], keys, hits, events)
-            return hits
-        per = -(-K // self.chunks)
-        for s in self.side:
-            self.ops.fork(s)
-        for c in range(self.chunks):
-            lo, hi = c * per, min(K, (c + 1) * per)
-            if lo >= hi:
-                break
-            with self.ops.stream_ctx(self.side[c & 1]):
-                # pieces c and c+2 share a stream and a buffer set: stream order keeps them apart
-                self._one(self.buf[c & 1], keys[lo:hi], hits[lo:hi], events if c == 0 else None)
-        for s in self.side:
-            self.ops.join(s)
-        return hits
+    def close(self):
+        if self._h:
+            _lib.load().umgap_comm_free(self._h)
+            self._h = None
 
-    def check_overflow(self):
-        if any(int(b["overflow"].item()) != 0 for b in self.buf):
-            raise RuntimeError("sharded lookup: a send region overflowed its capacity; raise `slack`")
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Sharded:
+    """One rank's view of the table sharded over `comm.world` GPUs."""
+
+    def __init__(self, shard_index, taxonomy, comm, max_keys, pieces=8, slack=0.03):
+        self.index, self.taxonomy, self.comm = shard_index, taxonomy, comm   # borrowed by the C handle: keep them alive
+        h = C.c_void_p()
+        check(_lib.load().umgap_sharded_create(shard_index._h, taxonomy._h if taxonomy is not None else None, comm._h, max_keys, pieces, slack,
+                                               C.byref(h)))
+        self._h = h
+
+    @property
+    def value_bytes(self):
+        return _lib.load().umgap_sharded_value_bytes(self._h)
+
+    @property
+    def region_slots(self):
+        return _lib.load().umgap_sharded_region_slots(self._h)
+
+    @property
+    def pieces(self):
+        return _lib.load().umgap_sharded_pieces(self._h)
+
+    def wire_bytes_per_step_and_peer(self):
+        """(out, back): bytes this rank sends to EACH peer per call (keys) and gets back from it (values)."""
+        return 6 * self.region_slots * self.pieces, self.value_bytes * self.region_slots * self.pieces
+
+    def lookup9(self, d_keys45, d_out, miss_value=0, stream=None):
+        from .api import _dev_ptr, _stream_ptr
+        check(_lib.load().umgap_sharded_lookup9_dev(self._h, _dev_ptr(d_keys45), d_keys45.numel(), miss_value, _dev_ptr(d_out), _stream_ptr(stream)))
+        return d_out
+
+    def classify9(self, d_keys45, n_reads, kmers_per_read, d_out_taxon, d_out_status, method="tree", strategy="lca*", factor=0.25,
+                  lower_bound=0.0, ranked_only=False, fragments_per_read=0, min_seed_size=2, max_gap_size=0, stream=None):
+        from .api import METHODS, STRATEGIES, _dev_ptr, _stream_ptr
+        check(_lib.load().umgap_sharded_classify9_dev(self._h, METHODS[method], STRATEGIES[strategy], factor, lower_bound, int(ranked_only),
+                                                      _dev_ptr(d_keys45), n_reads, kmers_per_read, fragments_per_read, min_seed_size, max_gap_size,
+                                                      _dev_ptr(d_out_taxon), _dev_ptr(d_out_status), _stream_ptr(stream)))
+
+    def check(self):
+        """Synchronises; raises if an exchange region overflowed since the last check."""
+        check(_lib.load().umgap_sharded_check(self._h))
+
+    def probe_ms(self):
+        ms = C.c_float()
+        check(_lib.load().umgap_sharded_probe_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self._h:
+            _lib.load().umgap_sharded_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(script, argv, world, timeout=None, extra_env=None):
+    """Starts `world` copies of `script argv` as one process per rank (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment, rendezvous on 127.0.0.1) and waits for them: what `python bench.py --gpus N` does when it was not started
+    under torch.distributed.run.  Called BEFORE the parent touches the GPU (children are fresh processes, the parent never
+    re-executes itself).  Returns the largest exit code; a rank that outlives `timeout` seconds is killed (exit code 124)."""
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "UMGAP_SPAWNED": "1"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if extra_env:
+            env.update(extra_env)
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env))
+    rc = 0
+    import time
+    deadline = None if timeout is None else time.time() + timeout
+    for p in procs:
+        try:
+            p.wait(None if deadline is None else max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            rc = max(rc, 124)
+    for p in procs:
+        if p.poll() is None:
+            p.kill()
+            p.wait()
+        rc = max(rc, abs(p.returncode))
+    return rc

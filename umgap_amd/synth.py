@@ -95,15 +95,16 @@ class SyntheticWorkload:
         self.d_row_of_id = torch.from_numpy(row_of_id.view(np.int32)).to(self.device)
         self.index = Index.synthetic(self.n_keys, self.d_taxon_of_row, MUL_A, ADD_B, load_factor, shard, n_shards) if build_index else None
 
-    def reads(self, first_pair, n_pairs, d_keys=None, kmers_per_pair=KMERS_PER_PAIR, stream=None):
-        """Packed 9-mers of pairs [first_pair, first_pair+n_pairs) as an int64 CUDA tensor."""
+    def reads(self, first_pair, n_pairs, d_keys=None, kmers_per_pair=KMERS_PER_PAIR, stream=None, path_percent=60, unrelated_percent=10):
+        """Packed 9-mers of pairs [first_pair, first_pair+n_pairs) as an int64 CUDA tensor (the 60 / 10 / 30 mix of the
+        module docstring unless told otherwise)."""
         import ctypes as C
         import torch
         from . import _lib
         from .api import _dev_ptr, _stream_ptr
         if d_keys is None:
             d_keys = torch.empty(n_pairs * kmers_per_pair, dtype=torch.int64, device=self.device)
-        _lib.check(_lib.load().umgap_synth_reads9_dev(self.taxonomy._h, _dev_ptr(self.d_taxon_of_row), _dev_ptr(self.d_row_of_id),
-                                                      self.n_tax, self.n_keys, MUL_A, ADD_B, SEED_READS, first_pair, n_pairs,
-                                                      kmers_per_pair, _dev_ptr(d_keys), _stream_ptr(stream)))
+        _lib.check(_lib.load().umgap_synth_reads9_mix_dev(self.taxonomy._h, _dev_ptr(self.d_taxon_of_row), _dev_ptr(self.d_row_of_id),
+                                                          self.n_tax, self.n_keys, MUL_A, ADD_B, SEED_READS, first_pair, n_pairs,
+                                                          kmers_per_pair, path_percent, unrelated_percent, _dev_ptr(d_keys), _stream_ptr(stream)))
         return d_keys
