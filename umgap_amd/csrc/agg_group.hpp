@@ -1,0 +1,281 @@
+// agg_group.hpp -- the general aggregation (MRTL, tree-hybrid, rmq-hybrid) for a GROUP of reads held by one wave in LDS
+// (the fused kernels of classify.hip), with the taxonomy round trips batched over the group (round 2).
+//
+// general_read (agg_general.hpp) takes one read at a time and pays 2 (MRTL) to 4 (hybrids) DEPENDENT cache round trips per
+// read -- {pre,last} of the survivors, depth + range minimum of the adjacent pairs, their parents, the snap of the answer --
+// so a group of 12 reads sat through ~30-50 of them one after another (70 % of the wave cycles in SQ_WAIT_ANY,
+// profiles/r01_v8_pmc_classify.json).  Here every phase runs over all reads of the group before the next one starts:
+//
+//   P1  per read, LDS only : count + filter (lds_count), survivors compacted IN PLACE over the strip
+//   P2  whole group        : {pre,last} of every survivor                                   1 round trip
+//   P3a per read, LDS only : errors / empties, sort by preorder index; MRTL finishes here
+//   P3b whole group        : depth of every survivor, adjacent-pair range minima (hybrids)  1 round trip
+//                            parents of the minima (+ subtree ends for rmq-hybrid)          1 round trip
+//   P3c per read, LDS only : the greedy descent (tree-hybrid) / the candidate scores (rmq-hybrid)
+//   P4  whole group        : snap of the answers, one lane per read, results stored coalesced   1 round trip
+//
+// The per-read arithmetic (sums in `nearest ancestor first` order, the f32 division of src/tree/mix.rs:57, the products of
+// src/rmq/mix.rs:52-54, ties to the smallest preorder index) is that of general_read, statement for statement: the two must
+// give identical answers (tests/test_gpu_parity.py compares them bit for bit).  A group whose survivors exceed GCAP is
+// processed in several sub-batches; a read with more than 64 distinct taxa is handed to the large-scratch pass as before.
+#pragma once
+#include "agg_general.hpp"
+
+namespace umgap {
+namespace agg {
+
+constexpr uint32_t GCAP = 160;     // survivors (distinct filtered taxa) of one sub-batch
+constexpr uint32_t GREADS = 64;    // reads of one sub-batch (one lane per read in P4)
+constexpr uint32_t ST_PENDING = 0x100u, ST_DEFER = 0x101u;   // internal per-read states (not UMGAP_READ_* values)
+
+struct GroupScratch {
+    uint32_t hkeys[256], hcnt[256];   // the per-read hash table of lds_count (clean between reads)
+    uint32_t last[GCAP];
+    float cnt[GCAP];
+    uint32_t dep[GCAP], adj[GCAP], lca[GCAP];
+    uint32_t roff[GREADS + 1], rans[GREADS], rstat[GREADS];
+};
+
+// Aggregates reads [0, nr) of a group whose taxa sit in the wave's strip (read k at wtaxa[k*stride .. +stride), stride <= 128,
+// 0 = no hit).  The strip is consumed.  Results go to out_taxon/out_status[first_read + k]; a read that needs the
+// large-scratch pass is appended to `defer` (or flagged UMGAP_READ_UNSUPPORTED when there is no list).  se_panic: bit
+// (k * frags + f) set = seedextend panicked on fragment f of read k (classify.hip).
+template <bool BOUND>
+__device__ __forceinline__ void general_group(const TaxView& V, GroupScratch& G, int method, int strategy, float factor, float lower_bound,
+                                              uint32_t* wtaxa, uint32_t stride, uint32_t nr, uint32_t lane, uint64_t se_panic, uint32_t frags,
+                                              size_t first_read, uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status,
+                                              uint32_t* __restrict__ defer, uint32_t* __restrict__ defer_count) {
+    const bool tree_like = method != UMGAP_METHOD_RMQ || strategy == UMGAP_STRATEGY_MRTL;
+    uint32_t k0 = 0;
+    while (k0 < nr) {
+        // ---- P1: count + filter, survivors compacted over the strip from `base` on -----------------------------------------
+        const uint32_t base = k0 * stride;
+        uint32_t w = 0, k = k0;
+        if (lane == 0) G.roff[0] = 0;
+        while (k < nr && k - k0 < GREADS) {
+            const uint32_t* rt = wtaxa + k * stride;
+            const uint32_t t0 = lane < stride ? rt[lane] : 0u, t1 = 64 + lane < stride ? rt[64 + lane] : 0u;
+            bool keep0, keep1;
+            float c0, c1;
+            lds_count(G.hkeys, G.hcnt, t0, t1, lower_bound, keep0, keep1, c0, c1);
+            const uint64_t b0 = __ballot(keep0), b1 = __ballot(keep1);
+            const uint32_t n0 = (uint32_t)__builtin_popcountll(b0), ns = n0 + (uint32_t)__builtin_popcountll(b1);
+            if (ns > 64) {                      // more distinct taxa than one lane each: the large-scratch pass takes the read
+                if (lane == 0) { G.rstat[k - k0] = ST_DEFER; G.roff[k - k0 + 1] = w; }
+                k++;
+                continue;
+            }
+            if (w + ns > GCAP) {
+                if (k == k0) {                   // cannot happen (ns <= 64 <= GCAP), kept as a guard against an endless loop
+                    if (lane == 0) { G.rstat[0] = ST_DEFER; G.roff[1] = w; }
+                    k++;
+                }
+                break;                           // the read opens the next sub-batch (its taxa are untouched)
+            }
+            wave_sync();                         // every lane holds its taxa in registers before the strip is overwritten
+            if (keep0) { const uint32_t i = w + (uint32_t)__builtin_popcountll(b0 & lanemask_lt(lane)); wtaxa[base + i] = t0; G.cnt[i] = c0; }
+            if (keep1) { const uint32_t i = w + n0 + (uint32_t)__builtin_popcountll(b1 & lanemask_lt(lane)); wtaxa[base + i] = t1; G.cnt[i] = c1; }
+            w += ns;
+            if (lane == 0) { G.rstat[k - k0] = ST_PENDING; G.roff[k - k0 + 1] = w; }
+            wave_sync();
+            k++;
+        }
+        const uint32_t nb = k - k0;              // reads of this sub-batch
+        wave_sync();
+        // ---- P2: {pre, last} of every survivor, one round trip; the strip now holds preorder indexes -----------------------
+        bool any_err = false;
+        for (uint32_t eb = 0; eb < w; eb += 64) {
+            const uint32_t e = eb + lane;
+            uint64_t errkey = NOERR;
+            if (e < w) {
+                const uint32_t t = wtaxa[base + e];
+                Hit h{NONE, NONE};
+                if (BOUND) {
+                    uint32_t lo, hi;
+                    bound::size_bounds(t, lo, hi);
+                    h.pre = bound::pre_of(t);
+                    h.last = lo == hi ? h.pre + lo : V.last_of_pre[h.pre];
+                } else h = resolve(V, tree_like, t, errkey);
+                wtaxa[base + e] = h.pre;
+                G.last[e] = h.last;
+                G.dep[e] = (uint32_t)errkey;      // free until P3b: the element's error key (NOERR = all ones)
+                G.adj[e] = (uint32_t)(errkey >> 32);
+            }
+            any_err = any_err || __any(errkey != NOERR);
+        }
+        wave_sync();
+        // ---- P3a: per read -- errors, empties, sort by preorder index; MRTL is finished here (LDS only) ---------------------
+        for (uint32_t r = 0; r < nb; r++) {
+            if (G.rstat[r] != ST_PENDING) continue;                       // wave-uniform
+            const uint32_t o0 = G.roff[r], D = G.roff[r + 1] - o0;       // D <= 64: one lane per element
+            if (any_err) {
+                const uint64_t ek = wave_min64(lane < D ? (((uint64_t)G.adj[o0 + lane] << 32) | G.dep[o0 + lane]) : NOERR);
+                if (ek != NOERR) {
+                    if (lane == 0) { G.rstat[r] = ((ek >> 32) & 1) ? UMGAP_READ_PANIC : UMGAP_READ_UNKNOWN_TAXON; G.rans[r] = (uint32_t)ek; }
+                    continue;
+                }
+            }
+            if (D == 0) {
+                if (lane == 0) { G.rstat[r] = UMGAP_READ_EMPTY; G.rans[r] = 1; }   // literal "1" (src/commands/taxa2agg.rs:174-175)
+                continue;
+            }
+            // sort (distinct taxa => distinct keys): rank by counting, scattered back in place
+            const uint32_t p = lane < D ? wtaxa[base + o0 + lane] : 0u;
+            const uint32_t l = lane < D ? G.last[o0 + lane] : 0u;
+            const float c = lane < D ? G.cnt[o0 + lane] : 0.0f;
+            uint32_t rank = 0;
+            for (uint32_t f = 0; f < D; f++) rank += wtaxa[base + o0 + f] < p;
+            wave_sync();
+            if (lane < D) {
+                wtaxa[base + o0 + rank] = p;
+                G.last[o0 + rank] = l;
+                G.cnt[o0 + rank] = c;
+                G.adj[o0 + rank] = NONE;          // "no next element in this read" until P3b fills the inner ones
+            }
+            wave_sync();
+            if (strategy == UMGAP_STRATEGY_MRTL) {
+                float score = -__builtin_inff();
+                if (lane < D) {
+                    score = G.cnt[o0 + lane];
+                    const uint32_t pi = wtaxa[base + o0 + lane];
+                    for (uint32_t j = lane; j-- > 0;)
+                        if (G.last[o0 + j] >= pi) score = __fadd_rn(score, G.cnt[o0 + j]);   // ancestor, nearest first (src/rmq/rtl.rs:42-49)
+                }
+                const float m = wave_maxf(score);
+                const uint32_t bi = wave_min(lane < D && score == m ? lane : NONE);
+                if (lane == 0) G.rans[r] = wtaxa[base + o0 + bi];
+            }
+        }
+        wave_sync();
+        if (strategy != UMGAP_STRATEGY_MRTL) {
+            // ---- P3b: depth of every survivor and the LCA of every adjacent pair of a read, whole sub-batch at once ----------
+            // element e has a successor in its read unless it is the read's last one; the reads' ends are in roff
+            for (uint32_t eb = 0; eb < w; eb += 64) {
+                const uint32_t e = eb + lane;
+                uint32_t u = 0, v = 0, du = 0, lu = 0;
+                bool inner = false, anc = false;
+                uint64_t m = 0;
+                if (e < w) {
+                    u = wtaxa[base + e];
+                    lu = G.last[e];
+                    // is e the last element of its read?  (reads are short lists: scan the offsets)
+                    inner = true;
+                    for (uint32_t r = 0; r < nb; r++) if (G.roff[r + 1] == e + 1) inner = false;
+                    if (u == NONE) inner = false;                         // element of a read that ended in an error
+                    if (u != NONE) du = V.depth[u];
+                    if (inner) {
+                        v = wtaxa[base + e + 1];
+                        anc = lu >= v;                                    // u is an ancestor of v
+                        if (!anc) m = lane_argmin_depth(V, u + 1, v);     // LCA = parent of a shallowest node in (pre[u], pre[v]]
+                    }
+                }
+                uint32_t node = u, nlast = lu;
+                if (inner && !anc) {
+                    node = V.parent_pre[(uint32_t)m];
+                    if (method == UMGAP_METHOD_RMQ) nlast = V.last_of_pre[node];   // rmq::mix weighs the LCA candidates by their subtree
+                }
+                if (e < w && u != NONE) {
+                    if (inner) { G.lca[e] = node; G.adj[e] = anc ? du : (uint32_t)(m >> 32) - 1u; }
+                    G.dep[e] = method == UMGAP_METHOD_RMQ ? nlast : du;  // tree::mix needs the depths, rmq::mix the candidates' subtree ends
+                }
+            }
+            wave_sync();
+            // ---- P3c: per read, LDS only ------------------------------------------------------------------------------------
+            for (uint32_t r = 0; r < nb; r++) {
+                if (G.rstat[r] != ST_PENDING) continue;
+                const uint32_t o0 = G.roff[r], D = G.roff[r + 1] - o0;
+                const uint32_t* bpre = wtaxa + base + o0;
+                uint32_t ans = NONE;
+                if (method == UMGAP_METHOD_TREE) {
+                    // tree::mix, one lane per list element (the body of general_read's CAP <= 64 path)
+                    const uint32_t kx = lane;
+                    float pfx = kx < D ? G.cnt[o0 + kx] : 0.0f;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { float t = __shfl_up(pfx, o, 64); if (lane >= (uint32_t)o) pfx = __fadd_rn(pfx, t); }
+                    const uint32_t adj_k = kx + 1 < D ? G.adj[o0 + kx] : NONE;
+                    const uint32_t dep_k = kx < D ? G.dep[o0 + kx] : 0u;
+                    uint32_t i = 0, j = D - 1;
+                    float wcur = __shfl(pfx, (int)(D - 1), 64);
+                    for (;;) {
+                        bool inr = kx >= i && kx < j;
+                        uint32_t suf = inr ? adj_k : NONE;
+#pragma unroll
+                        for (int o = 1; o < 64; o <<= 1) {
+                            uint32_t t = (uint32_t)__shfl_down((int)suf, o, 64);
+                            if (lane + (uint32_t)o < 64) suf = t < suf ? t : suf;
+                        }
+                        const uint64_t branch = __ballot(inr && dep_k != suf);
+                        if (!branch) { ans = bpre[j]; break; }               // a pure chain down to the last element
+                        i = (uint32_t)__builtin_ctzll(branch);
+                        const uint32_t mm = (uint32_t)__shfl((int)suf, (int)i, 64);
+                        inr = kx >= i && kx < j;
+                        const uint64_t eq = __ballot(inr && adj_k == mm);
+                        const uint32_t node = G.lca[o0 + __builtin_ctzll(eq)];
+                        const uint64_t ends = eq | (1ull << j);              // a child ends at every cut and at j
+                        const bool is_end = (ends >> kx) & 1ull;
+                        const uint64_t below = ends & lanemask_lt(kx);
+                        const uint32_t st = below ? 64u - (uint32_t)__builtin_clzll(below) : i;   // where this child starts
+                        const float before_raw = __shfl(pfx, (int)((st - 1u) & 63u), 64);
+                        const float seg = is_end ? __fsub_rn(pfx, st ? before_raw : 0.0f) : -1.0f;
+                        const float best_w = wave_maxf(seg);
+                        const uint32_t best_e = wave_min(is_end && seg == best_w ? kx : NONE);   // first maximum
+                        const uint32_t best_s = (uint32_t)__shfl((int)st, (int)best_e, 64);
+                        if (__fdiv_rn(best_w, wcur) < factor) { ans = node; break; }  // src/tree/mix.rs:57-59
+                        wcur = best_w;
+                        i = best_s;
+                        j = best_e;
+                    }
+                } else {
+                    // rmq::mix: candidates = the hits and the LCAs of adjacent hits; weights by interval tests (src/rmq/mix.rs:52-54)
+                    const float one_minus = __fsub_rn(1.0f, factor);
+                    float best = -__builtin_inff();
+                    uint32_t best_p = NONE;
+                    const uint32_t n_cand = 2 * D - 1;
+                    for (uint32_t cb = 0; cb < n_cand; cb += 64) {
+                        const uint32_t cnd = cb + lane;
+                        if (cnd < n_cand) {
+                            const uint32_t pc = cnd < D ? bpre[cnd] : G.lca[o0 + cnd - D];
+                            const uint32_t lc = cnd < D ? G.last[o0 + cnd] : G.dep[o0 + cnd - D];
+                            float lw = 0.0f, rw = 0.0f;
+                            for (uint32_t q = 0; q < D; q++) {
+                                const uint32_t pk = bpre[q];
+                                if (pc <= pk && pk <= lc) lw = __fadd_rn(lw, G.cnt[o0 + q]);              // hit below-or-at the candidate
+                                if (pk <= pc && pc <= G.last[o0 + q]) rw = __fadd_rn(rw, G.cnt[o0 + q]);  // hit above-or-at the candidate
+                            }
+                            const float score = __fadd_rn(__fmul_rn(lw, factor), __fmul_rn(rw, one_minus));
+                            if (score > best || (score == best && pc < best_p)) { best = score; best_p = pc; }
+                        }
+                    }
+                    const float m = wave_maxf(best);
+                    ans = wave_min(best == m ? best_p : NONE);
+                }
+                if (lane == 0) G.rans[r] = ans;
+            }
+            wave_sync();
+        }
+        // ---- P4: snap + store, one lane per read -----------------------------------------------------------------------------
+        if (lane < nb) {
+            const size_t read = first_read + k0 + lane;
+            uint32_t st = G.rstat[lane], tx = G.rans[lane];
+            if (st == ST_PENDING) {
+                tx = V.snap_of_pre[tx];            // snapping[aggregate] (src/commands/taxa2agg.rs:178)
+                st = tx == NONE ? UMGAP_READ_PANIC : UMGAP_READ_OK;
+            }
+            const uint32_t kk = k0 + lane;
+            const bool sp = se_panic && ((se_panic >> (kk * frags)) & ((frags >= 64 ? 0ull : (1ull << frags)) - 1ull));
+            if (sp) { st = UMGAP_READ_PANIC; tx = 0; }
+            if (st == ST_DEFER) {
+                if (defer) defer[atomicAdd(defer_count, 1u)] = (uint32_t)read;
+                else { out_taxon[read] = 0; out_status[read] = UMGAP_READ_UNSUPPORTED; }
+            } else {
+                out_taxon[read] = tx;
+                out_status[read] = st;
+            }
+        }
+        wave_sync();
+        k0 = k;
+    }
+}
+
+}  // namespace agg
+}  // namespace umgap

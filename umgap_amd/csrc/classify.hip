@@ -16,6 +16,7 @@
 // has the commentary).  k_classify9_general is the same pipeline for MRTL and the hybrids, k_classify_prot9 takes the
 // reads as protein fragments (rolling keys from LDS) instead of packed k-mers.
 #include "agg_general.hpp"
+#include "agg_group.hpp"
 #include "bound.hpp"
 #include "probe_common.hpp"
 #include "shard_wire.hpp"
@@ -295,6 +296,47 @@ __global__ __launch_bounds__(256) void k_classify9_general(TableView T, TaxView 
     }
 }
 
+// First pass of the same pipeline with the aggregate batched over the group (agg_group.hpp): the taxonomy round trips are
+// paid once per group and phase instead of once per read.  Reads with more than 64 distinct taxa go to the `defer` list, which
+// k_classify9_general<128, 512> (one read at a time, large scratch) then works through.
+template <bool BOUND, bool GATHER>
+__global__ __launch_bounds__(256) void k_classify9_group(TableView T, TaxView V, int method, int strategy, float factor,
+                                                         const uint64_t* __restrict__ keys, size_t n_reads, uint32_t stride, uint32_t frags,
+                                                         uint32_t min_seed, uint32_t max_gap, float lower_bound,
+                                                         uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status,
+                                                         uint32_t* __restrict__ defer, uint32_t* __restrict__ defer_count, HitSource H) {
+    __shared__ uint32_t lds_taxa[4][STRIP];
+    __shared__ GroupScratch scratch[4];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t* wtaxa = lds_taxa[wv];
+    GroupScratch& S = scratch[wv];
+    for (uint32_t i = lane; i < 256; i += 64) { S.hkeys[i] = 0u; S.hcnt[i] = 0u; }
+    wave_lds_sync();
+    uint32_t G = STRIP / stride;
+    if (frags && G * frags > 64) G = 64 / frags;
+    const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const size_t n_groups = (n_reads + G - 1) / G;
+    for (size_t g = wave0; g < n_groups; g += nwaves) {
+        const size_t r0 = g * G;
+        const uint32_t nr = (uint32_t)min((size_t)G, n_reads - r0);
+        const uint32_t nk = nr * stride;
+        if (GATHER) gather_group_to_strip(H, r0 * stride, nk, wtaxa, lane);
+        else probe_group_to_strip(T, keys + r0 * stride, nk, wtaxa, lane);
+        wave_lds_sync();
+        uint64_t se_panic = 0;
+        if (frags) {
+            const uint32_t flen = stride / frags;
+            bool pk = false;
+            if (lane < nr * frags) pk = seedextend_lds(wtaxa + lane * flen, flen, min_seed, max_gap);
+            se_panic = __ballot(pk);
+            wave_lds_sync();
+        }
+        general_group<BOUND>(V, S, method, strategy, factor, lower_bound, wtaxa, stride, nr, lane, se_panic, frags, r0, out_taxon, out_status, defer, defer_count);
+        wave_lds_sync();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Surface B: the reads arrive as protein fragments (what FGSpp / `translate` emit and
 // `prot2kmer2lca` consumes, ~1.2 B per k-mer instead of 8 B): read r owns fragments
@@ -500,9 +542,9 @@ int launch_classify9_from_hits(umgap_taxonomy* tx, int method, int strategy, flo
         uint32_t* d_count = d_defer;
         uint32_t* d_list = d_defer + 1;
         UMGAP_HIP(hipMemsetAsync(d_count, 0, sizeof(uint32_t), s));
-        hipLaunchKernelGGL((k_classify9_general<64, 256, false, true>), dim3((unsigned)g), dim3(256), 0, s, none, V, method, strategy, factor, (const uint64_t*)nullptr,
+        hipLaunchKernelGGL((k_classify9_group<false, true>), dim3((unsigned)g), dim3(256), 0, s, none, V, method, strategy, factor, (const uint64_t*)nullptr,
                            n_reads, kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status,
-                           (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_list, d_count, H);
+                           d_list, d_count, H);
         hipLaunchKernelGGL((k_classify9_general<128, 512, false, true>), dim3(256), dim3(256), 0, s, none, V, method, strategy, factor, (const uint64_t*)nullptr,
                            n_reads, kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status,
                            (const uint32_t*)d_list, (const uint32_t*)d_count, (uint32_t*)nullptr, (uint32_t*)nullptr, H);
@@ -577,9 +619,9 @@ extern "C" int umgap_classify9_strategy_dev(umgap_index* ix, umgap_taxonomy* tx,
     TaxView V = view_of(tx, ranked_only);
     // first pass, then the reads with more than 64 distinct taxa (at most 128: kmers_per_read <= 128)
 #define UMGAP_LAUNCH_GENERAL(BOUND)                                                                                                              \
-    hipLaunchKernelGGL((k_classify9_general<64, 256, BOUND, false>), dim3((unsigned)g), dim3(256), 0, s, ix->view, V, method, strategy, factor, d_keys45, \
+    hipLaunchKernelGGL((k_classify9_group<BOUND, false>), dim3((unsigned)g), dim3(256), 0, s, ix->view, V, method, strategy, factor, d_keys45,         \
                        n_reads, kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status,           \
-                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_list, d_count, HitSource{});                                          \
+                       d_list, d_count, HitSource{});                                                                                              \
     hipLaunchKernelGGL((k_classify9_general<128, 512, BOUND, false>), dim3(256), dim3(256), 0, s, ix->view, V, method, strategy, factor, d_keys45, n_reads, \
                        kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status,                    \
                        (const uint32_t*)d_list, (const uint32_t*)d_count, (uint32_t*)nullptr, (uint32_t*)nullptr, HitSource{})
