@@ -72,6 +72,31 @@ res["lookup_var_Glookups_per_s"] = round(n_q / ms / 1e6, 2)
 res["hit_rate"] = round(hitrate, 3)
 assert abs(hitrate - 0.7) < 0.01
 assert bool((out[:nm] == taxa[:nm]).all())
+res["var_batches_in_flight"] = int(os.environ.get("UMGAP_VAR_BATCHES", "1"))
+# The queries above arrive in the order the members were inserted, so consecutive lookups verify against consecutive heap
+# bytes (cache friendly).  Real reads do not: the same measurement over a RANDOM permutation of a 50 M-query sample.
+n_s = min(n_q, 50_000_000)
+lens = (qo[1:n_s + 1] - qo[:n_s])
+perm = torch.randperm(n_s, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+# keep the 70 / 30 mix: sample positions across the whole query list
+pick = (perm.to(torch.float64) * (n_q / n_s)).to(torch.int64)
+plen = (qo[pick + 1] - qo[pick])
+po = torch.zeros(n_s + 1, dtype=torch.int64, device=dev)
+torch.cumsum(plen, 0, out=po[1:])
+tot = int(po[-1].item())
+src = torch.repeat_interleave(qo[pick] - po[:-1], plen) + torch.arange(tot, dtype=torch.int64, device=dev)
+pd = qd[src]
+del src, lens
+pout = torch.empty(n_s, dtype=torch.int32, device=dev)
+ix.lookup_var_dev(pd, po, pout)
+torch.cuda.synchronize()
+assert bool((pout == out[pick]).all())
+t0.record()
+for _ in range(3):
+    ix.lookup_var_dev(pd, po, pout)
+t1.record(); torch.cuda.synchronize()
+res["lookup_var_shuffled_Glookups_per_s"] = round(n_s / (t0.elapsed_time(t1) / 3) / 1e6, 2)
+del pd, po, pout, pick, perm, plen
 # aggregation: reads of 16 hits drawn like the 9-mer reads (source path / unrelated / miss)
 from umgap_amd.synth import SyntheticWorkload
 del ix, qd, qo, out

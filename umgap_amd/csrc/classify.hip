@@ -528,8 +528,9 @@ int launch_classify9_from_hits(umgap_taxonomy* tx, int method, int strategy, flo
     if (!n_reads) return UMGAP_OK;
     uint32_t G = 1024u / kmers_per_read;
     if (fragments_per_read && G * fragments_per_read > 64) G = 64 / fragments_per_read;
-    size_t g = ((n_reads + G - 1) / G + 3) / 4;
-    if (g > 256 * 8) g = 256 * 8;
+    // one group per wave, as many workgroups as groups: short-lived workgroups, so this piece's aggregate shares the compute
+    // units with the probe and the pack of the pieces behind it
+    const size_t g = ((n_reads + G - 1) / G + 3) / 4;
     TaxView V = view_of(tx, ranked_only);
     const TableView none{};
     if (strategy == UMGAP_STRATEGY_LCA_STAR) {

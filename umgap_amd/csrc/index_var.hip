@@ -102,13 +102,12 @@ __device__ __forceinline__ uint32_t var_stash_lookup(const VarView& T, uint64_t 
     return miss;
 }
 
-// One query per lane in; the 64 queries of a wave are probed in four rounds of 16 quads.
-__global__ __launch_bounds__(256) void k_lookup_var(const uint8_t* __restrict__ qbytes, const uint64_t* __restrict__ qoff, size_t n,
-                                                    uint32_t miss, uint32_t* __restrict__ out, VarView T) {
-    const uint32_t lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
-    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
-    for (size_t base = wave * 64; base < n; base += nwaves * 64) {
+// One batch of 64 queries (one per lane) straight from global memory: the round-1 kernel body, kept for batches whose bytes
+// cannot be staged in LDS (ill-formed offsets: a "key" longer than 63 bytes inside the batch) -- see k_lookup_var below.
+__device__ __noinline__ void lookup_batch_global(const uint8_t* __restrict__ qbytes, const uint64_t* __restrict__ qoff, size_t n, size_t base,
+                                                    uint32_t miss, uint32_t* __restrict__ out, const VarView& T, uint32_t lane) {
+    const uint32_t q = lane >> 2, j = lane & 3;
+    {
         size_t i = base + lane;
         uint64_t h = 0, o = 0;
         uint32_t len = 0, valid = 0;
@@ -188,6 +187,231 @@ __global__ __launch_bounds__(256) void k_lookup_var(const uint8_t* __restrict__ 
                 if (k < n) out[k] = res[r];
             }
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The tryptic probe, round 2.  Round 1 read the query bytes from global memory three times per lookup (hash, first word,
+// comparison) with per-lane unaligned 8-byte loads -- ~20 vector-cache accesses per lookup, which, not the L2-miss rate, set
+// its pace (16.5 G lookups/s at 26 G requests/s).  Now a wave takes two batches of 64 queries at a time:
+//   1. the batch's bytes -- one contiguous range of the query buffer, <= 4 KB -- are copied to the wave's LDS strip with
+//      aligned 16-byte loads (the only time they are read from global memory);
+//   2. every lane hashes its key FROM LDS (aligned dword reads + v_alignbyte);
+//   3. the 8 home buckets (2 batches x 4 rounds) are fetched back to back, a quad per bucket;
+//   4. for the slot whose tag and length agree the QUAD fetches the key's heap bytes together (lane j: bytes 16j..16j+15,
+//      one instruction covers the whole key) and compares them with the query bytes in LDS;
+//   5. the rare rest (a second candidate in the bucket, displacement chain, stash) takes the round-1 path.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t VAR_STAGE = 64 * VAR_MAX_LEN + 16 + 48;   // a batch's bytes + alignment slack + read-ahead of the dword window
+typedef u32x4 __attribute__((aligned(1))) u32x4_unaligned;
+
+// 32 / 64 bits of the staged bytes at byte offset s (any alignment)
+__device__ __forceinline__ uint32_t lds_load32(const uint32_t* w, uint32_t s) {
+    const uint32_t k = s >> 2;
+    return __builtin_amdgcn_alignbyte(w[k + 1], w[k], s & 3u);
+}
+__device__ __forceinline__ uint64_t lds_load64(const uint32_t* w, uint32_t s) {
+    const uint32_t k = s >> 2, sh = s & 3u;
+    const uint32_t a = w[k], b = w[k + 1], c = w[k + 2];
+    return ((uint64_t)__builtin_amdgcn_alignbyte(c, b, sh) << 32) | __builtin_amdgcn_alignbyte(b, a, sh);
+}
+// hash_bytes over staged bytes (same words in the same order)
+__device__ __forceinline__ uint64_t hash_lds(const uint32_t* w, uint32_t s, uint32_t len) {
+    uint64_t h = 0xCBF29CE484222325ull ^ ((uint64_t)len * 0x9E3779B97F4A7C15ull);
+    if (len >= 8) {
+        uint32_t i = 0;
+        for (; i + 8 <= len; i += 8) {
+            h = (h ^ lds_load64(w, s + i)) * 0xD6E8FEB86659FD93ull;
+            h ^= h >> 29;
+        }
+        if (i < len) {
+            h = (h ^ lds_load64(w, s + len - 8)) * 0xD6E8FEB86659FD93ull;
+            h ^= h >> 29;
+        }
+    } else {
+        for (uint32_t i = 0; i < len; i++) h = (h ^ (lds_load32(w, s + i) & 0xFFu)) * 0x100000001B3ull;
+    }
+    h ^= h >> 32;
+    h *= 0xD6E8FEB86659FD93ull;
+    h ^= h >> 32;
+    return h;
+}
+
+// the rare rest of one round (quad-uniform call): every candidate slot of the home bucket verified by its own lane against the
+// query bytes in global memory, then the displacement chain, then the stash -- the round-1 sequence
+__device__ __noinline__ uint32_t lookup_round_slow(const VarView& T, const uint8_t* qp, uint32_t len, uint64_t hq, u32x4 e, uint32_t miss, uint32_t j) {
+    const uint64_t bucket = __umul64hi(hq, T.nb);
+    const uint32_t want = ((uint32_t)hq & 0x01FFFFFFu) | (len << 25);
+    const uint64_t off = ((uint64_t)e.w << 32) | e.z;
+    uint32_t hit = 0, vv = 0, r_out = miss;
+    if (off != VAR_EMPTY && (e.x & 0x7FFFFFFFu) == want && bytes_equal(T.heap + off, qp, len)) { hit = 1; vv = e.y; }
+    uint32_t f = quad_or(hit | (((j == 0) ? (e.x >> 31) : 0u) << 1));
+    vv = quad_or(vv);
+    bool found = f & 1u, go = !found && (f & 2u);
+    if (found) r_out = vv;
+    for (uint32_t d = 1; go && d <= VAR_MAX_DISP; d++) {
+        const u32x4 ed = __builtin_nontemporal_load(T.slots + (bucket + d) * VAR_SLOTS + j);
+        const uint64_t offd = ((uint64_t)ed.w << 32) | ed.z;
+        vv = 0; hit = 0;
+        if (offd != VAR_EMPTY && (ed.x & 0x7FFFFFFFu) == want && bytes_equal(T.heap + offd, qp, len)) { hit = 1; vv = ed.y; }
+        f = quad_or(hit | (((j == 0) ? (ed.x >> 31) : 0u) << 1));
+        vv = quad_or(vv);
+        if (f & 1u) { r_out = vv; found = true; go = false; }
+        else if (!(f & 2u)) go = false;
+    }
+    if (!found && go && T.n_stash) r_out = var_stash_lookup(T, hq, qp, len, miss);
+    return r_out;
+}
+
+// NB batches of 64 queries per wave and step.
+template <int NB>
+__global__ __launch_bounds__(256) void k_lookup_var(const uint8_t* __restrict__ qbytes, const uint64_t* __restrict__ qoff, size_t n,
+                                                    uint32_t miss, uint32_t* __restrict__ out, VarView T) {
+    __shared__ uint32_t lds[4][NB][VAR_STAGE / 4];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const uint64_t all_end = n ? qoff[n] : 0;      // the query buffer is valid on [qbytes, qbytes + qoff[n])
+    for (size_t base0 = wave * 64 * NB; base0 < n; base0 += nwaves * 64 * NB) {
+        // ---- 1. offsets, staging ----------------------------------------------------------------------------------------------
+        uint64_t o[NB], h[NB];
+        uint32_t meta[NB];           // staged offset (13 bits) | len << 13 (6 bits) | valid << 19
+        bool staged[NB];
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const size_t base = base0 + 64 * b, i = base + lane;
+            uint64_t o1 = 0;
+            uint32_t len = 0, valid = 0, soff = 0;
+            o[b] = 0;
+            h[b] = 0;
+            if (i < n) {
+                o[b] = qoff[i];
+                o1 = qoff[i + 1];
+                const uint64_t l64 = o1 - o[b];
+                if (o1 >= o[b] && l64 >= 1 && l64 <= VAR_MAX_LEN) { len = (uint32_t)l64; valid = 1; }
+            }
+            // the batch's byte range: from the first lane's start to the last lane's end
+            const uint32_t nl = base < n ? (uint32_t)min((size_t)64, n - base) : 0u;
+            staged[b] = false;
+            if (nl) {
+                const uint32_t f_lo = (uint32_t)__shfl((int)(uint32_t)o[b], 0, 64), f_hi = (uint32_t)__shfl((int)(uint32_t)(o[b] >> 32), 0, 64);
+                const uint32_t e_lo = (uint32_t)__shfl((int)(uint32_t)o1, (int)nl - 1, 64), e_hi = (uint32_t)__shfl((int)(uint32_t)(o1 >> 32), (int)nl - 1, 64);
+                const uint64_t first = ((uint64_t)f_hi << 32) | f_lo, end = ((uint64_t)e_hi << 32) | e_lo;
+                // every key must lie inside [first, end) and the range must fit the strip; otherwise the batch takes the global path
+                const bool inside = !valid || (o[b] >= first && o[b] + len <= end);
+                const uint64_t a0 = (uint64_t)(uintptr_t)(qbytes + first) & ~15ull;                  // absolute, 16-byte aligned
+                const uint64_t span = end >= first ? (uint64_t)(uintptr_t)(qbytes + end) - a0 : ~0ull;
+                staged[b] = span <= 64 * VAR_MAX_LEN + 16 && end <= all_end && !__any(!inside);
+                if (staged[b]) {
+                    const uint64_t lo_abs = (uint64_t)(uintptr_t)qbytes, hi_abs = (uint64_t)(uintptr_t)(qbytes + all_end);
+                    u32x4* dst = reinterpret_cast<u32x4*>(lds[wv][b]);
+                    for (uint32_t c = lane; (uint64_t)c * 16 < span; c += 64) {
+                        const uint64_t a = a0 + (uint64_t)c * 16;
+                        u32x4 v{0u, 0u, 0u, 0u};
+                        if (a >= lo_abs && a + 16 <= hi_abs) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a));
+                        else {   // the chunk straddles an end of the buffer: byte by byte, inside only
+                            uint32_t wds[4] = {0u, 0u, 0u, 0u};
+                            for (uint32_t t = 0; t < 16; t++)
+                                if (a + t >= lo_abs && a + t < hi_abs) wds[t >> 2] |= (uint32_t)*reinterpret_cast<const uint8_t*>(a + t) << (8 * (t & 3));
+                            v = u32x4{wds[0], wds[1], wds[2], wds[3]};
+                        }
+                        dst[c] = v;
+                    }
+                    soff = (uint32_t)((uint64_t)(uintptr_t)(qbytes + o[b]) - a0);
+                } else {
+                    lookup_batch_global(qbytes, qoff, n, base, miss, out, T, lane);   // ill-formed offsets: the round-1 path, nothing live yet
+                    valid = 0;
+                }
+            }
+            meta[b] = soff | (len << 13) | (valid << 19);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- 2. hash from LDS -------------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+            if (meta[b] >> 19) h[b] = hash_lds(lds[wv][b], meta[b] & 0x1FFFu, (meta[b] >> 13) & 63u);
+        // ---- 3. the home buckets of NB x 4 rounds, back to back -----------------------------------------------------------------
+        uint32_t rm[NB][4], want[NB][4];     // rm: the round's meta (the owning lane's) | first candidate lane << 20 (4 = none) | #candidates << 23
+        u32x4 e[NB][4], hp[NB][4];
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int src = 16 * r + (int)q;
+                rm[b][r] = (uint32_t)__shfl((int)meta[b], src, 64);
+                const uint32_t hl = (uint32_t)__shfl((int)(uint32_t)h[b], src, 64), hh = (uint32_t)__shfl((int)(uint32_t)(h[b] >> 32), src, 64);
+                const uint64_t hq = ((uint64_t)hh << 32) | hl;
+                want[b][r] = (hl & 0x01FFFFFFu) | (((rm[b][r] >> 13) & 63u) << 25);
+                e[b][r] = (rm[b][r] >> 19) ? __builtin_nontemporal_load(T.slots + __umul64hi(hq, T.nb) * VAR_SLOTS + j) : u32x4{0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            }
+        // ---- 4. the candidates' heap bytes, a quad per key ---------------------------------------------------------------------
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint64_t off = ((uint64_t)e[b][r].w << 32) | e[b][r].z;
+                const uint32_t cand = ((rm[b][r] >> 19) && off != VAR_EMPTY && (e[b][r].x & 0x7FFFFFFFu) == want[b][r]) ? 1u : 0u;
+                const uint32_t bits = quad_or(cand << j);
+                const uint32_t ci = bits ? (uint32_t)__builtin_ctz(bits) : 4u;
+                rm[b][r] |= (ci << 20) | ((uint32_t)__builtin_popcount(bits) << 23);
+                const int srcl = (int)((lane & ~3u) | (ci & 3u));
+                const uint32_t ol = (uint32_t)__shfl((int)e[b][r].z, srcl, 64), oh = (uint32_t)__shfl((int)e[b][r].w, srcl, 64);
+                hp[b][r] = u32x4{0u, 0u, 0u, 0u};
+                if (ci < 4u && 16u * j < ((rm[b][r] >> 13) & 63u))
+                    hp[b][r] = *reinterpret_cast<const u32x4_unaligned*>(T.heap + ((((uint64_t)oh << 32) | ol) + 16u * j));
+            }
+        // ---- 5. compare with the query bytes in LDS; the rare rest on the round-1 path ------------------------------------------
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const size_t base = base0 + 64 * b;
+            if (!staged[b]) continue;                       // wave-uniform (done above, or past the end)
+            uint32_t res[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                uint32_t r_out = miss;
+                const uint32_t m = rm[b][r], ln = (m >> 13) & 63u, ci = (m >> 20) & 7u, nc = m >> 23;
+                if ((m >> 19) & 1u) {   // quad-uniform
+                    uint32_t mism = 0;
+                    if (ci < 4u && 16u * j < ln) {
+                        const uint32_t* w = lds[wv][b];
+                        const uint32_t s = (m & 0x1FFFu) + 16u * j, k = s >> 2, sh = s & 3u;
+                        const uint32_t w0 = w[k], w1 = w[k + 1], w2 = w[k + 2], w3 = w[k + 3], w4 = w[k + 4];
+                        const uint32_t qd[4] = {__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh),
+                                                __builtin_amdgcn_alignbyte(w3, w2, sh), __builtin_amdgcn_alignbyte(w4, w3, sh)};
+                        const uint32_t hd[4] = {hp[b][r].x, hp[b][r].y, hp[b][r].z, hp[b][r].w};
+                        const uint32_t left = ln - 16u * j;       // bytes of the key from this lane's piece on (>= 1)
+#pragma unroll
+                        for (uint32_t d = 0; d < 4; d++) {
+                            const uint32_t nv = left > 4u * d ? min(left - 4u * d, 4u) : 0u;
+                            const uint32_t mask = nv >= 4u ? 0xFFFFFFFFu : ((1u << (8u * nv)) - 1u);
+                            mism |= (qd[d] ^ hd[d]) & mask;
+                        }
+                    }
+                    const uint32_t bad = quad_or(mism ? 1u : 0u);
+                    const uint32_t val = (uint32_t)__shfl((int)e[b][r].y, (int)((lane & ~3u) | (ci & 3u)), 64);
+                    const uint32_t ovf = quad_or((j == 0) ? (e[b][r].x >> 31) : 0u);
+                    if (ci < 4u && !bad) r_out = val;
+                    else if (nc > 1u || ovf) {
+                        // another slot of the bucket shares tag and length (~1e-7), or the home bucket overflowed at build time
+                        const int src = 16 * r + (int)q;
+                        const uint64_t oq = (uint64_t)(uint32_t)__shfl((int)(uint32_t)o[b], src, 64) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(o[b] >> 32), src, 64) << 32);
+                        const uint64_t hq = (uint64_t)(uint32_t)__shfl((int)(uint32_t)h[b], src, 64) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(h[b] >> 32), src, 64) << 32);
+                        r_out = lookup_round_slow(T, qbytes + oq, ln, hq, e[b][r], miss, j);
+                    }
+                }
+                res[r] = r_out;
+            }
+            if (j == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const size_t k = base + 16 * r + q;
+                    if (k < n) out[k] = res[r];
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -312,7 +536,7 @@ int var_build(umgap_var_index** out, uint8_t* d_heap, uint64_t heap_bytes, const
         if (rc) break;
         // self check: every key finds its own taxon (a duplicate key finds the other copy's)
         if (n) {
-            hipLaunchKernelGGL(k_lookup_var, dim3(grid_for(n)), dim3(256), 0, stream, d_heap, d_off, n, 0xFFFFFFFFu, d_got, v->view());
+            hipLaunchKernelGGL(k_lookup_var<1>, dim3(grid_for(n)), dim3(256), 0, stream, d_heap, d_off, n, 0xFFFFFFFFu, d_got, v->view());
             hipLaunchKernelGGL(k_selfcheck_var, dim3(grid_for(n)), dim3(256), 0, stream, d_got, d_vals, n, d_flags);
             e = hipMemcpyAsync(&h, d_flags, sizeof(h), hipMemcpyDeviceToHost, stream);
             if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -330,13 +554,23 @@ int var_build(umgap_var_index** out, uint8_t* d_heap, uint64_t heap_bytes, const
 
 int var_lookup_dev(const umgap_var_index* v, const uint8_t* d_bytes, const uint64_t* d_off, size_t n, uint32_t miss, uint32_t* d_out, hipStream_t s) {
     // a grid of whole resident rounds (two of them): with a partial last round the kernel measured 16 % slower
-    static int per_cu = 0;
-    if (!per_cu) {
-        int b = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_lookup_var, 256, 0) != hipSuccess || b < 1) b = 4;
-        per_cu = 2 * b;
+    static int per_cu[2] = {0, 0};
+    static int nb_choice = -1;
+    if (nb_choice < 0) {
+        const char* env = getenv("UMGAP_VAR_BATCHES");     // A/B switch of the measurement tools: batches of 64 in flight per wave
+        nb_choice = (env && env[0] == '2') ? 2 : 1;
     }
-    if (n) hipLaunchKernelGGL(k_lookup_var, dim3(grid_for(n, (size_t)per_cu)), dim3(256), 0, s, d_bytes, d_off, n, miss, d_out, v->view());
+    const int which = nb_choice == 2 ? 1 : 0;
+    if (!per_cu[which]) {
+        int b = 0;
+        hipError_t e = which ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_lookup_var<2>, 256, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_lookup_var<1>, 256, 0);
+        if (e != hipSuccess || b < 1) b = 4;
+        per_cu[which] = 2 * b;
+    }
+    if (n) {
+        if (which) hipLaunchKernelGGL(k_lookup_var<2>, dim3(grid_for(n, (size_t)per_cu[which])), dim3(256), 0, s, d_bytes, d_off, n, miss, d_out, v->view());
+        else hipLaunchKernelGGL(k_lookup_var<1>, dim3(grid_for(n, (size_t)per_cu[which])), dim3(256), 0, s, d_bytes, d_off, n, miss, d_out, v->view());
+    }
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
 }
@@ -373,7 +607,7 @@ int umgap_index_build_var_dev(const uint8_t* d_bytes, const uint64_t* d_offsets,
     int rc = new_var_handle(device, &ix);
     if (rc) return rc;
     uint8_t* heap = nullptr;
-    hipError_t e = hipMalloc((void**)&heap, std::max<uint64_t>(n_bytes, 1));
+    hipError_t e = hipMalloc((void**)&heap, n_bytes + 64);   // the probe's quad reads 16-byte pieces: up to 15 bytes past a key's end
     if (e == hipSuccess && n_bytes) e = hipMemcpyAsync(heap, d_bytes, n_bytes, hipMemcpyDeviceToDevice, ix->stream);
     if (e != hipSuccess) { if (heap) (void)hipFree(heap); umgap_index_free(ix); return fail(UMGAP_ERR_NOMEM, std::string("var index heap: ") + hipGetErrorString(e)); }
     rc = var_build(&ix->var, heap, n_bytes, d_offsets, d_taxa, n, load_factor, ix->stream);
@@ -392,7 +626,7 @@ int umgap_index_build_var(const uint8_t* bytes, const uint64_t* offsets, const u
     std::vector<uint64_t> rel(n + 1, 0);
     for (size_t i = 0; i <= n && n; i++) rel[i] = offsets[i] - base;
     uint8_t* db = nullptr; uint64_t* doff = nullptr; uint32_t* dv = nullptr;
-    hipError_t e = hipMalloc((void**)&db, std::max<uint64_t>(n_bytes, 1));
+    hipError_t e = hipMalloc((void**)&db, n_bytes + 64);   // becomes the heap: padded for the probe's 16-byte pieces
     if (e == hipSuccess) e = hipMalloc((void**)&doff, (n + 1) * 8);
     if (e == hipSuccess) e = hipMalloc((void**)&dv, std::max<size_t>(n, 1) * 4);
     if (e == hipSuccess && n_bytes) e = hipMemcpy(db, bytes + base, n_bytes, hipMemcpyHostToDevice);
@@ -519,7 +753,7 @@ int var_open(umgap_index* ix, const IndexFileHeader& h, FILE* f, const char* pat
     bool ok = true;
     auto slurp = [&](void** d, size_t total) {
         if (!ok) return;
-        if (hipMalloc(d, std::max<size_t>(total, 1)) != hipSuccess) { ok = false; return; }
+        if (hipMalloc(d, total + 64) != hipSuccess) { ok = false; return; }   // + 64: the heap is read in 16-byte pieces past a key's end
         for (size_t off = 0; ok && off < total; off += chunk) {
             size_t len = std::min(chunk, total - off);
             if (fread(buf.data(), 1, len, f) != len) { ok = false; break; }

@@ -124,14 +124,17 @@ struct umgap_comm {
 
 namespace {
 
-// every rank sends `bytes` to every rank (its own share included): recv region p <- rank p's send region `rank`
+// every rank sends `bytes` to every OTHER rank: recv region p <- rank p's send region `rank`.  A rank's own share never
+// travels (nor is it copied): the kernels read / write region `rank` in place (k_shard_probe).
 int comm_alltoall(umgap_comm* c, const void* send, void* recv, size_t bytes, hipStream_t s) {
+    if (c->world == 1) return UMGAP_OK;
     if (c->hub) {
         LocalHub& H = *c->hub;
         H.send[c->rank] = send;
         UMGAP_HIP(hipEventRecord(H.ready[c->rank], s));
         H.barrier();
         for (int p = 0; p < c->world; p++) {
+            if (p == c->rank) continue;
             UMGAP_HIP(hipStreamWaitEvent(s, H.ready[p], 0));
             UMGAP_HIP(hipMemcpyAsync((char*)recv + (size_t)p * bytes, (const char*)H.send[p] + (size_t)c->rank * bytes, bytes, hipMemcpyDeviceToDevice, s));
         }
@@ -144,6 +147,7 @@ int comm_alltoall(umgap_comm* c, const void* send, void* recv, size_t bytes, hip
     Rccl* R = rccl();
     UMGAP_NCCL(R->GroupStart());
     for (int p = 0; p < c->world; p++) {
+        if (p == c->rank) continue;
         UMGAP_NCCL(R->Send((const char*)send + (size_t)p * bytes, bytes, ncclUint8, p, c->nccl, s));
         UMGAP_NCCL(R->Recv((char*)recv + (size_t)p * bytes, bytes, ncclUint8, p, c->nccl, s));
     }
@@ -261,52 +265,63 @@ __global__ __launch_bounds__(256) void k_shard_pad(uint8_t* __restrict__ send, c
     for (uint64_t i = filled + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) hi[i] = (uint16_t)wire::HI_NOKEY;
 }
 
-// received keys (world regions x cap slots) -> one value per slot.  A wave takes 128 consecutive slots (cap is a multiple
-// of 128, so they share a region): two probe batches in flight, results gathered into packed words and stored coalesced.
+// keys (world regions x cap slots) -> one value per slot.  Region `self` is this rank's own share: read from the send buffer
+// it was packed into and answered straight into the buffer the returned values are gathered from -- no copy, no wire.
+// One wave = 128 consecutive slots (cap is a multiple of 128, so they share a region): two probe batches in flight; the
+// results are packed in the wave's LDS strip and leave as whole 16-byte-per-lane stores.  One step per wave and a grid of
+// as many workgroups as there is work: the workgroups are short-lived, so kernels of the other pieces (pack, aggregate,
+// RCCL's copies) keep getting compute units while a probe is running.
 template <int VB>
-__global__ __launch_bounds__(256) void k_shard_probe(TableView T, const uint8_t* __restrict__ recv, uint64_t cap, uint64_t n_slots, uint32_t* __restrict__ ret) {
-    const uint32_t lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+__global__ __launch_bounds__(256) void k_shard_probe(TableView T, const uint8_t* __restrict__ recv, const uint8_t* __restrict__ own_send, uint32_t self,
+                                                     uint64_t cap, uint64_t n_slots, uint32_t* __restrict__ ret, uint32_t* __restrict__ own_ret) {
+    __shared__ uint32_t lds_out[4][128];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
+    const uint64_t s0 = (((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 128;
     constexpr uint32_t MISS = VB == 3 ? 0xFFFFFFu : 0xFFFFFFFFu;
-    for (uint64_t s0 = wave * 128; s0 < n_slots; s0 += nwaves * 128) {
-        const uint64_t region = s0 / cap, pos0 = s0 - region * cap;
-        const uint8_t* rb = recv + region * cap * 6;
-        const uint32_t* lo = reinterpret_cast<const uint32_t*>(rb) + pos0;
-        const uint16_t* hi = reinterpret_cast<const uint16_t*>(rb + cap * 4) + pos0;
-        ProbeBatch B[2];
-        uint32_t res[2][4];
+    if (s0 >= n_slots) return;
+    const uint64_t region = s0 / cap, pos0 = s0 - region * cap;
+    const uint8_t* rb = (region == self ? own_send : recv) + region * cap * 6;
+    const uint32_t* lo = reinterpret_cast<const uint32_t*>(rb) + pos0;
+    const uint16_t* hi = reinterpret_cast<const uint16_t*>(rb + cap * 4) + pos0;
+    ProbeBatch B[2];
+    uint32_t res[2][4];
 #pragma unroll
-        for (int b = 0; b < 2; b++) {
-            const uint32_t l = __builtin_nontemporal_load(lo + 64 * b + lane);
-            const uint32_t hh = __builtin_nontemporal_load(hi + 64 * b + lane);
-            uint32_t local = 0, tag = 0, valid = 0;
-            if (hh < (1u << 13)) {
-                const uint64_t h = ((uint64_t)hh << 32) | l;
-                const uint32_t a = (uint32_t)(h >> R_BITS);
-                tag = (uint32_t)h & R_MASK;
-                const uint32_t bkt = a * T.m + (uint32_t)(((uint64_t)tag * T.m) >> R_BITS);
-                local = bkt - T.home_lo;
-                valid = (bkt >= T.home_lo && bkt < T.home_hi) ? 1u : 0u;   // a key this shard does not own is a miss
-            }
-            probe_issue(T, local, tag | (valid << 31), lane, B[b]);
+    for (int b = 0; b < 2; b++) {
+        const uint32_t l = __builtin_nontemporal_load(lo + 64 * b + lane);
+        const uint32_t hh = __builtin_nontemporal_load(hi + 64 * b + lane);
+        uint32_t local = 0, tag = 0, valid = 0;
+        if (hh < (1u << 13)) {
+            const uint64_t h = ((uint64_t)hh << 32) | l;
+            const uint32_t a = (uint32_t)(h >> R_BITS);
+            tag = (uint32_t)h & R_MASK;
+            const uint32_t bkt = a * T.m + (uint32_t)(((uint64_t)tag * T.m) >> R_BITS);
+            local = bkt - T.home_lo;
+            valid = (bkt >= T.home_lo && bkt < T.home_hi) ? 1u : 0u;   // a key this shard does not own is a miss
         }
-        probe_eval_multi<2>(T, B, MISS, lane, res);
-#pragma unroll
-        for (int b = 0; b < 2; b++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const uint64_t s = s0 + 64 * b + 16 * r;          // slot of quad 0 of this round
-                if (VB == 4) {
-                    if (j == 0) ret[s + q] = res[b][r];
-                } else {
-                    // four 24-bit values -> three words: quad i = q & 3 of a group of four builds word i from its value and the next quad's
-                    const uint32_t t = res[b][r] & 0xFFFFFFu, tn = (uint32_t)__shfl_down((int)t, 4, 64);
-                    const uint32_t i = q & 3;
-                    const uint32_t w = i == 0 ? (t | (tn << 24)) : (i == 1 ? ((t >> 8) | (tn << 16)) : ((t >> 16) | (tn << 8)));
-                    if (j == 0 && i < 3) ret[(s >> 2) * 3 + (q >> 2) * 3 + i] = w;
-                }
-            }
+        probe_issue(T, local, tag | (valid << 31), lane, B[b]);
     }
+    probe_eval_multi<2>(T, B, MISS, lane, res);
+    uint32_t* wl = lds_out[wv];
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const uint32_t s = 64 * b + 16 * r;                  // slot (within the wave's 128) of quad 0 of this round
+            if (VB == 4) {
+                if (j == 0) wl[s + q] = res[b][r];
+            } else {
+                // four 24-bit values -> three words: quad i = q & 3 of a group of four builds word i from its value and the next quad's
+                const uint32_t t = res[b][r] & 0xFFFFFFu, tn = (uint32_t)__shfl_down((int)t, 4, 64);
+                const uint32_t i = q & 3;
+                const uint32_t w = i == 0 ? (t | (tn << 24)) : (i == 1 ? ((t >> 8) | (tn << 16)) : ((t >> 16) | (tn << 8)));
+                if (j == 0 && i < 3) wl[(s >> 2) * 3 + (q >> 2) * 3 + i] = w;
+            }
+        }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // 128 slots = 96 (VB 3) or 128 (VB 4) words = 24 or 32 lanes x 16 bytes, contiguous
+    uint32_t* dst = (region == self ? own_ret : ret) + (VB == 4 ? s0 : (s0 >> 2) * 3);
+    if (lane < (VB == 4 ? 32u : 24u)) reinterpret_cast<u32x4*>(dst)[lane] = reinterpret_cast<const u32x4*>(wl)[lane];
 }
 
 // the plain sharded get(): out[i] = value of key i (perm order undone), or miss_value
@@ -378,7 +393,7 @@ int piece_out(umgap_sharded* sh, BufSet& S, const uint64_t* d_keys, size_t nk, b
     hipStream_t s = S.stream;
     UMGAP_HIP(hipMemsetAsync(S.cursor, 0, W * sizeof(unsigned long long), s));
     const size_t tile = 256 * PACK_PER_THREAD;
-    unsigned g = (unsigned)std::min<size_t>((nk + tile - 1) / tile, 2048);
+    unsigned g = (unsigned)((nk + tile - 1) / tile);   // one tile per workgroup: short-lived workgroups leave room for the other pieces' kernels
     if (g < 1) g = 1;
     hipLaunchKernelGGL(k_shard_pack, dim3(g), dim3(256), 0, s, d_keys, nk, T.m, T.nb, W, sh->cap, S.send_keys, S.perm, S.cursor, sh->d_overflow);
     hipLaunchKernelGGL(k_shard_pad, dim3(64, W), dim3(256), 0, s, S.send_keys, S.cursor, sh->cap);
@@ -386,11 +401,11 @@ int piece_out(umgap_sharded* sh, BufSet& S, const uint64_t* d_keys, size_t nk, b
     int rc = comm_alltoall(sh->comm, S.send_keys, S.recv_keys, (size_t)sh->cap * 6, s);
     if (rc) return rc;
     const uint64_t n_slots = sh->cap * W;
-    unsigned gp = (unsigned)std::min<uint64_t>((n_slots / 128 + 3) / 4, 256 * 8);
-    if (gp < 1) gp = 1;
+    const unsigned gp = (unsigned)((n_slots / 128 + 3) / 4);
+    const uint32_t self = (uint32_t)sh->comm->rank;
     if (time_probe) UMGAP_HIP(hipEventRecord(sh->ev_probe0, s));
-    if (sh->value_bytes == 3) hipLaunchKernelGGL(k_shard_probe<3>, dim3(gp), dim3(256), 0, s, T, S.recv_keys, sh->cap, n_slots, S.ret_send);
-    else hipLaunchKernelGGL(k_shard_probe<4>, dim3(gp), dim3(256), 0, s, T, S.recv_keys, sh->cap, n_slots, S.ret_send);
+    if (sh->value_bytes == 3) hipLaunchKernelGGL(k_shard_probe<3>, dim3(gp), dim3(256), 0, s, T, S.recv_keys, S.send_keys, self, sh->cap, n_slots, S.ret_send, S.ret_recv);
+    else hipLaunchKernelGGL(k_shard_probe<4>, dim3(gp), dim3(256), 0, s, T, S.recv_keys, S.send_keys, self, sh->cap, n_slots, S.ret_send, S.ret_recv);
     UMGAP_HIP(hipGetLastError());
     if (time_probe) { UMGAP_HIP(hipEventRecord(sh->ev_probe1, s)); sh->probe_timed = true; }
     return UMGAP_OK;
