@@ -383,6 +383,63 @@ def test_prot2tryp2lca_matches_oracle(tryptic, flags):
     assert out.count(b"\n") > 600
 
 
+def test_prot2tryp2lca_custom_pattern(tryptic):
+    """-p <regex> (src/commands/prot2tryp2lca.rs:65-68,112-115): the pattern is applied as replace_all(.., "$1\\n$2") twice.  A
+    pattern that spells the default differently must reproduce the default's output; a different enzyme (cut after K only) is
+    checked against the same two substitutions done in Python over a dict of the index."""
+    import re
+    rng = np.random.default_rng(19)
+    recs, prots = [], []
+    for r in range(120):
+        prot = tryptic["proteins"][int(rng.integers(0, len(tryptic["proteins"])))]
+        if rng.random() < 0.3:
+            prot = prot[: len(prot) // 3] + "*" + prot[len(prot) // 3:]
+        prots.append(prot)
+        recs.append(">p%d\n%s\n" % (r, prot))
+    fasta = "".join(recs).encode()
+    rc0, out0, _ = run(["prot2tryp2lca", "-o", "-l", "5", "-L", "50", tryptic["idx"]], fasta)
+    rc1, out1, err1 = run(["prot2tryp2lca", "-o", "-l", "5", "-L", "50", "-p", "([RK])([^P])", tryptic["idx"]], fasta)
+    assert rc0 == 0 == rc1 and out1 == out0, err1
+    table = dict(l.split("\t") for l in open(tryptic["tsv"]).read().splitlines())
+    pat = re.compile("(K)([^P])")
+    want = []
+    for r, prot in enumerate(prots):
+        want.append(">p%d" % r)
+        cut = pat.sub(r"\1\n\2", pat.sub(r"\1\n\2", prot)).replace("*", "\n")
+        want += [table.get(pep, "0") for pep in cut.split("\n") if 5 <= len(pep) <= 50]
+    rc2, out2, err2 = run(["prot2tryp2lca", "-o", "-l", "5", "-L", "50", "--pattern", "(K)([^P])", tryptic["idx"]], fasta)
+    assert rc2 == 0 and out2.decode().splitlines() == want, err2
+    assert out2 != out0
+    rc, _, err = run(["prot2tryp2lca", "-p", "([KR", tryptic["idx"]], fasta)
+    assert rc == 1 and err.startswith(b"Error: ")
+
+
+@pytest.mark.parametrize("k,flags", [(7, ["-o"]), (12, []), (12, ["-o", "-c", "7"]), (64, ["-o"])])
+def test_prot2kmer2lca_any_k_on_a_byte_string_index(tryptic, k, flags):
+    """src/commands/prot2kmer2lca.rs:71-73,172-179: -k is free; an index whose keys are byte strings serves every window length
+    (records shorter than k vanish with their header), byte for byte like the oracle."""
+    rng = np.random.default_rng(k)
+    peps = [p for p in tryptic["peps"] if len(p) == k]
+    recs = []
+    for r in range(200):
+        prot = tryptic["proteins"][int(rng.integers(0, len(tryptic["proteins"])))][: int(rng.integers(0, 90))]
+        if peps and rng.random() < 0.5 and len(prot) > k:
+            s = int(rng.integers(0, len(prot) - k))
+            prot = prot[:s] + peps[int(rng.integers(0, len(peps)))] + prot[s + k:]
+        recs.append(">q%d\n%s\n%s\n" % (r, prot[: len(prot) // 2], prot[len(prot) // 2:]))     # hard-wrapped: unwrapped by the reader
+    fasta = "".join(recs).encode()
+    rc, out, err = run(["prot2kmer2lca", "-k", str(k)] + flags + [tryptic["idx"]], fasta)
+    orc, oout, _ = O.run_cli(["prot2kmer2lca", "-k", str(k)] + flags + [tryptic["tsv"]], fasta)
+    assert rc == 0 == orc and out == oout, err
+    if k == 12 and "-o" not in flags:
+        assert any(l.isdigit() and l != "0" for l in out.decode().splitlines())
+    # a multi-byte character inside a window panics like the reference's slice (exit 101), after the completed chunks
+    bad = fasta + ">x\nACDEFGHIKLM\xc3\xa9NPQRSTVWYACDEFGHIKLMNPQRSTVWYACDEFGHIKLMNPQRSTVWYACDEFGHIKLMNPQRSTVWY\n>y\nAAAA\n".encode("latin1")
+    rc, out, err = run(["prot2kmer2lca", "-k", str(k), "-o", "-c", "50", tryptic["idx"]], bad)
+    orc, oout, _ = O.run_cli(["prot2kmer2lca", "-k", str(k), "-o", "-c", "50", tryptic["tsv"]], bad)
+    assert rc == orc == 101 and out == oout, (rc, orc, len(out), len(oout))
+
+
 def test_tryptic_precision_pipeline_matches_oracle(tryptic, world):
     """scripts/umgap-analyse.sh:295-298 minus FGSpp: prot2tryp2lca -l9 -L45 | uniq -d / | taxa2agg -l5 -m rmq -a mrtl
     (and the tryptic-sensitivity variant -l1)."""

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <functional>
 #include <map>
+#include <regex>
 
 #include "../../../include/umgap_hip.h"
 #include "fastpath.hpp"
@@ -336,12 +337,17 @@ umgap_index* open_index(const std::string& path) {
 
 // record loop shared by pept2lca (variable-length index) and prot2tryp2lca: `expand` turns one
 // sequence line into the peptides to look up
+// `unwrap`: the record's lines are one sequence (prot2kmer2lca reads with unwrap = true, src/io/fasta.rs:62-64).
+// `keep_record` (optional): a record it rejects prints nothing, not even its header (src/commands/prot2kmer2lca.rs:172),
+// but still counts towards its chunk.
 void stream_strings(FILE* in, FILE* outf, umgap_index* ix, bool one_on_one, size_t chunk,
-                    const std::function<void(const std::string&, StringBatch&)>& expand) {
+                    const std::function<void(const std::string&, StringBatch&)>& expand, bool unwrap = false,
+                    const std::function<bool(const Record&)>& keep_record = nullptr) {
     if (chunk == 0) chunk = 1;
-    FastaReader reader(in, false);
+    FastaReader reader(in, unwrap);
     Out out(outf);
     std::vector<std::string> headers;
+    std::vector<char> skip;     // record prints nothing at all
     std::vector<size_t> first;  // index of the record's first peptide in the batch
     StringBatch batch;
     std::vector<uint32_t> taxa;
@@ -349,25 +355,32 @@ void stream_strings(FILE* in, FILE* outf, umgap_index* ix, bool one_on_one, size
     auto run = [&](size_t keep) {
         lookup_strings(ix, batch, taxa);
         for (size_t r = 0; r < headers.size() && r < keep; r++) {
+            if (skip[r]) continue;
             out.buf.push_back('>'); out.buf.append(headers[r]); out.buf.push_back('\n');
             size_t end = r + 1 < headers.size() ? first[r + 1] : batch.size();
             for (size_t i = first[r]; i < end; i++)
                 if (taxa[i] != 0 || one_on_one) { append_u64(out.buf, taxa[i]); out.buf.push_back('\n'); }
             out.maybe_flush();
         }
-        headers.clear(); first.clear(); batch.clear();
+        headers.clear(); first.clear(); batch.clear(); skip.clear();
     };
     Record rec;
     try {
         while (reader.read_record(rec)) {
             first.push_back(batch.size());
+            const bool kept = !keep_record || keep_record(rec);
+            skip.push_back(kept ? 0 : 1);
             headers.push_back(std::move(rec.header));
-            for (auto& s : rec.sequence) expand(s, batch);
+            if (kept) for (auto& s : rec.sequence) expand(s, batch);
             // flush on chunk boundaries only, so that an error can still drop the whole open chunk
             if ((batch.bytes.size() >= (64u << 20) || headers.size() >= (1u << 20)) && headers.size() % chunk == 0) run(headers.size());
         }
     } catch (CliError&) {
         run(headers.size() / chunk * chunk);   // ChunkedRecords drops the chunk the error falls in (src/io/fasta.rs:125-131)
+        out.flush();
+        throw;
+    } catch (CliPanic&) {
+        run((headers.size() - 1) / chunk * chunk);   // a panic inside the record just pushed: its chunk is lost as well
         out.flush();
         throw;
     }
@@ -394,11 +407,24 @@ int cmd_prot2tryp2lca(const std::vector<std::string>& args) {
     size_t chunk = (size_t)opt_usize(p, "chunksize", 240);
     size_t minlen = (size_t)opt_usize(p, "minlen", 5), maxlen = (size_t)opt_usize(p, "maxlen", 50);
     std::string keep = p.get("keep").value_or(""), drop = p.get("drop").value_or("");
-    if (p.get("pattern").value_or("([KR])([^P])") != "([KR])([^P])")
-        throw CliError("only the default cleavage pattern ([KR])([^P]) is supported by the accelerated prot2tryp2lca");
+    const std::string pattern = p.get("pattern").value_or("([KR])([^P])");
+    const bool default_pattern = pattern == "([KR])([^P])";
+    // -p <regex> (src/commands/prot2tryp2lca.rs:65-68,96,112-115): replace_all(pattern, "$1\n$2") applied twice, host side.
+    // The reference compiles it with Rust's `regex` crate; here it is std::regex (ECMAScript), which reads the common
+    // subset -- literals, classes, groups, alternation, quantifiers -- the same way.  The default pattern keeps the scanner below.
+    std::regex custom;
+    if (!default_pattern) {
+        try { custom = std::regex(pattern, std::regex::ECMAScript | std::regex::optimize); }
+        catch (const std::regex_error& e) { throw CliError(std::string("regex parse error: ") + e.what()); }
+    }
     std::string path = need_positional(p, "fst-file");
     umgap_index* ix = open_index(path);
-    auto expand = [&](const std::string& seq, StringBatch& b) {
+    auto expand = [&](const std::string& seq_in, StringBatch& b) {
+        std::string cut;
+        if (!default_pattern) {
+            cut = std::regex_replace(std::regex_replace(seq_in, custom, "$1\n$2"), custom, "$1\n$2");   // twice: a letter can end one match and start the next
+        }
+        const std::string& seq = default_pattern ? seq_in : cut;
         size_t st = 0;
         auto emit = [&](size_t a, size_t e) {
             std::string_view pep(seq.data() + a, e - a);
@@ -413,7 +439,7 @@ int cmd_prot2tryp2lca(const std::vector<std::string>& args) {
         for (size_t i = 0; i < seq.size(); i++) {
             char c = seq[i];
             if (c == '*' || c == '\n') { emit(st, i); st = i + 1; }
-            else if ((c == 'K' || c == 'R') && i + 1 < seq.size() && seq[i + 1] != 'P') { emit(st, i + 1); st = i + 1; }
+            else if (default_pattern && (c == 'K' || c == 'R') && i + 1 < seq.size() && seq[i + 1] != 'P') { emit(st, i + 1); st = i + 1; }
         }
         emit(st, seq.size());
     };
@@ -428,8 +454,24 @@ int cmd_prot2kmer2lca(const std::vector<std::string>& args) {
     size_t chunk = (size_t)opt_usize(p, "chunksize", 240);
     std::string path = need_positional(p, "fst-file");
     umgap_index* ix = open_index(path);
-    if (umgap_index_kind(ix) != 9) throw CliError("prot2kmer2lca needs a 9-mer index");
     bool o = p.has("one-on-one");
+    // A packed 9-mer table answers k = 9; any other k can only miss there (its keys are 9 residues long), which the fast
+    // path emits without asking the device.  A byte-string (variable-length) table serves EVERY k like the reference's fst
+    // does (src/commands/prot2kmer2lca.rs:71-73,172-179): all windows of k residues through umgap_index_lookup_var.
+    const bool var_index = umgap_index_kind(ix) != 9;
+    auto stream = [&](FILE* in, FILE* outf) {
+        if (!var_index) { stream_lookup(in, outf, ix, o, true, k, chunk); return; }
+        stream_strings(in, outf, ix, o, chunk,
+                       [&](const std::string& seq, StringBatch& b) {
+                           for (size_t i = 0; i + k <= seq.size(); i++) {
+                               // &prot[i..i + k] panics unless both ends are char boundaries
+                               if (((unsigned char)seq[i] & 0xC0) == 0x80 || (i + k < seq.size() && ((unsigned char)seq[i + k] & 0xC0) == 0x80))
+                                   throw CliPanic("byte index is not a char boundary");
+                               b.add(std::string_view(seq.data() + i, k));
+                           }
+                       },
+                       true, [&](const Record& r) { return !r.sequence.empty() && r.sequence[0].size() >= k; });
+    };
     if (auto sock = p.get("socket")) {
         // src/commands/prot2kmer2lca.rs:116-137: sequential connections, status lines on stdout
         int fd = socket(AF_UNIX, SOCK_STREAM, 0);
@@ -447,7 +489,7 @@ int cmd_prot2kmer2lca(const std::vector<std::string>& args) {
             FILE* in = fdopen(c, "rb");
             FILE* outf = fdopen(dup(c), "wb");
             try {
-                stream_lookup(in, outf, ix, o, true, k, chunk);
+                stream(in, outf);
                 printf("Connection finished succesfully.\n");
             } catch (CliError& e) { printf("Connection died with an error: %s\n", e.what()); }
             fflush(stdout);
@@ -455,7 +497,7 @@ int cmd_prot2kmer2lca(const std::vector<std::string>& args) {
             fclose(in);
         }
     }
-    stream_lookup(stdin, stdout, ix, o, true, k, chunk);
+    stream(stdin, stdout);
     umgap_index_free(ix);
     return 0;
 }

@@ -266,7 +266,7 @@ __device__ __noinline__ uint32_t lookup_round_slow(const VarView& T, const uint8
 // NB batches of 64 queries per wave and step.
 template <int NB>
 __global__ __launch_bounds__(256) void k_lookup_var(const uint8_t* __restrict__ qbytes, const uint64_t* __restrict__ qoff, size_t n,
-                                                    uint32_t miss, uint32_t* __restrict__ out, VarView T) {
+                                                    uint32_t miss, uint32_t* __restrict__ out, VarView T, uint32_t force_global) {
     __shared__ uint32_t lds[4][NB][VAR_STAGE / 4];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void k_lookup_var(const uint8_t* __restrict__ 
                 const bool inside = !valid || (o[b] >= first && o[b] + len <= end);
                 const uint64_t a0 = (uint64_t)(uintptr_t)(qbytes + first) & ~15ull;                  // absolute, 16-byte aligned
                 const uint64_t span = end >= first ? (uint64_t)(uintptr_t)(qbytes + end) - a0 : ~0ull;
-                staged[b] = span <= 64 * VAR_MAX_LEN + 16 && end <= all_end && !__any(!inside);
+                staged[b] = span <= 64 * VAR_MAX_LEN + 16 && end <= all_end && !__any(!inside) && !force_global;
                 if (staged[b]) {
                     const uint64_t lo_abs = (uint64_t)(uintptr_t)qbytes, hi_abs = (uint64_t)(uintptr_t)(qbytes + all_end);
                     u32x4* dst = reinterpret_cast<u32x4*>(lds[wv][b]);
@@ -371,6 +371,11 @@ __global__ __launch_bounds__(256) void k_lookup_var(const uint8_t* __restrict__ 
             for (int r = 0; r < 4; r++) {
                 uint32_t r_out = miss;
                 const uint32_t m = rm[b][r], ln = (m >> 13) & 63u, ci = (m >> 20) & 7u, nc = m >> 23;
+                // the key's offset and hash live in lane 16r + q: fetched while every lane is still active (a shuffle from a lane that
+                // the quad-uniform branch below has switched off reads nothing)
+                const int src = 16 * r + (int)q;
+                const uint64_t oq = (uint64_t)(uint32_t)__shfl((int)(uint32_t)o[b], src, 64) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(o[b] >> 32), src, 64) << 32);
+                const uint64_t hq = (uint64_t)(uint32_t)__shfl((int)(uint32_t)h[b], src, 64) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(h[b] >> 32), src, 64) << 32);
                 if ((m >> 19) & 1u) {   // quad-uniform
                     uint32_t mism = 0;
                     if (ci < 4u && 16u * j < ln) {
@@ -394,9 +399,6 @@ __global__ __launch_bounds__(256) void k_lookup_var(const uint8_t* __restrict__ 
                     if (ci < 4u && !bad) r_out = val;
                     else if (nc > 1u || ovf) {
                         // another slot of the bucket shares tag and length (~1e-7), or the home bucket overflowed at build time
-                        const int src = 16 * r + (int)q;
-                        const uint64_t oq = (uint64_t)(uint32_t)__shfl((int)(uint32_t)o[b], src, 64) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(o[b] >> 32), src, 64) << 32);
-                        const uint64_t hq = (uint64_t)(uint32_t)__shfl((int)(uint32_t)h[b], src, 64) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(h[b] >> 32), src, 64) << 32);
                         r_out = lookup_round_slow(T, qbytes + oq, ln, hq, e[b][r], miss, j);
                     }
                 }
@@ -498,6 +500,12 @@ int var_set_stash(umgap_var_index* v, std::vector<std::array<uint64_t, 3>>& e) {
     return UMGAP_OK;
 }
 
+// UMGAP_VAR_GLOBAL=1: every batch takes the round-1 global-memory path (A/B measurements, debugging)
+static uint32_t var_force_global() {
+    const char* e = getenv("UMGAP_VAR_GLOBAL");
+    return (e && e[0] == '1') ? 1u : 0u;
+}
+
 // d_heap / d_off / d_vals: device arrays; the heap is adopted by the index (not copied) when own_heap.
 int var_build(umgap_var_index** out, uint8_t* d_heap, uint64_t heap_bytes, const uint64_t* d_off, const uint32_t* d_vals, size_t n,
               double load, hipStream_t stream) {
@@ -536,7 +544,7 @@ int var_build(umgap_var_index** out, uint8_t* d_heap, uint64_t heap_bytes, const
         if (rc) break;
         // self check: every key finds its own taxon (a duplicate key finds the other copy's)
         if (n) {
-            hipLaunchKernelGGL(k_lookup_var<1>, dim3(grid_for(n)), dim3(256), 0, stream, d_heap, d_off, n, 0xFFFFFFFFu, d_got, v->view());
+            hipLaunchKernelGGL(k_lookup_var<1>, dim3(grid_for(n)), dim3(256), 0, stream, d_heap, d_off, n, 0xFFFFFFFFu, d_got, v->view(), var_force_global());
             hipLaunchKernelGGL(k_selfcheck_var, dim3(grid_for(n)), dim3(256), 0, stream, d_got, d_vals, n, d_flags);
             e = hipMemcpyAsync(&h, d_flags, sizeof(h), hipMemcpyDeviceToHost, stream);
             if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -568,8 +576,8 @@ int var_lookup_dev(const umgap_var_index* v, const uint8_t* d_bytes, const uint6
         per_cu[which] = 2 * b;
     }
     if (n) {
-        if (which) hipLaunchKernelGGL(k_lookup_var<2>, dim3(grid_for(n, (size_t)per_cu[which])), dim3(256), 0, s, d_bytes, d_off, n, miss, d_out, v->view());
-        else hipLaunchKernelGGL(k_lookup_var<1>, dim3(grid_for(n, (size_t)per_cu[which])), dim3(256), 0, s, d_bytes, d_off, n, miss, d_out, v->view());
+        if (which) hipLaunchKernelGGL(k_lookup_var<2>, dim3(grid_for(n, (size_t)per_cu[which])), dim3(256), 0, s, d_bytes, d_off, n, miss, d_out, v->view(), var_force_global());
+        else hipLaunchKernelGGL(k_lookup_var<1>, dim3(grid_for(n, (size_t)per_cu[which])), dim3(256), 0, s, d_bytes, d_off, n, miss, d_out, v->view(), var_force_global());
     }
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
