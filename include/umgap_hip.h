@@ -61,7 +61,7 @@ extern "C" {
 #define UMGAP_READ_EMPTY 1         /* no taxa left after the filters: out_taxon = 1 (:174)  */
 #define UMGAP_READ_UNKNOWN_TAXON 2 /* Err(UnknownTaxon(out_taxon)): host aborts, exit 1     */
 #define UMGAP_READ_PANIC 3         /* index out of bounds / unwrap on None: host exits 101  */
-#define UMGAP_READ_UNSUPPORTED 4   /* > 1024 distinct taxa in one read (hybrid/mrtl only): not computed */
+#define UMGAP_READ_UNSUPPORTED 4   /* > 32 768 distinct taxa in one read (hybrid/mrtl only): not computed */
 
 #define UMGAP_METHOD_TREE 0 /* -m tree (src/commands/taxa2agg.rs:186-190) */
 #define UMGAP_METHOD_RMQ 1  /* -m rmq  */

@@ -357,6 +357,32 @@ def test_general_random_vs_oracle(api, method, strategy, factor):
 
 
 @pytest.mark.parametrize("method,strategy,factor", [("rmq", "mrtl", 0.0), ("tree", "hybrid", 0.25), ("rmq", "hybrid", 0.5)])
+def test_general_more_than_1024_distinct_taxa(api, method, strategy, factor):
+    """The reference has no limit on the distinct taxa of a read (src/tree/mix.rs:43-64, src/rmq/rtl.rs:39-57): beyond the
+    1024 of the large LDS scratch a third pass keeps the read's working set in global memory (up to 32 768 distinct)."""
+    from umgap_amd.synth import synthetic_taxonomy
+    rng = np.random.default_rng(71)
+    ids, par, valid, rank = synthetic_taxonomy(8000, 12000, max_depth=30, seed=17)
+    tx = api.Taxonomy(ids, par, valid, rank)
+    agg = O.Aggregator(O.Taxonomy.from_arrays(ids, par, valid, rank), method, strategy, factor)
+    reads = [rng.choice(ids, 5).tolist()]
+    for k in (1100, 2600):
+        reads.append(rng.choice(ids, k, replace=False).tolist())                                        # k distinct, once each
+        reads.append(np.concatenate([rng.choice(ids, k, replace=False), rng.choice(ids[:40], 500)]).tolist())   # + a heavy core
+    reads.append(rng.choice(ids, 7).tolist())
+    taxa, offs = _csr(reads)
+    for lb in (0.0, 2.0):
+        t, s = tx.aggregate(taxa, offs, method=method, strategy=strategy, factor=factor, lower_bound=lb)
+        assert not (s == 4).any()                                                                       # nothing UNSUPPORTED
+        nbad, bad, wt, ws = agg.taxa2agg_check(taxa, offs, t, s, lower_bound=lb)
+        assert nbad == 0, (lb, [(len(reads[int(b)]), int(t[int(b)]), int(s[int(b)]), int(wt[int(b)]), int(ws[int(b)])) for b in bad[:3]])
+    # the same reads twice in one call and again afterwards: the global scratch is handed back clean
+    t2, s2 = tx.aggregate(np.concatenate([taxa, taxa]), np.concatenate([offs, offs[1:] + offs[-1]]), method=method, strategy=strategy, factor=factor, lower_bound=2.0)
+    n = len(reads)
+    assert (t2[:n] == t).all() and (t2[n:] == t).all() and (s2[:n] == s).all() and (s2[n:] == s).all()
+
+
+@pytest.mark.parametrize("method,strategy,factor", [("rmq", "mrtl", 0.0), ("tree", "hybrid", 0.25), ("rmq", "hybrid", 0.5)])
 def test_general_unknown_and_orphans_vs_oracle(api, method, strategy, factor):
     rng = np.random.default_rng(5)
     ids = np.array([1, 2, 3, 4, 5, 6, 7, 8, 20, 21, 22, 30], np.uint32)

@@ -8,6 +8,12 @@
 namespace umgap {
 namespace agg {
 
+__device__ __forceinline__ void wave_sync() {  // LDS hand-off between lanes of one wave
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// The working set of one read: in LDS, sized at compile time ...
 template <int CAP, int HCAP>
 struct Scratch {
     uint32_t hkeys[HCAP], hcnt[HCAP];
@@ -18,12 +24,41 @@ struct Scratch {
     uint32_t b_pre[CAP], b_last[CAP];
     float b_cnt[CAP];
     uint32_t b_dep[CAP], b_adj[CAP], b_lca[CAP];
+    static constexpr bool kLanePerElement = CAP <= 64;
+    __device__ static constexpr uint32_t cap() { return CAP; }
+    __device__ static constexpr uint32_t hcap() { return HCAP; }
+    __device__ static void sync() { wave_sync(); }
 };
-
-__device__ __forceinline__ void wave_sync() {  // LDS hand-off between lanes of one wave
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
+// ... or in global memory, sized at run time (the pass for reads with more distinct taxa than any LDS scratch holds: the
+// reference has no limit, src/tree/mix.rs:43-64, src/rmq/rtl.rs:39-57).  Lanes of one wave hand data to each other through
+// it, so a hand-off is an agent-scope fence (the vector cache is not coherent with the stores that go to L2).
+struct ScratchGlobal {
+    uint32_t *hkeys, *hcnt, *a_tax, *a_slot;
+    float* a_cnt;
+    uint32_t *s_pre, *s_last;
+    float* s_cnt;
+    uint32_t *b_pre, *b_last;
+    float* b_cnt;
+    uint32_t *b_dep, *b_adj, *b_lca;
+    uint32_t cap_, hcap_;
+    static constexpr bool kLanePerElement = false;
+    __device__ uint32_t cap() const { return cap_; }
+    __device__ uint32_t hcap() const { return hcap_; }
+    __device__ static void sync() {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "agent");
+        __builtin_amdgcn_wave_barrier();
+    }
+    // words of global memory one read's scratch takes
+    __host__ __device__ static size_t words(uint32_t cap, uint32_t hcap) { return 2 * (size_t)hcap + 12 * (size_t)cap; }
+    __host__ __device__ void carve(uint32_t* base, uint32_t cap, uint32_t hcap) {
+        cap_ = cap; hcap_ = hcap;
+        hkeys = base; base += hcap; hcnt = base; base += hcap;
+        a_tax = base; base += cap; a_slot = base; base += cap; a_cnt = (float*)base; base += cap;
+        s_pre = base; base += cap; s_last = base; base += cap; s_cnt = (float*)base; base += cap;
+        b_pre = base; base += cap; b_last = base; base += cap; b_cnt = (float*)base; base += cap;
+        b_dep = base; base += cap; b_adj = base; base += cap; b_lca = base;
+    }
+};
 __device__ __forceinline__ uint64_t lanemask_lt(uint32_t lane) { return (1ull << lane) - 1ull; }
 __device__ __forceinline__ float wave_maxf(float v) {
 #pragma unroll
@@ -65,9 +100,10 @@ __device__ __forceinline__ uint64_t lane_argmin_depth(const TaxView& V, uint32_t
 // more than CAP distinct taxa (nothing written; S clean).
 // BOUND: the taxa are the interval codes of a table bound to the taxonomy (bound.hpp): {pre, last} come from the code
 // itself when the subtree is smaller than 32 nodes (exact size), from one 4-byte gather otherwise; nothing can be unknown.
-template <bool SCORED, int CAP, int HCAP, bool BOUND = false>
-__device__ __forceinline__ bool general_read(const TaxView& V, Scratch<CAP, HCAP>& S, int method, int strategy, float factor, float lower_bound,
-                                             const uint32_t* rp, const float* sp, uint64_t n, uint32_t lane, uint32_t& res_taxon, uint32_t& res_status) {
+template <bool SCORED, class SCR, bool BOUND = false>
+__device__ __forceinline__ bool general_read_t(const TaxView& V, SCR& S, int method, int strategy, float factor, float lower_bound,
+                                               const uint32_t* rp, const float* sp, uint64_t n, uint32_t lane, uint32_t& res_taxon, uint32_t& res_status) {
+    const uint32_t CAP = S.cap(), HCAP = S.hcap();
     // rmq::rtl walks `ancestors` like the tree aggregators (src/rmq/rtl.rs:42-49)
     const bool tree_like = method != UMGAP_METHOD_RMQ || strategy == UMGAP_STRATEGY_MRTL;
     res_taxon = 0;
@@ -100,11 +136,11 @@ __device__ __forceinline__ bool general_read(const TaxView& V, Scratch<CAP, HCAP
             nd += (uint32_t)__builtin_popcountll(lm);
             overflow = nd > CAP || __any(full);
         }
-        wave_sync();
+        SCR::sync();
         if (overflow) {
             // give the table back clean; the caller hands the read to a pass with a larger scratch
             for (uint32_t i = lane; i < HCAP; i += 64) { S.hkeys[i] = 0u; S.hcnt[i] = 0u; }
-            wave_sync();
+            SCR::sync();
             return false;
         }
         // multiplicities, then clean the slots this read used
@@ -128,7 +164,7 @@ __device__ __forceinline__ bool general_read(const TaxView& V, Scratch<CAP, HCAP
                 if (e < nd) S.a_cnt[e] = acc;
             }
         }
-        wave_sync();
+        SCR::sync();
 
         // ---- 2. filter + resolve + compact the survivors ---------------------------------
         uint32_t D = 0;
@@ -151,7 +187,7 @@ __device__ __forceinline__ bool general_read(const TaxView& V, Scratch<CAP, HCAP
             if (surv) { S.s_pre[idx] = h.pre; S.s_last[idx] = h.last; S.s_cnt[idx] = S.a_cnt[e]; }
             D += (uint32_t)__builtin_popcountll(m);
         }
-        wave_sync();
+        SCR::sync();
         if (__any(errkey != NOERR)) {
             uint64_t ek = wave_min64(errkey);
             res_status = ((ek >> 32) & 1) ? UMGAP_READ_PANIC : UMGAP_READ_UNKNOWN_TAXON;
@@ -171,7 +207,7 @@ __device__ __forceinline__ bool general_read(const TaxView& V, Scratch<CAP, HCAP
                 for (uint32_t f = 0; f < D; f++) rank += S.s_pre[f] < p;
                 if (e < D) { S.b_pre[rank] = p; S.b_last[rank] = S.s_last[e]; S.b_cnt[rank] = S.s_cnt[e]; }
             }
-            wave_sync();
+            SCR::sync();
             uint32_t ans = NONE;  // preorder index of the aggregate
             if (strategy == UMGAP_STRATEGY_MRTL) {
                 // ---- MRTL ----
@@ -206,8 +242,8 @@ __device__ __forceinline__ bool general_read(const TaxView& V, Scratch<CAP, HCAP
                         }
                     }
                 }
-                wave_sync();
-                if (method == UMGAP_METHOD_TREE && CAP <= 64 && !SCORED) {
+                SCR::sync();
+                if (method == UMGAP_METHOD_TREE && SCR::kLanePerElement && !SCORED) {
                     // ---- tree::mix, one lane per list element: every level of the greedy descent is three wave
                     // reductions instead of two serial scans of the range.  Unscored counts are small integers, so
                     // the children's values (Tree::aggregate) are exact differences of one prefix sum.
@@ -308,6 +344,13 @@ __device__ __forceinline__ bool general_read(const TaxView& V, Scratch<CAP, HCAP
         }
     }
     return true;
+}
+
+// the LDS form under its round-1 name
+template <bool SCORED, int CAP, int HCAP, bool BOUND = false>
+__device__ __forceinline__ bool general_read(const TaxView& V, Scratch<CAP, HCAP>& S, int method, int strategy, float factor, float lower_bound,
+                                             const uint32_t* rp, const float* sp, uint64_t n, uint32_t lane, uint32_t& res_taxon, uint32_t& res_status) {
+    return general_read_t<SCORED, Scratch<CAP, HCAP>, BOUND>(V, S, method, strategy, factor, lower_bound, rp, sp, n, lane, res_taxon, res_status);
 }
 
 }  // namespace agg

@@ -25,7 +25,7 @@ using namespace umgap;
 namespace umgap {
 int launch_general(const TaxView& V, int method, int strategy, float factor, float lower_bound, const uint32_t* d_taxa,
                    const float* d_scores, const uint64_t* d_offsets, uint32_t stride, size_t n_reads, uint32_t* d_out_taxon,
-                   uint32_t* d_out_status, uint32_t* d_defer, hipStream_t stream);
+                   uint32_t* d_out_status, uint32_t* d_defer, uint32_t* d_big, hipStream_t stream);
 }
 
 namespace {
@@ -206,10 +206,11 @@ int launch(umgap_taxonomy* tx, int method, int strategy, float factor, float low
         if (d_scores) hipLaunchKernelGGL(k_agg_lca<true>, grid, block, 0, stream, V, method, d_taxa, d_scores, d_offsets, stride, n_reads, lower_bound, d_out_taxon, d_out_status);
         else hipLaunchKernelGGL(k_agg_lca<false>, grid, block, 0, stream, V, method, d_taxa, d_scores, d_offsets, stride, n_reads, lower_bound, d_out_taxon, d_out_status);
     } else {
-        uint32_t* d_defer = defer_list_for(tx, stream, (n_reads + 1) * sizeof(uint32_t));
-        if (!d_defer) return UMGAP_ERR_NOMEM;
+        uint32_t* d_defer = defer_list_for(tx, stream, 2 * (n_reads + 1) * sizeof(uint32_t));
+        uint32_t* d_big = big_scratch_for(tx);
+        if (!d_defer || !d_big) return UMGAP_ERR_NOMEM;
         return launch_general(V, method, strategy, factor, lower_bound, d_taxa, d_scores, d_offsets, stride, n_reads, d_out_taxon,
-                              d_out_status, d_defer, stream);
+                              d_out_status, d_defer, d_big, stream);
     }
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;

@@ -76,18 +76,49 @@ __global__ __launch_bounds__(64 * WAVES) void k_agg_general(TaxView V, int metho
     }
 }
 
+// Third pass: reads with more distinct taxa than the large LDS scratch holds (> 1024), one wave per read with its working
+// set in global memory (ScratchGlobal).  Slow (the sort and the scans are quadratic in the distinct taxa) and rare.
+template <bool SCORED>
+__global__ __launch_bounds__(64) void k_agg_general_big(TaxView V, int method, int strategy, float factor, const uint32_t* __restrict__ taxa,
+                                                        const float* __restrict__ scores, const uint64_t* __restrict__ offsets, uint32_t stride,
+                                                        float lower_bound, uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status,
+                                                        const uint32_t* __restrict__ todo, const uint32_t* __restrict__ todo_count,
+                                                        uint32_t* __restrict__ scratch, uint32_t cap, uint32_t hcap) {
+    ScratchGlobal S;
+    S.carve(scratch + (size_t)blockIdx.x * ScratchGlobal::words(cap, hcap), cap, hcap);
+    const uint32_t lane = threadIdx.x & 63;
+    const size_t n_work = (size_t)*todo_count;
+    for (size_t w = blockIdx.x; w < n_work; w += gridDim.x) {
+        const size_t r = (size_t)todo[w];
+        uint64_t off, end;
+        if (offsets) { off = offsets[r]; end = offsets[r + 1]; } else { off = (uint64_t)r * stride; end = off + stride; }
+        uint32_t res_taxon = 0, res_status = UMGAP_READ_OK;
+        const bool ok = general_read_t<SCORED, ScratchGlobal>(V, S, method, strategy, factor, lower_bound, taxa + off, SCORED ? scores + off : nullptr,
+                                                             end - off, lane, res_taxon, res_status);
+        ScratchGlobal::sync();
+        if (lane == 0) {
+            out_taxon[r] = ok ? res_taxon : 0u;
+            out_status[r] = ok ? res_status : (uint32_t)UMGAP_READ_UNSUPPORTED;
+        }
+    }
+}
+
 }  // namespace
 
 namespace umgap {
 
-// Launches the general aggregation: the compact-scratch pass over all reads, then the
-// large-scratch pass over whatever it deferred.  `d_defer` must hold n_reads + 1 u32.
+// Launches the general aggregation: the compact-scratch pass over all reads, the large-scratch pass over whatever it
+// deferred (> 64 distinct taxa), and the global-memory pass over what that one deferred (> 1024).  `d_defer` must hold
+// 2 * (n_reads + 1) u32; d_big = BIG_SLOTS read scratches of ScratchGlobal::words(BIG_CAP, BIG_HCAP) words, hash parts zero.
 int launch_general(const TaxView& V, int method, int strategy, float factor, float lower_bound, const uint32_t* d_taxa,
                    const float* d_scores, const uint64_t* d_offsets, uint32_t stride, size_t n_reads, uint32_t* d_out_taxon,
-                   uint32_t* d_out_status, uint32_t* d_defer, hipStream_t stream) {
+                   uint32_t* d_out_status, uint32_t* d_defer, uint32_t* d_big, hipStream_t stream) {
     uint32_t* d_count = d_defer;      // [0] = number of deferred reads
     uint32_t* d_list = d_defer + 1;
+    uint32_t* d_count2 = d_defer + n_reads + 1;
+    uint32_t* d_list2 = d_count2 + 1;
     UMGAP_HIP(hipMemsetAsync(d_count, 0, sizeof(uint32_t), stream));
+    UMGAP_HIP(hipMemsetAsync(d_count2, 0, sizeof(uint32_t), stream));
     size_t g = (n_reads + 3) / 4;
     if (g > 256 * 8) g = 256 * 8;
     if (g < 1) g = 1;
@@ -96,14 +127,16 @@ int launch_general(const TaxView& V, int method, int strategy, float factor, flo
         hipLaunchKernelGGL((k_agg_general<true, 64, 512, 4>), grid, block, 0, stream, V, method, strategy, factor, d_taxa, d_scores, d_offsets, stride,
                            n_reads, lower_bound, d_out_taxon, d_out_status, (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_list, d_count);
         hipLaunchKernelGGL((k_agg_general<true, 1024, 4096, 1>), big_grid, big_block, 0, stream, V, method, strategy, factor, d_taxa, d_scores, d_offsets,
-                           stride, n_reads, lower_bound, d_out_taxon, d_out_status, (const uint32_t*)d_list, (const uint32_t*)d_count, (uint32_t*)nullptr,
-                           (uint32_t*)nullptr);
+                           stride, n_reads, lower_bound, d_out_taxon, d_out_status, (const uint32_t*)d_list, (const uint32_t*)d_count, d_list2, d_count2);
+        hipLaunchKernelGGL(k_agg_general_big<true>, dim3(BIG_SLOTS), dim3(64), 0, stream, V, method, strategy, factor, d_taxa, d_scores, d_offsets, stride,
+                           lower_bound, d_out_taxon, d_out_status, (const uint32_t*)d_list2, (const uint32_t*)d_count2, d_big, BIG_CAP, BIG_HCAP);
     } else {
         hipLaunchKernelGGL((k_agg_general<false, 64, 256, 4>), grid, block, 0, stream, V, method, strategy, factor, d_taxa, d_scores, d_offsets, stride,
                            n_reads, lower_bound, d_out_taxon, d_out_status, (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_list, d_count);
         hipLaunchKernelGGL((k_agg_general<false, 1024, 4096, 1>), big_grid, big_block, 0, stream, V, method, strategy, factor, d_taxa, d_scores, d_offsets,
-                           stride, n_reads, lower_bound, d_out_taxon, d_out_status, (const uint32_t*)d_list, (const uint32_t*)d_count, (uint32_t*)nullptr,
-                           (uint32_t*)nullptr);
+                           stride, n_reads, lower_bound, d_out_taxon, d_out_status, (const uint32_t*)d_list, (const uint32_t*)d_count, d_list2, d_count2);
+        hipLaunchKernelGGL(k_agg_general_big<false>, dim3(BIG_SLOTS), dim3(64), 0, stream, V, method, strategy, factor, d_taxa, d_scores, d_offsets, stride,
+                           lower_bound, d_out_taxon, d_out_status, (const uint32_t*)d_list2, (const uint32_t*)d_count2, d_big, BIG_CAP, BIG_HCAP);
     }
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;

@@ -356,7 +356,7 @@ constexpr int NSETS = 3;
 
 struct BufSet {
     hipStream_t stream = nullptr;
-    hipEvent_t done = nullptr;
+    hipEvent_t done = nullptr, probed = nullptr;
     uint8_t *send_keys = nullptr, *recv_keys = nullptr;
     uint32_t *ret_send = nullptr, *ret_recv = nullptr, *perm = nullptr;
     unsigned long long* cursor = nullptr;
@@ -387,7 +387,11 @@ int sharded_args_ok(umgap_sharded* sh, const char* who) {
 }
 
 // one piece, first half: pack -> pad -> key exchange -> local probe, all on the set's stream
-int piece_out(umgap_sharded* sh, BufSet& S, const uint64_t* d_keys, size_t nk, bool time_probe) {
+// `after` (nullable): the set whose probe must have finished before this piece's probe starts.  One probe saturates the
+// chip's random-request path, so two at once only slow each other down; chained, the probes run back to back and the pack and
+// the aggregate of the neighbouring pieces (streaming / ALU work) run underneath them.  Without the chain three pieces march
+// through their stages in lockstep and nothing overlaps (profiles/r02_sharded_timeline_lockstep.txt).
+int piece_out(umgap_sharded* sh, BufSet& S, const BufSet* after, const uint64_t* d_keys, size_t nk, bool time_probe) {
     const uint32_t W = (uint32_t)sh->comm->world;
     const TableView& T = sh->ix->view;
     hipStream_t s = S.stream;
@@ -403,10 +407,12 @@ int piece_out(umgap_sharded* sh, BufSet& S, const uint64_t* d_keys, size_t nk, b
     const uint64_t n_slots = sh->cap * W;
     const unsigned gp = (unsigned)((n_slots / 128 + 3) / 4);
     const uint32_t self = (uint32_t)sh->comm->rank;
+    if (after) UMGAP_HIP(hipStreamWaitEvent(s, after->probed, 0));
     if (time_probe) UMGAP_HIP(hipEventRecord(sh->ev_probe0, s));
     if (sh->value_bytes == 3) hipLaunchKernelGGL(k_shard_probe<3>, dim3(gp), dim3(256), 0, s, T, S.recv_keys, S.send_keys, self, sh->cap, n_slots, S.ret_send, S.ret_recv);
     else hipLaunchKernelGGL(k_shard_probe<4>, dim3(gp), dim3(256), 0, s, T, S.recv_keys, S.send_keys, self, sh->cap, n_slots, S.ret_send, S.ret_recv);
     UMGAP_HIP(hipGetLastError());
+    UMGAP_HIP(hipEventRecord(S.probed, s));
     if (time_probe) { UMGAP_HIP(hipEventRecord(sh->ev_probe1, s)); sh->probe_timed = true; }
     return UMGAP_OK;
 }
@@ -574,7 +580,8 @@ int umgap_sharded_create(umgap_index* shard, umgap_taxonomy* tx, umgap_comm* com
         S.ret_recv = (uint32_t*)p; p += b_vals;
         S.perm = (uint32_t*)p; p += b_perm;
         S.cursor = (unsigned long long*)p; p += b_cur;
-        if (hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&S.done, hipEventDisableTiming) != hipSuccess) {
+        if (hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&S.done, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&S.probed, hipEventDisableTiming) != hipSuccess) {
             umgap_sharded_free(sh);
             return fail(UMGAP_ERR_DEVICE, "umgap_sharded_create: stream / event creation failed");
         }
@@ -596,6 +603,7 @@ void umgap_sharded_free(umgap_sharded* sh) {
     for (auto& S : sh->set) {
         if (S.stream) (void)hipStreamDestroy(S.stream);
         if (S.done) (void)hipEventDestroy(S.done);
+        if (S.probed) (void)hipEventDestroy(S.probed);
     }
     if (sh->ev_in) (void)hipEventDestroy(sh->ev_in);
     if (sh->ev_probe0) (void)hipEventDestroy(sh->ev_probe0);
@@ -620,7 +628,7 @@ int umgap_sharded_lookup9_dev(umgap_sharded* sh, const uint64_t* d_keys45, size_
     for (size_t t = 0; t <= np; t++) {
         if (t < np) {
             const size_t lo = std::min(n, t * per), hi = std::min(n, (t + 1) * per);
-            if ((rc = piece_out(sh, sh->set[t % NSETS], d_keys45 + lo, hi - lo, t == 0))) return rc;
+            if ((rc = piece_out(sh, sh->set[t % NSETS], t ? &sh->set[(t - 1) % NSETS] : nullptr, d_keys45 + lo, hi - lo, t == 0))) return rc;
         }
         if (t >= 1) {
             const size_t c = t - 1, lo = std::min(n, c * per), hi = std::min(n, (c + 1) * per);
@@ -659,7 +667,7 @@ int umgap_sharded_classify9_dev(umgap_sharded* sh, int method, int strategy, flo
     for (size_t t = 0; t <= np; t++) {
         if (t < np) {
             const size_t lo = std::min(n_reads, t * per), hi = std::min(n_reads, (t + 1) * per);
-            if ((rc = piece_out(sh, sh->set[t % NSETS], d_keys45 + lo * kmers_per_read, (hi - lo) * kmers_per_read, t == 0))) return rc;
+            if ((rc = piece_out(sh, sh->set[t % NSETS], t ? &sh->set[(t - 1) % NSETS] : nullptr, d_keys45 + lo * kmers_per_read, (hi - lo) * kmers_per_read, t == 0))) return rc;
         }
         if (t >= 1) {
             const size_t c = t - 1, lo = std::min(n_reads, c * per), hi = std::min(n_reads, (c + 1) * per);

@@ -235,6 +235,21 @@ uint32_t* defer_list_for(umgap_taxonomy* tx, hipStream_t stream, size_t bytes) {
     }
     return L.d;
 }
+uint32_t* big_scratch_for(umgap_taxonomy* tx) {
+    std::lock_guard<std::mutex> g(tx->defer_mutex);
+    if (!tx->d_big_scratch) {
+        // 12 * cap + 2 * hcap words per slot (agg_general.hpp: ScratchGlobal::words)
+        const size_t bytes = (size_t)BIG_SLOTS * (2 * (size_t)BIG_HCAP + 12 * (size_t)BIG_CAP) * sizeof(uint32_t);
+        hipError_t e = hipMalloc((void**)&tx->d_big_scratch, bytes);
+        if (e == hipSuccess) e = hipMemset(tx->d_big_scratch, 0, bytes);   // the hash tables start (and are handed back) clean
+        if (e != hipSuccess) {
+            if (tx->d_big_scratch) (void)hipFree(tx->d_big_scratch);
+            tx->d_big_scratch = nullptr;
+            fail(UMGAP_ERR_NOMEM, std::string("hipMalloc(global aggregation scratch): ") + hipGetErrorString(e));
+        }
+    }
+    return tx->d_big_scratch;
+}
 }  // namespace umgap
 
 extern "C" {
@@ -255,6 +270,7 @@ void umgap_taxonomy_free(umgap_taxonomy* tx) {
         if (p) (void)hipFree(p);
     for (auto& kv : tx->defer_lists)
         if (kv.second.d) (void)hipFree(kv.second.d);
+    if (tx->d_big_scratch) (void)hipFree(tx->d_big_scratch);
     if (tx->stream) (void)hipStreamDestroy(tx->stream);
     if (tx->stream2) (void)hipStreamDestroy(tx->stream2);
     if (tx->h_flags) (void)hipHostFree(tx->h_flags);

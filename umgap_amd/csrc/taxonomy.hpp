@@ -59,6 +59,7 @@ struct umgap_taxonomy {
     struct DeferList { uint32_t* d = nullptr; size_t bytes = 0; };
     std::map<hipStream_t, DeferList> defer_lists;
     std::mutex defer_mutex;
+    uint32_t* d_big_scratch = nullptr;   // global-memory working sets of the third aggregation pass (umgap::big_scratch_for), made on first use
     // indexes whose values are currently bound to this taxonomy (bind.hip): unbound again by umgap_taxonomy_free,
     // dropped from the list by umgap_index_free
     std::vector<umgap_index*> bound_indexes;
@@ -68,6 +69,10 @@ namespace umgap {
 // The calling stream's deferred-read list, at least `bytes` long (grown with hipFree + hipMalloc, which wait for the
 // device, so a launch still using the old list has finished).  nullptr + error set on failure.
 uint32_t* defer_list_for(umgap_taxonomy* tx, hipStream_t stream, size_t bytes);
+// Reads with more than 1024 distinct taxa (general aggregation only) are aggregated with their working set in global
+// memory: BIG_SLOTS reads at a time, up to BIG_CAP distinct taxa each; beyond that UMGAP_READ_UNSUPPORTED.
+constexpr uint32_t BIG_SLOTS = 16, BIG_CAP = 1u << 15, BIG_HCAP = 1u << 16;
+uint32_t* big_scratch_for(umgap_taxonomy* tx);
 
 struct TaxView {
     const uint2* by_id;
