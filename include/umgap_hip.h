@@ -311,6 +311,8 @@ uint32_t umgap_sharded_pieces(const umgap_sharded* sh);
  * times (n may differ, 0 included); enqueues on internal streams ordered after `stream` and joins them back into it. */
 int umgap_sharded_lookup9_dev(umgap_sharded* sh, const uint64_t* d_keys45, size_t n, uint32_t miss_value,
                               uint32_t* d_out_taxa, void* stream);
+/* The same from / to HOST arrays (staged through the group's own device buffers; returns when out_taxa is filled).  Collective. */
+int umgap_sharded_lookup9(umgap_sharded* sh, const uint64_t* keys45, size_t n, uint32_t miss_value, uint32_t* out_taxa);
 /* The fused 9-mer pipeline over the sharded table: as umgap_classify9_dev / umgap_classify9_strategy_dev (any strategy),
  * results bit-identical to theirs on a whole table.  Collective like the lookup. */
 int umgap_sharded_classify9_dev(umgap_sharded* sh, int method, int strategy, float factor, float lower_bound,

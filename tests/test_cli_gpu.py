@@ -103,6 +103,30 @@ def test_prot2kmer2lca_matches_oracle(world, k_flags):
     assert rc == 0 == orc and out == oout, err
 
 
+@pytest.mark.parametrize("shards,local", [(1, False), (2, True), (5, True)])
+def test_prot2kmer2lca_shards(world, shards, local):
+    """`umgap prot2kmer2lca --shards N`: the index sharded over N GPUs inside one process (RCCL), what the resident server of
+    scripts/umgap-analyse.sh:257-264 becomes when the index outgrows one GPU.  Same bytes out as the single-table command.
+    A one-GPU box runs N = 1 over RCCL and N > 1 with every rank on GPU 0 (UMGAP_SHARDS_LOCAL)."""
+    rng = np.random.default_rng(50 + shards)
+    recs = []
+    for r in range(2000):
+        n = int(rng.integers(0, 70))
+        prot = "".join(rng.choice(list(LETTERS + "*"), n))
+        if rng.random() < 0.6 and n > 20:
+            s = int(rng.integers(0, n - 12))
+            prot = prot[:s] + world["kmers"][int(rng.integers(0, len(world["kmers"])))] + prot[s + 9:]
+        recs.append(">p%d\n%s\n" % (r, prot))
+    fasta = "".join(recs).encode()
+    rc0, out0, err0 = run(["prot2kmer2lca", "-o", world["idx"]], fasta)
+    env = {"UMGAP_SHARDS_LOCAL": "1"} if local else {}
+    rc, out, err = _run_env(["prot2kmer2lca", "-o", "--shards", str(shards), world["idx"]], fasta, UMGAP_BLOCK_BYTES=20000, **env)
+    assert rc0 == 0 == rc and out == out0, err
+    assert sum(1 for l in out.decode().splitlines() if l.isdigit() and l != "0") > 500
+    rc, out, err = _run_env(["prot2kmer2lca", "--shards", str(shards), world["idx"]], fasta, **env)
+    assert rc == 0 and out == run(["prot2kmer2lca", world["idx"]], fasta)[1], err
+
+
 def _taxa_fasta(w, rng, n_records, unknown=False):
     ids = w["ids"]
     recs = []

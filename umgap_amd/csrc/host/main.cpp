@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <functional>
 #include <map>
+#include <memory>
 #include <regex>
 
 #include "../../../include/umgap_hip.h"
@@ -266,7 +267,10 @@ void format_lookup_part(const char* d, const uint32_t* taxa, bool one_on_one, co
 // Output follows the reference's chunking (src/io/fasta.rs:118-137, src/commands/pept2lca.rs:83-101): records
 // are printed per chunk of `chunk` records, and a read error or a panic prints nothing of the chunk it falls
 // in.  The partial chunk at the end of a block is therefore held back until the next block confirms it.
-void stream_lookup(FILE* in, FILE* outf, umgap_index* ix, bool one_on_one, bool kmer_mode, size_t k, size_t chunk) {
+// get() over a batch of packed 9-mers: one GPU's table, or the table sharded over several
+using LookupFn = std::function<void(const uint64_t* keys, size_t n, uint32_t* taxa)>;
+
+void stream_lookup(FILE* in, FILE* outf, const LookupFn& lookup, bool one_on_one, bool kmer_mode, size_t k, size_t chunk) {
     if (chunk == 0) chunk = 1;
     BlockReader blocks(in);
     const unsigned T = worker_count();
@@ -303,7 +307,7 @@ void stream_lookup(FILE* in, FILE* outf, umgap_index* ix, bool one_on_one, bool 
         keys.resize(total);
         parallel_for(used, [&](size_t i) { if (!parts[i].keys.empty()) memcpy(keys.data() + parts[i].key_base, parts[i].keys.data(), parts[i].keys.size() * 8); });
         taxa.resize(total);
-        if (total) LIB(umgap_index_lookup9(ix, keys.data(), total, 0u, taxa.data()));
+        if (total) lookup(keys.data(), total, taxa.data());
         // per part: records below `limit` go to P.out, the rest to the tail (held back)
         std::vector<std::string> tails(used);
         parallel_for(used, [&](size_t i) {
@@ -327,6 +331,65 @@ void stream_lookup(FILE* in, FILE* outf, umgap_index* ix, bool one_on_one, bool 
     fwrite(held.data(), 1, held.size(), outf);   // EOF closes the last chunk
     fflush(outf);
 }
+
+void stream_lookup(FILE* in, FILE* outf, umgap_index* ix, bool one_on_one, bool kmer_mode, size_t k, size_t chunk) {
+    stream_lookup(in, outf, [ix](const uint64_t* keys, size_t n, uint32_t* taxa) { LIB(umgap_index_lookup9(ix, keys, n, 0u, taxa)); }, one_on_one, kmer_mode, k, chunk);
+}
+
+// --shards N: the index sharded by bucket range over N GPUs inside this one process (one host thread per GPU), the exchange
+// over RCCL -- what the resident `umgap prot2kmer2lca -m -o -s <socket>` server of scripts/umgap-analyse.sh:257-264 becomes
+// when the index outgrows one GPU.  Rank r holds shard r (umgap_index_open_shard) on GPU r and looks up the r-th slice of every
+// batch; umgap_sharded_lookup9 routes each k-mer to its owner and back.  UMGAP_SHARDS_LOCAL=1 puts every rank on GPU 0 with
+// the library's device-to-device transport (rehearsal on a one-GPU box; the tests use it).
+struct ShardGang {
+    std::vector<umgap_index*> ix;
+    std::vector<umgap_comm*> comm;
+    std::vector<umgap_sharded*> sh;
+    uint64_t max_keys = 48u << 20;     // per rank and call
+    int n = 0;
+    template <class F>
+    void each_rank(F f) {              // f(rank) on n threads; the first failure is rethrown
+        std::vector<std::thread> ts;
+        std::vector<std::exception_ptr> errs(n);
+        for (int r = 0; r < n; r++) ts.emplace_back([&, r]() { try { f(r); } catch (...) { errs[r] = std::current_exception(); } });
+        for (auto& t : ts) t.join();
+        for (auto& e : errs) if (e) std::rethrow_exception(e);
+    }
+    ShardGang(const std::string& path, int shards) : n(shards) {
+        const bool local = getenv("UMGAP_SHARDS_LOCAL") != nullptr;
+        if (shards < 1 || shards > 64) throw CliError("--shards must be in 1..64");
+        if (!local && umgap_device_count() < shards) throw CliError("--shards " + std::to_string(shards) + " needs that many GPUs (" + std::to_string(umgap_device_count()) + " visible)");
+        ix.assign(n, nullptr); comm.assign(n, nullptr); sh.assign(n, nullptr);
+        uint8_t id[128];
+        if (local) { if (umgap_comm_init_local(n, 0, comm.data()) != UMGAP_OK) throw CliError(umgap_last_error()); }
+        else if (umgap_comm_unique_id(id) != UMGAP_OK) throw CliError(umgap_last_error());
+        each_rank([&](int r) {
+            const int dev = local ? 0 : r;
+            LIB(umgap_index_open_shard(path.c_str(), 1u << dev, (uint32_t)r, (uint32_t)n, &ix[r]));
+            if (umgap_index_kind(ix[r]) != 9) throw CliError("--shards needs a 9-mer index");
+            if (!local) LIB(umgap_comm_init_rank(id, n, r, dev, &comm[r]));
+            LIB(umgap_sharded_create(ix[r], nullptr, comm[r], max_keys, 4, 0.05, &sh[r]));
+        });
+    }
+    ~ShardGang() {
+        for (auto s : sh) umgap_sharded_free(s);
+        for (auto c : comm) umgap_comm_free(c);
+        for (auto i : ix) umgap_index_free(i);
+    }
+    void lookup(const uint64_t* keys, size_t total, uint32_t* taxa) {
+        // every rank makes the same number of (collective) calls: rounds of at most n * max_keys keys, split evenly
+        for (size_t done = 0; done < total;) {
+            const size_t round = std::min<size_t>(total - done, (size_t)n * max_keys), per = (round + n - 1) / n;
+            each_rank([&](int r) {
+                const size_t lo = std::min(round, (size_t)r * per), hi = std::min(round, (size_t)(r + 1) * per);
+                LIB(umgap_sharded_lookup9(sh[r], keys + done + lo, hi - lo, 0u, taxa + done + lo));
+            });
+            done += round;
+        }
+        // an overflowed exchange region would have answered some k-mers with a miss: refuse to print such a batch
+        each_rank([&](int r) { LIB(umgap_sharded_check(sh[r])); });
+    }
+};
 
 umgap_index* open_index(const std::string& path) {
     umgap_index* ix = nullptr;
@@ -449,17 +512,21 @@ int cmd_prot2tryp2lca(const std::vector<std::string>& args) {
 }
 
 int cmd_prot2kmer2lca(const std::vector<std::string>& args) {
-    Parsed p = parse_args(args, {{'k', "length", true}, {'o', "one-on-one", false}, {'s', "socket", true}, {'m', "in-memory", false}, {'c', "chunksize", true}});
+    Parsed p = parse_args(args, {{'k', "length", true}, {'o', "one-on-one", false}, {'s', "socket", true}, {'m', "in-memory", false}, {'c', "chunksize", true},
+                                 {0, "shards", true}});
     size_t k = (size_t)opt_usize(p, "length", 9);
     size_t chunk = (size_t)opt_usize(p, "chunksize", 240);
     std::string path = need_positional(p, "fst-file");
-    umgap_index* ix = open_index(path);
     bool o = p.has("one-on-one");
+    std::unique_ptr<ShardGang> gang;
+    if (p.has("shards")) gang.reset(new ShardGang(path, (int)opt_usize(p, "shards", 1)));
+    umgap_index* ix = gang ? nullptr : open_index(path);
     // A packed 9-mer table answers k = 9; any other k can only miss there (its keys are 9 residues long), which the fast
     // path emits without asking the device.  A byte-string (variable-length) table serves EVERY k like the reference's fst
     // does (src/commands/prot2kmer2lca.rs:71-73,172-179): all windows of k residues through umgap_index_lookup_var.
-    const bool var_index = umgap_index_kind(ix) != 9;
+    const bool var_index = !gang && umgap_index_kind(ix) != 9;
     auto stream = [&](FILE* in, FILE* outf) {
+        if (gang) { stream_lookup(in, outf, [&](const uint64_t* keys, size_t n, uint32_t* taxa) { gang->lookup(keys, n, taxa); }, o, true, k, chunk); return; }
         if (!var_index) { stream_lookup(in, outf, ix, o, true, k, chunk); return; }
         stream_strings(in, outf, ix, o, chunk,
                        [&](const std::string& seq, StringBatch& b) {

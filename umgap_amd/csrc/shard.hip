@@ -377,6 +377,10 @@ struct umgap_sharded {
     uint32_t* d_overflow = nullptr;
     hipEvent_t ev_in = nullptr, ev_probe0 = nullptr, ev_probe1 = nullptr;
     bool probe_timed = false;
+    // staging of the host-pointer umgap_sharded_lookup9 (made on first use)
+    hipStream_t h_stream = nullptr;
+    uint64_t* d_hkeys = nullptr;
+    uint32_t* d_hout = nullptr;
 };
 
 namespace {
@@ -609,6 +613,9 @@ void umgap_sharded_free(umgap_sharded* sh) {
     if (sh->ev_probe0) (void)hipEventDestroy(sh->ev_probe0);
     if (sh->ev_probe1) (void)hipEventDestroy(sh->ev_probe1);
     if (sh->block) (void)hipFree(sh->block);
+    if (sh->h_stream) (void)hipStreamDestroy(sh->h_stream);
+    if (sh->d_hkeys) (void)hipFree(sh->d_hkeys);
+    if (sh->d_hout) (void)hipFree(sh->d_hout);
     delete sh;
 }
 
@@ -642,6 +649,24 @@ int umgap_sharded_lookup9_dev(umgap_sharded* sh, const uint64_t* d_keys45, size_
         }
     }
     return join_streams(sh, caller);
+}
+
+int umgap_sharded_lookup9(umgap_sharded* sh, const uint64_t* keys45, size_t n, uint32_t miss_value, uint32_t* out_taxa) {
+    int rc = sharded_args_ok(sh, "umgap_sharded_lookup9");
+    if (rc) return rc;
+    if (n && (!keys45 || !out_taxa)) return fail(UMGAP_ERR_INVALID, "umgap_sharded_lookup9: null argument");
+    if (n > sh->max_keys) return fail(UMGAP_ERR_INVALID, "umgap_sharded_lookup9: more keys than the max_keys_per_call the group was created with");
+    if (!sh->h_stream) {
+        UMGAP_HIP(hipStreamCreateWithFlags(&sh->h_stream, hipStreamNonBlocking));
+        UMGAP_HIP(hipMalloc((void**)&sh->d_hkeys, sh->max_keys * 8));
+        UMGAP_HIP(hipMalloc((void**)&sh->d_hout, sh->max_keys * 4));
+    }
+    if (n) UMGAP_HIP(hipMemcpyAsync(sh->d_hkeys, keys45, n * 8, hipMemcpyHostToDevice, sh->h_stream));
+    rc = umgap_sharded_lookup9_dev(sh, sh->d_hkeys, n, miss_value, sh->d_hout, sh->h_stream);   // collective even when n == 0
+    if (rc) return rc;
+    if (n) UMGAP_HIP(hipMemcpyAsync(out_taxa, sh->d_hout, n * 4, hipMemcpyDeviceToHost, sh->h_stream));
+    UMGAP_HIP(hipStreamSynchronize(sh->h_stream));
+    return UMGAP_OK;
 }
 
 int umgap_sharded_classify9_dev(umgap_sharded* sh, int method, int strategy, float factor, float lower_bound, int ranked_only,
