@@ -361,6 +361,13 @@ struct ShardGang {
         if (!local && umgap_device_count() < shards) throw CliError("--shards " + std::to_string(shards) + " needs that many GPUs (" + std::to_string(umgap_device_count()) + " visible)");
         ix.assign(n, nullptr); comm.assign(n, nullptr); sh.assign(n, nullptr);
         uint8_t id[128];
+        // RCCL announces its version on stdout when the first communicator comes up; stdout is this command's data, so it
+        // points at stderr until the gang stands
+        struct StdoutToStderr {
+            int saved;
+            StdoutToStderr() { fflush(stdout); saved = dup(1); if (saved >= 0) dup2(2, 1); }
+            ~StdoutToStderr() { fflush(stdout); if (saved >= 0) { dup2(saved, 1); close(saved); } }
+        } quiet;
         if (local) { if (umgap_comm_init_local(n, 0, comm.data()) != UMGAP_OK) throw CliError(umgap_last_error()); }
         else if (umgap_comm_unique_id(id) != UMGAP_OK) throw CliError(umgap_last_error());
         each_rank([&](int r) {
