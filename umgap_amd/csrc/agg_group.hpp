@@ -277,5 +277,130 @@ __device__ __forceinline__ void general_group(const TaxView& V, GroupScratch& G,
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// LCA* for a group of reads, the same way: the closed form (M = the surviving taxon of largest
+// preorder index, h' = the smallest-preorder survivor that is not an ancestor of M; answer M if there is none, else LCA(h', M))
+// needs {pre,last} of the survivors (unbound table), one range minimum and one snap per read -- three dependent round trips
+// per read in lca_star_from_lds, here three per GROUP: survivors of all reads resolved together, then one lane per read
+// for the range minimum (lane_argmin_depth) and the snap.
+// ------------------------------------------------------------------------------------------------------------------------
+struct LcaScratch {
+    uint32_t hkeys[256], hcnt[256];
+    uint32_t last[GCAP], ehi[GCAP];   // subtree end of a survivor -- or, for a taxon that did not resolve (pre = NONE), its error key (low, high)
+    uint32_t roff[GREADS + 1], rM[GREADS], rhp[GREADS], rstat[GREADS], rans[GREADS];
+};
+
+// one_read(k, res_taxon, res_status): the per-read path (lca_star[_bound]_from_lds) for a read with more than 64 surviving
+// taxa; its part of the strip is still untouched when it is called.
+template <bool BOUND, class OneRead>
+__device__ __forceinline__ void lca_group(const TaxView& V, LcaScratch& G, bool tree_like, float lower_bound, uint32_t* wtaxa, uint32_t stride,
+                                          uint32_t nr, uint32_t lane, uint64_t se_panic, uint32_t frags, size_t first_read,
+                                          uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status, OneRead one_read) {
+    auto se_panicked = [&](uint32_t k) -> bool {
+        return se_panic && ((se_panic >> (k * frags)) & ((frags >= 64 ? 0ull : (1ull << frags)) - 1ull));
+    };
+    uint32_t k0 = 0;
+    while (k0 < nr) {
+        // ---- count + filter per read (LDS only); survivors compacted in place over the strip from `base` on ----
+        const uint32_t base = k0 * stride;
+        uint32_t w = 0, k = k0;
+        bool big = false;                       // the sub-batch ends in front of a read that takes the per-read path
+        if (lane == 0) G.roff[0] = 0;
+        while (k < nr && k - k0 < GREADS) {
+            const uint32_t* rt = wtaxa + k * stride;
+            const uint32_t t0 = lane < stride ? rt[lane] : 0u, t1 = 64 + lane < stride ? rt[64 + lane] : 0u;
+            bool keep0, keep1;
+            float c0, c1;
+            lds_count(G.hkeys, G.hcnt, t0, t1, lower_bound, keep0, keep1, c0, c1);
+            const uint64_t b0 = __ballot(keep0), b1 = __ballot(keep1);
+            const uint32_t n0 = (uint32_t)__builtin_popcountll(b0), ns = n0 + (uint32_t)__builtin_popcountll(b1);
+            if (ns > 64) { big = true; break; }
+            if (w + ns > GCAP) break;
+            wave_sync();                         // every lane holds its taxa in registers before the strip is overwritten
+            if (keep0) wtaxa[base + w + (uint32_t)__builtin_popcountll(b0 & lanemask_lt(lane))] = t0;
+            if (keep1) wtaxa[base + w + n0 + (uint32_t)__builtin_popcountll(b1 & lanemask_lt(lane))] = t1;
+            w += ns;
+            if (lane == 0) G.roff[k - k0 + 1] = w;
+            wave_sync();
+            k++;
+        }
+        const uint32_t nb = k - k0;
+        wave_sync();
+        // ---- {pre, last} of every survivor: one round trip (a bound table's codes carry them) ----
+        bool any_err = false;
+        if (!BOUND) {
+            for (uint32_t eb = 0; eb < w; eb += 64) {
+                const uint32_t e = eb + lane;
+                uint64_t errkey = NOERR;
+                if (e < w) {
+                    const Hit h = resolve(V, tree_like, wtaxa[base + e], errkey);
+                    wtaxa[base + e] = h.pre;                               // NONE: the taxon did not resolve
+                    G.last[e] = h.pre != NONE ? h.last : (uint32_t)errkey;
+                    G.ehi[e] = (uint32_t)(errkey >> 32);
+                }
+                any_err = any_err || __any(errkey != NOERR);
+            }
+            wave_sync();
+        }
+        // ---- per read: M = the deepest-in-preorder survivor, h' = the first survivor that is not its ancestor (LDS / registers) ----
+        for (uint32_t r = 0; r < nb; r++) {
+            const uint32_t o0 = G.roff[r], D = G.roff[r + 1] - o0;        // D <= 64: one lane per survivor
+            uint32_t st = ST_PENDING, M = 0, hp = NONE, ans = 0;
+            if (D == 0) { st = UMGAP_READ_EMPTY; ans = 1; }              // literal "1" (src/commands/taxa2agg.rs:174-175)
+            else if (BOUND) {
+                const uint32_t v = lane < D ? wtaxa[base + o0 + lane] : 0u;
+                const uint32_t p = lane < D ? bound::pre_of(v) : 0u;
+                M = wave_max(p);
+                bool not_anc = false;
+                if (lane < D) {
+                    uint32_t lo, hi;
+                    bound::size_bounds(v, lo, hi);
+                    if (M > p + hi) not_anc = true;
+                    else if (M > p + lo) not_anc = V.last_of_pre[p] < M;  // inside the rounding gap: the exact subtree end
+                }
+                hp = wave_min(not_anc ? p : NONE);
+            } else {
+                const uint32_t p = lane < D ? wtaxa[base + o0 + lane] : 0u;
+                const uint32_t l = lane < D ? G.last[o0 + lane] : 0u;
+                uint64_t ek = NOERR;
+                if (any_err) ek = wave_min64((lane < D && p == NONE) ? (((uint64_t)G.ehi[o0 + lane] << 32) | l) : NOERR);
+                if (ek != NOERR) {
+                    st = ((ek >> 32) & 1) ? UMGAP_READ_PANIC : UMGAP_READ_UNKNOWN_TAXON;
+                    ans = (uint32_t)ek;
+                } else {
+                    M = wave_max(lane < D ? p : 0u);
+                    hp = wave_min((lane < D && l < M) ? p : NONE);
+                }
+            }
+            if (lane == 0) { G.rstat[r] = st; G.rans[r] = ans; G.rM[r] = M; G.rhp[r] = hp; }
+        }
+        wave_sync();
+        // ---- one lane per read: the range minimum (one round trip), the snap (one round trip), the results stored together ----
+        if (lane < nb) {
+            const size_t read = first_read + k0 + lane;
+            uint32_t st = G.rstat[lane], tx = G.rans[lane];
+            if (st == ST_PENDING) {
+                const uint32_t M = G.rM[lane], hp = G.rhp[lane];
+                if (hp != NONE) tx = V.psnap_of_pre[(uint32_t)lane_argmin_depth(V, hp + 1, M)];   // LCA(h', M) = parent of a shallowest node in (pre[h'], pre[M]]
+                else tx = V.snap_of_pre[M];
+                st = tx == NONE ? UMGAP_READ_PANIC : UMGAP_READ_OK;
+            }
+            if (se_panicked(k0 + lane)) { st = UMGAP_READ_PANIC; tx = 0; }
+            out_taxon[read] = tx;
+            out_status[read] = st;
+        }
+        wave_sync();
+        k0 = k;
+        if (big) {
+            uint32_t res_taxon, res_status;
+            one_read(k0, res_taxon, res_status);
+            if (se_panicked(k0)) { res_status = UMGAP_READ_PANIC; res_taxon = 0; }
+            if (lane == 0) { out_taxon[first_read + k0] = res_taxon; out_status[first_read + k0] = res_status; }
+            wave_sync();
+            k0++;
+        }
+    }
+}
+
 }  // namespace agg
 }  // namespace umgap

@@ -197,11 +197,13 @@ template <bool BOUND, bool GATHER>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_classify9(TableView T, TaxView V, int method, const uint64_t* __restrict__ keys,
                                                    size_t n_reads, uint32_t stride, uint32_t frags, uint32_t min_seed, uint32_t max_gap,
                                                    float lower_bound, uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status, HitSource H) {
-    __shared__ uint32_t lds_taxa[4][STRIP], lds_keys[4][256], lds_cnt[4][256];
+    __shared__ uint32_t lds_taxa[4][STRIP];
+    __shared__ LcaScratch scratch[4];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t* wtaxa = lds_taxa[wv];
-    uint32_t* wkeys = lds_keys[wv];
-    uint32_t* wcnt = lds_cnt[wv];
+    LcaScratch& S = scratch[wv];
+    uint32_t* wkeys = S.hkeys;
+    uint32_t* wcnt = S.hcnt;
 #pragma unroll
     for (int i = 0; i < 4; i++) { wkeys[lane + 64 * i] = 0u; wcnt[lane + 64 * i] = 0u; }
     const bool tree_like = method != UMGAP_METHOD_RMQ;
@@ -226,17 +228,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             se_panic = __ballot(pk);
             wave_lds_sync();
         }
-        // ---- aggregate each read of the group ----
-        for (uint32_t k = 0; k < nr; k++) {
-            uint32_t res_taxon, res_status;
-            if (BOUND) lca_star_bound_from_lds(V, wtaxa + k * stride, stride, lower_bound, wkeys, wcnt, lane, res_taxon, res_status);
-            else lca_star_from_lds(V, tree_like, wtaxa + k * stride, stride, lower_bound, wkeys, wcnt, lane, res_taxon, res_status);
-            if (se_panic && ((se_panic >> (k * frags)) & ((frags >= 64 ? 0ull : (1ull << frags)) - 1ull))) { res_taxon = 0; res_status = UMGAP_READ_PANIC; }
-            if (lane == 0) {
-                out_taxon[r0 + k] = res_taxon;
-                out_status[r0 + k] = res_status;
-            }
-        }
+        // ---- aggregate the group: taxonomy round trips once per group, not once per read (agg_group.hpp) ----
+        lca_group<BOUND>(V, S, tree_like, lower_bound, wtaxa, stride, nr, lane, se_panic, frags, r0, out_taxon, out_status,
+                         [&](uint32_t k, uint32_t& res_taxon, uint32_t& res_status) {
+                             if (BOUND) lca_star_bound_from_lds(V, wtaxa + k * stride, stride, lower_bound, wkeys, wcnt, lane, res_taxon, res_status);
+                             else lca_star_from_lds(V, tree_like, wtaxa + k * stride, stride, lower_bound, wkeys, wcnt, lane, res_taxon, res_status);
+                         });
         wave_lds_sync();
     }
 }

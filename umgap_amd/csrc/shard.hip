@@ -11,7 +11,7 @@
 //   exchange  all-to-all of the values back
 //   classify  gather the hits of each read through perm into LDS -> [seedextend] -> aggregate                  classify.hip (GATHER)
 //
-// A batch is cut into pieces of whole reads that run as a software pipeline over three buffer sets, each with its own
+// A batch is cut into pieces of whole reads that run as a software pipeline over four buffer sets, each with its own
 // stream: while piece t is packed and its keys travel, piece t-1 is probed and piece t-2 is aggregated.  The exchanges are
 // issued in the order A(0) A(1) R(0) A(2) R(1) ... on every rank (RCCL runs one communicator's operations in issue
 // order), so a return exchange never waits behind the key exchange of the piece after it.  Regions have a fixed capacity
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void k_max_value(const uint64_t* __restrict__ 
     if (m) atomicMax(out, m);
 }
 
-constexpr int NSETS = 3;
+constexpr int NSETS = 4;   // one more than the stages of a piece in flight: a pack never waits for the aggregate three pieces back
 
 struct BufSet {
     hipStream_t stream = nullptr;
