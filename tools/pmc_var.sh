@@ -1,17 +1,28 @@
+#!/bin/bash
+# Profile of the tryptic probe k_lookup_var (BASELINE configs[4]): rocprofv3 --kernel-trace --stats, then one --pmc pass per
+# counter set (with --kernel-trace only), over tools/bench_config5.py.  Launches of the kernel in that script, in order: the
+# build's self check (n = n_keys), 4 x the insertion-ordered queries, 4 x the shuffled 50 M-query sample.
+#   tools/pmc_var.sh [tag] [n_keys] [n_queries]    -> gpurun_out/<tag>/ ; summarise with tools/pmc_var_summary.py on the build machine
 set -eo pipefail
+tag=${1:-r02_lookup_var}
+nk=${2:-400000000}
+nq=${3:-200000000}
+out=gpurun_out/$tag
+mkdir -p "$out"
 export TMPDIR=/tmp
-out=gpurun_out/pmc_var
-mkdir -p $out
-for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_FLAT" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"; do
-    name=$(echo "$set" | tr ' ' '_' | cut -c1-30)
-    rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$out/$name" -o pmc -- python tools/bench_config5.py 200000000 200000000 > "$out/$name.log" 2>&1
-done
-python - <<'PY'
-import csv,glob
-c={}
-for path in glob.glob("gpurun_out/pmc_var/**/*counter_collection.csv", recursive=True):
-    for row in csv.DictReader(open(path)):
-        if "k_lookup_var" in row["Kernel_Name"]:
-            c.setdefault(row["Counter_Name"],[]).append(float(row["Counter_Value"]))
-for k,v in sorted(c.items()): print(k, ["%.3g"%x for x in v])
-PY
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o stats -- python tools/bench_config5.py $nk $nq > "$out/stats.log" 2>&1
+find "$out/stats" -name "*kernel_stats.csv" -exec cp {} "$out/kernel_stats.csv" \;
+i=0
+while read -r set; do
+    [ -z "$set" ] && continue
+    i=$((i + 1))
+    name=$(printf "p%02d" $i)
+    rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$out/$name" -o pmc -- python tools/bench_config5.py $nk $nq > "$out/$name.log" 2>&1 || echo "pass $name ($set) failed" | tee -a "$out/failed.txt"
+    echo "pmc pass $name done: $set"
+done <<'SETS'
+SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE
+SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_FLAT
+TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum
+TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum
+SETS
+grep -h "^{" "$out/stats.log" | tail -1

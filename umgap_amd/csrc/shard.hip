@@ -11,8 +11,9 @@
 //   exchange  all-to-all of the values back
 //   classify  gather the hits of each read through perm into LDS -> [seedextend] -> aggregate                  classify.hip (GATHER)
 //
-// A batch is cut into pieces of whole reads that run as a software pipeline over four buffer sets, each with its own
-// stream: while piece t is packed and its keys travel, piece t-1 is probed and piece t-2 is aggregated.  The exchanges are
+// A batch is cut into pieces of whole reads that flow through three stage streams (pack + key exchange | probe | value
+// exchange + aggregate) over four buffer sets: while piece t is packed and its keys travel, piece t-1 is probed and piece
+// t-2 is aggregated.  The exchanges are
 // issued in the order A(0) A(1) R(0) A(2) R(1) ... on every rank (RCCL runs one communicator's operations in issue
 // order), so a return exchange never waits behind the key exchange of the piece after it.  Regions have a fixed capacity
 // (the mixer spreads keys evenly: expected K/N per region, `slack` on top), which keeps every message the same size on
@@ -352,13 +353,13 @@ __global__ __launch_bounds__(256) void k_max_value(const uint64_t* __restrict__ 
     if (m) atomicMax(out, m);
 }
 
-constexpr int NSETS = 4;   // one more than the stages of a piece in flight: a pack never waits for the aggregate three pieces back
+constexpr int NSETS = 4;    // exchange buffer sets: piece t uses set t % NSETS
+constexpr int NPERM = 8;    // perm buffers (piece t uses t % NPERM): a pack never waits for the aggregate NSETS pieces back
 
 struct BufSet {
-    hipStream_t stream = nullptr;
-    hipEvent_t done = nullptr, probed = nullptr;
+    hipEvent_t packed = nullptr, probed = nullptr;   // piece using this set: keys exchanged / probe finished
     uint8_t *send_keys = nullptr, *recv_keys = nullptr;
-    uint32_t *ret_send = nullptr, *ret_recv = nullptr, *perm = nullptr;
+    uint32_t *ret_send = nullptr, *ret_recv = nullptr;
     unsigned long long* cursor = nullptr;
 };
 
@@ -374,6 +375,15 @@ struct umgap_sharded {
     void* block = nullptr;
     size_t block_bytes = 0;
     BufSet set[NSETS];
+    uint32_t* perm[NPERM] = {};
+    hipEvent_t aggregated[NPERM] = {};   // piece using this perm buffer: aggregate (or un-permute) finished
+    // one stream per STAGE: pack + key exchange | probe | value exchange + aggregate.  Pieces flow through them in order, so
+    // the probes -- each of which saturates the chip's random-request path -- run back to back while the pack of the pieces
+    // ahead and the aggregate of the pieces behind (streaming / ALU work) run underneath them.  (One stream per PIECE, the
+    // first version, marched three pieces through their stages in lockstep: profiles/r02_sharded_timeline_lockstep.txt.)
+    hipStream_t s_pack = nullptr, s_probe = nullptr, s_agg = nullptr;
+    hipEvent_t ev_done[3] = {};
+    uint64_t piece_no = 0;               // pieces issued so far (event slots are reused cyclically)
     uint32_t* d_overflow = nullptr;
     hipEvent_t ev_in = nullptr, ev_probe0 = nullptr, ev_probe1 = nullptr;
     bool probe_timed = false;
@@ -391,49 +401,68 @@ int sharded_args_ok(umgap_sharded* sh, const char* who) {
 }
 
 // one piece, first half: pack -> pad -> key exchange -> local probe, all on the set's stream
-// `after` (nullable): the set whose probe must have finished before this piece's probe starts.  One probe saturates the
-// chip's random-request path, so two at once only slow each other down; chained, the probes run back to back and the pack and
-// the aggregate of the neighbouring pieces (streaming / ALU work) run underneath them.  Without the chain three pieces march
-// through their stages in lockstep and nothing overlaps (profiles/r02_sharded_timeline_lockstep.txt).
-int piece_out(umgap_sharded* sh, BufSet& S, const BufSet* after, const uint64_t* d_keys, size_t nk, bool time_probe) {
+// Piece t of a call, first half.  Stream s_pack: pack -> pad -> key exchange; stream s_probe: the local probe.
+//   pack(t)  overwrites send_keys / recv_keys of set t % NSETS, last read by probe(t - NSETS), and perm t % NPERM, last read
+//            by the aggregate of piece t - NPERM;
+//   probe(t) overwrites the value buffers of its set, last read by the value exchange and the aggregate of piece t - NSETS.
+int piece_out(umgap_sharded* sh, const uint64_t* d_keys, size_t nk, bool time_probe) {
+    const uint64_t t = sh->piece_no;
+    BufSet& S = sh->set[t % NSETS];
+    uint32_t* perm = sh->perm[t % NPERM];
     const uint32_t W = (uint32_t)sh->comm->world;
     const TableView& T = sh->ix->view;
-    hipStream_t s = S.stream;
-    UMGAP_HIP(hipMemsetAsync(S.cursor, 0, W * sizeof(unsigned long long), s));
+    if (t >= NSETS) UMGAP_HIP(hipStreamWaitEvent(sh->s_pack, S.probed, 0));
+    if (t >= NPERM) UMGAP_HIP(hipStreamWaitEvent(sh->s_pack, sh->aggregated[t % NPERM], 0));
+    UMGAP_HIP(hipMemsetAsync(S.cursor, 0, W * sizeof(unsigned long long), sh->s_pack));
     const size_t tile = 256 * PACK_PER_THREAD;
-    unsigned g = (unsigned)((nk + tile - 1) / tile);   // one tile per workgroup: short-lived workgroups leave room for the other pieces' kernels
+    unsigned g = (unsigned)((nk + tile - 1) / tile);   // one tile per workgroup: short-lived workgroups leave room for the other stages' kernels
     if (g < 1) g = 1;
-    hipLaunchKernelGGL(k_shard_pack, dim3(g), dim3(256), 0, s, d_keys, nk, T.m, T.nb, W, sh->cap, S.send_keys, S.perm, S.cursor, sh->d_overflow);
-    hipLaunchKernelGGL(k_shard_pad, dim3(64, W), dim3(256), 0, s, S.send_keys, S.cursor, sh->cap);
+    hipLaunchKernelGGL(k_shard_pack, dim3(g), dim3(256), 0, sh->s_pack, d_keys, nk, T.m, T.nb, W, sh->cap, S.send_keys, perm, S.cursor, sh->d_overflow);
+    hipLaunchKernelGGL(k_shard_pad, dim3(64, W), dim3(256), 0, sh->s_pack, S.send_keys, S.cursor, sh->cap);
     UMGAP_HIP(hipGetLastError());
-    int rc = comm_alltoall(sh->comm, S.send_keys, S.recv_keys, (size_t)sh->cap * 6, s);
+    int rc = comm_alltoall(sh->comm, S.send_keys, S.recv_keys, (size_t)sh->cap * 6, sh->s_pack);
     if (rc) return rc;
+    UMGAP_HIP(hipEventRecord(S.packed, sh->s_pack));
+    // ---- probe ----
+    hipStream_t s = sh->s_probe;
+    UMGAP_HIP(hipStreamWaitEvent(s, S.packed, 0));
+    if (t >= NSETS) UMGAP_HIP(hipStreamWaitEvent(s, sh->aggregated[(t - NSETS) % NPERM], 0));
     const uint64_t n_slots = sh->cap * W;
     const unsigned gp = (unsigned)((n_slots / 128 + 3) / 4);
     const uint32_t self = (uint32_t)sh->comm->rank;
-    if (after) UMGAP_HIP(hipStreamWaitEvent(s, after->probed, 0));
     if (time_probe) UMGAP_HIP(hipEventRecord(sh->ev_probe0, s));
     if (sh->value_bytes == 3) hipLaunchKernelGGL(k_shard_probe<3>, dim3(gp), dim3(256), 0, s, T, S.recv_keys, S.send_keys, self, sh->cap, n_slots, S.ret_send, S.ret_recv);
     else hipLaunchKernelGGL(k_shard_probe<4>, dim3(gp), dim3(256), 0, s, T, S.recv_keys, S.send_keys, self, sh->cap, n_slots, S.ret_send, S.ret_recv);
     UMGAP_HIP(hipGetLastError());
     UMGAP_HIP(hipEventRecord(S.probed, s));
     if (time_probe) { UMGAP_HIP(hipEventRecord(sh->ev_probe1, s)); sh->probe_timed = true; }
+    sh->piece_no = t + 1;
     return UMGAP_OK;
 }
 
-int piece_back(umgap_sharded* sh, BufSet& S) {
-    return comm_alltoall(sh->comm, S.ret_send, S.ret_recv, (size_t)sh->cap * sh->value_bytes, S.stream);
+// Piece t, second half, on s_agg: the values travel back; the caller then enqueues its consumer (aggregate / un-permute) on
+// s_agg and calls piece_done.
+int piece_back(umgap_sharded* sh, uint64_t t) {
+    BufSet& S = sh->set[t % NSETS];
+    UMGAP_HIP(hipStreamWaitEvent(sh->s_agg, S.probed, 0));
+    return comm_alltoall(sh->comm, S.ret_send, S.ret_recv, (size_t)sh->cap * sh->value_bytes, sh->s_agg);
+}
+int piece_done(umgap_sharded* sh, uint64_t t) {
+    UMGAP_HIP(hipEventRecord(sh->aggregated[t % NPERM], sh->s_agg));
+    return UMGAP_OK;
 }
 
 int fork_streams(umgap_sharded* sh, hipStream_t caller) {
     UMGAP_HIP(hipEventRecord(sh->ev_in, caller));
-    for (auto& S : sh->set) UMGAP_HIP(hipStreamWaitEvent(S.stream, sh->ev_in, 0));
+    for (hipStream_t s : {sh->s_pack, sh->s_probe, sh->s_agg}) UMGAP_HIP(hipStreamWaitEvent(s, sh->ev_in, 0));
     return UMGAP_OK;
 }
 int join_streams(umgap_sharded* sh, hipStream_t caller) {
-    for (auto& S : sh->set) {
-        UMGAP_HIP(hipEventRecord(S.done, S.stream));
-        UMGAP_HIP(hipStreamWaitEvent(caller, S.done, 0));
+    int i = 0;
+    for (hipStream_t s : {sh->s_pack, sh->s_probe, sh->s_agg}) {
+        UMGAP_HIP(hipEventRecord(sh->ev_done[i], s));
+        UMGAP_HIP(hipStreamWaitEvent(caller, sh->ev_done[i], 0));
+        i++;
     }
     return UMGAP_OK;
 }
@@ -572,8 +601,8 @@ int umgap_sharded_create(umgap_index* shard, umgap_taxonomy* tx, umgap_comm* com
     // one block: per set {send keys, recv keys, values out, values back, perm, cursor}
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t b_keys = pad(cap * W * 6), b_vals = pad(cap * W * 4 + 64), b_perm = pad(sh->piece_keys * 4), b_cur = pad(W * 8);
-    const size_t per_set = 2 * b_keys + 2 * b_vals + b_perm + b_cur;
-    sh->block_bytes = NSETS * per_set + 256;
+    const size_t per_set = 2 * b_keys + 2 * b_vals + b_cur;
+    sh->block_bytes = NSETS * per_set + NPERM * b_perm + 256;
     e = hipMalloc(&sh->block, sh->block_bytes);
     if (e != hipSuccess) { delete sh; return fail(UMGAP_ERR_NOMEM, std::string("umgap_sharded_create: hipMalloc of the exchange buffers (") + std::to_string(sh->block_bytes >> 20) + " MiB): " + hipGetErrorString(e)); }
     char* p = (char*)sh->block;
@@ -582,16 +611,22 @@ int umgap_sharded_create(umgap_index* shard, umgap_taxonomy* tx, umgap_comm* com
         S.recv_keys = (uint8_t*)p; p += b_keys;
         S.ret_send = (uint32_t*)p; p += b_vals;
         S.ret_recv = (uint32_t*)p; p += b_vals;
-        S.perm = (uint32_t*)p; p += b_perm;
         S.cursor = (unsigned long long*)p; p += b_cur;
-        if (hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&S.done, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&S.probed, hipEventDisableTiming) != hipSuccess) {
+        if (hipEventCreateWithFlags(&S.packed, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&S.probed, hipEventDisableTiming) != hipSuccess) {
             umgap_sharded_free(sh);
-            return fail(UMGAP_ERR_DEVICE, "umgap_sharded_create: stream / event creation failed");
+            return fail(UMGAP_ERR_DEVICE, "umgap_sharded_create: event creation failed");
         }
+    }
+    for (int i = 0; i < NPERM; i++) {
+        sh->perm[i] = (uint32_t*)p; p += b_perm;
+        if (hipEventCreateWithFlags(&sh->aggregated[i], hipEventDisableTiming) != hipSuccess) { umgap_sharded_free(sh); return fail(UMGAP_ERR_DEVICE, "umgap_sharded_create: event creation failed"); }
     }
     sh->d_overflow = (uint32_t*)p;
     e = hipMemset(sh->d_overflow, 0, 4);
+    for (hipStream_t* st : {&sh->s_pack, &sh->s_probe, &sh->s_agg})
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    for (int i = 0; i < 3; i++)
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&sh->ev_done[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sh->ev_in, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreate(&sh->ev_probe0);
     if (e == hipSuccess) e = hipEventCreate(&sh->ev_probe1);
@@ -605,10 +640,12 @@ void umgap_sharded_free(umgap_sharded* sh) {
     (void)hipSetDevice(sh->device);
     (void)hipDeviceSynchronize();
     for (auto& S : sh->set) {
-        if (S.stream) (void)hipStreamDestroy(S.stream);
-        if (S.done) (void)hipEventDestroy(S.done);
+        if (S.packed) (void)hipEventDestroy(S.packed);
         if (S.probed) (void)hipEventDestroy(S.probed);
     }
+    for (auto ev : sh->aggregated) if (ev) (void)hipEventDestroy(ev);
+    for (auto ev : sh->ev_done) if (ev) (void)hipEventDestroy(ev);
+    for (hipStream_t st : {sh->s_pack, sh->s_probe, sh->s_agg}) if (st) (void)hipStreamDestroy(st);
     if (sh->ev_in) (void)hipEventDestroy(sh->ev_in);
     if (sh->ev_probe0) (void)hipEventDestroy(sh->ev_probe0);
     if (sh->ev_probe1) (void)hipEventDestroy(sh->ev_probe1);
@@ -632,20 +669,23 @@ int umgap_sharded_lookup9_dev(umgap_sharded* sh, const uint64_t* d_keys45, size_
     // every rank takes part in every exchange, even with nothing to look up: the piece count is fixed
     const size_t per = sh->piece_keys, np = sh->pieces;
     if ((rc = fork_streams(sh, caller))) return rc;
+    const uint64_t first = sh->piece_no;
     for (size_t t = 0; t <= np; t++) {
         if (t < np) {
             const size_t lo = std::min(n, t * per), hi = std::min(n, (t + 1) * per);
-            if ((rc = piece_out(sh, sh->set[t % NSETS], t ? &sh->set[(t - 1) % NSETS] : nullptr, d_keys45 + lo, hi - lo, t == 0))) return rc;
+            if ((rc = piece_out(sh, d_keys45 + lo, hi - lo, t == 0))) return rc;
         }
         if (t >= 1) {
             const size_t c = t - 1, lo = std::min(n, c * per), hi = std::min(n, (c + 1) * per);
-            BufSet& S = sh->set[c % NSETS];
-            if ((rc = piece_back(sh, S))) return rc;
+            const uint64_t pc = first + c;
+            if ((rc = piece_back(sh, pc))) return rc;
             if (hi > lo) {
                 unsigned g = (unsigned)std::min<size_t>((hi - lo + 255) / 256, 2048);
-                hipLaunchKernelGGL(k_shard_unpermute, dim3(g), dim3(256), 0, S.stream, HitSource{S.ret_recv, S.perm, sh->value_bytes}, hi - lo, miss_value, d_out_taxa + lo);
+                hipLaunchKernelGGL(k_shard_unpermute, dim3(g), dim3(256), 0, sh->s_agg, HitSource{sh->set[pc % NSETS].ret_recv, sh->perm[pc % NPERM], sh->value_bytes},
+                                   hi - lo, miss_value, d_out_taxa + lo);
                 UMGAP_HIP(hipGetLastError());
             }
+            if ((rc = piece_done(sh, pc))) return rc;
         }
     }
     return join_streams(sh, caller);
@@ -689,18 +729,21 @@ int umgap_sharded_classify9_dev(umgap_sharded* sh, int method, int strategy, flo
     if (per == 0) return fail(UMGAP_ERR_INVALID, "umgap_sharded_classify9_dev: a piece cannot hold one read (lower `pieces`)");
     if ((uint64_t)per * np < n_reads) return fail(UMGAP_ERR_INVALID, "umgap_sharded_classify9_dev: the reads do not fit the pieces (create the group with a max_keys_per_call that is a multiple of pieces * kmers_per_read)");
     if ((rc = fork_streams(sh, caller))) return rc;
+    const uint64_t first = sh->piece_no;
     for (size_t t = 0; t <= np; t++) {
         if (t < np) {
             const size_t lo = std::min(n_reads, t * per), hi = std::min(n_reads, (t + 1) * per);
-            if ((rc = piece_out(sh, sh->set[t % NSETS], t ? &sh->set[(t - 1) % NSETS] : nullptr, d_keys45 + lo * kmers_per_read, (hi - lo) * kmers_per_read, t == 0))) return rc;
+            if ((rc = piece_out(sh, d_keys45 + lo * kmers_per_read, (hi - lo) * kmers_per_read, t == 0))) return rc;
         }
         if (t >= 1) {
             const size_t c = t - 1, lo = std::min(n_reads, c * per), hi = std::min(n_reads, (c + 1) * per);
-            BufSet& S = sh->set[c % NSETS];
-            if ((rc = piece_back(sh, S))) return rc;
-            rc = launch_classify9_from_hits(sh->tx, method, strategy, factor, lower_bound, ranked_only, HitSource{S.ret_recv, S.perm, sh->value_bytes}, hi - lo,
-                                            kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, d_out_taxon + lo, d_out_status + lo, S.stream);
+            const uint64_t pc = first + c;
+            if ((rc = piece_back(sh, pc))) return rc;
+            rc = launch_classify9_from_hits(sh->tx, method, strategy, factor, lower_bound, ranked_only,
+                                            HitSource{sh->set[pc % NSETS].ret_recv, sh->perm[pc % NPERM], sh->value_bytes}, hi - lo, kmers_per_read,
+                                            fragments_per_read, min_seed_size, max_gap_size, d_out_taxon + lo, d_out_status + lo, sh->s_agg);
             if (rc) return rc;
+            if ((rc = piece_done(sh, pc))) return rc;
         }
     }
     return join_streams(sh, caller);
