@@ -357,7 +357,7 @@ constexpr int NSETS = 4;    // exchange buffer sets: piece t uses set t % NSETS
 constexpr int NPERM = 8;    // perm buffers (piece t uses t % NPERM): a pack never waits for the aggregate NSETS pieces back
 
 struct BufSet {
-    hipEvent_t packed = nullptr, probed = nullptr;   // piece using this set: keys exchanged / probe finished
+    hipEvent_t filled = nullptr, packed = nullptr, probed = nullptr;   // piece using this set: packed / keys exchanged / probe finished
     uint8_t *send_keys = nullptr, *recv_keys = nullptr;
     uint32_t *ret_send = nullptr, *ret_recv = nullptr;
     unsigned long long* cursor = nullptr;
@@ -377,11 +377,11 @@ struct umgap_sharded {
     BufSet set[NSETS];
     uint32_t* perm[NPERM] = {};
     hipEvent_t aggregated[NPERM] = {};   // piece using this perm buffer: aggregate (or un-permute) finished
-    // one stream per STAGE: pack + key exchange | probe | value exchange + aggregate.  Pieces flow through them in order, so
-    // the probes -- each of which saturates the chip's random-request path -- run back to back while the pack of the pieces
-    // ahead and the aggregate of the pieces behind (streaming / ALU work) run underneath them.  (One stream per PIECE, the
-    // first version, marched three pieces through their stages in lockstep: profiles/r02_sharded_timeline_lockstep.txt.)
-    hipStream_t s_pack = nullptr, s_probe = nullptr, s_agg = nullptr;
+    // one stream per STAGE: key exchange | pack + probe | value exchange + aggregate.  Pieces flow through them in order: the
+    // probes -- each of which saturates the chip's random-request path -- run back to back with the packs between them, the
+    // keys of the pieces ahead travel meanwhile and the aggregate of the pieces behind runs underneath.  (One stream per
+    // PIECE, the first version, marched three pieces through their stages in lockstep: profiles/r02_sharded_timeline_lockstep.txt.)
+    hipStream_t s_keys = nullptr, s_probe = nullptr, s_agg = nullptr;
     hipEvent_t ev_done[3] = {};
     uint64_t piece_no = 0;               // pieces issued so far (event slots are reused cyclically)
     uint32_t* d_overflow = nullptr;
@@ -401,29 +401,48 @@ int sharded_args_ok(umgap_sharded* sh, const char* who) {
 }
 
 // one piece, first half: pack -> pad -> key exchange -> local probe, all on the set's stream
-// Piece t of a call, first half.  Stream s_pack: pack -> pad -> key exchange; stream s_probe: the local probe.
-//   pack(t)  overwrites send_keys / recv_keys of set t % NSETS, last read by probe(t - NSETS), and perm t % NPERM, last read
-//            by the aggregate of piece t - NPERM;
-//   probe(t) overwrites the value buffers of its set, last read by the value exchange and the aggregate of piece t - NSETS.
-int piece_out(umgap_sharded* sh, const uint64_t* d_keys, size_t nk, bool time_probe) {
-    const uint64_t t = sh->piece_no;
+// The stages of piece t (global piece number; set t % NSETS, perm t % NPERM).
+//   pack  (s_probe) overwrites send_keys of its set, last read by the key exchange and the probe of piece t - NSETS (both
+//                   earlier on s_probe / waited for below), and perm, last read by the aggregate of piece t - NPERM;
+//   keys  (s_keys)  send_keys -> recv_keys over the wire, after the pack;
+//   probe (s_probe) after the keys; overwrites the value buffers of its set, last read by the value exchange and the
+//                   aggregate of piece t - NSETS.
+// pack and probe share ONE stream on purpose: beside a probe a pack takes 3.9 ms instead of 0.64 (the probe's workgroups take
+// nearly every slot that frees up, stream priorities do not change that: profiles/r02_sharded_timeline_*.txt), and the probe
+// of piece t + 1 needs it.  The stream runs  pack(t + LOOK)  between  probe(t - 1)  and  probe(t), so a pack never runs
+// beside a probe and the keys of piece t + LOOK travel while pieces t .. t + LOOK - 1 are probed.
+constexpr uint64_t LOOK = 2;
+
+int stage_pack(umgap_sharded* sh, uint64_t t, const uint64_t* d_keys, size_t nk) {
     BufSet& S = sh->set[t % NSETS];
-    uint32_t* perm = sh->perm[t % NPERM];
     const uint32_t W = (uint32_t)sh->comm->world;
     const TableView& T = sh->ix->view;
-    if (t >= NSETS) UMGAP_HIP(hipStreamWaitEvent(sh->s_pack, S.probed, 0));
-    if (t >= NPERM) UMGAP_HIP(hipStreamWaitEvent(sh->s_pack, sh->aggregated[t % NPERM], 0));
-    UMGAP_HIP(hipMemsetAsync(S.cursor, 0, W * sizeof(unsigned long long), sh->s_pack));
+    hipStream_t s = sh->s_probe;
+    if (t >= NSETS) UMGAP_HIP(hipStreamWaitEvent(s, S.packed, 0));          // the key exchange of piece t - NSETS has read send_keys
+    if (t >= NPERM) UMGAP_HIP(hipStreamWaitEvent(s, sh->aggregated[t % NPERM], 0));
+    UMGAP_HIP(hipMemsetAsync(S.cursor, 0, W * sizeof(unsigned long long), s));
     const size_t tile = 256 * PACK_PER_THREAD;
-    unsigned g = (unsigned)((nk + tile - 1) / tile);   // one tile per workgroup: short-lived workgroups leave room for the other stages' kernels
+    unsigned g = (unsigned)((nk + tile - 1) / tile);
     if (g < 1) g = 1;
-    hipLaunchKernelGGL(k_shard_pack, dim3(g), dim3(256), 0, sh->s_pack, d_keys, nk, T.m, T.nb, W, sh->cap, S.send_keys, perm, S.cursor, sh->d_overflow);
-    hipLaunchKernelGGL(k_shard_pad, dim3(64, W), dim3(256), 0, sh->s_pack, S.send_keys, S.cursor, sh->cap);
+    hipLaunchKernelGGL(k_shard_pack, dim3(g), dim3(256), 0, s, d_keys, nk, T.m, T.nb, W, sh->cap, S.send_keys, sh->perm[t % NPERM], S.cursor, sh->d_overflow);
+    hipLaunchKernelGGL(k_shard_pad, dim3(64, W), dim3(256), 0, s, S.send_keys, S.cursor, sh->cap);
     UMGAP_HIP(hipGetLastError());
-    int rc = comm_alltoall(sh->comm, S.send_keys, S.recv_keys, (size_t)sh->cap * 6, sh->s_pack);
+    UMGAP_HIP(hipEventRecord(S.filled, s));
+    return UMGAP_OK;
+}
+int stage_keys(umgap_sharded* sh, uint64_t t) {
+    BufSet& S = sh->set[t % NSETS];
+    UMGAP_HIP(hipStreamWaitEvent(sh->s_keys, S.filled, 0));
+    if (t >= NSETS) UMGAP_HIP(hipStreamWaitEvent(sh->s_keys, S.probed, 0));   // recv_keys was read by the probe of piece t - NSETS
+    int rc = comm_alltoall(sh->comm, S.send_keys, S.recv_keys, (size_t)sh->cap * 6, sh->s_keys);
     if (rc) return rc;
-    UMGAP_HIP(hipEventRecord(S.packed, sh->s_pack));
-    // ---- probe ----
+    UMGAP_HIP(hipEventRecord(S.packed, sh->s_keys));
+    return UMGAP_OK;
+}
+int stage_probe(umgap_sharded* sh, uint64_t t, bool time_probe) {
+    BufSet& S = sh->set[t % NSETS];
+    const uint32_t W = (uint32_t)sh->comm->world;
+    const TableView& T = sh->ix->view;
     hipStream_t s = sh->s_probe;
     UMGAP_HIP(hipStreamWaitEvent(s, S.packed, 0));
     if (t >= NSETS) UMGAP_HIP(hipStreamWaitEvent(s, sh->aggregated[(t - NSETS) % NPERM], 0));
@@ -436,7 +455,6 @@ int piece_out(umgap_sharded* sh, const uint64_t* d_keys, size_t nk, bool time_pr
     UMGAP_HIP(hipGetLastError());
     UMGAP_HIP(hipEventRecord(S.probed, s));
     if (time_probe) { UMGAP_HIP(hipEventRecord(sh->ev_probe1, s)); sh->probe_timed = true; }
-    sh->piece_no = t + 1;
     return UMGAP_OK;
 }
 
@@ -454,12 +472,12 @@ int piece_done(umgap_sharded* sh, uint64_t t) {
 
 int fork_streams(umgap_sharded* sh, hipStream_t caller) {
     UMGAP_HIP(hipEventRecord(sh->ev_in, caller));
-    for (hipStream_t s : {sh->s_pack, sh->s_probe, sh->s_agg}) UMGAP_HIP(hipStreamWaitEvent(s, sh->ev_in, 0));
+    for (hipStream_t s : {sh->s_keys, sh->s_probe, sh->s_agg}) UMGAP_HIP(hipStreamWaitEvent(s, sh->ev_in, 0));
     return UMGAP_OK;
 }
 int join_streams(umgap_sharded* sh, hipStream_t caller) {
     int i = 0;
-    for (hipStream_t s : {sh->s_pack, sh->s_probe, sh->s_agg}) {
+    for (hipStream_t s : {sh->s_keys, sh->s_probe, sh->s_agg}) {
         UMGAP_HIP(hipEventRecord(sh->ev_done[i], s));
         UMGAP_HIP(hipStreamWaitEvent(caller, sh->ev_done[i], 0));
         i++;
@@ -612,7 +630,8 @@ int umgap_sharded_create(umgap_index* shard, umgap_taxonomy* tx, umgap_comm* com
         S.ret_send = (uint32_t*)p; p += b_vals;
         S.ret_recv = (uint32_t*)p; p += b_vals;
         S.cursor = (unsigned long long*)p; p += b_cur;
-        if (hipEventCreateWithFlags(&S.packed, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&S.probed, hipEventDisableTiming) != hipSuccess) {
+        if (hipEventCreateWithFlags(&S.filled, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&S.packed, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&S.probed, hipEventDisableTiming) != hipSuccess) {
             umgap_sharded_free(sh);
             return fail(UMGAP_ERR_DEVICE, "umgap_sharded_create: event creation failed");
         }
@@ -623,15 +642,8 @@ int umgap_sharded_create(umgap_index* shard, umgap_taxonomy* tx, umgap_comm* com
     }
     sh->d_overflow = (uint32_t*)p;
     e = hipMemset(sh->d_overflow, 0, 4);
-    // The probe's workgroups are short-lived and there are hundreds of thousands of them: at equal priority they take nearly
-    // every slot that frees up and a pack that runs beside a probe takes 3.8 ms instead of 0.64 (profiles/r02_sharded_*).
-    // The two light stages therefore run on high-priority streams: their workgroups are placed first, finish in about their
-    // stand-alone time and the probe fills whatever they leave.
-    int prio_least = 0, prio_greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&sh->s_pack, hipStreamNonBlocking, prio_greatest);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&sh->s_agg, hipStreamNonBlocking, prio_greatest);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&sh->s_probe, hipStreamNonBlocking, prio_least);
+    for (hipStream_t* st : {&sh->s_keys, &sh->s_probe, &sh->s_agg})
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
     for (int i = 0; i < 3; i++)
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sh->ev_done[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sh->ev_in, hipEventDisableTiming);
@@ -647,12 +659,13 @@ void umgap_sharded_free(umgap_sharded* sh) {
     (void)hipSetDevice(sh->device);
     (void)hipDeviceSynchronize();
     for (auto& S : sh->set) {
+        if (S.filled) (void)hipEventDestroy(S.filled);
         if (S.packed) (void)hipEventDestroy(S.packed);
         if (S.probed) (void)hipEventDestroy(S.probed);
     }
     for (auto ev : sh->aggregated) if (ev) (void)hipEventDestroy(ev);
     for (auto ev : sh->ev_done) if (ev) (void)hipEventDestroy(ev);
-    for (hipStream_t st : {sh->s_pack, sh->s_probe, sh->s_agg}) if (st) (void)hipStreamDestroy(st);
+    for (hipStream_t st : {sh->s_keys, sh->s_probe, sh->s_agg}) if (st) (void)hipStreamDestroy(st);
     if (sh->ev_in) (void)hipEventDestroy(sh->ev_in);
     if (sh->ev_probe0) (void)hipEventDestroy(sh->ev_probe0);
     if (sh->ev_probe1) (void)hipEventDestroy(sh->ev_probe1);
@@ -677,10 +690,17 @@ int umgap_sharded_lookup9_dev(umgap_sharded* sh, const uint64_t* d_keys45, size_
     const size_t per = sh->piece_keys, np = sh->pieces;
     if ((rc = fork_streams(sh, caller))) return rc;
     const uint64_t first = sh->piece_no;
+    sh->piece_no += np;
+    auto pack_piece = [&](size_t t) -> int {
+        const size_t lo = std::min(n, t * per), hi = std::min(n, (t + 1) * per);
+        int r = stage_pack(sh, first + t, d_keys45 + lo, hi - lo);
+        return r ? r : stage_keys(sh, first + t);
+    };
+    for (size_t t = 0; t < std::min<size_t>(LOOK, np); t++) if ((rc = pack_piece(t))) return rc;
     for (size_t t = 0; t <= np; t++) {
         if (t < np) {
-            const size_t lo = std::min(n, t * per), hi = std::min(n, (t + 1) * per);
-            if ((rc = piece_out(sh, d_keys45 + lo, hi - lo, t == 0))) return rc;
+            if (t + LOOK < np && (rc = pack_piece(t + LOOK))) return rc;
+            if ((rc = stage_probe(sh, first + t, t == 0))) return rc;
         }
         if (t >= 1) {
             const size_t c = t - 1, lo = std::min(n, c * per), hi = std::min(n, (c + 1) * per);
@@ -737,10 +757,17 @@ int umgap_sharded_classify9_dev(umgap_sharded* sh, int method, int strategy, flo
     if ((uint64_t)per * np < n_reads) return fail(UMGAP_ERR_INVALID, "umgap_sharded_classify9_dev: the reads do not fit the pieces (create the group with a max_keys_per_call that is a multiple of pieces * kmers_per_read)");
     if ((rc = fork_streams(sh, caller))) return rc;
     const uint64_t first = sh->piece_no;
+    sh->piece_no += np;
+    auto pack_piece = [&](size_t t) -> int {
+        const size_t lo = std::min(n_reads, t * per), hi = std::min(n_reads, (t + 1) * per);
+        int r = stage_pack(sh, first + t, d_keys45 + lo * kmers_per_read, (hi - lo) * kmers_per_read);
+        return r ? r : stage_keys(sh, first + t);
+    };
+    for (size_t t = 0; t < std::min<size_t>(LOOK, np); t++) if ((rc = pack_piece(t))) return rc;
     for (size_t t = 0; t <= np; t++) {
         if (t < np) {
-            const size_t lo = std::min(n_reads, t * per), hi = std::min(n_reads, (t + 1) * per);
-            if ((rc = piece_out(sh, d_keys45 + lo * kmers_per_read, (hi - lo) * kmers_per_read, t == 0))) return rc;
+            if (t + LOOK < np && (rc = pack_piece(t + LOOK))) return rc;
+            if ((rc = stage_probe(sh, first + t, t == 0))) return rc;
         }
         if (t >= 1) {
             const size_t c = t - 1, lo = std::min(n_reads, c * per), hi = std::min(n_reads, (c + 1) * per);
