@@ -465,7 +465,7 @@ int piece_back(umgap_sharded* sh, uint64_t t) {
     UMGAP_HIP(hipStreamWaitEvent(sh->s_agg, S.probed, 0));
     return comm_alltoall(sh->comm, S.ret_send, S.ret_recv, (size_t)sh->cap * sh->value_bytes, sh->s_agg);
 }
-// The aggregate of piece t is held back until the pack of piece t + LOOK (which follows probe(t) on s_probe) has finished:
+// The aggregate of piece t is held back until the pack of piece t + LOOK + 1 (the one that follows probe(t) on s_probe) has finished:
 // side by side the two slow each other down (pack 1.4 ms instead of 0.64) and the next probe waits for the pack; beside the
 // next probe the aggregate costs nothing extra.
 int hold_for_pack(umgap_sharded* sh, uint64_t t_ahead) {
@@ -713,7 +713,7 @@ int umgap_sharded_lookup9_dev(umgap_sharded* sh, const uint64_t* d_keys45, size_
             const size_t c = t - 1, lo = std::min(n, c * per), hi = std::min(n, (c + 1) * per);
             const uint64_t pc = first + c;
             if ((rc = piece_back(sh, pc))) return rc;
-            if (c + LOOK < np && (rc = hold_for_pack(sh, pc + LOOK))) return rc;
+            if (c + LOOK + 1 < np && (rc = hold_for_pack(sh, pc + LOOK + 1))) return rc;
             if (hi > lo) {
                 unsigned g = (unsigned)std::min<size_t>((hi - lo + 255) / 256, 2048);
                 hipLaunchKernelGGL(k_shard_unpermute, dim3(g), dim3(256), 0, sh->s_agg, HitSource{sh->set[pc % NSETS].ret_recv, sh->perm[pc % NPERM], sh->value_bytes},
@@ -781,7 +781,7 @@ int umgap_sharded_classify9_dev(umgap_sharded* sh, int method, int strategy, flo
             const size_t c = t - 1, lo = std::min(n_reads, c * per), hi = std::min(n_reads, (c + 1) * per);
             const uint64_t pc = first + c;
             if ((rc = piece_back(sh, pc))) return rc;
-            if (c + LOOK < np && (rc = hold_for_pack(sh, pc + LOOK))) return rc;
+            if (c + LOOK + 1 < np && (rc = hold_for_pack(sh, pc + LOOK + 1))) return rc;
             rc = launch_classify9_from_hits(sh->tx, method, strategy, factor, lower_bound, ranked_only,
                                             HitSource{sh->set[pc % NSETS].ret_recv, sh->perm[pc % NPERM], sh->value_bytes}, hi - lo, kmers_per_read,
                                             fragments_per_read, min_seed_size, max_gap_size, d_out_taxon + lo, d_out_status + lo, sh->s_agg);
