@@ -268,18 +268,20 @@ __global__ __launch_bounds__(256) void k_shard_pad(uint8_t* __restrict__ send, c
 
 // keys (world regions x cap slots) -> one value per slot.  Region `self` is this rank's own share: read from the send buffer
 // it was packed into and answered straight into the buffer the returned values are gathered from -- no copy, no wire.
-// One wave = 128 consecutive slots (cap is a multiple of 128, so they share a region): two probe batches in flight; the
-// results are packed in the wave's LDS strip and leave as whole 16-byte-per-lane stores.  One step per wave and a grid of
-// as many workgroups as there is work: the workgroups are short-lived, so kernels of the other pieces (pack, aggregate,
-// RCCL's copies) keep getting compute units while a probe is running.
+// One wave step = 128 consecutive slots (cap is a multiple of 128, so they share a region): two probe batches in flight; the
+// results are packed in the wave's LDS strip and leave as whole 16-byte-per-lane stores.  The grid is PERSISTENT and small
+// (two workgroups per CU = 8 waves = ~1000 sectors in flight per CU, several times what the request ceiling needs): the
+// hardware dispatches one grid of a queue at a time, so a grid of 200 000 short workgroups keeps every other stream's kernel
+// waiting until its last workgroup is placed (a pack "beside" such a probe made no progress at all: r02_sharded_timeline_*),
+// while a resident grid that leaves half of each CU's wave slots free lets pack, aggregate and RCCL's copies run next to it.
 template <int VB>
 __global__ __launch_bounds__(256) void k_shard_probe(TableView T, const uint8_t* __restrict__ recv, const uint8_t* __restrict__ own_send, uint32_t self,
                                                      uint64_t cap, uint64_t n_slots, uint32_t* __restrict__ ret, uint32_t* __restrict__ own_ret) {
     __shared__ uint32_t lds_out[4][128];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
-    const uint64_t s0 = (((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * 128;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     constexpr uint32_t MISS = VB == 3 ? 0xFFFFFFu : 0xFFFFFFFFu;
-    if (s0 >= n_slots) return;
+    for (uint64_t s0 = wave * 128; s0 < n_slots; s0 += nwaves * 128) {
     const uint64_t region = s0 / cap, pos0 = s0 - region * cap;
     const uint8_t* rb = (region == self ? own_send : recv) + region * cap * 6;
     const uint32_t* lo = reinterpret_cast<const uint32_t*>(rb) + pos0;
@@ -323,6 +325,9 @@ __global__ __launch_bounds__(256) void k_shard_probe(TableView T, const uint8_t*
     // 128 slots = 96 (VB 3) or 128 (VB 4) words = 24 or 32 lanes x 16 bytes, contiguous
     uint32_t* dst = (region == self ? own_ret : ret) + (VB == 4 ? s0 : (s0 >> 2) * 3);
     if (lane < (VB == 4 ? 32u : 24u)) reinterpret_cast<u32x4*>(dst)[lane] = reinterpret_cast<const u32x4*>(wl)[lane];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    }
 }
 
 // the plain sharded get(): out[i] = value of key i (perm order undone), or miss_value
@@ -402,23 +407,21 @@ int sharded_args_ok(umgap_sharded* sh, const char* who) {
 
 // one piece, first half: pack -> pad -> key exchange -> local probe, all on the set's stream
 // The stages of piece t (global piece number; set t % NSETS, perm t % NPERM).
-//   pack  (s_probe) overwrites send_keys of its set, last read by the key exchange and the probe of piece t - NSETS (both
-//                   earlier on s_probe / waited for below), and perm, last read by the aggregate of piece t - NPERM;
+//   pack  (s_keys)  overwrites send_keys of its set, last read by the key exchange (earlier on s_keys) and the probe of piece
+//                   t - NSETS (waited for), and perm, last read by the aggregate of piece t - NPERM;
 //   keys  (s_keys)  send_keys -> recv_keys over the wire, after the pack;
 //   probe (s_probe) after the keys; overwrites the value buffers of its set, last read by the value exchange and the
 //                   aggregate of piece t - NSETS.
-// pack and probe share ONE stream on purpose: beside a probe a pack takes 3.9 ms instead of 0.64 (the probe's workgroups take
-// nearly every slot that frees up, stream priorities do not change that: profiles/r02_sharded_timeline_*.txt), and the probe
-// of piece t + 1 needs it.  The stream runs  pack(t + LOOK)  between  probe(t - 1)  and  probe(t), so a pack never runs
-// beside a probe and the keys of piece t + LOOK travel while pieces t .. t + LOOK - 1 are probed.
+// The pack and the key exchange of piece t + LOOK are issued before the probe of piece t: they run (on s_keys) while pieces
+// t .. t + LOOK - 1 are probed.
 constexpr uint64_t LOOK = 2;
 
 int stage_pack(umgap_sharded* sh, uint64_t t, const uint64_t* d_keys, size_t nk) {
     BufSet& S = sh->set[t % NSETS];
     const uint32_t W = (uint32_t)sh->comm->world;
     const TableView& T = sh->ix->view;
-    hipStream_t s = sh->s_probe;
-    if (t >= NSETS) UMGAP_HIP(hipStreamWaitEvent(s, S.packed, 0));          // the key exchange of piece t - NSETS has read send_keys
+    hipStream_t s = sh->s_keys;                                               // the key exchange of piece t - NSETS is earlier on this stream
+    if (t >= NSETS) UMGAP_HIP(hipStreamWaitEvent(s, S.probed, 0));          // the probe of piece t - NSETS has read its own share of send_keys
     if (t >= NPERM) UMGAP_HIP(hipStreamWaitEvent(s, sh->aggregated[t % NPERM], 0));
     UMGAP_HIP(hipMemsetAsync(S.cursor, 0, W * sizeof(unsigned long long), s));
     const size_t tile = 256 * PACK_PER_THREAD;
@@ -447,7 +450,7 @@ int stage_probe(umgap_sharded* sh, uint64_t t, bool time_probe) {
     UMGAP_HIP(hipStreamWaitEvent(s, S.packed, 0));
     if (t >= NSETS) UMGAP_HIP(hipStreamWaitEvent(s, sh->aggregated[(t - NSETS) % NPERM], 0));
     const uint64_t n_slots = sh->cap * W;
-    const unsigned gp = (unsigned)((n_slots / 128 + 3) / 4);
+    const unsigned gp = (unsigned)std::min<uint64_t>((n_slots / 128 + 3) / 4, 256 * 2);
     const uint32_t self = (uint32_t)sh->comm->rank;
     if (time_probe) UMGAP_HIP(hipEventRecord(sh->ev_probe0, s));
     if (sh->value_bytes == 3) hipLaunchKernelGGL(k_shard_probe<3>, dim3(gp), dim3(256), 0, s, T, S.recv_keys, S.send_keys, self, sh->cap, n_slots, S.ret_send, S.ret_recv);
@@ -464,13 +467,6 @@ int piece_back(umgap_sharded* sh, uint64_t t) {
     BufSet& S = sh->set[t % NSETS];
     UMGAP_HIP(hipStreamWaitEvent(sh->s_agg, S.probed, 0));
     return comm_alltoall(sh->comm, S.ret_send, S.ret_recv, (size_t)sh->cap * sh->value_bytes, sh->s_agg);
-}
-// The aggregate of piece t is held back until the pack of piece t + LOOK + 1 (the one that follows probe(t) on s_probe) has finished:
-// side by side the two slow each other down (pack 1.4 ms instead of 0.64) and the next probe waits for the pack; beside the
-// next probe the aggregate costs nothing extra.
-int hold_for_pack(umgap_sharded* sh, uint64_t t_ahead) {
-    UMGAP_HIP(hipStreamWaitEvent(sh->s_agg, sh->set[t_ahead % NSETS].filled, 0));
-    return UMGAP_OK;
 }
 int piece_done(umgap_sharded* sh, uint64_t t) {
     UMGAP_HIP(hipEventRecord(sh->aggregated[t % NPERM], sh->s_agg));
@@ -713,7 +709,6 @@ int umgap_sharded_lookup9_dev(umgap_sharded* sh, const uint64_t* d_keys45, size_
             const size_t c = t - 1, lo = std::min(n, c * per), hi = std::min(n, (c + 1) * per);
             const uint64_t pc = first + c;
             if ((rc = piece_back(sh, pc))) return rc;
-            if (c + LOOK + 1 < np && (rc = hold_for_pack(sh, pc + LOOK + 1))) return rc;
             if (hi > lo) {
                 unsigned g = (unsigned)std::min<size_t>((hi - lo + 255) / 256, 2048);
                 hipLaunchKernelGGL(k_shard_unpermute, dim3(g), dim3(256), 0, sh->s_agg, HitSource{sh->set[pc % NSETS].ret_recv, sh->perm[pc % NPERM], sh->value_bytes},
@@ -781,7 +776,6 @@ int umgap_sharded_classify9_dev(umgap_sharded* sh, int method, int strategy, flo
             const size_t c = t - 1, lo = std::min(n_reads, c * per), hi = std::min(n_reads, (c + 1) * per);
             const uint64_t pc = first + c;
             if ((rc = piece_back(sh, pc))) return rc;
-            if (c + LOOK + 1 < np && (rc = hold_for_pack(sh, pc + LOOK + 1))) return rc;
             rc = launch_classify9_from_hits(sh->tx, method, strategy, factor, lower_bound, ranked_only,
                                             HitSource{sh->set[pc % NSETS].ret_recv, sh->perm[pc % NPERM], sh->value_bytes}, hi - lo, kmers_per_read,
                                             fragments_per_read, min_seed_size, max_gap_size, d_out_taxon + lo, d_out_status + lo, sh->s_agg);
