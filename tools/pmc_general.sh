@@ -1,19 +1,16 @@
+#!/bin/bash
+# PMC counters of the fused kernels for the other strategies (k_classify9_group = first pass, k_classify9_general = the
+# one-read-per-wave pass for reads with > 64 distinct taxa) and of the headline kernel, from the `other_pipelines` legs of bench.py.
+#   tools/pmc_general.sh [tag]   -> gpurun_out/<tag>/ ; prints the means per launch; tools/pmc_general_summary.py writes profiles/<tag>.json
 set -eo pipefail
+tag=${1:-r02_pmc_general}
 export TMPDIR=/tmp
-out=gpurun_out/pmc_gen
+out=gpurun_out/$tag
 mkdir -p $out
-for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" "TCC_HIT_sum TCC_MISS_sum"; do
-    name=$(echo "$set" | tr ' ' '_' | cut -c1-30)
-    rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$out/$name" -o pmc -- python bench.py --steps 2 --warmup 1 --batches 2 --no-cpu-baseline --no-gather > "$out/$name.log" 2>&1
+i=0
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum"; do
+    i=$((i + 1))
+    rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$out/p$i" -o pmc -- python bench.py --steps 2 --warmup 1 --batches 2 --no-cpu-baseline --no-gather --no-end-to-end > "$out/p$i.log" 2>&1
+    echo "pass $i done"
 done
-python - <<'PY'
-import csv,glob,json
-c={}
-for path in glob.glob("gpurun_out/pmc_gen/**/*counter_collection.csv", recursive=True):
-    for row in csv.DictReader(open(path)):
-        n=row["Kernel_Name"]
-        if "k_classify9" in n:
-            key=("general<64" if "general<64" in n or "generalILi64" in n else "general<128" if "general" in n else "lca*")
-            c.setdefault(key,{}).setdefault(row["Counter_Name"],[]).append(float(row["Counter_Value"]))
-print(json.dumps({k:{cc:[round(x/1e6,1) for x in v] for cc,v in d.items()} for k,d in c.items()}, indent=0))
-PY
+python tools/pmc_general_summary.py "$out" "$tag"

@@ -24,7 +24,7 @@
 namespace umgap {
 namespace agg {
 
-constexpr uint32_t GCAP = 160;     // survivors (distinct filtered taxa) of one sub-batch
+constexpr uint32_t GCAP = 152;     // survivors (distinct filtered taxa) of one sub-batch
 constexpr uint32_t GREADS = 64;    // reads of one sub-batch (one lane per read in P4)
 constexpr uint32_t ST_PENDING = 0x100u, ST_DEFER = 0x101u;   // internal per-read states (not UMGAP_READ_* values)
 
@@ -34,6 +34,7 @@ struct GroupScratch {
     float cnt[GCAP];
     uint32_t dep[GCAP], adj[GCAP], lca[GCAP];
     uint32_t roff[GREADS + 1], rans[GREADS], rstat[GREADS];
+    uint8_t rid[GCAP];                 // read (within the sub-batch) of every survivor
 };
 
 // Aggregates reads [0, nr) of a group whose taxa sit in the wave's strip (read k at wtaxa[k*stride .. +stride), stride <= 128,
@@ -73,8 +74,8 @@ __device__ __forceinline__ void general_group(const TaxView& V, GroupScratch& G,
                 break;                           // the read opens the next sub-batch (its taxa are untouched)
             }
             wave_sync();                         // every lane holds its taxa in registers before the strip is overwritten
-            if (keep0) { const uint32_t i = w + (uint32_t)__builtin_popcountll(b0 & lanemask_lt(lane)); wtaxa[base + i] = t0; G.cnt[i] = c0; }
-            if (keep1) { const uint32_t i = w + n0 + (uint32_t)__builtin_popcountll(b1 & lanemask_lt(lane)); wtaxa[base + i] = t1; G.cnt[i] = c1; }
+            if (keep0) { const uint32_t i = w + (uint32_t)__builtin_popcountll(b0 & lanemask_lt(lane)); wtaxa[base + i] = t0; G.cnt[i] = c0; G.rid[i] = (uint8_t)(k - k0); }
+            if (keep1) { const uint32_t i = w + n0 + (uint32_t)__builtin_popcountll(b1 & lanemask_lt(lane)); wtaxa[base + i] = t1; G.cnt[i] = c1; G.rid[i] = (uint8_t)(k - k0); }
             w += ns;
             if (lane == 0) { G.rstat[k - k0] = ST_PENDING; G.roff[k - k0 + 1] = w; }
             wave_sync();
@@ -104,46 +105,70 @@ __device__ __forceinline__ void general_group(const TaxView& V, GroupScratch& G,
             any_err = any_err || __any(errkey != NOERR);
         }
         wave_sync();
-        // ---- P3a: per read -- errors, empties, sort by preorder index; MRTL is finished here (LDS only) ---------------------
-        for (uint32_t r = 0; r < nb; r++) {
-            if (G.rstat[r] != ST_PENDING) continue;                       // wave-uniform
-            const uint32_t o0 = G.roff[r], D = G.roff[r + 1] - o0;       // D <= 64: one lane per element
-            if (any_err) {
-                const uint64_t ek = wave_min64(lane < D ? (((uint64_t)G.adj[o0 + lane] << 32) | G.dep[o0 + lane]) : NOERR);
-                if (ek != NOERR) {
-                    if (lane == 0) { G.rstat[r] = ((ek >> 32) & 1) ? UMGAP_READ_PANIC : UMGAP_READ_UNKNOWN_TAXON; G.rans[r] = (uint32_t)ek; }
-                    continue;
+        // ---- P3a: errors, empties, sort by preorder index, MRTL -- LDS only, and FLAT: one lane per read for the per-read
+        // decisions, one lane per survivor of the whole sub-batch (up to GCAP = 3 per lane) for the sort and the MRTL scores,
+        // instead of twelve passes of a mostly idle wave (a read has ~15-25 survivors) ------------------------------------------
+        if (lane < nb && G.rstat[lane] == ST_PENDING) {
+            const uint32_t o0 = G.roff[lane], o1 = G.roff[lane + 1];
+            uint64_t ek = NOERR;
+            if (any_err)
+                for (uint32_t e = o0; e < o1; e++) { const uint64_t k2 = ((uint64_t)G.adj[e] << 32) | G.dep[e]; ek = k2 < ek ? k2 : ek; }
+            if (ek != NOERR) { G.rstat[lane] = ((ek >> 32) & 1) ? UMGAP_READ_PANIC : UMGAP_READ_UNKNOWN_TAXON; G.rans[lane] = (uint32_t)ek; }
+            else if (o1 == o0) { G.rstat[lane] = UMGAP_READ_EMPTY; G.rans[lane] = 1; }   // literal "1" (src/commands/taxa2agg.rs:174-175)
+        }
+        wave_sync();
+        {
+            // sort every read's survivors by preorder index (distinct taxa => distinct keys): rank by counting inside the read,
+            // all elements first read into registers, then scattered back in place
+            constexpr uint32_t EPL = (GCAP + 63) / 64;
+            uint32_t sp[EPL], sl[EPL], sdst[EPL];
+            float sc[EPL];
+#pragma unroll
+            for (uint32_t u = 0; u < EPL; u++) {
+                const uint32_t e = u * 64 + lane;
+                sdst[u] = NONE;
+                sp[u] = sl[u] = 0u;
+                sc[u] = 0.0f;
+                if (e < w) {
+                    const uint32_t r = G.rid[e], o0 = G.roff[r], o1 = G.roff[r + 1];
+                    sp[u] = wtaxa[base + e];
+                    sl[u] = G.last[e];
+                    sc[u] = G.cnt[e];
+                    uint32_t rank = 0;
+                    for (uint32_t f = o0; f < o1; f++) rank += wtaxa[base + f] < sp[u];
+                    sdst[u] = o0 + rank;
                 }
             }
-            if (D == 0) {
-                if (lane == 0) { G.rstat[r] = UMGAP_READ_EMPTY; G.rans[r] = 1; }   // literal "1" (src/commands/taxa2agg.rs:174-175)
-                continue;
-            }
-            // sort (distinct taxa => distinct keys): rank by counting, scattered back in place
-            const uint32_t p = lane < D ? wtaxa[base + o0 + lane] : 0u;
-            const uint32_t l = lane < D ? G.last[o0 + lane] : 0u;
-            const float c = lane < D ? G.cnt[o0 + lane] : 0.0f;
-            uint32_t rank = 0;
-            for (uint32_t f = 0; f < D; f++) rank += wtaxa[base + o0 + f] < p;
             wave_sync();
-            if (lane < D) {
-                wtaxa[base + o0 + rank] = p;
-                G.last[o0 + rank] = l;
-                G.cnt[o0 + rank] = c;
-                G.adj[o0 + rank] = NONE;          // "no next element in this read" until P3b fills the inner ones
-            }
+#pragma unroll
+            for (uint32_t u = 0; u < EPL; u++)
+                if (sdst[u] != NONE) {
+                    wtaxa[base + sdst[u]] = sp[u];
+                    G.last[sdst[u]] = sl[u];
+                    G.cnt[sdst[u]] = sc[u];
+                    G.adj[sdst[u]] = NONE;        // "no next element in this read" until P3b fills the inner ones
+                }                                 // (rid needs no move: an element stays inside its read)
             wave_sync();
-            if (strategy == UMGAP_STRATEGY_MRTL) {
-                float score = -__builtin_inff();
-                if (lane < D) {
-                    score = G.cnt[o0 + lane];
-                    const uint32_t pi = wtaxa[base + o0 + lane];
-                    for (uint32_t j = lane; j-- > 0;)
-                        if (G.last[o0 + j] >= pi) score = __fadd_rn(score, G.cnt[o0 + j]);   // ancestor, nearest first (src/rmq/rtl.rs:42-49)
+        }
+        if (strategy == UMGAP_STRATEGY_MRTL) {
+            // score(x) = count(x) + the counts of its ancestors among the read's survivors, nearest first (src/rmq/rtl.rs:42-49)
+            for (uint32_t eb = 0; eb < w; eb += 64) {
+                const uint32_t e = eb + lane;
+                if (e < w) {
+                    const uint32_t o0 = G.roff[G.rid[e]], pi = wtaxa[base + e];
+                    float score = G.cnt[e];
+                    for (uint32_t j = e; j-- > o0;)
+                        if (G.last[j] >= pi) score = __fadd_rn(score, G.cnt[j]);
+                    G.dep[e] = __float_as_uint(score);
                 }
-                const float m = wave_maxf(score);
-                const uint32_t bi = wave_min(lane < D && score == m ? lane : NONE);
-                if (lane == 0) G.rans[r] = wtaxa[base + o0 + bi];
+            }
+            wave_sync();
+            if (lane < nb && G.rstat[lane] == ST_PENDING) {   // argmax, the first of several maxima (= smallest preorder index)
+                const uint32_t o0 = G.roff[lane], o1 = G.roff[lane + 1];
+                float best = -__builtin_inff();
+                uint32_t be = o0;
+                for (uint32_t e = o0; e < o1; e++) { const float sc2 = __uint_as_float(G.dep[e]); if (sc2 > best) { best = sc2; be = e; } }
+                G.rans[lane] = wtaxa[base + be];
             }
         }
         wave_sync();
