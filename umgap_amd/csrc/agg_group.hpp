@@ -314,25 +314,56 @@ struct LcaScratch {
     uint32_t last[GCAP], ehi[GCAP];   // subtree end of a survivor -- or, for a taxon that did not resolve (pre = NONE), its error key (low, high)
     uint32_t roff[GREADS + 1], rM[GREADS], rhp[GREADS], rstat[GREADS], rans[GREADS];
 };
+// the same as pointers with run-time limits, so that a kernel can lay the arrays over LDS it has to spare (k_classify_prot9
+// re-uses the staging area of the reads' bytes, which is dead once the windows are probed)
+struct LcaView {
+    uint32_t *hkeys, *hcnt;           // 256 each, all zero between reads
+    uint32_t *last, *ehi;             // cap each
+    uint32_t *roff, *rM, *rhp, *rstat, *rans;   // reads + 1, reads, reads, reads, reads
+    uint32_t cap, reads;              // reads <= 64
+};
+__device__ __forceinline__ LcaView view_of(LcaScratch& S) {
+    return LcaView{S.hkeys, S.hcnt, S.last, S.ehi, S.roff, S.rM, S.rhp, S.rstat, S.rans, GCAP, GREADS};
+}
+// words of LDS a view over `cap` survivors and `reads` reads needs besides the two hash arrays
+__host__ __device__ constexpr uint32_t lca_view_words(uint32_t cap, uint32_t reads) { return 2 * cap + 5 * reads + 1; }
+__device__ __forceinline__ LcaView lca_view_over(uint32_t* hkeys, uint32_t* hcnt, uint32_t* mem, uint32_t cap, uint32_t reads) {
+    return LcaView{hkeys, hcnt, mem, mem + cap, mem + 2 * cap, mem + 2 * cap + reads + 1, mem + 2 * cap + 2 * reads + 1,
+                   mem + 2 * cap + 3 * reads + 1, mem + 2 * cap + 4 * reads + 1, cap, reads};
+}
 
 // one_read(k, res_taxon, res_status): the per-read path (lca_star[_bound]_from_lds) for a read with more than 64 surviving
 // taxa; its part of the strip is still untouched when it is called.
-template <bool BOUND, class OneRead>
-__device__ __forceinline__ void lca_group(const TaxView& V, LcaScratch& G, bool tree_like, float lower_bound, uint32_t* wtaxa, uint32_t stride,
-                                          uint32_t nr, uint32_t lane, uint64_t se_panic, uint32_t frags, size_t first_read,
-                                          uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status, OneRead one_read) {
+// span(k, start, n): read k of the group owns wtaxa[start .. start + n), n <= 128; the reads lie one after another (start is
+// non-decreasing in k and a read does not overlap the next), which is what lets the survivors be compacted in place.
+// span returns false for a read the kernel cannot take (surface B: too many windows): it gets `skip_status` and no answer.
+template <bool BOUND, class Span, class OneRead>
+__device__ __forceinline__ void lca_group_spans(const TaxView& V, const LcaView& G, bool tree_like, float lower_bound, uint32_t* wtaxa, Span span,
+                                                uint32_t nr, uint32_t lane, uint64_t se_panic, uint32_t frags, size_t first_read,
+                                                uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status, OneRead one_read,
+                                                uint32_t skip_status = UMGAP_READ_UNSUPPORTED) {
     auto se_panicked = [&](uint32_t k) -> bool {
         return se_panic && ((se_panic >> (k * frags)) & ((frags >= 64 ? 0ull : (1ull << frags)) - 1ull));
     };
     uint32_t k0 = 0;
     while (k0 < nr) {
         // ---- count + filter per read (LDS only); survivors compacted in place over the strip from `base` on ----
-        const uint32_t base = k0 * stride;
+        uint32_t base = 0, n_first = 0;
+        const bool first_ok = span(k0, base, n_first);
         uint32_t w = 0, k = k0;
         bool big = false;                       // the sub-batch ends in front of a read that takes the per-read path
         if (lane == 0) G.roff[0] = 0;
-        while (k < nr && k - k0 < GREADS) {
-            const uint32_t* rt = wtaxa + k * stride;
+        while (k < nr && k - k0 < G.reads) {
+            uint32_t start = 0, stride = 0;
+            const bool ok = k == k0 ? first_ok : span(k, start, stride);
+            if (k == k0) { start = base; stride = n_first; }
+            if (!ok) {                          // not representable: no survivors, marked below (wave-uniform)
+                if (lane == 0) { G.roff[k - k0 + 1] = w; G.rM[k - k0] = NONE; }
+                k++;
+                continue;
+            }
+            if (lane == 0) G.rM[k - k0] = 0;
+            const uint32_t* rt = wtaxa + start;
             const uint32_t t0 = lane < stride ? rt[lane] : 0u, t1 = 64 + lane < stride ? rt[64 + lane] : 0u;
             bool keep0, keep1;
             float c0, c1;
@@ -340,7 +371,7 @@ __device__ __forceinline__ void lca_group(const TaxView& V, LcaScratch& G, bool 
             const uint64_t b0 = __ballot(keep0), b1 = __ballot(keep1);
             const uint32_t n0 = (uint32_t)__builtin_popcountll(b0), ns = n0 + (uint32_t)__builtin_popcountll(b1);
             if (ns > 64) { big = true; break; }
-            if (w + ns > GCAP) break;
+            if (w + ns > G.cap) break;
             wave_sync();                         // every lane holds its taxa in registers before the strip is overwritten
             if (keep0) wtaxa[base + w + (uint32_t)__builtin_popcountll(b0 & lanemask_lt(lane))] = t0;
             if (keep1) wtaxa[base + w + n0 + (uint32_t)__builtin_popcountll(b1 & lanemask_lt(lane))] = t1;
@@ -371,7 +402,8 @@ __device__ __forceinline__ void lca_group(const TaxView& V, LcaScratch& G, bool 
         for (uint32_t r = 0; r < nb; r++) {
             const uint32_t o0 = G.roff[r], D = G.roff[r + 1] - o0;        // D <= 64: one lane per survivor
             uint32_t st = ST_PENDING, M = 0, hp = NONE, ans = 0;
-            if (D == 0) { st = UMGAP_READ_EMPTY; ans = 1; }              // literal "1" (src/commands/taxa2agg.rs:174-175)
+            if (G.rM[r] == NONE) { st = skip_status; ans = 0; }          // a read span() refused
+            else if (D == 0) { st = UMGAP_READ_EMPTY; ans = 1; }         // literal "1" (src/commands/taxa2agg.rs:174-175)
             else if (BOUND) {
                 const uint32_t v = lane < D ? wtaxa[base + o0 + lane] : 0u;
                 const uint32_t p = lane < D ? bound::pre_of(v) : 0u;
@@ -425,6 +457,15 @@ __device__ __forceinline__ void lca_group(const TaxView& V, LcaScratch& G, bool 
             k0++;
         }
     }
+}
+
+// the fixed-stride form (packed k-mers: read k owns wtaxa[k * stride .. + stride))
+template <bool BOUND, class OneRead>
+__device__ __forceinline__ void lca_group(const TaxView& V, LcaScratch& G, bool tree_like, float lower_bound, uint32_t* wtaxa, uint32_t stride,
+                                          uint32_t nr, uint32_t lane, uint64_t se_panic, uint32_t frags, size_t first_read,
+                                          uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status, OneRead one_read) {
+    lca_group_spans<BOUND>(V, view_of(G), tree_like, lower_bound, wtaxa, [stride](uint32_t k, uint32_t& start, uint32_t& n) { start = k * stride; n = stride; return true; },
+                           nr, lane, se_panic, frags, first_read, out_taxon, out_status, one_read);
 }
 
 }  // namespace agg

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256, 4) void k_classify_prot9(TableView T, TaxView 
                                                         uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status) {
     __shared__ uint32_t lds_taxa[4][STRIP], lds_keys[4][256], lds_cnt[4][256];
     __shared__ uint32_t lds_fstart[4][64], lds_fwin[4][64], lds_fbyte[4][64], lds_total[4][PROT_GROUP];
-    __shared__ uint8_t lds_bytes[4][PROT_GROUP * PROT_MAX_BYTES];
+    __shared__ __attribute__((aligned(16))) uint8_t lds_bytes[4][PROT_GROUP * PROT_MAX_BYTES];   // also the LCA scratch of the aggregate stage (u32 arrays)
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
     uint32_t* wtaxa = lds_taxa[wv];
     uint32_t* wkeys = lds_keys[wv];
@@ -496,20 +496,22 @@ __global__ __launch_bounds__(256, 4) void k_classify_prot9(TableView T, TaxView 
             se_panic = __ballot(pk);
             wave_lds_sync();
         }
-        // ---- aggregate ----
-        for (uint32_t k = 0; k < nr; k++) {
-            const uint32_t total = lds_total[wv][k];
-            uint32_t res_taxon = 0, res_status = 4u;   // UMGAP_READ_UNSUPPORTED: use lookup_prot9 + aggregate for such reads
-            if (total != 0xFFFFFFFFu) {
-                if (BOUND) lca_star_bound_from_lds(V, wtaxa + wfstart[k * F], total, lower_bound, wkeys, wcnt, lane, res_taxon, res_status);
-                else lca_star_from_lds(V, tree_like, wtaxa + wfstart[k * F], total, lower_bound, wkeys, wcnt, lane, res_taxon, res_status);
-            }
-            if (se_panic && ((se_panic >> (k * F)) & ((1ull << F) - 1ull))) { res_taxon = 0; res_status = UMGAP_READ_PANIC; }
-            if (lane == 0) {
-                out_taxon[r0 + k] = res_taxon;
-                out_status[r0 + k] = res_status;
-            }
-        }
+        // ---- aggregate: the group's reads together (agg_group.hpp); its scratch lies over the byte staging area, which is dead now ----
+        static_assert(lca_view_words(PROT_GROUP * PROT_MAX_WINDOWS / 8, PROT_GROUP) * 4 <= PROT_GROUP * PROT_MAX_BYTES, "the LCA scratch must fit the staging area");
+        const LcaView LV = lca_view_over(wkeys, wcnt, reinterpret_cast<uint32_t*>(wbytes), PROT_GROUP * PROT_MAX_WINDOWS / 8, PROT_GROUP);
+        lca_group_spans<BOUND>(V, LV, tree_like, lower_bound, wtaxa,
+                               [&](uint32_t k, uint32_t& start, uint32_t& n) {
+                                   const uint32_t total = lds_total[wv][k];
+                                   start = wfstart[k * F];
+                                   n = total == 0xFFFFFFFFu ? 0u : total;
+                                   return total != 0xFFFFFFFFu;     // false: more than 128 windows or 384 bytes (use lookup_prot9 + aggregate for such reads)
+                               },
+                               nr, lane, se_panic, F, r0, out_taxon, out_status,
+                               [&](uint32_t k, uint32_t& res_taxon, uint32_t& res_status) {
+                                   if (BOUND) lca_star_bound_from_lds(V, wtaxa + wfstart[k * F], lds_total[wv][k], lower_bound, wkeys, wcnt, lane, res_taxon, res_status);
+                                   else lca_star_from_lds(V, tree_like, wtaxa + wfstart[k * F], lds_total[wv][k], lower_bound, wkeys, wcnt, lane, res_taxon, res_status);
+                               },
+                               4u);
         wave_lds_sync();
     }
 }
