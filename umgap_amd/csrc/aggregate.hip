@@ -26,6 +26,8 @@ namespace umgap {
 int launch_general(const TaxView& V, int method, int strategy, float factor, float lower_bound, const uint32_t* d_taxa,
                    const float* d_scores, const uint64_t* d_offsets, uint32_t stride, size_t n_reads, uint32_t* d_out_taxon,
                    uint32_t* d_out_status, uint32_t* d_defer, uint32_t* d_big, hipStream_t stream);
+int launch_strided_group(const TaxView& V, int method, int strategy, float factor, float lower_bound, const uint32_t* d_taxa, uint32_t stride,
+                         size_t n_reads, uint32_t* d_out_taxon, uint32_t* d_out_status, uint32_t* d_list, uint32_t* d_count, hipStream_t stream);
 }
 
 namespace {
@@ -202,6 +204,8 @@ int launch(umgap_taxonomy* tx, int method, int strategy, float factor, float low
     if (!n_reads) return UMGAP_OK;
     TaxView V = view_of(tx, ranked_only);
     dim3 grid(agg_grid(n_reads)), block(256);
+    if (strategy == UMGAP_STRATEGY_LCA_STAR && !d_scores && !d_offsets && stride >= 1 && stride <= 128)
+        return launch_strided_group(V, method, strategy, factor, lower_bound, d_taxa, stride, n_reads, d_out_taxon, d_out_status, nullptr, nullptr, stream);
     if (strategy == UMGAP_STRATEGY_LCA_STAR) {
         if (d_scores) hipLaunchKernelGGL(k_agg_lca<true>, grid, block, 0, stream, V, method, d_taxa, d_scores, d_offsets, stride, n_reads, lower_bound, d_out_taxon, d_out_status);
         else hipLaunchKernelGGL(k_agg_lca<false>, grid, block, 0, stream, V, method, d_taxa, d_scores, d_offsets, stride, n_reads, lower_bound, d_out_taxon, d_out_status);

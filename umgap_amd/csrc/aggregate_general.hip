@@ -107,6 +107,9 @@ __global__ __launch_bounds__(64) void k_agg_general_big(TaxView V, int method, i
 
 namespace umgap {
 
+int launch_strided_group(const TaxView& V, int method, int strategy, float factor, float lower_bound, const uint32_t* d_taxa, uint32_t stride,
+                         size_t n_reads, uint32_t* d_out_taxon, uint32_t* d_out_status, uint32_t* d_list, uint32_t* d_count, hipStream_t stream);
+
 // Launches the general aggregation: the compact-scratch pass over all reads, the large-scratch pass over whatever it
 // deferred (> 64 distinct taxa), and the global-memory pass over what that one deferred (> 1024).  `d_defer` must hold
 // 2 * (n_reads + 1) u32; d_big = BIG_SLOTS read scratches of ScratchGlobal::words(BIG_CAP, BIG_HCAP) words, hash parts zero.
@@ -123,7 +126,15 @@ int launch_general(const TaxView& V, int method, int strategy, float factor, flo
     if (g > 256 * 8) g = 256 * 8;
     if (g < 1) g = 1;
     dim3 grid((unsigned)g), block(256), big_grid(256), big_block(64);
-    if (d_scores) {
+    const bool grouped = !d_scores && !d_offsets && stride >= 1 && stride <= 128;   // aggregate_group.hip takes the first pass
+    if (grouped) {
+        int rc = launch_strided_group(V, method, strategy, factor, lower_bound, d_taxa, stride, n_reads, d_out_taxon, d_out_status, d_list, d_count, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL((k_agg_general<false, 1024, 4096, 1>), big_grid, big_block, 0, stream, V, method, strategy, factor, d_taxa, d_scores, d_offsets,
+                           stride, n_reads, lower_bound, d_out_taxon, d_out_status, (const uint32_t*)d_list, (const uint32_t*)d_count, d_list2, d_count2);
+        hipLaunchKernelGGL(k_agg_general_big<false>, dim3(BIG_SLOTS), dim3(64), 0, stream, V, method, strategy, factor, d_taxa, d_scores, d_offsets, stride,
+                           lower_bound, d_out_taxon, d_out_status, (const uint32_t*)d_list2, (const uint32_t*)d_count2, d_big, BIG_CAP, BIG_HCAP);
+    } else if (d_scores) {
         hipLaunchKernelGGL((k_agg_general<true, 64, 512, 4>), grid, block, 0, stream, V, method, strategy, factor, d_taxa, d_scores, d_offsets, stride,
                            n_reads, lower_bound, d_out_taxon, d_out_status, (const uint32_t*)nullptr, (const uint32_t*)nullptr, d_list, d_count);
         hipLaunchKernelGGL((k_agg_general<true, 1024, 4096, 1>), big_grid, big_block, 0, stream, V, method, strategy, factor, d_taxa, d_scores, d_offsets,

@@ -69,70 +69,7 @@ __device__ __forceinline__ bool seedextend_lds(uint32_t* t, uint32_t n, uint32_t
     return panicked;
 }
 
-// LCA* of one read whose taxa sit in LDS at rt[0..n) (n <= 128), shared by both fused kernels.
-__device__ __forceinline__ void lca_star_from_lds(const TaxView& V, bool tree_like, const uint32_t* rt, uint32_t n, float lower_bound,
-                                                  uint32_t* wkeys, uint32_t* wcnt, uint32_t lane, uint32_t& res_taxon, uint32_t& res_status) {
-    uint32_t t0 = lane < n ? rt[lane] : 0u, t1 = 64 + lane < n ? rt[64 + lane] : 0u;
-    bool keep0, keep1;
-    float c0, c1;
-    lds_count(wkeys, wcnt, t0, t1, lower_bound, keep0, keep1, c0, c1);
-    uint64_t errkey = NOERR;
-    Hit h0{NONE, NONE}, h1{NONE, NONE};
-    if (keep0) h0 = resolve(V, tree_like, t0, errkey);
-    if (keep1) h1 = resolve(V, tree_like, t1, errkey);
-    bool any = false;
-    uint32_t maxpre = 0;
-    if (h0.pre != NONE) { any = true; maxpre = h0.pre; }
-    if (h1.pre != NONE) { any = true; maxpre = max(maxpre, h1.pre); }
-    if (__any(errkey != NOERR)) {
-        uint64_t ek = wave_min64(errkey);
-        res_status = ((ek >> 32) & 1) ? UMGAP_READ_PANIC : UMGAP_READ_UNKNOWN_TAXON;
-        res_taxon = (uint32_t)ek;
-    } else if (!__any(any)) {
-        res_status = UMGAP_READ_EMPTY;   // literal "1" (src/commands/taxa2agg.rs:174-175)
-        res_taxon = 1;
-    } else {
-        const uint32_t M = wave_max(any ? maxpre : 0u);
-        uint32_t hp = NONE;
-        if (h0.pre != NONE && h0.last < M) hp = h0.pre;
-        if (h1.pre != NONE && h1.last < M) hp = min(hp, h1.pre);
-        hp = wave_min(hp);
-        if (hp != NONE) res_taxon = V.psnap_of_pre[wave_argmin_depth(V, hp + 1, M, lane)];
-        else res_taxon = V.snap_of_pre[M];
-        res_status = res_taxon == NONE ? UMGAP_READ_PANIC : UMGAP_READ_OK;
-    }
-}
-
-// The same for a table BOUND to the taxonomy (bound.hpp): the strip holds {pre + 1, size code} instead of taxon ids, so
-// no by-id gather is needed; only a survivor whose subtree end falls inside the code's rounding gap fetches it.
-__device__ __forceinline__ void lca_star_bound_from_lds(const TaxView& V, const uint32_t* rt, uint32_t n, float lower_bound,
-                                                        uint32_t* wkeys, uint32_t* wcnt, uint32_t lane, uint32_t& res_taxon, uint32_t& res_status) {
-    uint32_t t0 = lane < n ? rt[lane] : 0u, t1 = 64 + lane < n ? rt[64 + lane] : 0u;
-    bool keep0, keep1;
-    float c0, c1;
-    lds_count(wkeys, wcnt, t0, t1, lower_bound, keep0, keep1, c0, c1);
-    if (!__any(keep0 || keep1)) {
-        res_status = UMGAP_READ_EMPTY;   // literal "1" (src/commands/taxa2agg.rs:174-175)
-        res_taxon = 1;
-        return;
-    }
-    const uint32_t p0 = keep0 ? bound::pre_of(t0) : 0u, p1 = keep1 ? bound::pre_of(t1) : 0u;
-    const uint32_t M = wave_max(max(p0, p1));
-    auto not_ancestor_of_M = [&](uint32_t v, uint32_t p) -> bool {   // last[x] < pre[M] ?
-        uint32_t lo, hi;
-        bound::size_bounds(v, lo, hi);
-        if (M > p + hi) return true;
-        if (M <= p + lo) return false;
-        return V.last_of_pre[p] < M;                                  // inside the rounding gap: the exact subtree end
-    };
-    uint32_t hp = NONE;
-    if (keep0 && not_ancestor_of_M(t0, p0)) hp = p0;
-    if (keep1 && not_ancestor_of_M(t1, p1)) hp = min(hp, p1);
-    hp = wave_min(hp);
-    if (hp != NONE) res_taxon = V.psnap_of_pre[wave_argmin_depth(V, hp + 1, M, lane)];
-    else res_taxon = V.snap_of_pre[M];
-    res_status = res_taxon == NONE ? UMGAP_READ_PANIC : UMGAP_READ_OK;
-}
+// (lca_star_from_lds / lca_star_bound_from_lds, the per-read LCA* over a strip in LDS, live in agg_group.hpp)
 
 __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
