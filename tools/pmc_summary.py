@@ -22,7 +22,7 @@ for path in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recurs
     with open(path, newline="") as f:
         for row in csv.DictReader(f):
             name = row["Kernel_Name"]
-            for k in ("k_classify9", "k_classify9_general", "k_classify_prot9", "k_lookup9", "k_agg_lca"):
+            for k in ("k_classify9", "k_classify9_group", "k_classify9_general", "k_classify_prot9", "k_lookup9", "k_agg_lca"):
                 if k + "(" in name or k + "<" in name:
                     counters.setdefault(k, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
 summary = {k: {c: sum(v) / len(v) for c, v in sorted(cs.items())} for k, cs in counters.items()}

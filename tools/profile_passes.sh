@@ -10,13 +10,13 @@ tag=${1:-r01}
 out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline > "$out/stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-end-to-end > "$out/stats.log" 2>&1
 echo "stats pass done"
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" \
            "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE" \
            "SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT"; do
     name=$(echo "$set" | tr ' ' '_' | cut -c1-30)
-    rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$out/$name" -o pmc -- python bench.py --steps 2 --warmup 1 --batches 2 --no-cpu-baseline --no-gather > "$out/$name.log" 2>&1
+    rocprofv3 --pmc $set --kernel-trace --output-format csv -d "$out/$name" -o pmc -- python bench.py --steps 2 --warmup 1 --batches 2 --no-cpu-baseline --no-gather --no-extras > "$out/$name.log" 2>&1
     echo "pmc pass $name done"
 done
 python tools/pmc_summary.py "$out" "$tag"
