@@ -10,7 +10,7 @@ tag=${1:-r01}
 out=gpurun_out/$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o stats -- python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-end-to-end > "$out/stats.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/stats" -o stats -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > "$out/stats.log" 2>&1
 echo "stats pass done"
 for set in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" \
            "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY GRBM_GUI_ACTIVE" \
