@@ -995,14 +995,17 @@ def _run_ranks(world, fn):
             raise e
 
 
-@pytest.mark.parametrize("world,pieces", [(1, 1), (2, 3), (3, 8), (8, 4)])
-def test_sharded_table_local_ranks_match_whole_table(api, torch_cuda, world, pieces):
+@pytest.mark.parametrize("world,pieces,own_share", [(1, 1, "probed in place"), (2, 3, "probed in place"), (3, 8, "packed"), (8, 4, "probed in place"), (2, 2, "packed")])
+def test_sharded_table_local_ranks_match_whole_table(api, torch_cuda, world, pieces, own_share, monkeypatch):
     """The N-rank sharded path of the C ABI (pack 6-byte keys -> exchange -> probe on the owner -> 3-byte values back ->
     gather + [seedextend] + aggregate), all ranks on this one GPU through the local communicator: every rank's answers are
     bit-identical to the whole-table kernels, for the plain get() and for the fused pipeline with every strategy."""
     torch = torch_cuda
     from umgap_amd.dist import Comm, Sharded
     from umgap_amd.synth import ADD_B, MUL_A, SyntheticWorkload
+    # a rank's own keys are normally probed by the kernel that consumes the hits; UMGAP_SHARD_NO_LOCAL=1 (read when the group is
+    # created) sends them through pack / probe / gather like everybody else's
+    monkeypatch.setenv("UMGAP_SHARD_NO_LOCAL", "1" if own_share == "packed" else "0")
     n_tax, n_keys, stride = 20_000, 1_500_000, 84
     w = SyntheticWorkload(n_tax=n_tax, n_keys=n_keys)
     n_reads = [4001 + 173 * r for r in range(world)]                       # ragged: every rank owns a different number of reads

@@ -111,17 +111,46 @@ __device__ __forceinline__ void probe_group_to_strip(const TableView& T, const u
 
 // Sharded mode (shard.hip): the hits of a group were looked up by the shards that own the keys and came back over the
 // exchange; key i of the batch sits at slot perm[i] of the returned buffer (NOSLOT: the key was not representable or its
-// send region overflowed => miss), 3 or 4 bytes per slot (shard_wire.hpp), all-ones = miss.
-__device__ __forceinline__ void gather_group_to_strip(const HitSource& H, size_t first_key, uint32_t nk, uint32_t* wtaxa, uint32_t lane) {
+// send region overflowed => miss), 3 or 4 bytes per slot (shard_wire.hpp), all-ones = miss.  Keys this rank owns itself
+// (perm = LOCAL) never went anywhere: they are probed here, against the rank's shard.
+__device__ __forceinline__ void gather_group_to_strip(const TableView& T, const HitSource& H, size_t first_key, uint32_t nk, uint32_t* wtaxa, uint32_t lane) {
     const uint32_t* pp = H.perm + first_key;
+    const uint32_t q = lane >> 2, j = lane & 3;
     for (uint32_t i0 = 0; i0 < nk; i0 += 256) {     // four independent perm loads, then four independent gathers, per lane
         uint32_t slot[4], val[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) { const uint32_t i = i0 + 64 * u + lane; slot[u] = i < nk ? __builtin_nontemporal_load(pp + i) : wire::NOSLOT; }
 #pragma unroll
-        for (int u = 0; u < 4; u++) val[u] = slot[u] == wire::NOSLOT ? 0u : wire::load_value(H.ret, slot[u], H.value_bytes);
+        for (int u = 0; u < 4; u++) val[u] = slot[u] >= wire::LOCAL ? 0u : wire::load_value(H.ret, slot[u], H.value_bytes);
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const uint32_t i = i0 + 64 * u + lane; if (i < nk) wtaxa[i] = val[u]; }
+        for (int u = 0; u < 4; u++) { const uint32_t i = i0 + 64 * u + lane; if (i < nk && slot[u] != wire::LOCAL) wtaxa[i] = val[u]; }
+        // the rank's own keys: probed here, two chunks of 64 in flight (keys that travelled take no part: no request is issued for them)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const bool l0 = slot[2 * h] == wire::LOCAL, l1 = slot[2 * h + 1] == wire::LOCAL;
+            const uint64_t m0 = __ballot(l0), m1 = __ballot(l1);
+            if (!(m0 | m1)) continue;               // wave-uniform
+            ProbeBatch B[2];
+            uint32_t res[2][4];
+            {
+                uint32_t local = 0, tag = 0, valid = 0;
+                if (l0) valid = locate(T, __builtin_nontemporal_load(H.keys + first_key + i0 + 128 * h + lane), local, tag) ? 1u : 0u;
+                probe_issue(T, local, tag | (valid << 31), lane, B[0]);
+            }
+            {
+                uint32_t local = 0, tag = 0, valid = 0;
+                if (l1) valid = locate(T, __builtin_nontemporal_load(H.keys + first_key + i0 + 128 * h + 64 + lane), local, tag) ? 1u : 0u;
+                probe_issue(T, local, tag | (valid << 31), lane, B[1]);
+            }
+            probe_eval_multi<2>(T, B, 0u, lane, res);
+            if (j == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    if ((m0 >> (16 * r + q)) & 1ull) wtaxa[i0 + 128 * h + 16 * r + q] = res[0][r];
+                    if ((m1 >> (16 * r + q)) & 1ull) wtaxa[i0 + 128 * h + 64 + 16 * r + q] = res[1][r];
+                }
+            }
+        }
     }
 }
 
@@ -153,7 +182,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const size_t r0 = g * G;
         const uint32_t nr = (uint32_t)min((size_t)G, n_reads - r0);
         const uint32_t nk = nr * stride;                   // keys of this group (<= STRIP)
-        if (GATHER) gather_group_to_strip(H, r0 * stride, nk, wtaxa, lane);
+        if (GATHER) gather_group_to_strip(T, H, r0 * stride, nk, wtaxa, lane);
         else probe_group_to_strip(T, keys + r0 * stride, nk, wtaxa, lane);
         wave_lds_sync();
         // ---- seedextend per fragment (one lane per fragment, nr * frags <= 64) ----
@@ -203,7 +232,7 @@ __global__ __launch_bounds__(256) void k_classify9_general(TableView T, TaxView 
         const size_t r0 = todo ? (size_t)todo[g] : g * G;
         const uint32_t nr = todo ? 1u : (uint32_t)min((size_t)G, n_reads - r0);
         const uint32_t nk = nr * stride;
-        if (GATHER) gather_group_to_strip(H, r0 * stride, nk, wtaxa, lane);
+        if (GATHER) gather_group_to_strip(T, H, r0 * stride, nk, wtaxa, lane);
         else probe_group_to_strip(T, keys + r0 * stride, nk, wtaxa, lane);
         wave_lds_sync();
         uint64_t se_panic = 0;
@@ -255,7 +284,7 @@ __global__ __launch_bounds__(256) void k_classify9_group(TableView T, TaxView V,
         const size_t r0 = g * G;
         const uint32_t nr = (uint32_t)min((size_t)G, n_reads - r0);
         const uint32_t nk = nr * stride;
-        if (GATHER) gather_group_to_strip(H, r0 * stride, nk, wtaxa, lane);
+        if (GATHER) gather_group_to_strip(T, H, r0 * stride, nk, wtaxa, lane);
         else probe_group_to_strip(T, keys + r0 * stride, nk, wtaxa, lane);
         wave_lds_sync();
         uint64_t se_panic = 0;
@@ -458,7 +487,7 @@ __global__ __launch_bounds__(256, 4) void k_classify_prot9(TableView T, TaxView 
 namespace umgap {
 // seedextend + aggregate of reads whose hits came back over the exchange (shard.hip): the fused kernels with the probe stage
 // replaced by a gather through `perm`.  Same argument rules as umgap_classify9[_strategy]_dev, checked by the caller.
-int launch_classify9_from_hits(umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound, int ranked_only, const HitSource& H,
+int launch_classify9_from_hits(umgap_index* ix, umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound, int ranked_only, const HitSource& H,
                                size_t n_reads, uint32_t kmers_per_read, uint32_t fragments_per_read, uint32_t min_seed_size, uint32_t max_gap_size,
                                uint32_t* d_out_taxon, uint32_t* d_out_status, hipStream_t s) {
     if (!n_reads) return UMGAP_OK;
@@ -468,7 +497,7 @@ int launch_classify9_from_hits(umgap_taxonomy* tx, int method, int strategy, flo
     // units with the probe and the pack of the pieces behind it
     const size_t g = ((n_reads + G - 1) / G + 3) / 4;
     TaxView V = view_of(tx, ranked_only);
-    const TableView none{};
+    const TableView none = ix->view;     // the shard: the rank's own keys (perm = LOCAL) are probed by these kernels
     if (strategy == UMGAP_STRATEGY_LCA_STAR) {
         hipLaunchKernelGGL((k_classify9<false, true>), dim3((unsigned)g), dim3(256), 0, s, none, V, method, (const uint64_t*)nullptr, n_reads, kmers_per_read,
                            fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status, H);

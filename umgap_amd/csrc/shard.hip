@@ -37,7 +37,7 @@
 #include "taxonomy.hpp"
 
 namespace umgap {
-int launch_classify9_from_hits(umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound, int ranked_only, const HitSource& H,
+int launch_classify9_from_hits(umgap_index* ix, umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound, int ranked_only, const HitSource& H,
                                size_t n_reads, uint32_t kmers_per_read, uint32_t fragments_per_read, uint32_t min_seed_size, uint32_t max_gap_size,
                                uint32_t* d_out_taxon, uint32_t* d_out_status, hipStream_t s);
 }
@@ -199,7 +199,7 @@ __device__ __forceinline__ uint32_t owner_of_bucket(uint32_t b, uint32_t nb, uin
 constexpr int PACK_PER_THREAD = 16;
 __global__ __launch_bounds__(256) void k_shard_pack(const uint64_t* __restrict__ keys, size_t n, uint32_t m, uint32_t nb, uint32_t world,
                                                     uint64_t cap, uint8_t* __restrict__ send, uint32_t* __restrict__ perm,
-                                                    unsigned long long* __restrict__ cursor, uint32_t* __restrict__ overflow) {
+                                                    unsigned long long* __restrict__ cursor, uint32_t* __restrict__ overflow, uint32_t local_owner) {
     __shared__ uint32_t cnt[64];
     __shared__ unsigned long long base[64];
     const uint32_t lane = threadIdx.x & 63;
@@ -221,6 +221,7 @@ __global__ __launch_bounds__(256) void k_shard_pack(const uint64_t* __restrict__
                     h[k] = mix45(key);
                     const uint32_t a = (uint32_t)(h[k] >> R_BITS), r = (uint32_t)h[k] & R_MASK;
                     own[k] = owner_of_bucket(a * m + (uint32_t)(((uint64_t)r * m) >> R_BITS), nb, world);
+                    if (own[k] == local_owner) own[k] = 0xFFFFFFFEu;   // this rank's own key: marked, not packed (local_owner = NONE switches that off)
                 }
             }
             for (uint32_t o = 0; o < world; o++) {     // wave-aggregated LDS reservation
@@ -240,8 +241,8 @@ __global__ __launch_bounds__(256) void k_shard_pack(const uint64_t* __restrict__
         for (int k = 0; k < PACK_PER_THREAD; k++) {
             const size_t i = t0 + (size_t)k * blockDim.x + threadIdx.x;
             if (i >= n) continue;
-            uint32_t slot = wire::NOSLOT;
-            if (own[k] != 0xFFFFFFFFu) {
+            uint32_t slot = own[k] == 0xFFFFFFFEu ? wire::LOCAL : wire::NOSLOT;
+            if (own[k] < 0xFFFFFFFEu) {
                 const uint64_t pos = base[own[k]] + lpos[k];
                 if (pos < cap) {
                     uint8_t* region = send + (size_t)own[k] * cap * 6;
@@ -276,13 +277,14 @@ __global__ __launch_bounds__(256) void k_shard_pad(uint8_t* __restrict__ send, c
 // while a resident grid that leaves half of each CU's wave slots free lets pack, aggregate and RCCL's copies run next to it.
 template <int VB>
 __global__ __launch_bounds__(256) void k_shard_probe(TableView T, const uint8_t* __restrict__ recv, const uint8_t* __restrict__ own_send, uint32_t self,
-                                                     uint64_t cap, uint64_t n_slots, uint32_t* __restrict__ ret, uint32_t* __restrict__ own_ret) {
+                                                     uint32_t skip_self, uint64_t cap, uint64_t n_slots, uint32_t* __restrict__ ret, uint32_t* __restrict__ own_ret) {
     __shared__ uint32_t lds_out[4][128];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     constexpr uint32_t MISS = VB == 3 ? 0xFFFFFFu : 0xFFFFFFFFu;
     for (uint64_t s0 = wave * 128; s0 < n_slots; s0 += nwaves * 128) {
     const uint64_t region = s0 / cap, pos0 = s0 - region * cap;
+    if (skip_self && region == self) continue;     // the rank's own keys were not packed (they are probed by the consuming kernel)
     const uint8_t* rb = (region == self ? own_send : recv) + region * cap * 6;
     const uint32_t* lo = reinterpret_cast<const uint32_t*>(rb) + pos0;
     const uint16_t* hi = reinterpret_cast<const uint16_t*>(rb + cap * 4) + pos0;
@@ -330,16 +332,33 @@ __global__ __launch_bounds__(256) void k_shard_probe(TableView T, const uint8_t*
     }
 }
 
-// the plain sharded get(): out[i] = value of key i (perm order undone), or miss_value
-__global__ __launch_bounds__(256) void k_shard_unpermute(HitSource H, size_t n, uint32_t miss_value, uint32_t* __restrict__ out) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t step = (size_t)gridDim.x * blockDim.x;
+// the plain sharded get(): out[i] = value of key i (perm order undone), or miss_value.  A wave takes 64 keys: the values of
+// the keys that travelled are gathered, the rank's own keys (perm = LOCAL) are probed here (the quad probe, all lanes take part).
+__global__ __launch_bounds__(256) void k_shard_unpermute(TableView T, HitSource H, size_t n, uint32_t miss_value, uint32_t* __restrict__ out) {
+    const uint32_t lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
     const uint32_t mr = wire::miss_raw(H.value_bytes);
-    for (; i < n; i += step) {
-        const uint32_t slot = H.perm[i];
-        uint32_t v = mr;
-        if (slot != wire::NOSLOT) v = wire::load_raw(H.ret, slot, H.value_bytes);
-        out[i] = v == mr ? miss_value : v;
+    for (size_t base = wave * 64; base < n; base += nwaves * 64) {
+        const size_t i = base + lane;
+        const uint32_t slot = i < n ? H.perm[i] : wire::NOSLOT;
+        const bool is_local = slot == wire::LOCAL;
+        uint32_t local = 0, tag = 0, valid = 0;
+        if (is_local) valid = locate(T, H.keys[i], local, tag) ? 1u : 0u;
+        const uint64_t lm = __ballot(is_local);
+        if (i < n && !is_local) {
+            uint32_t v = mr;
+            if (slot != wire::NOSLOT) v = wire::load_raw(H.ret, slot, H.value_bytes);
+            out[i] = v == mr ? miss_value : v;
+        }
+        if (lm) {   // wave-uniform
+            uint32_t res[4];
+            wave_probe64_vals(T, local, tag | (valid << 31), miss_value, lane, res);
+            if (j == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    if ((lm >> (16 * r + q)) & 1ull) out[base + 16 * r + q] = res[r];
+            }
+        }
     }
 }
 
@@ -389,6 +408,7 @@ struct umgap_sharded {
     hipStream_t s_keys = nullptr, s_probe = nullptr, s_agg = nullptr;
     hipEvent_t ev_done[3] = {};
     uint64_t piece_no = 0;               // pieces issued so far (event slots are reused cyclically)
+    bool local_bypass = true;            // the rank's own keys are probed by the consuming kernel (UMGAP_SHARD_NO_LOCAL=1 sends them through pack / probe / gather like the rest)
     uint32_t* d_overflow = nullptr;
     hipEvent_t ev_in = nullptr, ev_probe0 = nullptr, ev_probe1 = nullptr;
     bool probe_timed = false;
@@ -427,7 +447,8 @@ int stage_pack(umgap_sharded* sh, uint64_t t, const uint64_t* d_keys, size_t nk)
     const size_t tile = 256 * PACK_PER_THREAD;
     unsigned g = (unsigned)((nk + tile - 1) / tile);
     if (g < 1) g = 1;
-    hipLaunchKernelGGL(k_shard_pack, dim3(g), dim3(256), 0, s, d_keys, nk, T.m, T.nb, W, sh->cap, S.send_keys, sh->perm[t % NPERM], S.cursor, sh->d_overflow);
+    hipLaunchKernelGGL(k_shard_pack, dim3(g), dim3(256), 0, s, d_keys, nk, T.m, T.nb, W, sh->cap, S.send_keys, sh->perm[t % NPERM], S.cursor, sh->d_overflow,
+                       sh->local_bypass ? (uint32_t)sh->comm->rank : UMGAP_NONE);
     hipLaunchKernelGGL(k_shard_pad, dim3(64, W), dim3(256), 0, s, S.send_keys, S.cursor, sh->cap);
     UMGAP_HIP(hipGetLastError());
     UMGAP_HIP(hipEventRecord(S.filled, s));
@@ -453,8 +474,8 @@ int stage_probe(umgap_sharded* sh, uint64_t t, bool time_probe) {
     const unsigned gp = (unsigned)std::min<uint64_t>((n_slots / 128 + 3) / 4, 256 * 2);
     const uint32_t self = (uint32_t)sh->comm->rank;
     if (time_probe) UMGAP_HIP(hipEventRecord(sh->ev_probe0, s));
-    if (sh->value_bytes == 3) hipLaunchKernelGGL(k_shard_probe<3>, dim3(gp), dim3(256), 0, s, T, S.recv_keys, S.send_keys, self, sh->cap, n_slots, S.ret_send, S.ret_recv);
-    else hipLaunchKernelGGL(k_shard_probe<4>, dim3(gp), dim3(256), 0, s, T, S.recv_keys, S.send_keys, self, sh->cap, n_slots, S.ret_send, S.ret_recv);
+    if (sh->value_bytes == 3) hipLaunchKernelGGL(k_shard_probe<3>, dim3(gp), dim3(256), 0, s, T, S.recv_keys, S.send_keys, self, sh->local_bypass ? 1u : 0u, sh->cap, n_slots, S.ret_send, S.ret_recv);
+    else hipLaunchKernelGGL(k_shard_probe<4>, dim3(gp), dim3(256), 0, s, T, S.recv_keys, S.send_keys, self, sh->local_bypass ? 1u : 0u, sh->cap, n_slots, S.ret_send, S.ret_recv);
     UMGAP_HIP(hipGetLastError());
     UMGAP_HIP(hipEventRecord(S.probed, s));
     if (time_probe) { UMGAP_HIP(hipEventRecord(sh->ev_probe1, s)); sh->probe_timed = true; }
@@ -599,6 +620,7 @@ int umgap_sharded_create(umgap_index* shard, umgap_taxonomy* tx, umgap_comm* com
     sh->max_keys = max_keys_per_call;
     sh->pieces = pieces;
     sh->piece_keys = (max_keys_per_call + pieces - 1) / pieces;
+    { const char* nl = getenv("UMGAP_SHARD_NO_LOCAL"); sh->local_bypass = !(nl && nl[0] == '1'); }
     // a region receives piece_keys / W keys on average; binomial spread ~ sqrt of that, so slack + 8 sigma + one tile
     const double mean = (double)sh->piece_keys / W;
     uint64_t cap = (uint64_t)(mean * (1.0 + slack) + 8.0 * std::sqrt(mean + 1.0)) + 4096;
@@ -710,9 +732,9 @@ int umgap_sharded_lookup9_dev(umgap_sharded* sh, const uint64_t* d_keys45, size_
             const uint64_t pc = first + c;
             if ((rc = piece_back(sh, pc))) return rc;
             if (hi > lo) {
-                unsigned g = (unsigned)std::min<size_t>((hi - lo + 255) / 256, 2048);
-                hipLaunchKernelGGL(k_shard_unpermute, dim3(g), dim3(256), 0, sh->s_agg, HitSource{sh->set[pc % NSETS].ret_recv, sh->perm[pc % NPERM], sh->value_bytes},
-                                   hi - lo, miss_value, d_out_taxa + lo);
+                unsigned g = (unsigned)std::min<size_t>((hi - lo + 255) / 256, 2048);   // 4 waves x 64 keys per workgroup and step
+                hipLaunchKernelGGL(k_shard_unpermute, dim3(g), dim3(256), 0, sh->s_agg, sh->ix->view,
+                                   HitSource{sh->set[pc % NSETS].ret_recv, sh->perm[pc % NPERM], sh->value_bytes, d_keys45 + lo}, hi - lo, miss_value, d_out_taxa + lo);
                 UMGAP_HIP(hipGetLastError());
             }
             if ((rc = piece_done(sh, pc))) return rc;
@@ -776,8 +798,8 @@ int umgap_sharded_classify9_dev(umgap_sharded* sh, int method, int strategy, flo
             const size_t c = t - 1, lo = std::min(n_reads, c * per), hi = std::min(n_reads, (c + 1) * per);
             const uint64_t pc = first + c;
             if ((rc = piece_back(sh, pc))) return rc;
-            rc = launch_classify9_from_hits(sh->tx, method, strategy, factor, lower_bound, ranked_only,
-                                            HitSource{sh->set[pc % NSETS].ret_recv, sh->perm[pc % NPERM], sh->value_bytes}, hi - lo, kmers_per_read,
+            rc = launch_classify9_from_hits(sh->ix, sh->tx, method, strategy, factor, lower_bound, ranked_only,
+                                            HitSource{sh->set[pc % NSETS].ret_recv, sh->perm[pc % NPERM], sh->value_bytes, d_keys45 + lo * kmers_per_read}, hi - lo, kmers_per_read,
                                             fragments_per_read, min_seed_size, max_gap_size, d_out_taxon + lo, d_out_status + lo, sh->s_agg);
             if (rc) return rc;
             if ((rc = piece_done(sh, pc))) return rc;

@@ -5,6 +5,8 @@
 // remainder straight from h (common.hpp), so nothing is hashed twice.  A send buffer holds `world` regions of `cap`
 // slots; region o = [cap x u32: h & 0xFFFFFFFF][cap x u16: h >> 32] = 6*cap contiguous bytes = one message to peer o.
 // A u16 of 0xFFFF marks a slot that holds no key (the unused tail of a region).
+// A rank's OWN share (1/N of the keys) takes none of this: the pack only marks those keys (perm = LOCAL) and the kernel that
+// consumes the hits probes them itself, between its gathers -- no 6-byte copy, no value store, no gather for them.
 // Back (values): one value per slot, same slot order, `value_bytes` = 3 or 4 bytes each (3 when every value of every
 // shard is below 2^24 - 1, which holds for NCBI taxon ids); all-ones = the key is absent.  3-byte values are packed four
 // to three u32 words (cap is a multiple of 4).
@@ -15,13 +17,16 @@ namespace umgap {
 
 struct HitSource {
     const uint32_t* ret = nullptr;   // returned values, slot order
-    const uint32_t* perm = nullptr;  // key i of the batch -> slot (wire::NOSLOT = not sent: answered with a miss)
+    const uint32_t* perm = nullptr;  // key i of the batch -> slot; wire::NOSLOT = not sent (answered with a miss);
+                                     // wire::LOCAL = the rank owns the key: probed where it is consumed, never packed
     uint32_t value_bytes = 4;
+    const uint64_t* keys = nullptr;  // the batch's packed 9-mers (same indexing as perm): read again for the LOCAL keys
 };
 
 namespace wire {
 
 constexpr uint32_t NOSLOT = 0xFFFFFFFFu;
+constexpr uint32_t LOCAL = 0xFFFFFFFEu;
 constexpr uint32_t HI_NOKEY = 0xFFFFu;
 
 __host__ __device__ inline uint32_t miss_raw(uint32_t value_bytes) { return value_bytes == 3 ? 0xFFFFFFu : 0xFFFFFFFFu; }
