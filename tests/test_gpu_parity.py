@@ -1077,6 +1077,9 @@ def test_sharded_table_wide_values_and_overflow(api, torch_cuda):
     comms = Comm.local(world)
     outs = [torch.empty(len(q), dtype=torch.int32, device="cuda") for _ in range(world)]
     tripped = [False] * world
+    # a present key owned by each rank (a rank's OWN keys never travel, so only somebody else's key can overflow a region)
+    owner = whole.owner9_dev(d_q[:2000], world).cpu().numpy()
+    key_of_owner = [int(np.nonzero(owner == o)[0][0]) for o in range(world)]
 
     def rank_body(r):
         torch.cuda.set_device(0)
@@ -1086,7 +1089,8 @@ def test_sharded_table_wide_values_and_overflow(api, torch_cuda):
         sh.lookup9(d_q, outs[r], miss_value=9, stream=st)
         sh.check()
         # a batch that goes to ONE owner overflows its region: flagged, and still flagged after a clean call
-        skew = d_q[:1].repeat(len(q))
+        other = key_of_owner[(r + 1) % world]
+        skew = d_q[other:other + 1].repeat(len(q))
         o2 = torch.empty(len(q), dtype=torch.int32, device="cuda")
         torch.cuda.synchronize()
         sh.lookup9(skew, o2, miss_value=9, stream=st)
@@ -1096,7 +1100,7 @@ def test_sharded_table_wide_values_and_overflow(api, torch_cuda):
         except api.UmgapError as e:
             tripped[r] = "overflowed" in e.message
         v = o2.cpu().numpy().view(np.uint32)
-        assert set(np.unique(v).tolist()) <= {9, int(want[0].item()) & 0xFFFFFFFF}      # the right value or a miss, nothing else
+        assert set(np.unique(v).tolist()) <= {9, int(want[other].item()) & 0xFFFFFFFF}  # the right value or a miss, nothing else
         sh.check()                                                                      # the flag is cleared by the report
         sh.close()
 
