@@ -497,9 +497,9 @@ int launch_classify9_from_hits(umgap_index* ix, umgap_taxonomy* tx, int method, 
     // units with the probe and the pack of the pieces behind it
     const size_t g = ((n_reads + G - 1) / G + 3) / 4;
     TaxView V = view_of(tx, ranked_only);
-    const TableView none = ix->view;     // the shard: the rank's own keys (perm = LOCAL) are probed by these kernels
+    const TableView shard = ix->view;    // the rank's own keys (perm = LOCAL) are probed by these kernels
     if (strategy == UMGAP_STRATEGY_LCA_STAR) {
-        hipLaunchKernelGGL((k_classify9<false, true>), dim3((unsigned)g), dim3(256), 0, s, none, V, method, (const uint64_t*)nullptr, n_reads, kmers_per_read,
+        hipLaunchKernelGGL((k_classify9<false, true>), dim3((unsigned)g), dim3(256), 0, s, shard, V, method, (const uint64_t*)nullptr, n_reads, kmers_per_read,
                            fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status, H);
     } else {
         if (n_reads >= 0xFFFFFFFFull) return fail(UMGAP_ERR_INVALID, "at most 2^32 - 2 reads per call");
@@ -508,10 +508,10 @@ int launch_classify9_from_hits(umgap_index* ix, umgap_taxonomy* tx, int method, 
         uint32_t* d_count = d_defer;
         uint32_t* d_list = d_defer + 1;
         UMGAP_HIP(hipMemsetAsync(d_count, 0, sizeof(uint32_t), s));
-        hipLaunchKernelGGL((k_classify9_group<false, true>), dim3((unsigned)g), dim3(256), 0, s, none, V, method, strategy, factor, (const uint64_t*)nullptr,
+        hipLaunchKernelGGL((k_classify9_group<false, true>), dim3((unsigned)g), dim3(256), 0, s, shard, V, method, strategy, factor, (const uint64_t*)nullptr,
                            n_reads, kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status,
                            d_list, d_count, H);
-        hipLaunchKernelGGL((k_classify9_general<128, 512, false, true>), dim3(256), dim3(256), 0, s, none, V, method, strategy, factor, (const uint64_t*)nullptr,
+        hipLaunchKernelGGL((k_classify9_general<128, 512, false, true>), dim3(256), dim3(256), 0, s, shard, V, method, strategy, factor, (const uint64_t*)nullptr,
                            n_reads, kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status,
                            (const uint32_t*)d_list, (const uint32_t*)d_count, (uint32_t*)nullptr, (uint32_t*)nullptr, H);
     }
