@@ -495,8 +495,7 @@ int launch_classify9_from_hits(umgap_index* ix, umgap_taxonomy* tx, int method, 
     if (fragments_per_read && G * fragments_per_read > 64) G = 64 / fragments_per_read;
     // one group per wave, as many workgroups as groups: short-lived workgroups, so this piece's aggregate shares the compute
     // units with the probe and the pack of the pieces behind it
-    size_t g = ((n_reads + G - 1) / G + 3) / 4;
-    { static const char* cap_env = getenv("UMGAP_SHARD_AGG_GRID"); if (cap_env) { size_t c = (size_t)atol(cap_env); if (c && g > c) g = c; } }   // experiment knob
+    const size_t g = ((n_reads + G - 1) / G + 3) / 4;   // (a capped, persistent grid and 4 instead of 8 pieces measured the same: 25.2-25.9 ms)
     TaxView V = view_of(tx, ranked_only);
     const TableView shard = ix->view;    // the rank's own keys (perm = LOCAL) are probed by these kernels
     if (strategy == UMGAP_STRATEGY_LCA_STAR) {
