@@ -142,7 +142,8 @@ def main():
                 data, mine, theirs = soup(rng, prot_item, int(rng.integers(0, 12))), ["prot2kmer2lca"] + flags + [idx], ["prot2kmer2lca"] + flags + [idx_tsv]
             elif cmd == "prot2kmer2agg":
                 se, uq, ag = [(["-g", "1", "-s", "3"], ["-d", "/"], ["-l", "2", "-a", "lca*"]), (["-s", "2"], [], ["-a", "hybrid"]),
-                              (["-g", "1", "-s", "2"], ["-d", "/"], ["-l", "1", "-m", "rmq", "-a", "mrtl"])][int(rng.integers(0, 3))]
+                              (["-g", "1", "-s", "2"], ["-d", "/"], ["-l", "1", "-m", "rmq", "-a", "mrtl"]),
+                              (["-g", "1", "-s", "1"], ["-d", "/"], ["-l", "1", "-a", "lca*"]), (["-g", "2", "-s", "0"], [], ["-m", "rmq", "-a", "hybrid"])][int(rng.integers(0, 5))]
                 data = soup(rng, prot_item, int(rng.integers(0, 12)))
                 stage, ok = data, True
                 for theirs in (["prot2kmer2lca", "-o", idx_tsv], ["seedextend"] + se, ["uniq"] + uq, ["taxa2agg"] + ag + [tsv]):
