@@ -62,6 +62,20 @@ def test_no_cpu_fallback(lib):
     assert rc == _lib.ERR_DEVICE
 
 
+def test_round2_entry_points_fail_loudly_without_gpu(lib):
+    """Pinned buffers and communicators need the device too: nothing of the sharded path has a host-side stand-in."""
+    if _has_gpu(lib):
+        pytest.skip("a GPU is visible")
+    p = C.c_void_p()
+    assert lib.umgap_host_alloc(4096, C.byref(p)) == _lib.ERR_DEVICE and not p.value
+    ranks = (C.c_void_p * 2)()
+    assert lib.umgap_comm_init_local(2, 0, ranks) == _lib.ERR_DEVICE
+    assert lib.umgap_comm_init_local(0, 0, ranks) == _lib.ERR_INVALID
+    assert lib.umgap_comm_world(None) == 0 and lib.umgap_comm_rank(None) == -1
+    h = C.c_void_p()
+    assert lib.umgap_sharded_create(None, None, None, 1024, 1, 0.1, C.byref(h)) == _lib.ERR_INVALID
+
+
 def test_taxonomy_validation_mirrors_reference_panics(lib):
     """TaxonTree::new panics (src/taxon.rs:226,239-246) surface as UMGAP_ERR_PANIC before any GPU use."""
     def create(ids, par):
