@@ -180,6 +180,7 @@ def sharded_section(args, w, keys, rank, world, device, B, d_taxon, d_status, wa
     torch.cuda.empty_cache()
     shard = Index.synthetic(args.n_keys, w.d_taxon_of_row, synth.MUL_A, synth.ADD_B, args.load_factor, rank, world)
     comm = Comm.from_torch_distributed(device.index or 0)
+    comm.selftest(1 << 20)      # RCCL send/recv group to every rank (itself included), contents checked
     per_piece = -(-B // args.pieces)
     sh = Sharded(shard, w.taxonomy, comm, per_piece * args.pieces * KMERS, pieces=args.pieces)
     steps = max(2, min(5, args.steps))

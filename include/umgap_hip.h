@@ -295,6 +295,10 @@ int umgap_comm_init_rank(const uint8_t* id128, int world, int rank, int device, 
 int umgap_comm_init_local(int world, int device, umgap_comm** out_ranks /* world handles */);
 int umgap_comm_world(const umgap_comm* c);
 int umgap_comm_rank(const umgap_comm* c);
+/* Collective: every rank sends a known pattern of `bytes_per_peer` bytes to every rank INCLUDING itself through the transport
+ * of the sharded lookup (RCCL send/recv group, or the local hub) and checks what arrives.  With world 1 this still drives
+ * ncclSend/ncclRecv (to self), so the binding can be verified on a one-GPU box. */
+int umgap_comm_selftest(umgap_comm* c, size_t bytes_per_peer);
 void umgap_comm_free(umgap_comm* c);
 /* The sharded table of one rank: `shard` must be shard rank-of-world of the communicator; `tx` (nullable) is needed by
  * umgap_sharded_classify9_dev.  max_keys_per_call bounds one call; it is cut into `pieces` (0 = 8) pipelined pieces of

@@ -1139,6 +1139,21 @@ def test_sharded_table_rccl_world1(api, torch_cuda):
     comm.close()
 
 
+def test_comm_selftest_drives_the_transport(api, torch_cuda):
+    """umgap_comm_selftest moves a known pattern to every rank INCLUDING the sender through the lookup's own transport:
+    on the one-rank RCCL communicator that is a real ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd on a side stream
+    (the calls the N-rank exchange makes and a one-GPU box cannot otherwise reach); on the local hub, three ranks."""
+    from umgap_amd.dist import Comm
+    comm = Comm.init_rank(Comm.unique_id(), 1, 0, 0)
+    for nbytes in (1, 4099, 3 << 20):
+        comm.selftest(nbytes)
+    comm.close()
+    comms = Comm.local(3)
+    _run_ranks(3, lambda r: (torch_cuda.cuda.set_device(0), comms[r].selftest(70001)))
+    for c in comms:
+        c.close()
+
+
 # ---------------------------------------------------------------------------------------------
 # surface B: protein fragments in, fused kernel (LDS-staged k-mer packing) vs the oracle stages
 # ---------------------------------------------------------------------------------------------

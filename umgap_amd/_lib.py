@@ -111,6 +111,7 @@ def load():
         "umgap_comm_init_local": (i32, [i32, i32, pp]),
         "umgap_comm_world": (i32, [vp]),
         "umgap_comm_rank": (i32, [vp]),
+        "umgap_comm_selftest": (i32, [vp, sz]),
         "umgap_comm_free": (None, [vp]),
         "umgap_sharded_create": (i32, [vp, vp, vp, u64, u32, dbl, pp]),
         "umgap_sharded_free": (None, [vp]),

@@ -375,6 +375,7 @@ struct ShardGang {
             LIB(umgap_index_open_shard(path.c_str(), 1u << dev, (uint32_t)r, (uint32_t)n, &ix[r]));
             if (umgap_index_kind(ix[r]) != 9) throw CliError("--shards needs a 9-mer index");
             if (!local) LIB(umgap_comm_init_rank(id, n, r, dev, &comm[r]));
+            LIB(umgap_comm_selftest(comm[r], 1 << 16));   // a link that drops or garbles bytes shows up here, not in the answers
             LIB(umgap_sharded_create(ix[r], nullptr, comm[r], max_keys, 4, 0.05, &sh[r]));
         });
     }

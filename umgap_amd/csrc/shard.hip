@@ -30,6 +30,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "probe_common.hpp"
@@ -91,6 +92,12 @@ Rccl* rccl() {
     return &R;
 }
 
+// the pointers above carry the prototypes of <rccl/rccl.h>
+static_assert(std::is_same<decltype(Rccl::Send), decltype(&ncclSend)>::value && std::is_same<decltype(Rccl::Recv), decltype(&ncclRecv)>::value &&
+                  std::is_same<decltype(Rccl::AllReduce), decltype(&ncclAllReduce)>::value && std::is_same<decltype(Rccl::CommInitRank), decltype(&ncclCommInitRank)>::value &&
+                  std::is_same<decltype(Rccl::GetUniqueId), decltype(&ncclGetUniqueId)>::value,
+              "RCCL binding out of step with rccl.h");
+
 #define UMGAP_NCCL(expr)                                                                                          \
     do {                                                                                                          \
         ncclResult_t r__ = (expr);                                                                                \
@@ -127,15 +134,16 @@ namespace {
 
 // every rank sends `bytes` to every OTHER rank: recv region p <- rank p's send region `rank`.  A rank's own share never
 // travels (nor is it copied): the kernels read / write region `rank` in place (k_shard_probe).
-int comm_alltoall(umgap_comm* c, const void* send, void* recv, size_t bytes, hipStream_t s) {
-    if (c->world == 1) return UMGAP_OK;
+// `with_self` (umgap_comm_selftest only) moves region `rank` too, through the same transport.
+int comm_alltoall(umgap_comm* c, const void* send, void* recv, size_t bytes, hipStream_t s, bool with_self = false) {
+    if (c->world == 1 && !with_self) return UMGAP_OK;
     if (c->hub) {
         LocalHub& H = *c->hub;
         H.send[c->rank] = send;
         UMGAP_HIP(hipEventRecord(H.ready[c->rank], s));
         H.barrier();
         for (int p = 0; p < c->world; p++) {
-            if (p == c->rank) continue;
+            if (p == c->rank && !with_self) continue;
             UMGAP_HIP(hipStreamWaitEvent(s, H.ready[p], 0));
             UMGAP_HIP(hipMemcpyAsync((char*)recv + (size_t)p * bytes, (const char*)H.send[p] + (size_t)c->rank * bytes, bytes, hipMemcpyDeviceToDevice, s));
         }
@@ -148,7 +156,7 @@ int comm_alltoall(umgap_comm* c, const void* send, void* recv, size_t bytes, hip
     Rccl* R = rccl();
     UMGAP_NCCL(R->GroupStart());
     for (int p = 0; p < c->world; p++) {
-        if (p == c->rank) continue;
+        if (p == c->rank && !with_self) continue;
         UMGAP_NCCL(R->Send((const char*)send + (size_t)p * bytes, bytes, ncclUint8, p, c->nccl, s));
         UMGAP_NCCL(R->Recv((char*)recv + (size_t)p * bytes, bytes, ncclUint8, p, c->nccl, s));
     }
@@ -578,6 +586,40 @@ int umgap_comm_init_local(int world, int device, umgap_comm** out_ranks) {
 
 int umgap_comm_world(const umgap_comm* c) { return c ? c->world : 0; }
 int umgap_comm_rank(const umgap_comm* c) { return c ? c->rank : -1; }
+
+// byte i of the message rank `from` sends to rank `to`
+static inline uint8_t selftest_byte(int from, int to, size_t i) { return (uint8_t)(from * 131 + to * 31 + i * 7 + (i >> 8)); }
+
+int umgap_comm_selftest(umgap_comm* c, size_t bytes_per_peer) {
+    if (!c || !bytes_per_peer) return fail(UMGAP_ERR_INVALID, "umgap_comm_selftest: null argument");
+    int rc = use_device(c->device);
+    if (rc) return rc;
+    const size_t B = bytes_per_peer, W = (size_t)c->world;
+    std::vector<uint8_t> h(W * B);
+    for (size_t p = 0; p < W; p++)
+        for (size_t i = 0; i < B; i++) h[p * B + i] = selftest_byte(c->rank, (int)p, i);
+    uint8_t *d_send = nullptr, *d_recv = nullptr;
+    hipStream_t s = nullptr;
+    auto done = [&](int code) {
+        if (s) (void)hipStreamDestroy(s);
+        (void)hipFree(d_send);
+        (void)hipFree(d_recv);
+        return code;
+    };
+    if (hipMalloc((void**)&d_send, W * B) != hipSuccess || hipMalloc((void**)&d_recv, W * B) != hipSuccess || hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess)
+        return done(fail(UMGAP_ERR_NOMEM, "umgap_comm_selftest: allocation failed"));
+    if (hipMemcpy(d_send, h.data(), W * B, hipMemcpyHostToDevice) != hipSuccess || hipMemset(d_recv, 0, W * B) != hipSuccess)
+        return done(fail(UMGAP_ERR_DEVICE, "umgap_comm_selftest: copy in failed"));
+    rc = comm_alltoall(c, d_send, d_recv, B, s, /*with_self=*/true);
+    if (rc) return done(rc);
+    if (hipStreamSynchronize(s) != hipSuccess || hipMemcpy(h.data(), d_recv, W * B, hipMemcpyDeviceToHost) != hipSuccess)
+        return done(fail(UMGAP_ERR_DEVICE, "umgap_comm_selftest: the exchange did not complete"));
+    for (size_t p = 0; p < W; p++)
+        for (size_t i = 0; i < B; i++)
+            if (h[p * B + i] != selftest_byte((int)p, c->rank, i))
+                return done(fail(UMGAP_ERR_DEVICE, "umgap_comm_selftest: rank " + std::to_string(c->rank) + " got a wrong byte " + std::to_string(i) + " from rank " + std::to_string(p)));
+    return done(UMGAP_OK);
+}
 
 void umgap_comm_free(umgap_comm* c) {
     if (!c) return;

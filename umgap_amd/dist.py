@@ -62,6 +62,10 @@ class Comm:
         check(_lib.load().umgap_comm_init_local(world, device, arr))
         return [cls(arr[r], "local") for r in range(world)]
 
+    def selftest(self, bytes_per_peer=1 << 20):
+        """Collective: a known pattern through the lookup's own transport, to every rank including this one."""
+        check(_lib.load().umgap_comm_selftest(self._h, bytes_per_peer))
+
     def close(self):
         if self._h:
             _lib.load().umgap_comm_free(self._h)
