@@ -153,6 +153,8 @@ class Watchdog:
         self.rank, self.line, self.seconds, self.exit_code = rank, line, seconds, exit_code
 
     def bail(self):
+        sys.stderr.write("bench.py: rank %d: the sharded section stalled for %d s; giving up on it (exit status %d)\n" % (self.rank, self.seconds, self.exit_code))
+        sys.stderr.flush()
         if self.rank == 0:
             self.line["sharded"] = {"error": "timed out after %d s" % self.seconds}
             print(json.dumps(self.line), flush=True)
