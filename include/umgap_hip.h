@@ -17,7 +17,7 @@
  *   seedextend record state machine    src/commands/seedextend.rs:99-148  -> umgap_seedextend_dev
  *   the four 9-mer stages of scripts/umgap-analyse.sh:257-310 in one call (hits never leave the device)
  *                                                                         -> umgap_classify9[_strategy]_dev,
- *                                                                            umgap_classify_prot9_dev,
+ *                                                                            umgap_classify_prot9[_strategy]_dev,
  *                                                                            umgap_classify_records (host records)
  *
  * Conventions
@@ -256,6 +256,14 @@ int umgap_classify_prot9_dev(umgap_index* ix, umgap_taxonomy* tx, int method, fl
                              const uint8_t* d_bytes, const uint64_t* d_frag_offsets, size_t n_reads,
                              uint32_t fragments_per_read, int seedextend, uint32_t min_seed_size,
                              uint32_t max_gap_size, uint32_t* d_out_taxon, uint32_t* d_out_status, void* stream);
+/* Surface B with any aggregation strategy (UMGAP_STRATEGY_LCA_STAR forwards to the call above; `factor` as in
+ * umgap_aggregate).  For MRTL and the hybrids a read with more than 64 distinct taxa surviving the count filter is also
+ * UMGAP_READ_UNSUPPORTED: this kernel has no large-scratch pass behind it. */
+int umgap_classify_prot9_strategy_dev(umgap_index* ix, umgap_taxonomy* tx, int method, int strategy, float factor,
+                                      float lower_bound, int ranked_only, const uint8_t* d_bytes,
+                                      const uint64_t* d_frag_offsets, size_t n_reads, uint32_t fragments_per_read,
+                                      int seedextend, uint32_t min_seed_size, uint32_t max_gap_size,
+                                      uint32_t* d_out_taxon, uint32_t* d_out_status, void* stream);
 
 /* The same pipeline for a block of FASTA records held in HOST memory -- what a fused
  * `prot2kmer2lca -o | seedextend -s S -g G | uniq [-d D] | taxa2agg ...` command needs per block

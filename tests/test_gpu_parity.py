@@ -1180,9 +1180,12 @@ def _pack_windows(arr2d):
     return keys, ok
 
 
+@pytest.mark.parametrize("mode", [("tree", "lca*"), ("tree", "hybrid"), ("rmq", "hybrid"), ("rmq", "mrtl")])
 @pytest.mark.parametrize("with_seedextend", [False, True])
-def test_fused_classify_prot9_vs_oracle(api, torch_cuda, with_seedextend):
+def test_fused_classify_prot9_vs_oracle(api, torch_cuda, with_seedextend, mode):
+    """umgap_classify_prot9[_strategy]_dev (fragments in, one taxon per read out) against the oracle's stages, every strategy."""
     torch = torch_cuda
+    method, strategy = mode
     import ctypes as C
     from umgap_amd import _lib
     from umgap_amd.api import Index, _dev_ptr, _stream_ptr
@@ -1199,8 +1202,8 @@ def test_fused_classify_prot9_vs_oracle(api, torch_cuda, with_seedextend):
     roffs = torch.arange(0, (n_reads * F + 1) * flen, flen, dtype=torch.int64, device="cuda")
     d_t = torch.empty(n_reads, dtype=torch.int32, device="cuda")
     d_s = torch.empty_like(d_t)
-    api.classify_prot9_dev(ix, w.taxonomy, reads, roffs, n_reads, F, d_t, d_s, method="tree", lower_bound=2.0, seedextend=with_seedextend,
-                           min_seed_size=3, max_gap_size=1)
+    api.classify_prot9_dev(ix, w.taxonomy, reads, roffs, n_reads, F, d_t, d_s, method=method, strategy=strategy, factor=0.25, lower_bound=2.0,
+                           seedextend=with_seedextend, min_seed_size=3, max_gap_size=1)
     torch.cuda.synchronize()
     # oracle side: the index as a sorted (key -> min taxon) array, lookups by searchsorted
     pk, pok = _pack_windows(prot.cpu().numpy().reshape(n_frag, flen))
@@ -1228,7 +1231,7 @@ def test_fused_classify_prot9_vs_oracle(api, torch_cuda, with_seedextend):
             kept = O.seedextend_record(hits[r * per:(r + 1) * per], 3, 1)
             out[r * per:r * per + len(kept)] = kept
         hits = out
-    agg = O.Aggregator(O.Taxonomy.from_arrays(w.ids, w.parents, w.valid, w.rank), "tree", "lca*")
+    agg = O.Aggregator(O.Taxonomy.from_arrays(w.ids, w.parents, w.valid, w.rank), method, strategy, 0.25)
     offs = np.arange(n_reads + 1, dtype=np.uint64) * (F * per)
     t, s = d_t.cpu().numpy().view(np.uint32), d_s.cpu().numpy().view(np.uint32)
     nbad, bad, wt, ws = agg.taxa2agg_check(hits, offs, t, s, lower_bound=2.0, nthreads=8)
@@ -1237,8 +1240,8 @@ def test_fused_classify_prot9_vs_oracle(api, torch_cuda, with_seedextend):
     # the same launch on the table bound to the taxonomy: bit-identical
     ix.bind(w.taxonomy)
     d_t2, d_s2 = torch.empty_like(d_t), torch.empty_like(d_s)
-    api.classify_prot9_dev(ix, w.taxonomy, reads, roffs, n_reads, F, d_t2, d_s2, method="tree", lower_bound=2.0, seedextend=with_seedextend,
-                           min_seed_size=3, max_gap_size=1)
+    api.classify_prot9_dev(ix, w.taxonomy, reads, roffs, n_reads, F, d_t2, d_s2, method=method, strategy=strategy, factor=0.25, lower_bound=2.0,
+                           seedextend=with_seedextend, min_seed_size=3, max_gap_size=1)
     torch.cuda.synchronize()
     ix.unbind(w.taxonomy)
     assert torch.equal(d_t, d_t2) and torch.equal(d_s, d_s2)
@@ -1254,7 +1257,7 @@ def test_classify_prot9_ragged_fragments(api, torch_cuda):
     par = np.maximum(1, ids // 2).astype(np.uint32)
     par[0] = 1
     tx = api.Taxonomy(ids, par)
-    agg = O.Aggregator(O.Taxonomy.from_arrays(ids, par), "tree", "lca*")
+    otx = O.Taxonomy.from_arrays(ids, par)
     vals = rng.choice(ids, len(kmers)).astype(np.uint32)
     keys, _ = api.pack9_array(kmers)
     ix = api.Index.build(keys, vals)
@@ -1273,19 +1276,74 @@ def test_classify_prot9_ragged_fragments(api, torch_cuda):
             frags.append(bytes(p))
         data, offs = api._concat(frags)
         n_reads = 400
-        d_t = torch.empty(n_reads, dtype=torch.int32, device="cuda")
-        d_s = torch.empty_like(d_t)
-        api.classify_prot9_dev(ix, tx, torch.from_numpy(data.copy()).cuda(), torch.from_numpy(offs.view(np.int64)).cuda(), n_reads, F, d_t, d_s,
-                               method="tree", lower_bound=2.0)
-        torch.cuda.synchronize()
         hits, roffs = [], [0]
         for r in range(n_reads):
             for f in frags[r * F:(r + 1) * F]:
                 hits += [d.get(f[i:i + 9], 0) for i in range(max(0, len(f) - 8))]
             roffs.append(len(hits))
-        t, s = d_t.cpu().numpy().view(np.uint32), d_s.cpu().numpy().view(np.uint32)
-        nbad, bad, wt, ws = agg.taxa2agg_check(np.array(hits, np.uint32), np.array(roffs, np.uint64), t, s, lower_bound=2.0)
-        assert nbad == 0, (F, bad)
+        d_data, d_offs = torch.from_numpy(data.copy()).cuda(), torch.from_numpy(offs.view(np.int64)).cuda()
+        for method, strategy, lb in (("tree", "lca*", 2.0), ("rmq", "mrtl", 1.0), ("tree", "hybrid", 2.0), ("rmq", "hybrid", 0.0)):
+            d_t = torch.full((n_reads,), -1, dtype=torch.int32, device="cuda")
+            d_s = torch.full_like(d_t, -1)
+            api.classify_prot9_dev(ix, tx, d_data, d_offs, n_reads, F, d_t, d_s, method=method, strategy=strategy, factor=0.4, lower_bound=lb)
+            torch.cuda.synchronize()
+            t, s = d_t.cpu().numpy().view(np.uint32), d_s.cpu().numpy().view(np.uint32)
+            agg = O.Aggregator(otx, method, strategy, 0.4)
+            nbad, bad, wt, ws = agg.taxa2agg_check(np.array(hits, np.uint32), np.array(roffs, np.uint64), t, s, lower_bound=lb)
+            assert nbad == 0, (F, method, strategy, bad)
+
+
+def test_classify_prot9_overlong_reads_are_flagged(api, torch_cuda):
+    """A read of more than 128 windows or 384 bytes is UMGAP_READ_UNSUPPORTED (include/umgap_hip.h) with every strategy, and
+    the reads that share its group are unaffected."""
+    torch = torch_cuda
+    rng = np.random.default_rng(5)
+    letters = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    kmers = sorted({rng.choice(letters, 9).tobytes() for _ in range(500)})
+    ids = np.arange(1, 60, dtype=np.uint32)
+    par = np.maximum(1, ids // 3).astype(np.uint32)
+    tx = api.Taxonomy(ids, par)
+    otx = O.Taxonomy.from_arrays(ids, par)
+    vals = rng.choice(ids, len(kmers)).astype(np.uint32)
+    keys, _ = api.pack9_array(kmers)
+    ix = api.Index.build(keys, vals)
+    d = dict(zip(kmers, vals.tolist()))
+    F, n_reads = 2, 203
+    frags, long_read = [], np.zeros(n_reads, bool)
+    for r in range(n_reads):
+        kind = r % 7
+        lens = (70, 70) if kind == 3 else ((300, 100) if kind == 5 else (int(rng.integers(9, 60)), int(rng.integers(0, 60))))   # 124 windows; 400 bytes
+        if r % 29 == 0:
+            lens = (137, 0)                                                                                                    # 129 windows
+        long_read[r] = sum(max(0, n - 8) for n in lens) > 128 or sum(lens) > 384
+        for n in lens:
+            p = bytearray(rng.choice(letters, n).tobytes())
+            for _k in range(n // 12):
+                s0 = int(rng.integers(0, n - 8))
+                p[s0:s0 + 9] = kmers[int(rng.integers(0, 25))]
+            frags.append(bytes(p))
+    assert long_read.sum() > 20 and (~long_read).sum() > 100
+    data, offs = api._concat(frags)
+    d_data, d_offs = torch.from_numpy(data.copy()).cuda(), torch.from_numpy(offs.view(np.int64)).cuda()
+    hits, roffs = [], [0]
+    for r in range(n_reads):
+        if not long_read[r]:
+            for f in frags[r * F:(r + 1) * F]:
+                hits += [d.get(f[i:i + 9], 0) for i in range(max(0, len(f) - 8))]
+        roffs.append(len(hits))
+    for method, strategy in (("tree", "lca*"), ("rmq", "mrtl"), ("tree", "hybrid")):
+        d_t = torch.full((n_reads,), -1, dtype=torch.int32, device="cuda")
+        d_s = torch.full_like(d_t, -1)
+        api.classify_prot9_dev(ix, tx, d_data, d_offs, n_reads, F, d_t, d_s, method=method, strategy=strategy, factor=0.25, lower_bound=1.0)
+        torch.cuda.synchronize()
+        t, s = d_t.cpu().numpy().view(np.uint32).copy(), d_s.cpu().numpy().view(np.uint32).copy()
+        assert (s[long_read] == 4).all() and (t[long_read] == 0).all(), (method, strategy)
+        assert (s[~long_read] != 4).all()
+        agg = O.Aggregator(otx, method, strategy, 0.25)
+        _, _, wt, ws = agg.taxa2agg_check(np.array(hits, np.uint32), np.array(roffs, np.uint64), lower_bound=1.0)
+        t[long_read], s[long_read] = wt[long_read], ws[long_read]           # the flagged reads are empty records on the oracle side
+        nbad, bad, _, _ = agg.taxa2agg_check(np.array(hits, np.uint32), np.array(roffs, np.uint64), t, s, lower_bound=1.0)
+        assert nbad == 0, (method, strategy, bad)
 
 
 def test_classify_records_long_ragged_reads(api, torch_cuda):

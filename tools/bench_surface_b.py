@@ -45,19 +45,24 @@ res = {"n_proteome_fragments": n_frag, "index_keys": n_frag * (flen - 8), "table
        "input_bytes_per_pair": F * flen + (F * 8), "setup_s": round(setup, 1)}
 ix.bind(w.taxonomy)     # values = preorder interval codes: the aggregate stage gathers nothing by id
 res["table_bound_to_taxonomy"] = True
-for name, se in (("classify_prot9", False), ("classify_prot9_seedextend", True)):
-    classify_prot9_dev(ix, w.taxonomy, batches[0], roffs, n_pairs, F, d_t, d_s, method="tree", lower_bound=2.0, seedextend=se, min_seed_size=3, max_gap_size=1)
+# the 9-mer presets of scripts/umgap-analyse.sh:277-310: lca* -l2 (with / without seedextend), then the hybrid and MRTL ones
+legs = (("classify_prot9", False, "tree", "lca*", 2.0), ("classify_prot9_seedextend", True, "tree", "lca*", 2.0),
+        ("classify_prot9_seedextend_hybrid", True, "rmq", "hybrid", 1.0), ("classify_prot9_mrtl", False, "rmq", "mrtl", 1.0))
+for name, se, method, strategy, lb in legs:
+    kw = dict(method=method, strategy=strategy, factor=0.25, lower_bound=lb, seedextend=se, min_seed_size=3, max_gap_size=1)
+    classify_prot9_dev(ix, w.taxonomy, batches[0], roffs, n_pairs, F, d_t, d_s, **kw)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for i in range(steps):
-        classify_prot9_dev(ix, w.taxonomy, batches[i], roffs, n_pairs, F, d_t, d_s, method="tree", lower_bound=2.0, seedextend=se, min_seed_size=3, max_gap_size=1)
+        classify_prot9_dev(ix, w.taxonomy, batches[i], roffs, n_pairs, F, d_t, d_s, **kw)
     b.record()
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / steps
     st = d_s.cpu()
     res[name] = {"pairs_per_s": round(n_pairs / ms * 1e3, 1), "ms_per_step": round(ms, 3), "G_lookups_per_s": round(n_pairs * 84 / ms / 1e6, 2),
-                 "status_ok_frac": round(float((st == 0).float().mean()), 3), "status_empty_frac": round(float((st == 1).float().mean()), 3)}
+                 "status_ok_frac": round(float((st == 0).float().mean()), 3), "status_empty_frac": round(float((st == 1).float().mean()), 3),
+                 "status_unsupported_frac": round(float((st == 4).float().mean()), 5)}
 # host-fed estimate: PCIe Gen5 x16 (~50 GB/s achievable) on 116 B per pair in + 8 B out
 res["pcie_bound_pairs_per_s_at_50GBps"] = round(50e9 / (res["input_bytes_per_pair"] + 8), 1)
 print(json.dumps(res))

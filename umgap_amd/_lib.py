@@ -98,6 +98,7 @@ def load():
         "umgap_classify9_dev": (i32, [vp, vp, i32, f32, i32, vp, sz, u32, u32, u32, u32, vp, vp, vp]),
         "umgap_classify9_strategy_dev": (i32, [vp, vp, i32, i32, f32, f32, i32, vp, sz, u32, u32, u32, u32, vp, vp, vp]),
         "umgap_classify_prot9_dev": (i32, [vp, vp, i32, f32, i32, vp, vp, sz, u32, i32, u32, u32, vp, vp, vp]),
+        "umgap_classify_prot9_strategy_dev": (i32, [vp, vp, i32, i32, f32, f32, i32, vp, vp, sz, u32, i32, u32, u32, vp, vp, vp]),
         "umgap_index_builder_new": (i32, [u64, dbl, i32, pp]),
         "umgap_index_builder_add": (i32, [vp, vp, vp, sz]),
         "umgap_index_builder_finish": (i32, [vp, pp]),

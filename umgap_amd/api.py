@@ -352,11 +352,13 @@ def classify9_dev(index, taxonomy, d_keys45, n_reads, kmers_per_read, d_out_taxo
 
 
 def classify_prot9_dev(index, taxonomy, d_bytes, d_frag_offsets, n_reads, fragments_per_read, d_out_taxon, d_out_status, method="tree",
-                       lower_bound=0.0, ranked_only=False, seedextend=False, min_seed_size=2, max_gap_size=0, stream=None):
-    """Fused surface B: protein fragments -> 9-mer windows (LDS) -> probe -> [seedextend] -> LCA*."""
-    check(_lib.load().umgap_classify_prot9_dev(index._h, taxonomy._h, METHODS[method], lower_bound, int(ranked_only), _dev_ptr(d_bytes),
-                                               _dev_ptr(d_frag_offsets), n_reads, fragments_per_read, int(seedextend), min_seed_size,
-                                               max_gap_size, _dev_ptr(d_out_taxon), _dev_ptr(d_out_status), _stream_ptr(stream)))
+                       lower_bound=0.0, ranked_only=False, seedextend=False, min_seed_size=2, max_gap_size=0, stream=None, strategy="lca*",
+                       factor=0.25):
+    """Fused surface B: protein fragments -> 9-mer windows (LDS) -> probe -> [seedextend] -> aggregate (any strategy)."""
+    check(_lib.load().umgap_classify_prot9_strategy_dev(index._h, taxonomy._h, METHODS[method], STRATEGIES[strategy], factor, lower_bound,
+                                                        int(ranked_only), _dev_ptr(d_bytes), _dev_ptr(d_frag_offsets), n_reads, fragments_per_read,
+                                                        int(seedextend), min_seed_size, max_gap_size, _dev_ptr(d_out_taxon), _dev_ptr(d_out_status),
+                                                        _stream_ptr(stream)))
 
 
 def classify_records(index, taxonomy, fragments, read_frags, method="tree", strategy="hybrid", factor=0.25, lower_bound=0.0,

@@ -40,12 +40,32 @@ struct GroupScratch {
 // Aggregates reads [0, nr) of a group whose taxa sit in the wave's strip (read k at wtaxa[k*stride .. +stride), stride <= 128,
 // 0 = no hit).  The strip is consumed.  Results go to out_taxon/out_status[first_read + k]; a read that needs the
 // large-scratch pass is appended to `defer` (or flagged UMGAP_READ_UNSUPPORTED when there is no list).  se_panic: bit
-// (k * frags + f) set = seedextend panicked on fragment f of read k (classify.hip).
-template <bool BOUND>
-__device__ __forceinline__ void general_group(const TaxView& V, GroupScratch& G, int method, int strategy, float factor, float lower_bound,
+// (k * frags + f) set = seedextend panicked on fragment f of read k (classify.hip).  unsupported: bit k set = the caller could
+// not stage read k (its strip is empty); reported as UMGAP_READ_UNSUPPORTED.
+// The same scratch as pointers, for a kernel that lays the arrays over LDS it no longer needs (k_classify_prot9).
+struct GroupView {
+    uint32_t *hkeys, *hcnt, *last;
+    float* cnt;
+    uint32_t *dep, *adj, *lca, *roff, *rans, *rstat;
+    uint8_t* rid;
+};
+constexpr uint32_t GROUP_VIEW_SURVIVOR_WORDS = 5 * GCAP;   // last, cnt, dep, adj, lca
+// survivor arrays over `mem` (GROUP_VIEW_SURVIVOR_WORDS words), per-read arrays over `reads` (3 * GREADS + 1 words + GCAP bytes)
+__device__ __forceinline__ GroupView group_view_over(uint32_t* hkeys, uint32_t* hcnt, uint32_t* mem, uint32_t* reads) {
+    GroupView G;
+    G.hkeys = hkeys; G.hcnt = hcnt;
+    G.last = mem; G.cnt = reinterpret_cast<float*>(mem + GCAP); G.dep = mem + 2 * GCAP; G.adj = mem + 3 * GCAP; G.lca = mem + 4 * GCAP;
+    G.roff = reads; G.rans = reads + GREADS + 1; G.rstat = reads + 2 * GREADS + 1;
+    G.rid = reinterpret_cast<uint8_t*>(reads + 3 * GREADS + 1);
+    return G;
+}
+constexpr uint32_t GROUP_VIEW_READ_WORDS = 3 * GREADS + 1 + (GCAP + 3) / 4;
+
+template <bool BOUND, class GS>
+__device__ __forceinline__ void general_group(const TaxView& V, GS& G, int method, int strategy, float factor, float lower_bound,
                                               uint32_t* wtaxa, uint32_t stride, uint32_t nr, uint32_t lane, uint64_t se_panic, uint32_t frags,
                                               size_t first_read, uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status,
-                                              uint32_t* __restrict__ defer, uint32_t* __restrict__ defer_count) {
+                                              uint32_t* __restrict__ defer, uint32_t* __restrict__ defer_count, uint64_t unsupported = 0ull) {
     const bool tree_like = method != UMGAP_METHOD_RMQ || strategy == UMGAP_STRATEGY_MRTL;
     uint32_t k0 = 0;
     while (k0 < nr) {
@@ -289,6 +309,7 @@ __device__ __forceinline__ void general_group(const TaxView& V, GroupScratch& G,
             const uint32_t kk = k0 + lane;
             const bool sp = se_panic && ((se_panic >> (kk * frags)) & ((frags >= 64 ? 0ull : (1ull << frags)) - 1ull));
             if (sp) { st = UMGAP_READ_PANIC; tx = 0; }
+            if ((unsupported >> kk) & 1ull) { st = UMGAP_READ_UNSUPPORTED; tx = 0; }
             if (st == ST_DEFER) {
                 if (defer) defer[atomicAdd(defer_count, 1u)] = (uint32_t)read;
                 else { out_taxon[read] = 0; out_status[read] = UMGAP_READ_UNSUPPORTED; }

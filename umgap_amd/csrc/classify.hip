@@ -311,18 +311,33 @@ __global__ __launch_bounds__(256) void k_classify9_group(TableView T, TaxView V,
 // ---------------------------------------------------------------------------------------------
 constexpr uint32_t PROT_MAX_FRAGS = 16, PROT_MAX_BYTES = 384, PROT_MAX_WINDOWS = 128, PROT_GROUP = STRIP / PROT_MAX_WINDOWS;  // 8 reads
 
-template <bool BOUND>
-__global__ __launch_bounds__(256, 4) void k_classify_prot9(TableView T, TaxView V, int method, const uint8_t* __restrict__ bytes,
-                                                        const uint64_t* __restrict__ foff, size_t n_reads, uint32_t F, uint32_t do_seed,
-                                                        uint32_t min_seed, uint32_t max_gap, float lower_bound,
-                                                        uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status) {
-    __shared__ uint32_t lds_taxa[4][STRIP], lds_keys[4][256], lds_cnt[4][256];
+// per-wave aggregate scratch of k_classify_prot9: LCA* wants the count table only (its LcaView lies over the byte staging
+// area), the other strategies the group scratch of agg_group.hpp (whose count table comes first)
+template <bool GENERAL>
+struct ProtScratch {
+    uint32_t keys[256], cnt[256];
+};
+template <>
+struct ProtScratch<true> {
+    uint32_t keys[256], cnt[256];
+    uint32_t reads[GROUP_VIEW_READ_WORDS];   // the per-read arrays of the group scratch; its survivor arrays lie over the byte staging area
+};
+
+// GENERAL = false: LCA* (the kernel of umgap_classify_prot9_dev, 4 workgroups per CU; 3 for GENERAL).  GENERAL = true: MRTL and the hybrids
+// through general_group -- the reads of a group sit at a fixed stride of 128 in the strip instead of back to back.
+template <bool BOUND, bool GENERAL>
+__global__ __launch_bounds__(256, GENERAL ? 3 : 4) void k_classify_prot9(TableView T, TaxView V, int method, int strategy, float factor,
+                                                                      const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ foff, size_t n_reads,
+                                                                      uint32_t F, uint32_t do_seed, uint32_t min_seed, uint32_t max_gap, float lower_bound,
+                                                                      uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status) {
+    __shared__ uint32_t lds_taxa[4][STRIP];
+    __shared__ ProtScratch<GENERAL> lds_scratch[4];
     __shared__ uint32_t lds_fstart[4][64], lds_fwin[4][64], lds_fbyte[4][64], lds_total[4][PROT_GROUP];
     __shared__ __attribute__((aligned(16))) uint8_t lds_bytes[4][PROT_GROUP * PROT_MAX_BYTES];   // also the LCA scratch of the aggregate stage (u32 arrays)
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
     uint32_t* wtaxa = lds_taxa[wv];
-    uint32_t* wkeys = lds_keys[wv];
-    uint32_t* wcnt = lds_cnt[wv];
+    uint32_t* wkeys = lds_scratch[wv].keys;
+    uint32_t* wcnt = lds_scratch[wv].cnt;
     uint8_t* wbytes = lds_bytes[wv];
     uint32_t* wfstart = lds_fstart[wv];
     uint32_t* wfwin = lds_fwin[wv];
@@ -368,8 +383,12 @@ __global__ __launch_bounds__(256, 4) void k_classify_prot9(TableView T, TaxView 
         uint32_t incl = my_win;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= (uint32_t)o) incl += t; }
-        const uint32_t my_start = incl - my_win;
+        uint32_t my_start = incl - my_win;
         const uint32_t W = (uint32_t)__shfl((int)incl, 63, 64);          // windows of the group (<= STRIP)
+        if (GENERAL) {                                                   // read k starts at k * 128 (every lane shuffles)
+            const uint32_t rd_start = (uint32_t)__shfl((int)my_start, (int)((k_of * F) & 63), 64);
+            my_start = k_of * PROT_MAX_WINDOWS + (my_start - rd_start);
+        }
         wfstart[lane] = lane < nfr ? my_start : 0xFFFFFFFFu;
         wfwin[lane] = my_win;
         wfbyte[lane] = k_of * PROT_MAX_BYTES + my_rel;
@@ -414,6 +433,11 @@ __global__ __launch_bounds__(256, 4) void k_classify_prot9(TableView T, TaxView 
             bo = wfbyte[f] + w0;
         }
         wave_lds_sync();   // the table is read; the strip may be written now
+        if (GENERAL) {     // the gaps between the reads must read "no hit"
+#pragma unroll
+            for (uint32_t i = 0; i < STRIP; i += 64) wtaxa[i + lane] = 0u;
+            wave_lds_sync();
+        }
         for (uint32_t t = 0; t < R; t += 2) {
             ProbeBatch B[2];
             uint32_t pr[2][4];
@@ -461,6 +485,17 @@ __global__ __launch_bounds__(256, 4) void k_classify_prot9(TableView T, TaxView 
             if (lane < nfr && my_win) pk = seedextend_lds(wtaxa + my_start, my_win, min_seed, max_gap);
             se_panic = __ballot(pk);
             wave_lds_sync();
+        }
+        if constexpr (GENERAL) {
+            // ---- aggregate, any strategy: reads at stride 128; no large-scratch pass behind this kernel, so a read with more than
+            // 64 distinct surviving taxa is reported UMGAP_READ_UNSUPPORTED like the over-long ones ----
+            static_assert(GROUP_VIEW_SURVIVOR_WORDS * 4 <= PROT_GROUP * PROT_MAX_BYTES, "the group scratch must fit the staging area");
+            GroupView GV = group_view_over(wkeys, wcnt, reinterpret_cast<uint32_t*>(wbytes), lds_scratch[wv].reads);
+            const uint64_t too_long = __ballot(lane < nr && lds_total[wv][lane] == 0xFFFFFFFFu);
+            general_group<BOUND>(V, GV, method, strategy, factor, lower_bound, wtaxa, PROT_MAX_WINDOWS, nr, lane, se_panic, F, r0, out_taxon, out_status, nullptr, nullptr,
+                                 too_long);
+            wave_lds_sync();
+            continue;
         }
         // ---- aggregate: the group's reads together (agg_group.hpp); its scratch lies over the byte staging area, which is dead now ----
         static_assert(lca_view_words(PROT_GROUP * PROT_MAX_WINDOWS / 8, PROT_GROUP) * 4 <= PROT_GROUP * PROT_MAX_BYTES, "the LCA scratch must fit the staging area");
@@ -601,11 +636,20 @@ extern "C" int umgap_classify_prot9_dev(umgap_index* ix, umgap_taxonomy* tx, int
                                         const uint8_t* d_bytes, const uint64_t* d_frag_offsets, size_t n_reads, uint32_t fragments_per_read,
                                         int seedextend, uint32_t min_seed_size, uint32_t max_gap_size, uint32_t* d_out_taxon,
                                         uint32_t* d_out_status, void* stream) {
+    return umgap_classify_prot9_strategy_dev(ix, tx, method, UMGAP_STRATEGY_LCA_STAR, 0.0f, lower_bound, ranked_only, d_bytes, d_frag_offsets, n_reads,
+                                             fragments_per_read, seedextend, min_seed_size, max_gap_size, d_out_taxon, d_out_status, stream);
+}
+
+extern "C" int umgap_classify_prot9_strategy_dev(umgap_index* ix, umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound,
+                                                 int ranked_only, const uint8_t* d_bytes, const uint64_t* d_frag_offsets, size_t n_reads,
+                                                 uint32_t fragments_per_read, int seedextend, uint32_t min_seed_size, uint32_t max_gap_size,
+                                                 uint32_t* d_out_taxon, uint32_t* d_out_status, void* stream) {
     if (!ix || !tx || (n_reads && (!d_bytes || !d_frag_offsets || !d_out_taxon || !d_out_status))) return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: null argument");
     if (ix->bound_to && ix->bound_to != tx) return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: the index is bound to another taxonomy");
     if (ix->kind != 9) return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: needs a 9-mer index");
     if (fragments_per_read == 0 || fragments_per_read > PROT_MAX_FRAGS) return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: fragments_per_read must be in 1..16");
     if (method != UMGAP_METHOD_TREE && method != UMGAP_METHOD_RMQ) return fail(UMGAP_ERR_INVALID, "unknown method");
+    if (strategy != UMGAP_STRATEGY_LCA_STAR && strategy != UMGAP_STRATEGY_HYBRID && strategy != UMGAP_STRATEGY_MRTL) return fail(UMGAP_ERR_INVALID, "unknown strategy");
     if (ix->device != tx->device) return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: index and taxonomy live on different devices");
     int rc = use_device(ix->device);
     if (rc) return rc;
@@ -614,12 +658,13 @@ extern "C" int umgap_classify_prot9_dev(umgap_index* ix, umgap_taxonomy* tx, int
     if (G * fragments_per_read > 64) G = 64 / fragments_per_read;
     size_t g = ((n_reads + G - 1) / G + 3) / 4;
     if (g > 256 * 8) g = 256 * 8;
-    if (ix->bound_to)
-        hipLaunchKernelGGL(k_classify_prot9<true>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, d_bytes,
+    const bool general = strategy != UMGAP_STRATEGY_LCA_STAR, bound = ix->bound_to != nullptr;
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, strategy, factor, d_bytes,
                            d_frag_offsets, n_reads, fragments_per_read, seedextend ? 1u : 0u, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status);
-    else
-        hipLaunchKernelGGL(k_classify_prot9<false>, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, d_bytes,
-                           d_frag_offsets, n_reads, fragments_per_read, seedextend ? 1u : 0u, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status);
+    };
+    if (general) { if (bound) launch(k_classify_prot9<true, true>); else launch(k_classify_prot9<false, true>); }
+    else { if (bound) launch(k_classify_prot9<true, false>); else launch(k_classify_prot9<false, false>); }
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
 }
