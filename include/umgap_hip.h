@@ -160,6 +160,9 @@ int umgap_index_lookup_var_dev(umgap_index* ix, const uint8_t* d_bytes, const ui
 /* Every (key, taxon) of a whole table, in table order (the caller sorts).  *n_out = number of keys
  * (also when it exceeds cap; then only the first cap are written). */
 int umgap_index_dump9(const umgap_index* ix, uint64_t* keys45, uint32_t* taxa, size_t cap, size_t* n_out);
+/* Variable-length table: key i = heap_out[offsets_out[i] .. + lens_out[i]).  Call once with heap_out = NULL to learn
+ * *heap_bytes_out (the key heap plus the keys the table holds inside its slots, which are unpacked behind it), then again
+ * with a buffer of that size. */
 int umgap_index_dump_var(const umgap_index* ix, uint8_t* heap_out, uint64_t heap_cap, uint64_t* offsets_out,
                          uint32_t* lens_out, uint32_t* taxa_out, size_t cap, size_t* n_out, uint64_t* heap_bytes_out);
 

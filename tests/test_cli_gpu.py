@@ -683,6 +683,16 @@ def test_buildindex_printindex_round_trip(world, tryptic, tmp_path):
         assert subprocess.run([UMGAP, "buildindex"], stdin=fin, stdout=fout).returncode == 0
     rc, out, _ = run(["printindex", str(i)])
     assert rc == 0 and out == b"AAAAA\t2759\nBBBBBB\t9153\n"
+    # keys the table holds inside its slots (<= 17 letters) next to keys in the heap, in one index: the TSV comes back byte for byte
+    rng = np.random.default_rng(4)
+    ks = sorted({rng.choice(np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8), int(rng.integers(1, 40))).tobytes() for _ in range(5000)} | {b"A", b"AA", b"Z" * 17, b"Z" * 18, b"a1", b"K*"})
+    body = b"".join(k + b"\t" + str(i * 7 + 1).encode() + b"\n" for i, k in enumerate(ks))
+    t2, i2 = tmp_path / "mixed.tsv", tmp_path / "mixed.index"
+    t2.write_bytes(body)
+    with open(t2, "rb") as fin, open(i2, "wb") as fout:
+        assert subprocess.run([UMGAP, "buildindex"], stdin=fin, stdout=fout).returncode == 0
+    rc, out, _ = run(["printindex", str(i2)])
+    assert rc == 0 and out == body
     # out-of-order and duplicate keys are refused like fst::MapBuilder::insert does
     for bad in (b"BBBBB\t1\nAAAAA\t2\n", b"AAAAA\t1\nAAAAA\t2\n", b"AAAAA\tx\n", b"AAAAA\n"):
         p = subprocess.run([UMGAP, "buildindex"], input=bad, stdout=subprocess.PIPE, stderr=subprocess.PIPE)

@@ -874,6 +874,39 @@ def test_var_index_matches_dict(api, tmp_path):
         api.Index.build_var([b"A" * 64], np.array([1], np.uint32))
 
 
+def test_var_index_inline_keys(api, tmp_path):
+    """Keys of at most 17 letters live inside their slot (index_var.hip): lengths around the limit, residues that straddle the
+    slot's words, 'A' padding told apart by the length, short keys that do NOT qualify (bytes outside 'A'..'Z'), full tables
+    with overflow chains and the stash -- against a dict."""
+    rng = np.random.default_rng(99)
+    letters = np.frombuffer(b"ABCDEFGHIKLMNPQRSTVWYZ", np.uint8)
+    special = [b"A", b"AA", b"AAA", b"A" * 16, b"A" * 17, b"A" * 18, b"Z", b"Z" * 17, b"Z" * 18, b"ACDEFGHIKLMNPQRST", b"ACDEFGHIKLMNPQRSTV",
+               b"abc", b"A*C", b"\x00", b"\xff" * 5, b"[", b"@", b"AAAAAAAAAAAAZ", b"AAAAAAAAAAAAP", b"AAAAAAAAAAAAAZ", b"AAAAAAAAAAAABA"]
+    keys = set(special)
+    for n in range(1, 22):
+        for _ in range(3000 if n > 4 else 20):
+            keys.add(rng.choice(letters, n).tobytes())
+    for _ in range(2000):                                        # short keys with one byte that does not qualify
+        k = bytearray(rng.choice(letters, int(rng.integers(1, 18))).tobytes())
+        k[int(rng.integers(0, len(k)))] = int(rng.choice([42, 64, 91, 97, 0, 255]))
+        keys.add(bytes(k))
+    keys = sorted(keys)
+    vals = rng.integers(1, 1 << 31, len(keys)).astype(np.uint32)
+    d = dict(zip(keys, vals.tolist()))
+    strangers = [rng.choice(letters, int(rng.integers(1, 22))).tobytes() for _ in range(20000)]
+    near = [k[:-1] for k in keys[:4000] if len(k) > 1] + [k + b"A" for k in keys[:4000]] + [k[:-1] + b"B" for k in keys[4000:8000]]
+    q = keys + strangers + near
+    want = np.array([d.get(p, 0) for p in q], np.uint32)
+    for load in (0.0, 0.93):
+        ix = api.Index.build_var(keys, vals, load_factor=load)
+        assert (ix.lookup_var(q, miss_value=0) == want).all(), load
+    path = tmp_path / "inline.umgapix"
+    ix.save(path)
+    assert (api.Index.open(path).lookup_var(q) == want).all()
+    with pytest.raises(api.UmgapError, match="duplicate"):
+        api.Index.build_var([b"AAAAAK", b"CCCCC", b"AAAAAK"], np.array([1, 2, 3], np.uint32))
+
+
 def test_pept2lca_doc_example_tryptic(api):
     """src/commands/pept2lca.rs:24-46 verbatim."""
     ix = api.Index.build_var([b"AAALTER", b"ENFVYLAK"], np.array([2, 3398], np.uint32))

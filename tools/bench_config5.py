@@ -4,6 +4,7 @@ aggregation strategies the tryptic / sensitivity pipelines use (MRTL -l1/-l5, hy
 Everything is generated on the device.  Prints one JSON line."""
 import ctypes as C
 import json
+import math
 import os
 import sys
 
@@ -17,6 +18,7 @@ from umgap_amd.api import Index, _dev_ptr, _stream_ptr
 dev = torch.device("cuda", 0)
 n_keys = int(sys.argv[1]) if len(sys.argv) > 1 else 400_000_000
 n_q = int(sys.argv[2]) if len(sys.argv) > 2 else 200_000_000
+LENGTHS = sys.argv[3] if len(sys.argv) > 3 else "uniform"        # "uniform": 14..45; "tryptic": 14 + geometric, most keys short
 L = _lib.load()
 
 
@@ -29,7 +31,15 @@ def splitmix(x):
 
 def peptides(first, n, seed):
     idx = torch.arange(first, first + n, dtype=torch.int64, device=dev)
-    lens = 14 + (splitmix(idx ^ seed) & 0x7FFFFFFF) % 32          # 14..45 residues (12-mers would collide at 1 G keys)
+    u = splitmix(idx ^ seed) & 0x7FFFFFFF
+    if LENGTHS == "tryptic":
+        # a cleavage site every ~10 residues: 14 + geometric(p = 0.1), at most 45 (no shorter than 14: the generator's peptides end in
+        # K or R, and random shorter ones collide at 1 G keys).  34 % of the keys have at most 17 residues and live inside their slot;
+        # among real tryptic peptides of 5..50 residues it is about 70 %.
+        g = torch.floor(torch.log((u.to(torch.float64) + 0.5) / 2147483648.0) / math.log(0.9)).to(torch.int64)
+        lens = 14 + torch.clamp(g, max=31)
+    else:
+        lens = 14 + u % 32                                        # 14..45 residues (12-mers would collide at 1 G keys)
     offs = torch.zeros(n + 1, dtype=torch.int64, device=dev)
     torch.cumsum(lens, 0, out=offs[1:])
     total = int(offs[-1].item())
@@ -39,7 +49,7 @@ def peptides(first, n, seed):
 
 
 w = synth.SyntheticWorkload(n_tax=2_500_000, n_keys=1000, build_index=False)
-res = {"n_keys": n_keys, "n_queries": n_q}
+res = {"n_keys": n_keys, "n_queries": n_q, "key_lengths": LENGTHS}
 data, offs, total = peptides(0, n_keys, 43)
 taxa = w.d_taxon_of_row[torch.arange(n_keys, device=dev) % w.n_tax].contiguous()
 t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
@@ -68,11 +78,16 @@ for _ in range(3):
 t1.record(); torch.cuda.synchronize()
 ms = t0.elapsed_time(t1) / 3
 hitrate = float((out != 0).float().mean().item())
+ql = qo[1:] - qo[:-1]
+res["mean_key_bytes"] = round(float(ql.float().mean().item()), 2)
+res["frac_keys_at_most_17"] = round(float((ql <= 17).float().mean().item()), 3)
+del ql
 res["lookup_var_Glookups_per_s"] = round(n_q / ms / 1e6, 2)
 res["hit_rate"] = round(hitrate, 3)
 assert abs(hitrate - 0.7) < 0.01
 assert bool((out[:nm] == taxa[:nm]).all())
 res["var_batches_in_flight"] = int(os.environ.get("UMGAP_VAR_BATCHES", "1"))
+res["inline_keys"] = os.environ.get("UMGAP_VAR_INLINE", "1") != "0"
 # The queries above arrive in the order the members were inserted, so consecutive lookups verify against consecutive heap
 # bytes (cache friendly).  Real reads do not: the same measurement over a RANDOM permutation of a 50 M-query sample.
 n_s = min(n_q, 50_000_000)
@@ -97,6 +112,9 @@ for _ in range(3):
 t1.record(); torch.cuda.synchronize()
 res["lookup_var_shuffled_Glookups_per_s"] = round(n_s / (t0.elapsed_time(t1) / 3) / 1e6, 2)
 del pd, po, pout, pick, perm, plen
+if LENGTHS != "uniform":
+    print(json.dumps(res))
+    sys.exit(0)
 # aggregation: reads of 16 hits drawn like the 9-mer reads (source path / unrelated / miss)
 from umgap_amd.synth import SyntheticWorkload
 del ix, qd, qo, out

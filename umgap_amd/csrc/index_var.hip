@@ -10,6 +10,9 @@
 // reads the home bucket (hash-chosen); a slot whose tag and length agree is VERIFIED byte by byte
 // against the heap, so answers are exact; an overflowed bucket sends the probe on to the next one
 // (<= 15 steps, then the stash).  Hits cost two requests (bucket + heap line), misses one.
+// INLINE keys (round 2): a key of at most 17 bytes, all in 'A'..'Z' -- most tryptic peptides -- is stored IN its slot at 5 bits per
+// residue: bit 63 of the offset word set, its low 63 bits and the 22 low bits of the tag field hold the 85 key bits (the length
+// field stays).  Such a slot is compared word for word: exact, and no heap request at all -- one request per lookup, hit or miss.
 #include <algorithm>
 #include <array>
 #include <cmath>
@@ -24,7 +27,72 @@ namespace umgap {
 static constexpr uint32_t VAR_SLOTS = 4, VAR_MAX_DISP = 15, VAR_MAX_LEN = 63;
 static constexpr uint64_t VAR_EMPTY = ~0ull;
 
+static constexpr uint32_t VAR_INLINE_MAX = 17;
+static constexpr uint64_t VAR_INLINE = 1ull << 63;
+
 typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+
+// (lo, hi) of an inline key: lo = the slot's offset word (flag included; never all ones: a residue code is < 26), hi = the
+// 22 bits that go to the tag field.  `byte(i)` yields key byte i.  False: the key does not qualify.
+template <class Byte>
+__host__ __device__ inline bool pack_inline_with(Byte byte, uint32_t len, uint64_t& lo, uint32_t& hi) {
+    lo = 0;
+    hi = 0;
+    if (len > VAR_INLINE_MAX) return false;
+    uint64_t x0 = 0, x1 = 0;
+    bool ok = true;
+#pragma unroll
+    for (uint32_t i = 0; i < VAR_INLINE_MAX; i++) {
+        if (i < len) {
+            const uint32_t c = (uint32_t)byte(i) - 'A';
+            ok = ok && c < 26u;
+            const uint32_t sh = 5 * i;
+            if (sh < 64) {
+                x0 |= (uint64_t)(c & 31u) << sh;
+                if (sh > 59) x1 |= (uint64_t)(c & 31u) >> (64 - sh);
+            } else x1 |= (uint64_t)(c & 31u) << (sh - 64);
+        }
+    }
+    lo = x0 | VAR_INLINE;
+    hi = (uint32_t)((x1 << 1) | (x0 >> 63));
+    return ok;
+}
+__host__ __device__ inline bool pack_inline(const uint8_t* p, uint32_t len, uint64_t& lo, uint32_t& hi) {
+    return pack_inline_with([p](uint32_t i) { return p[i]; }, len, lo, hi);
+}
+// The same from the key's first 20 bytes as five little-endian words (bytes past `len` may hold anything): four residues per
+// word at a time -- the probe's version, ~80 VALU operations per key instead of ~170.
+__device__ __forceinline__ bool pack_inline_words(const uint32_t (&d)[5], uint32_t len, uint64_t& lo, uint32_t& hi) {
+    uint32_t u[5], bad = 0;
+#pragma unroll
+    for (int w = 0; w < 5; w++) {
+        const int nv = (int)len - 4 * w;                                     // key bytes in this word (may be <= 0 or >= 4)
+        const uint32_t mask = nv >= 4 ? 0xFFFFFFFFu : (nv <= 0 ? 0u : (0xFFFFFFFFu >> (32 - 8 * nv)));
+        const uint32_t x = d[w];
+        // a byte outside 'A'..'Z' raises its top bit in one of the three terms (a borrow or carry only travels upwards, into
+        // bytes that are then bad or masked themselves)
+        bad |= (x | (x + 0x25252525u) | ~((x | 0x80808080u) - 0x41414141u)) & 0x80808080u & mask;
+        const uint32_t c = (x - 0x41414141u) & mask;                          // four residue codes, 8 bits apart
+        const uint32_t t = (c & 0x001F001Fu) | ((c & 0x1F001F00u) >> 3);      // 10 + 10 bits, 16 bits apart
+        u[w] = (t & 0x3FFu) | ((t >> 6) & 0xFFC00u);                          // 20 bits
+    }
+    const uint64_t x0 = (uint64_t)u[0] | ((uint64_t)u[1] << 20) | ((uint64_t)u[2] << 40) | ((uint64_t)u[3] << 60);
+    const uint32_t x1 = (u[3] >> 4) | (u[4] << 16);
+    lo = x0 | VAR_INLINE;
+    hi = (x1 << 1) | (uint32_t)(x0 >> 63);
+    return bad == 0;
+}
+// the key bytes of an inline slot (word0 = tag field | len << 25 | ..., off = offset word); returns the length
+__host__ inline uint32_t unpack_inline(uint32_t word0, uint64_t off, uint8_t* out) {
+    const uint32_t len = (word0 >> 25) & 63u, hi = word0 & 0x01FFFFFFu;
+    const uint64_t x0 = (off & ~VAR_INLINE) | ((uint64_t)(hi & 1u) << 63), x1 = hi >> 1;
+    for (uint32_t i = 0; i < len && i < VAR_INLINE_MAX; i++) {
+        const uint32_t sh = 5 * i;
+        uint64_t c = sh < 64 ? (x0 >> sh) | (sh > 59 ? x1 << (64 - sh) : 0ull) : x1 >> (sh - 64);
+        out[i] = (uint8_t)('A' + (c & 31u));
+    }
+    return len;
+}
 
 // 8 bytes at a time (unaligned 64-bit loads; the last word overlaps the previous one when len is
 // not a multiple of 8), byte-wise only for keys shorter than 8
@@ -58,6 +126,7 @@ struct VarView {
     const uint64_t* stash_off;
     const uint32_t* stash_val;
     uint32_t n_stash;
+    uint32_t inline_max;    // keys of at most this many letters live in their slot (0: none do -- tables written before round 2)
 };
 
 struct umgap_var_index {
@@ -68,7 +137,8 @@ struct umgap_var_index {
     uint64_t* d_stash_off = nullptr;
     uint32_t* d_stash_val = nullptr;
     uint32_t n_stash = 0;
-    VarView view() const { return VarView{d_slots, d_heap, nb, d_stash_hash, d_stash_off, d_stash_val, n_stash}; }
+    uint32_t inline_max = 0;
+    VarView view() const { return VarView{d_slots, d_heap, nb, d_stash_hash, d_stash_off, d_stash_val, n_stash, inline_max}; }
 };
 
 namespace {
@@ -86,6 +156,14 @@ __device__ __forceinline__ bool bytes_equal(const uint8_t* a, const uint8_t* b, 
     for (uint32_t i = 0; i < len; i++)
         if (a[i] != b[i]) return false;
     return true;
+}
+
+// does slot word (w0, off) hold the query?  (qin: the query is an inline key (kq, its tag-field bits already in `want`))
+__device__ __forceinline__ bool slot_holds(const VarView& T, uint32_t w0, uint64_t off, uint32_t want, bool qin, uint64_t kq, const uint8_t* qp, uint32_t len) {
+    if (off == VAR_EMPTY || (w0 & 0x7FFFFFFFu) != want) return false;
+    if (qin) return off == kq;
+    if (off >> 63) return false;          // an inline slot whose 25 tag-field bits happen to equal the query's tag
+    return bytes_equal(T.heap + off, qp, len);
 }
 
 __device__ __forceinline__ uint32_t var_stash_lookup(const VarView& T, uint64_t h, const uint8_t* q, uint32_t len, uint32_t miss) {
@@ -116,6 +194,10 @@ __device__ __noinline__ void lookup_batch_global(const uint8_t* __restrict__ qby
             uint64_t l64 = qoff[i + 1] - o;
             if (l64 >= 1 && l64 <= VAR_MAX_LEN) { len = (uint32_t)l64; h = hash_bytes(qbytes + o, len); valid = 1; }
         }
+        uint64_t kq = 0;
+        uint32_t khi = 0;
+        const uint32_t inl = valid && len <= T.inline_max && pack_inline(qbytes + o, len, kq, khi) ? 1u : 0u;
+        const uint32_t wantv = (inl ? khi : ((uint32_t)h & 0x01FFFFFFu)) | (len << 25);
         // Three phases so that the four rounds overlap their memory round trips (walking each round to its end before
         // the next started, as the first version did, kept 16 requests per wave in flight; +6 %.  Fetching all words of
         // a key in one go for hashing / comparison instead of word by word was tried twice (always 8 clamped words; predicated
@@ -124,8 +206,8 @@ __device__ __noinline__ void lookup_batch_global(const uint8_t* __restrict__ qby
         //   2. the first 8 key bytes in the heap of every slot whose tag and length agree (default cache policy: the
         //      line stays close for phase 3), together with the query's first word;
         //   3. full comparison, then the rare displacement chain / stash.
-        uint32_t res[4], v[4], ln[4], want[4];
-        uint64_t hq[4], bucket[4];
+        uint32_t res[4], v[4], ln[4], want[4], qi[4];
+        uint64_t hq[4], bucket[4], kqr[4];
         const uint8_t* qp[4];
         u32x4 e[4];
 #pragma unroll
@@ -138,7 +220,9 @@ __device__ __noinline__ void lookup_batch_global(const uint8_t* __restrict__ qby
             hq[r] = ((uint64_t)hh << 32) | hl;
             qp[r] = qbytes + (((uint64_t)oh << 32) | ol);
             bucket[r] = __umul64hi(hq[r], T.nb);
-            want[r] = ((uint32_t)hq[r] & 0x01FFFFFFu) | (ln[r] << 25);
+            want[r] = (uint32_t)__shfl((int)wantv, src, 64);
+            qi[r] = (uint32_t)__shfl((int)inl, src, 64);
+            kqr[r] = (uint64_t)(uint32_t)__shfl((int)(uint32_t)kq, src, 64) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(kq >> 32), src, 64) << 32);
             e[r] = v[r] ? __builtin_nontemporal_load(T.slots + bucket[r] * VAR_SLOTS + j) : u32x4{0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu};
         }
         uint64_t hw[4], qw[4];
@@ -146,9 +230,9 @@ __device__ __noinline__ void lookup_batch_global(const uint8_t* __restrict__ qby
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const uint64_t off = ((uint64_t)e[r].w << 32) | e[r].z;
-            cand[r] = v[r] && off != VAR_EMPTY && (e[r].x & 0x7FFFFFFFu) == want[r];
+            cand[r] = v[r] && off != VAR_EMPTY && (e[r].x & 0x7FFFFFFFu) == want[r] && (qi[r] ? off == kqr[r] : !(off >> 63));
             hw[r] = qw[r] = 0;
-            if (cand[r] && ln[r] >= 8) {
+            if (cand[r] && !qi[r] && ln[r] >= 8) {
                 hw[r] = *reinterpret_cast<const u64_unaligned*>(T.heap + off);
                 qw[r] = *reinterpret_cast<const u64_unaligned*>(qp[r]);
             }
@@ -159,7 +243,7 @@ __device__ __noinline__ void lookup_batch_global(const uint8_t* __restrict__ qby
             if (v[r]) {  // quad-uniform
                 const uint64_t off = ((uint64_t)e[r].w << 32) | e[r].z;
                 uint32_t val = 0, hit = 0;
-                if (cand[r] && hw[r] == qw[r] && bytes_equal(T.heap + off, qp[r], ln[r])) { hit = 1; val = e[r].y; }
+                if (cand[r] && (qi[r] || (hw[r] == qw[r] && bytes_equal(T.heap + off, qp[r], ln[r])))) { hit = 1; val = e[r].y; }
                 uint32_t ovf = (j == 0) ? (e[r].x >> 31) : 0u;
                 uint32_t f = quad_or(hit | (ovf << 1));
                 val = quad_or(val);
@@ -169,7 +253,7 @@ __device__ __noinline__ void lookup_batch_global(const uint8_t* __restrict__ qby
                     u32x4 ed = __builtin_nontemporal_load(T.slots + (bucket[r] + d) * VAR_SLOTS + j);
                     uint64_t offd = ((uint64_t)ed.w << 32) | ed.z;
                     val = 0; hit = 0;
-                    if (offd != VAR_EMPTY && (ed.x & 0x7FFFFFFFu) == want[r] && bytes_equal(T.heap + offd, qp[r], ln[r])) { hit = 1; val = ed.y; }
+                    if (slot_holds(T, ed.x, offd, want[r], qi[r], kqr[r], qp[r], ln[r])) { hit = 1; val = ed.y; }
                     ovf = (j == 0) ? (ed.x >> 31) : 0u;
                     f = quad_or(hit | (ovf << 1));
                     val = quad_or(val);
@@ -239,12 +323,14 @@ __device__ __forceinline__ uint64_t hash_lds(const uint32_t* w, uint32_t s, uint
 
 // the rare rest of one round (quad-uniform call): every candidate slot of the home bucket verified by its own lane against the
 // query bytes in global memory, then the displacement chain, then the stash -- the round-1 sequence
-__device__ __noinline__ uint32_t lookup_round_slow(const VarView& T, const uint8_t* qp, uint32_t len, uint64_t hq, u32x4 e, uint32_t miss, uint32_t j) {
+// (want / qin / kq: what the slot's first word must be, whether the query is an inline key, and its offset word if so -- all
+// computed once by the lane that owns the query)
+__device__ __noinline__ uint32_t lookup_round_slow(const VarView& T, const uint8_t* qp, uint32_t len, uint64_t hq, u32x4 e, uint32_t miss, uint32_t j,
+                                                    uint32_t want, bool qin, uint64_t kq) {
     const uint64_t bucket = __umul64hi(hq, T.nb);
-    const uint32_t want = ((uint32_t)hq & 0x01FFFFFFu) | (len << 25);
     const uint64_t off = ((uint64_t)e.w << 32) | e.z;
     uint32_t hit = 0, vv = 0, r_out = miss;
-    if (off != VAR_EMPTY && (e.x & 0x7FFFFFFFu) == want && bytes_equal(T.heap + off, qp, len)) { hit = 1; vv = e.y; }
+    if (slot_holds(T, e.x, off, want, qin, kq, qp, len)) { hit = 1; vv = e.y; }
     uint32_t f = quad_or(hit | (((j == 0) ? (e.x >> 31) : 0u) << 1));
     vv = quad_or(vv);
     bool found = f & 1u, go = !found && (f & 2u);
@@ -253,7 +339,7 @@ __device__ __noinline__ uint32_t lookup_round_slow(const VarView& T, const uint8
         const u32x4 ed = __builtin_nontemporal_load(T.slots + (bucket + d) * VAR_SLOTS + j);
         const uint64_t offd = ((uint64_t)ed.w << 32) | ed.z;
         vv = 0; hit = 0;
-        if (offd != VAR_EMPTY && (ed.x & 0x7FFFFFFFu) == want && bytes_equal(T.heap + offd, qp, len)) { hit = 1; vv = ed.y; }
+        if (slot_holds(T, ed.x, offd, want, qin, kq, qp, len)) { hit = 1; vv = ed.y; }
         f = quad_or(hit | (((j == 0) ? (ed.x >> 31) : 0u) << 1));
         vv = quad_or(vv);
         if (f & 1u) { r_out = vv; found = true; go = false; }
@@ -265,7 +351,7 @@ __device__ __noinline__ uint32_t lookup_round_slow(const VarView& T, const uint8
 
 // NB batches of 64 queries per wave and step.
 template <int NB>
-__global__ __launch_bounds__(256) void k_lookup_var(const uint8_t* __restrict__ qbytes, const uint64_t* __restrict__ qoff, size_t n,
+__global__ __launch_bounds__(256, NB == 1 ? 4 : 3) void k_lookup_var(const uint8_t* __restrict__ qbytes, const uint64_t* __restrict__ qoff, size_t n,
                                                     uint32_t miss, uint32_t* __restrict__ out, VarView T, uint32_t force_global) {
     __shared__ uint32_t lds[4][NB][VAR_STAGE / 4];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
@@ -327,10 +413,30 @@ __global__ __launch_bounds__(256) void k_lookup_var(const uint8_t* __restrict__ 
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // ---- 2. hash from LDS -------------------------------------------------------------------------------------------------
+        // ---- 2. hash from LDS; short keys packed for the word-for-word comparison with inline slots ---------------------------
+        uint64_t kq[NB];
+        uint32_t wantv[NB];          // what the slot's first word must be (bit 31 aside)
 #pragma unroll
-        for (int b = 0; b < NB; b++)
-            if (meta[b] >> 19) h[b] = hash_lds(lds[wv][b], meta[b] & 0x1FFFu, (meta[b] >> 13) & 63u);
+        for (int b = 0; b < NB; b++) {
+            kq[b] = 0;
+            wantv[b] = 0;
+            if (meta[b] >> 19) {
+                const uint32_t* w = lds[wv][b];
+                const uint32_t s = meta[b] & 0x1FFFu, len = (meta[b] >> 13) & 63u;
+                h[b] = hash_lds(w, s, len);
+                uint32_t khi = 0;
+                bool inl = false;
+                if (len <= T.inline_max) {
+                    const uint32_t k = s >> 2, sh = s & 3u;
+                    const uint32_t a0 = w[k], a1 = w[k + 1], a2 = w[k + 2], a3 = w[k + 3], a4 = w[k + 4], a5 = w[k + 5];
+                    const uint32_t d[5] = {__builtin_amdgcn_alignbyte(a1, a0, sh), __builtin_amdgcn_alignbyte(a2, a1, sh), __builtin_amdgcn_alignbyte(a3, a2, sh),
+                                           __builtin_amdgcn_alignbyte(a4, a3, sh), __builtin_amdgcn_alignbyte(a5, a4, sh)};
+                    inl = pack_inline_words(d, len, kq[b], khi);
+                }
+                wantv[b] = (inl ? khi : ((uint32_t)h[b] & 0x01FFFFFFu)) | (len << 25);
+                meta[b] |= inl ? (1u << 26) : 0u;
+            }
+        }
         // ---- 3. the home buckets of NB x 4 rounds, back to back -----------------------------------------------------------------
         uint32_t rm[NB][4], want[NB][4];     // rm: the round's meta (the owning lane's) | first candidate lane << 20 (4 = none) | #candidates << 23
         u32x4 e[NB][4], hp[NB][4];
@@ -342,8 +448,8 @@ __global__ __launch_bounds__(256) void k_lookup_var(const uint8_t* __restrict__ 
                 rm[b][r] = (uint32_t)__shfl((int)meta[b], src, 64);
                 const uint32_t hl = (uint32_t)__shfl((int)(uint32_t)h[b], src, 64), hh = (uint32_t)__shfl((int)(uint32_t)(h[b] >> 32), src, 64);
                 const uint64_t hq = ((uint64_t)hh << 32) | hl;
-                want[b][r] = (hl & 0x01FFFFFFu) | (((rm[b][r] >> 13) & 63u) << 25);
-                e[b][r] = (rm[b][r] >> 19) ? __builtin_nontemporal_load(T.slots + __umul64hi(hq, T.nb) * VAR_SLOTS + j) : u32x4{0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                want[b][r] = (uint32_t)__shfl((int)wantv[b], src, 64);
+                e[b][r] = ((rm[b][r] >> 19) & 1u) ? __builtin_nontemporal_load(T.slots + __umul64hi(hq, T.nb) * VAR_SLOTS + j) : u32x4{0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu};
             }
         // ---- 4. the candidates' heap bytes, a quad per key ---------------------------------------------------------------------
 #pragma unroll
@@ -351,14 +457,18 @@ __global__ __launch_bounds__(256) void k_lookup_var(const uint8_t* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const uint64_t off = ((uint64_t)e[b][r].w << 32) | e[b][r].z;
-                const uint32_t cand = ((rm[b][r] >> 19) && off != VAR_EMPTY && (e[b][r].x & 0x7FFFFFFFu) == want[b][r]) ? 1u : 0u;
+                const int srcq = 16 * r + (int)q;
+                const uint64_t kqr = (uint64_t)(uint32_t)__shfl((int)(uint32_t)kq[b], srcq, 64) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(kq[b] >> 32), srcq, 64) << 32);
+                const bool qin = (rm[b][r] >> 26) & 1u;
+                // an inline query matches its slot word for word (that IS the verification); any other candidate is a heap slot
+                const uint32_t cand = (((rm[b][r] >> 19) & 1u) && off != VAR_EMPTY && (e[b][r].x & 0x7FFFFFFFu) == want[b][r] && (qin ? off == kqr : !(off >> 63))) ? 1u : 0u;
                 const uint32_t bits = quad_or(cand << j);
                 const uint32_t ci = bits ? (uint32_t)__builtin_ctz(bits) : 4u;
                 rm[b][r] |= (ci << 20) | ((uint32_t)__builtin_popcount(bits) << 23);
                 const int srcl = (int)((lane & ~3u) | (ci & 3u));
                 const uint32_t ol = (uint32_t)__shfl((int)e[b][r].z, srcl, 64), oh = (uint32_t)__shfl((int)e[b][r].w, srcl, 64);
                 hp[b][r] = u32x4{0u, 0u, 0u, 0u};
-                if (ci < 4u && 16u * j < ((rm[b][r] >> 13) & 63u))
+                if (ci < 4u && !qin && 16u * j < ((rm[b][r] >> 13) & 63u))
                     hp[b][r] = *reinterpret_cast<const u32x4_unaligned*>(T.heap + ((((uint64_t)oh << 32) | ol) + 16u * j));
             }
         // ---- 5. compare with the query bytes in LDS; the rare rest on the round-1 path ------------------------------------------
@@ -370,15 +480,17 @@ __global__ __launch_bounds__(256) void k_lookup_var(const uint8_t* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 uint32_t r_out = miss;
-                const uint32_t m = rm[b][r], ln = (m >> 13) & 63u, ci = (m >> 20) & 7u, nc = m >> 23;
+                const uint32_t m = rm[b][r], ln = (m >> 13) & 63u, ci = (m >> 20) & 7u, nc = (m >> 23) & 7u;
+                const bool qin = (m >> 26) & 1u;
                 // the key's offset and hash live in lane 16r + q: fetched while every lane is still active (a shuffle from a lane that
                 // the quad-uniform branch below has switched off reads nothing)
                 const int src = 16 * r + (int)q;
                 const uint64_t oq = (uint64_t)(uint32_t)__shfl((int)(uint32_t)o[b], src, 64) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(o[b] >> 32), src, 64) << 32);
                 const uint64_t hq = (uint64_t)(uint32_t)__shfl((int)(uint32_t)h[b], src, 64) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(h[b] >> 32), src, 64) << 32);
+                const uint64_t kqs = (uint64_t)(uint32_t)__shfl((int)(uint32_t)kq[b], src, 64) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(kq[b] >> 32), src, 64) << 32);
                 if ((m >> 19) & 1u) {   // quad-uniform
                     uint32_t mism = 0;
-                    if (ci < 4u && 16u * j < ln) {
+                    if (ci < 4u && !qin && 16u * j < ln) {
                         const uint32_t* w = lds[wv][b];
                         const uint32_t s = (m & 0x1FFFu) + 16u * j, k = s >> 2, sh = s & 3u;
                         const uint32_t w0 = w[k], w1 = w[k + 1], w2 = w[k + 2], w3 = w[k + 3], w4 = w[k + 4];
@@ -399,7 +511,7 @@ __global__ __launch_bounds__(256) void k_lookup_var(const uint8_t* __restrict__ 
                     if (ci < 4u && !bad) r_out = val;
                     else if (nc > 1u || ovf) {
                         // another slot of the bucket shares tag and length (~1e-7), or the home bucket overflowed at build time
-                        r_out = lookup_round_slow(T, qbytes + oq, ln, hq, e[b][r], miss, j);
+                        r_out = lookup_round_slow(T, qbytes + oq, ln, hq, e[b][r], miss, j, want[b][r], qin, kqs);
                     }
                 }
                 res[r] = r_out;
@@ -419,7 +531,7 @@ __global__ __launch_bounds__(256) void k_lookup_var(const uint8_t* __restrict__ 
 
 __global__ __launch_bounds__(256) void k_insert_var(u32x4* __restrict__ slots, uint64_t nb, const uint8_t* __restrict__ heap,
                                                     const uint64_t* __restrict__ off, const uint32_t* __restrict__ vals, size_t n,
-                                                    VarFlags* flags, uint64_t* __restrict__ stash) {
+                                                    VarFlags* flags, uint64_t* __restrict__ stash, uint32_t inline_max) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
@@ -428,13 +540,17 @@ __global__ __launch_bounds__(256) void k_insert_var(u32x4* __restrict__ slots, u
         uint32_t len = (uint32_t)l64;
         uint64_t h = hash_bytes(heap + o, len);
         uint64_t bucket = __umul64hi(h, nb);
-        uint32_t w0 = ((uint32_t)h & 0x01FFFFFFu) | (len << 25);
+        uint64_t kq = 0;
+        uint32_t khi = 0;
+        const bool inl = len <= inline_max && pack_inline(heap + o, len, kq, khi);
+        const uint32_t w0 = (inl ? khi : ((uint32_t)h & 0x01FFFFFFu)) | (len << 25);
+        const unsigned long long word = inl ? kq : o;     // the offset word: the key itself, or where it lies in the heap
         bool placed = false;
         for (uint32_t d = 0; d <= VAR_MAX_DISP && !placed; d++) {
             uint32_t* s = reinterpret_cast<uint32_t*>(slots + (bucket + d) * VAR_SLOTS);
             for (uint32_t k = 0; k < VAR_SLOTS && !placed; k++) {
                 unsigned long long* offp = reinterpret_cast<unsigned long long*>(s + 4 * k + 2);  // w2:w3, 8-byte aligned
-                if (atomicCAS(offp, (unsigned long long)VAR_EMPTY, (unsigned long long)o) == VAR_EMPTY) {
+                if (atomicCAS(offp, (unsigned long long)VAR_EMPTY, word) == VAR_EMPTY) {
                     s[4 * k + 1] = vals[i];
                     atomicOr(s + 4 * k, w0);  // OR, not store: slot 0's word also carries the overflow flag
                     placed = true;
@@ -514,6 +630,10 @@ int var_build(umgap_var_index** out, uint8_t* d_heap, uint64_t heap_bytes, const
     v->d_heap = d_heap;
     v->heap_bytes = heap_bytes;
     v->n_keys = n;
+    {
+        const char* e = getenv("UMGAP_VAR_INLINE");      // A/B switch of the measurement tools: 0 = every key in the heap
+        v->inline_max = (e && e[0] == '0') ? 0u : VAR_INLINE_MAX;
+    }
     VarFlags* d_flags = nullptr;
     uint64_t* d_stash = nullptr;
     uint32_t* d_got = nullptr;
@@ -529,7 +649,7 @@ int var_build(umgap_var_index** out, uint8_t* d_heap, uint64_t heap_bytes, const
         v->nb = nb;
         hipLaunchKernelGGL(k_fill_var, dim3(grid_for(nslots)), dim3(256), 0, stream, v->d_slots, nslots);
         (void)hipMemsetAsync(d_flags, 0, sizeof(VarFlags), stream);
-        if (n) hipLaunchKernelGGL(k_insert_var, dim3(grid_for(n)), dim3(256), 0, stream, v->d_slots, nb, d_heap, d_off, d_vals, n, d_flags, d_stash);
+        if (n) hipLaunchKernelGGL(k_insert_var, dim3(grid_for(n)), dim3(256), 0, stream, v->d_slots, nb, d_heap, d_off, d_vals, n, d_flags, d_stash, v->inline_max);
         VarFlags h{};
         hipError_t e = hipMemcpyAsync(&h, d_flags, sizeof(h), hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -658,6 +778,7 @@ int umgap_index_dump_var(const umgap_index* ix, uint8_t* heap_out, uint64_t heap
     *heap_bytes_out = v->heap_bytes;
     if (heap_out && heap_cap >= v->heap_bytes && v->heap_bytes) UMGAP_HIP(hipMemcpy(heap_out, v->d_heap, v->heap_bytes, hipMemcpyDeviceToHost));
     size_t n = 0;
+    uint64_t appended = 0;      // inline keys are unpacked behind the heap copy
     const size_t total = (size_t)(v->nb + VAR_MAX_DISP) * VAR_SLOTS, chunk = 1u << 22;
     std::vector<uint32_t> buf(chunk * 4);
     for (size_t s0 = 0; s0 < total; s0 += chunk) {
@@ -666,10 +787,19 @@ int umgap_index_dump_var(const umgap_index* ix, uint8_t* heap_out, uint64_t heap
         for (size_t i = 0; i < cnt; i++) {
             uint64_t off = ((uint64_t)buf[4 * i + 3] << 32) | buf[4 * i + 2];
             if (off == VAR_EMPTY) continue;
-            if (n < cap) { offsets_out[n] = off; lens_out[n] = (buf[4 * i] >> 25) & 63u; taxa_out[n] = buf[4 * i + 1]; }
+            const uint32_t len = (buf[4 * i] >> 25) & 63u;
+            if (off & VAR_INLINE) {
+                uint8_t key[VAR_INLINE_MAX];
+                unpack_inline(buf[4 * i], off, key);
+                off = v->heap_bytes + appended;
+                if (heap_out && heap_cap >= off + len) memcpy(heap_out + off, key, len);
+                appended += len;
+            }
+            if (n < cap) { offsets_out[n] = off; lens_out[n] = len; taxa_out[n] = buf[4 * i + 1]; }
             n++;
         }
     }
+    *heap_bytes_out = v->heap_bytes + appended;
     if (v->n_stash) {
         std::vector<uint64_t> so(v->n_stash);
         std::vector<uint32_t> sv(v->n_stash);
@@ -729,7 +859,7 @@ int var_save(const umgap_index* ix, FILE* f) {
     const umgap_var_index* v = ix->var;
     IndexFileHeader h{};
     memcpy(h.magic, "UMGAPIX1", 8);
-    h.version = 1; h.kind = 2; h.n_keys = v->n_keys; h.m = 0; h.nb = 0;
+    h.version = 1; h.kind = 2; h.n_keys = v->n_keys; h.m = v->inline_max; h.nb = 0;
     h.mix_c1 = v->nb; h.mix_c2 = v->heap_bytes; h.r_bits = VAR_MAX_DISP; h.slots = VAR_SLOTS; h.n_stash = v->n_stash;
     bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
     const size_t chunk = 64u << 20;
@@ -755,6 +885,8 @@ int var_open(umgap_index* ix, const IndexFileHeader& h, FILE* f, const char* pat
     ix->var = v;
     ix->kind = 2;
     v->nb = h.mix_c1; v->heap_bytes = h.mix_c2; v->n_keys = h.n_keys; v->n_stash = (uint32_t)h.n_stash;
+    if (h.m > VAR_INLINE_MAX) return fail(UMGAP_ERR_FORMAT, std::string(path) + ": unsupported UMGAPIX1 (var) inline-key length");
+    v->inline_max = h.m;      // 0 in files written before inline keys existed: every slot points into the heap
     ix->n_keys = h.n_keys;
     const size_t chunk = 64u << 20;
     std::vector<char> buf(chunk);
