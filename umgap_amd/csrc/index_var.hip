@@ -183,7 +183,9 @@ __device__ __forceinline__ uint32_t var_stash_lookup(const VarView& T, uint64_t 
 // One batch of 64 queries (one per lane) straight from global memory: the round-1 kernel body, kept for batches whose bytes
 // cannot be staged in LDS (ill-formed offsets: a "key" longer than 63 bytes inside the batch) -- see k_lookup_var below.
 __device__ __noinline__ void lookup_batch_global(const uint8_t* __restrict__ qbytes, const uint64_t* __restrict__ qoff, size_t n, size_t base,
-                                                    uint32_t miss, uint32_t* __restrict__ out, const VarView& T, uint32_t lane) {
+                                                    uint32_t miss, uint32_t* __restrict__ out, const VarView T, uint32_t lane) {
+    // (T by value, here and in lookup_round_slow: a reference would put the kernel's copy on the stack, and every T.slots / T.nb of
+    // the hot loop would become a scratch load whose s_waitcnt vmcnt(0) also waits for whatever the pipelined kernel has in flight)
     const uint32_t q = lane >> 2, j = lane & 3;
     {
         size_t i = base + lane;
@@ -325,7 +327,7 @@ __device__ __forceinline__ uint64_t hash_lds(const uint32_t* w, uint32_t s, uint
 // query bytes in global memory, then the displacement chain, then the stash -- the round-1 sequence
 // (want / qin / kq: what the slot's first word must be, whether the query is an inline key, and its offset word if so -- all
 // computed once by the lane that owns the query)
-__device__ __noinline__ uint32_t lookup_round_slow(const VarView& T, const uint8_t* qp, uint32_t len, uint64_t hq, u32x4 e, uint32_t miss, uint32_t j,
+__device__ __noinline__ uint32_t lookup_round_slow(const VarView T, const uint8_t* qp, uint32_t len, uint64_t hq, u32x4 e, uint32_t miss, uint32_t j,
                                                     uint32_t want, bool qin, uint64_t kq) {
     const uint64_t bucket = __umul64hi(hq, T.nb);
     const uint64_t off = ((uint64_t)e.w << 32) | e.z;
@@ -349,183 +351,244 @@ __device__ __noinline__ uint32_t lookup_round_slow(const VarView& T, const uint8
     return r_out;
 }
 
-// NB batches of 64 queries per wave and step.
-template <int NB>
-__global__ __launch_bounds__(256, NB == 1 ? 4 : 3) void k_lookup_var(const uint8_t* __restrict__ qbytes, const uint64_t* __restrict__ qoff, size_t n,
-                                                    uint32_t miss, uint32_t* __restrict__ out, VarView T, uint32_t force_global) {
-    __shared__ uint32_t lds[4][NB][VAR_STAGE / 4];
-    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
+// ---- steps 2..5 for ONE staged batch (w = the wave's LDS strip that holds its bytes) --------------------------------------------
+// per-lane state of a batch: meta = staged offset (13 bits) | len << 13 (6 bits) | valid << 19 | inline << 26; the key of lane l lies
+// at a0 + (meta & 0x1FFF) in the query buffer (a0 = the 16-byte aligned absolute address the strip starts at)
+struct VarLaneKey {
+    uint64_t h, kq;      // hash; offset word of an inline key
+    uint32_t meta, wantv;   // wantv: what the slot's first word must be (bit 31 aside)
+};
+
+// 2. hash from LDS; short keys packed for the word-for-word comparison with inline slots
+__device__ __forceinline__ VarLaneKey var_hash_and_pack(const VarView& T, const uint32_t* w, uint32_t meta) {
+    VarLaneKey K{0, 0, meta, 0};
+    if ((meta >> 19) & 1u) {
+        const uint32_t s = meta & 0x1FFFu, len = (meta >> 13) & 63u;
+        K.h = hash_lds(w, s, len);
+        uint32_t khi = 0;
+        bool inl = false;
+        if (len <= T.inline_max) {
+            const uint32_t k = s >> 2, sh = s & 3u;
+            const uint32_t a0 = w[k], a1 = w[k + 1], a2 = w[k + 2], a3 = w[k + 3], a4 = w[k + 4], a5 = w[k + 5];
+            const uint32_t d[5] = {__builtin_amdgcn_alignbyte(a1, a0, sh), __builtin_amdgcn_alignbyte(a2, a1, sh), __builtin_amdgcn_alignbyte(a3, a2, sh),
+                                   __builtin_amdgcn_alignbyte(a4, a3, sh), __builtin_amdgcn_alignbyte(a5, a4, sh)};
+            inl = pack_inline_words(d, len, K.kq, khi);
+        }
+        K.wantv = (inl ? khi : ((uint32_t)K.h & 0x01FFFFFFu)) | (len << 25);
+        K.meta |= inl ? (1u << 26) : 0u;
+    }
+    return K;
+}
+
+// 3..5: the home buckets of the 4 rounds back to back (a quad per bucket), the candidates' heap bytes (lane j: bytes 16j..16j+15),
+// comparison with the query bytes in LDS; the rare rest on the round-1 path
+__device__ __forceinline__ void var_probe_staged(const VarView& T, const uint32_t* w, const VarLaneKey& K, uint64_t a0, size_t base, size_t n, uint32_t miss,
+                                                 uint32_t* __restrict__ out, uint32_t lane) {
+    const uint32_t q = lane >> 2, j = lane & 3;
+    uint32_t rm[4], want[4];     // rm: the round's meta (the owning lane's) | first candidate lane << 20 (4 = none) | #candidates << 23
+    u32x4 e[4], hp[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int src = 16 * r + (int)q;
+        rm[r] = (uint32_t)__shfl((int)K.meta, src, 64);
+        const uint32_t hl = (uint32_t)__shfl((int)(uint32_t)K.h, src, 64), hh = (uint32_t)__shfl((int)(uint32_t)(K.h >> 32), src, 64);
+        const uint64_t hq = ((uint64_t)hh << 32) | hl;
+        want[r] = (uint32_t)__shfl((int)K.wantv, src, 64);
+        e[r] = ((rm[r] >> 19) & 1u) ? __builtin_nontemporal_load(T.slots + __umul64hi(hq, T.nb) * VAR_SLOTS + j) : u32x4{0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const uint64_t off = ((uint64_t)e[r].w << 32) | e[r].z;
+        const int srcq = 16 * r + (int)q;
+        const uint64_t kqr = (uint64_t)(uint32_t)__shfl((int)(uint32_t)K.kq, srcq, 64) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(K.kq >> 32), srcq, 64) << 32);
+        const bool qin = (rm[r] >> 26) & 1u;
+        // an inline query matches its slot word for word (that IS the verification); any other candidate is a heap slot
+        const uint32_t cand = (((rm[r] >> 19) & 1u) && off != VAR_EMPTY && (e[r].x & 0x7FFFFFFFu) == want[r] && (qin ? off == kqr : !(off >> 63))) ? 1u : 0u;
+        const uint32_t bits = quad_or(cand << j);
+        const uint32_t ci = bits ? (uint32_t)__builtin_ctz(bits) : 4u;
+        rm[r] |= (ci << 20) | ((uint32_t)__builtin_popcount(bits) << 23);
+        const int srcl = (int)((lane & ~3u) | (ci & 3u));
+        const uint32_t ol = (uint32_t)__shfl((int)e[r].z, srcl, 64), oh = (uint32_t)__shfl((int)e[r].w, srcl, 64);
+        hp[r] = u32x4{0u, 0u, 0u, 0u};
+        if (ci < 4u && !qin && 16u * j < ((rm[r] >> 13) & 63u))
+            hp[r] = *reinterpret_cast<const u32x4_unaligned*>(T.heap + ((((uint64_t)oh << 32) | ol) + 16u * j));
+    }
+    uint32_t res[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        uint32_t r_out = miss;
+        const uint32_t m = rm[r], ln = (m >> 13) & 63u, ci = (m >> 20) & 7u, nc = (m >> 23) & 7u;
+        const bool qin = (m >> 26) & 1u;
+        // the key's hash and packed form live in lane 16r + q: fetched while every lane is still active (a shuffle from a lane that
+        // the quad-uniform branch below has switched off reads nothing)
+        const int src = 16 * r + (int)q;
+        const uint64_t hq = (uint64_t)(uint32_t)__shfl((int)(uint32_t)K.h, src, 64) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(K.h >> 32), src, 64) << 32);
+        const uint64_t kqs = (uint64_t)(uint32_t)__shfl((int)(uint32_t)K.kq, src, 64) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(K.kq >> 32), src, 64) << 32);
+        if ((m >> 19) & 1u) {   // quad-uniform
+            uint32_t mism = 0;
+            if (ci < 4u && !qin && 16u * j < ln) {
+                const uint32_t s = (m & 0x1FFFu) + 16u * j, k = s >> 2, sh = s & 3u;
+                const uint32_t w0 = w[k], w1 = w[k + 1], w2 = w[k + 2], w3 = w[k + 3], w4 = w[k + 4];
+                const uint32_t qd[4] = {__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh),
+                                        __builtin_amdgcn_alignbyte(w3, w2, sh), __builtin_amdgcn_alignbyte(w4, w3, sh)};
+                const uint32_t hd[4] = {hp[r].x, hp[r].y, hp[r].z, hp[r].w};
+                const uint32_t left = ln - 16u * j;       // bytes of the key from this lane's piece on (>= 1)
+#pragma unroll
+                for (uint32_t d = 0; d < 4; d++) {
+                    const uint32_t nv = left > 4u * d ? min(left - 4u * d, 4u) : 0u;
+                    const uint32_t mask = nv >= 4u ? 0xFFFFFFFFu : ((1u << (8u * nv)) - 1u);
+                    mism |= (qd[d] ^ hd[d]) & mask;
+                }
+            }
+            const uint32_t bad = quad_or(mism ? 1u : 0u);
+            const uint32_t val = (uint32_t)__shfl((int)e[r].y, (int)((lane & ~3u) | (ci & 3u)), 64);
+            const uint32_t ovf = quad_or((j == 0) ? (e[r].x >> 31) : 0u);
+            if (ci < 4u && !bad) r_out = val;
+            else if (nc > 1u || ovf) {
+                // another slot of the bucket shares tag and length (~1e-7), or the home bucket overflowed at build time
+                r_out = lookup_round_slow(T, reinterpret_cast<const uint8_t*>(a0 + (m & 0x1FFFu)), ln, hq, e[r], miss, j, want[r], qin, kqs);
+            }
+        }
+        res[r] = r_out;
+    }
+    if (j == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const size_t k = base + 16 * r + q;
+            if (k < n) out[k] = res[r];
+        }
+    }
+}
+
+// Where a batch's bytes go: the byte range [first, end) of the query buffer that holds its keys, from the 16-byte aligned address a0
+// on.  ok = every key lies inside it, it fits the strip and the buffer -- otherwise the batch takes the global-memory path.
+struct VarStage {
+    uint64_t a0, span;
+    bool ok;
+};
+// o / o1: the lane's key is bytes [o, o1) of the buffer (lanes past the end of the list hold an empty key); first / end: the range
+__device__ __forceinline__ VarStage var_stage_plan(const uint8_t* qbytes, uint64_t all_end, uint64_t o, uint64_t o1, uint64_t first, uint64_t end,
+                                                   uint32_t force_global, uint32_t& meta) {
+    const uint64_t l64 = o1 - o;
+    const bool valid = o1 >= o && l64 >= 1 && l64 <= VAR_MAX_LEN;
+    const uint32_t len = valid ? (uint32_t)l64 : 0u;
+    const bool inside = !valid || (o >= first && o + len <= end);
+    VarStage S;
+    S.a0 = (uint64_t)(uintptr_t)(qbytes + first) & ~15ull;                                    // absolute, 16-byte aligned
+    S.span = end >= first ? (uint64_t)(uintptr_t)(qbytes + end) - S.a0 : ~0ull;
+    S.ok = S.span <= 64 * VAR_MAX_LEN + 16 && end <= all_end && !__any(!inside) && !force_global;
+    const uint32_t soff = S.ok ? (uint32_t)((uint64_t)(uintptr_t)(qbytes + o) - S.a0) : 0u;
+    meta = (soff & 0x1FFFu) | (len << 13) | ((valid && S.ok ? 1u : 0u) << 19);
+    return S;
+}
+// one 16-byte chunk that straddles an end of the query buffer: byte by byte, inside only
+__device__ __noinline__ u32x4 var_edge_chunk(uint64_t a, uint64_t lo_abs, uint64_t hi_abs) {
+    uint32_t wds[4] = {0u, 0u, 0u, 0u};
+    for (uint32_t t = 0; t < 16; t++)
+        if (a + t >= lo_abs && a + t < hi_abs) wds[t >> 2] |= (uint32_t)*reinterpret_cast<const uint8_t*>(a + t) << (8 * (t & 3));
+    return u32x4{wds[0], wds[1], wds[2], wds[3]};
+}
+
+// The plain kernel: offsets -> staging (aligned 16-byte loads, through registers) -> probe, one batch of 64 queries per wave and step.
+__global__ __launch_bounds__(256, 4) void k_lookup_var(const uint8_t* __restrict__ qbytes, const uint64_t* __restrict__ qoff, size_t n,
+                                                       uint32_t miss, uint32_t* __restrict__ out, VarView T, uint32_t force_global) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4][VAR_STAGE / 4];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
     const uint64_t all_end = n ? qoff[n] : 0;      // the query buffer is valid on [qbytes, qbytes + qoff[n])
-    for (size_t base0 = wave * 64 * NB; base0 < n; base0 += nwaves * 64 * NB) {
-        // ---- 1. offsets, staging ----------------------------------------------------------------------------------------------
-        uint64_t o[NB], h[NB];
-        uint32_t meta[NB];           // staged offset (13 bits) | len << 13 (6 bits) | valid << 19
-        bool staged[NB];
-#pragma unroll
-        for (int b = 0; b < NB; b++) {
-            const size_t base = base0 + 64 * b, i = base + lane;
-            uint64_t o1 = 0;
-            uint32_t len = 0, valid = 0, soff = 0;
-            o[b] = 0;
-            h[b] = 0;
-            if (i < n) {
-                o[b] = qoff[i];
-                o1 = qoff[i + 1];
-                const uint64_t l64 = o1 - o[b];
-                if (o1 >= o[b] && l64 >= 1 && l64 <= VAR_MAX_LEN) { len = (uint32_t)l64; valid = 1; }
-            }
-            // the batch's byte range: from the first lane's start to the last lane's end
-            const uint32_t nl = base < n ? (uint32_t)min((size_t)64, n - base) : 0u;
-            staged[b] = false;
-            if (nl) {
-                const uint32_t f_lo = (uint32_t)__shfl((int)(uint32_t)o[b], 0, 64), f_hi = (uint32_t)__shfl((int)(uint32_t)(o[b] >> 32), 0, 64);
-                const uint32_t e_lo = (uint32_t)__shfl((int)(uint32_t)o1, (int)nl - 1, 64), e_hi = (uint32_t)__shfl((int)(uint32_t)(o1 >> 32), (int)nl - 1, 64);
-                const uint64_t first = ((uint64_t)f_hi << 32) | f_lo, end = ((uint64_t)e_hi << 32) | e_lo;
-                // every key must lie inside [first, end) and the range must fit the strip; otherwise the batch takes the global path
-                const bool inside = !valid || (o[b] >= first && o[b] + len <= end);
-                const uint64_t a0 = (uint64_t)(uintptr_t)(qbytes + first) & ~15ull;                  // absolute, 16-byte aligned
-                const uint64_t span = end >= first ? (uint64_t)(uintptr_t)(qbytes + end) - a0 : ~0ull;
-                staged[b] = span <= 64 * VAR_MAX_LEN + 16 && end <= all_end && !__any(!inside) && !force_global;
-                if (staged[b]) {
-                    const uint64_t lo_abs = (uint64_t)(uintptr_t)qbytes, hi_abs = (uint64_t)(uintptr_t)(qbytes + all_end);
-                    u32x4* dst = reinterpret_cast<u32x4*>(lds[wv][b]);
-                    for (uint32_t c = lane; (uint64_t)c * 16 < span; c += 64) {
-                        const uint64_t a = a0 + (uint64_t)c * 16;
-                        u32x4 v{0u, 0u, 0u, 0u};
-                        if (a >= lo_abs && a + 16 <= hi_abs) v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a));
-                        else {   // the chunk straddles an end of the buffer: byte by byte, inside only
-                            uint32_t wds[4] = {0u, 0u, 0u, 0u};
-                            for (uint32_t t = 0; t < 16; t++)
-                                if (a + t >= lo_abs && a + t < hi_abs) wds[t >> 2] |= (uint32_t)*reinterpret_cast<const uint8_t*>(a + t) << (8 * (t & 3));
-                            v = u32x4{wds[0], wds[1], wds[2], wds[3]};
-                        }
-                        dst[c] = v;
-                    }
-                    soff = (uint32_t)((uint64_t)(uintptr_t)(qbytes + o[b]) - a0);
-                } else {
-                    lookup_batch_global(qbytes, qoff, n, base, miss, out, T, lane);   // ill-formed offsets: the round-1 path, nothing live yet
-                    valid = 0;
-                }
-            }
-            meta[b] = soff | (len << 13) | (valid << 19);
+    const uint64_t lo_abs = (uint64_t)(uintptr_t)qbytes, hi_abs = (uint64_t)(uintptr_t)(qbytes + all_end);
+    for (size_t base = wave * 64; base < n; base += nwaves * 64) {
+        const uint32_t nl = (uint32_t)min((size_t)64, n - base);
+        const uint64_t oe = qoff[base + nl];
+        const uint64_t o = lane < nl ? qoff[base + lane] : oe, o1 = lane + 1 < nl ? qoff[base + lane + 1] : oe;
+        const uint64_t first = (uint64_t)(uint32_t)__shfl((int)(uint32_t)o, 0, 64) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(o >> 32), 0, 64) << 32);
+        uint32_t meta;
+        const VarStage S = var_stage_plan(qbytes, all_end, o, o1, first, oe, force_global, meta);
+        if (!S.ok) {                                   // ill-formed offsets: the round-1 path (wave-uniform)
+            lookup_batch_global(qbytes, qoff, n, base, miss, out, T, lane);
+            continue;
+        }
+        u32x4* dst = reinterpret_cast<u32x4*>(lds[wv]);
+        for (uint32_t c = lane; (uint64_t)c * 16 < S.span; c += 64) {
+            const uint64_t a = S.a0 + (uint64_t)c * 16;
+            dst[c] = (a >= lo_abs && a + 16 <= hi_abs) ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(a)) : var_edge_chunk(a, lo_abs, hi_abs);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        // ---- 2. hash from LDS; short keys packed for the word-for-word comparison with inline slots ---------------------------
-        uint64_t kq[NB];
-        uint32_t wantv[NB];          // what the slot's first word must be (bit 31 aside)
-#pragma unroll
-        for (int b = 0; b < NB; b++) {
-            kq[b] = 0;
-            wantv[b] = 0;
-            if (meta[b] >> 19) {
-                const uint32_t* w = lds[wv][b];
-                const uint32_t s = meta[b] & 0x1FFFu, len = (meta[b] >> 13) & 63u;
-                h[b] = hash_lds(w, s, len);
-                uint32_t khi = 0;
-                bool inl = false;
-                if (len <= T.inline_max) {
-                    const uint32_t k = s >> 2, sh = s & 3u;
-                    const uint32_t a0 = w[k], a1 = w[k + 1], a2 = w[k + 2], a3 = w[k + 3], a4 = w[k + 4], a5 = w[k + 5];
-                    const uint32_t d[5] = {__builtin_amdgcn_alignbyte(a1, a0, sh), __builtin_amdgcn_alignbyte(a2, a1, sh), __builtin_amdgcn_alignbyte(a3, a2, sh),
-                                           __builtin_amdgcn_alignbyte(a4, a3, sh), __builtin_amdgcn_alignbyte(a5, a4, sh)};
-                    inl = pack_inline_words(d, len, kq[b], khi);
-                }
-                wantv[b] = (inl ? khi : ((uint32_t)h[b] & 0x01FFFFFFu)) | (len << 25);
-                meta[b] |= inl ? (1u << 26) : 0u;
-            }
-        }
-        // ---- 3. the home buckets of NB x 4 rounds, back to back -----------------------------------------------------------------
-        uint32_t rm[NB][4], want[NB][4];     // rm: the round's meta (the owning lane's) | first candidate lane << 20 (4 = none) | #candidates << 23
-        u32x4 e[NB][4], hp[NB][4];
-#pragma unroll
-        for (int b = 0; b < NB; b++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int src = 16 * r + (int)q;
-                rm[b][r] = (uint32_t)__shfl((int)meta[b], src, 64);
-                const uint32_t hl = (uint32_t)__shfl((int)(uint32_t)h[b], src, 64), hh = (uint32_t)__shfl((int)(uint32_t)(h[b] >> 32), src, 64);
-                const uint64_t hq = ((uint64_t)hh << 32) | hl;
-                want[b][r] = (uint32_t)__shfl((int)wantv[b], src, 64);
-                e[b][r] = ((rm[b][r] >> 19) & 1u) ? __builtin_nontemporal_load(T.slots + __umul64hi(hq, T.nb) * VAR_SLOTS + j) : u32x4{0u, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu};
-            }
-        // ---- 4. the candidates' heap bytes, a quad per key ---------------------------------------------------------------------
-#pragma unroll
-        for (int b = 0; b < NB; b++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const uint64_t off = ((uint64_t)e[b][r].w << 32) | e[b][r].z;
-                const int srcq = 16 * r + (int)q;
-                const uint64_t kqr = (uint64_t)(uint32_t)__shfl((int)(uint32_t)kq[b], srcq, 64) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(kq[b] >> 32), srcq, 64) << 32);
-                const bool qin = (rm[b][r] >> 26) & 1u;
-                // an inline query matches its slot word for word (that IS the verification); any other candidate is a heap slot
-                const uint32_t cand = (((rm[b][r] >> 19) & 1u) && off != VAR_EMPTY && (e[b][r].x & 0x7FFFFFFFu) == want[b][r] && (qin ? off == kqr : !(off >> 63))) ? 1u : 0u;
-                const uint32_t bits = quad_or(cand << j);
-                const uint32_t ci = bits ? (uint32_t)__builtin_ctz(bits) : 4u;
-                rm[b][r] |= (ci << 20) | ((uint32_t)__builtin_popcount(bits) << 23);
-                const int srcl = (int)((lane & ~3u) | (ci & 3u));
-                const uint32_t ol = (uint32_t)__shfl((int)e[b][r].z, srcl, 64), oh = (uint32_t)__shfl((int)e[b][r].w, srcl, 64);
-                hp[b][r] = u32x4{0u, 0u, 0u, 0u};
-                if (ci < 4u && !qin && 16u * j < ((rm[b][r] >> 13) & 63u))
-                    hp[b][r] = *reinterpret_cast<const u32x4_unaligned*>(T.heap + ((((uint64_t)oh << 32) | ol) + 16u * j));
-            }
-        // ---- 5. compare with the query bytes in LDS; the rare rest on the round-1 path ------------------------------------------
-#pragma unroll
-        for (int b = 0; b < NB; b++) {
-            const size_t base = base0 + 64 * b;
-            if (!staged[b]) continue;                       // wave-uniform (done above, or past the end)
-            uint32_t res[4];
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                uint32_t r_out = miss;
-                const uint32_t m = rm[b][r], ln = (m >> 13) & 63u, ci = (m >> 20) & 7u, nc = (m >> 23) & 7u;
-                const bool qin = (m >> 26) & 1u;
-                // the key's offset and hash live in lane 16r + q: fetched while every lane is still active (a shuffle from a lane that
-                // the quad-uniform branch below has switched off reads nothing)
-                const int src = 16 * r + (int)q;
-                const uint64_t oq = (uint64_t)(uint32_t)__shfl((int)(uint32_t)o[b], src, 64) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(o[b] >> 32), src, 64) << 32);
-                const uint64_t hq = (uint64_t)(uint32_t)__shfl((int)(uint32_t)h[b], src, 64) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(h[b] >> 32), src, 64) << 32);
-                const uint64_t kqs = (uint64_t)(uint32_t)__shfl((int)(uint32_t)kq[b], src, 64) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(kq[b] >> 32), src, 64) << 32);
-                if ((m >> 19) & 1u) {   // quad-uniform
-                    uint32_t mism = 0;
-                    if (ci < 4u && !qin && 16u * j < ln) {
-                        const uint32_t* w = lds[wv][b];
-                        const uint32_t s = (m & 0x1FFFu) + 16u * j, k = s >> 2, sh = s & 3u;
-                        const uint32_t w0 = w[k], w1 = w[k + 1], w2 = w[k + 2], w3 = w[k + 3], w4 = w[k + 4];
-                        const uint32_t qd[4] = {__builtin_amdgcn_alignbyte(w1, w0, sh), __builtin_amdgcn_alignbyte(w2, w1, sh),
-                                                __builtin_amdgcn_alignbyte(w3, w2, sh), __builtin_amdgcn_alignbyte(w4, w3, sh)};
-                        const uint32_t hd[4] = {hp[b][r].x, hp[b][r].y, hp[b][r].z, hp[b][r].w};
-                        const uint32_t left = ln - 16u * j;       // bytes of the key from this lane's piece on (>= 1)
-#pragma unroll
-                        for (uint32_t d = 0; d < 4; d++) {
-                            const uint32_t nv = left > 4u * d ? min(left - 4u * d, 4u) : 0u;
-                            const uint32_t mask = nv >= 4u ? 0xFFFFFFFFu : ((1u << (8u * nv)) - 1u);
-                            mism |= (qd[d] ^ hd[d]) & mask;
-                        }
-                    }
-                    const uint32_t bad = quad_or(mism ? 1u : 0u);
-                    const uint32_t val = (uint32_t)__shfl((int)e[b][r].y, (int)((lane & ~3u) | (ci & 3u)), 64);
-                    const uint32_t ovf = quad_or((j == 0) ? (e[b][r].x >> 31) : 0u);
-                    if (ci < 4u && !bad) r_out = val;
-                    else if (nc > 1u || ovf) {
-                        // another slot of the bucket shares tag and length (~1e-7), or the home bucket overflowed at build time
-                        r_out = lookup_round_slow(T, qbytes + oq, ln, hq, e[b][r], miss, j, want[b][r], qin, kqs);
-                    }
-                }
-                res[r] = r_out;
-            }
-            if (j == 0) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const size_t k = base + 16 * r + q;
-                    if (k < n) out[k] = res[r];
-                }
-            }
-        }
+        const VarLaneKey K = var_hash_and_pack(T, lds[wv], meta);
+        var_probe_staged(T, lds[wv], K, S.a0, base, n, miss, out, lane);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// The pipelined kernel (default).  A batch costs four DEPENDENT round trips in the plain kernel -- offsets, query bytes, bucket,
+// heap -- and with 4 waves per SIMD that chain, not the request rate, sets the pace of ordered queries.  Here the first two run
+// one and two batches ahead: while batch t probes, the bytes of batch t + 1 travel from global memory straight into the other LDS
+// strip (global_load_lds_dwordx4: no registers held, nothing to wait for until the strip is read an iteration later) and the
+// offsets of batch t + 2 are in flight into two registers.
+__global__ __launch_bounds__(256, 4) void k_lookup_var_pipe(const uint8_t* __restrict__ qbytes, const uint64_t* __restrict__ qoff, size_t n,
+                                                            uint32_t miss, uint32_t* __restrict__ out, VarView T) {
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4][2][VAR_STAGE / 4];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t step = (((size_t)gridDim.x * blockDim.x) >> 6) * 64;
+    size_t base = wave * 64;
+    if (base >= n) return;
+    const uint64_t all_end = qoff[n];
+    const uint64_t lo_abs = (uint64_t)(uintptr_t)qbytes, hi_abs = (uint64_t)(uintptr_t)(qbytes + all_end);
+    // offsets of a batch: lane l holds qoff[min(b + l, n)] -- past the end of the list that is the buffer's end, an empty key -- and
+    // every lane the batch's end.  Two plain loads whose values nothing looks at before the next iteration (a select between them
+    // here would make the wave wait for them, and for the strip transfer issued just before, on the spot).
+    auto load_offsets = [&](size_t b, uint64_t& o, uint64_t& oe) {
+        o = qoff[min(b + lane, n)];
+        oe = qoff[min(b + 64, n)];
+    };
+    // plans the staging of a batch from its offsets and starts it into strip `buf`; returns the plan, the lane's meta in `meta`
+    auto start_stage = [&](uint64_t o, uint64_t oe, uint32_t buf, uint32_t& meta) {
+        const uint32_t dl = (uint32_t)__shfl_down((int)(uint32_t)o, 1, 64), dh = (uint32_t)__shfl_down((int)(uint32_t)(o >> 32), 1, 64);
+        const uint64_t o1 = lane < 63 ? (((uint64_t)dh << 32) | dl) : oe;
+        const uint64_t first = (uint64_t)(uint32_t)__shfl((int)(uint32_t)o, 0, 64) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(o >> 32), 0, 64) << 32);
+        const VarStage S = var_stage_plan(qbytes, all_end, o, o1, first, oe, 0u, meta);
+        if (S.ok) {
+            uint32_t* strip = lds[wv][buf];
+            for (uint32_t c0 = 0; (uint64_t)c0 * 16 < S.span; c0 += 64) {          // wave-uniform trip count (<= 4)
+                const uint32_t c = c0 + lane;
+                const uint64_t a = S.a0 + (uint64_t)c * 16;
+                if ((uint64_t)c * 16 < S.span) {
+                    if (a >= lo_abs && a + 16 <= hi_abs)
+                        __builtin_amdgcn_global_load_lds(reinterpret_cast<const u32x4*>(a), (__attribute__((address_space(3))) void*)(strip + c0 * 4), 16, 0, 0);
+                    else reinterpret_cast<u32x4*>(strip)[c] = var_edge_chunk(a, lo_abs, hi_abs);
+                }
+            }
+        }
+        return S;
+    };
+    uint64_t o_next, oe_next;
+    uint32_t meta_cur;
+    load_offsets(base, o_next, oe_next);
+    VarStage S_cur = start_stage(o_next, oe_next, 0u, meta_cur);
+    load_offsets(base + step, o_next, oe_next);
+    for (uint32_t t = 0;; t++) {
+        const size_t next = base + step, next2 = next + step;
+        // everything issued an iteration ago (the strip of this batch, the offsets of the next) has long arrived
+        __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t* w = lds[wv][t & 1u];
+        VarLaneKey K{0, 0, 0, 0};
+        if (S_cur.ok) K = var_hash_and_pack(T, w, meta_cur);
+        VarStage S_next{0, 0, false};
+        uint32_t meta_next = 0;
+        if (next < n) S_next = start_stage(o_next, oe_next, (t + 1u) & 1u, meta_next);
+        load_offsets(next2, o_next, oe_next);      // unconditional (indexes clamp to n): a value merged under a branch is waited for at the merge
+        if (S_cur.ok) var_probe_staged(T, w, K, S_cur.a0, base, n, miss, out, lane);
+        else lookup_batch_global(qbytes, qoff, n, base, miss, out, T, lane);
+        if (next >= n) break;
+        base = next;
+        S_cur = S_next;
+        meta_cur = meta_next;
     }
 }
 
@@ -664,7 +727,7 @@ int var_build(umgap_var_index** out, uint8_t* d_heap, uint64_t heap_bytes, const
         if (rc) break;
         // self check: every key finds its own taxon (a duplicate key finds the other copy's)
         if (n) {
-            hipLaunchKernelGGL(k_lookup_var<1>, dim3(grid_for(n)), dim3(256), 0, stream, d_heap, d_off, n, 0xFFFFFFFFu, d_got, v->view(), var_force_global());
+            hipLaunchKernelGGL(k_lookup_var, dim3(grid_for(n)), dim3(256), 0, stream, d_heap, d_off, n, 0xFFFFFFFFu, d_got, v->view(), var_force_global());
             hipLaunchKernelGGL(k_selfcheck_var, dim3(grid_for(n)), dim3(256), 0, stream, d_got, d_vals, n, d_flags);
             e = hipMemcpyAsync(&h, d_flags, sizeof(h), hipMemcpyDeviceToHost, stream);
             if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -683,21 +746,21 @@ int var_build(umgap_var_index** out, uint8_t* d_heap, uint64_t heap_bytes, const
 int var_lookup_dev(const umgap_var_index* v, const uint8_t* d_bytes, const uint64_t* d_off, size_t n, uint32_t miss, uint32_t* d_out, hipStream_t s) {
     // a grid of whole resident rounds (two of them): with a partial last round the kernel measured 16 % slower
     static int per_cu[2] = {0, 0};
-    static int nb_choice = -1;
-    if (nb_choice < 0) {
-        const char* env = getenv("UMGAP_VAR_BATCHES");     // A/B switch of the measurement tools: batches of 64 in flight per wave
-        nb_choice = (env && env[0] == '2') ? 2 : 1;
+    static int pipe = -1;
+    if (pipe < 0) {
+        const char* env = getenv("UMGAP_VAR_PIPE");       // A/B switch of the measurement tools: 0 = the plain kernel
+        pipe = (env && env[0] == '0') ? 0 : 1;
     }
-    const int which = nb_choice == 2 ? 1 : 0;
+    const int which = (pipe && !var_force_global()) ? 1 : 0;
     if (!per_cu[which]) {
         int b = 0;
-        hipError_t e = which ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_lookup_var<2>, 256, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_lookup_var<1>, 256, 0);
+        hipError_t e = which ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_lookup_var_pipe, 256, 0) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_lookup_var, 256, 0);
         if (e != hipSuccess || b < 1) b = 4;
         per_cu[which] = 2 * b;
     }
     if (n) {
-        if (which) hipLaunchKernelGGL(k_lookup_var<2>, dim3(grid_for(n, (size_t)per_cu[which])), dim3(256), 0, s, d_bytes, d_off, n, miss, d_out, v->view(), var_force_global());
-        else hipLaunchKernelGGL(k_lookup_var<1>, dim3(grid_for(n, (size_t)per_cu[which])), dim3(256), 0, s, d_bytes, d_off, n, miss, d_out, v->view(), var_force_global());
+        if (which) hipLaunchKernelGGL(k_lookup_var_pipe, dim3(grid_for(n, (size_t)per_cu[which])), dim3(256), 0, s, d_bytes, d_off, n, miss, d_out, v->view());
+        else hipLaunchKernelGGL(k_lookup_var, dim3(grid_for(n, (size_t)per_cu[which])), dim3(256), 0, s, d_bytes, d_off, n, miss, d_out, v->view(), var_force_global());
     }
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
