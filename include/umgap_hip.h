@@ -156,6 +156,25 @@ int umgap_index_lookup_var(umgap_index* ix, const uint8_t* bytes, const uint64_t
 int umgap_index_lookup_var_dev(umgap_index* ix, const uint8_t* d_bytes, const uint64_t* d_offsets, size_t n,
                                uint32_t miss_value, uint32_t* d_out_taxa, void* stream);
 
+/* ---- tryptic digest on the device: the front half of `prot2tryp2lca` (src/commands/prot2tryp2lca.rs:107-131) ----------- */
+/* The default cleavage pattern `([KR])([^P])` as a per-byte rule: a piece starts where a fragment starts, after a K or R that
+ * is not followed by P, and at and after every `*`.  Fragment f = d_bytes[d_frag_offsets[f] .. d_frag_offsets[f+1]) (offsets
+ * must not decrease).  Every byte belongs to exactly one piece and pieces lie back to back, so the digest is the sorted list of
+ * piece starts plus the end: piece i = d_bytes[d_piece_offsets[i] .. d_piece_offsets[i+1]) -- the (bytes, offsets) key list
+ * umgap_index_lookup_var_dev takes as it is.  A `*` is a piece of its own (one byte); empty lines do not arise.
+ * *n_pieces is always set; the offsets (n_pieces + 1 of them) are written only if cap >= n_pieces + 1: call once with cap = 0 to
+ * size the buffer.  Synchronous (the count makes a host round trip).  A custom -p pattern stays with the host (umgap CLI). */
+int umgap_digest_tryp_dev(const uint8_t* d_bytes, const uint64_t* d_frag_offsets, size_t n_fragments,
+                          uint64_t* d_piece_offsets, size_t cap, size_t* n_pieces, int device, void* stream);
+/* The tryptic pipeline of scripts/umgap-analyse.sh (prot2tryp2lca -l min -L max | taxa2agg ...) for device-resident reads:
+ * read r owns fragments [r*F, (r+1)*F); digest as above, pieces of min_len..max_len bytes are looked up in the variable-length
+ * index (every other piece, and every `*`, is no hit), and the hits of a read are aggregated as umgap_aggregate_dev does.
+ * -k / -d (contains / lacks) are not offered here.  Synchronous; *n_pieces_out (nullable) = pieces the digest produced. */
+int umgap_classify_tryp_dev(umgap_index* ix, umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound,
+                            int ranked_only, const uint8_t* d_bytes, const uint64_t* d_frag_offsets, size_t n_reads,
+                            uint32_t fragments_per_read, uint32_t min_len, uint32_t max_len, uint32_t* d_out_taxon,
+                            uint32_t* d_out_status, uint64_t* n_pieces_out, void* stream);
+
 /* ---- dump: fst::Map::stream() as used by `umgap printindex` (src/commands/printindex.rs:43-47) ---- */
 /* Every (key, taxon) of a whole table, in table order (the caller sorts).  *n_out = number of keys
  * (also when it exceeds cap; then only the first cap are written). */
@@ -366,6 +385,11 @@ int umgap_synth_index_build_shard(uint64_t n_keys, const uint32_t* d_taxon_of_ro
  * d_bytes[d_offsets[i] .. d_offsets[i+1]) with letters determined by (seed, first+i). */
 int umgap_synth_peptides_dev(uint64_t first, size_t n, uint64_t seed, const uint64_t* d_offsets,
                              uint8_t* d_bytes, int device, void* stream);
+/* The same, but peptides that a tryptic digest gives back whole (no K or R inside, no leading P, the last letter K or R), and
+ * with arbitrary global numbers: peptide i is number d_ids[i] (d_ids NULL: first + i).  A read for umgap_classify_tryp_dev is a
+ * list of such numbers written back to back. */
+int umgap_synth_tryptic_dev(const uint64_t* d_ids, uint64_t first, size_t n, uint64_t seed, const uint64_t* d_offsets,
+                            uint8_t* d_bytes, int device, void* stream);
 /* Synthetic proteome (surface B): an index whose keys are all 9-residue windows of the given
  * fragments (value = the fragment's taxon, smallest taxon on duplicate 9-mers), and reads made of
  * mutated copies of proteome fragments. */

@@ -1379,6 +1379,97 @@ def test_classify_prot9_overlong_reads_are_flagged(api, torch_cuda):
         assert nbad == 0, (method, strategy, bad)
 
 
+def _tryptic_pieces(seq):
+    """The reference's digest of one sequence (src/commands/prot2tryp2lca.rs:107-116), literally: the regex applied twice, `*`
+    to newline, empty lines dropped."""
+    import re
+    pat = re.compile(rb"([KR])([^P])")
+    once = pat.sub(rb"\1\n\2", seq)
+    twice = pat.sub(rb"\1\n\2", once)
+    return [p for p in twice.replace(b"*", b"\n").split(b"\n") if p]
+
+
+def test_digest_tryp_dev_matches_the_regex(api, torch_cuda):
+    """umgap_digest_tryp_dev against the reference's regex digest: K/R runs, KP / RP, `*` (single, runs, at the ends), empty and
+    one-byte fragments, fragments that end in K, a P that opens a fragment -- and sizes that straddle the 2048-byte tiles."""
+    torch = torch_cuda
+    rng = np.random.default_rng(31)
+    alphabet = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWYKRKRPP**", np.uint8)
+    special = [b"", b"K", b"P", b"*", b"**", b"KP", b"KK", b"KRP", b"KKP", b"RPK", b"AK", b"KA", b"*K*", b"PKPKP", b"AAAK*", b"*AAAK", b"KR" * 40,
+               b"A" * 5000, b"K" * 3000, b"AKP" * 900]
+    for trial, n_frag in enumerate((1, 7, 400, 3000)):
+        frags = [special[i % len(special)] if i % 3 == 0 else rng.choice(alphabet, int(rng.integers(0, 120))).tobytes() for i in range(n_frag)]
+        data, offs = api._concat(frags)
+        pad = rng.integers(0, 9)                      # the byte range need not start at 0
+        d_bytes = torch.from_numpy(np.concatenate([np.full(pad, ord("K"), np.uint8), data, np.full(3, ord("K"), np.uint8)])).cuda()
+        d_offs = torch.from_numpy((offs + np.uint64(pad)).view(np.int64)).cuda()
+        got = api.digest_tryp_dev(d_bytes, d_offs).cpu().numpy().view(np.uint64)
+        host = d_bytes.cpu().numpy().tobytes()
+        pieces = [host[int(a):int(b)] for a, b in zip(got[:-1], got[1:])]
+        whole = b"".join(frags)
+        assert b"".join(pieces) == whole and int(got[0]) == pad and int(got[-1]) == pad + len(whole), trial
+        assert all(len(p) > 0 for p in pieces)
+        want = [p for f in frags for p in _tryptic_pieces(f)]
+        assert [p for p in pieces if p != b"*"] == want, trial
+        assert all(p == b"*" or b"*" not in p for p in pieces)
+
+
+@pytest.mark.parametrize("mode", [("tree", "hybrid", 0.25, 0.0), ("rmq", "mrtl", 0.0, 1.0), ("tree", "lca*", 0.0, 2.0), ("rmq", "hybrid", 0.4, 1.0)])
+def test_classify_tryp_dev_vs_oracle(api, torch_cuda, mode):
+    """umgap_classify_tryp_dev = digest + length window + lookup + aggregate, against the regex digest, a dict and the oracle's
+    taxa2agg -- 1..3 fragments per read, windows 5..50 and 1..63."""
+    torch = torch_cuda
+    method, strategy, factor, lb = mode
+    rng = np.random.default_rng(17)
+    letters = np.frombuffer(b"ACDEFGHILMNPQSTVWY", np.uint8)
+
+    def peptide():
+        k = int(rng.integers(1, 30))
+        p = bytearray(rng.choice(letters, k).tobytes())
+        p[-1] = ord("K") if rng.random() < 0.5 else ord("R")
+        if p[0] == ord("P"):
+            p[0] = ord("A")
+        return bytes(p)
+    peps = sorted({peptide() for _ in range(6000)} | {b"*"})           # a `*` key must never be found through the digest
+    ids = np.arange(1, 200, dtype=np.uint32)
+    par = np.maximum(1, ids // 2).astype(np.uint32)
+    tx = api.Taxonomy(ids, par)
+    otx = O.Taxonomy.from_arrays(ids, par)
+    vals = rng.choice(ids, len(peps)).astype(np.uint32)
+    ix = api.Index.build_var(peps, vals)
+    d = dict(zip(peps, vals.tolist()))
+    pool = [p for p in peps if p != b"*"][:60]                           # few distinct peptides per read survive -l
+    for F, (lo, hi) in ((1, (5, 50)), (3, (1, 63)), (2, (9, 45))):
+        n_reads = 700
+        frags = []
+        for _ in range(n_reads * F):
+            parts = []
+            for _k in range(int(rng.integers(0, 7))):
+                u = rng.random()
+                parts.append(pool[int(rng.integers(0, len(pool)))] if u < 0.6 else (peptide() if u < 0.85 else (b"*" if u < 0.93 else b"P" + peptide())))
+            frags.append(b"".join(parts))
+        data, offs = api._concat(frags)
+        d_bytes, d_offs = torch.from_numpy(np.concatenate([data, np.zeros(1, np.uint8)])).cuda(), torch.from_numpy(offs.view(np.int64)).cuda()
+        d_t = torch.full((n_reads,), -1, dtype=torch.int32, device="cuda")
+        d_s = torch.full_like(d_t, -1)
+        n_pieces = api.classify_tryp_dev(ix, tx, d_bytes, d_offs, n_reads, F, d_t, d_s, method=method, strategy=strategy, factor=factor, lower_bound=lb,
+                                         min_len=lo, max_len=hi)
+        hits, roffs = [], [0]
+        for r in range(n_reads):
+            for f in frags[r * F:(r + 1) * F]:
+                hits += [d.get(p, 0) for p in _tryptic_pieces(f) if lo <= len(p) <= hi]
+            roffs.append(len(hits))
+        assert n_pieces >= len(hits)
+        t, s = d_t.cpu().numpy().view(np.uint32), d_s.cpu().numpy().view(np.uint32)
+        agg = O.Aggregator(otx, method, strategy, factor)
+        nbad, bad, wt, ws = agg.taxa2agg_check(np.array(hits, np.uint32), np.array(roffs, np.uint64), t, s, lower_bound=lb)
+        assert nbad == 0, (F, lo, hi, bad)
+        assert (s == 0).sum() > 10 and (s == 0).mean() > (0.3 if lb < 2 else 0.0)
+    nine = api.Index.build(np.array([5], np.uint64), np.array([7], np.uint32))
+    with pytest.raises(api.UmgapError, match="variable-length"):
+        api.classify_tryp_dev(nine, tx, d_bytes, d_offs, 1, 1, d_t, d_s)
+
+
 def test_classify_records_long_ragged_reads(api, torch_cuda):
     """umgap_classify_records (host records in, one taxon per read out; what `umgap prot2kmer2agg` calls per block) on reads
     the fused kernels do not take: 1..12 fragments of 9..700 residues (6-frame translations, whole proteins), every

@@ -111,6 +111,9 @@ def load():
         "umgap_comm_init_rank": (i32, [vp, i32, i32, i32, pp]),
         "umgap_comm_init_local": (i32, [i32, i32, pp]),
         "umgap_comm_world": (i32, [vp]),
+        "umgap_synth_tryptic_dev": (i32, [vp, u64, sz, u64, vp, vp, i32, vp]),
+        "umgap_digest_tryp_dev": (i32, [vp, vp, sz, vp, sz, C.POINTER(sz), i32, vp]),
+        "umgap_classify_tryp_dev": (i32, [vp, vp, i32, i32, f32, f32, i32, vp, vp, sz, u32, u32, u32, vp, vp, C.POINTER(u64), vp]),
         "umgap_comm_rank": (i32, [vp]),
         "umgap_comm_selftest": (i32, [vp, sz]),
         "umgap_comm_free": (None, [vp]),

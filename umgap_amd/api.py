@@ -361,6 +361,28 @@ def classify_prot9_dev(index, taxonomy, d_bytes, d_frag_offsets, n_reads, fragme
                                                         _stream_ptr(stream)))
 
 
+def digest_tryp_dev(d_bytes, d_frag_offsets, device=0, stream=None):
+    """Tryptic digest on the device (default pattern of `prot2tryp2lca`): returns a device int64 tensor of n_pieces + 1 offsets."""
+    import torch
+    n_frag = d_frag_offsets.numel() - 1
+    n = C.c_size_t()
+    check(_lib.load().umgap_digest_tryp_dev(_dev_ptr(d_bytes), _dev_ptr(d_frag_offsets), n_frag, None, 0, C.byref(n), device, _stream_ptr(stream)))
+    out = torch.empty(n.value + 1, dtype=torch.int64, device=d_frag_offsets.device)
+    check(_lib.load().umgap_digest_tryp_dev(_dev_ptr(d_bytes), _dev_ptr(d_frag_offsets), n_frag, _dev_ptr(out), out.numel(), C.byref(n), device,
+                                            _stream_ptr(stream)))
+    return out
+
+
+def classify_tryp_dev(index, taxonomy, d_bytes, d_frag_offsets, n_reads, fragments_per_read, d_out_taxon, d_out_status, method="tree",
+                      strategy="hybrid", factor=0.25, lower_bound=0.0, ranked_only=False, min_len=5, max_len=50, stream=None):
+    """Fused tryptic pipeline: protein fragments -> digest -> variable-length lookup -> aggregate.  Returns the number of pieces."""
+    n = C.c_uint64()
+    check(_lib.load().umgap_classify_tryp_dev(index._h, taxonomy._h, METHODS[method], STRATEGIES[strategy], factor, lower_bound, int(ranked_only),
+                                              _dev_ptr(d_bytes), _dev_ptr(d_frag_offsets), n_reads, fragments_per_read, min_len, max_len,
+                                              _dev_ptr(d_out_taxon), _dev_ptr(d_out_status), C.byref(n), _stream_ptr(stream)))
+    return n.value
+
+
 def classify_records(index, taxonomy, fragments, read_frags, method="tree", strategy="hybrid", factor=0.25, lower_bound=0.0,
                      ranked_only=False, seedextend=True, min_seed_size=2, max_gap_size=0):
     """`prot2kmer2lca -o | seedextend | uniq | taxa2agg` for host-side records: `fragments` = list of bytes (one

@@ -183,7 +183,7 @@ __device__ __forceinline__ uint32_t var_stash_lookup(const VarView& T, uint64_t 
 // One batch of 64 queries (one per lane) straight from global memory: the round-1 kernel body, kept for batches whose bytes
 // cannot be staged in LDS (ill-formed offsets: a "key" longer than 63 bytes inside the batch) -- see k_lookup_var below.
 __device__ __noinline__ void lookup_batch_global(const uint8_t* __restrict__ qbytes, const uint64_t* __restrict__ qoff, size_t n, size_t base,
-                                                    uint32_t miss, uint32_t* __restrict__ out, const VarView T, uint32_t lane) {
+                                                    uint32_t miss, uint32_t* __restrict__ out, const VarView T, uint32_t lane, uint32_t min_len, uint32_t max_len) {
     // (T by value, here and in lookup_round_slow: a reference would put the kernel's copy on the stack, and every T.slots / T.nb of
     // the hot loop would become a scratch load whose s_waitcnt vmcnt(0) also waits for whatever the pipelined kernel has in flight)
     const uint32_t q = lane >> 2, j = lane & 3;
@@ -194,7 +194,7 @@ __device__ __noinline__ void lookup_batch_global(const uint8_t* __restrict__ qby
         if (i < n) {
             o = qoff[i];
             uint64_t l64 = qoff[i + 1] - o;
-            if (l64 >= 1 && l64 <= VAR_MAX_LEN) { len = (uint32_t)l64; h = hash_bytes(qbytes + o, len); valid = 1; }
+            if (l64 >= min_len && l64 <= max_len) { len = (uint32_t)l64; h = hash_bytes(qbytes + o, len); valid = 1; }
         }
         uint64_t kq = 0;
         uint32_t khi = 0;
@@ -467,10 +467,12 @@ struct VarStage {
     bool ok;
 };
 // o / o1: the lane's key is bytes [o, o1) of the buffer (lanes past the end of the list hold an empty key); first / end: the range
+// (min_len / max_len: 1 <= min_len, max_len <= VAR_MAX_LEN; a key whose length lies outside is answered with a miss without a probe --
+// the length filter of prot2tryp2lca, src/commands/prot2tryp2lca.rs:117-120)
 __device__ __forceinline__ VarStage var_stage_plan(const uint8_t* qbytes, uint64_t all_end, uint64_t o, uint64_t o1, uint64_t first, uint64_t end,
-                                                   uint32_t force_global, uint32_t& meta) {
+                                                   uint32_t force_global, uint32_t min_len, uint32_t max_len, uint32_t& meta) {
     const uint64_t l64 = o1 - o;
-    const bool valid = o1 >= o && l64 >= 1 && l64 <= VAR_MAX_LEN;
+    const bool valid = o1 >= o && l64 >= min_len && l64 <= max_len;
     const uint32_t len = valid ? (uint32_t)l64 : 0u;
     const bool inside = !valid || (o >= first && o + len <= end);
     VarStage S;
@@ -491,7 +493,8 @@ __device__ __noinline__ u32x4 var_edge_chunk(uint64_t a, uint64_t lo_abs, uint64
 
 // The plain kernel: offsets -> staging (aligned 16-byte loads, through registers) -> probe, one batch of 64 queries per wave and step.
 __global__ __launch_bounds__(256, 4) void k_lookup_var(const uint8_t* __restrict__ qbytes, const uint64_t* __restrict__ qoff, size_t n,
-                                                       uint32_t miss, uint32_t* __restrict__ out, VarView T, uint32_t force_global) {
+                                                       uint32_t miss, uint32_t* __restrict__ out, VarView T, uint32_t force_global, uint32_t min_len,
+                                                       uint32_t max_len) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[4][VAR_STAGE / 4];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -504,9 +507,9 @@ __global__ __launch_bounds__(256, 4) void k_lookup_var(const uint8_t* __restrict
         const uint64_t o = lane < nl ? qoff[base + lane] : oe, o1 = lane + 1 < nl ? qoff[base + lane + 1] : oe;
         const uint64_t first = (uint64_t)(uint32_t)__shfl((int)(uint32_t)o, 0, 64) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(o >> 32), 0, 64) << 32);
         uint32_t meta;
-        const VarStage S = var_stage_plan(qbytes, all_end, o, o1, first, oe, force_global, meta);
+        const VarStage S = var_stage_plan(qbytes, all_end, o, o1, first, oe, force_global, min_len, max_len, meta);
         if (!S.ok) {                                   // ill-formed offsets: the round-1 path (wave-uniform)
-            lookup_batch_global(qbytes, qoff, n, base, miss, out, T, lane);
+            lookup_batch_global(qbytes, qoff, n, base, miss, out, T, lane, min_len, max_len);
             continue;
         }
         u32x4* dst = reinterpret_cast<u32x4*>(lds[wv]);
@@ -529,7 +532,7 @@ __global__ __launch_bounds__(256, 4) void k_lookup_var(const uint8_t* __restrict
 // strip (global_load_lds_dwordx4: no registers held, nothing to wait for until the strip is read an iteration later) and the
 // offsets of batch t + 2 are in flight into two registers.
 __global__ __launch_bounds__(256, 4) void k_lookup_var_pipe(const uint8_t* __restrict__ qbytes, const uint64_t* __restrict__ qoff, size_t n,
-                                                            uint32_t miss, uint32_t* __restrict__ out, VarView T) {
+                                                            uint32_t miss, uint32_t* __restrict__ out, VarView T, uint32_t min_len, uint32_t max_len) {
     __shared__ __attribute__((aligned(16))) uint32_t lds[4][2][VAR_STAGE / 4];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -550,7 +553,7 @@ __global__ __launch_bounds__(256, 4) void k_lookup_var_pipe(const uint8_t* __res
         const uint32_t dl = (uint32_t)__shfl_down((int)(uint32_t)o, 1, 64), dh = (uint32_t)__shfl_down((int)(uint32_t)(o >> 32), 1, 64);
         const uint64_t o1 = lane < 63 ? (((uint64_t)dh << 32) | dl) : oe;
         const uint64_t first = (uint64_t)(uint32_t)__shfl((int)(uint32_t)o, 0, 64) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(o >> 32), 0, 64) << 32);
-        const VarStage S = var_stage_plan(qbytes, all_end, o, o1, first, oe, 0u, meta);
+        const VarStage S = var_stage_plan(qbytes, all_end, o, o1, first, oe, 0u, min_len, max_len, meta);
         if (S.ok) {
             uint32_t* strip = lds[wv][buf];
             for (uint32_t c0 = 0; (uint64_t)c0 * 16 < S.span; c0 += 64) {          // wave-uniform trip count (<= 4)
@@ -584,7 +587,7 @@ __global__ __launch_bounds__(256, 4) void k_lookup_var_pipe(const uint8_t* __res
         if (next < n) S_next = start_stage(o_next, oe_next, (t + 1u) & 1u, meta_next);
         load_offsets(next2, o_next, oe_next);      // unconditional (indexes clamp to n): a value merged under a branch is waited for at the merge
         if (S_cur.ok) var_probe_staged(T, w, K, S_cur.a0, base, n, miss, out, lane);
-        else lookup_batch_global(qbytes, qoff, n, base, miss, out, T, lane);
+        else lookup_batch_global(qbytes, qoff, n, base, miss, out, T, lane, min_len, max_len);
         if (next >= n) break;
         base = next;
         S_cur = S_next;
@@ -727,7 +730,7 @@ int var_build(umgap_var_index** out, uint8_t* d_heap, uint64_t heap_bytes, const
         if (rc) break;
         // self check: every key finds its own taxon (a duplicate key finds the other copy's)
         if (n) {
-            hipLaunchKernelGGL(k_lookup_var, dim3(grid_for(n)), dim3(256), 0, stream, d_heap, d_off, n, 0xFFFFFFFFu, d_got, v->view(), var_force_global());
+            hipLaunchKernelGGL(k_lookup_var, dim3(grid_for(n)), dim3(256), 0, stream, d_heap, d_off, n, 0xFFFFFFFFu, d_got, v->view(), var_force_global(), 1u, VAR_MAX_LEN);
             hipLaunchKernelGGL(k_selfcheck_var, dim3(grid_for(n)), dim3(256), 0, stream, d_got, d_vals, n, d_flags);
             e = hipMemcpyAsync(&h, d_flags, sizeof(h), hipMemcpyDeviceToHost, stream);
             if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -743,7 +746,10 @@ int var_build(umgap_var_index** out, uint8_t* d_heap, uint64_t heap_bytes, const
     return UMGAP_OK;
 }
 
-int var_lookup_dev(const umgap_var_index* v, const uint8_t* d_bytes, const uint64_t* d_off, size_t n, uint32_t miss, uint32_t* d_out, hipStream_t s) {
+int var_lookup_dev(const umgap_var_index* v, const uint8_t* d_bytes, const uint64_t* d_off, size_t n, uint32_t miss, uint32_t* d_out, hipStream_t s,
+                   uint32_t min_len, uint32_t max_len) {
+    if (min_len < 1) min_len = 1;
+    if (max_len > VAR_MAX_LEN) max_len = VAR_MAX_LEN;
     // a grid of whole resident rounds (two of them): with a partial last round the kernel measured 16 % slower
     static int per_cu[2] = {0, 0};
     static int pipe = -1;
@@ -759,8 +765,8 @@ int var_lookup_dev(const umgap_var_index* v, const uint8_t* d_bytes, const uint6
         per_cu[which] = 2 * b;
     }
     if (n) {
-        if (which) hipLaunchKernelGGL(k_lookup_var_pipe, dim3(grid_for(n, (size_t)per_cu[which])), dim3(256), 0, s, d_bytes, d_off, n, miss, d_out, v->view());
-        else hipLaunchKernelGGL(k_lookup_var, dim3(grid_for(n, (size_t)per_cu[which])), dim3(256), 0, s, d_bytes, d_off, n, miss, d_out, v->view(), var_force_global());
+        if (which) hipLaunchKernelGGL(k_lookup_var_pipe, dim3(grid_for(n, (size_t)per_cu[which])), dim3(256), 0, s, d_bytes, d_off, n, miss, d_out, v->view(), min_len, max_len);
+        else hipLaunchKernelGGL(k_lookup_var, dim3(grid_for(n, (size_t)per_cu[which])), dim3(256), 0, s, d_bytes, d_off, n, miss, d_out, v->view(), var_force_global(), min_len, max_len);
     }
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
@@ -883,7 +889,7 @@ int umgap_index_lookup_var_dev(umgap_index* ix, const uint8_t* d_bytes, const ui
     if (n && (!d_bytes || !d_offsets || !d_out)) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup_var_dev: null argument");
     int rc = use_device(ix->device);
     if (rc) return rc;
-    return var_lookup_dev(ix->var, d_bytes, d_offsets, n, miss_value, d_out, (hipStream_t)stream);
+    return var_lookup_dev(ix->var, d_bytes, d_offsets, n, miss_value, d_out, (hipStream_t)stream, 1u, VAR_MAX_LEN);
 }
 
 int umgap_index_lookup_var(umgap_index* ix, const uint8_t* bytes, const uint64_t* offsets, size_t n, uint32_t miss_value, uint32_t* out) {
@@ -902,7 +908,7 @@ int umgap_index_lookup_var(umgap_index* ix, const uint8_t* bytes, const uint64_t
     if (e == hipSuccess && n_bytes) e = hipMemcpyAsync(db, bytes + base, n_bytes, hipMemcpyHostToDevice, ix->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(doff, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, ix->stream);
     if (e == hipSuccess) {
-        rc = var_lookup_dev(ix->var, db, doff, n, miss_value, dout, ix->stream);
+        rc = var_lookup_dev(ix->var, db, doff, n, miss_value, dout, ix->stream, 1u, VAR_MAX_LEN);
         if (!rc) e = hipMemcpyAsync(out, dout, n * 4, hipMemcpyDeviceToHost, ix->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
     }

@@ -148,6 +148,25 @@ __global__ __launch_bounds__(256) void k_synth_peptides(uint64_t first, size_t n
     }
 }
 
+// synthetic peptides that a tryptic digest gives back whole: no K or R inside, no leading P, the last letter K or R.  Peptide i
+// has global number ids[i] (or first + i) -- a read for the fused tryptic pipeline is a list of such numbers, written back to back.
+__global__ __launch_bounds__(256) void k_synth_tryptic(const uint64_t* __restrict__ ids, uint64_t first, size_t n, uint64_t seed,
+                                                       const uint64_t* __restrict__ offsets, uint8_t* __restrict__ bytes) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) {
+        const uint64_t o = offsets[i], len = offsets[i + 1] - o, number = ids ? ids[i] : first + i;
+        uint64_t h = splitmix64(seed ^ (number * 0x9E3779B97F4A7C15ull));
+        for (uint64_t j = 0; j < len; j++) {
+            if ((j & 7) == 0 && j) h = splitmix64(h + j);
+            uint32_t d = (uint32_t)((h >> (8 * (j & 7))) & 0xFF) % 18;
+            if (j == 0 && d == 11) d = 12;                                                     // no leading P
+            bytes[o + j] = (uint8_t)"ACDEFGHILMNPQSTVWY"[d];
+        }
+        if (len) bytes[o + len - 1] = (h >> 60) & 1 ? 'K' : 'R';
+    }
+}
+
 // synthetic surface-B reads: read r = F fragments of `flen` residues, each a copy of a proteome
 // fragment of the read's source taxon family with point mutations (a mutated residue makes the up to
 // nine windows that cover it miss); 1 % of the residues become '*' (stop codon, not [A-Z]).
@@ -229,6 +248,15 @@ int umgap_synth_peptides_dev(uint64_t first, size_t n, uint64_t seed, const uint
     int rc = use_device(device);
     if (rc) return rc;
     if (n) hipLaunchKernelGGL(k_synth_peptides, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, first, n, seed, d_offsets, d_bytes);
+    UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}
+
+int umgap_synth_tryptic_dev(const uint64_t* d_ids, uint64_t first, size_t n, uint64_t seed, const uint64_t* d_offsets, uint8_t* d_bytes, int device, void* stream) {
+    if (n && (!d_offsets || !d_bytes)) return fail(UMGAP_ERR_INVALID, "umgap_synth_tryptic_dev: null argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    if (n) hipLaunchKernelGGL(k_synth_tryptic, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, d_ids, first, n, seed, d_offsets, d_bytes);
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
 }

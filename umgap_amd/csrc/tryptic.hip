@@ -1,0 +1,277 @@
+// tryptic.hip — the front half of `prot2tryp2lca` on the device, and the tryptic pipeline fused behind it (gfx950 only).
+//
+// Reference (src/commands/prot2tryp2lca.rs:107-131): every sequence of a record is cut with the pattern `([KR])([^P])` ->
+// "$1\n$2" applied twice (a letter can end one match and start the next), `*` becomes a newline, empty lines go, peptides
+// outside [minlen, maxlen] go, the rest is looked up.  With that (default) pattern the cut is a per-byte rule: a new piece
+// starts at byte p when p opens a fragment, when bytes[p-1] is K or R and bytes[p] is not P, or at and after a `*`.
+// Every byte then belongs to exactly one piece and the pieces of a fragment lie back to back, so the digest is just the sorted
+// list of piece starts -- which is the (bytes, offsets) key list the variable-length probe takes as it is: no byte moves.
+// A `*` is a piece of its own here; it and the pieces outside the length window are answered with a miss without a probe
+// (the window goes into the probe kernel, index_var.hip), and 0 = "no hit" is what the aggregators skip.
+//
+//   k_tryp_mark     fragment starts -> one bit per byte                                     (n_fragments threads)
+//   k_tryp_count    piece starts per tile of 2048 bytes                                      (reads the bytes once)
+//   k_tryp_scan     exclusive scan of the tile counts                                        (one workgroup)
+//   k_tryp_write    the starts, in order: offsets[rank] = position                           (reads the bytes again)
+//   k_tryp_reads    first piece of every read by binary search in the offsets                (n_reads threads)
+// then k_lookup_var_pipe over the pieces and the CSR aggregate over the hits of each read.
+#include <algorithm>
+#include <vector>
+
+#include "common.hpp"
+#include "taxonomy.hpp"
+
+namespace umgap {
+int use_device(int device);
+int var_lookup_dev(const umgap_var_index* v, const uint8_t* d_bytes, const uint64_t* d_off, size_t n, uint32_t miss, uint32_t* d_out, hipStream_t s,
+                   uint32_t min_len, uint32_t max_len);
+}  // namespace umgap
+
+using namespace umgap;
+
+namespace {
+
+constexpr uint32_t TILE = 2048, PER_THREAD = 8;   // bytes per workgroup of 256 threads / per thread
+
+__global__ __launch_bounds__(256) void k_tryp_mark(const uint64_t* __restrict__ foff, size_t n_frag, uint64_t b0, uint64_t b1, uint32_t* __restrict__ bits,
+                                                   unsigned long long* __restrict__ bad) {
+    size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; f < n_frag; f += step) {
+        const uint64_t o = foff[f], o1 = foff[f + 1];
+        if (o1 < o || o < b0 || o1 > b1) { atomicAdd(bad, 1ull); continue; }
+        if (o1 > o) atomicOr(bits + ((o - b0) >> 5), 1u << ((o - b0) & 31u));
+    }
+}
+
+// the piece-start flags of the 8 bytes [rel, rel + 8) of the range (bit k: byte rel + k); n = bytes in the range
+__device__ __forceinline__ uint32_t piece_start_mask(const uint8_t* __restrict__ base, const uint32_t* __restrict__ bits, uint64_t rel, uint64_t n) {
+    if (rel >= n) return 0u;
+    uint8_t c[PER_THREAD + 1];
+    c[0] = rel ? base[rel - 1] : (uint8_t)'*';                 // the byte before the range's first: any separator will do (it opens a fragment anyway)
+#pragma unroll
+    for (uint32_t k = 0; k < PER_THREAD; k++) c[k + 1] = rel + k < n ? base[rel + k] : (uint8_t)0;
+    // the 8 fragment-start bits: rel is a multiple of 8, so they sit inside one word
+    const uint32_t fb = (bits[rel >> 5] >> (rel & 31u)) & 0xFFu;
+    uint32_t m = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER_THREAD; k++) {
+        const uint8_t prev = c[k], cur = c[k + 1];
+        const bool start = ((fb >> k) & 1u) || cur == '*' || prev == '*' || ((prev == 'K' || prev == 'R') && cur != 'P');
+        if (start && rel + k < n) m |= 1u << k;
+    }
+    return m;
+}
+
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds_wave_sums, uint32_t& block_total) {
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= (uint32_t)o) incl += t; }
+    if (lane == 63) lds_wave_sums[wv] = incl;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (uint32_t w = 0; w < blockDim.x / 64; w++) { const uint32_t s = lds_wave_sums[w]; if (w < wv) before += s; total += s; }
+    __syncthreads();
+    block_total = total;
+    return before + incl - v;
+}
+
+__global__ __launch_bounds__(256) void k_tryp_count(const uint8_t* __restrict__ base, const uint32_t* __restrict__ bits, uint64_t n, uint32_t* __restrict__ tile_counts) {
+    __shared__ uint32_t sums[4];
+    const uint64_t rel = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * PER_THREAD;
+    const uint32_t cnt = (uint32_t)__builtin_popcount(piece_start_mask(base, bits, rel, n));
+    uint32_t total;
+    (void)block_exclusive_scan(cnt, sums, total);
+    if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
+}
+
+// exclusive scan of n_tiles counts in place -> 64-bit bases; one workgroup of 1024 threads, every thread a contiguous chunk
+__global__ __launch_bounds__(1024) void k_tryp_scan(const uint32_t* __restrict__ tile_counts, size_t n_tiles, uint64_t* __restrict__ tile_base, uint64_t* __restrict__ total) {
+    __shared__ uint64_t part[1024];
+    const size_t chunk = (n_tiles + 1023) / 1024;
+    size_t lo = (size_t)threadIdx.x * chunk, hi = lo + chunk;
+    if (lo > n_tiles) lo = n_tiles;
+    if (hi > n_tiles) hi = n_tiles;
+    uint64_t s = 0;
+    for (size_t i = lo; i < hi; i++) s += tile_counts[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t run = 0;
+        for (uint32_t t = 0; t < 1024; t++) { const uint64_t v = part[t]; part[t] = run; run += v; }
+        *total = run;
+    }
+    __syncthreads();
+    uint64_t run = part[threadIdx.x];
+    for (size_t i = lo; i < hi; i++) { tile_base[i] = run; run += tile_counts[i]; }
+}
+
+__global__ __launch_bounds__(256) void k_tryp_write(const uint8_t* __restrict__ base, const uint32_t* __restrict__ bits, uint64_t n, uint64_t b0,
+                                                    const uint64_t* __restrict__ tile_base, uint64_t total, uint64_t cap, uint64_t* __restrict__ offsets) {
+    __shared__ uint32_t sums[4];
+    const uint64_t rel = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * PER_THREAD;
+    uint32_t m = piece_start_mask(base, bits, rel, n);
+    uint32_t blk_total;
+    uint64_t at = tile_base[blockIdx.x] + block_exclusive_scan((uint32_t)__builtin_popcount(m), sums, blk_total);
+    while (m) {
+        const uint32_t k = (uint32_t)__builtin_ctz(m);
+        m &= m - 1;
+        if (at < cap) offsets[at] = b0 + rel + k;
+        at++;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && total < cap + 1) offsets[total] = b0 + n;   // the end of the last piece
+}
+
+// first piece of read r = first piece that starts at or after the read's first byte (an empty read owns no piece)
+__global__ __launch_bounds__(256) void k_tryp_reads(const uint64_t* __restrict__ foff, size_t n_reads, uint32_t F, const uint64_t* __restrict__ offsets, uint64_t total,
+                                                    uint64_t* __restrict__ read_pieces) {
+    size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; r <= n_reads; r += step) {
+        if (r == n_reads) { read_pieces[r] = total; continue; }
+        const uint64_t target = foff[r * F];
+        uint64_t lo = 0, hi = total;
+        while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (offsets[mid] < target) lo = mid + 1; else hi = mid; }
+        read_pieces[r] = lo;
+    }
+}
+
+// a piece that is a `*` was never a peptide: only needed when the length window admits one-byte keys
+__global__ __launch_bounds__(256) void k_tryp_drop_stars(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ offsets, uint64_t total, uint32_t miss, uint32_t* __restrict__ hits) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < total; i += step)
+        if (bytes[offsets[i]] == '*') hits[i] = miss;
+}
+
+inline unsigned grid_for(size_t n) {
+    size_t g = (n + 255) / 256;
+    return (unsigned)std::max<size_t>(1, std::min<size_t>(g, 256 * 16));
+}
+
+// digest scratch of one call (freed by the caller)
+struct Digest {
+    uint32_t* bits = nullptr;
+    uint32_t* tile_counts = nullptr;
+    uint64_t* tile_base = nullptr;
+    uint64_t* d_total = nullptr;
+    unsigned long long* d_bad = nullptr;
+    uint64_t b0 = 0, n = 0, total = 0;
+    size_t n_tiles = 0;
+    void release() {
+        void* p[] = {bits, tile_counts, tile_base, d_total, d_bad};
+        for (void* q : p) if (q) (void)hipFree(q);
+        bits = nullptr; tile_counts = nullptr; tile_base = nullptr; d_total = nullptr; d_bad = nullptr;
+    }
+};
+
+// counts the pieces of fragments [0, n_frag) (host round trip for the count); leaves what k_tryp_write needs in D
+int digest_count(const uint8_t* d_bytes, const uint64_t* d_foff, size_t n_frag, hipStream_t s, Digest& D) {
+    uint64_t ends[2] = {0, 0};
+    UMGAP_HIP(hipMemcpyAsync(&ends[0], d_foff, 8, hipMemcpyDeviceToHost, s));
+    UMGAP_HIP(hipMemcpyAsync(&ends[1], d_foff + n_frag, 8, hipMemcpyDeviceToHost, s));
+    UMGAP_HIP(hipStreamSynchronize(s));
+    if (ends[1] < ends[0]) return fail(UMGAP_ERR_INVALID, "tryptic digest: fragment offsets must not decrease");
+    D.b0 = ends[0];
+    D.n = ends[1] - ends[0];
+    D.n_tiles = (size_t)((D.n + TILE - 1) / TILE);
+    if (D.n_tiles > 0x7FFFFFFFull) return fail(UMGAP_ERR_INVALID, "tryptic digest: more than 4 TB of fragments in one call");
+    const size_t words = (size_t)(D.n / 32) + 2;
+    if (hipMalloc((void**)&D.bits, words * 4) != hipSuccess || hipMalloc((void**)&D.tile_counts, std::max<size_t>(D.n_tiles, 1) * 4) != hipSuccess ||
+        hipMalloc((void**)&D.tile_base, std::max<size_t>(D.n_tiles, 1) * 8) != hipSuccess || hipMalloc((void**)&D.d_total, 8) != hipSuccess ||
+        hipMalloc((void**)&D.d_bad, 8) != hipSuccess)
+        return fail(UMGAP_ERR_NOMEM, "tryptic digest: hipMalloc of the scratch failed");
+    UMGAP_HIP(hipMemsetAsync(D.bits, 0, words * 4, s));
+    UMGAP_HIP(hipMemsetAsync(D.d_bad, 0, 8, s));
+    UMGAP_HIP(hipMemsetAsync(D.d_total, 0, 8, s));
+    hipLaunchKernelGGL(k_tryp_mark, dim3(grid_for(n_frag)), dim3(256), 0, s, d_foff, n_frag, D.b0, ends[1], D.bits, D.d_bad);
+    if (D.n_tiles) {
+        hipLaunchKernelGGL(k_tryp_count, dim3((unsigned)D.n_tiles), dim3(256), 0, s, d_bytes + D.b0, D.bits, D.n, D.tile_counts);
+        hipLaunchKernelGGL(k_tryp_scan, dim3(1), dim3(1024), 0, s, D.tile_counts, D.n_tiles, D.tile_base, D.d_total);
+    }
+    unsigned long long bad = 0;
+    UMGAP_HIP(hipMemcpyAsync(&D.total, D.d_total, 8, hipMemcpyDeviceToHost, s));
+    UMGAP_HIP(hipMemcpyAsync(&bad, D.d_bad, 8, hipMemcpyDeviceToHost, s));
+    UMGAP_HIP(hipStreamSynchronize(s));
+    if (bad) return fail(UMGAP_ERR_INVALID, "tryptic digest: fragment offsets must not decrease");
+    return UMGAP_OK;
+}
+
+// d_offsets holds cap + 1 entries, cap >= D.total (with no bytes at all the one block only writes the end: offsets[0] = b0)
+int digest_write(const uint8_t* d_bytes, hipStream_t s, const Digest& D, uint64_t* d_offsets, uint64_t cap) {
+    hipLaunchKernelGGL(k_tryp_write, dim3((unsigned)std::max<size_t>(D.n_tiles, 1)), dim3(256), 0, s, d_bytes + D.b0, D.bits, D.n, D.b0, D.tile_base, D.total, cap, d_offsets);
+    UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int umgap_digest_tryp_dev(const uint8_t* d_bytes, const uint64_t* d_frag_offsets, size_t n_fragments, uint64_t* d_piece_offsets, size_t cap,
+                          size_t* n_pieces, int device, void* stream) {
+    if (!n_pieces || (n_fragments && (!d_bytes || !d_frag_offsets)) || (cap && !d_piece_offsets)) return fail(UMGAP_ERR_INVALID, "umgap_digest_tryp_dev: null argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    *n_pieces = 0;
+    if (!n_fragments) return UMGAP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    Digest D;
+    rc = digest_count(d_bytes, d_frag_offsets, n_fragments, s, D);
+    if (!rc) {
+        *n_pieces = (size_t)D.total;
+        if (cap >= D.total + 1) {       // room for every start and the end
+            rc = digest_write(d_bytes, s, D, d_piece_offsets, D.total);
+            if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = fail(UMGAP_ERR_DEVICE, "umgap_digest_tryp_dev: the digest did not complete");
+        }
+    }
+    D.release();
+    return rc;
+}
+
+int umgap_classify_tryp_dev(umgap_index* ix, umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound, int ranked_only,
+                            const uint8_t* d_bytes, const uint64_t* d_frag_offsets, size_t n_reads, uint32_t fragments_per_read, uint32_t min_len,
+                            uint32_t max_len, uint32_t* d_out_taxon, uint32_t* d_out_status, uint64_t* n_pieces_out, void* stream) {
+    if (!ix || !tx || (n_reads && (!d_bytes || !d_frag_offsets || !d_out_taxon || !d_out_status))) return fail(UMGAP_ERR_INVALID, "umgap_classify_tryp_dev: null argument");
+    if (ix->kind != 2 || !ix->var) return fail(UMGAP_ERR_INVALID, "umgap_classify_tryp_dev: needs a variable-length (tryptic) index");
+    if (ix->device != tx->device) return fail(UMGAP_ERR_INVALID, "umgap_classify_tryp_dev: index and taxonomy live on different devices");
+    if (!fragments_per_read) return fail(UMGAP_ERR_INVALID, "umgap_classify_tryp_dev: fragments_per_read must be at least 1");
+    if (min_len < 1 || max_len < min_len) return fail(UMGAP_ERR_INVALID, "umgap_classify_tryp_dev: need 1 <= min_len <= max_len");
+    int rc = use_device(ix->device);
+    if (rc) return rc;
+    if (n_pieces_out) *n_pieces_out = 0;
+    if (!n_reads) return UMGAP_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n_frag = n_reads * fragments_per_read;
+    Digest D;
+    uint64_t *d_offsets = nullptr, *d_read_pieces = nullptr;
+    uint32_t* d_hits = nullptr;
+    auto done = [&](int code) {
+        (void)hipStreamSynchronize(s);        // the scratch is in use until the aggregate has run
+        D.release();
+        if (d_offsets) (void)hipFree(d_offsets);
+        if (d_read_pieces) (void)hipFree(d_read_pieces);
+        if (d_hits) (void)hipFree(d_hits);
+        return code;
+    };
+    rc = digest_count(d_bytes, d_frag_offsets, n_frag, s, D);
+    if (rc) return done(rc);
+    if (n_pieces_out) *n_pieces_out = D.total;
+    if (hipMalloc((void**)&d_offsets, (D.total + 1) * 8) != hipSuccess || hipMalloc((void**)&d_read_pieces, (n_reads + 1) * 8) != hipSuccess ||
+        hipMalloc((void**)&d_hits, std::max<uint64_t>(D.total, 1) * 4) != hipSuccess)
+        return done(fail(UMGAP_ERR_NOMEM, "umgap_classify_tryp_dev: hipMalloc of the piece list failed"));
+    rc = digest_write(d_bytes, s, D, d_offsets, D.total);
+    if (rc) return done(rc);
+    hipLaunchKernelGGL(k_tryp_reads, dim3(grid_for(n_reads + 1)), dim3(256), 0, s, d_frag_offsets, n_reads, fragments_per_read, d_offsets, D.total, d_read_pieces);
+    if (D.total) {
+        rc = var_lookup_dev(ix->var, d_bytes, d_offsets, (size_t)D.total, 0u, d_hits, s, min_len, max_len);
+        if (rc) return done(rc);
+        if (min_len <= 1) hipLaunchKernelGGL(k_tryp_drop_stars, dim3(grid_for((size_t)D.total)), dim3(256), 0, s, d_bytes, d_offsets, D.total, 0u, d_hits);
+    }
+    if (hipGetLastError() != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, "umgap_classify_tryp_dev: a launch failed"));
+    rc = umgap_aggregate_dev(tx, method, strategy, factor, lower_bound, ranked_only, d_hits, nullptr, d_read_pieces, n_reads, d_out_taxon, d_out_status, stream);
+    return done(rc);
+}
+
+}  // extern "C"
