@@ -89,7 +89,9 @@ void umgap_unpack9(uint64_t key45, char* nine_bytes);
  * the buckets overflow; 6.6 % at 0.6). */
 int umgap_index_build9(const uint64_t* keys45, const uint32_t* taxa, size_t n, double load_factor,
                        int device, umgap_index** out);
-/* Same, key/value arrays already in device memory (on `device`). */
+/* Same, key/value arrays already in device memory (on `device`).  Every build that takes device arrays (this one,
+ * umgap_index_build_var_dev, umgap_index_build_windows9_dev) first waits for the device: the arrays may have been produced on
+ * any stream. */
 int umgap_index_build9_dev(const uint64_t* d_keys45, const uint32_t* d_taxa, size_t n, double load_factor,
                            int device, umgap_index** out);
 /* Writes / reads the table image ("UMGAPIX1" format).  device_mask: bit d set =
@@ -169,7 +171,9 @@ int umgap_digest_tryp_dev(const uint8_t* d_bytes, const uint64_t* d_frag_offsets
 /* The tryptic pipeline of scripts/umgap-analyse.sh (prot2tryp2lca -l min -L max | taxa2agg ...) for device-resident reads:
  * read r owns fragments [r*F, (r+1)*F); digest as above, pieces of min_len..max_len bytes are looked up in the variable-length
  * index (every other piece, and every `*`, is no hit), and the hits of a read are aggregated as umgap_aggregate_dev does.
- * -k / -d (contains / lacks) are not offered here.  Synchronous; *n_pieces_out (nullable) = pieces the digest produced. */
+ * -k / -d (contains / lacks) are not offered here.  The digest's count makes a host round trip; everything after it is
+ * stream-ordered and the call returns without waiting for it.  Scratch lives in the index handle (grow-only): issue the calls
+ * of one handle on one stream.  *n_pieces_out (nullable) = pieces the digest produced. */
 int umgap_classify_tryp_dev(umgap_index* ix, umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound,
                             int ranked_only, const uint8_t* d_bytes, const uint64_t* d_frag_offsets, size_t n_reads,
                             uint32_t fragments_per_read, uint32_t min_len, uint32_t max_len, uint32_t* d_out_taxon,

@@ -395,6 +395,19 @@ def test_general_unknown_and_orphans_vs_oracle(api, method, strategy, factor):
     t, s = tx.aggregate(taxa, offs, method=method, strategy=strategy, factor=factor)
     nbad, bad, wt, ws = agg.taxa2agg_check(taxa, offs, t, s)
     assert nbad == 0, [(reads[int(b)], int(t[int(b)]), int(s[int(b)]), int(wt[int(b)]), int(ws[int(b)])) for b in bad[:5]]
+    # the same reads at a fixed stride (the group kernel of the fused pipelines): a read with an unknown taxon next to resolved ones
+    # must end in its error without its unresolved elements reaching the taxonomy tables (a GPU fault before the guard in P3b)
+    import torch
+    stride = 8
+    strided = np.zeros((len(reads), stride), np.uint32)
+    for i, r in enumerate(reads):
+        strided[i, :len(r)] = r
+    d_t = torch.empty(len(reads), dtype=torch.int32, device="cuda")
+    d_s = torch.empty_like(d_t)
+    tx.aggregate_strided_dev(torch.from_numpy(strided.view(np.int32)).cuda(), stride, len(reads), d_t, d_s, method=method, strategy=strategy, factor=factor)
+    torch.cuda.synchronize()
+    nbad, bad, _, _ = agg.taxa2agg_check(taxa, offs, d_t.cpu().numpy().view(np.uint32), d_s.cpu().numpy().view(np.uint32))
+    assert nbad == 0, bad
 
 
 def test_mrtl_scored_vs_oracle(api):

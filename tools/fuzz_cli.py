@@ -22,6 +22,7 @@ def run(args, data, env=None):
     e = dict(os.environ)
     e.update(env or {})
     p = subprocess.run([UMGAP] + args, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+    run.last_stderr = p.stderr
     return p.returncode, p.stdout
 
 
@@ -168,7 +169,7 @@ def main():
                 bad += 1
                 path = os.path.join(work, "fail_%s_%d.bin" % (cmd, case))
                 open(path, "wb").write(data)
-                print("MISMATCH", cmd, mine[1:], env, "rc", rc, orc, "input", repr(data[:400]), "out", out[:120], "want", oout[:120])
+                print("MISMATCH", cmd, mine[1:], env, "rc", rc, orc, "input", repr(data[:400]), "out", out[:120], "want", oout[:120], "stderr", run.last_stderr[-600:])
                 if bad >= 5:
                     raise SystemExit(1)
     print("fuzz: %d cases x %s, %d mismatches" % (n_cases, cmds, bad))

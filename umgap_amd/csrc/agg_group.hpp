@@ -41,7 +41,8 @@ struct GroupScratch {
 // 0 = no hit).  The strip is consumed.  Results go to out_taxon/out_status[first_read + k]; a read that needs the
 // large-scratch pass is appended to `defer` (or flagged UMGAP_READ_UNSUPPORTED when there is no list).  se_panic: bit
 // (k * frags + f) set = seedextend panicked on fragment f of read k (classify.hip).  unsupported: bit k set = the caller could
-// not stage read k (its strip is empty); reported as UMGAP_READ_UNSUPPORTED.
+// not stage read k (its strip is empty); reported as UMGAP_READ_UNSUPPORTED.  too_long: bit k set = read k did not fit the strip
+// (left empty): it goes to the defer list like a read with too many distinct taxa.
 // The same scratch as pointers, for a kernel that lays the arrays over LDS it no longer needs (k_classify_prot9).
 struct GroupView {
     uint32_t *hkeys, *hcnt, *last;
@@ -65,7 +66,8 @@ template <bool BOUND, class GS>
 __device__ __forceinline__ void general_group(const TaxView& V, GS& G, int method, int strategy, float factor, float lower_bound,
                                               uint32_t* wtaxa, uint32_t stride, uint32_t nr, uint32_t lane, uint64_t se_panic, uint32_t frags,
                                               size_t first_read, uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status,
-                                              uint32_t* __restrict__ defer, uint32_t* __restrict__ defer_count, uint64_t unsupported = 0ull) {
+                                              uint32_t* __restrict__ defer, uint32_t* __restrict__ defer_count, uint64_t unsupported = 0ull,
+                                              uint64_t too_long = 0ull) {
     const bool tree_like = method != UMGAP_METHOD_RMQ || strategy == UMGAP_STRATEGY_MRTL;
     uint32_t k0 = 0;
     while (k0 < nr) {
@@ -200,13 +202,13 @@ __device__ __forceinline__ void general_group(const TaxView& V, GS& G, int metho
                 uint32_t u = 0, v = 0, du = 0, lu = 0;
                 bool inner = false, anc = false;
                 uint64_t m = 0;
-                if (e < w) {
-                    u = wtaxa[base + e];
+                if (e < w && G.rstat[G.rid[e]] == ST_PENDING) {          // a read that ended in an error holds unresolved elements (NONE):
+                    u = wtaxa[base + e];                                  // none of them may reach the taxonomy tables
                     lu = G.last[e];
                     // is e the last element of its read?  (reads are short lists: scan the offsets)
                     inner = true;
                     for (uint32_t r = 0; r < nb; r++) if (G.roff[r + 1] == e + 1) inner = false;
-                    if (u == NONE) inner = false;                         // element of a read that ended in an error
+                    if (u == NONE) inner = false;
                     if (u != NONE) du = V.depth[u];
                     if (inner) {
                         v = wtaxa[base + e + 1];
@@ -219,7 +221,7 @@ __device__ __forceinline__ void general_group(const TaxView& V, GS& G, int metho
                     node = V.parent_pre[(uint32_t)m];
                     if (method == UMGAP_METHOD_RMQ) nlast = V.last_of_pre[node];   // rmq::mix weighs the LCA candidates by their subtree
                 }
-                if (e < w && u != NONE) {
+                if (e < w && u != NONE && G.rstat[G.rid[e]] == ST_PENDING) {
                     if (inner) { G.lca[e] = node; G.adj[e] = anc ? du : (uint32_t)(m >> 32) - 1u; }
                     G.dep[e] = method == UMGAP_METHOD_RMQ ? nlast : du;  // tree::mix needs the depths, rmq::mix the candidates' subtree ends
                 }
@@ -310,6 +312,7 @@ __device__ __forceinline__ void general_group(const TaxView& V, GS& G, int metho
             const bool sp = se_panic && ((se_panic >> (kk * frags)) & ((frags >= 64 ? 0ull : (1ull << frags)) - 1ull));
             if (sp) { st = UMGAP_READ_PANIC; tx = 0; }
             if ((unsupported >> kk) & 1ull) { st = UMGAP_READ_UNSUPPORTED; tx = 0; }
+            if ((too_long >> kk) & 1ull) st = ST_DEFER;
             if (st == ST_DEFER) {
                 if (defer) defer[atomicAdd(defer_count, 1u)] = (uint32_t)read;
                 else { out_taxon[read] = 0; out_status[read] = UMGAP_READ_UNSUPPORTED; }

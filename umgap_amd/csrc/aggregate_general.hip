@@ -109,6 +109,8 @@ namespace umgap {
 
 int launch_strided_group(const TaxView& V, int method, int strategy, float factor, float lower_bound, const uint32_t* d_taxa, uint32_t stride,
                          size_t n_reads, uint32_t* d_out_taxon, uint32_t* d_out_status, uint32_t* d_list, uint32_t* d_count, hipStream_t stream);
+int launch_csr_group(const TaxView& V, int method, int strategy, float factor, float lower_bound, const uint32_t* d_taxa, const uint64_t* d_offsets,
+                     size_t n_reads, uint32_t* d_out_taxon, uint32_t* d_out_status, uint32_t* d_list, uint32_t* d_count, hipStream_t stream);
 
 // Launches the general aggregation: the compact-scratch pass over all reads, the large-scratch pass over whatever it
 // deferred (> 64 distinct taxa), and the global-memory pass over what that one deferred (> 1024).  `d_defer` must hold
@@ -140,6 +142,14 @@ int launch_general(const TaxView& V, int method, int strategy, float factor, flo
         hipLaunchKernelGGL((k_agg_general<true, 1024, 4096, 1>), big_grid, big_block, 0, stream, V, method, strategy, factor, d_taxa, d_scores, d_offsets,
                            stride, n_reads, lower_bound, d_out_taxon, d_out_status, (const uint32_t*)d_list, (const uint32_t*)d_count, d_list2, d_count2);
         hipLaunchKernelGGL(k_agg_general_big<true>, dim3(BIG_SLOTS), dim3(64), 0, stream, V, method, strategy, factor, d_taxa, d_scores, d_offsets, stride,
+                           lower_bound, d_out_taxon, d_out_status, (const uint32_t*)d_list2, (const uint32_t*)d_count2, d_big, BIG_CAP, BIG_HCAP);
+    } else if (d_offsets) {
+        // unscored CSR: the first pass batched over groups of reads (aggregate_group.hip), the rest as above
+        int rc = launch_csr_group(V, method, strategy, factor, lower_bound, d_taxa, d_offsets, n_reads, d_out_taxon, d_out_status, d_list, d_count, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL((k_agg_general<false, 1024, 4096, 1>), big_grid, big_block, 0, stream, V, method, strategy, factor, d_taxa, d_scores, d_offsets,
+                           stride, n_reads, lower_bound, d_out_taxon, d_out_status, (const uint32_t*)d_list, (const uint32_t*)d_count, d_list2, d_count2);
+        hipLaunchKernelGGL(k_agg_general_big<false>, dim3(BIG_SLOTS), dim3(64), 0, stream, V, method, strategy, factor, d_taxa, d_scores, d_offsets, stride,
                            lower_bound, d_out_taxon, d_out_status, (const uint32_t*)d_list2, (const uint32_t*)d_count2, d_big, BIG_CAP, BIG_HCAP);
     } else {
         hipLaunchKernelGGL((k_agg_general<false, 64, 256, 4>), grid, block, 0, stream, V, method, strategy, factor, d_taxa, d_scores, d_offsets, stride,

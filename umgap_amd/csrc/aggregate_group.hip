@@ -39,9 +39,76 @@ __global__ __launch_bounds__(256) void k_agg_strided_group(TaxView V, int method
     }
 }
 
+// The same for the CSR layout (umgap_aggregate_dev: ragged reads, what taxa2agg and the tryptic pipeline produce).  A wave owns a
+// CHUNK of 64 consecutive reads (lane k: the span of read k) and works through it in sub-rounds: the stride of a sub-round is the
+// power of two that holds the longest read still to do (at most 128; longer reads go to the defer list), as many reads as then fit
+// the strip are laid out at that stride -- every strip slot fetches its own taxon, the span coming from the owning lane by
+// ds_bpermute -- and aggregated together.  Short reads (tryptic: 4-20 hits) run 32-64 to a sub-round instead of one per wave.
+__global__ __launch_bounds__(256) void k_agg_csr_group(TaxView V, int method, int strategy, float factor, const uint32_t* __restrict__ taxa,
+                                                       const uint64_t* __restrict__ offsets, size_t n_reads, float lower_bound, uint32_t* __restrict__ out_taxon,
+                                                       uint32_t* __restrict__ out_status, uint32_t* __restrict__ defer, uint32_t* __restrict__ defer_count) {
+    __shared__ uint32_t lds_taxa[4][STRIP];
+    __shared__ GroupScratch scratch[4];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t* wtaxa = lds_taxa[wv];
+    GroupScratch& S = scratch[wv];
+    for (uint32_t i = lane; i < 256; i += 64) { S.hkeys[i] = 0u; S.hcnt[i] = 0u; }
+    wave_sync();
+    const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const size_t n_chunks = (n_reads + 63) / 64;
+    for (size_t c = wave0; c < n_chunks; c += nwaves) {
+        const size_t r0 = c * 64;
+        const uint32_t nr_chunk = (uint32_t)min((size_t)64, n_reads - r0);
+        // lane k: where read r0 + k lies (index clamped: lanes past the end see an empty read)
+        const uint64_t o = offsets[min(r0 + lane, n_reads)], o1 = offsets[min(r0 + lane + 1, n_reads)];
+        const uint64_t l64 = o1 >= o ? o1 - o : 0ull;
+        const bool big = l64 > 128;                                        // does not fit a strip row: the large-scratch pass takes it
+        const uint32_t len = big ? 0u : (uint32_t)l64;
+        const uint32_t o_lo = (uint32_t)o, o_hi = (uint32_t)(o >> 32);
+        uint32_t k0 = 0;
+        while (k0 < nr_chunk) {
+            // stride: the power of two that holds the longest read from k0 on
+            uint32_t m = lane >= k0 && lane < nr_chunk ? len : 0u;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)m, d, 64); m = t > m ? t : m; }
+            uint32_t stride = 1;
+            while (stride < m) stride <<= 1;                                // wave-uniform
+            const uint32_t sh = (uint32_t)__builtin_ctz(stride);
+            const uint32_t nr = min(nr_chunk - k0, STRIP >> sh);
+            const uint32_t nk = nr << sh;
+            for (uint32_t i = lane; i < ((nk + 63u) & ~63u); i += 64) {     // every lane takes part in the shuffles
+                const uint32_t k = i >> sh, j = i & (stride - 1u);
+                const int src = (int)((k0 + k) & 63u);
+                const uint32_t lk = (uint32_t)__shfl((int)len, src, 64);
+                const uint64_t ok = (uint64_t)(uint32_t)__shfl((int)o_lo, src, 64) | ((uint64_t)(uint32_t)__shfl((int)o_hi, src, 64) << 32);
+                if (i < nk) wtaxa[i] = j < lk ? __builtin_nontemporal_load(taxa + ok + j) : 0u;
+            }
+            wave_sync();
+            const uint64_t too_long = (__ballot(big) >> k0) & (nr >= 64 ? ~0ull : ((1ull << nr) - 1ull));
+            general_group<false>(V, S, method, strategy, factor, lower_bound, wtaxa, stride, nr, lane, 0ull, 0u, r0 + k0, out_taxon, out_status, defer, defer_count, 0ull,
+                                 too_long);
+            wave_sync();
+            k0 += nr;
+        }
+    }
+}
+
 }  // namespace
 
 namespace umgap {
+
+int launch_csr_group(const TaxView& V, int method, int strategy, float factor, float lower_bound, const uint32_t* d_taxa, const uint64_t* d_offsets,
+                     size_t n_reads, uint32_t* d_out_taxon, uint32_t* d_out_status, uint32_t* d_list, uint32_t* d_count, hipStream_t stream) {
+    size_t g = ((n_reads + 63) / 64 + 3) / 4;
+    if (g > 256 * 8) g = 256 * 8;
+    if (g < 1) g = 1;
+    if (strategy == UMGAP_STRATEGY_LCA_STAR) return fail(UMGAP_ERR_INVALID, "launch_csr_group: LCA* has its own kernel");
+    hipLaunchKernelGGL(k_agg_csr_group, dim3((unsigned)g), dim3(256), 0, stream, V, method, strategy, factor, d_taxa, d_offsets, n_reads, lower_bound, d_out_taxon,
+                       d_out_status, d_list, d_count);
+    UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}
 
 // MRTL and the hybrids (LCA* keeps its per-read kernel in aggregate.hip, which measured 5 % faster on 16-hit reads): reads with
 // more than 64 distinct taxa land in the defer list (d_list, *d_count, zeroed by the caller), which the caller's large-scratch

@@ -121,4 +121,7 @@ struct umgap_index {
     // non-null: the slot values are not taxon ids but codes bound to that taxonomy (bound.hpp); only the bound
     // fused kernel understands them
     const void* bound_to = nullptr;
+    // grow-only device scratch of umgap_classify_tryp_dev (tryptic.hip): [0] sized by the bytes of a call, [1] by its pieces
+    void* tryp_scratch[2] = {nullptr, nullptr};
+    size_t tryp_scratch_bytes[2] = {0, 0};
 };

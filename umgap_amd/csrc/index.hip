@@ -490,6 +490,10 @@ int new_handle(int device, umgap_index** out) {
     ix->device = device;
     hipError_t e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ix; return fail(UMGAP_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    // a build reads the caller's device arrays on the handle's own (non-blocking) stream: whatever produced them, on whichever
+    // stream, must have finished -- once per handle, before a build that takes seconds
+    e = hipDeviceSynchronize();
+    if (e != hipSuccess) { (void)hipStreamDestroy(ix->stream); delete ix; return fail(UMGAP_ERR_DEVICE, std::string("hipDeviceSynchronize: ") + hipGetErrorString(e)); }
     *out = ix;
     return UMGAP_OK;
 }
@@ -741,6 +745,7 @@ void umgap_index_free(umgap_index* ix) {
             if (v[i] == ix) { v.erase(v.begin() + (long)i); break; }
     }
     if (ix->var) var_free(ix->var);
+    for (void* p : ix->tryp_scratch) if (p) (void)hipFree(p);
     if (ix->d_slots) (void)hipFree(ix->d_slots);
     if (ix->d_stash_keys) (void)hipFree(ix->d_stash_keys);
     if (ix->d_stash_vals) (void)hipFree(ix->d_stash_vals);

@@ -788,6 +788,10 @@ int new_var_handle(int device, umgap_index** out) {
     ix->kind = 2;
     hipError_t e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete ix; return fail(UMGAP_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    // a build reads the caller's device arrays on the handle's own (non-blocking) stream: whatever produced them, on whichever
+    // stream, must have finished -- once per handle, before a build that takes seconds
+    e = hipDeviceSynchronize();
+    if (e != hipSuccess) { (void)hipStreamDestroy(ix->stream); delete ix; return fail(UMGAP_ERR_DEVICE, std::string("hipDeviceSynchronize: ") + hipGetErrorString(e)); }
     *out = ix;
     return UMGAP_OK;
 }

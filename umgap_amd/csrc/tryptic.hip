@@ -150,7 +150,7 @@ inline unsigned grid_for(size_t n) {
     return (unsigned)std::max<size_t>(1, std::min<size_t>(g, 256 * 16));
 }
 
-// digest scratch of one call (freed by the caller)
+// digest scratch of one call: one allocation (the caller's own, or a handle's grow-only cache) carved into the five arrays
 struct Digest {
     uint32_t* bits = nullptr;
     uint32_t* tile_counts = nullptr;
@@ -159,12 +159,36 @@ struct Digest {
     unsigned long long* d_bad = nullptr;
     uint64_t b0 = 0, n = 0, total = 0;
     size_t n_tiles = 0;
+    void* owned = nullptr;              // freed by release(); null when the memory belongs to a cache
+    void** cache = nullptr;             // grow-only cache slot to use instead of a fresh allocation
+    size_t* cache_bytes = nullptr;
     void release() {
-        void* p[] = {bits, tile_counts, tile_base, d_total, d_bad};
-        for (void* q : p) if (q) (void)hipFree(q);
-        bits = nullptr; tile_counts = nullptr; tile_base = nullptr; d_total = nullptr; d_bad = nullptr;
+        if (owned) (void)hipFree(owned);
+        owned = nullptr;
     }
 };
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// `bytes` of device memory: from the cache slot (grown if too small; the stream is drained first, the old block may be in use) or fresh
+int scratch_get(void** cache, size_t* cache_bytes, size_t bytes, hipStream_t s, void** out, void** owned) {
+    if (cache) {
+        if (*cache_bytes < bytes) {
+            UMGAP_HIP(hipStreamSynchronize(s));
+            if (*cache) (void)hipFree(*cache);
+            *cache = nullptr;
+            *cache_bytes = 0;
+            const size_t want = bytes + bytes / 8;
+            if (hipMalloc(cache, want) != hipSuccess) return fail(UMGAP_ERR_NOMEM, "tryptic pipeline: hipMalloc of the scratch failed");
+            *cache_bytes = want;
+        }
+        *out = *cache;
+        return UMGAP_OK;
+    }
+    if (hipMalloc(out, bytes) != hipSuccess) return fail(UMGAP_ERR_NOMEM, "tryptic digest: hipMalloc of the scratch failed");
+    *owned = *out;
+    return UMGAP_OK;
+}
 
 // counts the pieces of fragments [0, n_frag) (host round trip for the count); leaves what k_tryp_write needs in D
 int digest_count(const uint8_t* d_bytes, const uint64_t* d_foff, size_t n_frag, hipStream_t s, Digest& D) {
@@ -177,11 +201,17 @@ int digest_count(const uint8_t* d_bytes, const uint64_t* d_foff, size_t n_frag, 
     D.n = ends[1] - ends[0];
     D.n_tiles = (size_t)((D.n + TILE - 1) / TILE);
     if (D.n_tiles > 0x7FFFFFFFull) return fail(UMGAP_ERR_INVALID, "tryptic digest: more than 4 TB of fragments in one call");
-    const size_t words = (size_t)(D.n / 32) + 2;
-    if (hipMalloc((void**)&D.bits, words * 4) != hipSuccess || hipMalloc((void**)&D.tile_counts, std::max<size_t>(D.n_tiles, 1) * 4) != hipSuccess ||
-        hipMalloc((void**)&D.tile_base, std::max<size_t>(D.n_tiles, 1) * 8) != hipSuccess || hipMalloc((void**)&D.d_total, 8) != hipSuccess ||
-        hipMalloc((void**)&D.d_bad, 8) != hipSuccess)
-        return fail(UMGAP_ERR_NOMEM, "tryptic digest: hipMalloc of the scratch failed");
+    const size_t words = (size_t)(D.n / 32) + 2, tiles = std::max<size_t>(D.n_tiles, 1);
+    const size_t b_bits = align256(words * 4), b_cnt = align256(tiles * 4), b_base = align256(tiles * 8);
+    void* mem = nullptr;
+    int rc = scratch_get(D.cache, D.cache_bytes, b_bits + b_cnt + b_base + 512, s, &mem, &D.owned);
+    if (rc) return rc;
+    char* p = (char*)mem;
+    D.bits = (uint32_t*)p; p += b_bits;
+    D.tile_counts = (uint32_t*)p; p += b_cnt;
+    D.tile_base = (uint64_t*)p; p += b_base;
+    D.d_total = (uint64_t*)p; p += 256;
+    D.d_bad = (unsigned long long*)p;
     UMGAP_HIP(hipMemsetAsync(D.bits, 0, words * 4, s));
     UMGAP_HIP(hipMemsetAsync(D.d_bad, 0, 8, s));
     UMGAP_HIP(hipMemsetAsync(D.d_total, 0, 8, s));
@@ -244,23 +274,27 @@ int umgap_classify_tryp_dev(umgap_index* ix, umgap_taxonomy* tx, int method, int
     if (!n_reads) return UMGAP_OK;
     hipStream_t s = (hipStream_t)stream;
     const size_t n_frag = n_reads * fragments_per_read;
+    // scratch: the index handle's two grow-only blocks (no allocation in the steady state, nothing to free, so no sync at the end:
+    // what follows the count is stream-ordered)
     Digest D;
+    D.cache = &ix->tryp_scratch[0];
+    D.cache_bytes = &ix->tryp_scratch_bytes[0];
     uint64_t *d_offsets = nullptr, *d_read_pieces = nullptr;
     uint32_t* d_hits = nullptr;
-    auto done = [&](int code) {
-        (void)hipStreamSynchronize(s);        // the scratch is in use until the aggregate has run
-        D.release();
-        if (d_offsets) (void)hipFree(d_offsets);
-        if (d_read_pieces) (void)hipFree(d_read_pieces);
-        if (d_hits) (void)hipFree(d_hits);
-        return code;
-    };
+    auto done = [&](int code) { return code; };
     rc = digest_count(d_bytes, d_frag_offsets, n_frag, s, D);
     if (rc) return done(rc);
     if (n_pieces_out) *n_pieces_out = D.total;
-    if (hipMalloc((void**)&d_offsets, (D.total + 1) * 8) != hipSuccess || hipMalloc((void**)&d_read_pieces, (n_reads + 1) * 8) != hipSuccess ||
-        hipMalloc((void**)&d_hits, std::max<uint64_t>(D.total, 1) * 4) != hipSuccess)
-        return done(fail(UMGAP_ERR_NOMEM, "umgap_classify_tryp_dev: hipMalloc of the piece list failed"));
+    {
+        const size_t b_off = align256((D.total + 1) * 8), b_rp = align256((n_reads + 1) * 8), b_hits = align256(std::max<uint64_t>(D.total, 1) * 4);
+        void *mem = nullptr, *unused = nullptr;
+        rc = scratch_get(&ix->tryp_scratch[1], &ix->tryp_scratch_bytes[1], b_off + b_rp + b_hits, s, &mem, &unused);
+        if (rc) return done(rc);
+        char* p = (char*)mem;
+        d_offsets = (uint64_t*)p; p += b_off;
+        d_read_pieces = (uint64_t*)p; p += b_rp;
+        d_hits = (uint32_t*)p;
+    }
     rc = digest_write(d_bytes, s, D, d_offsets, D.total);
     if (rc) return done(rc);
     hipLaunchKernelGGL(k_tryp_reads, dim3(grid_for(n_reads + 1)), dim3(256), 0, s, d_frag_offsets, n_reads, fragments_per_read, d_offsets, D.total, d_read_pieces);
