@@ -10,9 +10,9 @@
 // (the window goes into the probe kernel, index_var.hip), and 0 = "no hit" is what the aggregators skip.
 //
 //   k_tryp_mark     fragment starts -> one bit per byte                                     (n_fragments threads)
-//   k_tryp_count    piece starts per tile of 2048 bytes                                      (reads the bytes once)
+//   k_tryp_count    piece starts per tile of 2048 bytes, the flags kept (1 bit per byte)      (reads the bytes, once)
 //   k_tryp_scan     exclusive scan of the tile counts                                        (one workgroup)
-//   k_tryp_write    the starts, in order: offsets[rank] = position                           (reads the bytes again)
+//   k_tryp_write    the starts, in order: offsets[rank] = position                           (reads the flags)
 //   k_tryp_reads    first piece of every read by binary search in the offsets                (n_reads threads)
 // then k_lookup_var_pipe over the pieces and the CSR aggregate over the hits of each read.
 #include <algorithm>
@@ -49,8 +49,15 @@ __device__ __forceinline__ uint32_t piece_start_mask(const uint8_t* __restrict__
     if (rel >= n) return 0u;
     uint8_t c[PER_THREAD + 1];
     c[0] = rel ? base[rel - 1] : (uint8_t)'*';                 // the byte before the range's first: any separator will do (it opens a fragment anyway)
+    if (rel + PER_THREAD <= n) {                               // one 8-byte load (any alignment) instead of eight
+        typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+        const uint64_t v = *reinterpret_cast<const u64_unaligned*>(base + rel);
 #pragma unroll
-    for (uint32_t k = 0; k < PER_THREAD; k++) c[k + 1] = rel + k < n ? base[rel + k] : (uint8_t)0;
+        for (uint32_t k = 0; k < PER_THREAD; k++) c[k + 1] = (uint8_t)(v >> (8 * k));
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < PER_THREAD; k++) c[k + 1] = rel + k < n ? base[rel + k] : (uint8_t)0;
+    }
     // the 8 fragment-start bits: rel is a multiple of 8, so they sit inside one word
     const uint32_t fb = (bits[rel >> 5] >> (rel & 31u)) & 0xFFu;
     uint32_t m = 0;
@@ -77,41 +84,43 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* l
     return before + incl - v;
 }
 
-__global__ __launch_bounds__(256) void k_tryp_count(const uint8_t* __restrict__ base, const uint32_t* __restrict__ bits, uint64_t n, uint32_t* __restrict__ tile_counts) {
+// also keeps every thread's 8 flags (one byte per 8 bytes of input): k_tryp_write reads those instead of the bytes again
+__global__ __launch_bounds__(256) void k_tryp_count(const uint8_t* __restrict__ base, const uint32_t* __restrict__ bits, uint64_t n, uint32_t* __restrict__ tile_counts,
+                                                    uint8_t* __restrict__ masks) {
     __shared__ uint32_t sums[4];
     const uint64_t rel = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * PER_THREAD;
-    const uint32_t cnt = (uint32_t)__builtin_popcount(piece_start_mask(base, bits, rel, n));
+    const uint32_t mask = piece_start_mask(base, bits, rel, n);
+    masks[(uint64_t)blockIdx.x * 256 + threadIdx.x] = (uint8_t)mask;
+    const uint32_t cnt = (uint32_t)__builtin_popcount(mask);
     uint32_t total;
     (void)block_exclusive_scan(cnt, sums, total);
     if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
 }
 
-// exclusive scan of n_tiles counts in place -> 64-bit bases; one workgroup of 1024 threads, every thread a contiguous chunk
+// exclusive scan of the n_tiles counts -> 64-bit bases; one workgroup of 1024 threads walks the list in slabs of 4096 counts (four
+// consecutive counts per thread, so the loads and stores are coalesced; a slab costs two barriers)
 __global__ __launch_bounds__(1024) void k_tryp_scan(const uint32_t* __restrict__ tile_counts, size_t n_tiles, uint64_t* __restrict__ tile_base, uint64_t* __restrict__ total) {
-    __shared__ uint64_t part[1024];
-    const size_t chunk = (n_tiles + 1023) / 1024;
-    size_t lo = (size_t)threadIdx.x * chunk, hi = lo + chunk;
-    if (lo > n_tiles) lo = n_tiles;
-    if (hi > n_tiles) hi = n_tiles;
-    uint64_t s = 0;
-    for (size_t i = lo; i < hi; i++) s += tile_counts[i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t run = 0;
-        for (uint32_t t = 0; t < 1024; t++) { const uint64_t v = part[t]; part[t] = run; run += v; }
-        *total = run;
+    __shared__ uint32_t sums[16];
+    uint64_t run = 0;
+    for (size_t s0 = 0; s0 < n_tiles; s0 += 4096) {
+        const size_t i = s0 + (size_t)threadIdx.x * 4;
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = i + k < n_tiles ? tile_counts[i + k] : 0u;
+        uint32_t slab_total;
+        uint32_t at = block_exclusive_scan(v[0] + v[1] + v[2] + v[3], sums, slab_total);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { if (i + k < n_tiles) tile_base[i + k] = run + at; at += v[k]; }
+        run += slab_total;
     }
-    __syncthreads();
-    uint64_t run = part[threadIdx.x];
-    for (size_t i = lo; i < hi; i++) { tile_base[i] = run; run += tile_counts[i]; }
+    if (threadIdx.x == 0) *total = run;
 }
 
-__global__ __launch_bounds__(256) void k_tryp_write(const uint8_t* __restrict__ base, const uint32_t* __restrict__ bits, uint64_t n, uint64_t b0,
+__global__ __launch_bounds__(256) void k_tryp_write(const uint8_t* __restrict__ masks, uint64_t n, uint64_t b0,
                                                     const uint64_t* __restrict__ tile_base, uint64_t total, uint64_t cap, uint64_t* __restrict__ offsets) {
     __shared__ uint32_t sums[4];
     const uint64_t rel = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * PER_THREAD;
-    uint32_t m = piece_start_mask(base, bits, rel, n);
+    uint32_t m = rel < n ? (uint32_t)masks[(uint64_t)blockIdx.x * 256 + threadIdx.x] : 0u;
     uint32_t blk_total;
     uint64_t at = tile_base[blockIdx.x] + block_exclusive_scan((uint32_t)__builtin_popcount(m), sums, blk_total);
     while (m) {
@@ -157,6 +166,7 @@ struct Digest {
     uint64_t* tile_base = nullptr;
     uint64_t* d_total = nullptr;
     unsigned long long* d_bad = nullptr;
+    uint8_t* masks = nullptr;
     uint64_t b0 = 0, n = 0, total = 0;
     size_t n_tiles = 0;
     void* owned = nullptr;              // freed by release(); null when the memory belongs to a cache
@@ -202,14 +212,15 @@ int digest_count(const uint8_t* d_bytes, const uint64_t* d_foff, size_t n_frag, 
     D.n_tiles = (size_t)((D.n + TILE - 1) / TILE);
     if (D.n_tiles > 0x7FFFFFFFull) return fail(UMGAP_ERR_INVALID, "tryptic digest: more than 4 TB of fragments in one call");
     const size_t words = (size_t)(D.n / 32) + 2, tiles = std::max<size_t>(D.n_tiles, 1);
-    const size_t b_bits = align256(words * 4), b_cnt = align256(tiles * 4), b_base = align256(tiles * 8);
+    const size_t b_bits = align256(words * 4), b_cnt = align256(tiles * 4), b_base = align256(tiles * 8), b_masks = align256(tiles * 256);
     void* mem = nullptr;
-    int rc = scratch_get(D.cache, D.cache_bytes, b_bits + b_cnt + b_base + 512, s, &mem, &D.owned);
+    int rc = scratch_get(D.cache, D.cache_bytes, b_bits + b_cnt + b_base + b_masks + 512, s, &mem, &D.owned);
     if (rc) return rc;
     char* p = (char*)mem;
     D.bits = (uint32_t*)p; p += b_bits;
     D.tile_counts = (uint32_t*)p; p += b_cnt;
     D.tile_base = (uint64_t*)p; p += b_base;
+    D.masks = (uint8_t*)p; p += b_masks;
     D.d_total = (uint64_t*)p; p += 256;
     D.d_bad = (unsigned long long*)p;
     UMGAP_HIP(hipMemsetAsync(D.bits, 0, words * 4, s));
@@ -217,7 +228,7 @@ int digest_count(const uint8_t* d_bytes, const uint64_t* d_foff, size_t n_frag, 
     UMGAP_HIP(hipMemsetAsync(D.d_total, 0, 8, s));
     hipLaunchKernelGGL(k_tryp_mark, dim3(grid_for(n_frag)), dim3(256), 0, s, d_foff, n_frag, D.b0, ends[1], D.bits, D.d_bad);
     if (D.n_tiles) {
-        hipLaunchKernelGGL(k_tryp_count, dim3((unsigned)D.n_tiles), dim3(256), 0, s, d_bytes + D.b0, D.bits, D.n, D.tile_counts);
+        hipLaunchKernelGGL(k_tryp_count, dim3((unsigned)D.n_tiles), dim3(256), 0, s, d_bytes + D.b0, D.bits, D.n, D.tile_counts, D.masks);
         hipLaunchKernelGGL(k_tryp_scan, dim3(1), dim3(1024), 0, s, D.tile_counts, D.n_tiles, D.tile_base, D.d_total);
     }
     unsigned long long bad = 0;
@@ -229,8 +240,8 @@ int digest_count(const uint8_t* d_bytes, const uint64_t* d_foff, size_t n_frag, 
 }
 
 // d_offsets holds cap + 1 entries, cap >= D.total (with no bytes at all the one block only writes the end: offsets[0] = b0)
-int digest_write(const uint8_t* d_bytes, hipStream_t s, const Digest& D, uint64_t* d_offsets, uint64_t cap) {
-    hipLaunchKernelGGL(k_tryp_write, dim3((unsigned)std::max<size_t>(D.n_tiles, 1)), dim3(256), 0, s, d_bytes + D.b0, D.bits, D.n, D.b0, D.tile_base, D.total, cap, d_offsets);
+int digest_write(hipStream_t s, const Digest& D, uint64_t* d_offsets, uint64_t cap) {
+    hipLaunchKernelGGL(k_tryp_write, dim3((unsigned)std::max<size_t>(D.n_tiles, 1)), dim3(256), 0, s, D.masks, D.n, D.b0, D.tile_base, D.total, cap, d_offsets);
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
 }
@@ -252,7 +263,7 @@ int umgap_digest_tryp_dev(const uint8_t* d_bytes, const uint64_t* d_frag_offsets
     if (!rc) {
         *n_pieces = (size_t)D.total;
         if (cap >= D.total + 1) {       // room for every start and the end
-            rc = digest_write(d_bytes, s, D, d_piece_offsets, D.total);
+            rc = digest_write(s, D, d_piece_offsets, D.total);
             if (!rc && hipStreamSynchronize(s) != hipSuccess) rc = fail(UMGAP_ERR_DEVICE, "umgap_digest_tryp_dev: the digest did not complete");
         }
     }
@@ -295,7 +306,7 @@ int umgap_classify_tryp_dev(umgap_index* ix, umgap_taxonomy* tx, int method, int
         d_read_pieces = (uint64_t*)p; p += b_rp;
         d_hits = (uint32_t*)p;
     }
-    rc = digest_write(d_bytes, s, D, d_offsets, D.total);
+    rc = digest_write(s, D, d_offsets, D.total);
     if (rc) return done(rc);
     hipLaunchKernelGGL(k_tryp_reads, dim3(grid_for(n_reads + 1)), dim3(256), 0, s, d_frag_offsets, n_reads, fragments_per_read, d_offsets, D.total, d_read_pieces);
     if (D.total) {
