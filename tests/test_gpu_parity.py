@@ -1425,6 +1425,11 @@ def test_digest_tryp_dev_matches_the_regex(api, torch_cuda):
         want = [p for f in frags for p in _tryptic_pieces(f)]
         assert [p for p in pieces if p != b"*"] == want, trial
         assert all(p == b"*" or b"*" not in p for p in pieces)
+    # offsets that go backwards are refused, not followed
+    bad = torch.tensor([0, 10, 5, 20], dtype=torch.int64, device="cuda")
+    with pytest.raises(api.UmgapError, match="must not decrease"):
+        api.digest_tryp_dev(torch.zeros(32, dtype=torch.uint8, device="cuda"), bad)
+    assert api.digest_tryp_dev(torch.zeros(4, dtype=torch.uint8, device="cuda"), torch.tensor([2, 2, 2], dtype=torch.int64, device="cuda")).tolist() == [2]
 
 
 @pytest.mark.parametrize("mode", [("tree", "hybrid", 0.25, 0.0), ("rmq", "mrtl", 0.0, 1.0), ("tree", "lca*", 0.0, 2.0), ("rmq", "hybrid", 0.4, 1.0)])
