@@ -91,6 +91,25 @@ def rehearse_cpu(args):
     dist.destroy_process_group()
 
 
+def usable_cores():
+    """Threads this process can really run at once: the affinity mask, capped by the cgroup's CPU quota (a GPU box hands out a
+    share of the host -- os.cpu_count() still says 256 there)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()))):
+        try:
+            quota, period = parse(open(path).read())
+            if quota != "max" and int(quota) > 0:
+                n = min(n, max(1, int(int(quota) / int(period))))
+            break
+        except (OSError, ValueError):
+            continue
+    return max(1, n)
+
+
 def cpu_baseline(n_tax, ids, parents, valid, rank, taxonomy_handle, d_taxon_of_row, d_row_of_id, device):
     """Oracle ("port") timed on the host cores, bounded sample (DESIGN.md "CPU baseline")."""
     import numpy as np
@@ -99,7 +118,7 @@ def cpu_baseline(n_tax, ids, parents, valid, rank, taxonomy_handle, d_taxon_of_r
     import oracle_lib as O
     from umgap_amd import _lib, synth
     from umgap_amd.api import _dev_ptr, _stream_ptr
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     n_cpu_keys, n_pairs = 32_000_000, 200_000
     # CPU index: the first n_cpu_keys members of the synthetic index as a sorted array (binary search =
     # ~25 dependent accesses per get, standing in for the fst automaton walk)
