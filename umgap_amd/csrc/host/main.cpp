@@ -19,6 +19,7 @@
 #include <regex>
 
 #include "../../../include/umgap_hip.h"
+#include "async_io.hpp"
 #include "fastpath.hpp"
 #include "text.hpp"
 
@@ -365,8 +366,8 @@ struct ShardGang {
         // points at stderr until the gang stands
         struct StdoutToStderr {
             int saved;
-            StdoutToStderr() { fflush(stdout); saved = dup(1); if (saved >= 0) dup2(2, 1); }
-            ~StdoutToStderr() { fflush(stdout); if (saved >= 0) { dup2(saved, 1); close(saved); } }
+            StdoutToStderr() { fflush(stdout); umgap_host::AsyncIo::drain_all(); saved = dup(1); if (saved >= 0) dup2(2, 1); }
+            ~StdoutToStderr() { fflush(stdout); umgap_host::AsyncIo::drain_all(); if (saved >= 0) { dup2(saved, 1); close(saved); } }
         } quiet;
         if (local) { if (umgap_comm_init_local(n, 0, comm.data()) != UMGAP_OK) throw CliError(umgap_last_error()); }
         else if (umgap_comm_unique_id(id) != UMGAP_OK) throw CliError(umgap_last_error());
@@ -561,8 +562,9 @@ int cmd_prot2kmer2lca(const std::vector<std::string>& args) {
             int c = accept(fd, nullptr, nullptr);
             if (c < 0) continue;
             printf("Connection accepted. Processing...\n"); fflush(stdout);
-            FILE* in = fdopen(c, "rb");
-            FILE* outf = fdopen(dup(c), "wb");
+            const bool async_io = umgap_host::AsyncIo::enabled();
+            FILE* in = async_io ? umgap_host::AsyncIo::reader(c, true) : fdopen(c, "rb");
+            FILE* outf = async_io ? umgap_host::AsyncIo::writer(dup(c), true) : fdopen(dup(c), "wb");
             try {
                 stream(in, outf);
                 printf("Connection finished succesfully.\n");
@@ -1268,8 +1270,9 @@ int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
             int c = accept(fd, nullptr, nullptr);
             if (c < 0) continue;
             printf("Connection accepted. Processing...\n"); fflush(stdout);
-            FILE* in = fdopen(c, "rb");
-            FILE* outf = fdopen(dup(c), "wb");
+            const bool async_io = umgap_host::AsyncIo::enabled();
+            FILE* in = async_io ? umgap_host::AsyncIo::reader(c, true) : fdopen(c, "rb");
+            FILE* outf = async_io ? umgap_host::AsyncIo::writer(dup(c), true) : fdopen(dup(c), "wb");
             try {
                 stream(in, outf);
                 printf("Connection finished succesfully.\n");
@@ -1456,8 +1459,28 @@ int cmd_printindex(const std::vector<std::string>& args) {
 
 }  // namespace
 
+static int run_command(std::vector<std::string> args);
+
 int main(int argc, char** argv) {
     std::vector<std::string> args(argv + 1, argv + argc);
+    // stdin / stdout behind a reader and a writer thread (async_io.hpp): the stage's pace in a pipe chain is then the slowest of
+    // read, work and write instead of their sum.  Everything written is out before the process ends, whichever way it ends.
+    if (umgap_host::AsyncIo::enabled()) {
+        FILE* in = umgap_host::AsyncIo::reader(0);
+        FILE* out = umgap_host::AsyncIo::writer(1);
+        if (in && out) {
+            stdin = in;
+            stdout = out;
+            atexit([]() { fflush(stdout); umgap_host::AsyncIo::drain_all(); });
+        }
+    }
+    const int rc = run_command(std::move(args));
+    fflush(stdout);
+    umgap_host::AsyncIo::drain_all();
+    return rc;
+}
+
+static int run_command(std::vector<std::string> args) {
     try {
         if (args.empty()) usage_error("umgap: a subcommand is required (pept2lca, prot2kmer2lca, prot2tryp2lca, taxa2agg, seedextend, uniq, prot2kmer2agg, buildindex, printindex)");
         std::string cmd = args[0];
