@@ -504,8 +504,16 @@ def main():
             w.index = None
         del keys
         torch.cuda.empty_cache()
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
         try:
-            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            # BASELINE.json configs[4] as one device call per batch: the tryptic presets of umgap-analyse.sh:289-298 (digest -> length
+            # window -> variable-length lookup -> MRTL) over a 400 M-key tryptic index (tools/bench_tryptic_fused.py)
+            import bench_tryptic_fused
+            out["tryptic_pipeline"] = bench_tryptic_fused.run(400_000_000, 10_000_000, steps=3, workload=w)
+        except Exception as e:  # noqa: BLE001
+            out["tryptic_pipeline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+        try:
             import end_to_end
             out["end_to_end"], out["cpu_baseline_end_to_end"] = end_to_end.run()
         except Exception as e:  # noqa: BLE001

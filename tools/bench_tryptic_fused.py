@@ -20,9 +20,7 @@ import torch
 from umgap_amd import _lib, synth
 from umgap_amd.api import Index, _dev_ptr, _stream_ptr, classify_tryp_dev, digest_tryp_dev
 
-n_keys = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000_000
-n_pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
-F, PEPS, SEED, steps = 2, 2, 43, 3
+F, PEPS, SEED = 2, 2, 43
 L = _lib.load()
 dev = torch.device("cuda", 0)
 
@@ -49,59 +47,67 @@ def write_peptides(ids, first, n):
     return data, offs, total
 
 
-w = synth.SyntheticWorkload(n_tax=2_500_000, n_keys=1000, build_index=False)
-res = {"n_keys": n_keys, "pairs_per_step": n_pairs, "fragments_per_pair": F, "peptides_per_fragment": PEPS}
-t0 = time.perf_counter()
-data, offs, total = write_peptides(None, 0, n_keys)
-taxa = w.d_taxon_of_row[torch.arange(n_keys, device=dev) % w.n_tax].contiguous()
-h = C.c_void_p()
-_lib.check(L.umgap_index_build_var_dev(_dev_ptr(data), _dev_ptr(offs), _dev_ptr(taxa), n_keys, total, 0.0, 0, C.byref(h)))
-ix = Index(h.value)
-torch.cuda.synchronize()
-res["heap_GB"] = round(total / 1e9, 2)
-res["setup_s"] = round(time.perf_counter() - t0, 1)
-del data, offs, taxa
-torch.cuda.empty_cache()
-
-# reads: pair p draws a source row s; each of its F * PEPS peptides is, with 70 %, a member whose taxon row is s (number = s + k *
-# n_tax: every n_tax-th peptide carries the same taxon) or, one time in four, any member; with 30 % a stranger (number >= 10^12)
-batches = []
-for b in range(steps):
-    e = torch.arange(b * n_pairs * F * PEPS, (b + 1) * n_pairs * F * PEPS, dtype=torch.int64, device=dev)
-    r = splitmix(e ^ 0x5DEECE66D)
-    pair = e // (F * PEPS)
-    src = (splitmix(pair ^ 0x2545F491) & 0x7FFFFFFFFFFF) % w.n_tax
-    per_row = max(1, n_keys // w.n_tax)
-    same = src + ((r >> 8) & 0x7FFFFFFF) % per_row * w.n_tax
-    anym = ((r >> 8) & 0x7FFFFFFFFFFF) % n_keys
-    cls = (r & 0xFF) % 100
-    ids = torch.where(cls < 52, same, torch.where(cls < 70, anym, 10**12 + ((r >> 8) & 0x7FFFFFFFFFFF)))
-    ids = torch.clamp(ids, min=0)
-    d, o, tot = write_peptides(ids.contiguous(), 0, ids.numel())
-    foffs = o[::PEPS].contiguous()                     # a fragment = PEPS peptides
-    batches.append((d, foffs, tot))
-    del e, r, pair, src, same, anym, cls, ids, o
-res["input_bytes_per_pair"] = round(batches[0][2] / n_pairs + 8 * F, 1)
-d_t = torch.empty(n_pairs, dtype=torch.int32, device=dev)
-d_s = torch.empty_like(d_t)
-# what the digest gives back: exactly F * PEPS pieces per pair
-po = digest_tryp_dev(batches[0][0], batches[0][1])
-assert po.numel() - 1 == n_pairs * F * PEPS, (po.numel() - 1, n_pairs * F * PEPS)
-del po
-# (tryptic-precision is the same call with -l5; a pair of this workload has four peptides, so it would only time empty reads)
-for name, lb in (("tryptic_sensitivity_mrtl_l1", 1.0), ("tryptic_mrtl_l2", 2.0), ("max_sensitivity_tree_hybrid_f0.25_l1", 1.0)):
-    kw = dict(method="rmq", strategy="mrtl", lower_bound=lb, min_len=9, max_len=45)
-    if "hybrid" in name:
-        kw.update(method="tree", strategy="hybrid", factor=0.25)
-    classify_tryp_dev(ix, w.taxonomy, batches[0][0], batches[0][1], n_pairs, F, d_t, d_s, **kw)
-    torch.cuda.synchronize()
+def run(n_keys=1_000_000_000, n_pairs=10_000_000, steps=3, workload=None):
+    """Builds the index, the read batches, times the presets; returns the result dict.  `workload`: a SyntheticWorkload whose
+    taxonomy to reuse (bench.py), else one is made."""
+    w = workload if workload is not None else synth.SyntheticWorkload(n_tax=2_500_000, n_keys=1000, build_index=False)
+    res = {"n_keys": n_keys, "pairs_per_step": n_pairs, "fragments_per_pair": F, "peptides_per_fragment": PEPS}
     t0 = time.perf_counter()
-    for i in range(steps):
-        n_pieces = classify_tryp_dev(ix, w.taxonomy, batches[i][0], batches[i][1], n_pairs, F, d_t, d_s, **kw)
+    data, offs, total = write_peptides(None, 0, n_keys)
+    taxa = w.d_taxon_of_row[torch.arange(n_keys, device=dev) % w.n_tax].contiguous()
+    h = C.c_void_p()
+    _lib.check(L.umgap_index_build_var_dev(_dev_ptr(data), _dev_ptr(offs), _dev_ptr(taxa), n_keys, total, 0.0, 0, C.byref(h)))
+    ix = Index(h.value)
     torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
-    st = d_s.cpu()
-    res[name] = {"pairs_per_s": round(n_pairs / ms * 1e3, 1), "ms_per_step": round(ms, 3), "pieces_per_step": n_pieces,
-                 "G_pieces_per_s": round(n_pieces / ms / 1e6, 2), "status_ok_frac": round(float((st == 0).float().mean()), 3),
-                 "status_empty_frac": round(float((st == 1).float().mean()), 3)}
-print(json.dumps(res))
+    res["heap_GB"] = round(total / 1e9, 2)
+    res["setup_s"] = round(time.perf_counter() - t0, 1)
+    del data, offs, taxa
+    torch.cuda.empty_cache()
+
+    # reads: pair p draws a source row s; each of its F * PEPS peptides is, with 70 %, a member whose taxon row is s (number = s + k *
+    # n_tax: every n_tax-th peptide carries the same taxon) or, one time in four, any member; with 30 % a stranger (number >= 10^12)
+    batches = []
+    for b in range(steps):
+        e = torch.arange(b * n_pairs * F * PEPS, (b + 1) * n_pairs * F * PEPS, dtype=torch.int64, device=dev)
+        r = splitmix(e ^ 0x5DEECE66D)
+        pair = e // (F * PEPS)
+        src = (splitmix(pair ^ 0x2545F491) & 0x7FFFFFFFFFFF) % w.n_tax
+        per_row = max(1, n_keys // w.n_tax)
+        same = src + ((r >> 8) & 0x7FFFFFFF) % per_row * w.n_tax
+        anym = ((r >> 8) & 0x7FFFFFFFFFFF) % n_keys
+        cls = (r & 0xFF) % 100
+        ids = torch.where(cls < 52, same, torch.where(cls < 70, anym, 10**12 + ((r >> 8) & 0x7FFFFFFFFFFF)))
+        ids = torch.clamp(ids, min=0)
+        d, o, tot = write_peptides(ids.contiguous(), 0, ids.numel())
+        foffs = o[::PEPS].contiguous()                     # a fragment = PEPS peptides
+        batches.append((d, foffs, tot))
+        del e, r, pair, src, same, anym, cls, ids, o
+    res["input_bytes_per_pair"] = round(batches[0][2] / n_pairs + 8 * F, 1)
+    d_t = torch.empty(n_pairs, dtype=torch.int32, device=dev)
+    d_s = torch.empty_like(d_t)
+    # what the digest gives back: exactly F * PEPS pieces per pair
+    po = digest_tryp_dev(batches[0][0], batches[0][1])
+    assert po.numel() - 1 == n_pairs * F * PEPS, (po.numel() - 1, n_pairs * F * PEPS)
+    del po
+    # (tryptic-precision is the same call with -l5; a pair of this workload has four peptides, so it would only time empty reads)
+    for name, lb in (("tryptic_sensitivity_mrtl_l1", 1.0), ("tryptic_mrtl_l2", 2.0), ("max_sensitivity_tree_hybrid_f0.25_l1", 1.0)):
+        kw = dict(method="rmq", strategy="mrtl", lower_bound=lb, min_len=9, max_len=45)
+        if "hybrid" in name:
+            kw.update(method="tree", strategy="hybrid", factor=0.25)
+        classify_tryp_dev(ix, w.taxonomy, batches[0][0], batches[0][1], n_pairs, F, d_t, d_s, **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            n_pieces = classify_tryp_dev(ix, w.taxonomy, batches[i][0], batches[i][1], n_pairs, F, d_t, d_s, **kw)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
+        st = d_s.cpu()
+        res[name] = {"pairs_per_s": round(n_pairs / ms * 1e3, 1), "ms_per_step": round(ms, 3), "pieces_per_step": n_pieces,
+                     "G_pieces_per_s": round(n_pieces / ms / 1e6, 2), "status_ok_frac": round(float((st == 0).float().mean()), 3),
+                     "status_empty_frac": round(float((st == 1).float().mean()), 3)}
+    ix.close()
+    return res
+
+
+if __name__ == "__main__":
+    print(json.dumps(run(int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000_000, int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000)))
