@@ -108,3 +108,49 @@ def test_differential_fuzz_text_filters(taxonomy):
     p = subprocess.run([os.sys.executable, os.path.join(ROOT, "tools", "fuzz_cli.py"), "150", "seedextend", "uniq"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, FUZZ_SEED="3"))
     assert p.returncode == 0, p.stdout[-3000:]
+
+
+def _big_hits(n_records, seed=3):
+    rng = np.random.default_rng(seed)
+    vals = rng.integers(0, 50, (n_records, 30))
+    vals[rng.random(vals.shape) < 0.3] = 0
+    return b"".join(b">r%d/%d\n" % (i // 2, i % 2 + 1) + b"\n".join(b"%d" % v for v in vals[i]) + b"\n" for i in range(n_records))
+
+
+def test_async_io_same_bytes_through_a_pipe_chain(tmp_path):
+    """stdin / stdout behind reader and writer threads (async_io.hpp) against the plain path (UMGAP_ASYNC_IO=0): a chain of two
+    stages through a real pipe, blocks much smaller than the data, must give the same bytes -- and everything written must be out
+    when the process ends, also when it ends with an error."""
+    if not os.path.exists(UMGAP):
+        pytest.skip("umgap_amd/bin/umgap is not built")
+    data = _big_hits(60_000)
+    src = tmp_path / "hits.fa"
+    src.write_bytes(data)
+    outs = {}
+    for mode in ("0", "1"):
+        env = dict(os.environ, UMGAP_ASYNC_IO=mode, UMGAP_BLOCK_BYTES=str(1 << 16))
+        with open(src, "rb") as fi:
+            a = subprocess.Popen([UMGAP, "seedextend", "-g1", "-s2"], stdin=fi, stdout=subprocess.PIPE, env=env)
+            b = subprocess.Popen([UMGAP, "uniq", "-d", "/"], stdin=a.stdout, stdout=subprocess.PIPE, env=env)
+            a.stdout.close()
+            outs[mode] = b.communicate(timeout=120)[0]
+            assert a.wait(timeout=60) == 0 and b.returncode == 0
+    assert outs["0"] == outs["1"] and len(outs["1"]) > 100_000
+    # an error in the middle of the stream: what was written before it is all there, then exit 1
+    bad = data[:len(data) // 2] + b">x\nnot-a-number\n" + data[len(data) // 2:]
+    res = {m: run(["seedextend", "-g1", "-s2"], bad, UMGAP_ASYNC_IO=m, UMGAP_BLOCK_BYTES=1 << 16) for m in ("0", "1")}
+    assert res["0"][0] == res["1"][0] == 1 and res["0"][1] == res["1"][1] and res["0"][2] == res["1"][2] and len(res["1"][1]) > 10_000
+
+
+def test_async_io_consumer_that_leaves_early(tmp_path):
+    """A reader that closes the pipe after a few bytes (`| head`): the stage must end promptly (SIGPIPE), not hang on its writer."""
+    if not os.path.exists(UMGAP):
+        pytest.skip("umgap_amd/bin/umgap is not built")
+    src = tmp_path / "hits.fa"
+    src.write_bytes(_big_hits(200_000))
+    with open(src, "rb") as fi:
+        a = subprocess.Popen([UMGAP, "uniq", "-d", "/"], stdin=fi, stdout=subprocess.PIPE)
+        first = a.stdout.read(100)
+        a.stdout.close()
+        rc = a.wait(timeout=60)
+    assert len(first) == 100 and rc != 0
