@@ -72,6 +72,11 @@ __device__ __forceinline__ float wave_maxf(float v) {
 // a binary-lifting table: seven dependent gathers per LCA, as many random requests per read as the probes themselves.
 typedef uint32_t agg_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint64_t lane_argmin_depth(const TaxView& V, uint32_t lo, uint32_t hi) {
+    // Callers pass preorder indexes of resolved taxa only.  Two instructions of insurance all the same: an index past the tables
+    // (NONE from an unresolved taxon that slipped through) would be a GPU memory fault, which on this hardware can reset the
+    // node for everyone -- clamped, it is a wrong LCA in a read that is in an error state anyway.
+    hi = min(hi, V.n_blocks8 * 8u - 1u);
+    lo = min(lo, hi);
     const uint32_t bl = lo >> 3, bh = hi >> 3;
     const agg_u32x4* d4 = reinterpret_cast<const agg_u32x4*>(V.depth);
     const agg_u32x4 a0 = d4[2 * (size_t)bl], a1 = d4[2 * (size_t)bl + 1];
