@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Randomised differential test of the DEVICE aggregation paths against the oracle (the CLI fuzzer, tools/fuzz_cli.py, feeds byte
+soup through the commands; this one feeds taxon soup through the C ABI).  Every iteration draws a taxonomy (shape, invalid and
+unranked nodes, ids missing from it), reads (lengths 0..200, zeros, unknown ids, few or many distinct taxa) and runs them
+through
+  * umgap_aggregate_dev            CSR: k_agg_lca / k_agg_csr_group (+ the large-scratch passes),
+  * umgap_aggregate_strided_dev    fixed stride: k_agg_lca / k_agg_strided_group,
+  * umgap_classify9[_strategy]_dev the fused kernels over an index whose values are those taxa (unknown ids included), with and
+                                   without the table bound to the taxonomy where binding is possible,
+for every strategy, both methods, several -l / -f, ranked and unranked snapping, and checks each answer with the oracle's
+taxa2agg (tie sets honoured).  Prints one line per mismatch and a summary; exit status 1 if anything differed.
+    python tools/fuzz_device.py [iterations] [seed]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+
+import oracle_lib as O
+from umgap_amd import api
+from umgap_amd.synth import synthetic_taxonomy
+
+LETTERS = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+MODES = [("tree", "lca*"), ("rmq", "lca*"), ("tree", "hybrid"), ("rmq", "hybrid"), ("rmq", "mrtl"), ("tree", "mrtl")]
+
+
+def draw_taxonomy(rng):
+    n = int(rng.choice([30, 300, 5000]))
+    ids, par, valid, rank = synthetic_taxonomy(n, int(n * rng.uniform(1.2, 3.0)), max_depth=int(rng.integers(3, min(30, max(4, n // 4)))),
+                                               seed=int(rng.integers(1, 1 << 30)))
+    return ids, par, valid, rank
+
+
+def draw_reads(rng, ids, id_space, n_reads, max_len):
+    unknown = np.setdiff1d(np.arange(1, id_space + 50, dtype=np.uint32), ids)[:200]
+    reads = []
+    for _ in range(n_reads):
+        n = int(rng.integers(0, max_len + 1))
+        style = rng.random()
+        if style < 0.4:
+            pool = rng.choice(ids, int(rng.integers(1, 6)))
+        elif style < 0.8:
+            pool = rng.choice(ids, int(rng.integers(1, 80)))
+        else:
+            pool = ids
+        r = rng.choice(pool, n).astype(np.uint32)
+        r[rng.random(n) < rng.choice([0.0, 0.3, 0.9])] = 0
+        if len(unknown) and rng.random() < 0.15 and n:
+            r[rng.integers(0, n, int(rng.integers(1, 4)))] = rng.choice(unknown)
+        reads.append(r)
+    return reads
+
+
+def check(tag, agg, taxa, offs, t, s, lb, fails, ctx):
+    nbad, bad, wt, ws = agg.taxa2agg_check(taxa, offs, t, s, lower_bound=lb, ranked=ctx["ranked"])
+    if nbad:
+        b = int(bad[0])
+        fails.append(tag)
+        print("MISMATCH", tag, ctx, "read", b, "got", int(t[b]), int(s[b]), "want", int(wt[b]), int(ws[b]), "taxa", taxa[int(offs[b]):int(offs[b + 1])][:40].tolist(), flush=True)
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+    rng = np.random.default_rng(seed)
+    fails, n_checks = [], 0
+    print("fuzz_device: seed", seed, flush=True)
+    for it in range(iters):
+        ids, par, valid, rank = draw_taxonomy(rng)
+        tx = api.Taxonomy(ids, par, valid, rank)
+        otx = O.Taxonomy.from_arrays(ids, par, valid, rank)
+        max_len = int(rng.choice([6, 16, 84, 200]))
+        reads = draw_reads(rng, ids, int(ids.max()), int(rng.integers(50, 1500)), max_len)
+        taxa = np.concatenate(reads) if reads else np.zeros(0, np.uint32)
+        offs = np.zeros(len(reads) + 1, np.uint64)
+        offs[1:] = np.cumsum([len(r) for r in reads])
+        d_taxa = torch.from_numpy(taxa.view(np.int32).copy()).cuda() if len(taxa) else torch.zeros(1, dtype=torch.int32, device="cuda")
+        d_offs = torch.from_numpy(offs.view(np.int64)).cuda()
+        n = len(reads)
+        d_t = torch.empty(n, dtype=torch.int32, device="cuda")
+        d_s = torch.empty_like(d_t)
+        # the fused kernels: an index whose keys are the (read, position) pairs and whose values are the taxa (zeros = absent keys)
+        stride = max(1, max_len if max_len <= 128 else 128)
+        fused_ok = max_len <= 128
+        if fused_ok:
+            strided = np.zeros((n, stride), np.uint32)
+            for i, r in enumerate(reads):
+                strided[i, :len(r)] = r
+            d_strided = torch.from_numpy(strided.view(np.int32)).cuda()
+            nz = np.flatnonzero(strided.ravel())
+            keys_all = (np.arange(n * stride, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(12345)) % np.uint64(1 << 44)
+            keys_all = np.unique(keys_all, return_index=True)
+            fused_ok = len(keys_all[0]) == n * stride
+            if fused_ok:
+                key_of = (np.arange(n * stride, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(12345)) % np.uint64(1 << 44)
+                ix = api.Index.build(key_of[nz], strided.ravel()[nz]) if len(nz) else None
+                d_keys = torch.from_numpy(key_of.view(np.int64)).cuda()
+        for method, strategy in MODES:
+            for ranked in (False, True):
+                lb = float(rng.choice([0.0, 1.0, 2.0, 3.0]))
+                factor = float(rng.choice([0.1, 0.25, 0.5, 0.9]))
+                if strategy == "mrtl" and method == "tree":
+                    continue
+                agg = O.Aggregator(otx, method, strategy, factor)
+                ctx = dict(it=it, n_tax=len(ids), max_len=max_len, method=method, strategy=strategy, lb=lb, f=factor, ranked=ranked)
+                kw = dict(method=method, strategy=strategy, factor=factor, lower_bound=lb, ranked_only=ranked)
+                tx.aggregate_dev(d_taxa, d_offs, d_t, d_s, **kw)
+                torch.cuda.synchronize()
+                check("csr", agg, taxa, offs, d_t.cpu().numpy().view(np.uint32), d_s.cpu().numpy().view(np.uint32), lb, fails, ctx)
+                n_checks += 1
+                if max_len <= 128:
+                    d_t2, d_s2 = torch.empty_like(d_t), torch.empty_like(d_s)
+                    tx.aggregate_strided_dev(d_strided, stride, n, d_t2, d_s2, **kw)
+                    torch.cuda.synchronize()
+                    check("strided", agg, taxa, offs, d_t2.cpu().numpy().view(np.uint32), d_s2.cpu().numpy().view(np.uint32), lb, fails, ctx)
+                    n_checks += 1
+                    if fused_ok and ix is not None:
+                        for bind in (False, True):
+                            if bind:
+                                try:
+                                    ix.bind(tx)
+                                except api.UmgapError:
+                                    break          # a value outside the taxonomy: binding is refused, as documented
+                            api.classify9_dev(ix, tx, d_keys, n, stride, d_t2, d_s2, method=method, strategy=strategy, factor=factor, lower_bound=lb,
+                                              ranked_only=ranked)
+                            torch.cuda.synchronize()
+                            check("fused bound=%d" % bind, agg, taxa, offs, d_t2.cpu().numpy().view(np.uint32), d_s2.cpu().numpy().view(np.uint32), lb, fails, ctx)
+                            n_checks += 1
+                            if bind:
+                                ix.unbind(tx)
+        if (it + 1) % 5 == 0:
+            print("iteration %d: %d checks, %d mismatches" % (it + 1, n_checks, len(fails)), flush=True)
+    print("fuzz_device: %d iterations, %d checks, %d mismatches (seed %d)" % (iters, n_checks, len(fails), seed))
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
