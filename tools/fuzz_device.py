@@ -7,6 +7,7 @@ through
   * umgap_aggregate_strided_dev    fixed stride: k_agg_lca / k_agg_strided_group,
   * umgap_classify9[_strategy]_dev the fused kernels over an index whose values are those taxa (unknown ids included), with and
                                    without the table bound to the taxonomy where binding is possible,
+  * umgap_digest_tryp_dev          byte soup against the reference's regex digest,
 for every strategy, both methods, several -l / -f, ranked and unranked snapping, and checks each answer with the oracle's
 taxa2agg (tie sets honoured).  Prints one line per mismatch and a summary; exit status 1 if anything differed.
     python tools/fuzz_device.py [iterations] [seed]"""
@@ -53,6 +54,30 @@ def draw_reads(rng, ids, id_space, n_reads, max_len):
             r[rng.integers(0, n, int(rng.integers(1, 4)))] = rng.choice(unknown)
         reads.append(r)
     return reads
+
+
+def digest_leg(rng, fails):
+    """umgap_digest_tryp_dev on byte soup (any byte but a newline, which a FASTA sequence cannot hold) against the reference's regex
+    digest (src/commands/prot2tryp2lca.rs:107-116)."""
+    import re
+    pat = re.compile(rb"([KR])([^P])")
+    alphabet = np.frombuffer(bytes(b for b in range(256) if b != 10) + b"KRP*" * 40 + b"ACDEFGHILMNQSTVWY" * 8, np.uint8)
+    n_frag = int(rng.choice([1, 3, 50, 2000]))
+    frags = [rng.choice(alphabet, int(rng.choice([0, 1, 2, 9, 60, 300, 5000], p=[.1, .1, .1, .2, .3, .15, .05]))).tobytes() for _ in range(n_frag)]
+    pad = int(rng.integers(0, 20))
+    data = np.frombuffer(b"K" * pad + b"".join(frags) + b"RR", np.uint8)
+    offs = np.zeros(n_frag + 1, np.int64)
+    offs[1:] = np.cumsum([len(f) for f in frags])
+    got = api.digest_tryp_dev(torch.from_numpy(data.copy()).cuda(), torch.from_numpy(offs + pad).cuda()).cpu().numpy()
+    host = data.tobytes()
+    pieces = [host[int(a):int(b)] for a, b in zip(got[:-1], got[1:]) if host[int(a):int(b)] != b"*"]
+    want = []
+    for f in frags:
+        twice = pat.sub(rb"\1\n\2", pat.sub(rb"\1\n\2", f))
+        want += [p for p in twice.replace(b"*", b"\n").split(b"\n") if p]
+    if pieces != want:
+        fails.append("digest")
+        print("MISMATCH digest n_frag", n_frag, "pieces", len(pieces), "want", len(want), flush=True)
 
 
 def check(tag, agg, taxa, offs, t, s, lb, fails, ctx):
@@ -132,6 +157,8 @@ def main():
                             n_checks += 1
                             if bind:
                                 ix.unbind(tx)
+        digest_leg(rng, fails)
+        n_checks += 1
         if (it + 1) % 5 == 0:
             print("iteration %d: %d checks, %d mismatches" % (it + 1, n_checks, len(fails)), flush=True)
     print("fuzz_device: %d iterations, %d checks, %d mismatches (seed %d)" % (iters, n_checks, len(fails), seed))
