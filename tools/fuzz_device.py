@@ -80,6 +80,39 @@ def digest_leg(rng, fails):
         print("MISMATCH digest n_frag", n_frag, "pieces", len(pieces), "want", len(want), flush=True)
 
 
+def seedextend_leg(rng, tx, agg, ix, d_keys, strided, lb, fails, ctx):
+    """The fused probe -> seedextend -> aggregate kernels (every read end a fragment) against the oracle's literal seedextend
+    state machine followed by its taxa2agg; a fragment on which the reference would panic (src/commands/seedextend.rs:169-173)
+    must give READ_PANIC."""
+    n, stride = strided.shape
+    divisors = [f for f in (1, 2, 3, 4, 6, 8) if stride % f == 0 and stride // f >= 1]
+    F = int(rng.choice(divisors))
+    min_seed, max_gap = int(rng.choice([0, 1, 2, 3, 4])), int(rng.choice([0, 1, 2]))
+    flen = stride // F
+    hits, roffs, panicked = [], [0], np.zeros(n, bool)
+    for r in range(n):
+        for f in range(F):
+            kept = O.seedextend_record(strided[r, f * flen:(f + 1) * flen], min_seed, max_gap)
+            if kept is None:
+                panicked[r] = True
+            else:
+                hits += kept.tolist()
+        roffs.append(len(hits))
+    d_t = torch.empty(n, dtype=torch.int32, device="cuda")
+    d_s = torch.empty_like(d_t)
+    api.classify9_dev(ix, tx, d_keys, n, stride, d_t, d_s, method=ctx["method"], strategy=ctx["strategy"], factor=ctx["f"], lower_bound=lb,
+                      ranked_only=ctx["ranked"], fragments_per_read=F, min_seed_size=min_seed, max_gap_size=max_gap)
+    torch.cuda.synchronize()
+    t, s = d_t.cpu().numpy().view(np.uint32).copy(), d_s.cpu().numpy().view(np.uint32).copy()
+    if not (s[panicked] == api.READ_PANIC).all():
+        fails.append("seedextend panic")
+        print("MISMATCH seedextend panic", ctx, dict(F=F, s=min_seed, g=max_gap), flush=True)
+    hits, roffs = np.array(hits, np.uint32), np.array(roffs, np.uint64)
+    _, _, wt, ws = agg.taxa2agg_check(hits, roffs, lower_bound=lb, ranked=ctx["ranked"])
+    t[panicked], s[panicked] = wt[panicked], ws[panicked]          # those reads were checked above
+    check("fused seedextend F=%d s=%d g=%d" % (F, min_seed, max_gap), agg, hits, roffs, t, s, lb, fails, ctx)
+
+
 def check(tag, agg, taxa, offs, t, s, lb, fails, ctx):
     nbad, bad, wt, ws = agg.taxa2agg_check(taxa, offs, t, s, lower_bound=lb, ranked=ctx["ranked"])
     if nbad:
@@ -157,6 +190,8 @@ def main():
                             n_checks += 1
                             if bind:
                                 ix.unbind(tx)
+                        seedextend_leg(rng, tx, agg, ix, d_keys, strided, lb, fails, ctx)
+                        n_checks += 1
         digest_leg(rng, fails)
         n_checks += 1
         if (it + 1) % 5 == 0:
