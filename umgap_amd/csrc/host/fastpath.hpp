@@ -36,6 +36,9 @@ inline unsigned worker_count() {
 class BlockReader {
   public:
     explicit BlockReader(FILE* f, size_t block = default_block()) : f_(f), buf_(block) {}
+    // The view handed out by next() then stays valid until the call AFTER the next one (two buffers take turns): a caller can
+    // still format block n from its bytes while block n + 1 is being read and parsed.
+    void keep_previous_block() { keep_previous_ = true; }
     static size_t default_block() {
         const char* env = getenv("UMGAP_BLOCK_BYTES");  // tests shrink it to exercise the block seams
         if (env && *env) { long v = atol(env); if (v >= 16) return (size_t)v; }
@@ -44,7 +47,11 @@ class BlockReader {
     // Returns false when the stream is exhausted.  [data, data+len) holds whole records; the view
     // stays valid until the next call.
     bool next(const char*& data, size_t& len) {
-        if (carry_) { memmove(buf_.data(), buf_.data() + carry_off_, carry_); }
+        if (keep_previous_) {
+            if (other_.size() < buf_.size()) other_.resize(buf_.size());
+            if (carry_) memcpy(other_.data(), buf_.data() + carry_off_, carry_);
+            buf_.swap(other_);
+        } else if (carry_) { memmove(buf_.data(), buf_.data() + carry_off_, carry_); }
         size_t have = carry_;
         carry_ = 0;
         for (;;) {
@@ -83,9 +90,9 @@ class BlockReader {
 
   private:
     FILE* f_;
-    std::vector<char> buf_;
+    std::vector<char> buf_, other_;
     size_t carry_ = 0, carry_off_ = 0;
-    bool eof_ = false, first_ = true, first_line_error_ = false, lines_only_ = false;
+    bool eof_ = false, first_ = true, first_line_error_ = false, lines_only_ = false, keep_previous_ = false;
 };
 
 // Record-aligned split of a block into at most `parts` ranges [begin[i], begin[i+1]).

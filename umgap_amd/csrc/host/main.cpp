@@ -271,9 +271,13 @@ void format_lookup_part(const char* d, const uint32_t* taxa, bool one_on_one, co
 // get() over a batch of packed 9-mers: one GPU's table, or the table sharded over several
 using LookupFn = std::function<void(const uint64_t* keys, size_t n, uint32_t* taxa)>;
 
+// Two stages per block, overlapped: while block n is looked up on the device, formatted and written (stage B, on a helper
+// thread), block n + 1 is read and tokenized (stage A).  Stage B runs for one block at a time and in input order, so the
+// chunk bookkeeping (`held`, `g0`) and the order of output and errors are those of the plain loop.
 void stream_lookup(FILE* in, FILE* outf, const LookupFn& lookup, bool one_on_one, bool kmer_mode, size_t k, size_t chunk) {
     if (chunk == 0) chunk = 1;
     BlockReader blocks(in);
+    blocks.keep_previous_block();
     const unsigned T = worker_count();
     const char* d;
     size_t len;
@@ -281,12 +285,11 @@ void stream_lookup(FILE* in, FILE* outf, const LookupFn& lookup, bool one_on_one
     std::vector<uint32_t> taxa;
     std::string held;          // formatted records [held_from, g0): the still open chunk
     size_t g0 = 0;             // global index of the block's first record
-    while (blocks.next(d, len)) {
-        if (blocks.first_line_error()) throw CliError("Expected > at beginning of fasta header.");
-        std::vector<size_t> cuts = split_records(d, len, T);
-        const size_t np = cuts.size() - 1;
-        std::vector<LookupPart> parts(np);
-        parallel_for(np, [&](size_t i) { parse_lookup_part(d, cuts[i], cuts[i + 1], kmer_mode, k, parts[i]); });
+    struct Job { const char* d = nullptr; std::vector<LookupPart> parts; };
+    auto stage_b = [&](Job& job) {
+        const char* d = job.d;
+        std::vector<LookupPart>& parts = job.parts;
+        const size_t np = parts.size();
         // a failing range ends the stream: later ranges are dropped
         size_t used = np;
         for (size_t i = 0; i < np; i++)
@@ -328,6 +331,37 @@ void stream_lookup(FILE* in, FILE* outf, const LookupFn& lookup, bool one_on_one
         }
         for (size_t i = 0; i < used; i++) held.append(tails[i]);
         g0 += n_rec;
+    };
+    Job jobs[2];
+    int cur = 0;
+    std::thread helper;
+    std::exception_ptr helper_err;
+    auto join_helper = [&]() {
+        if (helper.joinable()) helper.join();
+        if (helper_err) { std::exception_ptr e = helper_err; helper_err = nullptr; std::rethrow_exception(e); }
+    };
+    try {
+        while (blocks.next(d, len)) {
+            if (blocks.first_line_error()) { join_helper(); throw CliError("Expected > at beginning of fasta header."); }
+            Job& J = jobs[cur];
+            std::vector<size_t> cuts = split_records(d, len, T);
+            const size_t np = cuts.size() - 1;
+            J.d = d;
+            J.parts.clear();
+            J.parts.resize(np);
+            parallel_for(np, [&](size_t i) { parse_lookup_part(d, cuts[i], cuts[i + 1], kmer_mode, k, J.parts[i]); });
+            join_helper();                         // stage B of the previous block is done (and has thrown here if it failed)
+            bool failing = false;
+            for (const LookupPart& P : J.parts) failing = failing || P.bad_utf8 || P.panic;
+            if (failing) { stage_b(J); continue; }  // the stream ends in this block: print what precedes the error and raise it now,
+                                                    // without waiting for input that will never be used
+            helper = std::thread([&stage_b, &helper_err, &J]() { try { stage_b(J); } catch (...) { helper_err = std::current_exception(); } });
+            cur ^= 1;
+        }
+        join_helper();
+    } catch (...) {
+        if (helper.joinable()) helper.join();      // never leave the thread behind; its own error, if any, came second
+        throw;
     }
     fwrite(held.data(), 1, held.size(), outf);   // EOF closes the last chunk
     fflush(outf);
