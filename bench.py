@@ -24,7 +24,6 @@ import argparse
 import json
 import os
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -60,6 +59,7 @@ def parse():
     ap.add_argument("--no-bind", action="store_true", help="keep taxon ids in the table (the fused kernel then gathers {pre,last} by id)")
     ap.add_argument("--rehearse-cpu", action="store_true", help="CPU/gloo rehearsal of the multi-rank plumbing (no GPU, no kernels)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds before self-launched ranks are killed")
+    ap.add_argument("--sharded-child", default=None, help=argparse.SUPPRESS)   # internal: run the sharded section in this (child) process
     return ap.parse_args()
 
 
@@ -172,28 +172,88 @@ def cpu_baseline(n_tax, ids, parents, valid, rank, taxonomy_handle, d_taxon_of_r
                           n_pairs, n_pairs * KMERS, n_cpu_keys, cores, t_lookup, n_pairs * KMERS / t_lookup / 1e6, reps, t_agg, cores, t_agg_all)}
 
 
-class Watchdog:
-    """A collective that stalls must not pass for success: prints what there is and exits non-zero."""
-
-    def __init__(self, seconds, rank, line, exit_code=3):
-        self.t = threading.Timer(seconds, self.bail)
-        self.t.daemon = True
-        self.rank, self.line, self.seconds, self.exit_code = rank, line, seconds, exit_code
-
-    def bail(self):
-        sys.stderr.write("bench.py: rank %d: the sharded section stalled for %d s; giving up on it (exit status %d)\n" % (self.rank, self.seconds, self.exit_code))
-        sys.stderr.flush()
-        if self.rank == 0:
-            self.line["sharded"] = {"error": "timed out after %d s" % self.seconds}
-            print(json.dumps(self.line), flush=True)
-        os._exit(self.exit_code)
+class stdout_to_stderr:
+    """RCCL announces its version on stdout when the first communicator comes up; stdout is for the one JSON line, so fd 1 points at
+    stderr meanwhile."""
 
     def __enter__(self):
-        self.t.start()
-        return self
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
 
     def __exit__(self, *a):
-        self.t.cancel()
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
+def run_sharded_child(args, rank, world, want_first):
+    """The sharded section in a CHILD process per rank (own process group on another port, own RCCL communicator): a crash, a GPU
+    fault or a stall in the exchange -- the one code path no one-GPU box can exercise beyond a single rank -- then costs the
+    "sharded" entry of the line, not the replica measurement that is already complete.  The parent has released its table; the
+    answers of batch 0 travel through a file for the bit-for-bit check."""
+    import subprocess
+    import tempfile
+
+    import torch
+    base = os.path.join(tempfile.gettempdir(), "umgap_sharded_%s" % os.environ.get("MASTER_PORT", "0"))
+    torch.save((want_first[0].cpu(), want_first[1].cpu()), "%s.rank%d.pt" % (base, rank))
+    if rank == 0 and os.path.exists(base):
+        os.remove(base)
+    env = dict(os.environ)
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29517")) + 17)
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)       # the children rendezvous among themselves, not through the launcher's store
+    cmd = [sys.executable, os.path.abspath(__file__), "--sharded-child", base, "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
+           "--pairs-per-step", str(args.pairs_per_step), "--batches", str(args.batches), "--n-keys", str(args.n_keys), "--n-tax", str(args.n_tax),
+           "--load-factor", str(args.load_factor), "--pieces", str(args.pieces)]
+    tail = ""
+    try:
+        p = subprocess.run(cmd, env=env, timeout=420, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        status, tail = p.returncode, p.stdout.decode(errors="replace")[-400:]
+    except subprocess.TimeoutExpired:
+        status = "no answer within 420 s"
+    try:
+        os.remove("%s.rank%d.pt" % (base, rank))
+    except OSError:
+        pass
+    if rank != 0:
+        return None
+    if status == 0 and os.path.exists(base):
+        res = json.load(open(base))
+        os.remove(base)
+        res["isolation"] = "child process per rank"
+        return res
+    return {"error": "the sharded child ended with %s" % (status,), "output_tail": tail}
+
+
+def sharded_child(args):
+    """Entry of the child started by run_sharded_child: same rank / world / device as its parent (environment), own process group."""
+    import torch
+    import torch.distributed as dist
+
+    from umgap_amd import synth
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    w = synth.SyntheticWorkload(n_tax=args.n_tax, n_keys=args.n_keys, id_space=int(args.n_tax * 1.4), load_factor=args.load_factor, device=local_rank,
+                                build_index=False)
+    B = args.pairs_per_step
+    n_batches = max(1, min(args.batches, args.steps + args.warmup))
+    keys = [w.reads((rank * n_batches + b) * B, B) for b in range(n_batches)]      # the parent's batches
+    want = torch.load("%s.rank%d.pt" % (args.sharded_child, rank))
+    want_first = (want[0].to(device), want[1].to(device))
+    d_taxon = torch.empty(B, dtype=torch.int32, device=device)
+    d_status = torch.empty_like(d_taxon)
+    res = sharded_section(args, w, keys, rank, world, device, B, d_taxon, d_status, want_first)
+    if rank == 0:
+        with open(args.sharded_child + ".tmp", "w") as f:
+            json.dump(res, f)
+        os.replace(args.sharded_child + ".tmp", args.sharded_child)
+    dist.destroy_process_group()
 
 
 def sharded_section(args, w, keys, rank, world, device, B, d_taxon, d_status, want_first):
@@ -252,6 +312,8 @@ def main():
         if rc:
             sys.stderr.write("bench.py: a rank failed or stalled (exit status %d)\n" % rc)
         sys.exit(rc)
+    if args.sharded_child:
+        return sharded_child(args)
     if args.rehearse_cpu:
         return rehearse_cpu(args)
     import numpy as np
@@ -271,10 +333,11 @@ def main():
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        seen = torch.ones(1, dtype=torch.int64, device=device)
-        dist.all_reduce(seen)                       # RCCL: every rank is really there
-        ranks_seen = int(seen.item())
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            seen = torch.ones(1, dtype=torch.int64, device=device)
+            dist.all_reduce(seen)                       # RCCL: every rank is really there
+            ranks_seen = int(seen.item())
     mode = args.mode
     if mode == "auto":
         mode = "replica"
@@ -483,15 +546,19 @@ def main():
         del d_out
         out["roofline"]["measured_gather_GBps"] = ceil
         out["roofline"]["frac_of_measured_64B_gather"] = round(lookups * 64 / (kernel_ms * 1e-3) / 1e9 / ceil["64"], 4)
+    sharded_failed = False
     if multi and args.mode != "replica":
-        # the sharded section is the headline only with --mode sharded: there a stall fails the run; as an extra beside the
-        # finished replica measurement it is reported in the line ("sharded": {"error": ...}) and the run still counts
-        with Watchdog(300, rank, out, exit_code=3 if args.mode == "sharded" else 0):
-            try:
-                out["sharded"] = sharded_section(args, w, keys, rank, world, device, B, d_taxon, d_status, want_first)
-            except Exception as e:  # noqa: BLE001
-                out["sharded"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        if args.mode == "sharded" and "value" in out["sharded"]:
+        # the replica has done its job: its HBM goes to the child's shard and exchange buffers
+        if w.index is not None:
+            w.index.close()
+            w.index = None
+        keys = None
+        torch.cuda.empty_cache()
+        res = run_sharded_child(args, rank, world, want_first)
+        if rank == 0:
+            out["sharded"] = res
+            sharded_failed = "value" not in res
+        if rank == 0 and args.mode == "sharded" and "value" in out["sharded"]:
             out["replica"] = {"value": out["value"], "ms_per_step": out["ms_per_step"]}
             out["value"], out["ms_per_step"] = out["sharded"]["value"], out["sharded"]["ms_per_step"]
             out["config"]["parallelism"] = "sharded x%d (bucket-range shards, RCCL exchange)" % world
@@ -502,7 +569,7 @@ def main():
         if w.index is not None:
             w.index.close()
             w.index = None
-        del keys
+        keys = None
         torch.cuda.empty_cache()
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         try:
@@ -522,6 +589,8 @@ def main():
         print(json.dumps(out), flush=True)
     if multi:
         dist.destroy_process_group()
+    if sharded_failed and args.mode == "sharded":
+        sys.exit(3)      # the sharded step WAS the headline: no number, no success
 
 
 if __name__ == "__main__":
