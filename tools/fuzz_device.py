@@ -8,6 +8,7 @@ through
   * umgap_classify9[_strategy]_dev the fused kernels over an index whose values are those taxa (unknown ids included), with and
                                    without the table bound to the taxonomy where binding is possible,
   * umgap_digest_tryp_dev          byte soup against the reference's regex digest,
+  * umgap_classify_prot9[_strategy]_dev, umgap_classify_tryp_dev   random proteins against a dict + the oracle,
 for every strategy, both methods, several -l / -f, ranked and unranked snapping, and checks each answer with the oracle's
 taxa2agg (tie sets honoured).  Prints one line per mismatch and a summary; exit status 1 if anything differed.
     python tools/fuzz_device.py [iterations] [seed]"""
@@ -78,6 +79,98 @@ def digest_leg(rng, fails):
     if pieces != want:
         fails.append("digest")
         print("MISMATCH digest n_frag", n_frag, "pieces", len(pieces), "want", len(want), flush=True)
+
+
+def protein_legs(rng, fails):
+    """The two fragment-fed fused pipelines on random proteins, own small taxonomy and indexes per call:
+    umgap_classify_prot9[_strategy]_dev (every 9-residue window; ragged fragments, `*`, reads beyond the kernel's limits must be
+    flagged, not guessed) and umgap_classify_tryp_dev (regex digest, length window), each against a dict + the oracle's taxa2agg."""
+    import re
+    letters = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    n_ids = int(rng.choice([15, 120]))
+    ids = np.arange(1, n_ids + 1, dtype=np.uint32)
+    par = np.maximum(1, ids // int(rng.choice([2, 3, 5]))).astype(np.uint32)
+    tx = api.Taxonomy(ids, par)
+    otx = O.Taxonomy.from_arrays(ids, par)
+    method, strategy = MODES[int(rng.integers(0, 5))]
+    factor, lb = float(rng.choice([0.1, 0.25, 0.6])), float(rng.choice([0.0, 1.0, 2.0]))
+    agg = O.Aggregator(otx, method, strategy, factor)
+    ctx = dict(method=method, strategy=strategy, lb=lb, f=factor, ranked=False)
+    F, n_reads = int(rng.choice([1, 2, 3, 7])), int(rng.integers(20, 400))
+    # ---- 9-mer windows ----
+    kmers = sorted({rng.choice(letters, 9).tobytes() for _ in range(400)})
+    kv = rng.choice(ids, len(kmers)).astype(np.uint32)
+    kd = dict(zip(kmers, kv.tolist()))
+    keys, _ = api.pack9_array(kmers)
+    ix9 = api.Index.build(keys, kv)
+    frags = []
+    for _ in range(n_reads * F):
+        n = int(rng.choice([0, 5, 9, 12, 30, 60, 140]))
+        p = bytearray(rng.choice(letters, n).tobytes())
+        for _k in range(n // 10):
+            s0 = int(rng.integers(0, n - 8))
+            p[s0:s0 + 9] = kmers[int(rng.integers(0, 30))]
+        if n and rng.random() < 0.15:
+            p[int(rng.integers(0, n))] = ord("*")
+        frags.append(bytes(p))
+    data, offs = api._concat(frags)
+    d_data, d_offs = torch.from_numpy(data.copy()).cuda(), torch.from_numpy(offs.view(np.int64)).cuda()
+    d_t = torch.full((n_reads,), -1, dtype=torch.int32, device="cuda")
+    d_s = torch.full_like(d_t, -1)
+    api.classify_prot9_dev(ix9, tx, d_data, d_offs, n_reads, F, d_t, d_s, method=method, strategy=strategy, factor=factor, lower_bound=lb)
+    torch.cuda.synchronize()
+    t, s = d_t.cpu().numpy().view(np.uint32).copy(), d_s.cpu().numpy().view(np.uint32).copy()
+    hits, roffs, too_long = [], [0], np.zeros(n_reads, bool)
+    for r in range(n_reads):
+        fr = frags[r * F:(r + 1) * F]
+        too_long[r] = sum(max(0, len(f) - 8) for f in fr) > 128 or sum(len(f) for f in fr) > 384
+        if not too_long[r]:
+            for f in fr:
+                hits += [kd.get(f[i:i + 9], 0) for i in range(max(0, len(f) - 8))]
+        roffs.append(len(hits))
+    hits, roffs = np.array(hits, np.uint32), np.array(roffs, np.uint64)
+    if not ((s[too_long] == 4).all() and (t[too_long] == 0).all()):
+        fails.append("prot9 limits"); print("MISMATCH prot9: a read beyond the limits was not flagged", ctx, flush=True)
+    unsupported = s == 4                                   # also: more than 64 distinct taxa after the filter (general strategies)
+    _, _, wt, ws = agg.taxa2agg_check(hits, roffs, lower_bound=lb)
+    if (unsupported & ~too_long).sum() > n_reads // 4:
+        fails.append("prot9 unsupported"); print("MISMATCH prot9: too many reads refused", ctx, flush=True)
+    t[unsupported], s[unsupported] = wt[unsupported], ws[unsupported]
+    check("prot9 F=%d" % F, agg, hits, roffs, t, s, lb, fails, ctx)
+    # ---- tryptic ----
+    pat = re.compile(rb"([KR])([^P])")
+
+    def peptide():
+        k = int(rng.integers(1, 25))
+        p = bytearray(rng.choice(np.frombuffer(b"ACDEFGHILMNPQSTVWY", np.uint8), k).tobytes())
+        p[-1] = ord("K") if rng.random() < 0.5 else ord("R")
+        if p[0] == ord("P"):
+            p[0] = ord("A")
+        return bytes(p)
+    peps = sorted({peptide() for _ in range(800)})
+    pv = rng.choice(ids, len(peps)).astype(np.uint32)
+    ixv = api.Index.build_var(peps, pv)
+    pd = dict(zip(peps, pv.tolist()))
+    lo, hi = [(5, 50), (1, 63), (9, 45), (3, 7)][int(rng.integers(0, 4))]
+    frags = []
+    for _ in range(n_reads * F):
+        parts = []
+        for _k in range(int(rng.integers(0, 8))):
+            u = rng.random()
+            parts.append(peps[int(rng.integers(0, 40))] if u < 0.6 else (peptide() if u < 0.8 else (b"*" if u < 0.9 else rng.choice(letters, int(rng.integers(1, 80))).tobytes())))
+        frags.append(b"".join(parts))
+    data, offs = api._concat(frags)
+    d_data, d_offs = torch.from_numpy(np.concatenate([data, np.zeros(1, np.uint8)])).cuda(), torch.from_numpy(offs.view(np.int64)).cuda()
+    api.classify_tryp_dev(ixv, tx, d_data, d_offs, n_reads, F, d_t, d_s, method=method, strategy=strategy, factor=factor, lower_bound=lb, min_len=lo, max_len=hi)
+    torch.cuda.synchronize()
+    hits, roffs = [], [0]
+    for r in range(n_reads):
+        for f in frags[r * F:(r + 1) * F]:
+            twice = pat.sub(rb"\1\n\2", pat.sub(rb"\1\n\2", f))
+            hits += [pd.get(p, 0) for p in twice.replace(b"*", b"\n").split(b"\n") if p and lo <= len(p) <= hi]
+        roffs.append(len(hits))
+    check("tryp F=%d window %d..%d" % (F, lo, hi), agg, np.array(hits, np.uint32), np.array(roffs, np.uint64), d_t.cpu().numpy().view(np.uint32),
+          d_s.cpu().numpy().view(np.uint32), lb, fails, ctx)
 
 
 def seedextend_leg(rng, tx, agg, ix, d_keys, strided, lb, fails, ctx):
@@ -193,7 +286,8 @@ def main():
                         seedextend_leg(rng, tx, agg, ix, d_keys, strided, lb, fails, ctx)
                         n_checks += 1
         digest_leg(rng, fails)
-        n_checks += 1
+        protein_legs(rng, fails)
+        n_checks += 3
         if (it + 1) % 5 == 0:
             print("iteration %d: %d checks, %d mismatches" % (it + 1, n_checks, len(fails)), flush=True)
     print("fuzz_device: %d iterations, %d checks, %d mismatches (seed %d)" % (iters, n_checks, len(fails), seed))
