@@ -10,7 +10,7 @@
 // (the window goes into the probe kernel, index_var.hip), and 0 = "no hit" is what the aggregators skip.
 //
 //   k_tryp_mark     fragment starts -> one bit per byte                                     (n_fragments threads)
-//   k_tryp_count    piece starts per tile of 2048 bytes, the flags kept (1 bit per byte)      (reads the bytes, once)
+//   k_tryp_count    piece starts per tile of 8 KB, the flags kept (1 bit per byte)            (reads the bytes, once)
 //   k_tryp_scan     exclusive scan of the tile counts                                        (one workgroup)
 //   k_tryp_write    the starts, in order: offsets[rank] = position                           (reads the flags)
 //   k_tryp_reads    first piece of every read by binary search in the offsets                (n_reads threads)
@@ -31,7 +31,7 @@ using namespace umgap;
 
 namespace {
 
-constexpr uint32_t TILE = 2048, PER_THREAD = 8;   // bytes per workgroup of 256 threads / per thread
+constexpr uint32_t PER_THREAD = 32, TILE = 256 * PER_THREAD;   // bytes per thread / per workgroup of 256 threads (8 KB)
 
 __global__ __launch_bounds__(256) void k_tryp_mark(const uint64_t* __restrict__ foff, size_t n_frag, uint64_t b0, uint64_t b1, uint32_t* __restrict__ bits,
                                                    unsigned long long* __restrict__ bad) {
@@ -44,30 +44,35 @@ __global__ __launch_bounds__(256) void k_tryp_mark(const uint64_t* __restrict__ 
     }
 }
 
-// the piece-start flags of the 8 bytes [rel, rel + 8) of the range (bit k: byte rel + k); n = bytes in the range
+// 0x80 in every byte of v that equals c (exact: no carry leaves a byte)
+__device__ __forceinline__ uint64_t bytes_equal_to(uint64_t v, uint8_t c) {
+    const uint64_t x = v ^ (0x0101010101010101ull * c), low7 = 0x7F7F7F7F7F7F7F7Full;
+    return ~(((x & low7) + low7) | x | low7);
+}
+
+// the piece-start flags of the 32 bytes [rel, rel + 32) of the range (bit k: byte rel + k); n = bytes in the range.  Eight bytes
+// at a time: K / R / P / `*` are found with byte-parallel arithmetic on the 64-bit word, "the byte before" is a shift by one byte
+// with the previous word's last byte carried in, and the eight flags are gathered with one multiplication.
 __device__ __forceinline__ uint32_t piece_start_mask(const uint8_t* __restrict__ base, const uint32_t* __restrict__ bits, uint64_t rel, uint64_t n) {
     if (rel >= n) return 0u;
-    uint8_t c[PER_THREAD + 1];
-    c[0] = rel ? base[rel - 1] : (uint8_t)'*';                 // the byte before the range's first: any separator will do (it opens a fragment anyway)
-    if (rel + PER_THREAD <= n) {                               // one 8-byte load (any alignment) instead of eight
-        typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
-        const uint64_t v = *reinterpret_cast<const u64_unaligned*>(base + rel);
+    typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+    uint8_t prev = rel ? base[rel - 1] : (uint8_t)'*';         // before the range's first byte: any separator (that byte opens a fragment anyway)
+    uint32_t m = bits[rel >> 5];                                // rel is a multiple of 32: the 32 fragment-start bits are one word
 #pragma unroll
-        for (uint32_t k = 0; k < PER_THREAD; k++) c[k + 1] = (uint8_t)(v >> (8 * k));
-    } else {
-#pragma unroll
-        for (uint32_t k = 0; k < PER_THREAD; k++) c[k + 1] = rel + k < n ? base[rel + k] : (uint8_t)0;
+    for (uint32_t w = 0; w < PER_THREAD / 8; w++) {
+        const uint64_t at = rel + 8 * w;
+        if (at >= n) break;
+        uint64_t v = 0;
+        if (at + 8 <= n) v = *reinterpret_cast<const u64_unaligned*>(base + at);
+        else for (uint32_t k = 0; at + k < n; k++) v |= (uint64_t)base[at + k] << (8 * k);
+        const uint64_t star = bytes_equal_to(v, '*'), kr = bytes_equal_to(v, 'K') | bytes_equal_to(v, 'R'), isp = bytes_equal_to(v, 'P');
+        const uint64_t prev_star = (star << 8) | (prev == '*' ? 0x80ull : 0ull), prev_kr = (kr << 8) | ((prev == 'K' || prev == 'R') ? 0x80ull : 0ull);
+        const uint64_t start = star | prev_star | (prev_kr & ~isp);                       // 0x80 per byte that opens a piece
+        m |= (uint32_t)(((start >> 7) * 0x0102040810204080ull) >> 56) << (8 * w);         // bit k <- byte k
+        prev = (uint8_t)(v >> 56);
     }
-    // the 8 fragment-start bits: rel is a multiple of 8, so they sit inside one word
-    const uint32_t fb = (bits[rel >> 5] >> (rel & 31u)) & 0xFFu;
-    uint32_t m = 0;
-#pragma unroll
-    for (uint32_t k = 0; k < PER_THREAD; k++) {
-        const uint8_t prev = c[k], cur = c[k + 1];
-        const bool start = ((fb >> k) & 1u) || cur == '*' || prev == '*' || ((prev == 'K' || prev == 'R') && cur != 'P');
-        if (start && rel + k < n) m |= 1u << k;
-    }
-    return m;
+    const uint64_t left = n - rel;                               // bytes past the end open nothing
+    return left >= 32 ? m : (m & ((1u << (uint32_t)left) - 1u));
 }
 
 __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds_wave_sums, uint32_t& block_total) {
@@ -84,13 +89,13 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* l
     return before + incl - v;
 }
 
-// also keeps every thread's 8 flags (one byte per 8 bytes of input): k_tryp_write reads those instead of the bytes again
+// also keeps every thread's 32 flags (one bit per byte of input): k_tryp_write reads those instead of the bytes again
 __global__ __launch_bounds__(256) void k_tryp_count(const uint8_t* __restrict__ base, const uint32_t* __restrict__ bits, uint64_t n, uint32_t* __restrict__ tile_counts,
-                                                    uint8_t* __restrict__ masks) {
+                                                    uint32_t* __restrict__ masks) {
     __shared__ uint32_t sums[4];
     const uint64_t rel = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * PER_THREAD;
     const uint32_t mask = piece_start_mask(base, bits, rel, n);
-    masks[(uint64_t)blockIdx.x * 256 + threadIdx.x] = (uint8_t)mask;
+    masks[(uint64_t)blockIdx.x * 256 + threadIdx.x] = mask;
     const uint32_t cnt = (uint32_t)__builtin_popcount(mask);
     uint32_t total;
     (void)block_exclusive_scan(cnt, sums, total);
@@ -116,11 +121,11 @@ __global__ __launch_bounds__(1024) void k_tryp_scan(const uint32_t* __restrict__
     if (threadIdx.x == 0) *total = run;
 }
 
-__global__ __launch_bounds__(256) void k_tryp_write(const uint8_t* __restrict__ masks, uint64_t n, uint64_t b0,
+__global__ __launch_bounds__(256) void k_tryp_write(const uint32_t* __restrict__ masks, uint64_t n, uint64_t b0,
                                                     const uint64_t* __restrict__ tile_base, uint64_t total, uint64_t cap, uint64_t* __restrict__ offsets) {
     __shared__ uint32_t sums[4];
     const uint64_t rel = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * PER_THREAD;
-    uint32_t m = rel < n ? (uint32_t)masks[(uint64_t)blockIdx.x * 256 + threadIdx.x] : 0u;
+    uint32_t m = rel < n ? masks[(uint64_t)blockIdx.x * 256 + threadIdx.x] : 0u;
     uint32_t blk_total;
     uint64_t at = tile_base[blockIdx.x] + block_exclusive_scan((uint32_t)__builtin_popcount(m), sums, blk_total);
     while (m) {
@@ -166,7 +171,7 @@ struct Digest {
     uint64_t* tile_base = nullptr;
     uint64_t* d_total = nullptr;
     unsigned long long* d_bad = nullptr;
-    uint8_t* masks = nullptr;
+    uint32_t* masks = nullptr;
     uint64_t b0 = 0, n = 0, total = 0;
     size_t n_tiles = 0;
     void* owned = nullptr;              // freed by release(); null when the memory belongs to a cache
@@ -212,7 +217,7 @@ int digest_count(const uint8_t* d_bytes, const uint64_t* d_foff, size_t n_frag, 
     D.n_tiles = (size_t)((D.n + TILE - 1) / TILE);
     if (D.n_tiles > 0x7FFFFFFFull) return fail(UMGAP_ERR_INVALID, "tryptic digest: more than 4 TB of fragments in one call");
     const size_t words = (size_t)(D.n / 32) + 2, tiles = std::max<size_t>(D.n_tiles, 1);
-    const size_t b_bits = align256(words * 4), b_cnt = align256(tiles * 4), b_base = align256(tiles * 8), b_masks = align256(tiles * 256);
+    const size_t b_bits = align256(words * 4), b_cnt = align256(tiles * 4), b_base = align256(tiles * 8), b_masks = align256(tiles * 256 * 4);
     void* mem = nullptr;
     int rc = scratch_get(D.cache, D.cache_bytes, b_bits + b_cnt + b_base + b_masks + 512, s, &mem, &D.owned);
     if (rc) return rc;
@@ -220,7 +225,7 @@ int digest_count(const uint8_t* d_bytes, const uint64_t* d_foff, size_t n_frag, 
     D.bits = (uint32_t*)p; p += b_bits;
     D.tile_counts = (uint32_t*)p; p += b_cnt;
     D.tile_base = (uint64_t*)p; p += b_base;
-    D.masks = (uint8_t*)p; p += b_masks;
+    D.masks = (uint32_t*)p; p += b_masks;
     D.d_total = (uint64_t*)p; p += 256;
     D.d_bad = (unsigned long long*)p;
     UMGAP_HIP(hipMemsetAsync(D.bits, 0, words * 4, s));
