@@ -9,6 +9,7 @@ through
                                    without the table bound to the taxonomy where binding is possible,
   * umgap_digest_tryp_dev          byte soup against the reference's regex digest,
   * umgap_classify_prot9[_strategy]_dev, umgap_classify_tryp_dev   random proteins against a dict + the oracle,
+  * umgap_sharded_{lookup9,classify9}_dev   N ranks as threads on this GPU against the whole-table kernels (every 4th iteration),
 for every strategy, both methods, several -l / -f, ranked and unranked snapping, and checks each answer with the oracle's
 taxa2agg (tie sets honoured).  Prints one line per mismatch and a summary; exit status 1 if anything differed.
     python tools/fuzz_device.py [iterations] [seed]"""
@@ -173,6 +174,76 @@ def protein_legs(rng, fails):
           d_s.cpu().numpy().view(np.uint32), lb, fails, ctx)
 
 
+def sharded_leg(rng, fails):
+    """The N-rank sharded path (pack -> exchange -> probe on the owner -> values back -> gather + aggregate) with all ranks as threads
+    on this GPU (local transport): random world, pieces, stride, read counts and strategy; every rank's answers must be bit-identical
+    to the whole-table kernels."""
+    import threading
+
+    from umgap_amd.dist import Comm, Sharded
+    from umgap_amd.synth import ADD_B, MUL_A, SyntheticWorkload
+    world, pieces = int(rng.choice([1, 2, 3, 5, 8])), int(rng.integers(1, 10))
+    stride = int(rng.choice([6, 16, 42, 84, 128]))
+    os.environ["UMGAP_SHARD_NO_LOCAL"] = str(int(rng.integers(0, 2)))
+    n_keys = int(rng.choice([50_000, 600_000]))
+    w = SyntheticWorkload(n_tax=int(rng.choice([500, 20_000])), n_keys=n_keys)
+    n_reads = [int(rng.integers(1, 3000)) for _ in range(world)]
+    max_keys = (max(n_reads) + pieces) // pieces * pieces * stride
+    keys = [w.reads(int(rng.integers(0, 1 << 20)), n_reads[r], kmers_per_pair=stride) for r in range(world)]
+    method, strategy = MODES[int(rng.integers(0, 5))]
+    lb, factor = float(rng.choice([0.0, 1.0, 2.0])), float(rng.choice([0.25, 0.6]))
+    frags = int(rng.choice([f for f in (0, 1, 2, 3) if f == 0 or stride % f == 0]))
+    kw = dict(method=method, strategy=strategy, factor=factor, lower_bound=lb, fragments_per_read=frags, min_seed_size=int(rng.integers(1, 4)), max_gap_size=int(rng.integers(0, 2)))
+    want_hits, want = [], []
+    for r in range(world):
+        want_hits.append(w.index.lookup9_dev(keys[r], miss_value=0).clone())
+        t = torch.empty(n_reads[r], dtype=torch.int32, device="cuda")
+        s_ = torch.empty_like(t)
+        api.classify9_dev(w.index, w.taxonomy, keys[r], n_reads[r], stride, t, s_, **kw)
+        want.append((t, s_))
+    torch.cuda.synchronize()
+    shards = [api.Index.synthetic(n_keys, w.d_taxon_of_row, MUL_A, ADD_B, 0.0, r, world) for r in range(world)]
+    comms = Comm.local(world)
+    got_hits = [torch.full_like(want_hits[r], -7) for r in range(world)]
+    got = [None] * world
+    errs = [None] * world
+
+    def body(r):
+        try:
+            torch.cuda.set_device(0)
+            sh = Sharded(shards[r], w.taxonomy, comms[r], max_keys, pieces=pieces)
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                sh.lookup9(keys[r], got_hits[r], miss_value=0, stream=st)
+                t = torch.full((n_reads[r],), -1, dtype=torch.int32, device="cuda")
+                s_ = torch.full_like(t, -1)
+                sh.classify9(keys[r], n_reads[r], stride, t, s_, stream=st, **kw)
+                got[r] = (t, s_)
+            st.synchronize()
+            sh.check()
+            sh.close()
+        except BaseException as e:  # noqa: BLE001
+            errs[r] = e
+    ts = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t_ in ts:
+        t_.start()
+    for t_ in ts:
+        t_.join(120)
+    ctx = dict(world=world, pieces=pieces, stride=stride, n_reads=n_reads, no_local=os.environ["UMGAP_SHARD_NO_LOCAL"], **kw)
+    if any(t_.is_alive() for t_ in ts) or any(errs):
+        fails.append("sharded")
+        print("MISMATCH sharded: a rank failed or is stuck", ctx, [repr(e) for e in errs if e], flush=True)
+        return
+    torch.cuda.synchronize()
+    for r in range(world):
+        if not (torch.equal(got_hits[r], want_hits[r]) and torch.equal(got[r][0], want[r][0]) and torch.equal(got[r][1], want[r][1])):
+            fails.append("sharded")
+            print("MISMATCH sharded rank", r, ctx, flush=True)
+            break
+    for c in comms:
+        c.close()
+
+
 def seedextend_leg(rng, tx, agg, ix, d_keys, strided, lb, fails, ctx):
     """The fused probe -> seedextend -> aggregate kernels (every read end a fragment) against the oracle's literal seedextend
     state machine followed by its taxa2agg; a fragment on which the reference would panic (src/commands/seedextend.rs:169-173)
@@ -288,6 +359,9 @@ def main():
         digest_leg(rng, fails)
         protein_legs(rng, fails)
         n_checks += 3
+        if it % 4 == 0:
+            sharded_leg(rng, fails)
+            n_checks += 1
         if (it + 1) % 5 == 0:
             print("iteration %d: %d checks, %d mismatches" % (it + 1, n_checks, len(fails)), flush=True)
     print("fuzz_device: %d iterations, %d checks, %d mismatches (seed %d)" % (iters, n_checks, len(fails), seed))
