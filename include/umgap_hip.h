@@ -193,8 +193,9 @@ int umgap_index_dump_var(const umgap_index* ix, uint8_t* heap_out, uint64_t heap
 /* rows in TSV order: id, parent, valid (0/1), rank (index into src/rank.rs:10-41, 0 = "no rank").
  * Children keep row order (Euler tour / preorder follow it, src/taxon.rs:224-247).
  * Errors: UMGAP_ERR_PANIC for the reference's panics (no rows, "More than one root!",
- * "There's no root!"); UMGAP_ERR_FORMAT for ids >= 2^32-1, duplicate ids or parent cycles
- * (the reference loops forever on a cycle; duplicates are refused here). */
+ * "There's no root!"); UMGAP_ERR_FORMAT for ids >= 2^32-1, the same id under two different parents, or parent cycles
+ * (the reference loops forever on a cycle).  An id repeated with the same parent is accepted as the reference takes it: the
+ * last row's rank / valid, the first row's place among its siblings. */
 int umgap_taxonomy_create(const uint32_t* id, const uint32_t* parent, const uint8_t* valid,
                           const uint8_t* rank, size_t n, int device, umgap_taxonomy** out);
 void umgap_taxonomy_free(umgap_taxonomy* tx);

@@ -91,8 +91,8 @@ def test_taxonomy_validation_mirrors_reference_panics(lib):
     assert rc == _lib.ERR_PANIC and b"There's no root!" in msg
     rc, msg = create([], [])
     assert rc == _lib.ERR_PANIC
-    rc, msg = create([1, 2, 2], [1, 1, 1])
-    assert rc == _lib.ERR_FORMAT and b"duplicate" in msg
+    rc, msg = create([1, 2, 3, 2], [1, 1, 1, 3])          # the same id under two parents: no tree (same-parent repeats are accepted)
+    assert rc == _lib.ERR_FORMAT and b"duplicate" in msg and b"different parents" in msg
     rc, msg = create([1, 2, 3], [1, 3, 2])
     assert rc == _lib.ERR_FORMAT and b"cycle" in msg
 

@@ -146,6 +146,28 @@ TAXA2AGG_MODES = [["-a", "lca*"], ["-a", "lca*", "-l", "2"], ["-m", "rmq", "-a",
                   [], ["-a", "hybrid", "-f", "0.5", "-r"], ["-m", "rmq", "-a", "hybrid", "--factor=0.75"], ["--lower-bound", "5", "-a", "lca*", "-r"]]
 
 
+def test_taxa2agg_taxonomy_with_repeated_rows(world, tmp_path):
+    """`taxons.tsv` with rows repeated under the same parent (other rank, other validity): same bytes as the oracle command, which keeps
+    the reference's last-row / both-links structures literally."""
+    rng = np.random.default_rng(8)
+    rows = open(world["tsv"], "rb").read().splitlines()
+    extra = []
+    for i in rng.choice(len(rows), 12, replace=False):
+        f = rows[int(i)].split(b"\t")
+        f[2] = rng.choice([b"species", b"genus", b"no rank", b"family"])
+        f[4] = rng.choice([b"\x01", b"\x00"])
+        extra.append((int(rng.integers(int(i) + 1, len(rows) + 1)), b"\t".join(f)))
+    for pos, row in sorted(extra, reverse=True):
+        rows.insert(pos, row)
+    tsv = tmp_path / "taxons_repeated.tsv"
+    tsv.write_bytes(b"\n".join(rows) + b"\n")
+    fasta = _taxa_fasta(world, rng, 600)
+    for mode in (["-a", "lca*", "-l", "2"], ["-m", "rmq", "-a", "mrtl"], [], ["-r", "-m", "rmq", "-a", "hybrid", "-f", "0.6"]):
+        rc, out, err = run(["taxa2agg"] + mode + [str(tsv)], fasta)
+        orc, oout, _ = O.run_cli(["taxa2agg"] + mode + [str(tsv)], fasta)
+        assert rc == orc and out == oout, (mode, err[-300:])
+
+
 @pytest.mark.parametrize("mode", TAXA2AGG_MODES)
 def test_taxa2agg_matches_oracle(world, mode):
     rng = np.random.default_rng(len(mode) + 11)

@@ -410,6 +410,33 @@ def test_general_unknown_and_orphans_vs_oracle(api, method, strategy, factor):
     assert nbad == 0, bad
 
 
+def test_taxonomy_with_repeated_rows_vs_oracle(api):
+    """A taxon id that occurs in several rows with the same parent: the reference keeps the last row's rank / valid (TaxonList::new,
+    src/taxon.rs:135-145) and both child links (TaxonTree::new, :228-241); the device tables keep the first link with the last
+    attributes.  Checked against the oracle, which restates the reference's structures literally (double links included), for every
+    strategy and both snappings.  The same id under two different parents is refused."""
+    from umgap_amd.synth import synthetic_taxonomy
+    rng = np.random.default_rng(41)
+    ids, par, valid, rank = synthetic_taxonomy(1500, 2500, max_depth=14, seed=9)
+    ids2, par2, valid2, rank2 = list(ids), list(par), list(valid), list(rank)
+    for p in rng.choice(len(ids), 25, replace=False):
+        pos = int(rng.integers(p + 1, len(ids2) + 1))
+        ids2.insert(pos, ids[p]); par2.insert(pos, par[p]); valid2.insert(pos, int(rng.integers(0, 2))); rank2.insert(pos, int(rng.integers(0, 28)))
+    ids2, par2 = np.array(ids2, np.uint32), np.array(par2, np.uint32)
+    valid2, rank2 = np.array(valid2, np.uint8), np.array(rank2, np.uint8)
+    tx = api.Taxonomy(ids2, par2, valid2, rank2)
+    otx = O.Taxonomy.from_arrays(ids2, par2, valid2, rank2)
+    reads = _random_reads(rng, ids, 4000, 25, zero_frac=0.15)
+    taxa, offs = _csr(reads)
+    for method, strategy in (("tree", "lca*"), ("rmq", "lca*"), ("tree", "hybrid"), ("rmq", "hybrid"), ("rmq", "mrtl")):
+        for ranked in (False, True):
+            t, s = tx.aggregate(taxa, offs, method=method, strategy=strategy, factor=0.3, lower_bound=1.0, ranked_only=ranked)
+            nbad, bad, _, _ = O.Aggregator(otx, method, strategy, 0.3).taxa2agg_check(taxa, offs, t, s, lower_bound=1.0, ranked=ranked)
+            assert nbad == 0, (method, strategy, ranked, bad)
+    with pytest.raises(api.UmgapError, match="different parents"):
+        api.Taxonomy(np.array([1, 2, 3, 2], np.uint32), np.array([1, 1, 1, 3], np.uint32))
+
+
 def test_mrtl_scored_vs_oracle(api):
     """rmq::rtl adds ancestor scores nearest-first (src/rmq/rtl.rs:42-46): deterministic up to ties."""
     from umgap_amd.synth import synthetic_taxonomy

@@ -35,28 +35,39 @@ int umgap_taxonomy_create(const uint32_t* id, const uint32_t* parent, const uint
         max_id = std::max(max_id, id[i]);
     }
     const uint32_t len = max_id + 1;  // TaxonList::new (src/taxon.rs:135-145)
+    // A repeated id.  The reference keeps the LAST row's name / rank / valid (TaxonList::new, src/taxon.rs:135-145) and BOTH child
+    // links (TaxonTree::new, :228-241).  With the same parent in every copy that is the tree without the repeats: the second visit
+    // of the subtree changes neither `ancestors` nor any first occurrence, and a range minimum that spans it passes through the
+    // parent anyway -- so the link of the first copy is kept (its place among the siblings) with the attributes of the last.
+    // Copies with DIFFERENT parents make a graph no preorder interval can hold: refused.
     std::vector<uint32_t> row_of_id(len, NONE);
+    std::vector<uint8_t> repeat(n, 0);           // this row repeats an earlier one: no link of its own
     for (size_t i = 0; i < n; i++) {
-        if (row_of_id[id[i]] != NONE) return fail(UMGAP_ERR_FORMAT, "duplicate taxon id " + std::to_string(id[i]) + " (refused; the reference keeps the last row but both child links)");
+        const uint32_t before = row_of_id[id[i]];
+        if (before != NONE) {
+            if (parent[before] != parent[i])
+                return fail(UMGAP_ERR_FORMAT, "duplicate taxon id " + std::to_string(id[i]) + " with two different parents (refused; the reference would keep both child links)");
+            repeat[i] = 1;
+        }
         row_of_id[id[i]] = (uint32_t)i;
     }
     // root = the only taxon with id == parent (src/taxon.rs:228-246)
     uint32_t root = NONE;
     size_t n_roots = 0;
     for (size_t i = 0; i < n; i++)
-        if (id[i] == parent[i]) { n_roots++; root = id[i]; }
+        if (id[i] == parent[i] && !repeat[i]) { n_roots++; root = id[i]; }
     if (n_roots > 1) return fail(UMGAP_ERR_PANIC, "More than one root!");
     if (n_roots == 0) return fail(UMGAP_ERR_PANIC, "There's no root!");
 
     // children in row order, CSR keyed by parent id (parents >= len can never be reached)
     std::vector<uint32_t> child_start(len + 1, 0), child(n);
     for (size_t i = 0; i < n; i++)
-        if (id[i] != parent[i] && parent[i] < len) child_start[parent[i] + 1]++;
+        if (id[i] != parent[i] && parent[i] < len && !repeat[i]) child_start[parent[i] + 1]++;
     for (uint32_t p = 0; p < len; p++) child_start[p + 1] += child_start[p];
     {
         std::vector<uint32_t> cur(child_start.begin(), child_start.end() - 1);
         for (size_t i = 0; i < n; i++)
-            if (id[i] != parent[i] && parent[i] < len) child[cur[parent[i]]++] = id[i];
+            if (id[i] != parent[i] && parent[i] < len && !repeat[i]) child[cur[parent[i]]++] = id[i];
     }
 
     auto* tx = new umgap_taxonomy();
