@@ -205,11 +205,23 @@ inline bool line_utf8_ok(std::string_view l) {
     return true;
 }
 
+// decimal digits of v, two at a time from a table, appended in one go
 inline void append_uint(std::string& s, uint64_t v) {
+    static const char pairs[] =
+        "0001020304050607080910111213141516171819202122232425262728293031323334353637383940414243444546474849"
+        "5051525354555657585960616263646566676869707172737475767778798081828384858687888990919293949596979899";
     char tmp[24];
-    int n = 0;
-    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
-    while (n) s.push_back(tmp[--n]);
+    char* p = tmp + sizeof(tmp);
+    while (v >= 100) {
+        const unsigned r = (unsigned)(v % 100);
+        v /= 100;
+        p -= 2;
+        p[0] = pairs[2 * r];
+        p[1] = pairs[2 * r + 1];
+    }
+    if (v >= 10) { p -= 2; p[0] = pairs[2 * v]; p[1] = pairs[2 * v + 1]; }
+    else *--p = (char)('0' + v);
+    s.append(p, (size_t)(tmp + sizeof(tmp) - p));
 }
 
 }  // namespace umgap_host

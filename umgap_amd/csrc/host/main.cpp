@@ -136,12 +136,7 @@ struct Out {
     void maybe_flush() { if (buf.size() > (1u << 22)) { fwrite(buf.data(), 1, buf.size(), f); buf.clear(); } }
 };
 
-void append_u64(std::string& s, uint64_t v) {
-    char tmp[24];
-    int n = 0;
-    do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v);
-    while (n) s.push_back(tmp[--n]);
-}
+void append_u64(std::string& s, uint64_t v) { append_uint(s, v); }
 
 // Looks up a batch of byte strings in either kind of index.  9-mer table: strings that are not
 // [A-Z]{9} miss without touching the device.  Result 0 = miss.
@@ -836,8 +831,10 @@ int cmd_seedextend(const std::vector<std::string>& args) {
             LineCursor lc{d + cuts[pi], d + cuts[pi + 1]};
             std::string_view line, header;
             std::vector<uint64_t> t;
+            std::vector<const char*> at;      // where item j's line starts in the block; at[n] = one past the last line
             std::vector<std::pair<size_t, size_t>> seeds;
-            bool open = false;
+            bool open = false, plain = true;  // plain: every line of the record is the number's own canonical text + '\n'
+                                              // (no sign, no leading zero, no CR): a kept range can be copied as it stands
             auto flush_record = [&]() {
                 if (!open) return;
                 open = false;
@@ -875,15 +872,25 @@ int cmd_seedextend(const std::vector<std::string>& args) {
                 P.out.push_back('>'); P.out.append(header); P.out.push_back('\n');
                 for (auto& se : seeds) {
                     if (se.first > se.second || se.second > t.size()) { P.panic = true; P.out.resize(mark); break; }   // taxons[start..end]
-                    for (size_t j = se.first; j < se.second; j++) { append_uint(P.out, t[j]); P.out.push_back('\n'); }
+                    // (the sentinel 0 pushed above has no line: a range that reaches it is formatted)
+                    if (se.first == se.second) continue;
+                    if (plain && se.second < t.size()) P.out.append(at[se.first], (size_t)(at[se.second] - at[se.first]));
+                    else for (size_t j = se.first; j < se.second; j++) { append_uint(P.out, t[j]); P.out.push_back('\n'); }
                 }
                 t.clear();
+                at.clear();
+                plain = true;
             };
             try {
                 while (lc.next(line) && !P.panic) {
                     if (!line_utf8_ok(line)) { flush_record(); P.error = CliError("stream did not contain valid UTF-8"); return; }
                     if (!line.empty() && line[0] == '>') { flush_record(); header = line.substr(1); open = true; continue; }
                     t.push_back(parse_usize(line));
+                    // canonical text followed directly by '\n'?  (lc.p is the start of the next line)
+                    const char* nxt = lc.p;
+                    if (line[0] == '+' || (line[0] == '0' && line.size() > 1) || nxt != line.data() + line.size() + 1 || nxt[-1] != '\n') plain = false;
+                    if (at.empty()) at.push_back(line.data());
+                    at.push_back(nxt);
                 }
                 flush_record();
             } catch (CliError& e) { P.error = e; }   // the failing record is not printed

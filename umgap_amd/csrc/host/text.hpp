@@ -34,6 +34,14 @@ inline uint64_t parse_usize(std::string_view s) {
         i = 1;
     }
     uint64_t v = 0;
+    if (s.size() - i <= 19) {          // cannot overflow 64 bits: no check per digit (taxon ids have 1-7 digits)
+        for (; i < s.size(); i++) {
+            unsigned c = (unsigned char)s[i] - '0';
+            if (c > 9) throw CliError("invalid digit found in string");
+            v = v * 10 + c;
+        }
+        return v;
+    }
     for (; i < s.size(); i++) {
         unsigned c = (unsigned char)s[i] - '0';
         if (c > 9) throw CliError("invalid digit found in string");
