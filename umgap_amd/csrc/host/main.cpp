@@ -251,11 +251,24 @@ void format_lookup_part(const char* d, const uint32_t* taxa, bool one_on_one, co
     size_t ki = 0, wi = 0;
     for (size_t r = 0; r < rb; r++)
         for (uint32_t i = 0; i < P.n_items[r] && wi < P.known.size(); i++, wi++) ki += P.known[wi];
+    // consecutive windows of a protein mostly carry the same taxon: the line of the previous item is kept and appended again
+    char last_line[24];
+    size_t last_len = 0;
+    uint32_t last_t = 0;
     for (size_t r = rb; r < re; r++) {
         if (P.emit[r]) { out.push_back('>'); out.append(d + P.hdr_off[r], P.hdr_len[r]); out.push_back('\n'); }
         for (uint32_t i = 0; i < P.n_items[r] && wi < P.known.size(); i++, wi++) {
             uint32_t t = P.known[wi] ? taxa[P.key_base + ki++] : 0u;
-            if (P.emit[r] && (t != 0 || one_on_one)) { append_uint(out, t); out.push_back('\n'); }  // src/commands/pept2lca.rs:93-95
+            if (P.emit[r] && (t != 0 || one_on_one)) {                                              // src/commands/pept2lca.rs:93-95
+                if (t != last_t || !last_len) {
+                    const size_t before = out.size();
+                    append_uint(out, t);
+                    out.push_back('\n');
+                    last_len = out.size() - before;
+                    memcpy(last_line, out.data() + before, last_len);
+                    last_t = t;
+                } else out.append(last_line, last_len);
+            }
         }
     }
 }
