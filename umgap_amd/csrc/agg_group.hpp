@@ -75,7 +75,44 @@ __device__ __forceinline__ void general_group(const TaxView& V, GS& G, int metho
         const uint32_t base = k0 * stride;
         uint32_t w = 0, k = k0;
         if (lane == 0) G.roff[0] = 0;
-        while (k < nr && k - k0 < GREADS) {
+        // Short reads (stride <= 16: the tryptic pipelines, CSR reads of a few hits): 64 / stride reads per pass, one lane per item.
+        // The multiplicity of an item is the number of equal items in its read -- stride - 1 shuffles and compares instead of the
+        // hash table below, whose ~100 instructions per READ are spent on a wave that is 75-95 % idle at this length -- and the
+        // item is its taxon's leader when no equal item precedes it.  Same survivors, counts and bookkeeping as the loop below.
+        const uint32_t per_pass = stride <= 16 ? 64u / stride : 0u;
+        const uint32_t r_in = per_pass ? lane / stride : 0u, j_in = per_pass ? lane - r_in * stride : 0u;
+        while (per_pass && k < nr && k - k0 < GREADS) {
+            const uint32_t rp = min(per_pass, min(nr - k, GREADS - (k - k0)));
+            const bool active = r_in < rp;
+            const uint32_t t = active ? wtaxa[(k + r_in) * stride + j_in] : 0u;
+            uint32_t mult = t != 0u ? 1u : 0u;
+            bool lead = t != 0u;
+            for (uint32_t d = 1; d < stride; d++) {
+                uint32_t jo = j_in + d;
+                if (jo >= stride) jo -= stride;
+                const uint32_t o = (uint32_t)__shfl((int)t, (int)(lane - j_in + jo), 64);    // another item of the same read
+                if (t != 0u && o == t) { mult++; if (jo < j_in) lead = false; }
+            }
+            const bool keep = lead && (float)mult >= lower_bound;                            // agg::filter keeps freq >= lower_bound
+            const uint64_t b = __ballot(keep);
+            const uint32_t n_pass = (uint32_t)__builtin_popcountll(b);
+            if (w + n_pass > GCAP) break;        // (k > k0 here: a pass holds at most 64 survivors) these reads open the next sub-batch
+            const uint32_t bit0 = r_in * stride;                                             // first bit of the lane's read
+            const uint32_t seg = (uint32_t)(b >> bit0) & ((1u << stride) - 1u);
+            const uint32_t before = (uint32_t)__builtin_popcountll(b & ((1ull << bit0) - 1ull));
+            wave_sync();                         // every lane holds its taxon in a register before the strip is overwritten
+            if (keep) {
+                const uint32_t i = w + before + (uint32_t)__builtin_popcount(seg & ((1u << j_in) - 1u));
+                wtaxa[base + i] = t;
+                G.cnt[i] = (float)mult;
+                G.rid[i] = (uint8_t)(k - k0 + r_in);
+            }
+            if (active && j_in == 0) { G.rstat[k - k0 + r_in] = ST_PENDING; G.roff[k - k0 + r_in + 1] = w + before + (uint32_t)__builtin_popcount(seg); }
+            w += n_pass;
+            wave_sync();
+            k += rp;
+        }
+        while (!per_pass && k < nr && k - k0 < GREADS) {
             const uint32_t* rt = wtaxa + k * stride;
             const uint32_t t0 = lane < stride ? rt[lane] : 0u, t1 = 64 + lane < stride ? rt[64 + lane] : 0u;
             bool keep0, keep1;
