@@ -242,9 +242,7 @@ __device__ __forceinline__ void general_group(const TaxView& V, GS& G, int metho
                 if (e < w && G.rstat[G.rid[e]] == ST_PENDING) {          // a read that ended in an error holds unresolved elements (NONE):
                     u = wtaxa[base + e];                                  // none of them may reach the taxonomy tables
                     lu = G.last[e];
-                    // is e the last element of its read?  (reads are short lists: scan the offsets)
-                    inner = true;
-                    for (uint32_t r = 0; r < nb; r++) if (G.roff[r + 1] == e + 1) inner = false;
+                    inner = G.roff[G.rid[e] + 1u] != e + 1;              // e is not the last element of its read
                     if (u == NONE) inner = false;
                     if (u != NONE) du = V.depth[u];
                     if (inner) {
@@ -265,9 +263,13 @@ __device__ __forceinline__ void general_group(const TaxView& V, GS& G, int metho
             }
             wave_sync();
             // ---- P3c: per read, LDS only ------------------------------------------------------------------------------------
+            // a read with a single survivor is that survivor (both mixes reduce to it): all of them at once, one lane per read
+            if (lane < nb && G.rstat[lane] == ST_PENDING && G.roff[lane + 1] - G.roff[lane] == 1u) G.rans[lane] = wtaxa[base + G.roff[lane]];
+            wave_sync();
             for (uint32_t r = 0; r < nb; r++) {
                 if (G.rstat[r] != ST_PENDING) continue;
                 const uint32_t o0 = G.roff[r], D = G.roff[r + 1] - o0;
+                if (D == 1u) continue;
                 const uint32_t* bpre = wtaxa + base + o0;
                 uint32_t ans = NONE;
                 if (method == UMGAP_METHOD_TREE) {
