@@ -119,7 +119,11 @@ __device__ __forceinline__ void gather_group_to_strip(const TableView& T, const 
     for (uint32_t i0 = 0; i0 < nk; i0 += 256) {     // four independent perm loads, then four independent gathers, per lane
         uint32_t slot[4], val[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const uint32_t i = i0 + 64 * u + lane; slot[u] = i < nk ? __builtin_nontemporal_load(pp + i) : wire::NOSLOT; }
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = i0 + 64 * u + lane;
+            slot[u] = wire::NOSLOT;
+            if (i < nk) slot[u] = wire::is_local_key(H, first_key + i) ? wire::LOCAL : __builtin_nontemporal_load(pp + i);   // a LOCAL key's perm entry is never read
+        }
 #pragma unroll
         for (int u = 0; u < 4; u++) val[u] = slot[u] >= wire::LOCAL ? 0u : wire::load_value(H.ret, slot[u], H.value_bytes);
 #pragma unroll

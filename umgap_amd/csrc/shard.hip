@@ -207,7 +207,8 @@ __device__ __forceinline__ uint32_t owner_of_bucket(uint32_t b, uint32_t nb, uin
 constexpr int PACK_PER_THREAD = 16;
 __global__ __launch_bounds__(256) void k_shard_pack(const uint64_t* __restrict__ keys, size_t n, uint32_t m, uint32_t nb, uint32_t world,
                                                     uint64_t cap, uint8_t* __restrict__ send, uint32_t* __restrict__ perm,
-                                                    unsigned long long* __restrict__ cursor, uint32_t* __restrict__ overflow, uint32_t local_owner) {
+                                                    unsigned long long* __restrict__ cursor, uint32_t* __restrict__ overflow, uint32_t local_owner,
+                                                    uint64_t* __restrict__ local_bits) {
     __shared__ uint32_t cnt[64];
     __shared__ unsigned long long base[64];
     const uint32_t lane = threadIdx.x & 63;
@@ -248,8 +249,11 @@ __global__ __launch_bounds__(256) void k_shard_pack(const uint64_t* __restrict__
 #pragma unroll
         for (int k = 0; k < PACK_PER_THREAD; k++) {
             const size_t i = t0 + (size_t)k * blockDim.x + threadIdx.x;
-            if (i >= n) continue;
-            uint32_t slot = own[k] == 0xFFFFFFFEu ? wire::LOCAL : wire::NOSLOT;
+            // the wave's 64 keys of this round are consecutive and start at a multiple of 64: their LOCAL flags are one word
+            const uint64_t lbits = __ballot(i < n && own[k] == 0xFFFFFFFEu);
+            if (lane == 0 && i < n) local_bits[i >> 6] = lbits;
+            if (i >= n || own[k] == 0xFFFFFFFEu) continue;     // a LOCAL key has no perm entry
+            uint32_t slot = wire::NOSLOT;
             if (own[k] < 0xFFFFFFFEu) {
                 const uint64_t pos = base[own[k]] + lpos[k];
                 if (pos < cap) {
@@ -348,8 +352,8 @@ __global__ __launch_bounds__(256) void k_shard_unpermute(TableView T, HitSource 
     const uint32_t mr = wire::miss_raw(H.value_bytes);
     for (size_t base = wave * 64; base < n; base += nwaves * 64) {
         const size_t i = base + lane;
-        const uint32_t slot = i < n ? H.perm[i] : wire::NOSLOT;
-        const bool is_local = slot == wire::LOCAL;
+        const bool is_local = i < n && wire::is_local_key(H, i);
+        const uint32_t slot = (i < n && !is_local) ? H.perm[i] : wire::NOSLOT;
         uint32_t local = 0, tag = 0, valid = 0;
         if (is_local) valid = locate(T, H.keys[i], local, tag) ? 1u : 0u;
         const uint64_t lm = __ballot(is_local);
@@ -408,6 +412,7 @@ struct umgap_sharded {
     size_t block_bytes = 0;
     BufSet set[NSETS];
     uint32_t* perm[NPERM] = {};
+    uint64_t* local_bits[NPERM] = {};    // beside each perm buffer: which keys of the piece are the rank's own
     hipEvent_t aggregated[NPERM] = {};   // piece using this perm buffer: aggregate (or un-permute) finished
     // one stream per STAGE: key exchange | pack + probe | value exchange + aggregate.  Pieces flow through them in order: the
     // probes -- each of which saturates the chip's random-request path -- run back to back with the packs between them, the
@@ -456,7 +461,7 @@ int stage_pack(umgap_sharded* sh, uint64_t t, const uint64_t* d_keys, size_t nk)
     unsigned g = (unsigned)((nk + tile - 1) / tile);
     if (g < 1) g = 1;
     hipLaunchKernelGGL(k_shard_pack, dim3(g), dim3(256), 0, s, d_keys, nk, T.m, T.nb, W, sh->cap, S.send_keys, sh->perm[t % NPERM], S.cursor, sh->d_overflow,
-                       sh->local_bypass ? (uint32_t)sh->comm->rank : UMGAP_NONE);
+                       sh->local_bypass ? (uint32_t)sh->comm->rank : UMGAP_NONE, sh->local_bits[t % NPERM]);
     hipLaunchKernelGGL(k_shard_pad, dim3(64, W), dim3(256), 0, s, S.send_keys, S.cursor, sh->cap);
     UMGAP_HIP(hipGetLastError());
     UMGAP_HIP(hipEventRecord(S.filled, s));
@@ -686,8 +691,9 @@ int umgap_sharded_create(umgap_index* shard, umgap_taxonomy* tx, umgap_comm* com
     // one block: per set {send keys, recv keys, values out, values back, perm, cursor}
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t b_keys = pad(cap * W * 6), b_vals = pad(cap * W * 4 + 64), b_perm = pad(sh->piece_keys * 4), b_cur = pad(W * 8);
+    const size_t b_bits = pad((sh->piece_keys / 64 + 2) * 8);
     const size_t per_set = 2 * b_keys + 2 * b_vals + b_cur;
-    sh->block_bytes = NSETS * per_set + NPERM * b_perm + 256;
+    sh->block_bytes = NSETS * per_set + NPERM * (b_perm + b_bits) + 256;
     e = hipMalloc(&sh->block, sh->block_bytes);
     if (e != hipSuccess) { delete sh; return fail(UMGAP_ERR_NOMEM, std::string("umgap_sharded_create: hipMalloc of the exchange buffers (") + std::to_string(sh->block_bytes >> 20) + " MiB): " + hipGetErrorString(e)); }
     char* p = (char*)sh->block;
@@ -705,6 +711,7 @@ int umgap_sharded_create(umgap_index* shard, umgap_taxonomy* tx, umgap_comm* com
     }
     for (int i = 0; i < NPERM; i++) {
         sh->perm[i] = (uint32_t*)p; p += b_perm;
+        sh->local_bits[i] = (uint64_t*)p; p += b_bits;
         if (hipEventCreateWithFlags(&sh->aggregated[i], hipEventDisableTiming) != hipSuccess) { umgap_sharded_free(sh); return fail(UMGAP_ERR_DEVICE, "umgap_sharded_create: event creation failed"); }
     }
     sh->d_overflow = (uint32_t*)p;
@@ -776,7 +783,7 @@ int umgap_sharded_lookup9_dev(umgap_sharded* sh, const uint64_t* d_keys45, size_
             if (hi > lo) {
                 unsigned g = (unsigned)std::min<size_t>((hi - lo + 255) / 256, 2048);   // 4 waves x 64 keys per workgroup and step
                 hipLaunchKernelGGL(k_shard_unpermute, dim3(g), dim3(256), 0, sh->s_agg, sh->ix->view,
-                                   HitSource{sh->set[pc % NSETS].ret_recv, sh->perm[pc % NPERM], sh->value_bytes, d_keys45 + lo}, hi - lo, miss_value, d_out_taxa + lo);
+                                   HitSource{sh->set[pc % NSETS].ret_recv, sh->perm[pc % NPERM], sh->value_bytes, d_keys45 + lo, sh->local_bits[pc % NPERM]}, hi - lo, miss_value, d_out_taxa + lo);
                 UMGAP_HIP(hipGetLastError());
             }
             if ((rc = piece_done(sh, pc))) return rc;
@@ -841,7 +848,7 @@ int umgap_sharded_classify9_dev(umgap_sharded* sh, int method, int strategy, flo
             const uint64_t pc = first + c;
             if ((rc = piece_back(sh, pc))) return rc;
             rc = launch_classify9_from_hits(sh->ix, sh->tx, method, strategy, factor, lower_bound, ranked_only,
-                                            HitSource{sh->set[pc % NSETS].ret_recv, sh->perm[pc % NPERM], sh->value_bytes, d_keys45 + lo * kmers_per_read}, hi - lo, kmers_per_read,
+                                            HitSource{sh->set[pc % NSETS].ret_recv, sh->perm[pc % NPERM], sh->value_bytes, d_keys45 + lo * kmers_per_read, sh->local_bits[pc % NPERM]}, hi - lo, kmers_per_read,
                                             fragments_per_read, min_seed_size, max_gap_size, d_out_taxon + lo, d_out_status + lo, sh->s_agg);
             if (rc) return rc;
             if ((rc = piece_done(sh, pc))) return rc;

@@ -5,8 +5,9 @@
 // remainder straight from h (common.hpp), so nothing is hashed twice.  A send buffer holds `world` regions of `cap`
 // slots; region o = [cap x u32: h & 0xFFFFFFFF][cap x u16: h >> 32] = 6*cap contiguous bytes = one message to peer o.
 // A u16 of 0xFFFF marks a slot that holds no key (the unused tail of a region).
-// A rank's OWN share (1/N of the keys) takes none of this: the pack only marks those keys (perm = LOCAL) and the kernel that
-// consumes the hits probes them itself, between its gathers -- no 6-byte copy, no value store, no gather for them.
+// A rank's OWN share (1/N of the keys) takes none of this: the pack only marks those keys -- one bit per key (local_bits), no
+// perm entry -- and the kernel that consumes the hits probes them itself, between its gathers: no 6-byte copy, no value store,
+// no gather and no 4-byte perm round trip for them.
 // Back (values): one value per slot, same slot order, `value_bytes` = 3 or 4 bytes each (3 when every value of every
 // shard is below 2^24 - 1, which holds for NCBI taxon ids); all-ones = the key is absent.  3-byte values are packed four
 // to three u32 words (cap is a multiple of 4).
@@ -21,9 +22,13 @@ struct HitSource {
                                      // wire::LOCAL = the rank owns the key: probed where it is consumed, never packed
     uint32_t value_bytes = 4;
     const uint64_t* keys = nullptr;  // the batch's packed 9-mers (same indexing as perm): read again for the LOCAL keys
+    const uint64_t* local_bits = nullptr;   // bit i set = key i is LOCAL: its perm entry was never written and is never read
 };
 
 namespace wire {
+
+// is key i of the batch the rank's own?  (no bitmap: the perm entry says so)
+__device__ __forceinline__ bool is_local_key(const HitSource& H, size_t i) { return H.local_bits && ((H.local_bits[i >> 6] >> (i & 63)) & 1ull); }
 
 constexpr uint32_t NOSLOT = 0xFFFFFFFFu;
 constexpr uint32_t LOCAL = 0xFFFFFFFEu;
