@@ -1128,6 +1128,82 @@ def test_sharded_table_local_ranks_match_whole_table(api, torch_cuda, world, pie
             assert torch.equal(got[(r, m)][0], want[(r, m)][0]), (world, r, m, "taxon")
 
 
+@pytest.mark.parametrize("world,stride,frags,pieces", [(3, 128, 0, 2), (2, 40, 2, 3), (4, 7, 0, 1), (2, 64, 64, 2), (5, 1, 0, 2)])
+def test_sharded_runs_other_strides_and_deferred_reads(api, torch_cuda, world, stride, frags, pieces):
+    """The exchange stores no per-key slot: pack and consumer walk the same RUNS of reads (the consumer's group: it depends on the
+    k-mers and fragments per read) and recompute every key's slot.  Other run geometries than the benchmark's, reads with more
+    than 64 distinct taxa (the large-scratch pass finds a deferred read inside its run), keys that are not packed 9-mers, and
+    an empty rank."""
+    torch = torch_cuda
+    from umgap_amd.api import Index, Taxonomy
+    from umgap_amd.dist import Comm, Sharded
+    from umgap_amd.synth import synthetic_taxonomy
+    ids, par, valid, rank = synthetic_taxonomy(5000, 8000, max_depth=12, seed=9)
+    tx = Taxonomy(ids, par, valid, rank)
+    rng = np.random.default_rng(1000 * world + stride)
+    n_keys = 50_000
+    keys = rng.permutation(np.unique(rng.integers(0, 1 << 45, 2 * n_keys, dtype=np.uint64)))[:n_keys]
+    vals = rng.choice(ids, n_keys).astype(np.uint32)
+    whole = Index.build(keys, vals)
+    n_reads = [0 if (r == 1 and world > 2) else 700 + 37 * r for r in range(world)]     # one rank has nothing to classify
+    qs = []
+    for r in range(world):
+        q = keys[rng.integers(0, n_keys, n_reads[r] * stride)]                         # all hits: as many distinct taxa as k-mers
+        few = (n_reads[r] // 3) * stride
+        q[:few] = keys[rng.integers(0, 40, few)]                                         # a third of the reads: few distinct taxa
+        miss = rng.random(len(q)) < 0.2
+        q[miss] = rng.integers(0, 1 << 45, int(miss.sum()), dtype=np.uint64)
+        q[rng.random(len(q)) < 0.01] = np.uint64((1 << 45) + 12345)                      # not a packed 9-mer: never sent, a miss
+        qs.append(torch.from_numpy(q.view(np.int64)).cuda())
+    max_keys = (max(n_reads) + pieces) // pieces * pieces * stride
+    modes = [("tree", "lca*", 0.0), ("tree", "hybrid", 0.0), ("rmq", "mrtl", 1.0), ("rmq", "hybrid", 0.0)]
+    want, want_hits = {}, []
+    for r in range(world):
+        want_hits.append(whole.lookup9_dev(qs[r], miss_value=0).clone() if n_reads[r] else torch.empty(0, dtype=torch.int32, device="cuda"))
+        for m in modes:
+            t = torch.empty(n_reads[r], dtype=torch.int32, device="cuda")
+            s = torch.empty_like(t)
+            if n_reads[r]:
+                api.classify9_dev(whole, tx, qs[r], n_reads[r], stride, t, s, method=m[0], strategy=m[1], factor=0.3, lower_bound=m[2],
+                                  fragments_per_read=frags, min_seed_size=2, max_gap_size=1)
+            want[(r, m)] = (t, s)
+    torch.cuda.synchronize()
+    if stride >= 100:
+        h = want_hits[0].cpu().numpy().view(np.uint32)
+        assert max(len(set(h[i * stride:(i + 1) * stride].tolist())) for i in range(n_reads[0])) > 64   # the deferred pass is exercised
+    shards = []
+    for r in range(world):
+        ix = Index.build(keys, vals)
+        ix.set_shard(r, world)
+        shards.append(ix)
+    comms = Comm.local(world)
+    got, got_hits = {}, [torch.full_like(want_hits[r], -7) for r in range(world)]
+
+    def rank_body(r):
+        torch.cuda.set_device(0)
+        sh = Sharded(shards[r], tx, comms[r], max_keys, pieces=pieces)
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            sh.lookup9(qs[r], got_hits[r], miss_value=0, stream=st)
+            for m in modes:
+                t = torch.full((n_reads[r],), -1, dtype=torch.int32, device="cuda")
+                s = torch.full_like(t, -1)
+                sh.classify9(qs[r], n_reads[r], stride, t, s, method=m[0], strategy=m[1], factor=0.3, lower_bound=m[2], fragments_per_read=frags,
+                             min_seed_size=2, max_gap_size=1, stream=st)
+                got[(r, m)] = (t, s)
+        st.synchronize()
+        sh.check()
+        sh.close()
+
+    _run_ranks(world, rank_body)
+    torch.cuda.synchronize()
+    for r in range(world):
+        assert torch.equal(got_hits[r], want_hits[r]), (world, r)
+        for m in modes:
+            assert torch.equal(got[(r, m)][1], want[(r, m)][1]), (world, r, m, "status")
+            assert torch.equal(got[(r, m)][0], want[(r, m)][0]), (world, r, m, "taxon")
+
+
 def test_sharded_table_wide_values_and_overflow(api, torch_cuda):
     """Values that need 4 bytes switch the return format; a region that overflows is reported by check() (sticky over
     several calls) and its keys are answered with a miss, never with another key's value."""

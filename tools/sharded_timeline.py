@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Timeline of the last sharded step out of a rocprofv3 --kernel-trace of bench.py --force-dist (tools/profile_sharded.sh):
+"""Timeline of the last sharded step out of a rocprofv3 --kernel-trace of tools/bench_sharded.py (tools/profile_sharded.sh):
 which of pack / probe / aggregate ran when, and the bench line's sharded figures.   tools/sharded_timeline.py gpurun_out/<tag> [out.txt]"""
 import csv
 import glob
@@ -11,13 +11,16 @@ src = sys.argv[1]
 trace = glob.glob(os.path.join(src, "stats", "**", "*kernel_trace.csv"), recursive=True)[0]
 rows = [r for r in csv.DictReader(open(trace)) if any(k in r["Kernel_Name"] for k in ("k_shard_pack", "k_shard_probe", "k_classify9<false, true>"))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-last = rows[-24:]
+n_pack = sum("k_shard_pack" in r["Kernel_Name"] for r in rows)
+n_probe = sum("k_shard_probe" in r["Kernel_Name"] for r in rows)
+pieces = max(1, n_probe // 4)        # bench_sharded.py: one check step + three timed steps
+last = rows[-(pieces * (2 + (1 if n_pack else 0))):]
 t0 = int(last[0]["Start_Timestamp"])
 lines = []
 for line in open(os.path.join(src, "stats.log"), errors="replace"):
-    if line.startswith("{") and '"sharded"' in line:
+    if line.startswith("{") and '"sharded_ms_per_step"' in line:
         d = json.loads(line)
-        lines.append("bench line under the profiler: sharded %.2f ms per step (%d pieces), replica %.2f ms" % (d["sharded"]["ms_per_step"], d["sharded"]["pieces"], d["ms_per_step"]))
+        lines.append("under the profiler: sharded %.2f ms per step (%d pieces, own keys %s), whole table %.2f ms" % (d["sharded_ms_per_step"], d["pieces"], d["own_keys"], d["whole_table_ms_per_step"]))
 lines.append("kernel     queue    start ->     end   (ms, last step)")
 for r in last:
     n = r["Kernel_Name"]

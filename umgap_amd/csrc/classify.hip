@@ -110,48 +110,63 @@ __device__ __forceinline__ void probe_group_to_strip(const TableView& T, const u
 
 
 // Sharded mode (shard.hip): the hits of a group were looked up by the shards that own the keys and came back over the
-// exchange; key i of the batch sits at slot perm[i] of the returned buffer (NOSLOT: the key was not representable or its
-// send region overflowed => miss), 3 or 4 bytes per slot (shard_wire.hpp), all-ones = miss.  Keys this rank owns itself
-// (perm = LOCAL) never went anywhere: they are probed here, against the rank's shard.
-__device__ __forceinline__ void gather_group_to_strip(const TableView& T, const HitSource& H, size_t first_key, uint32_t nk, uint32_t* wtaxa, uint32_t lane) {
-    const uint32_t* pp = H.perm + first_key;
+// exchange.  The group is one RUN of the piece (shard_wire.hpp): the wave walks its keys in rounds of 64, recomputes owner and
+// rank of every key exactly as the pack did and finds the key's value at base[run][owner] + rank of the returned buffer (3 or 4
+// bytes per slot, all-ones = miss; a key that was not representable or whose send region overflowed is a miss) -- the values
+// of a run lie in `world` contiguous stretches, so a round's loads coalesce.  Keys this rank owns itself never went anywhere:
+// they are probed here, against the rank's shard, with the hash already in hand.
+// The strip receives the keys [want_lo, want_hi) of the run (the whole run in the first pass; one read of it in the large-scratch
+// pass, which still has to walk the run from its start to know the ranks).
+__device__ __forceinline__ void gather_run_to_strip(const TableView& T, const HitSource& H, size_t run, size_t run_first_key, uint32_t want_lo, uint32_t want_hi,
+                                                    uint32_t* wtaxa, uint32_t lane) {
+    const uint64_t* kp = H.keys + run_first_key;
+    if (H.world == 1 && H.self == 0) { probe_group_to_strip(T, kp + want_lo, want_hi - want_lo, wtaxa, lane); return; }   // nobody else holds anything
     const uint32_t q = lane >> 2, j = lane & 3;
-    for (uint32_t i0 = 0; i0 < nk; i0 += 256) {     // four independent perm loads, then four independent gathers, per lane
-        uint32_t slot[4], val[4];
+    const double wn = (double)H.world / (double)T.nb;
+    const uint32_t base = lane < H.world ? H.bases[run * H.world + lane] : 0u;
+    uint32_t seen = 0;
+    for (uint32_t i0 = 0; i0 < want_hi; i0 += 256) {     // four rounds: four independent key loads, then four independent value loads, per lane
+        uint64_t key[4];
+        wire::Routed R[4];
+        uint32_t val[4];
+        uint64_t slot[4];
+        bool wanted[4], local[4], travelled[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t i = i0 + 64 * u + lane;
-            slot[u] = wire::NOSLOT;
-            if (i < nk) slot[u] = wire::is_local_key(H, first_key + i) ? wire::LOCAL : __builtin_nontemporal_load(pp + i);   // a LOCAL key's perm entry is never read
+            key[u] = i < want_hi ? __builtin_nontemporal_load(kp + i) : 0ull;
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) val[u] = slot[u] >= wire::LOCAL ? 0u : wire::load_value(H.ret, slot[u], H.value_bytes);
+        for (int u = 0; u < 4; u++) {
+            const uint32_t i = i0 + 64 * u + lane;
+            R[u] = wire::route(key[u], i < want_hi, T.m, T.nb, H.world, wn);
+            const uint32_t rank = wire::run_rank(R[u].owner, H.world, lane, seen);
+            const uint32_t b0 = (uint32_t)__shfl((int)base, (int)(R[u].owner & 63u), 64);
+            wanted[u] = i >= want_lo && i < want_hi;
+            local[u] = wanted[u] && R[u].owner == H.self;
+            const uint64_t pos = (uint64_t)b0 + rank;
+            travelled[u] = wanted[u] && R[u].owner != wire::NO_OWNER && R[u].owner != H.self && pos < H.cap;
+            slot[u] = (uint64_t)R[u].owner * H.cap + pos;
+        }
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const uint32_t i = i0 + 64 * u + lane; if (i < nk && slot[u] != wire::LOCAL) wtaxa[i] = val[u]; }
-        // the rank's own keys: probed here, two chunks of 64 in flight (keys that travelled take no part: no request is issued for them)
+        for (int u = 0; u < 4; u++) val[u] = travelled[u] ? wire::load_value(H.ret, slot[u], H.value_bytes) : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const uint32_t i = i0 + 64 * u + lane; if (wanted[u] && !local[u]) wtaxa[i - want_lo] = val[u]; }
+        // the rank's own keys: probed here, two rounds in flight (keys that travelled take no part: no request is issued for them)
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            const bool l0 = slot[2 * h] == wire::LOCAL, l1 = slot[2 * h + 1] == wire::LOCAL;
-            const uint64_t m0 = __ballot(l0), m1 = __ballot(l1);
+            const uint64_t m0 = __ballot(local[2 * h]), m1 = __ballot(local[2 * h + 1]);
             if (!(m0 | m1)) continue;               // wave-uniform
             ProbeBatch B[2];
             uint32_t res[2][4];
-            {
-                uint32_t local = 0, tag = 0, valid = 0;
-                if (l0) valid = locate(T, __builtin_nontemporal_load(H.keys + first_key + i0 + 128 * h + lane), local, tag) ? 1u : 0u;
-                probe_issue(T, local, tag | (valid << 31), lane, B[0]);
-            }
-            {
-                uint32_t local = 0, tag = 0, valid = 0;
-                if (l1) valid = locate(T, __builtin_nontemporal_load(H.keys + first_key + i0 + 128 * h + 64 + lane), local, tag) ? 1u : 0u;
-                probe_issue(T, local, tag | (valid << 31), lane, B[1]);
-            }
+            probe_issue(T, R[2 * h].bucket - T.home_lo, R[2 * h].tag | ((local[2 * h] ? 1u : 0u) << 31), lane, B[0]);
+            probe_issue(T, R[2 * h + 1].bucket - T.home_lo, R[2 * h + 1].tag | ((local[2 * h + 1] ? 1u : 0u) << 31), lane, B[1]);
             probe_eval_multi<2>(T, B, 0u, lane, res);
             if (j == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    if ((m0 >> (16 * r + q)) & 1ull) wtaxa[i0 + 128 * h + 16 * r + q] = res[0][r];
-                    if ((m1 >> (16 * r + q)) & 1ull) wtaxa[i0 + 128 * h + 64 + 16 * r + q] = res[1][r];
+                    if ((m0 >> (16 * r + q)) & 1ull) wtaxa[i0 + 128 * h + 16 * r + q - want_lo] = res[0][r];
+                    if ((m1 >> (16 * r + q)) & 1ull) wtaxa[i0 + 128 * h + 64 + 16 * r + q - want_lo] = res[1][r];
                 }
             }
         }
@@ -186,7 +201,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const size_t r0 = g * G;
         const uint32_t nr = (uint32_t)min((size_t)G, n_reads - r0);
         const uint32_t nk = nr * stride;                   // keys of this group (<= STRIP)
-        if (GATHER) gather_group_to_strip(T, H, r0 * stride, nk, wtaxa, lane);
+        if (GATHER) gather_run_to_strip(T, H, g, r0 * stride, 0u, nk, wtaxa, lane);
         else probe_group_to_strip(T, keys + r0 * stride, nk, wtaxa, lane);
         wave_lds_sync();
         // ---- seedextend per fragment (one lane per fragment, nr * frags <= 64) ----
@@ -236,8 +251,12 @@ __global__ __launch_bounds__(256) void k_classify9_general(TableView T, TaxView 
         const size_t r0 = todo ? (size_t)todo[g] : g * G;
         const uint32_t nr = todo ? 1u : (uint32_t)min((size_t)G, n_reads - r0);
         const uint32_t nk = nr * stride;
-        if (GATHER) gather_group_to_strip(T, H, r0 * stride, nk, wtaxa, lane);
-        else probe_group_to_strip(T, keys + r0 * stride, nk, wtaxa, lane);
+        if (GATHER) {
+            // the runs of the exchange are the groups of the FIRST pass (H.run keys): a deferred read is found inside its run
+            const size_t per_run = H.run / stride, run = r0 / per_run;
+            const uint32_t lo = (uint32_t)(r0 - run * per_run) * stride;
+            gather_run_to_strip(T, H, run, run * per_run * stride, lo, lo + nk, wtaxa, lane);
+        } else probe_group_to_strip(T, keys + r0 * stride, nk, wtaxa, lane);
         wave_lds_sync();
         uint64_t se_panic = 0;
         if (frags) {
@@ -288,7 +307,7 @@ __global__ __launch_bounds__(256) void k_classify9_group(TableView T, TaxView V,
         const size_t r0 = g * G;
         const uint32_t nr = (uint32_t)min((size_t)G, n_reads - r0);
         const uint32_t nk = nr * stride;
-        if (GATHER) gather_group_to_strip(T, H, r0 * stride, nk, wtaxa, lane);
+        if (GATHER) gather_run_to_strip(T, H, g, r0 * stride, 0u, nk, wtaxa, lane);
         else probe_group_to_strip(T, keys + r0 * stride, nk, wtaxa, lane);
         wave_lds_sync();
         uint64_t se_panic = 0;
@@ -530,8 +549,8 @@ int launch_classify9_from_hits(umgap_index* ix, umgap_taxonomy* tx, int method, 
                                size_t n_reads, uint32_t kmers_per_read, uint32_t fragments_per_read, uint32_t min_seed_size, uint32_t max_gap_size,
                                uint32_t* d_out_taxon, uint32_t* d_out_status, hipStream_t s) {
     if (!n_reads) return UMGAP_OK;
-    uint32_t G = 1024u / kmers_per_read;
-    if (fragments_per_read && G * fragments_per_read > 64) G = 64 / fragments_per_read;
+    const uint32_t G = classify9_group_reads(kmers_per_read, fragments_per_read);
+    if (H.run != G * kmers_per_read) return fail(UMGAP_ERR_INVALID, "launch_classify9_from_hits: the exchange was packed with another run length");
     // one group per wave, as many workgroups as groups: short-lived workgroups, so this piece's aggregate shares the compute
     // units with the probe and the pack of the pieces behind it
     const size_t g = ((n_reads + G - 1) / G + 3) / 4;   // (a capped, persistent grid and 4 instead of 8 pieces measured the same: 25.2-25.9 ms)

@@ -5,11 +5,11 @@
 // thread per GPU inside `umgap`) holds the home buckets [nb*r/N, nb*(r+1)/N) (+ halo) in its HBM, classifies its OWN reads and
 // asks the owners for the k-mers it does not hold:
 //
-//   pack      keys -> N regions by owner shard, 6 bytes per key (shard_wire.hpp), + perm[i] = slot of key i   k_shard_pack
+//   pack      keys -> N regions by owner shard, 6 bytes per key (shard_wire.hpp), + bases[run][owner]          k_shard_pack
 //   exchange  all-to-all of the regions over RCCL send/recv groups (xGMI)                                      comm_alltoall
 //   probe     the received keys against the local shard (the quad probe of probe_common.hpp), 3 or 4 B/value  k_shard_probe
 //   exchange  all-to-all of the values back
-//   classify  gather the hits of each read through perm into LDS -> [seedextend] -> aggregate                  classify.hip (GATHER)
+//   classify  the hits of a run of reads from their `world` contiguous stretches into LDS -> [seedextend] -> aggregate   classify.hip (GATHER)
 //
 // A batch is cut into pieces of whole reads that flow through three stage streams (pack + key exchange | probe | value
 // exchange + aggregate) over four buffer sets: while piece t is packed and its keys travel, piece t-1 is probed and piece
@@ -192,82 +192,69 @@ int comm_max_u32(umgap_comm* c, uint32_t* v) {
 // ------------------------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t owner_of_bucket(uint32_t b, uint32_t nb, uint32_t world) {
-    // shard s owns home buckets [nb*s/world, nb*(s+1)/world)   (alloc_table in index.hip)
-    uint32_t s = (uint32_t)(((uint64_t)b * world) / nb);
-    while ((uint64_t)nb * s / world > b) s--;
-    while ((uint64_t)nb * (s + 1) / world <= b) s++;
-    return s;
-}
-
-// keys -> per-owner regions of `send` (6 bytes per key: h = mix45(key) split 32 + 16) and perm[i] = owner * cap + position.
-// A workgroup handles a tile of 4096 keys: positions inside the tile come from LDS counters (one ds_add per wave and
-// owner), then ONE global atomic per owner reserves the tile's range, so a tile's keys for one owner are contiguous and
-// the later gather through perm stays cache friendly.  Keys with bits above 45 (not a packed 9-mer) are not sent.
-constexpr int PACK_PER_THREAD = 16;
-__global__ __launch_bounds__(256) void k_shard_pack(const uint64_t* __restrict__ keys, size_t n, uint32_t m, uint32_t nb, uint32_t world,
-                                                    uint64_t cap, uint8_t* __restrict__ send, uint32_t* __restrict__ perm,
-                                                    unsigned long long* __restrict__ cursor, uint32_t* __restrict__ overflow, uint32_t local_owner,
-                                                    uint64_t* __restrict__ local_bits) {
-    __shared__ uint32_t cnt[64];
-    __shared__ unsigned long long base[64];
-    const uint32_t lane = threadIdx.x & 63;
-    const size_t tile = (size_t)blockDim.x * PACK_PER_THREAD;
-    for (size_t t0 = (size_t)blockIdx.x * tile; t0 < n; t0 += (size_t)gridDim.x * tile) {
-        if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
-        __syncthreads();
-        uint64_t h[PACK_PER_THREAD];
-        uint32_t own[PACK_PER_THREAD], lpos[PACK_PER_THREAD];
+// keys -> per-owner regions of `send` (6 bytes per key: h = mix45(key) split 32 + 16) and bases[run][owner] = first slot of the
+// run's keys for that owner (shard_wire.hpp: the slot of a key is base + its rank among the run's keys of the same owner, which
+// the consumer recomputes; nothing per key is stored).  A wave takes one run (at most 1024 keys = 16 rounds of 64) and counts per
+// owner with ballots; the four waves of a workgroup add their counts up in LDS and ONE global atomic per owner reserves the
+// workgroup's range.  Keys with bits above 45 (not a packed 9-mer) are not sent, nor are the rank's own (local_owner).
+constexpr int PACK_ROUNDS = 16;
+__global__ __launch_bounds__(256) void k_shard_pack(const uint64_t* __restrict__ keys, size_t n, uint32_t run_len, uint32_t m, uint32_t nb, uint32_t world,
+                                                    double world_over_nb, uint64_t cap, uint8_t* __restrict__ send, uint32_t* __restrict__ bases,
+                                                    unsigned long long* __restrict__ cursor, uint32_t* __restrict__ overflow, uint32_t local_owner) {
+    __shared__ uint32_t wcnt[4][64];
+    __shared__ uint32_t wbase[4][64];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t n_runs = (n + run_len - 1) / run_len;
+    for (size_t run0 = (size_t)blockIdx.x * 4; run0 < n_runs; run0 += (size_t)gridDim.x * 4) {   // the same trip count for the four waves
+        const size_t run = run0 + wv, k0 = run * run_len;
+        const uint32_t len = run < n_runs ? (uint32_t)min((size_t)run_len, n - k0) : 0u;
+        uint64_t h[PACK_ROUNDS];
+        uint32_t meta[PACK_ROUNDS];   // owner | rank << 8, all-ones = not sent
+        uint32_t seen = 0;
 #pragma unroll
-        for (int k = 0; k < PACK_PER_THREAD; k++) {
-            const size_t i = t0 + (size_t)k * blockDim.x + threadIdx.x;
-            own[k] = 0xFFFFFFFFu;
-            h[k] = 0;
-            lpos[k] = 0;
-            if (i < n) {
-                const uint64_t key = __builtin_nontemporal_load(keys + i);
-                if ((key >> 45) == 0) {
-                    h[k] = mix45(key);
-                    const uint32_t a = (uint32_t)(h[k] >> R_BITS), r = (uint32_t)h[k] & R_MASK;
-                    own[k] = owner_of_bucket(a * m + (uint32_t)(((uint64_t)r * m) >> R_BITS), nb, world);
-                    if (own[k] == local_owner) own[k] = 0xFFFFFFFEu;   // this rank's own key: marked, not packed (local_owner = NONE switches that off)
-                }
-            }
-            for (uint32_t o = 0; o < world; o++) {     // wave-aggregated LDS reservation
-                const uint64_t mask = __ballot(own[k] == o);
-                if (!mask) continue;
-                const uint32_t leader = (uint32_t)__builtin_ctzll(mask);
-                uint32_t wbase = 0;
-                if (lane == leader) wbase = atomicAdd(&cnt[o], (uint32_t)__builtin_popcountll(mask));
-                wbase = (uint32_t)__shfl((int)wbase, (int)leader, 64);
-                if (own[k] == o) lpos[k] = wbase + (uint32_t)__builtin_popcountll(mask & ((1ull << lane) - 1ull));
-            }
+        for (int r = 0; r < PACK_ROUNDS; r++) {
+            h[r] = 0;
+            meta[r] = 0xFFFFFFFFu;
+            if (64u * r >= len) continue;   // wave-uniform
+            const uint32_t i = 64u * r + lane;
+            const uint64_t key = i < len ? __builtin_nontemporal_load(keys + k0 + i) : 0ull;
+            const wire::Routed R = wire::route(key, i < len, m, nb, world, world_over_nb);
+            const uint32_t owner = R.owner == local_owner ? wire::NO_OWNER : R.owner;   // this rank's own key: probed where it is consumed
+            const uint32_t rank = wire::run_rank(owner, world, lane, seen);
+            h[r] = R.h;
+            if (owner != wire::NO_OWNER) meta[r] = owner | (rank << 8);
+        }
+        wcnt[wv][lane] = seen;
+        __syncthreads();
+        if (wv == 0 && lane < world) {
+            const uint32_t c0 = wcnt[0][lane], c1 = wcnt[1][lane], c2 = wcnt[2][lane], c3 = wcnt[3][lane];
+            const uint32_t total = c0 + c1 + c2 + c3;
+            unsigned long long b = total ? atomicAdd(&cursor[lane], (unsigned long long)total) : 0ull;
+            auto sat = [](unsigned long long v) { return v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)v; };
+            wbase[0][lane] = sat(b);
+            wbase[1][lane] = sat(b + c0);
+            wbase[2][lane] = sat(b + c0 + c1);
+            wbase[3][lane] = sat(b + c0 + c1 + c2);
         }
         __syncthreads();
-        if (threadIdx.x < world) base[threadIdx.x] = cnt[threadIdx.x] ? atomicAdd(&cursor[threadIdx.x], (unsigned long long)cnt[threadIdx.x]) : 0ull;
-        __syncthreads();
+        const uint32_t base = lane < world ? wbase[wv][lane] : 0u;
+        if (run < n_runs && lane < world) bases[run * world + lane] = base;
 #pragma unroll
-        for (int k = 0; k < PACK_PER_THREAD; k++) {
-            const size_t i = t0 + (size_t)k * blockDim.x + threadIdx.x;
-            // the wave's 64 keys of this round are consecutive and start at a multiple of 64: their LOCAL flags are one word
-            const uint64_t lbits = __ballot(i < n && own[k] == 0xFFFFFFFEu);
-            if (lane == 0 && i < n) local_bits[i >> 6] = lbits;
-            if (i >= n || own[k] == 0xFFFFFFFEu) continue;     // a LOCAL key has no perm entry
-            uint32_t slot = wire::NOSLOT;
-            if (own[k] < 0xFFFFFFFEu) {
-                const uint64_t pos = base[own[k]] + lpos[k];
-                if (pos < cap) {
-                    uint8_t* region = send + (size_t)own[k] * cap * 6;
-                    reinterpret_cast<uint32_t*>(region)[pos] = (uint32_t)h[k];
-                    reinterpret_cast<uint16_t*>(region + cap * 4)[pos] = (uint16_t)(h[k] >> 32);
-                    slot = (uint32_t)((uint64_t)own[k] * cap + pos);
-                } else {
-                    atomicExch(overflow, 1u);   // sticky: umgap_sharded_check reports it; the key is answered with a miss
-                }
+        for (int r = 0; r < PACK_ROUNDS; r++) {
+            if (64u * r >= len) continue;   // wave-uniform
+            const uint32_t owner = meta[r] & 0xFFu;
+            const uint32_t b0 = (uint32_t)__shfl((int)base, (int)(owner & 63u), 64);
+            if (meta[r] == 0xFFFFFFFFu) continue;
+            const uint64_t pos = (uint64_t)b0 + (meta[r] >> 8);
+            if (pos < cap) {
+                uint8_t* region = send + (size_t)owner * cap * 6;
+                reinterpret_cast<uint32_t*>(region)[pos] = (uint32_t)h[r];
+                reinterpret_cast<uint16_t*>(region + cap * 4)[pos] = (uint16_t)(h[r] >> 32);
+            } else {
+                atomicExch(overflow, 1u);   // sticky: umgap_sharded_check reports it; the consumer answers the key with a miss
             }
-            perm[i] = slot;
         }
-        __syncthreads();
+        __syncthreads();   // wcnt / wbase are rewritten by the next trip
     }
 }
 
@@ -283,10 +270,10 @@ __global__ __launch_bounds__(256) void k_shard_pad(uint8_t* __restrict__ send, c
 // it was packed into and answered straight into the buffer the returned values are gathered from -- no copy, no wire.
 // One wave step = 128 consecutive slots (cap is a multiple of 128, so they share a region): two probe batches in flight; the
 // results are packed in the wave's LDS strip and leave as whole 16-byte-per-lane stores.  The grid is PERSISTENT and small
-// (two workgroups per CU = 8 waves = ~1000 sectors in flight per CU, several times what the request ceiling needs): the
+// (three workgroups per CU = 12 waves = ~1500 sectors in flight per CU, several times what the request ceiling needs): the
 // hardware dispatches one grid of a queue at a time, so a grid of 200 000 short workgroups keeps every other stream's kernel
 // waiting until its last workgroup is placed (a pack "beside" such a probe made no progress at all: r02_sharded_timeline_*),
-// while a resident grid that leaves half of each CU's wave slots free lets pack, aggregate and RCCL's copies run next to it.
+// while a resident grid that leaves part of each CU's wave slots free lets pack, aggregate and RCCL's copies run next to it.
 template <int VB>
 __global__ __launch_bounds__(256) void k_shard_probe(TableView T, const uint8_t* __restrict__ recv, const uint8_t* __restrict__ own_send, uint32_t self,
                                                      uint32_t skip_self, uint64_t cap, uint64_t n_slots, uint32_t* __restrict__ ret, uint32_t* __restrict__ own_ret) {
@@ -344,31 +331,42 @@ __global__ __launch_bounds__(256) void k_shard_probe(TableView T, const uint8_t*
     }
 }
 
-// the plain sharded get(): out[i] = value of key i (perm order undone), or miss_value.  A wave takes 64 keys: the values of
-// the keys that travelled are gathered, the rank's own keys (perm = LOCAL) are probed here (the quad probe, all lanes take part).
+// the plain sharded get(): out[i] = value of key i, or miss_value.  A wave takes one run of the piece (shard_wire.hpp) in rounds
+// of 64 keys: the values of the keys that travelled are read at base + rank, the rank's own keys are probed here (the quad probe,
+// all lanes take part).
 __global__ __launch_bounds__(256) void k_shard_unpermute(TableView T, HitSource H, size_t n, uint32_t miss_value, uint32_t* __restrict__ out) {
     const uint32_t lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
     const uint32_t mr = wire::miss_raw(H.value_bytes);
-    for (size_t base = wave * 64; base < n; base += nwaves * 64) {
-        const size_t i = base + lane;
-        const bool is_local = i < n && wire::is_local_key(H, i);
-        const uint32_t slot = (i < n && !is_local) ? H.perm[i] : wire::NOSLOT;
-        uint32_t local = 0, tag = 0, valid = 0;
-        if (is_local) valid = locate(T, H.keys[i], local, tag) ? 1u : 0u;
-        const uint64_t lm = __ballot(is_local);
-        if (i < n && !is_local) {
-            uint32_t v = mr;
-            if (slot != wire::NOSLOT) v = wire::load_raw(H.ret, slot, H.value_bytes);
-            out[i] = v == mr ? miss_value : v;
-        }
-        if (lm) {   // wave-uniform
-            uint32_t res[4];
-            wave_probe64_vals(T, local, tag | (valid << 31), miss_value, lane, res);
-            if (j == 0) {
+    const double wn = (double)H.world / (double)T.nb;
+    const size_t n_runs = (n + H.run - 1) / H.run;
+    for (size_t run = wave; run < n_runs; run += nwaves) {
+        const size_t k0 = run * H.run;
+        const uint32_t len = (uint32_t)min((size_t)H.run, n - k0);
+        const uint32_t base = lane < H.world ? H.bases[run * H.world + lane] : 0u;
+        uint32_t seen = 0;
+        for (uint32_t i0 = 0; i0 < len; i0 += 64) {
+            const uint32_t i = i0 + lane;
+            const uint64_t key = i < len ? __builtin_nontemporal_load(H.keys + k0 + i) : 0ull;
+            const wire::Routed R = wire::route(key, i < len, T.m, T.nb, H.world, wn);
+            const uint32_t rank = wire::run_rank(R.owner, H.world, lane, seen);
+            const uint32_t b0 = (uint32_t)__shfl((int)base, (int)(R.owner & 63u), 64);
+            const bool is_local = i < len && R.owner == H.self;
+            if (i < len && !is_local) {
+                uint32_t v = mr;
+                const uint64_t pos = (uint64_t)b0 + rank;
+                if (R.owner != wire::NO_OWNER && pos < H.cap) v = wire::load_raw(H.ret, (uint64_t)R.owner * H.cap + pos, H.value_bytes);
+                out[k0 + i] = v == mr ? miss_value : v;
+            }
+            const uint64_t lm = __ballot(is_local);
+            if (lm) {   // wave-uniform
+                uint32_t res[4];
+                wave_probe64_vals(T, R.bucket - T.home_lo, R.tag | ((is_local ? 1u : 0u) << 31), miss_value, lane, res);
+                if (j == 0) {
 #pragma unroll
-                for (int r = 0; r < 4; r++)
-                    if ((lm >> (16 * r + q)) & 1ull) out[base + 16 * r + q] = res[r];
+                    for (int r = 0; r < 4; r++)
+                        if ((lm >> (16 * r + q)) & 1ull) out[k0 + i0 + 16 * r + q] = res[r];
+                }
             }
         }
     }
@@ -390,7 +388,7 @@ __global__ __launch_bounds__(256) void k_max_value(const uint64_t* __restrict__ 
 }
 
 constexpr int NSETS = 4;    // exchange buffer sets: piece t uses set t % NSETS
-constexpr int NPERM = 8;    // perm buffers (piece t uses t % NPERM): a pack never waits for the aggregate NSETS pieces back
+constexpr int NPERM = 8;    // run-base buffers (piece t uses t % NPERM): a pack never waits for the aggregate NSETS pieces back
 
 struct BufSet {
     hipEvent_t filled = nullptr, packed = nullptr, probed = nullptr;   // piece using this set: packed / keys exchanged / probe finished
@@ -411,9 +409,8 @@ struct umgap_sharded {
     void* block = nullptr;
     size_t block_bytes = 0;
     BufSet set[NSETS];
-    uint32_t* perm[NPERM] = {};
-    uint64_t* local_bits[NPERM] = {};    // beside each perm buffer: which keys of the piece are the rank's own
-    hipEvent_t aggregated[NPERM] = {};   // piece using this perm buffer: aggregate (or un-permute) finished
+    uint32_t* bases[NPERM] = {};         // [run][world] first slots of a piece's runs (shard_wire.hpp)
+    hipEvent_t aggregated[NPERM] = {};   // piece using this buffer: aggregate (or un-permute) finished
     // one stream per STAGE: key exchange | pack + probe | value exchange + aggregate.  Pieces flow through them in order: the
     // probes -- each of which saturates the chip's random-request path -- run back to back with the packs between them, the
     // keys of the pieces ahead travel meanwhile and the aggregate of the pieces behind runs underneath.  (One stream per
@@ -439,9 +436,9 @@ int sharded_args_ok(umgap_sharded* sh, const char* who) {
 }
 
 // one piece, first half: pack -> pad -> key exchange -> local probe, all on the set's stream
-// The stages of piece t (global piece number; set t % NSETS, perm t % NPERM).
+// The stages of piece t (global piece number; set t % NSETS, run bases t % NPERM).
 //   pack  (s_keys)  overwrites send_keys of its set, last read by the key exchange (earlier on s_keys) and the probe of piece
-//                   t - NSETS (waited for), and perm, last read by the aggregate of piece t - NPERM;
+//                   t - NSETS (waited for), and the run bases, last read by the aggregate of piece t - NPERM;
 //   keys  (s_keys)  send_keys -> recv_keys over the wire, after the pack;
 //   probe (s_probe) after the keys; overwrites the value buffers of its set, last read by the value exchange and the
 //                   aggregate of piece t - NSETS.
@@ -449,19 +446,23 @@ int sharded_args_ok(umgap_sharded* sh, const char* who) {
 // t .. t + LOOK - 1 are probed.
 constexpr uint64_t LOOK = 2;
 
-int stage_pack(umgap_sharded* sh, uint64_t t, const uint64_t* d_keys, size_t nk) {
+int stage_pack(umgap_sharded* sh, uint64_t t, const uint64_t* d_keys, size_t nk, uint32_t run_len) {
     BufSet& S = sh->set[t % NSETS];
     const uint32_t W = (uint32_t)sh->comm->world;
     const TableView& T = sh->ix->view;
     hipStream_t s = sh->s_keys;                                               // the key exchange of piece t - NSETS is earlier on this stream
     if (t >= NSETS) UMGAP_HIP(hipStreamWaitEvent(s, S.probed, 0));          // the probe of piece t - NSETS has read its own share of send_keys
     if (t >= NPERM) UMGAP_HIP(hipStreamWaitEvent(s, sh->aggregated[t % NPERM], 0));
+    if (W == 1 && sh->local_bypass) {      // nobody to send to: every key is this rank's own and the consumer probes it where it stands
+        UMGAP_HIP(hipEventRecord(S.filled, s));
+        return UMGAP_OK;
+    }
     UMGAP_HIP(hipMemsetAsync(S.cursor, 0, W * sizeof(unsigned long long), s));
-    const size_t tile = 256 * PACK_PER_THREAD;
-    unsigned g = (unsigned)((nk + tile - 1) / tile);
+    const size_t n_runs = (nk + run_len - 1) / run_len;
+    unsigned g = (unsigned)std::min<size_t>((n_runs + 3) / 4, 256 * 8);   // persistent: a grid of short workgroups holds up the other streams' kernels (k_shard_probe)
     if (g < 1) g = 1;
-    hipLaunchKernelGGL(k_shard_pack, dim3(g), dim3(256), 0, s, d_keys, nk, T.m, T.nb, W, sh->cap, S.send_keys, sh->perm[t % NPERM], S.cursor, sh->d_overflow,
-                       sh->local_bypass ? (uint32_t)sh->comm->rank : UMGAP_NONE, sh->local_bits[t % NPERM]);
+    hipLaunchKernelGGL(k_shard_pack, dim3(g), dim3(256), 0, s, d_keys, nk, run_len, T.m, T.nb, W, (double)W / (double)T.nb, sh->cap, S.send_keys, sh->bases[t % NPERM],
+                       S.cursor, sh->d_overflow, sh->local_bypass ? (uint32_t)sh->comm->rank : wire::NO_OWNER);
     hipLaunchKernelGGL(k_shard_pad, dim3(64, W), dim3(256), 0, s, S.send_keys, S.cursor, sh->cap);
     UMGAP_HIP(hipGetLastError());
     UMGAP_HIP(hipEventRecord(S.filled, s));
@@ -484,7 +485,7 @@ int stage_probe(umgap_sharded* sh, uint64_t t, bool time_probe) {
     UMGAP_HIP(hipStreamWaitEvent(s, S.packed, 0));
     if (t >= NSETS) UMGAP_HIP(hipStreamWaitEvent(s, sh->aggregated[(t - NSETS) % NPERM], 0));
     const uint64_t n_slots = sh->cap * W;
-    const unsigned gp = (unsigned)std::min<uint64_t>((n_slots / 128 + 3) / 4, 256 * 2);
+    const unsigned gp = (unsigned)std::min<uint64_t>((n_slots / 128 + 3) / 4, 256 * 3);   // resident grid, 3 workgroups per CU (2: 33.4 ms per step, 3: 30.3, 4: 31.3, 8: 31.2)
     const uint32_t self = (uint32_t)sh->comm->rank;
     if (time_probe) UMGAP_HIP(hipEventRecord(sh->ev_probe0, s));
     if (sh->value_bytes == 3) hipLaunchKernelGGL(k_shard_probe<3>, dim3(gp), dim3(256), 0, s, T, S.recv_keys, S.send_keys, self, sh->local_bypass ? 1u : 0u, sh->cap, n_slots, S.ret_send, S.ret_recv);
@@ -505,6 +506,21 @@ int piece_back(umgap_sharded* sh, uint64_t t) {
 int piece_done(umgap_sharded* sh, uint64_t t) {
     UMGAP_HIP(hipEventRecord(sh->aggregated[t % NPERM], sh->s_agg));
     return UMGAP_OK;
+}
+
+constexpr uint32_t LOOKUP_RUN = 1024;    // keys per run of the plain get()
+
+HitSource hit_source(umgap_sharded* sh, uint64_t t, const uint64_t* d_piece_keys, uint32_t run_len) {
+    HitSource H;
+    H.ret = sh->set[t % NSETS].ret_recv;
+    H.bases = sh->bases[t % NPERM];
+    H.keys = d_piece_keys;
+    H.value_bytes = sh->value_bytes;
+    H.world = (uint32_t)sh->comm->world;
+    H.self = sh->local_bypass ? (uint32_t)sh->comm->rank : wire::NO_OWNER;
+    H.run = run_len;
+    H.cap = sh->cap;
+    return H;
 }
 
 int fork_streams(umgap_sharded* sh, hipStream_t caller) {
@@ -688,12 +704,11 @@ int umgap_sharded_create(umgap_index* shard, umgap_taxonomy* tx, umgap_comm* com
     rc = comm_max_u32(comm, &vmax);
     if (rc) { delete sh; return rc; }
     sh->value_bytes = vmax < 0xFFFFFFu ? 3 : 4;
-    // one block: per set {send keys, recv keys, values out, values back, perm, cursor}
+    // one block: per set {send keys, recv keys, values out, values back, cursor}, then the run bases (a run has at least 64 keys)
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t b_keys = pad(cap * W * 6), b_vals = pad(cap * W * 4 + 64), b_perm = pad(sh->piece_keys * 4), b_cur = pad(W * 8);
-    const size_t b_bits = pad((sh->piece_keys / 64 + 2) * 8);
+    const size_t b_keys = pad(cap * W * 6), b_vals = pad(cap * W * 4 + 64), b_bases = pad((sh->piece_keys / 64 + 2) * W * 4), b_cur = pad(W * 8);
     const size_t per_set = 2 * b_keys + 2 * b_vals + b_cur;
-    sh->block_bytes = NSETS * per_set + NPERM * (b_perm + b_bits) + 256;
+    sh->block_bytes = NSETS * per_set + NPERM * b_bases + 256;
     e = hipMalloc(&sh->block, sh->block_bytes);
     if (e != hipSuccess) { delete sh; return fail(UMGAP_ERR_NOMEM, std::string("umgap_sharded_create: hipMalloc of the exchange buffers (") + std::to_string(sh->block_bytes >> 20) + " MiB): " + hipGetErrorString(e)); }
     char* p = (char*)sh->block;
@@ -710,8 +725,7 @@ int umgap_sharded_create(umgap_index* shard, umgap_taxonomy* tx, umgap_comm* com
         }
     }
     for (int i = 0; i < NPERM; i++) {
-        sh->perm[i] = (uint32_t*)p; p += b_perm;
-        sh->local_bits[i] = (uint64_t*)p; p += b_bits;
+        sh->bases[i] = (uint32_t*)p; p += b_bases;
         if (hipEventCreateWithFlags(&sh->aggregated[i], hipEventDisableTiming) != hipSuccess) { umgap_sharded_free(sh); return fail(UMGAP_ERR_DEVICE, "umgap_sharded_create: event creation failed"); }
     }
     sh->d_overflow = (uint32_t*)p;
@@ -767,7 +781,7 @@ int umgap_sharded_lookup9_dev(umgap_sharded* sh, const uint64_t* d_keys45, size_
     sh->piece_no += np;
     auto pack_piece = [&](size_t t) -> int {
         const size_t lo = std::min(n, t * per), hi = std::min(n, (t + 1) * per);
-        int r = stage_pack(sh, first + t, d_keys45 + lo, hi - lo);
+        int r = stage_pack(sh, first + t, d_keys45 + lo, hi - lo, LOOKUP_RUN);
         return r ? r : stage_keys(sh, first + t);
     };
     for (size_t t = 0; t < std::min<size_t>(LOOK, np); t++) if ((rc = pack_piece(t))) return rc;
@@ -781,9 +795,9 @@ int umgap_sharded_lookup9_dev(umgap_sharded* sh, const uint64_t* d_keys45, size_
             const uint64_t pc = first + c;
             if ((rc = piece_back(sh, pc))) return rc;
             if (hi > lo) {
-                unsigned g = (unsigned)std::min<size_t>((hi - lo + 255) / 256, 2048);   // 4 waves x 64 keys per workgroup and step
-                hipLaunchKernelGGL(k_shard_unpermute, dim3(g), dim3(256), 0, sh->s_agg, sh->ix->view,
-                                   HitSource{sh->set[pc % NSETS].ret_recv, sh->perm[pc % NPERM], sh->value_bytes, d_keys45 + lo, sh->local_bits[pc % NPERM]}, hi - lo, miss_value, d_out_taxa + lo);
+                unsigned g = (unsigned)std::min<size_t>(((hi - lo + LOOKUP_RUN - 1) / LOOKUP_RUN + 3) / 4, 2048);   // a wave per run
+                hipLaunchKernelGGL(k_shard_unpermute, dim3(g), dim3(256), 0, sh->s_agg, sh->ix->view, hit_source(sh, pc, d_keys45 + lo, LOOKUP_RUN), hi - lo, miss_value,
+                                   d_out_taxa + lo);
                 UMGAP_HIP(hipGetLastError());
             }
             if ((rc = piece_done(sh, pc))) return rc;
@@ -829,12 +843,13 @@ int umgap_sharded_classify9_dev(umgap_sharded* sh, int method, int strategy, flo
     const size_t per = sh->piece_keys / kmers_per_read, np = sh->pieces;   // whole reads per piece
     if (per == 0) return fail(UMGAP_ERR_INVALID, "umgap_sharded_classify9_dev: a piece cannot hold one read (lower `pieces`)");
     if ((uint64_t)per * np < n_reads) return fail(UMGAP_ERR_INVALID, "umgap_sharded_classify9_dev: the reads do not fit the pieces (create the group with a max_keys_per_call that is a multiple of pieces * kmers_per_read)");
+    const uint32_t run_len = classify9_group_reads(kmers_per_read, fragments_per_read) * kmers_per_read;   // the consumer's group (classify.hip)
     if ((rc = fork_streams(sh, caller))) return rc;
     const uint64_t first = sh->piece_no;
     sh->piece_no += np;
     auto pack_piece = [&](size_t t) -> int {
         const size_t lo = std::min(n_reads, t * per), hi = std::min(n_reads, (t + 1) * per);
-        int r = stage_pack(sh, first + t, d_keys45 + lo * kmers_per_read, (hi - lo) * kmers_per_read);
+        int r = stage_pack(sh, first + t, d_keys45 + lo * kmers_per_read, (hi - lo) * kmers_per_read, run_len);
         return r ? r : stage_keys(sh, first + t);
     };
     for (size_t t = 0; t < std::min<size_t>(LOOK, np); t++) if ((rc = pack_piece(t))) return rc;
@@ -848,7 +863,7 @@ int umgap_sharded_classify9_dev(umgap_sharded* sh, int method, int strategy, flo
             const uint64_t pc = first + c;
             if ((rc = piece_back(sh, pc))) return rc;
             rc = launch_classify9_from_hits(sh->ix, sh->tx, method, strategy, factor, lower_bound, ranked_only,
-                                            HitSource{sh->set[pc % NSETS].ret_recv, sh->perm[pc % NPERM], sh->value_bytes, d_keys45 + lo * kmers_per_read, sh->local_bits[pc % NPERM]}, hi - lo, kmers_per_read,
+                                            hit_source(sh, pc, d_keys45 + lo * kmers_per_read, run_len), hi - lo, kmers_per_read,
                                             fragments_per_read, min_seed_size, max_gap_size, d_out_taxon + lo, d_out_status + lo, sh->s_agg);
             if (rc) return rc;
             if ((rc = piece_done(sh, pc))) return rc;
