@@ -145,10 +145,15 @@ int umgap_index_lookup_prot9_dev(umgap_index* ix, const uint8_t* d_bytes, const 
 
 /* ---- variable-length keys (tryptic peptides, 1..63 bytes) -------------------------------- */
 /* The same handle type; umgap_index_kind() tells 9 (packed 9-mer table) from 2 (byte-string table).
- * Key i = bytes[offsets[i] .. offsets[i+1]).  Exact match (candidates are verified byte by byte).
+ * Key i = bytes[offsets[i] .. offsets[i+1]).  Exact match.
  * Replaces fst::Map::get for the tryptic index (src/commands/pept2lca.rs:93,
- * src/commands/prot2tryp2lca.rs:130).  umgap_index_save / _open / _free work for both kinds. */
+ * src/commands/prot2tryp2lca.rs:130).  umgap_index_save / _open / _free work for both kinds.
+ * A byte-string table has one of two layouts, chosen at build time: when every key is a word over 'A'..'Z' (every tryptic
+ * index is) the keys themselves are stored in the table at 5 bits per residue, 1-3 adjacent 16-byte slots each, and a lookup is
+ * one 64-byte request, hit or miss (umgap_index_var_layout() = 1); otherwise slots point into a heap of key bytes and a
+ * candidate is verified byte by byte there (layout 0; the environment variable UMGAP_VAR_PACKED=0 forces it). */
 int umgap_index_kind(const umgap_index* ix);
+int umgap_index_var_layout(const umgap_index* ix);   /* 1 = keys in the slots, 0 = slots + heap, -1 = not a byte-string table */
 int umgap_index_build_var(const uint8_t* bytes, const uint64_t* offsets, const uint32_t* taxa, size_t n,
                           double load_factor, int device, umgap_index** out);
 int umgap_index_build_var_dev(const uint8_t* d_bytes, const uint64_t* d_offsets, const uint32_t* d_taxa, size_t n,

@@ -887,7 +887,9 @@ def _random_peptides(rng, n, lo=5, hi=50):
     return sorted(out)
 
 
-def test_var_index_matches_dict(api, tmp_path):
+@pytest.mark.parametrize("layout", ["keys in the slots", "slots + heap"])
+def test_var_index_matches_dict(api, tmp_path, layout, monkeypatch):
+    monkeypatch.setenv("UMGAP_VAR_PACKED", "1" if layout == "keys in the slots" else "0")   # read at build time
     rng = np.random.default_rng(12)
     peps = _random_peptides(rng, 120_000)
     vals = rng.integers(1, 1 << 31, len(peps)).astype(np.uint32)
@@ -895,6 +897,7 @@ def test_var_index_matches_dict(api, tmp_path):
     for load in (0.0, 0.9):       # 0.9 forces overflow chains
         ix = api.Index.build_var(peps, vals, load_factor=load)
         assert ix.kind == 2 and ix.num_keys == len(peps)
+        assert ix.var_layout == (1 if layout == "keys in the slots" else 0)
         assert (ix.lookup_var(peps) == vals).all()
         q = peps[:3000] + _random_peptides(rng, 3000) + [b"", b"A" * 64, b"K", peps[0][:-1], peps[0] + b"A", b"ACD*F", b"\xff\x00\x01"]
         want = np.array([d.get(p, 0) for p in q], np.uint32)
@@ -904,7 +907,7 @@ def test_var_index_matches_dict(api, tmp_path):
     path = tmp_path / "tryptic.umgapix"
     ix.save(path)
     ix2 = api.Index.open(path)
-    assert ix2.kind == 2 and (ix2.lookup_var(q) == want).all()
+    assert ix2.kind == 2 and ix2.var_layout == ix.var_layout and (ix2.lookup_var(q) == want).all()
     assert len(ix.lookup_var([])) == 0
     with pytest.raises(api.UmgapError):
         ix.lookup9(np.zeros(3, np.uint64))
@@ -945,6 +948,63 @@ def test_var_index_inline_keys(api, tmp_path):
     assert (api.Index.open(path).lookup_var(q) == want).all()
     with pytest.raises(api.UmgapError, match="duplicate"):
         api.Index.build_var([b"AAAAAK", b"CCCCC", b"AAAAAK"], np.array([1, 2, 3], np.uint32))
+
+
+def test_var_index_keys_in_the_slots(api, tmp_path):
+    """The packed layout (index_varp.hip): a key takes 1, 2 or 3 adjacent slots of one bucket (16 residues in the header slot, 24
+    per continuation).  Lengths around every boundary, keys that differ only in a continuation slot or only in their length
+    ('A' is residue 0, so padding and a trailing A must be told apart by the length), continuation images that are all zero,
+    queries with bytes outside 'A'..'Z' (never in such a table), full tables with overflow chains and the stash, save / open,
+    and the dump (printindex) -- against a dict."""
+    rng = np.random.default_rng(321)
+    letters = np.frombuffer(b"ABCDEFGHIKLMNPQRSTVWYZ", np.uint8)
+    keys = set()
+    for n in list(range(1, 64)):
+        for _ in range(400 if n > 3 else 15):
+            keys.add(rng.choice(letters, n).tobytes())
+    for n in (1, 15, 16, 17, 18, 39, 40, 41, 42, 62, 63):
+        keys.add(b"A" * n)
+        keys.add(b"Z" * n)
+        keys.add(b"A" * (n - 1) + b"B")
+    base = [rng.choice(letters, 63).tobytes() for _ in range(300)]
+    for k in base:                                   # families that share every slot but one
+        for cut in (16, 17, 40, 41, 63):
+            keys.add(k[:cut])
+        keys.add(k[:62] + (b"A" if k[62:] != b"A" else b"B"))
+        keys.add(k[:30] + b"A" + k[31:])
+        keys.add(k[:5] + b"A" + k[6:])
+    keys = sorted(keys)
+    vals = rng.integers(1, 1 << 32, len(keys), dtype=np.uint64).astype(np.uint32)
+    d = dict(zip(keys, vals.tolist()))
+    strangers = [rng.choice(letters, int(rng.integers(1, 64))).tobytes() for _ in range(20000)]
+    near = [k[:-1] for k in keys[:6000] if len(k) > 1] + [k + b"A" for k in keys[:6000] if len(k) < 63] + [k[:-1] + b"C" for k in keys[6000:12000]]
+    odd = [b"", b"A" * 64, b"A" * 200, b"abc", b"ACD*F", b"\xff\x00\x01", b"A" * 20 + b"*" + b"A" * 10, b"[" * 17, b"@" * 41, keys[5][:-1] + b"a"]
+    q = keys + strangers + near + odd
+    want = np.array([d.get(p, 0) for p in q], np.uint32)
+    for load in (0.0, 0.3, 0.95):
+        ix = api.Index.build_var(keys, vals, load_factor=load)
+        assert ix.var_layout == 1
+        assert (ix.lookup_var(q, miss_value=0) == want).all(), load
+        assert (ix.lookup_var(q[::-1], miss_value=7) == np.array([d.get(p, 7) for p in q[::-1]], np.uint32)).all(), load
+    path = tmp_path / "packed.umgapix"
+    ix.save(path)
+    ix2 = api.Index.open(path)
+    assert ix2.var_layout == 1 and ix2.num_keys == len(keys) and (ix2.lookup_var(q) == want).all()
+    # the dump gives every key back, once
+    from umgap_amd import _lib
+    import ctypes as C
+    n, hb = C.c_size_t(), C.c_uint64()
+    cap = len(keys) + 10
+    offs, lens, taxa = np.zeros(cap, np.uint64), np.zeros(cap, np.uint32), np.zeros(cap, np.uint32)
+    L = _lib.load()
+    _lib.check(L.umgap_index_dump_var(ix2._h, None, 0, offs.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), taxa.ctypes.data_as(C.c_void_p), cap, C.byref(n), C.byref(hb)))
+    heap = np.zeros(hb.value + 1, np.uint8)
+    _lib.check(L.umgap_index_dump_var(ix2._h, heap.ctypes.data_as(C.c_void_p), hb.value, offs.ctypes.data_as(C.c_void_p), lens.ctypes.data_as(C.c_void_p), taxa.ctypes.data_as(C.c_void_p), cap, C.byref(n), C.byref(hb)))
+    assert n.value == len(keys)
+    got = {heap[int(offs[i]):int(offs[i]) + int(lens[i])].tobytes(): int(taxa[i]) for i in range(n.value)}
+    assert got == d
+    with pytest.raises(api.UmgapError, match="duplicate"):
+        api.Index.build_var([b"AAAAAK" * 5, b"CCCCC", b"AAAAAK" * 5], np.array([1, 2, 3], np.uint32))
 
 
 def test_pept2lca_doc_example_tryptic(api):

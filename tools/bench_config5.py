@@ -59,7 +59,9 @@ t0.record()
 _lib.check(L.umgap_index_build_var_dev(_dev_ptr(data), _dev_ptr(offs), _dev_ptr(taxa), n_keys, total, 0.0, 0, C.byref(h)))
 t1.record(); torch.cuda.synchronize()
 ix = Index(h.value)
-res["heap_GB"] = round(total / 1e9, 2)
+res["layout"] = "keys in the slots (1-3 per key, no heap)" if ix.var_layout == 1 else "slots + heap"
+res["table_GB"] = round(ix.table_bytes / 1e9, 2)
+res["key_bytes_GB"] = round(total / 1e9, 2)
 res["build_s"] = round(t0.elapsed_time(t1) / 1e3, 2)
 del data, offs
 torch.cuda.empty_cache()

@@ -79,6 +79,7 @@ def load():
         "umgap_index_lookup9_lane_dev": (i32, [vp, vp, sz, u32, vp, vp]),
         "umgap_index_lookup_prot9_dev": (i32, [vp, vp, vp, vp, sz, u32, vp, vp]),
         "umgap_index_kind": (i32, [vp]),
+        "umgap_index_var_layout": (i32, [vp]),
         "umgap_index_build_var": (i32, [vp, vp, vp, sz, dbl, i32, pp]),
         "umgap_index_build_var_dev": (i32, [vp, vp, vp, sz, u64, dbl, i32, pp]),
         "umgap_index_lookup_var": (i32, [vp, vp, vp, sz, u32, vp]),

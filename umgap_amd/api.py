@@ -146,6 +146,11 @@ class Index:
     def kind(self):
         return _lib.load().umgap_index_kind(self._h)
 
+    @property
+    def var_layout(self):
+        """1: the keys live in the slots (words over 'A'..'Z'), 0: slots + heap, -1: not a byte-string table."""
+        return _lib.load().umgap_index_var_layout(self._h)
+
     def lookup_var(self, peptides, miss_value=0):
         data, offs = _concat(peptides)
         out = np.empty(len(peptides), np.uint32)

@@ -15,6 +15,7 @@
 
 namespace umgap {
 void var_free(umgap_var_index* v);
+uint64_t var_table_bytes(const umgap_var_index* v);   // slots + heap
 int var_save(const umgap_index* ix, FILE* f);
 int var_open(umgap_index* ix, const IndexFileHeader& h, FILE* f, const char* path);
 }
@@ -759,7 +760,10 @@ void umgap_index_free(umgap_index* ix) {
 
 uint64_t umgap_index_num_keys(const umgap_index* ix) { return ix ? ix->n_keys : 0; }
 uint64_t umgap_index_num_buckets(const umgap_index* ix) { return ix ? ix->view.nb : 0; }
-uint64_t umgap_index_table_bytes(const umgap_index* ix) { return ix ? (uint64_t)ix->view.n_resident * 64 : 0; }
+uint64_t umgap_index_table_bytes(const umgap_index* ix) {
+    if (!ix) return 0;
+    return ix->kind == 2 ? var_table_bytes(ix->var) : (uint64_t)ix->view.n_resident * 64;
+}
 int umgap_index_device(const umgap_index* ix) { return ix ? ix->device : -1; }
 
 int umgap_index_save(const umgap_index* ix, const char* path) {

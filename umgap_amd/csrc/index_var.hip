@@ -18,128 +18,11 @@
 #include <cmath>
 #include <vector>
 
-#include "probe_common.hpp"
+#include "var_index.hpp"
 
 using namespace umgap;
 using namespace umgap::probe;
 
-namespace umgap {
-static constexpr uint32_t VAR_SLOTS = 4, VAR_MAX_DISP = 15, VAR_MAX_LEN = 63;
-static constexpr uint64_t VAR_EMPTY = ~0ull;
-
-static constexpr uint32_t VAR_INLINE_MAX = 17;
-static constexpr uint64_t VAR_INLINE = 1ull << 63;
-
-typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
-
-// (lo, hi) of an inline key: lo = the slot's offset word (flag included; never all ones: a residue code is < 26), hi = the
-// 22 bits that go to the tag field.  `byte(i)` yields key byte i.  False: the key does not qualify.
-template <class Byte>
-__host__ __device__ inline bool pack_inline_with(Byte byte, uint32_t len, uint64_t& lo, uint32_t& hi) {
-    lo = 0;
-    hi = 0;
-    if (len > VAR_INLINE_MAX) return false;
-    uint64_t x0 = 0, x1 = 0;
-    bool ok = true;
-#pragma unroll
-    for (uint32_t i = 0; i < VAR_INLINE_MAX; i++) {
-        if (i < len) {
-            const uint32_t c = (uint32_t)byte(i) - 'A';
-            ok = ok && c < 26u;
-            const uint32_t sh = 5 * i;
-            if (sh < 64) {
-                x0 |= (uint64_t)(c & 31u) << sh;
-                if (sh > 59) x1 |= (uint64_t)(c & 31u) >> (64 - sh);
-            } else x1 |= (uint64_t)(c & 31u) << (sh - 64);
-        }
-    }
-    lo = x0 | VAR_INLINE;
-    hi = (uint32_t)((x1 << 1) | (x0 >> 63));
-    return ok;
-}
-__host__ __device__ inline bool pack_inline(const uint8_t* p, uint32_t len, uint64_t& lo, uint32_t& hi) {
-    return pack_inline_with([p](uint32_t i) { return p[i]; }, len, lo, hi);
-}
-// The same from the key's first 20 bytes as five little-endian words (bytes past `len` may hold anything): four residues per
-// word at a time -- the probe's version, ~80 VALU operations per key instead of ~170.
-__device__ __forceinline__ bool pack_inline_words(const uint32_t (&d)[5], uint32_t len, uint64_t& lo, uint32_t& hi) {
-    uint32_t u[5], bad = 0;
-#pragma unroll
-    for (int w = 0; w < 5; w++) {
-        const int nv = (int)len - 4 * w;                                     // key bytes in this word (may be <= 0 or >= 4)
-        const uint32_t mask = nv >= 4 ? 0xFFFFFFFFu : (nv <= 0 ? 0u : (0xFFFFFFFFu >> (32 - 8 * nv)));
-        const uint32_t x = d[w];
-        // a byte outside 'A'..'Z' raises its top bit in one of the three terms (a borrow or carry only travels upwards, into
-        // bytes that are then bad or masked themselves)
-        bad |= (x | (x + 0x25252525u) | ~((x | 0x80808080u) - 0x41414141u)) & 0x80808080u & mask;
-        const uint32_t c = (x - 0x41414141u) & mask;                          // four residue codes, 8 bits apart
-        const uint32_t t = (c & 0x001F001Fu) | ((c & 0x1F001F00u) >> 3);      // 10 + 10 bits, 16 bits apart
-        u[w] = (t & 0x3FFu) | ((t >> 6) & 0xFFC00u);                          // 20 bits
-    }
-    const uint64_t x0 = (uint64_t)u[0] | ((uint64_t)u[1] << 20) | ((uint64_t)u[2] << 40) | ((uint64_t)u[3] << 60);
-    const uint32_t x1 = (u[3] >> 4) | (u[4] << 16);
-    lo = x0 | VAR_INLINE;
-    hi = (x1 << 1) | (uint32_t)(x0 >> 63);
-    return bad == 0;
-}
-// the key bytes of an inline slot (word0 = tag field | len << 25 | ..., off = offset word); returns the length
-__host__ inline uint32_t unpack_inline(uint32_t word0, uint64_t off, uint8_t* out) {
-    const uint32_t len = (word0 >> 25) & 63u, hi = word0 & 0x01FFFFFFu;
-    const uint64_t x0 = (off & ~VAR_INLINE) | ((uint64_t)(hi & 1u) << 63), x1 = hi >> 1;
-    for (uint32_t i = 0; i < len && i < VAR_INLINE_MAX; i++) {
-        const uint32_t sh = 5 * i;
-        uint64_t c = sh < 64 ? (x0 >> sh) | (sh > 59 ? x1 << (64 - sh) : 0ull) : x1 >> (sh - 64);
-        out[i] = (uint8_t)('A' + (c & 31u));
-    }
-    return len;
-}
-
-// 8 bytes at a time (unaligned 64-bit loads; the last word overlaps the previous one when len is
-// not a multiple of 8), byte-wise only for keys shorter than 8
-__host__ __device__ inline uint64_t hash_bytes(const uint8_t* p, uint32_t len) {
-    uint64_t h = 0xCBF29CE484222325ull ^ ((uint64_t)len * 0x9E3779B97F4A7C15ull);
-    if (len >= 8) {
-        uint32_t i = 0;
-        for (; i + 8 <= len; i += 8) {
-            h = (h ^ *reinterpret_cast<const u64_unaligned*>(p + i)) * 0xD6E8FEB86659FD93ull;
-            h ^= h >> 29;
-        }
-        if (i < len) {
-            h = (h ^ *reinterpret_cast<const u64_unaligned*>(p + len - 8)) * 0xD6E8FEB86659FD93ull;
-            h ^= h >> 29;
-        }
-    } else {
-        for (uint32_t i = 0; i < len; i++) h = (h ^ p[i]) * 0x100000001B3ull;
-    }
-    h ^= h >> 32;
-    h *= 0xD6E8FEB86659FD93ull;
-    h ^= h >> 32;
-    return h;
-}
-}  // namespace umgap
-
-struct VarView {
-    const u32x4* slots;     // nb + VAR_MAX_DISP buckets x 4 slots
-    const uint8_t* heap;
-    uint64_t nb;
-    const uint64_t* stash_hash;  // sorted
-    const uint64_t* stash_off;
-    const uint32_t* stash_val;
-    uint32_t n_stash;
-    uint32_t inline_max;    // keys of at most this many letters live in their slot (0: none do -- tables written before round 2)
-};
-
-struct umgap_var_index {
-    u32x4* d_slots = nullptr;
-    uint8_t* d_heap = nullptr;
-    uint64_t heap_bytes = 0, nb = 0, n_keys = 0;
-    uint64_t* d_stash_hash = nullptr;
-    uint64_t* d_stash_off = nullptr;
-    uint32_t* d_stash_val = nullptr;
-    uint32_t n_stash = 0;
-    uint32_t inline_max = 0;
-    VarView view() const { return VarView{d_slots, d_heap, nb, d_stash_hash, d_stash_off, d_stash_val, n_stash, inline_max}; }
-};
 
 namespace {
 
@@ -288,19 +171,6 @@ __device__ __noinline__ void lookup_batch_global(const uint8_t* __restrict__ qby
 //      one instruction covers the whole key) and compares them with the query bytes in LDS;
 //   5. the rare rest (a second candidate in the bucket, displacement chain, stash) takes the round-1 path.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr uint32_t VAR_STAGE = 64 * VAR_MAX_LEN + 16 + 48;   // a batch's bytes + alignment slack + read-ahead of the dword window
-typedef u32x4 __attribute__((aligned(1))) u32x4_unaligned;
-
-// 32 / 64 bits of the staged bytes at byte offset s (any alignment)
-__device__ __forceinline__ uint32_t lds_load32(const uint32_t* w, uint32_t s) {
-    const uint32_t k = s >> 2;
-    return __builtin_amdgcn_alignbyte(w[k + 1], w[k], s & 3u);
-}
-__device__ __forceinline__ uint64_t lds_load64(const uint32_t* w, uint32_t s) {
-    const uint32_t k = s >> 2, sh = s & 3u;
-    const uint32_t a = w[k], b = w[k + 1], c = w[k + 2];
-    return ((uint64_t)__builtin_amdgcn_alignbyte(c, b, sh) << 32) | __builtin_amdgcn_alignbyte(b, a, sh);
-}
 // hash_bytes over staged bytes (same words in the same order)
 __device__ __forceinline__ uint64_t hash_lds(const uint32_t* w, uint32_t s, uint32_t len) {
     uint64_t h = 0xCBF29CE484222325ull ^ ((uint64_t)len * 0x9E3779B97F4A7C15ull);
@@ -458,37 +328,6 @@ __device__ __forceinline__ void var_probe_staged(const VarView& T, const uint32_
             if (k < n) out[k] = res[r];
         }
     }
-}
-
-// Where a batch's bytes go: the byte range [first, end) of the query buffer that holds its keys, from the 16-byte aligned address a0
-// on.  ok = every key lies inside it, it fits the strip and the buffer -- otherwise the batch takes the global-memory path.
-struct VarStage {
-    uint64_t a0, span;
-    bool ok;
-};
-// o / o1: the lane's key is bytes [o, o1) of the buffer (lanes past the end of the list hold an empty key); first / end: the range
-// (min_len / max_len: 1 <= min_len, max_len <= VAR_MAX_LEN; a key whose length lies outside is answered with a miss without a probe --
-// the length filter of prot2tryp2lca, src/commands/prot2tryp2lca.rs:117-120)
-__device__ __forceinline__ VarStage var_stage_plan(const uint8_t* qbytes, uint64_t all_end, uint64_t o, uint64_t o1, uint64_t first, uint64_t end,
-                                                   uint32_t force_global, uint32_t min_len, uint32_t max_len, uint32_t& meta) {
-    const uint64_t l64 = o1 - o;
-    const bool valid = o1 >= o && l64 >= min_len && l64 <= max_len;
-    const uint32_t len = valid ? (uint32_t)l64 : 0u;
-    const bool inside = !valid || (o >= first && o + len <= end);
-    VarStage S;
-    S.a0 = (uint64_t)(uintptr_t)(qbytes + first) & ~15ull;                                    // absolute, 16-byte aligned
-    S.span = end >= first ? (uint64_t)(uintptr_t)(qbytes + end) - S.a0 : ~0ull;
-    S.ok = S.span <= 64 * VAR_MAX_LEN + 16 && end <= all_end && !__any(!inside) && !force_global;
-    const uint32_t soff = S.ok ? (uint32_t)((uint64_t)(uintptr_t)(qbytes + o) - S.a0) : 0u;
-    meta = (soff & 0x1FFFu) | (len << 13) | ((valid && S.ok ? 1u : 0u) << 19);
-    return S;
-}
-// one 16-byte chunk that straddles an end of the query buffer: byte by byte, inside only
-__device__ __noinline__ u32x4 var_edge_chunk(uint64_t a, uint64_t lo_abs, uint64_t hi_abs) {
-    uint32_t wds[4] = {0u, 0u, 0u, 0u};
-    for (uint32_t t = 0; t < 16; t++)
-        if (a + t >= lo_abs && a + t < hi_abs) wds[t >> 2] |= (uint32_t)*reinterpret_cast<const uint8_t*>(a + t) << (8 * (t & 3));
-    return u32x4{wds[0], wds[1], wds[2], wds[3]};
 }
 
 // The plain kernel: offsets -> staging (aligned 16-byte loads, through registers) -> probe, one batch of 64 queries per wave and step.
@@ -658,13 +497,24 @@ inline int grid_for(size_t n, size_t per_cu = 8) {
 
 namespace umgap {
 
+// the packed format (index_varp.hip)
+int varp_scan(const uint8_t* d_bytes, const uint64_t* d_off, size_t n, hipStream_t stream, uint64_t* bad_len, uint64_t* not_az, uint64_t* slots);
+int varp_build(umgap_var_index* v, const uint8_t* d_bytes, const uint64_t* d_off, const uint32_t* d_vals, size_t n, uint64_t total_slots, double load,
+               hipStream_t stream);
+int varp_lookup_dev(const umgap_var_index* v, const uint8_t* d_bytes, const uint64_t* d_off, size_t n, uint32_t miss, uint32_t* d_out, hipStream_t s,
+                    uint32_t min_len, uint32_t max_len);
+int varp_dump(const umgap_var_index* v, uint8_t* heap_out, uint64_t heap_cap, uint64_t* offsets_out, uint32_t* lens_out, uint32_t* taxa_out, size_t cap,
+              size_t* n_out, uint64_t* heap_bytes_out);
+
 void var_free(umgap_var_index* v) {
     if (!v) return;
-    void* ptrs[] = {v->d_slots, v->d_heap, v->d_stash_hash, v->d_stash_off, v->d_stash_val};
+    void* ptrs[] = {v->d_slots, v->d_heap, v->d_stash_hash, v->d_stash_off, v->d_stash_val, v->d_pstash};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     delete v;
 }
+
+uint64_t var_table_bytes(const umgap_var_index* v) { return v ? (uint64_t)(v->nb + VAR_MAX_DISP) * 64 + v->heap_bytes : 0; }
 
 int var_set_stash(umgap_var_index* v, std::vector<std::array<uint64_t, 3>>& e) {
     if (e.empty()) return UMGAP_OK;
@@ -750,6 +600,7 @@ int var_lookup_dev(const umgap_var_index* v, const uint8_t* d_bytes, const uint6
                    uint32_t min_len, uint32_t max_len) {
     if (min_len < 1) min_len = 1;
     if (max_len > VAR_MAX_LEN) max_len = VAR_MAX_LEN;
+    if (v->packed()) return varp_lookup_dev(v, d_bytes, d_off, n, miss, d_out, s, min_len, max_len);
     // a grid of whole resident rounds (two of them): with a partial last round the kernel measured 16 % slower
     static int per_cu[2] = {0, 0};
     static int pipe = -1;
@@ -800,6 +651,7 @@ int new_var_handle(int device, umgap_index** out) {
 extern "C" {
 
 int umgap_index_kind(const umgap_index* ix) { return ix ? ix->kind : 0; }
+int umgap_index_var_layout(const umgap_index* ix) { return (ix && ix->kind == 2 && ix->var) ? (ix->var->packed() ? 1 : 0) : -1; }
 
 int umgap_index_build_var_dev(const uint8_t* d_bytes, const uint64_t* d_offsets, const uint32_t* d_taxa, size_t n, uint64_t n_bytes,
                               double load_factor, int device, umgap_index** out) {
@@ -807,6 +659,25 @@ int umgap_index_build_var_dev(const uint8_t* d_bytes, const uint64_t* d_offsets,
     umgap_index* ix = nullptr;
     int rc = new_var_handle(device, &ix);
     if (rc) return rc;
+    // Words over 'A'..'Z' (every tryptic index) take the packed format: the keys live in the table, the bytes are only read here.
+    // UMGAP_VAR_PACKED=0 keeps the legacy format (slots + heap) for them too (A/B measurements, tests of that path).
+    {
+        const char* env = getenv("UMGAP_VAR_PACKED");
+        uint64_t bad_len = 0, not_az = 0, slots = 0;
+        if (!(env && env[0] == '0') && n) {
+            rc = varp_scan(d_bytes, d_offsets, n, ix->stream, &bad_len, &not_az, &slots);
+            if (rc) { umgap_index_free(ix); return rc; }
+            if (bad_len) { umgap_index_free(ix); return fail(UMGAP_ERR_BUILD, "index build: " + std::to_string(bad_len) + " keys are empty or longer than 63 bytes"); }
+            if (!not_az) {
+                ix->var = new umgap_var_index();
+                rc = varp_build(ix->var, d_bytes, d_offsets, d_taxa, n, slots, load_factor, ix->stream);
+                if (rc) { umgap_index_free(ix); return rc; }
+                ix->n_keys = n;
+                *out = ix;
+                return UMGAP_OK;
+            }
+        }
+    }
     uint8_t* heap = nullptr;
     hipError_t e = hipMalloc((void**)&heap, n_bytes + 64);   // the probe's quad reads 16-byte pieces: up to 15 bytes past a key's end
     if (e == hipSuccess && n_bytes) e = hipMemcpyAsync(heap, d_bytes, n_bytes, hipMemcpyDeviceToDevice, ix->stream);
@@ -848,6 +719,7 @@ int umgap_index_dump_var(const umgap_index* ix, uint8_t* heap_out, uint64_t heap
     int rc = use_device(ix->device);
     if (rc) return rc;
     const umgap_var_index* v = ix->var;
+    if (v->packed()) return varp_dump(v, heap_out, heap_cap, offsets_out, lens_out, taxa_out, cap, n_out, heap_bytes_out);
     *heap_bytes_out = v->heap_bytes;
     if (heap_out && heap_cap >= v->heap_bytes && v->heap_bytes) UMGAP_HIP(hipMemcpy(heap_out, v->d_heap, v->heap_bytes, hipMemcpyDeviceToHost));
     size_t n = 0;
@@ -945,10 +817,13 @@ int var_save(const umgap_index* ix, FILE* f) {
         }
     };
     dump(v->d_slots, (size_t)(v->nb + VAR_MAX_DISP) * 64);
-    dump(v->d_heap, v->heap_bytes);
-    dump(v->d_stash_hash, (size_t)v->n_stash * 8);
-    dump(v->d_stash_off, (size_t)v->n_stash * 8);
-    dump(v->d_stash_val, (size_t)v->n_stash * 4);
+    if (v->packed()) dump(v->d_pstash, (size_t)v->n_stash * sizeof(VarpStashEntry));     // no heap: the keys are in the slots
+    else {
+        dump(v->d_heap, v->heap_bytes);
+        dump(v->d_stash_hash, (size_t)v->n_stash * 8);
+        dump(v->d_stash_off, (size_t)v->n_stash * 8);
+        dump(v->d_stash_val, (size_t)v->n_stash * 4);
+    }
     return ok ? UMGAP_OK : fail(UMGAP_ERR_IO, "error writing the index file");
 }
 
@@ -958,7 +833,7 @@ int var_open(umgap_index* ix, const IndexFileHeader& h, FILE* f, const char* pat
     ix->var = v;
     ix->kind = 2;
     v->nb = h.mix_c1; v->heap_bytes = h.mix_c2; v->n_keys = h.n_keys; v->n_stash = (uint32_t)h.n_stash;
-    if (h.m > VAR_INLINE_MAX) return fail(UMGAP_ERR_FORMAT, std::string(path) + ": unsupported UMGAPIX1 (var) inline-key length");
+    if (h.m > VAR_INLINE_MAX && h.m != VARP_INLINE_ALL) return fail(UMGAP_ERR_FORMAT, std::string(path) + ": unsupported UMGAPIX1 (var) inline-key length");
     v->inline_max = h.m;      // 0 in files written before inline keys existed: every slot points into the heap
     ix->n_keys = h.n_keys;
     const size_t chunk = 64u << 20;
@@ -974,10 +849,14 @@ int var_open(umgap_index* ix, const IndexFileHeader& h, FILE* f, const char* pat
         }
     };
     slurp((void**)&v->d_slots, (size_t)(v->nb + VAR_MAX_DISP) * 64);
-    slurp((void**)&v->d_heap, v->heap_bytes);
-    slurp((void**)&v->d_stash_hash, (size_t)v->n_stash * 8);
-    slurp((void**)&v->d_stash_off, (size_t)v->n_stash * 8);
-    slurp((void**)&v->d_stash_val, (size_t)v->n_stash * 4);
+    if (v->packed()) {
+        if (v->n_stash) slurp((void**)&v->d_pstash, (size_t)v->n_stash * sizeof(VarpStashEntry));
+    } else {
+        slurp((void**)&v->d_heap, v->heap_bytes);
+        slurp((void**)&v->d_stash_hash, (size_t)v->n_stash * 8);
+        slurp((void**)&v->d_stash_off, (size_t)v->n_stash * 8);
+        slurp((void**)&v->d_stash_val, (size_t)v->n_stash * 4);
+    }
     if (!ok) return fail(UMGAP_ERR_IO, std::string(path) + ": truncated or unreadable table");
     return UMGAP_OK;
 }
