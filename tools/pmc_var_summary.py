@@ -20,13 +20,13 @@ n_q = bench["n_queries"] if bench else None
 n_s = min(n_q, 50_000_000) if n_q else None
 acc = {}
 for path in glob.glob(os.path.join(src, "p*", "**", "*counter_collection.csv"), recursive=True):
-    rows = [r for r in csv.DictReader(open(path)) if "k_lookup_var_pipe" in r["Kernel_Name"]]
+    rows = [r for r in csv.DictReader(open(path)) if "k_lookup_var_pipe" in r["Kernel_Name"] or "k_lookup_varp" in r["Kernel_Name"]]
     by_counter = {}
     for r in rows:
         by_counter.setdefault(r["Counter_Name"], {}).setdefault(int(r["Dispatch_Id"]), []).append(float(r["Counter_Value"]))
     for c, disp in by_counter.items():
-        per = [sum(disp[d]) for d in sorted(disp)]          # launches of the pipelined kernel in order: 4 x ordered, 4 x shuffled
-        if len(per) >= 8:                                   # (the build's self check runs the plain kernel k_lookup_var)
+        per = [sum(disp[d]) for d in sorted(disp)][-8:]     # the last launches of the probe kernel, in order: 4 x ordered, 4 x shuffled
+        if len(per) >= 8:                                   # (before them: the build's self check)
             acc[c] = {"ordered": sum(per[1:4]) / 3, "shuffled": sum(per[5:8]) / 3}
 out = {"_doc": "tools/pmc_var.sh: rocprofv3 --pmc (one counter set per pass, --kernel-trace only) over tools/bench_config5.py; mean per launch of "
                "k_lookup_var for the insertion-ordered queries (%s lookups per launch) and the shuffled sample (%s)." % (n_q, n_s),

@@ -154,14 +154,20 @@ __device__ __forceinline__ bool varp_pack_lds(const uint32_t* w, uint32_t s, uin
 
 // A quad holds a bucket (lane j: slot j = e).  Does it hold the query -- header image (y, z, w), continuation images c1, c2, S slots?
 // Returns bit 0 = found (val = its taxon, quad-uniform); bits 23..30 = where the keys displaced from THIS bucket went (slot 0's marks).
+// (whole-slot compares as xor / or chains: one v_cmp per image instead of four and no scalar and-chains)
 __device__ __forceinline__ uint32_t varp_eval(u32x4 e, uint32_t qy, uint32_t qz, uint32_t qw, const uint32_t (&c1)[4], const uint32_t (&c2)[4], uint32_t S,
                                               uint32_t j, uint32_t& val) {
-    const uint32_t m0 = (e.y == qy && e.z == qz && (e.w & ~VARP_WHERE) == qw) ? 1u : 0u;        // qw carries the header mark: a continuation slot never matches
-    const uint32_t m1 = (e.x == c1[0] && e.y == c1[1] && e.z == c1[2] && e.w == c1[3]) ? 1u : 0u;
-    const uint32_t m2 = (e.x == c2[0] && e.y == c2[1] && e.z == c2[2] && e.w == c2[3]) ? 1u : 0u;
-    const uint32_t n1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m1, 0xF9, 0xF, 0xF, true);   // quad_perm [1,2,3,3]: the next slot's m1
-    const uint32_t n2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m2, 0xFE, 0xF, 0xF, true);   // quad_perm [2,3,3,3]: the slot after's m2
-    const uint32_t f = m0 & ((S < 2u) | (j < 3u ? n1 : 0u)) & ((S < 3u) | (j < 2u ? n2 : 0u));
+    uint32_t f = (((e.y ^ qy) | (e.z ^ qz) | ((e.w & ~VARP_WHERE) ^ qw)) == 0u) ? 1u : 0u;       // qw carries the header mark: a continuation slot never matches
+    if (S >= 2u) {      // quad-uniform
+        const uint32_t m1 = (((e.x ^ c1[0]) | (e.y ^ c1[1]) | (e.z ^ c1[2]) | (e.w ^ c1[3])) == 0u) ? 1u : 0u;
+        const uint32_t n1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m1, 0xF9, 0xF, 0xF, true);   // quad_perm [1,2,3,3]: the next slot's m1
+        f &= j < 3u ? n1 : 0u;
+        if (S >= 3u) {
+            const uint32_t m2 = (((e.x ^ c2[0]) | (e.y ^ c2[1]) | (e.z ^ c2[2]) | (e.w ^ c2[3])) == 0u) ? 1u : 0u;
+            const uint32_t n2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)m2, 0xFE, 0xF, 0xF, true);   // quad_perm [2,3,3,3]: the slot after's m2
+            f &= j < 2u ? n2 : 0u;
+        }
+    }
     val = quad_or(f ? e.x : 0u);
     return quad_or(f | (j == 0u ? (e.w & VARP_WHERE) : 0u));
 }
@@ -188,7 +194,7 @@ __device__ __noinline__ uint32_t varp_stash_lookup(const VarView T, uint32_t h, 
 // lane r of the caller's quad (r a compile-time constant): a DPP move, no LDS traffic, legal under quad-uniform branches
 template <int R>
 __device__ __forceinline__ uint32_t quad_bcast(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, R | (R << 2) | (R << 4) | (R << 6), 0xF, 0xF, false);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, R | (R << 2) | (R << 4) | (R << 6), 0xF, 0xF, true);   // (old = 0 + bound_ctrl: the form the compiler folds into the consuming instruction)
 }
 
 // One batch of 64 packed queries (K: the lane's own; K.q[0][1] == 0: no probe, a miss).  A quad serves the four queries of its
@@ -408,7 +414,9 @@ int varp_lookup_dev(const umgap_var_index* v, const uint8_t* d_bytes, const uint
 // Builds the packed table of `v` (slots, stash) from the caller's keys; `total_slots` from varp_scan.  The key bytes are only read.
 int varp_build(umgap_var_index* v, const uint8_t* d_bytes, const uint64_t* d_off, const uint32_t* d_vals, size_t n, uint64_t total_slots, double load,
                hipStream_t stream) {
-    if (!(load > 0.0 && load < 1.0)) load = 0.5;
+    // default fill 0.4 of the slots: entries of 1-3 slots in buckets of 4 leave holes, and past ~0.45 more keys than the stash takes
+    // find no room within VARP_MAX_DISP buckets (1 G keys of 14-45 letters: 82.5 GB of table, 7 % of the keys displaced)
+    if (!(load > 0.0 && load < 1.0)) load = 0.4;
     v->inline_max = VARP_INLINE_ALL;
     v->n_keys = n;
     VarpFlags* d_flags = nullptr;

@@ -199,24 +199,21 @@ __host__ inline uint32_t varp_unpack(const uint32_t* hdr, const uint32_t* c1, co
     return len;
 }
 // hash of a packed key (the images that are in use; the length is part of the header image).  32 bits, one 32-bit multiplication per
-// word: 64-bit multiplications are a dozen quarter-rate instructions each on this chip and the probe computes one hash per lookup.
+// two words: 64-bit multiplications are a dozen quarter-rate instructions each on this chip and the probe computes one hash per lookup.
 // The home bucket is the high half of hash x buckets (the table has fewer than 2^32 buckets).
 __host__ __device__ inline uint32_t varp_hash(const VarpKey& K) {
     const uint32_t S = varp_slots(K.q[0][1] & 63u), C1 = 0x85EBCA6Bu, C2 = 0xC2B2AE35u;
+    // two words per multiplication: the second one enters rotated into the product
+    auto rot = [](uint32_t v, int r) { return (v << r) | (v >> (32 - r)); };
     uint32_t a = (K.q[0][1] ^ 0x9E3779B9u) * C1;
-    a = ((a ^ (a >> 15)) ^ K.q[0][2]) * C2;
-    a = ((a ^ (a >> 13)) ^ K.q[0][3]) * C1;
+    a = ((a ^ (a >> 15)) ^ K.q[0][2]) * C2 + rot(K.q[0][3], 13);
     if (S >= 2) {
-        a = ((a ^ (a >> 16)) ^ K.q[1][0]) * C2;
-        a = ((a ^ (a >> 15)) ^ K.q[1][1]) * C1;
-        a = ((a ^ (a >> 13)) ^ K.q[1][2]) * C2;
-        a = ((a ^ (a >> 16)) ^ K.q[1][3]) * C1;
+        a = ((a ^ (a >> 13)) ^ K.q[1][0]) * C1 + rot(K.q[1][1], 7);
+        a = ((a ^ (a >> 16)) ^ K.q[1][2]) * C2 + rot(K.q[1][3], 19);
     }
     if (S >= 3) {
-        a = ((a ^ (a >> 15)) ^ K.q[2][0]) * C2;
-        a = ((a ^ (a >> 13)) ^ K.q[2][1]) * C1;
-        a = ((a ^ (a >> 16)) ^ K.q[2][2]) * C2;
-        a = ((a ^ (a >> 15)) ^ K.q[2][3]) * C1;
+        a = ((a ^ (a >> 15)) ^ K.q[2][0]) * C1 + rot(K.q[2][1], 11);
+        a = ((a ^ (a >> 13)) ^ K.q[2][2]) * C2 + rot(K.q[2][3], 23);
     }
     a ^= a >> 16;
     a *= C1;
