@@ -1188,7 +1188,7 @@ def test_sharded_table_local_ranks_match_whole_table(api, torch_cuda, world, pie
             assert torch.equal(got[(r, m)][0], want[(r, m)][0]), (world, r, m, "taxon")
 
 
-@pytest.mark.parametrize("world,stride,frags,pieces", [(3, 128, 0, 2), (2, 40, 2, 3), (4, 7, 0, 1), (2, 64, 64, 2), (5, 1, 0, 2)])
+@pytest.mark.parametrize("world,stride,frags,pieces", [(3, 128, 0, 2), (2, 40, 2, 3), (4, 7, 0, 1), (2, 64, 64, 2), (5, 1, 0, 2), (2, 33, 33, 1)])
 def test_sharded_runs_other_strides_and_deferred_reads(api, torch_cuda, world, stride, frags, pieces):
     """The exchange stores no per-key slot: pack and consumer walk the same RUNS of reads (the consumer's group: it depends on the
     k-mers and fragments per read) and recompute every key's slot.  Other run geometries than the benchmark's, reads with more

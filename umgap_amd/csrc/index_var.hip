@@ -835,6 +835,7 @@ int var_open(umgap_index* ix, const IndexFileHeader& h, FILE* f, const char* pat
     v->nb = h.mix_c1; v->heap_bytes = h.mix_c2; v->n_keys = h.n_keys; v->n_stash = (uint32_t)h.n_stash;
     if (h.m > VAR_INLINE_MAX && h.m != VARP_INLINE_ALL) return fail(UMGAP_ERR_FORMAT, std::string(path) + ": unsupported UMGAPIX1 (var) inline-key length");
     v->inline_max = h.m;      // 0 in files written before inline keys existed: every slot points into the heap
+    if (v->packed() && v->nb >= (1ull << 32)) return fail(UMGAP_ERR_FORMAT, std::string(path) + ": packed var table with 2^32 buckets or more");
     ix->n_keys = h.n_keys;
     const size_t chunk = 64u << 20;
     std::vector<char> buf(chunk);

@@ -306,7 +306,8 @@ __device__ __noinline__ VarpKey varp_pack_global(const uint8_t* __restrict__ qby
 // memory straight into the other LDS strip and the offsets of batch t + 2 are in flight -- with the packed probe in it.
 __global__ __launch_bounds__(256, 4) void k_lookup_varp(const uint8_t* __restrict__ qbytes, const uint64_t* __restrict__ qoff, size_t n, uint32_t miss,
                                                         uint32_t* __restrict__ out, VarView T, uint32_t min_len, uint32_t max_len) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[4][2][VAR_STAGE / 4];
+    // (+ 16 words per strip: the packer reads four words at a time as far as the LONGEST key of the wave goes, from every lane's key start)
+    __shared__ __attribute__((aligned(16))) uint32_t lds[4][2][VAR_STAGE / 4 + 16];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t step = (((size_t)gridDim.x * blockDim.x) >> 6) * 64;
@@ -428,6 +429,7 @@ int varp_build(umgap_var_index* v, const uint8_t* d_bytes, const uint64_t* d_off
         hipMalloc((void**)&d_got, std::max<size_t>(n, 1) * 4) != hipSuccess) { cleanup(); return fail(UMGAP_ERR_NOMEM, "hipMalloc(var index build)"); }
     uint64_t nb = std::max<uint64_t>(1024, (uint64_t)std::ceil((double)total_slots / (VAR_SLOTS * load)));
     for (int attempt = 0; attempt < 4; attempt++) {
+        if (nb >= (1ull << 32)) { rc = fail(UMGAP_ERR_BUILD, "index build: the packed layout holds fewer than 2^32 buckets (256 GB of table)"); break; }
         if (v->d_slots) { (void)hipFree(v->d_slots); v->d_slots = nullptr; }
         if (d_used) { (void)hipFree(d_used); d_used = nullptr; }
         const size_t nbuckets = (size_t)(nb + VAR_MAX_DISP), used_words = nbuckets / 2 + 2;

@@ -410,6 +410,7 @@ struct umgap_sharded {
     size_t block_bytes = 0;
     BufSet set[NSETS];
     uint32_t* bases[NPERM] = {};         // [run][world] first slots of a piece's runs (shard_wire.hpp)
+    uint64_t bases_runs = 0;             // runs a bases buffer holds
     hipEvent_t aggregated[NPERM] = {};   // piece using this buffer: aggregate (or un-permute) finished
     // one stream per STAGE: key exchange | pack + probe | value exchange + aggregate.  Pieces flow through them in order: the
     // probes -- each of which saturates the chip's random-request path -- run back to back with the packs between them, the
@@ -459,6 +460,7 @@ int stage_pack(umgap_sharded* sh, uint64_t t, const uint64_t* d_keys, size_t nk,
     }
     UMGAP_HIP(hipMemsetAsync(S.cursor, 0, W * sizeof(unsigned long long), s));
     const size_t n_runs = (nk + run_len - 1) / run_len;
+    if (n_runs > sh->bases_runs) return fail(UMGAP_ERR_INVALID, "sharded lookup: runs of " + std::to_string(run_len) + " k-mers do not fit the run table of this group");
     unsigned g = (unsigned)std::min<size_t>((n_runs + 3) / 4, 256 * 8);   // persistent: a grid of short workgroups holds up the other streams' kernels (k_shard_probe)
     if (g < 1) g = 1;
     hipLaunchKernelGGL(k_shard_pack, dim3(g), dim3(256), 0, s, d_keys, nk, run_len, T.m, T.nb, W, (double)W / (double)T.nb, sh->cap, S.send_keys, sh->bases[t % NPERM],
@@ -704,9 +706,11 @@ int umgap_sharded_create(umgap_index* shard, umgap_taxonomy* tx, umgap_comm* com
     rc = comm_max_u32(comm, &vmax);
     if (rc) { delete sh; return rc; }
     sh->value_bytes = vmax < 0xFFFFFFu ? 3 : 4;
-    // one block: per set {send keys, recv keys, values out, values back, cursor}, then the run bases (a run has at least 64 keys)
+    // one block: per set {send keys, recv keys, values out, values back, cursor}, then the run bases
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t b_keys = pad(cap * W * 6), b_vals = pad(cap * W * 4 + 64), b_bases = pad((sh->piece_keys / 64 + 2) * W * 4), b_cur = pad(W * 8);
+    // (the shortest run the fused kernels form is 33 k-mers: one read of 33..64 fragments of one k-mer each; stage_pack checks)
+    sh->bases_runs = sh->piece_keys / 32 + 2;
+    const size_t b_keys = pad(cap * W * 6), b_vals = pad(cap * W * 4 + 64), b_bases = pad(sh->bases_runs * W * 4), b_cur = pad(W * 8);
     const size_t per_set = 2 * b_keys + 2 * b_vals + b_cur;
     sh->block_bytes = NSETS * per_set + NPERM * b_bases + 256;
     e = hipMalloc(&sh->block, sh->block_bytes);
