@@ -294,6 +294,9 @@ void stream_lookup(FILE* in, FILE* outf, const LookupFn& lookup, bool one_on_one
     std::string held;          // formatted records [held_from, g0): the still open chunk
     size_t g0 = 0;             // global index of the block's first record
     struct Job { const char* d = nullptr; std::vector<LookupPart> parts; };
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const bool timing = getenv("UMGAP_TIMING") != nullptr;   // phase times on stderr
+    double t_read = 0, t_parse = 0, t_wait = 0, t_keys = 0, t_lookup = 0, t_format = 0, t_write = 0;
     auto stage_b = [&](Job& job) {
         const char* d = job.d;
         std::vector<LookupPart>& parts = job.parts;
@@ -316,10 +319,13 @@ void stream_lookup(FILE* in, FILE* outf, const LookupFn& lookup, bool one_on_one
         } else {
             limit = (g0 + n_rec) / chunk * chunk;   // the open chunk at the end is held back (released at EOF below)
         }
+        double t0 = now();
         keys.resize(total);
         parallel_for(used, [&](size_t i) { if (!parts[i].keys.empty()) memcpy(keys.data() + parts[i].key_base, parts[i].keys.data(), parts[i].keys.size() * 8); });
         taxa.resize(total);
+        t_keys += now() - t0; t0 = now();
         if (total) lookup(keys.data(), total, taxa.data());
+        t_lookup += now() - t0; t0 = now();
         // per part: records below `limit` go to P.out, the rest to the tail (held back)
         std::vector<std::string> tails(used);
         parallel_for(used, [&](size_t i) {
@@ -329,9 +335,11 @@ void stream_lookup(FILE* in, FILE* outf, const LookupFn& lookup, bool one_on_one
             format_lookup_part(d, taxa.data(), one_on_one, parts[i], 0, cut, parts[i].out);
             if (cut < nr && !failed) format_lookup_part(d, taxa.data(), one_on_one, parts[i], cut, nr, tails[i]);
         });
+        t_format += now() - t0; t0 = now();
         const size_t held_from = g0 / chunk * chunk;
         if (!held.empty() && limit > held_from) { fwrite(held.data(), 1, held.size(), outf); held.clear(); }
         for (size_t i = 0; i < used; i++) fwrite(parts[i].out.data(), 1, parts[i].out.size(), outf);
+        t_write += now() - t0;
         if (failed) {
             fflush(outf);
             if (parts[used - 1].panic) throw CliPanic("byte index is not a char boundary");
@@ -349,7 +357,10 @@ void stream_lookup(FILE* in, FILE* outf, const LookupFn& lookup, bool one_on_one
         if (helper_err) { std::exception_ptr e = helper_err; helper_err = nullptr; std::rethrow_exception(e); }
     };
     try {
-        while (blocks.next(d, len)) {
+        for (;;) {
+            double t0 = now();
+            if (!blocks.next(d, len)) break;
+            t_read += now() - t0; t0 = now();
             if (blocks.first_line_error()) { join_helper(); throw CliError("Expected > at beginning of fasta header."); }
             Job& J = jobs[cur];
             std::vector<size_t> cuts = split_records(d, len, T);
@@ -358,7 +369,9 @@ void stream_lookup(FILE* in, FILE* outf, const LookupFn& lookup, bool one_on_one
             J.parts.clear();
             J.parts.resize(np);
             parallel_for(np, [&](size_t i) { parse_lookup_part(d, cuts[i], cuts[i + 1], kmer_mode, k, J.parts[i]); });
+            t_parse += now() - t0; t0 = now();
             join_helper();                         // stage B of the previous block is done (and has thrown here if it failed)
+            t_wait += now() - t0;
             bool failing = false;
             for (const LookupPart& P : J.parts) failing = failing || P.bad_utf8 || P.panic;
             if (failing) { stage_b(J); continue; }  // the stream ends in this block: print what precedes the error and raise it now,
@@ -373,6 +386,8 @@ void stream_lookup(FILE* in, FILE* outf, const LookupFn& lookup, bool one_on_one
     }
     fwrite(held.data(), 1, held.size(), outf);   // EOF closes the last chunk
     fflush(outf);
+    if (timing) fprintf(stderr, "stream_lookup: stage A: read %.3f, parse %.3f, wait for stage B %.3f | stage B: gather keys %.3f, lookup %.3f, format %.3f, write %.3f\n",
+                        t_read, t_parse, t_wait, t_keys, t_lookup, t_format, t_write);
 }
 
 void stream_lookup(FILE* in, FILE* outf, umgap_index* ix, bool one_on_one, bool kmer_mode, size_t k, size_t chunk) {
