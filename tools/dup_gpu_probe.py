@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Can two RCCL ranks share ONE GPU (so that the N = 2 exchange could be rehearsed on a one-GPU box)?  No: ncclCommInitRank fails
+with "Duplicate GPU detected : rank 0 and rank 1 both on CUDA device ..." (RCCL 2.26.6, round 3).  Kept as the evidence behind
+DESIGN.md section 6: N > 1 over RCCL needs N devices; the N-rank protocol is covered on one GPU by the local transport instead.
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 tools/dup_gpu_probe.py"""
 import os, sys, torch, torch.distributed as dist
 rank=int(os.environ["RANK"]); world=int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(0)
