@@ -810,6 +810,54 @@ int umgap_index_save(const umgap_index* ix, const char* path) {
     return UMGAP_OK;
 }
 
+}  // extern "C"
+
+namespace umgap {
+// bytes [file_off, file_off + total) of `fd` -> device memory.  The ~100 GB body of a table is pulled in by several threads, each
+// with its own pinned buffer and stream: pread (page cache or NVMe queue depth) of one chunk overlaps the uploads of the others
+// (a single read-then-copy loop tops out near 4 GB/s; this runs at 45 GB/s from a warm page cache).  Pinned staging per loader
+// thread: 32 MiB for the big tables, less for small ones (pinning memory is not free and the command-line tools open an index
+// per invocation).  UMGAP_LOAD_THREADS overrides the 8 loader threads.
+bool load_file_range(int fd, off_t file_off, size_t total, void* d_dst, int device) {
+    if (!total) return true;
+    const size_t chunk = std::min<size_t>(32u << 20, std::max<size_t>(1u << 20, (total / 32 + 4095) & ~(size_t)4095));
+    const size_t n_chunks = (total + chunk - 1) / chunk;
+    std::atomic<bool> ok{true};
+    std::atomic<size_t> next{0};
+    auto work = [&]() {
+        if (hipSetDevice(device) != hipSuccess) { ok = false; return; }
+        void* pinned = nullptr;
+        hipStream_t st = nullptr;
+        if (hipHostMalloc(&pinned, chunk, hipHostMallocDefault) != hipSuccess) { ok = false; return; }
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipHostFree(pinned); ok = false; return; }
+        for (size_t c; ok && (c = next.fetch_add(1)) < n_chunks;) {
+            const size_t off = c * chunk, len = std::min(chunk, total - off);
+            size_t got = 0;
+            while (got < len) {
+                ssize_t r = pread(fd, (char*)pinned + got, len - got, file_off + (off_t)(off + got));
+                if (r <= 0) { ok = false; break; }
+                got += (size_t)r;
+            }
+            if (!ok) break;
+            if (hipMemcpyAsync((char*)d_dst + off, pinned, len, hipMemcpyHostToDevice, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) { ok = false; break; }
+        }
+        (void)hipStreamDestroy(st);
+        (void)hipHostFree(pinned);
+    };
+    unsigned n_threads = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* env = getenv("UMGAP_LOAD_THREADS")) { int v = atoi(env); if (v >= 1) n_threads = (unsigned)std::min(v, 32); }
+    n_threads = (unsigned)std::max<size_t>(1, std::min<size_t>(n_threads, n_chunks));
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < n_threads; t++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+    return ok;
+}
+}  // namespace umgap
+
+extern "C" {
+
 int umgap_index_open_shard(const char* path, uint32_t device_mask, uint32_t shard, uint32_t n_shards, umgap_index** out) {
     if (!path || !out) return fail(UMGAP_ERR_INVALID, "umgap_index_open: null argument");
     if (n_shards == 0) n_shards = 1;
@@ -852,44 +900,8 @@ int umgap_index_open_shard(const char* path, uint32_t device_mask, uint32_t shar
     // the uploads of the others (a single read-then-copy loop tops out near 4 GB/s).
     // pinned staging per loader thread: 32 MiB for the big tables, less for small ones (pinning memory is not free and
     // the command-line tools open an index per invocation)
-    const size_t body_bytes = (size_t)(hi - lo) * 64;
-    const size_t chunk = std::min<size_t>(32u << 20, std::max<size_t>(1u << 20, (body_bytes / 32 + 4095) & ~(size_t)4095));
     const int fd = fileno(f);
-    std::atomic<bool> ok{true};
-    auto load_range = [&](uint64_t first_bucket, uint64_t count, size_t dst_bucket, unsigned n_threads) {
-        const size_t total = (size_t)count * 64, n_chunks = (total + chunk - 1) / chunk;
-        const off_t base = (off_t)(sizeof(h) + first_bucket * 64);
-        std::atomic<size_t> next{0};
-        auto work = [&]() {
-            if (hipSetDevice(device) != hipSuccess) { ok = false; return; }
-            void* pinned = nullptr;
-            hipStream_t st = nullptr;
-            if (hipHostMalloc(&pinned, chunk, hipHostMallocDefault) != hipSuccess) { ok = false; return; }
-            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipHostFree(pinned); ok = false; return; }
-            for (size_t c; ok && (c = next.fetch_add(1)) < n_chunks;) {
-                const size_t off = c * chunk, len = std::min(chunk, total - off);
-                size_t got = 0;
-                while (got < len) {
-                    ssize_t r = pread(fd, (char*)pinned + got, len - got, base + (off_t)(off + got));
-                    if (r <= 0) { ok = false; break; }
-                    got += (size_t)r;
-                }
-                if (!ok) break;
-                if (hipMemcpyAsync((char*)ix->d_slots + dst_bucket * 64 + off, pinned, len, hipMemcpyHostToDevice, st) != hipSuccess ||
-                    hipStreamSynchronize(st) != hipSuccess) { ok = false; break; }
-            }
-            (void)hipStreamDestroy(st);
-            (void)hipHostFree(pinned);
-        };
-        n_threads = (unsigned)std::max<size_t>(1, std::min<size_t>(n_threads, n_chunks));
-        std::vector<std::thread> th;
-        for (unsigned t = 1; t < n_threads; t++) th.emplace_back(work);
-        work();
-        for (auto& t : th) t.join();
-    };
-    unsigned n_loaders = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
-    if (const char* env = getenv("UMGAP_LOAD_THREADS")) { int v = atoi(env); if (v >= 1) n_loaders = (unsigned)std::min(v, 32); }
-    load_range(lo, hi - lo, 0, n_loaders);
+    bool ok = load_file_range(fd, (off_t)(sizeof(h) + (uint64_t)lo * 64), (size_t)(hi - lo) * 64, ix->d_slots, device);
     {
         char halo[MAX_DISP * 64];
         for (uint32_t d = 0; ok && d < MAX_DISP; d++)

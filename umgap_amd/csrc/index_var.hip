@@ -497,6 +497,8 @@ inline int grid_for(size_t n, size_t per_cu = 8) {
 
 namespace umgap {
 
+bool load_file_range(int fd, off_t file_off, size_t total, void* d_dst, int device);   // index.hip
+
 // the packed format (index_varp.hip)
 int varp_scan(const uint8_t* d_bytes, const uint64_t* d_off, size_t n, hipStream_t stream, uint64_t* bad_len, uint64_t* not_az, uint64_t* slots);
 int varp_build(umgap_var_index* v, const uint8_t* d_bytes, const uint64_t* d_off, const uint32_t* d_vals, size_t n, uint64_t total_slots, double load,
@@ -837,17 +839,15 @@ int var_open(umgap_index* ix, const IndexFileHeader& h, FILE* f, const char* pat
     v->inline_max = h.m;      // 0 in files written before inline keys existed: every slot points into the heap
     if (v->packed() && v->nb >= (1ull << 32)) return fail(UMGAP_ERR_FORMAT, std::string(path) + ": packed var table with 2^32 buckets or more");
     ix->n_keys = h.n_keys;
-    const size_t chunk = 64u << 20;
-    std::vector<char> buf(chunk);
+    // the sections follow the header back to back; each is pulled in by the parallel loader of the 9-mer tables (index.hip)
     bool ok = true;
+    const int fd = fileno(f);
+    off_t at = (off_t)sizeof(IndexFileHeader);
     auto slurp = [&](void** d, size_t total) {
         if (!ok) return;
         if (hipMalloc(d, total + 64) != hipSuccess) { ok = false; return; }   // + 64: the heap is read in 16-byte pieces past a key's end
-        for (size_t off = 0; ok && off < total; off += chunk) {
-            size_t len = std::min(chunk, total - off);
-            if (fread(buf.data(), 1, len, f) != len) { ok = false; break; }
-            if (hipMemcpy((char*)*d + off, buf.data(), len, hipMemcpyHostToDevice) != hipSuccess) ok = false;
-        }
+        ok = load_file_range(fd, at, total, *d, ix->device);
+        at += (off_t)total;
     };
     slurp((void**)&v->d_slots, (size_t)(v->nb + VAR_MAX_DISP) * 64);
     if (v->packed()) {
