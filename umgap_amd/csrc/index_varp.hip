@@ -28,7 +28,9 @@ namespace {
 struct VarpFlags {
     unsigned long long bad_len, not_az, slots, n_stash, too_full, mismatch;
 };
-constexpr uint32_t VARP_STASH_CAP = 1u << 20;
+// stash capacity of a build: a few keys in ten thousand find no room within VARP_MAX_DISP buckets at the default fill (0.8 per
+// thousand of 1 G keys of 14-45 letters), so it grows with the table
+inline size_t varp_stash_cap(size_t n) { return std::max<size_t>((size_t)1 << 20, n / 256); }
 
 __global__ __launch_bounds__(256) void k_varp_scan(const uint8_t* __restrict__ heap, const uint64_t* __restrict__ off, size_t n, VarpFlags* flags) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void k_varp_scan(const uint8_t* __restrict__ h
 // takes a later one-slot entry).  Where a displaced key went is recorded in slot 0 of its HOME bucket (var_index.hpp).
 __global__ __launch_bounds__(256) void k_varp_insert(u32x4* __restrict__ slots, uint32_t* __restrict__ used, uint64_t nb, const uint8_t* __restrict__ heap,
                                                      const uint64_t* __restrict__ off, const uint32_t* __restrict__ vals, size_t n, VarpFlags* flags,
-                                                     VarpStashEntry* __restrict__ stash) {
+                                                     VarpStashEntry* __restrict__ stash, unsigned long long stash_cap) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t step = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += step) {
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256) void k_varp_insert(u32x4* __restrict__ slots, 
         }
         if (!placed) {
             const unsigned long long at = atomicAdd(&flags->n_stash, 1ull);
-            if (at < VARP_STASH_CAP) {
+            if (at < stash_cap) {
                 VarpStashEntry E;
                 E.hash = h;
                 E.img[0] = K.q[0][1]; E.img[1] = K.q[0][2]; E.img[2] = K.q[0][3];
@@ -425,7 +427,7 @@ int varp_build(umgap_var_index* v, const uint8_t* d_bytes, const uint64_t* d_off
     uint32_t *d_got = nullptr, *d_used = nullptr;
     int rc = UMGAP_OK;
     auto cleanup = [&]() { for (void* p : {(void*)d_flags, (void*)d_stash, (void*)d_got, (void*)d_used}) if (p) (void)hipFree(p); };
-    if (hipMalloc((void**)&d_flags, sizeof(VarpFlags)) != hipSuccess || hipMalloc((void**)&d_stash, (size_t)VARP_STASH_CAP * sizeof(VarpStashEntry)) != hipSuccess ||
+    if (hipMalloc((void**)&d_flags, sizeof(VarpFlags)) != hipSuccess || hipMalloc((void**)&d_stash, varp_stash_cap(n) * sizeof(VarpStashEntry)) != hipSuccess ||
         hipMalloc((void**)&d_got, std::max<size_t>(n, 1) * 4) != hipSuccess) { cleanup(); return fail(UMGAP_ERR_NOMEM, "hipMalloc(var index build)"); }
     uint64_t nb = std::max<uint64_t>(1024, (uint64_t)std::ceil((double)total_slots / (VAR_SLOTS * load)));
     for (int attempt = 0; attempt < 4; attempt++) {
@@ -438,7 +440,7 @@ int varp_build(umgap_var_index* v, const uint8_t* d_bytes, const uint64_t* d_off
         hipError_t e = hipMemsetAsync(v->d_slots, 0, nbuckets * 64, stream);
         if (e == hipSuccess) e = hipMemsetAsync(d_used, 0, used_words * 4, stream);
         if (e == hipSuccess) e = hipMemsetAsync(d_flags, 0, sizeof(VarpFlags), stream);
-        if (e == hipSuccess && n) hipLaunchKernelGGL(k_varp_insert, dim3(varp_grid(n, 8)), dim3(256), 0, stream, v->d_slots, d_used, nb, d_bytes, d_off, d_vals, n, d_flags, d_stash);
+        if (e == hipSuccess && n) hipLaunchKernelGGL(k_varp_insert, dim3(varp_grid(n, 8)), dim3(256), 0, stream, v->d_slots, d_used, nb, d_bytes, d_off, d_vals, n, d_flags, d_stash, (unsigned long long)varp_stash_cap(n));
         VarpFlags h{};
         if (e == hipSuccess) e = hipMemcpyAsync(&h, d_flags, sizeof(h), hipMemcpyDeviceToHost, stream);
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -465,6 +467,9 @@ int varp_build(umgap_var_index* v, const uint8_t* d_bytes, const uint64_t* d_off
             if (e != hipSuccess) { rc = fail(UMGAP_ERR_DEVICE, std::string("var index self-check: ") + hipGetErrorString(e)); break; }
             if (h.mismatch) { rc = fail(UMGAP_ERR_BUILD, "index build: duplicate keys (keys must be distinct, cf. fst::MapBuilder::insert)"); break; }
         }
+        if (getenv("UMGAP_TIMING"))
+            fprintf(stderr, "packed var table: %zu keys in %llu slots, %llu buckets (fill %.3f), %llu keys in the stash (attempt %d)\n", n,
+                    (unsigned long long)total_slots, (unsigned long long)nb, (double)total_slots / (4.0 * (double)nb), (unsigned long long)h.n_stash, attempt + 1);
         rc = UMGAP_OK;
         break;
     }
