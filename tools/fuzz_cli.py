@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle_lib as O
 
-UMGAP = os.path.join(ROOT, "umgap_amd", "bin", "umgap")
+UMGAP = os.environ.get("UMGAP_BIN") or os.path.join(ROOT, "umgap_amd", "bin", "umgap")   # UMGAP_BIN: e.g. a sanitizer build of the host code
 LETTERS = "ACDEFGHIKLMNPQRSTVWY"
 
 
