@@ -59,7 +59,9 @@ def run(n_keys=1_000_000_000, n_pairs=10_000_000, steps=3, workload=None):
     _lib.check(L.umgap_index_build_var_dev(_dev_ptr(data), _dev_ptr(offs), _dev_ptr(taxa), n_keys, total, 0.0, 0, C.byref(h)))
     ix = Index(h.value)
     torch.cuda.synchronize()
-    res["heap_GB"] = round(total / 1e9, 2)
+    res["index_layout"] = "keys in the slots (no heap)" if ix.var_layout == 1 else "slots + heap"
+    res["key_bytes_GB"] = round(total / 1e9, 2)
+    res["table_GB"] = round(ix.table_bytes / 1e9, 2)
     res["setup_s"] = round(time.perf_counter() - t0, 1)
     del data, offs, taxa
     torch.cuda.empty_cache()
