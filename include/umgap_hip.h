@@ -144,7 +144,7 @@ int umgap_index_lookup_prot9_dev(umgap_index* ix, const uint8_t* d_bytes, const 
                                  uint32_t* d_out_taxa, void* stream);
 
 /* ---- variable-length keys (tryptic peptides, 1..63 bytes) -------------------------------- */
-/* The same handle type; umgap_index_kind() tells 9 (packed 9-mer table) from 2 (byte-string table).
+/* The same handle type; umgap_index_kind() tells 9 (packed 9-mer table) from 2 (byte-string table) and 10 (9-mer table in walk order).
  * Key i = bytes[offsets[i] .. offsets[i+1]).  Exact match.
  * Replaces fst::Map::get for the tryptic index (src/commands/pept2lca.rs:93,
  * src/commands/prot2tryp2lca.rs:130).  umgap_index_save / _open / _free work for both kinds.
@@ -406,6 +406,20 @@ int umgap_synth_tryptic_dev(const uint64_t* d_ids, uint64_t first, size_t n, uin
 int umgap_index_build_windows9_dev(const uint8_t* d_bytes, const uint64_t* d_offsets, const uint32_t* d_taxa,
                                    size_t n_fragments, uint32_t max_fragment_len, uint64_t expected_keys,
                                    double load_factor, int device, umgap_index** out);
+/* The same index in WALK order (round 3; umgap_index_kind() = 10).  Consecutive 9-mers of a protein share eight residues, but a
+ * hash table sends each to a bucket of its own: one 64-byte request per window.  Built from the proteome itself -- fragments in
+ * the order given, as umgap_index_build_windows9_dev takes them, same values (smallest taxon on duplicate 9-mers) -- the table
+ * maps a 9-mer to the number of the first window that holds it and a walk array keeps, per window of the proteome, the taxon
+ * beside the low key bits and a "continues the previous window" flag.  A run of read windows that follows the proteome is then
+ * answered by one probe plus the few sectors of the walk array behind the position it returned, each step verified (exact: the
+ * key of an entry is determined by its predecessor's); where the read leaves the walk the next window is probed again.
+ * Served by umgap_classify_prot9[_strategy]_dev (walking), umgap_index_lookup_prot9_dev and umgap_index_lookup9_dev (position
+ * from the table, taxon from the walk array); the other entry points want a kind-9 table.  Fewer than 2^32 - 1 windows.
+ * Measured (tools/bench_surface_b.py --walk, 2.1 G-key proteome index): reads that are proteome fragments with 0 / 1 / 3 / 6 % of
+ * their residues changed classify 2.3 / 2.1 / 1.5 / 1.2 times as fast as over the plain table; at 20 % the plain table is faster. */
+int umgap_index_build_walk9_dev(const uint8_t* d_bytes, const uint64_t* d_offsets, const uint32_t* d_taxa,
+                                size_t n_fragments, uint32_t max_fragment_len, uint64_t expected_keys,
+                                double load_factor, int device, umgap_index** out);
 int umgap_synth_prot_reads_dev(const uint8_t* d_proteome, uint64_t n_proteome_fragments, uint32_t fragment_len,
                                uint64_t seed, uint64_t first_read, size_t n_reads, uint32_t fragments_per_read,
                                uint32_t mutations_per_mille, uint8_t* d_out, int device, void* stream);

@@ -1054,6 +1054,8 @@ def test_lookup_prot9_dev_matches_windows(api, torch_cuda):
         if n and rng.random() < 0.2:
             p[int(rng.integers(0, n))] = ord("*")
         peps.append(bytes(p))
+        if rng.random() < 0.01:
+            peps += [b""] * int(rng.integers(60, 300)) + [b"ACDEFG"] * 5     # long runs of peptides without a window (window_locate.hpp's long way)
     data, offs = api._concat(peps)
     out_offs = np.zeros(len(peps) + 1, np.uint64)
     out_offs[1:] = np.cumsum([max(0, len(p) - 8) for p in peps])
@@ -1454,6 +1456,115 @@ def test_fused_classify_prot9_vs_oracle(api, torch_cuda, with_seedextend, mode):
     torch.cuda.synchronize()
     ix.unbind(w.taxonomy)
     assert torch.equal(d_t, d_t2) and torch.equal(d_s, d_s2)
+
+
+@pytest.mark.parametrize("mutations_per_mille", [0, 30, 250])
+def test_walk_index_matches_plain_table(api, torch_cuda, mutations_per_mille):
+    """The 9-mer index in walk order (umgap_index_build_walk9_dev, index_walk.hip): same proteome, same values as the plain table
+    (umgap_index_build_windows9_dev: smallest taxon on duplicate 9-mers), so every answer must be bit-identical -- get() of packed
+    9-mers, the windows of protein fragments, and the fused surface-B pipeline for every strategy, with and without seedextend --
+    on reads that follow the proteome exactly, that deviate from it (every break re-anchors the walk), and that hardly match at
+    all.  The proteome has fragments of every length (shorter than 9, with '*' and lower-case bytes inside) and whole fragments
+    repeated under another taxon (duplicate 9-mers: the walk position is the first occurrence, the value the smallest taxon)."""
+    torch = torch_cuda
+    import ctypes as C
+    from umgap_amd import _lib
+    from umgap_amd.api import Index, _dev_ptr, _stream_ptr
+    from umgap_amd.synth import SyntheticWorkload
+    L = _lib.load()
+    rng = np.random.default_rng(5 + mutations_per_mille)
+    letters = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    w = SyntheticWorkload(n_tax=4000, n_keys=1000, build_index=False)
+    # proteome: ragged fragments, some odd bytes, some repeated
+    frags = []
+    for i in range(30_000):
+        n = int(rng.choice([0, 3, 8, 9, 10, 25, 50, 50, 50, 73, 120]))
+        f = bytearray(rng.choice(letters, n).tobytes())
+        if n > 12 and rng.random() < 0.05:
+            f[int(rng.integers(0, n))] = int(rng.choice([42, 88 + 32, 64]))      # '*', 'x', '@'
+        frags.append(bytes(f))
+    frags += [frags[int(i)] for i in rng.integers(0, len(frags), 3000)]            # duplicates, other taxa below
+    n_frag = len(frags)
+    pdata = np.frombuffer(b"".join(frags), np.uint8)
+    poffs = np.zeros(n_frag + 1, np.int64)
+    poffs[1:] = np.cumsum([len(f) for f in frags])
+    ptaxa = rng.choice(w.ids, n_frag).astype(np.uint32)
+    d_p = torch.from_numpy(pdata.copy()).cuda()
+    d_po = torch.from_numpy(poffs).cuda()
+    d_pt = torch.from_numpy(ptaxa.view(np.int32)).cuda()
+    max_len = max(len(f) for f in frags)
+    n_win = int(sum(max(0, len(f) - 8) for f in frags))
+    hp, hw = C.c_void_p(), C.c_void_p()
+    _lib.check(L.umgap_index_build_windows9_dev(_dev_ptr(d_p), _dev_ptr(d_po), _dev_ptr(d_pt), n_frag, max_len, n_win, 0.0, 0, C.byref(hp)))
+    _lib.check(L.umgap_index_build_walk9_dev(_dev_ptr(d_p), _dev_ptr(d_po), _dev_ptr(d_pt), n_frag, max_len, n_win, 0.0, 0, C.byref(hw)))
+    plain, walk = Index(hp.value), Index(hw.value)
+    assert plain.kind == 9 and walk.kind == 10 and walk.num_keys == plain.num_keys
+    # reads: mutated copies of the 50-residue fragments, plus ragged reads cut from the proteome and random ones
+    long_ids = np.array([i for i, f in enumerate(frags) if len(f) == 50 and all(65 <= c <= 90 for c in f)], np.int64)
+    n_reads, F = 3000, 2
+    rfr = []
+    for r in range(n_reads * F):
+        c = rng.random()
+        if c < 0.7:
+            f = bytearray(frags[int(rng.choice(long_ids))])
+            for k in range(len(f)):
+                if rng.random() * 1000 < mutations_per_mille:
+                    f[k] = int(rng.choice(letters))
+            a, b = (0, len(f)) if rng.random() < 0.6 else sorted(rng.integers(0, len(f) + 1, 2).tolist())
+            rfr.append(bytes(f[a:b]))
+        elif c < 0.85:
+            src = frags[int(rng.integers(0, n_frag))]
+            rfr.append(src[:int(rng.integers(0, min(len(src), 60) + 1))])
+        else:
+            rfr.append(rng.choice(letters, int(rng.integers(0, 40))).tobytes())
+    rdata = np.frombuffer(b"".join(rfr) + b"A", np.uint8)[:-1]
+    roffs = np.zeros(len(rfr) + 1, np.int64)
+    roffs[1:] = np.cumsum([len(f) for f in rfr])
+    d_r = torch.from_numpy(rdata.copy()).cuda() if len(rdata) else torch.empty(0, dtype=torch.uint8, device="cuda")
+    d_ro = torch.from_numpy(roffs).cuda()
+    # windows of the reads through both tables
+    ooffs = np.zeros(len(rfr) + 1, np.int64)
+    ooffs[1:] = np.cumsum([max(0, len(f) - 8) for f in rfr])
+    d_oo = torch.from_numpy(ooffs).cuda()
+    h0 = torch.full((int(ooffs[-1]),), -3, dtype=torch.int32, device="cuda")
+    h1 = torch.full_like(h0, -5)
+    plain.lookup_prot9_dev(d_r, d_ro, d_oo, h0, miss_value=0)
+    walk.lookup_prot9_dev(d_r, d_ro, d_oo, h1, miss_value=0)
+    torch.cuda.synchronize()
+    assert torch.equal(h0, h1)
+    if mutations_per_mille == 0:
+        assert (h0 != 0).float().mean().item() > 0.5
+    # packed 9-mers
+    keys = np.unique(rng.integers(0, 1 << 45, 5000, dtype=np.uint64))
+    pk = []
+    for f in frags[:400]:
+        for i in range(max(0, len(f) - 8)):
+            k, ok = 0, True
+            for c in f[i:i + 9]:
+                ok = ok and 65 <= c <= 90
+                k = (k << 5) | ((c - 65) & 31)
+            if ok:
+                pk.append(k)
+    q = torch.from_numpy(np.concatenate([keys, np.array(pk, np.uint64)]).view(np.int64)).cuda()
+    assert torch.equal(plain.lookup9_dev(q, miss_value=7), walk.lookup9_dev(q, miss_value=7))
+    # the fused pipeline
+    for method, strategy, lb, se in (("tree", "lca*", 2.0, False), ("tree", "lca*", 1.0, True), ("rmq", "lca*", 0.0, False), ("tree", "hybrid", 1.0, True),
+                                     ("rmq", "mrtl", 1.0, False), ("rmq", "hybrid", 0.0, True)):
+        outs = []
+        for ix in (plain, walk):
+            t = torch.full((n_reads,), -1, dtype=torch.int32, device="cuda")
+            st = torch.full_like(t, -1)
+            api.classify_prot9_dev(ix, w.taxonomy, d_r, d_ro, n_reads, F, t, st, method=method, strategy=strategy, factor=0.25, lower_bound=lb,
+                                   seedextend=se, min_seed_size=2, max_gap_size=1)
+            outs.append((t, st))
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0][1], outs[1][1]), (method, strategy, "status")
+        assert torch.equal(outs[0][0], outs[1][0]), (method, strategy, "taxon")
+    # entry points that want a plain table say so
+    with pytest.raises(api.UmgapError):
+        api.classify9_dev(walk, w.taxonomy, q[:84], 1, 84, torch.empty(1, dtype=torch.int32, device="cuda"), torch.empty(1, dtype=torch.int32, device="cuda"))
+    with pytest.raises(api.UmgapError):
+        walk.bind(w.taxonomy)
 
 
 def test_classify_prot9_ragged_fragments(api, torch_cuda):

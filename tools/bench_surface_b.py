@@ -2,8 +2,10 @@
 """Surface B of the 9-mer high-precision path: the reads arrive as protein
 fragments (2 x 50 residues per pair, 100 B instead of 672 B of packed k-mers) and ONE kernel does
 LDS-staged k-mer packing -> probe -> [seedextend -g1 -s3] -> taxa2agg -l2 -a lca*.
-The index holds every 9-mer of a synthetic proteome (n_frag fragments of 50 residues).
-Prints one JSON line."""
+The index holds every 9-mer of a synthetic proteome (n_frag fragments of 50 residues); reads are proteome fragments with
+`mutations_per_mille` of their residues replaced.  --walk builds the same index in walk order (umgap_index_build_walk9_dev) and
+checks its answers bit for bit against the plain table's on the first batch.  Prints one JSON line.
+    python tools/bench_surface_b.py [n_proteome_fragments] [n_pairs] [mutations_per_mille] [--walk]"""
 import ctypes as C
 import json
 import os
@@ -16,8 +18,11 @@ import torch
 from umgap_amd import _lib, synth
 from umgap_amd.api import Index, _dev_ptr, _stream_ptr, classify_prot9_dev
 
-n_frag = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000_000
-n_pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
+WALK = "--walk" in sys.argv
+argv = [a for a in sys.argv[1:] if not a.startswith("--")]
+n_frag = int(argv[0]) if len(argv) > 0 else 100_000_000
+n_pairs = int(argv[1]) if len(argv) > 1 else 10_000_000
+mut = int(argv[2]) if len(argv) > 2 else 30
 flen, F, steps = 50, 2, 5
 L = _lib.load()
 dev = torch.device("cuda", 0)
@@ -32,30 +37,51 @@ _lib.check(L.umgap_index_build_windows9_dev(_dev_ptr(prot), _dev_ptr(offs), _dev
 ix = Index(h.value)
 torch.cuda.synchronize()
 setup = time.perf_counter() - t0
+wx = None
+if WALK:
+    t0 = time.perf_counter()
+    hw = C.c_void_p()
+    _lib.check(L.umgap_index_build_walk9_dev(_dev_ptr(prot), _dev_ptr(offs), _dev_ptr(taxa), n_frag, flen, n_frag * (flen - 8), 0.5, 0, C.byref(hw)))
+    wx = Index(hw.value)
+    torch.cuda.synchronize()
+    walk_setup = time.perf_counter() - t0
 del offs, taxa
 batches = []
 for b in range(steps):
     r = torch.empty(n_pairs * F * flen, dtype=torch.uint8, device=dev)
-    _lib.check(L.umgap_synth_prot_reads_dev(_dev_ptr(prot), n_frag, flen, 44, b * n_pairs, n_pairs, F, 30, _dev_ptr(r), 0, _stream_ptr(None)))
+    _lib.check(L.umgap_synth_prot_reads_dev(_dev_ptr(prot), n_frag, flen, 44, b * n_pairs, n_pairs, F, mut, _dev_ptr(r), 0, _stream_ptr(None)))
     batches.append(r)
 roffs = torch.arange(0, (n_pairs * F + 1) * flen, flen, dtype=torch.int64, device=dev)
 d_t = torch.empty(n_pairs, dtype=torch.int32, device=dev)
 d_s = torch.empty_like(d_t)
 res = {"n_proteome_fragments": n_frag, "index_keys": n_frag * (flen - 8), "table_GB": round(ix.table_bytes / 1e9, 2), "pairs_per_step": n_pairs,
-       "input_bytes_per_pair": F * flen + (F * 8), "setup_s": round(setup, 1)}
-ix.bind(w.taxonomy)     # values = preorder interval codes: the aggregate stage gathers nothing by id
-res["table_bound_to_taxonomy"] = True
+       "input_bytes_per_pair": F * flen + (F * 8), "setup_s": round(setup, 1), "mutations_per_mille": mut}
+if WALK:
+    # reference answers of the plain table (unbound) for the first batch, every leg
+    res.update({"layout": "walk order: table of window numbers + walk array (umgap_index_build_walk9_dev)", "walk_setup_s": round(walk_setup, 1),
+                "walk_table_GB": round(wx.table_bytes / 1e9, 2), "walk_array_GB": round(n_frag * (flen - 8) * 8 / 1e9, 2)})
+else:
+    ix.bind(w.taxonomy)     # values = preorder interval codes: the aggregate stage gathers nothing by id
+    res["table_bound_to_taxonomy"] = True
 # the 9-mer presets of scripts/umgap-analyse.sh:277-310: lca* -l2 (with / without seedextend), then the hybrid and MRTL ones
 legs = (("classify_prot9", False, "tree", "lca*", 2.0), ("classify_prot9_seedextend", True, "tree", "lca*", 2.0),
         ("classify_prot9_seedextend_hybrid", True, "rmq", "hybrid", 1.0), ("classify_prot9_mrtl", False, "rmq", "mrtl", 1.0))
+use = wx if WALK else ix
 for name, se, method, strategy, lb in legs:
     kw = dict(method=method, strategy=strategy, factor=0.25, lower_bound=lb, seedextend=se, min_seed_size=3, max_gap_size=1)
-    classify_prot9_dev(ix, w.taxonomy, batches[0], roffs, n_pairs, F, d_t, d_s, **kw)
+    same = None
+    if WALK:
+        t0_, s0_ = torch.empty_like(d_t), torch.empty_like(d_s)
+        classify_prot9_dev(ix, w.taxonomy, batches[0], roffs, n_pairs, F, t0_, s0_, **kw)
+    classify_prot9_dev(use, w.taxonomy, batches[0], roffs, n_pairs, F, d_t, d_s, **kw)
     torch.cuda.synchronize()
+    if WALK:
+        same = bool(torch.equal(t0_, d_t) and torch.equal(s0_, d_s))
+        del t0_, s0_
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for i in range(steps):
-        classify_prot9_dev(ix, w.taxonomy, batches[i], roffs, n_pairs, F, d_t, d_s, **kw)
+        classify_prot9_dev(use, w.taxonomy, batches[i], roffs, n_pairs, F, d_t, d_s, **kw)
     b.record()
     torch.cuda.synchronize()
     ms = a.elapsed_time(b) / steps
@@ -63,6 +89,8 @@ for name, se, method, strategy, lb in legs:
     res[name] = {"pairs_per_s": round(n_pairs / ms * 1e3, 1), "ms_per_step": round(ms, 3), "G_lookups_per_s": round(n_pairs * 84 / ms / 1e6, 2),
                  "status_ok_frac": round(float((st == 0).float().mean()), 3), "status_empty_frac": round(float((st == 1).float().mean()), 3),
                  "status_unsupported_frac": round(float((st == 4).float().mean()), 5)}
+    if same is not None:
+        res[name]["bit_identical_to_plain_table"] = same
 # host-fed estimate: PCIe Gen5 x16 (~50 GB/s achievable) on 116 B per pair in + 8 B out
 res["pcie_bound_pairs_per_s_at_50GBps"] = round(50e9 / (res["input_bytes_per_pair"] + 8), 1)
 print(json.dumps(res))

@@ -348,11 +348,20 @@ struct ProtScratch<true> {
 
 // GENERAL = false: LCA* (the kernel of umgap_classify_prot9_dev, 4 workgroups per CU; 3 for GENERAL).  GENERAL = true: MRTL and the hybrids
 // through general_group -- the reads of a group sit at a fixed stride of 128 in the strip instead of back to back.
-template <bool BOUND, bool GENERAL>
+// WALK (a kind-10 index, index_walk.hip): the table's values are window numbers of the proteome and the taxa live in the walk array E.
+// A lane's run of consecutive windows is then answered by ONE probe -- its first window -- plus the entries E[p + 1 ..] behind the
+// position p the probe returned, as long as each entry continues its predecessor and carries the window's low key bits (by
+// induction its key equals the window's: exact); where the chain breaks, that window is probed and the walk goes on from there.
+struct WalkView {
+    const uint64_t* E = nullptr;   // taxon | (low 31 key bits | continues << 31) << 32
+    uint64_t n = 0;
+};
+
+template <bool BOUND, bool GENERAL, bool WALK>
 __global__ __launch_bounds__(256, GENERAL ? 3 : 4) void k_classify_prot9(TableView T, TaxView V, int method, int strategy, float factor,
                                                                       const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ foff, size_t n_reads,
                                                                       uint32_t F, uint32_t do_seed, uint32_t min_seed, uint32_t max_gap, float lower_bound,
-                                                                      uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status) {
+                                                                      uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status, WalkView WK) {
     __shared__ uint32_t lds_taxa[4][STRIP];
     __shared__ ProtScratch<GENERAL> lds_scratch[4];
     __shared__ uint32_t lds_fstart[4][64], lds_fwin[4][64], lds_fbyte[4][64], lds_total[4][PROT_GROUP];
@@ -461,42 +470,157 @@ __global__ __launch_bounds__(256, GENERAL ? 3 : 4) void k_classify_prot9(TableVi
             for (uint32_t i = 0; i < STRIP; i += 64) wtaxa[i + lane] = 0u;
             wave_lds_sync();
         }
-        for (uint32_t t = 0; t < R; t += 2) {
-            ProbeBatch B[2];
-            uint32_t pr[2][4];
-            const bool two = t + 1 < R;
+        if constexpr (WALK) {
+            // ---- phase 1: the first window of every run is its ANCHOR: one quad-probe batch (lane = key), then the walk ----
+            uint32_t done_n = 0;                                   // windows [0, done_n) of the run have their answer in the strip
+            {
+                uint64_t akey = 0;
+                uint32_t apoison = 0;
+                if (run_cnt) {
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                if (h == 1 && !two) { probe_skip(B[1]); break; }   // wave-uniform
-                const uint32_t tt = t + h;
-                const bool active = tt < run_cnt;
+                    for (int c9 = 0; c9 < 9; c9++) {
+                        const uint32_t code = (uint32_t)wbytes[bo + c9] - 'A';
+                        if (code >= 26u) apoison = c9 + 1;        // that many windows, this one included, hold the byte
+                        akey = (akey << 5) | (code & 31u);
+                    }
+                }
                 uint32_t valid = 0, loc = 0, tg = 0;
-                if (tt == 0) {            // wave-uniform: the first window of every run is read whole
-                    if (active) {
+                if (run_cnt && apoison == 0) valid = locate(T, akey, loc, tg) ? 1u : 0u;
+                ProbeBatch B;
+                uint32_t pr[4];
+                probe_issue(T, loc, tg | (valid << 31), lane, B);
+                probe_eval(T, B, NONE, lane, pr);
+                // the answer to lane L's key sits, quad-uniform, in quad L & 15 as round L >> 4
+                const int src = 4 * (int)(lane & 15u);
+                const uint32_t v0 = (uint32_t)__shfl((int)pr[0], src, 64), v1 = (uint32_t)__shfl((int)pr[1], src, 64),
+                               v2 = (uint32_t)__shfl((int)pr[2], src, 64), v3 = (uint32_t)__shfl((int)pr[3], src, 64);
+                const uint32_t r4 = lane >> 4;
+                const uint32_t pos = r4 == 0 ? v0 : (r4 == 1 ? v1 : (r4 == 2 ? v2 : v3));
+                if (run_cnt) {
+                    if (!valid || pos == NONE || pos >= WK.n) { wtaxa[sb] = 0u; done_n = 1; }   // the anchor is not in the table: no hit
+                    else {
+                        // the walk: entries pos, pos + 1, ... four at a time (consecutive: the next four mostly lie in a sector already fetched),
+                        // each verified against the rolling key
+                        uint64_t wkey = akey;
+                        uint32_t wpoison = 0;
+                        bool go = true;
+                        for (uint32_t c0 = 0; go && c0 < run_cnt; c0 += 4) {
+                            uint64_t e[4];
 #pragma unroll
-                        for (int c9 = 0; c9 < 9; c9++) {
-                            const uint32_t code = (uint32_t)wbytes[bo + c9] - 'A';
-                            if (code >= 26u) poison = c9 + 1;             // that many windows, this one included, hold the byte
-                            key = (key << 5) | (code & 31u);
+                            for (uint32_t k = 0; k < 4; k++) e[k] = (c0 + k < run_cnt && (uint64_t)pos + c0 + k < WK.n) ? WK.E[(uint64_t)pos + c0 + k] : 0x7FFFFFFF00000000ull;   // (past the end: low bits that match no window)
+#pragma unroll
+                            for (uint32_t k = 0; k < 4; k++) {
+                                const uint32_t t = c0 + k;
+                                if (go && t < run_cnt) {
+                                    bool ok = true;
+                                    if (t) {                       // the next residue enters, the oldest leaves
+                                        const uint32_t code = (uint32_t)wbytes[bo + t + 8] - 'A';
+                                        wkey = ((wkey << 5) | (code & 31u)) & MASK45;
+                                        wpoison = code >= 26u ? 9u : (wpoison ? wpoison - 1u : 0u);
+                                        const uint32_t ey = (uint32_t)(e[k] >> 32);
+                                        ok = wpoison == 0 && (ey >> 31) && (ey & 0x7FFFFFFFu) == ((uint32_t)wkey & 0x7FFFFFFFu);
+                                    }
+                                    if (ok) { wtaxa[sb + t] = (uint32_t)e[k]; done_n = t + 1; }
+                                    else go = false;
+                                }
+                            }
                         }
                     }
-                } else if (active) {      // the next residue enters, the oldest leaves
-                    const uint32_t code = (uint32_t)wbytes[bo + tt + 8] - 'A';
-                    key = ((key << 5) | (code & 31u)) & MASK45;
-                    poison = code >= 26u ? 9u : (poison ? poison - 1u : 0u);
                 }
-                if (active && poison == 0) valid = locate(T, key, loc, tg) ? 1u : 0u;
-                probe_issue(T, loc, tg | (valid << 31), lane, B[h]);
             }
-            probe_eval_multi<2>(T, B, 0u, lane, pr);
-            // the result of round x belongs to the window of lane 16x + q: fetch its strip position (every lane shuffles)
+            // ---- phase 2: what the walks did not reach is probed window by window, two batches in flight (the loop of the plain table with
+            // most lanes idle), from the first step at which some lane still lacks an answer; a hit takes its taxon from the walk array ----
+            uint32_t t0 = wave_min(done_n < run_cnt ? done_n : 0xFFFFu);
+            if (t0 < R) {                                            // wave-uniform
+                t0 &= ~1u;
+                for (uint32_t t = t0; t < R; t += 2) {
+                    const bool two = t + 1 < R;
+                    ProbeBatch B[2];
+                    uint32_t pr[2][4];
+                    bool mine[2] = {false, false};
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const uint32_t sidx = (t + h < run_cnt) ? sb + t + h : NONE;
+                    for (int h = 0; h < 2; h++) {
+                        if (h == 1 && !two) { probe_skip(B[1]); break; }   // wave-uniform
+                        const uint32_t tt = t + h;
+                        const bool active = tt < run_cnt;
+                        uint32_t valid = 0, loc = 0, tg = 0;
+                        if (tt == t0) {           // wave-uniform: the first window looked at is read whole
+                            if (active) {
+                                key = 0;
+                                poison = 0;
 #pragma unroll
-                for (int x = 0; x < 4; x++) {
-                    const uint32_t dst = (uint32_t)__shfl((int)sidx, 16 * x + (int)q, 64);
-                    if (j == 0 && dst != NONE && (h == 0 || two)) wtaxa[dst] = pr[h][x];
+                                for (int c9 = 0; c9 < 9; c9++) {
+                                    const uint32_t code = (uint32_t)wbytes[bo + tt + c9] - 'A';
+                                    if (code >= 26u) poison = c9 + 1;
+                                    key = (key << 5) | (code & 31u);
+                                }
+                            }
+                        } else if (active) {
+                            const uint32_t code = (uint32_t)wbytes[bo + tt + 8] - 'A';
+                            key = ((key << 5) | (code & 31u)) & MASK45;
+                            poison = code >= 26u ? 9u : (poison ? poison - 1u : 0u);
+                        }
+                        mine[h] = active && tt >= done_n;
+                        if (mine[h] && poison == 0) valid = locate(T, key, loc, tg) ? 1u : 0u;
+                        probe_issue(T, loc, tg | (valid << 31), lane, B[h]);
+                    }
+                    if (!__any(mine[0] || mine[1])) continue;       // wave-uniform: every window of this pair of steps has its answer
+                    probe_eval_multi<2>(T, B, NONE, lane, pr);
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const uint32_t sidx = mine[h] ? sb + t + h : NONE;
+                        uint32_t dsts[4];
+                        uint64_t ev[4];
+#pragma unroll
+                        for (int x = 0; x < 4; x++) {
+                            dsts[x] = (uint32_t)__shfl((int)sidx, 16 * x + (int)q, 64);
+                            ev[x] = 0ull;
+                            if (j == 0 && dsts[x] != NONE && pr[h][x] != NONE && pr[h][x] < WK.n) ev[x] = WK.E[pr[h][x]];
+                        }
+#pragma unroll
+                        for (int x = 0; x < 4; x++)
+                            if (j == 0 && dsts[x] != NONE && (h == 0 || two)) wtaxa[dsts[x]] = (uint32_t)ev[x];
+                    }
+                }
+            }
+        } else {
+            for (uint32_t t = 0; t < R; t += 2) {
+                ProbeBatch B[2];
+                uint32_t pr[2][4];
+                const bool two = t + 1 < R;
+    #pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    if (h == 1 && !two) { probe_skip(B[1]); break; }   // wave-uniform
+                    const uint32_t tt = t + h;
+                    const bool active = tt < run_cnt;
+                    uint32_t valid = 0, loc = 0, tg = 0;
+                    if (tt == 0) {            // wave-uniform: the first window of every run is read whole
+                        if (active) {
+    #pragma unroll
+                            for (int c9 = 0; c9 < 9; c9++) {
+                                const uint32_t code = (uint32_t)wbytes[bo + c9] - 'A';
+                                if (code >= 26u) poison = c9 + 1;             // that many windows, this one included, hold the byte
+                                key = (key << 5) | (code & 31u);
+                            }
+                        }
+                    } else if (active) {      // the next residue enters, the oldest leaves
+                        const uint32_t code = (uint32_t)wbytes[bo + tt + 8] - 'A';
+                        key = ((key << 5) | (code & 31u)) & MASK45;
+                        poison = code >= 26u ? 9u : (poison ? poison - 1u : 0u);
+                    }
+                    if (active && poison == 0) valid = locate(T, key, loc, tg) ? 1u : 0u;
+                    probe_issue(T, loc, tg | (valid << 31), lane, B[h]);
+                }
+                probe_eval_multi<2>(T, B, 0u, lane, pr);
+                // the result of round x belongs to the window of lane 16x + q: fetch its strip position (every lane shuffles)
+    #pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const uint32_t sidx = (t + h < run_cnt) ? sb + t + h : NONE;
+    #pragma unroll
+                    for (int x = 0; x < 4; x++) {
+                        const uint32_t dst = (uint32_t)__shfl((int)sidx, 16 * x + (int)q, 64);
+                        if (j == 0 && dst != NONE && (h == 0 || two)) wtaxa[dst] = pr[h][x];
+                    }
                 }
             }
         }
@@ -669,7 +793,7 @@ extern "C" int umgap_classify_prot9_strategy_dev(umgap_index* ix, umgap_taxonomy
                                                  uint32_t* d_out_taxon, uint32_t* d_out_status, void* stream) {
     if (!ix || !tx || (n_reads && (!d_bytes || !d_frag_offsets || !d_out_taxon || !d_out_status))) return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: null argument");
     if (ix->bound_to && ix->bound_to != tx) return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: the index is bound to another taxonomy");
-    if (ix->kind != 9) return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: needs a 9-mer index");
+    if (ix->kind != 9 && ix->kind != 10) return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: needs a 9-mer index");
     if (fragments_per_read == 0 || fragments_per_read > PROT_MAX_FRAGS) return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: fragments_per_read must be in 1..16");
     if (method != UMGAP_METHOD_TREE && method != UMGAP_METHOD_RMQ) return fail(UMGAP_ERR_INVALID, "unknown method");
     if (strategy != UMGAP_STRATEGY_LCA_STAR && strategy != UMGAP_STRATEGY_HYBRID && strategy != UMGAP_STRATEGY_MRTL) return fail(UMGAP_ERR_INVALID, "unknown strategy");
@@ -681,13 +805,15 @@ extern "C" int umgap_classify_prot9_strategy_dev(umgap_index* ix, umgap_taxonomy
     if (G * fragments_per_read > 64) G = 64 / fragments_per_read;
     size_t g = ((n_reads + G - 1) / G + 3) / 4;
     if (g > 256 * 8) g = 256 * 8;
-    const bool general = strategy != UMGAP_STRATEGY_LCA_STAR, bound = ix->bound_to != nullptr;
+    const bool general = strategy != UMGAP_STRATEGY_LCA_STAR, bound = ix->bound_to != nullptr, walk = ix->kind == 10;
+    const WalkView WK{ix->d_walk, ix->n_walk};
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, strategy, factor, d_bytes,
-                           d_frag_offsets, n_reads, fragments_per_read, seedextend ? 1u : 0u, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status);
+                           d_frag_offsets, n_reads, fragments_per_read, seedextend ? 1u : 0u, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status, WK);
     };
-    if (general) { if (bound) launch(k_classify_prot9<true, true>); else launch(k_classify_prot9<false, true>); }
-    else { if (bound) launch(k_classify_prot9<true, false>); else launch(k_classify_prot9<false, false>); }
+    if (walk) { if (general) launch(k_classify_prot9<false, true, true>); else launch(k_classify_prot9<false, false, true>); }
+    else if (general) { if (bound) launch(k_classify_prot9<true, true, false>); else launch(k_classify_prot9<false, true, false>); }
+    else { if (bound) launch(k_classify_prot9<true, false, false>); else launch(k_classify_prot9<false, false, false>); }
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
 }

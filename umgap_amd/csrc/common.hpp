@@ -105,7 +105,9 @@ struct umgap_var_index;  // index_var.hip
 
 struct umgap_index {
     int device = 0;
-    int kind = 9;                      // 9 = packed 9-mer table, 2 = variable-length (byte string) table
+    int kind = 9;                      // 9 = packed 9-mer table, 2 = variable-length (byte string) table, 10 = 9-mer table in walk order (index_walk.hip)
+    uint64_t* d_walk = nullptr;        // kind 10: E[p] = taxon | (low 31 key bits | continues << 31) << 32 for window p of the proteome; the table's values are positions
+    uint64_t n_walk = 0;
     umgap_var_index* var = nullptr;    // kind 2
     uint64_t* d_slots = nullptr;  // nb * 8 slots (whole table) or the shard's range
     uint64_t n_keys = 0;

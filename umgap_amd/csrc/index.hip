@@ -11,10 +11,17 @@
 #include <vector>
 
 #include "probe_common.hpp"
+#include "window_locate.hpp"
 #include "taxonomy.hpp"
 
 namespace umgap {
 void var_free(umgap_var_index* v);
+// index_walk.hip
+int walk_fill(umgap_index* t1, const uint8_t* d_bytes, const uint64_t* d_offsets, const uint64_t* d_wbase, size_t n_fragments, uint32_t max_fragment_len,
+              uint64_t* d_E, hipStream_t s);
+int walk_map_positions(const umgap_index* ix, uint32_t* d_vals, size_t n, uint32_t miss, hipStream_t s);
+int walk_lookup_prot9(const umgap_index* ix, const uint8_t* d_bytes, const uint64_t* d_offsets, const uint64_t* d_out_offsets, size_t n_prot, size_t n_windows,
+                      uint32_t miss, uint32_t* d_out, hipStream_t s);
 uint64_t var_table_bytes(const umgap_var_index* v);   // slots + heap
 int var_save(const umgap_index* ix, FILE* f);
 int var_open(umgap_index* ix, const IndexFileHeader& h, FILE* f, const char* path);
@@ -99,20 +106,22 @@ __global__ __launch_bounds__(256) void k_lookup_prot9(const uint8_t* __restrict_
                                                       const uint64_t* __restrict__ out_offsets, size_t n_prot,
                                                       size_t n_windows, uint32_t miss, uint32_t* __restrict__ out,
                                                       TableView T) {
+    __shared__ uint32_t lds_tmp[4][192];
     const uint32_t lane = threadIdx.x & 63;
     const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
-    for (size_t base = wave * 64; base < n_windows; base += nwaves * 64) {
+    // a wave takes a contiguous range of windows (a multiple of 64): the fragment cursor moves along with it (window_locate.hpp)
+    const size_t per_wave = ((n_windows + nwaves - 1) / nwaves + 63) & ~(size_t)63;
+    const size_t first = wave * per_wave, last = min(n_windows, first + per_wave);
+    if (first >= n_windows) return;
+    WindowCursor cur = window_cursor(out_offsets, offsets, n_prot, first);
+    for (size_t base = first; base < last; base += 64) {
         size_t g = base + lane;
         uint32_t local = 0, tag = 0, valid = 0;
+        uint64_t w = 0;
+        const uint64_t start = locate_window<false>(cur, out_offsets, offsets, n_prot, base, lane, lds_tmp[threadIdx.x >> 6], w);   // every lane takes part
         if (g < n_windows) {
-            // largest p with out_offsets[p] <= g
-            size_t lo = 0, hi = n_prot;
-            while (hi - lo > 1) {
-                size_t mid = (lo + hi) >> 1;
-                if (out_offsets[mid] <= g) lo = mid; else hi = mid;
-            }
-            const uint8_t* s = bytes + offsets[lo] + (g - out_offsets[lo]);
+            const uint8_t* s = bytes + start;
             uint64_t key = 0;
             bool ok = true;
 #pragma unroll
@@ -218,9 +227,45 @@ __global__ __launch_bounds__(256) void k_insert_synth(uint64_t* __restrict__ slo
 // Index built from protein fragments: every 9-residue window of fragment i maps to taxa[i]; when the
 // same 9-mer occurs in several fragments the SMALLEST taxon wins (deterministic stand-in for the
 // LCA that `umgap joinkmers` would compute; only the synthetic proteome uses this).
+// windows of every fragment (a fragment of fewer than 9 residues has none) and their exclusive scan: one workgroup walks the list in
+// slabs of 4096 counts
+__global__ __launch_bounds__(256) void k_window_counts(const uint64_t* __restrict__ off, size_t n_frag, uint32_t* __restrict__ cnt) {
+    size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; f < n_frag; f += step) {
+        const uint64_t len = off[f + 1] - off[f];
+        cnt[f] = (off[f + 1] >= off[f] && len >= 9 && len < 0xFFFFFFFFull) ? (uint32_t)(len - 8) : 0u;
+    }
+}
+__global__ __launch_bounds__(1024) void k_scan_counts(const uint32_t* __restrict__ cnt, size_t n, uint64_t* __restrict__ base, uint64_t* __restrict__ total) {
+    __shared__ uint32_t wsum[16];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint64_t run = 0;
+    for (size_t s0 = 0; s0 < n; s0 += 4096) {
+        const size_t i = s0 + (size_t)threadIdx.x * 4;
+        uint32_t v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = i + k < n ? cnt[i + k] : 0u;
+        const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= (uint32_t)o) incl += t; }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        uint32_t before = 0, slab = 0;
+        for (uint32_t w = 0; w < 16; w++) { if (w < wv) before += wsum[w]; slab += wsum[w]; }
+        uint64_t at = run + before + incl - mine;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { if (i + k < n) base[i + k] = at; at += v[k]; }
+        run += slab;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { base[n] = run; *total = run; }
+}
+
 __global__ __launch_bounds__(256) void k_insert_windows(uint64_t* __restrict__ slots, uint32_t m, uint32_t nb, const uint8_t* __restrict__ bytes,
                                                         const uint64_t* __restrict__ off, const uint32_t* __restrict__ taxa, size_t n_frag,
-                                                        uint32_t max_len, BuildFlags* flags) {
+                                                        uint32_t max_len, BuildFlags* flags, const uint64_t* __restrict__ wbase) {
     size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x, total = n_frag * max_len;
     for (; g < total; g += stride) {
@@ -236,7 +281,7 @@ __global__ __launch_bounds__(256) void k_insert_windows(uint64_t* __restrict__ s
             key = (key << 5) | ((ch - 'A') & 31u);
         }
         if (!ok) continue;
-        uint32_t b, tag, val = taxa[i];
+        uint32_t b, tag, val = taxa ? taxa[i] : (uint32_t)(wbase[i] + w);   // taxa == null: the window's number in the proteome (walk order, index_walk.hip)
         probe_of_key(key, m, b, tag);
         bool done = false;
         for (uint32_t d = 0; d <= MAX_DISP && !done; d++) {
@@ -746,6 +791,7 @@ void umgap_index_free(umgap_index* ix) {
             if (v[i] == ix) { v.erase(v.begin() + (long)i); break; }
     }
     if (ix->var) var_free(ix->var);
+    if (ix->d_walk) (void)hipFree(ix->d_walk);
     for (void* p : ix->tryp_scratch) if (p) (void)hipFree(p);
     if (ix->d_slots) (void)hipFree(ix->d_slots);
     if (ix->d_stash_keys) (void)hipFree(ix->d_stash_keys);
@@ -769,6 +815,7 @@ int umgap_index_device(const umgap_index* ix) { return ix ? ix->device : -1; }
 int umgap_index_save(const umgap_index* ix, const char* path) {
     if (!ix || !path) return fail(UMGAP_ERR_INVALID, "umgap_index_save: null argument");
     if (ix->bound_to) return fail(UMGAP_ERR_INVALID, "the index is bound to a taxonomy (umgap_index_bind_taxonomy): its values are interval codes, not taxon ids; unbind it first");
+    if (ix->kind == 10) return fail(UMGAP_ERR_INVALID, "umgap_index_save: a walk-order index has no file format yet (rebuild it from the proteome)");
     if (ix->kind == 2) {
         int rcv = use_device(ix->device);
         if (rcv) return rcv;
@@ -957,12 +1004,59 @@ int umgap_index_build_windows9_dev(const uint8_t* d_bytes, const uint64_t* d_off
     // no stash here: a chain longer than MAX_DISP grows the table instead (synthetic use only)
     rc = build_with(ix, expected_keys, load, 0, 1, [&](umgap_index* x, BuildFlags* f, uint64_t*) {
         if (n_fragments) hipLaunchKernelGGL(k_insert_windows, dim3(grid_for(n_fragments * (size_t)max_fragment_len, 256, 256 * 16)), dim3(256), 0, x->stream,
-                                            x->d_slots, x->view.m, x->view.nb, d_bytes, d_offsets, d_taxa, n_fragments, max_fragment_len, f);
+                                            x->d_slots, x->view.m, x->view.nb, d_bytes, d_offsets, d_taxa, n_fragments, max_fragment_len, f, (const uint64_t*)nullptr);
         return UMGAP_OK;
     });
     if (rc) { umgap_index_free(ix); return rc; }
     *out = ix;
     return UMGAP_OK;
+}
+
+// The 9-mer index of a proteome in WALK order (index_walk.hip): the table maps a 9-mer to the number p of the first window of
+// the proteome that holds it, and E[p] holds the taxon (smallest taxon over the fragments that hold the 9-mer, as
+// umgap_index_build_windows9_dev) beside the low key bits and a "continues the previous window" flag.
+int umgap_index_build_walk9_dev(const uint8_t* d_bytes, const uint64_t* d_offsets, const uint32_t* d_taxa, size_t n_fragments,
+                                uint32_t max_fragment_len, uint64_t expected_keys, double load, int device, umgap_index** out) {
+    if (!out || !n_fragments || !d_bytes || !d_offsets || !d_taxa || max_fragment_len < 9) return fail(UMGAP_ERR_INVALID, "umgap_index_build_walk9_dev: bad argument");
+    umgap_index* t1 = nullptr;
+    int rc = umgap_index_build_windows9_dev(d_bytes, d_offsets, d_taxa, n_fragments, max_fragment_len, expected_keys, load, device, &t1);   // the values
+    if (rc) return rc;
+    umgap_index* ix = nullptr;
+    uint32_t* d_cnt = nullptr;
+    uint64_t *d_wbase = nullptr, *d_total = nullptr;
+    auto done = [&](int code) {
+        for (void* p : {(void*)d_cnt, (void*)d_wbase, (void*)d_total}) if (p) (void)hipFree(p);
+        umgap_index_free(t1);
+        if (code && ix) umgap_index_free(ix);
+        return code;
+    };
+    rc = new_handle(device, &ix);
+    if (rc) return done(rc);
+    if (hipMalloc((void**)&d_cnt, n_fragments * 4) != hipSuccess || hipMalloc((void**)&d_wbase, (n_fragments + 1) * 8) != hipSuccess || hipMalloc((void**)&d_total, 8) != hipSuccess)
+        return done(fail(UMGAP_ERR_NOMEM, "umgap_index_build_walk9_dev: hipMalloc failed"));
+    // number the windows: fragment f owns windows [wbase[f], wbase[f + 1])
+    hipLaunchKernelGGL(k_window_counts, dim3(grid_for(n_fragments)), dim3(256), 0, ix->stream, d_offsets, n_fragments, d_cnt);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, ix->stream, d_cnt, n_fragments, d_wbase, d_total);
+    uint64_t n_windows = 0;
+    hipError_t e = hipMemcpyAsync(&n_windows, d_total, 8, hipMemcpyDeviceToHost, ix->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+    if (e != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, std::string("umgap_index_build_walk9_dev: ") + hipGetErrorString(e)));
+    if (n_windows >= 0xFFFFFFFFull) return done(fail(UMGAP_ERR_INVALID, "umgap_index_build_walk9_dev: a walk index numbers its windows with 32 bits (fewer than 2^32 - 1 windows)"));
+    rc = build_with(ix, expected_keys, load, 0, 1, [&](umgap_index* x, BuildFlags* f, uint64_t*) {
+        hipLaunchKernelGGL(k_insert_windows, dim3(grid_for(n_fragments * (size_t)max_fragment_len, 256, 256 * 16)), dim3(256), 0, x->stream,
+                           x->d_slots, x->view.m, x->view.nb, d_bytes, d_offsets, (const uint32_t*)nullptr, n_fragments, max_fragment_len, f, (const uint64_t*)d_wbase);
+        return UMGAP_OK;
+    });
+    if (rc) return done(rc);
+    if (hipMalloc((void**)&ix->d_walk, std::max<uint64_t>(n_windows, 1) * 8) != hipSuccess) return done(fail(UMGAP_ERR_NOMEM, "umgap_index_build_walk9_dev: hipMalloc of the walk array failed"));
+    ix->n_walk = n_windows;
+    rc = walk_fill(t1, d_bytes, d_offsets, d_wbase, n_fragments, max_fragment_len, ix->d_walk, ix->stream);
+    if (!rc && hipStreamSynchronize(ix->stream) != hipSuccess) rc = fail(UMGAP_ERR_DEVICE, "umgap_index_build_walk9_dev: the fill failed");
+    if (rc) return done(rc);
+    ix->kind = 10;
+    ix->n_keys = t1->n_keys;
+    *out = ix;
+    return done(UMGAP_OK);
 }
 
 int umgap_index_partition9_dev(const umgap_index* ix, const uint64_t* d_keys, size_t n, uint32_t n_shards, uint64_t cap,
@@ -980,17 +1074,19 @@ int umgap_index_partition9_dev(const umgap_index* ix, const uint64_t* d_keys, si
 int umgap_index_lookup9_dev(umgap_index* ix, const uint64_t* d_keys, size_t n, uint32_t miss, uint32_t* d_out, void* stream) {
     if (!ix || (n && (!d_keys || !d_out))) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup9_dev: null argument");
     if (ix->bound_to) return fail(UMGAP_ERR_INVALID, "the index is bound to a taxonomy (umgap_index_bind_taxonomy): its values are interval codes, not taxon ids; unbind it first");
-    if (ix->kind != 9) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup9_dev: not a 9-mer index");
+    if (ix->kind != 9 && ix->kind != 10) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup9_dev: not a 9-mer index");
     int rc = use_device(ix->device);
     if (rc) return rc;
-    if (n) hipLaunchKernelGGL(k_lookup9, dim3(grid_for(n, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, d_keys, n, miss, d_out, ix->view);
+    if (n) hipLaunchKernelGGL(k_lookup9, dim3(grid_for(n, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, d_keys, n, ix->kind == 10 ? UMGAP_NONE : miss, d_out, ix->view);
     UMGAP_HIP(hipGetLastError());
+    if (ix->kind == 10) return walk_map_positions(ix, d_out, n, miss, (hipStream_t)stream);
     return UMGAP_OK;
 }
 
 // measurement-only entry: the lane-per-key variant
 int umgap_index_lookup9_lane_dev(umgap_index* ix, const uint64_t* d_keys, size_t n, uint32_t miss, uint32_t* d_out, void* stream) {
     if (!ix || (n && (!d_keys || !d_out))) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup9_lane_dev: null argument");
+    if (ix->kind != 9) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup9_lane_dev: not a plain 9-mer index");
     if (ix->bound_to) return fail(UMGAP_ERR_INVALID, "the index is bound to a taxonomy (umgap_index_bind_taxonomy): its values are interval codes, not taxon ids; unbind it first");
     int rc = use_device(ix->device);
     if (rc) return rc;
@@ -1009,6 +1105,8 @@ int umgap_index_lookup_prot9_dev(umgap_index* ix, const uint8_t* d_bytes, const 
     uint64_t n_windows = 0;
     UMGAP_HIP(hipMemcpyAsync(&n_windows, d_out_offsets + n_prot, sizeof(uint64_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
     UMGAP_HIP(hipStreamSynchronize((hipStream_t)stream));
+    if (ix->kind != 9 && ix->kind != 10) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup_prot9_dev: not a 9-mer index");
+    if (ix->kind == 10) return walk_lookup_prot9(ix, d_bytes, d_offsets, d_out_offsets, n_prot, (size_t)n_windows, miss, d_out, (hipStream_t)stream);   // walking (index_walk.hip)
     if (n_windows) hipLaunchKernelGGL(k_lookup_prot9, dim3(grid_for(n_windows)), dim3(256), 0, (hipStream_t)stream, d_bytes, d_offsets, d_out_offsets, n_prot, (size_t)n_windows, miss, d_out, ix->view);
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;

@@ -1,0 +1,270 @@
+// index_walk.hip — the 9-mer index of a proteome laid out in WALK order (kind 10; round 3).
+//
+// Consecutive 9-mers of a protein fragment share eight residues, yet a hash table sends each of them to a bucket of its own: one
+// 64-byte request per window, and ~50 G requests/s is the chip's ceiling.  When the index is built from a
+// proteome (umgap_index_build_walk9_dev; UMGAP's own index is derived from UniProt proteins), "the order in which the proteome
+// lists its windows" is a ready-made walk order:
+//     E[p]   = taxon of the key (the table's answer: smallest taxon over the fragments that hold the 9-mer)
+//              | (low 31 key bits | continues << 31) << 32                                  8 bytes, p = number of the window
+//              ("continues": window p - 1 is the previous window of the same fragment, so key(p) = key(p - 1) << 5 | last residue)
+//     table  = the exact hash table of common.hpp with value = p of the FIRST window that holds the key
+// A read fragment whose windows follow the proteome is then answered by ONE probe (its first window, the anchor, gives p) plus the
+// few sectors of E[p + 1 ..]: window j behind the anchor is answered by E[p + j] iff every entry on the way continues its
+// predecessor and carries the window's low key bits -- by induction its key then EQUALS the window's, so the answer is exact (no
+// fingerprints).  Where the read leaves the walk (a mutation, a window the proteome lists elsewhere first) the next window is
+// probed again and walks on from its own position.  The fused surface-B kernels do this (classify.hip); the plain get() calls
+// take the position from the table and the taxon from E (two passes).
+// Measured first as a prototype (tools/bench_walk_lookup.py, kept below as umgap_walkproto_lookup): 840 M windows of reads that are
+// proteome fragments with 3 % of their residues changed in 12.4 ms against 28.8 ms for the plain table, bit-identical.
+#include <algorithm>
+
+#include "probe_common.hpp"
+#include "window_locate.hpp"
+
+using namespace umgap;
+using namespace umgap::probe;
+
+namespace {
+
+__device__ __forceinline__ uint32_t lane_get(const TableView& T, uint64_t key, uint32_t miss) {
+    uint32_t local, tag, res = miss;
+    if (!locate(T, key, local, tag)) return miss;
+    const uint4* p = reinterpret_cast<const uint4*>(T.slots) + (size_t)local * 4;
+    uint32_t want = tag;
+    for (uint32_t d = 0;; d++) {
+        const uint4 e0 = p[0], e1 = p[1], e2 = p[2], e3 = p[3];
+        bool hit = false;
+#define UMGAP_CMP(E)                                                  \
+    if ((E.x & TAG_MASK) == want) { res = E.y; hit = true; }          \
+    if ((E.z & TAG_MASK) == want) { res = E.w; hit = true; }
+        UMGAP_CMP(e0) UMGAP_CMP(e1) UMGAP_CMP(e2) UMGAP_CMP(e3)
+#undef UMGAP_CMP
+        const bool ovf = e0.x != 0xFFFFFFFFu && (e0.x >> 31);
+        if (hit || !ovf) break;
+        if (d == MAX_DISP) { if (T.n_stash) res = stash_lookup(T, local + T.home_lo, tag, miss); break; }
+        p += 4;
+        want += 1u << R_BITS;
+    }
+    return res;
+}
+
+// key of window w of fragment f (fragments of flen bytes back to back); false: a byte outside 'A'..'Z'
+__device__ __forceinline__ bool window_key(const uint8_t* __restrict__ bytes, uint64_t f, uint32_t w, uint32_t flen, uint64_t& key) {
+    const uint8_t* p = bytes + f * flen + w;
+    key = 0;
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+        const uint32_t ch = (uint32_t)p[c] - 'A';
+        ok = ok && ch < 26u;
+        key = (key << 5) | (ch & 31u);
+    }
+    return ok;
+}
+
+// E for every window of the proteome: iteration space as k_insert_windows (fragment i, window w < max_len)
+__global__ __launch_bounds__(256) void k_walk_fill(TableView T1, const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ off, const uint64_t* __restrict__ wbase,
+                                                   size_t n_frag, uint32_t max_len, uint64_t* __restrict__ E) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, total = n_frag * max_len;
+    for (; g < total; g += stride) {
+        const size_t i = g / max_len;
+        const uint32_t w = (uint32_t)(g % max_len);
+        const uint64_t o = off[i], len = off[i + 1] - o;
+        if (len < 9 || w + 9 > len) continue;
+        uint64_t key = 0;
+        bool ok = true;
+#pragma unroll
+        for (int c = 0; c < 9; c++) {
+            const uint32_t ch = (uint32_t)bytes[o + w + c] - 'A';
+            ok = ok && ch < 26u;
+            key = (key << 5) | (ch & 31u);
+        }
+        uint32_t taxon = 0, lo = 0x7FFFFFFFu;       // low bits 31 (no residue has that code): matches no window
+        if (ok) { taxon = lane_get(T1, key, 0u); lo = (uint32_t)key & 0x7FFFFFFFu; }
+        if (w > 0) lo |= 0x80000000u;
+        E[wbase[i] + w] = (uint64_t)taxon | ((uint64_t)lo << 32);
+    }
+}
+
+// positions (the table's values) -> taxa
+__global__ __launch_bounds__(256) void k_walk_map(const uint64_t* __restrict__ E, uint64_t n_E, uint32_t* __restrict__ vals, size_t n, uint32_t miss) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) {
+        const uint32_t p = vals[i];
+        vals[i] = (p == UMGAP_NONE || p >= n_E) ? miss : (uint32_t)E[p];
+    }
+}
+
+// hits[gw] for every window gw of the reads (fragments of flen residues): a wave takes 64 consecutive windows
+__global__ __launch_bounds__(256) void k_walk_lookup(TableView H2, const uint64_t* __restrict__ E64, uint64_t n_E, const uint8_t* __restrict__ reads, uint64_t n_frag,
+                                                     uint32_t flen, uint32_t anchor_every, uint32_t* __restrict__ hits, unsigned long long* __restrict__ stats) {
+    const uint32_t W = flen - 8, lane = threadIdx.x & 63;
+    const uint2* E = reinterpret_cast<const uint2*>(E64);       // x = taxon, y = low key bits | continues << 31
+    const uint64_t total = n_frag * W;
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    unsigned long long n_walked = 0, n_probed = 0;
+    for (uint64_t g0 = wave * 64; g0 < total; g0 += nwaves * 64) {
+        const uint64_t gw = g0 + lane;
+        const uint64_t f = gw < total ? gw / W : 0;
+        const uint32_t w = gw < total ? (uint32_t)(gw - f * W) : 0u;
+        uint64_t key = 0;
+        const bool valid = gw < total && window_key(reads, f, w, flen, key);
+        // distance to the window's anchor: every anchor_every-th window of a fragment, and the wave's first lane (so that no walk
+        // starts in another wave)
+        const uint32_t j = min(w % anchor_every, lane);
+        // 1. anchors: one H2 probe each
+        uint32_t pos = UMGAP_NONE;
+        if (valid && j == 0) pos = lane_get(H2, key, UMGAP_NONE);
+        // 2. the windows behind an anchor: E[anchor position + j]
+        const int a = (int)lane - (int)j;                            // the anchor's lane
+        const uint32_t apos = (uint32_t)__shfl((int)pos, a, 64);
+        bool cand = gw < total && apos != UMGAP_NONE && (uint64_t)apos + j < n_E;
+        uint2 e{0u, 0u};
+        if (cand) e = E[(uint64_t)apos + j];
+        const bool ok_self = cand && (e.y & 0x7FFFFFFFu) == ((uint32_t)key & 0x7FFFFFFFu) && valid && (j == 0 || (e.y >> 31));
+        const uint64_t okm = __ballot(ok_self);
+        bool walked = false;
+        if (cand) {
+            const uint64_t need = ((j + 1u >= 64u ? ~0ull : ((1ull << (j + 1)) - 1ull)) << a);   // lanes a .. lane
+            walked = (okm & need) == need;
+        }
+        uint32_t hit = 0;
+        if (walked) hit = e.x;
+        else if (valid) {
+            // 3. not reached by a walk: its own probe, then its entry
+            const uint32_t p = j == 0 ? pos : lane_get(H2, key, UMGAP_NONE);
+            if (p != UMGAP_NONE && p < n_E) hit = E[p].x;
+        }
+        if (gw < total) hits[gw] = hit;
+        n_walked += (walked && j != 0) ? 1ull : 0ull;
+        n_probed += (valid && (j == 0 || !walked)) ? 1ull : 0ull;
+    }
+    if (stats) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            n_walked += (unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)n_walked, d, 64);
+            n_probed += (unsigned long long)(uint32_t)__shfl_xor((int)(uint32_t)n_probed, d, 64);
+        }
+        if (lane == 0) { atomicAdd(&stats[0], n_walked); atomicAdd(&stats[1], n_probed); }
+    }
+}
+
+// The get() of protein windows (umgap_index_lookup_prot9_dev) over a walk index, window-parallel: lane = window g of the flat
+// list (fragment found by binary search in the output offsets, as the plain kernel does).  Every 8th window of a fragment, and the
+// wave's first lane, is an ANCHOR: one quad-probe batch gives their positions; every other window reads the entry `its distance`
+// behind its anchor's position and is answered by it iff all entries from the anchor on continue their predecessor and carry
+// their window's low key bits (one ballot).  Windows not reached that way take a second batch of probes and their entry.
+__device__ __forceinline__ uint32_t lane_result(const uint32_t (&res)[4], uint32_t lane) {
+    // the answer to lane L's key sits, quad-uniform, in quad L & 15 as round L >> 4
+    const int src = 4 * (int)(lane & 15u);
+    const uint32_t v0 = (uint32_t)__shfl((int)res[0], src, 64), v1 = (uint32_t)__shfl((int)res[1], src, 64),
+                   v2 = (uint32_t)__shfl((int)res[2], src, 64), v3 = (uint32_t)__shfl((int)res[3], src, 64);
+    const uint32_t r4 = lane >> 4;
+    return r4 == 0 ? v0 : (r4 == 1 ? v1 : (r4 == 2 ? v2 : v3));
+}
+
+__global__ __launch_bounds__(256) void k_walk_lookup_prot9(TableView H2, const uint64_t* __restrict__ E, uint64_t n_E, const uint8_t* __restrict__ bytes,
+                                                           const uint64_t* __restrict__ offsets, const uint64_t* __restrict__ out_offsets, size_t n_prot,
+                                                           size_t n_windows, uint32_t miss, uint32_t* __restrict__ out) {
+    constexpr uint32_t EVERY = 8;
+    __shared__ uint32_t lds_tmp[4][192];
+    const uint32_t lane = threadIdx.x & 63;
+    const size_t wave = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    // a wave takes a contiguous range of windows (a multiple of 64): the fragment cursor moves along with it (window_locate.hpp)
+    const size_t per_wave = ((n_windows + nwaves - 1) / nwaves + 63) & ~(size_t)63;
+    const size_t first = wave * per_wave, last = min(n_windows, first + per_wave);
+    if (first >= n_windows) return;
+    WindowCursor cur = window_cursor(out_offsets, offsets, n_prot, first);
+    for (size_t base = first; base < last; base += 64) {
+        const size_t g = base + lane;
+        uint64_t key = 0;
+        bool valid = false;
+        uint32_t w = 0;
+        uint64_t ww = 0;
+        const uint64_t start = locate_window<true>(cur, out_offsets, offsets, n_prot, base, lane, lds_tmp[threadIdx.x >> 6], ww);   // every lane takes part
+        if (g < n_windows) {
+            w = ww > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ww;
+            const uint8_t* s = bytes + start;
+            valid = true;
+#pragma unroll
+            for (int c = 0; c < 9; c++) {
+                const uint32_t ch = (uint32_t)s[c] - 'A';
+                valid = valid && ch < 26u;
+                key = (key << 5) | (ch & 31u);
+            }
+        }
+        const uint32_t j = min(w % EVERY, lane);                     // distance to the window's anchor (same fragment, same wave)
+        // 1. the anchors
+        uint32_t local = 0, tag = 0, ok1 = 0;
+        if (valid && j == 0) ok1 = locate(H2, key, local, tag) ? 1u : 0u;
+        uint32_t res[4];
+        wave_probe64_vals(H2, local, tag | (ok1 << 31), UMGAP_NONE, lane, res);
+        const uint32_t pos = lane_result(res, lane);
+        // 2. the windows behind them
+        const int a = (int)lane - (int)j;
+        const uint32_t apos = (uint32_t)__shfl((int)pos, a, 64);
+        const bool cand = g < n_windows && apos != UMGAP_NONE && (uint64_t)apos + j < n_E;
+        uint64_t e = 0;
+        if (cand) e = E[(uint64_t)apos + j];
+        const uint32_t ey = (uint32_t)(e >> 32);
+        const bool ok_self = cand && valid && (ey & 0x7FFFFFFFu) == ((uint32_t)key & 0x7FFFFFFFu) && (j == 0 || (ey >> 31));
+        const uint64_t okm = __ballot(ok_self);
+        const uint64_t need = (((1ull << (j + 1)) - 1ull) << a);       // lanes a .. lane (j < 8)
+        const bool walked = cand && (okm & need) == need;
+        // 3. the rest: their own probe (anchors that missed have their answer already), then their entry
+        uint32_t local2 = 0, tag2 = 0, ok2 = 0;
+        const bool again = valid && !walked && j != 0;
+        if (again) ok2 = locate(H2, key, local2, tag2) ? 1u : 0u;
+        uint32_t hit = miss;
+        if (walked) hit = (uint32_t)e;
+        if (__any(again)) {                                            // wave-uniform
+            wave_probe64_vals(H2, local2, tag2 | (ok2 << 31), UMGAP_NONE, lane, res);
+            const uint32_t p2 = lane_result(res, lane);
+            if (again && p2 != UMGAP_NONE && p2 < n_E) hit = (uint32_t)E[p2];
+        }
+        if (g < n_windows) out[g] = hit;
+    }
+}
+
+}  // namespace
+
+namespace umgap {
+int walk_fill(umgap_index* t1, const uint8_t* d_bytes, const uint64_t* d_offsets, const uint64_t* d_wbase, size_t n_fragments, uint32_t max_fragment_len,
+              uint64_t* d_E, hipStream_t s) {
+    size_t g = (n_fragments * (size_t)max_fragment_len + 255) / 256;
+    g = std::max<size_t>(1, std::min<size_t>(g, 256 * 16));
+    hipLaunchKernelGGL(k_walk_fill, dim3((unsigned)g), dim3(256), 0, s, t1->view, d_bytes, d_offsets, d_wbase, n_fragments, max_fragment_len, d_E);
+    UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}
+int walk_lookup_prot9(const umgap_index* ix, const uint8_t* d_bytes, const uint64_t* d_offsets, const uint64_t* d_out_offsets, size_t n_prot, size_t n_windows,
+                      uint32_t miss, uint32_t* d_out, hipStream_t s) {
+    if (n_windows) hipLaunchKernelGGL(k_walk_lookup_prot9, dim3((unsigned)std::max<size_t>(1, std::min<size_t>((n_windows + 255) / 256, 256 * 8))), dim3(256), 0, s, ix->view,
+                                      ix->d_walk, ix->n_walk, d_bytes, d_offsets, d_out_offsets, n_prot, n_windows, miss, d_out);
+    UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}
+int walk_map_positions(const umgap_index* ix, uint32_t* d_vals, size_t n, uint32_t miss, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_walk_map, dim3((unsigned)std::max<size_t>(1, std::min<size_t>((n + 255) / 256, 256 * 16))), dim3(256), 0, s, ix->d_walk, ix->n_walk, d_vals, n, miss);
+    UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}
+}  // namespace umgap
+
+extern "C" {
+
+// EXPERIMENT kept beside the product (tools/bench_walk_lookup.py; not in the public header): hits of every window of reads made of
+// fragments of exactly flen residues, anchors every `anchor_every` windows; d_stats (nullable): {windows answered by a walk, probes made}
+int umgap_walkproto_lookup(umgap_index* ix, const uint8_t* d_reads, uint64_t n_frag, uint32_t flen, uint32_t anchor_every,
+                           uint32_t* d_hits, unsigned long long* d_stats, void* stream) {
+    if (!ix || ix->kind != 10 || !d_reads || !d_hits || flen < 9 || anchor_every < 1 || anchor_every > 32) return fail(UMGAP_ERR_INVALID, "umgap_walkproto_lookup: bad argument");
+    int rc = use_device(ix->device);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_walk_lookup, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, ix->view, ix->d_walk, ix->n_walk, d_reads, n_frag, flen, anchor_every, d_hits, d_stats);
+    UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}
+
+}  // extern "C"
