@@ -528,59 +528,67 @@ __global__ __launch_bounds__(256, GENERAL ? 3 : 4) void k_classify_prot9(TableVi
                     }
                 }
             }
-            // ---- phase 2: what the walks did not reach is probed window by window, two batches in flight (the loop of the plain table with
-            // most lanes idle), from the first step at which some lane still lacks an answer; a hit takes its taxon from the walk array ----
-            uint32_t t0 = wave_min(done_n < run_cnt ? done_n : 0xFFFFu);
-            if (t0 < R) {                                            // wave-uniform
-                t0 &= ~1u;
-                for (uint32_t t = t0; t < R; t += 2) {
-                    const bool two = t + 1 < R;
-                    ProbeBatch B[2];
-                    uint32_t pr[2][4];
-                    bool mine[2] = {false, false};
+            // ---- phase 2: what the walks did not reach, COMPACTED: the unanswered windows of all lanes form one list (strip index | byte
+            // offset << 10, in the count tables of the aggregate stage, which are idle and all zero now) and are probed 128 at a time,
+            // lane = list item -- dense batches instead of one sparse step per window of the longest hole; a hit takes its taxon from
+            // the walk array ----
+            {
+                const uint32_t mine_n = run_cnt - done_n;
+                uint32_t incl2 = mine_n;
 #pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        if (h == 1 && !two) { probe_skip(B[1]); break; }   // wave-uniform
-                        const uint32_t tt = t + h;
-                        const bool active = tt < run_cnt;
-                        uint32_t valid = 0, loc = 0, tg = 0;
-                        if (tt == t0) {           // wave-uniform: the first window looked at is read whole
-                            if (active) {
-                                key = 0;
-                                poison = 0;
+                for (int o = 1; o < 64; o <<= 1) { const uint32_t tt = (uint32_t)__shfl_up((int)incl2, o, 64); if (lane >= (uint32_t)o) incl2 += tt; }
+                const uint32_t my_first = incl2 - mine_n, U = (uint32_t)__shfl((int)incl2, 63, 64);       // U = unanswered windows of the group (wave-uniform)
+                uint32_t* list = wkeys;                                  // 512 words: keys[256] and cnt[256] lie back to back
+                for (uint32_t l0 = 0; l0 < U; l0 += 512) {               // wave-uniform; one trip unless more than half the strip is unanswered
+                    for (uint32_t x = 0; x < mine_n; x++) {
+                        const uint32_t at = my_first + x;
+                        if (at >= l0 && at < l0 + 512) list[at - l0] = (sb + done_n + x) | ((bo + done_n + x) << 10);
+                    }
+                    wave_lds_sync();
+                    const uint32_t n_here = U - l0 < 512u ? U - l0 : 512u;
+                    for (uint32_t i0 = 0; i0 < n_here; i0 += 128) {
+                        ProbeBatch B[2];
+                        uint32_t pr[2][4], item[2];
+                        const bool two = i0 + 64 < n_here;
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            if (h == 1 && !two) { probe_skip(B[1]); item[1] = NONE; break; }   // wave-uniform
+                            const uint32_t i = i0 + 64 * h + lane;
+                            item[h] = i < n_here ? list[i] : NONE;
+                            uint32_t valid = 0, loc = 0, tg = 0;
+                            if (item[h] != NONE) {
+                                const uint32_t byte0 = item[h] >> 10;
+                                uint64_t k9 = 0;
+                                bool ok = true;
 #pragma unroll
                                 for (int c9 = 0; c9 < 9; c9++) {
-                                    const uint32_t code = (uint32_t)wbytes[bo + tt + c9] - 'A';
-                                    if (code >= 26u) poison = c9 + 1;
-                                    key = (key << 5) | (code & 31u);
+                                    const uint32_t code = (uint32_t)wbytes[byte0 + c9] - 'A';
+                                    ok = ok && code < 26u;
+                                    k9 = (k9 << 5) | (code & 31u);
                                 }
+                                if (ok) valid = locate(T, k9, loc, tg) ? 1u : 0u;
                             }
-                        } else if (active) {
-                            const uint32_t code = (uint32_t)wbytes[bo + tt + 8] - 'A';
-                            key = ((key << 5) | (code & 31u)) & MASK45;
-                            poison = code >= 26u ? 9u : (poison ? poison - 1u : 0u);
+                            probe_issue(T, loc, tg | (valid << 31), lane, B[h]);
                         }
-                        mine[h] = active && tt >= done_n;
-                        if (mine[h] && poison == 0) valid = locate(T, key, loc, tg) ? 1u : 0u;
-                        probe_issue(T, loc, tg | (valid << 31), lane, B[h]);
-                    }
-                    if (!__any(mine[0] || mine[1])) continue;       // wave-uniform: every window of this pair of steps has its answer
-                    probe_eval_multi<2>(T, B, NONE, lane, pr);
+                        probe_eval_multi<2>(T, B, NONE, lane, pr);
 #pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        const uint32_t sidx = mine[h] ? sb + t + h : NONE;
-                        uint32_t dsts[4];
-                        uint64_t ev[4];
-#pragma unroll
-                        for (int x = 0; x < 4; x++) {
-                            dsts[x] = (uint32_t)__shfl((int)sidx, 16 * x + (int)q, 64);
-                            ev[x] = 0ull;
-                            if (j == 0 && dsts[x] != NONE && pr[h][x] != NONE && pr[h][x] < WK.n) ev[x] = WK.E[pr[h][x]];
+                        for (int h = 0; h < 2; h++) {
+                            if (h == 1 && !two) break;                     // wave-uniform
+                            // the answer to lane L's item sits, quad-uniform, in quad L & 15 as round L >> 4
+                            const int src = 4 * (int)(lane & 15u);
+                            const uint32_t v0 = (uint32_t)__shfl((int)pr[h][0], src, 64), v1 = (uint32_t)__shfl((int)pr[h][1], src, 64),
+                                           v2 = (uint32_t)__shfl((int)pr[h][2], src, 64), v3 = (uint32_t)__shfl((int)pr[h][3], src, 64);
+                            const uint32_t r4 = lane >> 4;
+                            const uint32_t pos = r4 == 0 ? v0 : (r4 == 1 ? v1 : (r4 == 2 ? v2 : v3));
+                            if (item[h] != NONE) wtaxa[item[h] & 1023u] = (pos != NONE && pos < WK.n) ? (uint32_t)WK.E[pos] : 0u;
                         }
-#pragma unroll
-                        for (int x = 0; x < 4; x++)
-                            if (j == 0 && dsts[x] != NONE && (h == 0 || two)) wtaxa[dsts[x]] = (uint32_t)ev[x];
                     }
+                    wave_lds_sync();
+                }
+                if (U) {                                                  // the count tables go back to all zero
+#pragma unroll
+                    for (int i = 0; i < 8; i++) list[lane + 64 * i] = 0u;
+                    wave_lds_sync();
                 }
             }
         } else {
