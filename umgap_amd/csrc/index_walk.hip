@@ -14,8 +14,10 @@
 // fingerprints).  Where the read leaves the walk (a mutation, a window the proteome lists elsewhere first) the next window is
 // probed again and walks on from its own position.  The fused surface-B kernels do this (classify.hip); the plain get() calls
 // take the position from the table and the taxon from E (two passes).
-// Measured first as a prototype (tools/bench_walk_lookup.py, kept below as umgap_walkproto_lookup): 840 M windows of reads that are
-// proteome fragments with 3 % of their residues changed in 12.4 ms against 28.8 ms for the plain table, bit-identical.
+// Measured first as a prototype for fragments of one fixed length (kept below as umgap_walkproto_lookup: lane = window by plain
+// arithmetic, anchors probed lane-per-key): 840 M windows of reads that are proteome fragments with 0 / 1 / 3 / 6 % of their
+// residues changed in 7.6 / 8.8 / 12.5 / 16.8 ms, bit-identical to the plain table's answers (which then took 29 ms, most of it a
+// binary search per window that window_locate.hpp has since replaced: 17.5 ms).  The product kernels: profiles/r03_walk_index.json.
 #include <algorithm>
 
 #include "probe_common.hpp"
