@@ -9,6 +9,7 @@ through
                                    without the table bound to the taxonomy where binding is possible,
   * umgap_digest_tryp_dev          byte soup against the reference's regex digest,
   * umgap_classify_prot9[_strategy]_dev, umgap_classify_tryp_dev   random proteins against a dict + the oracle,
+  * the 9-mer index in walk order (umgap_index_build_walk9_dev)   against the plain table of the same random proteome, bit for bit,
   * umgap_sharded_{lookup9,classify9}_dev   N ranks as threads on this GPU against the whole-table kernels (every 4th iteration),
 for every strategy, both methods, several -l / -f, ranked and unranked snapping, and checks each answer with the oracle's
 taxa2agg (tie sets honoured).  Prints one line per mismatch and a summary; exit status 1 if anything differed.
@@ -80,6 +81,84 @@ def digest_leg(rng, fails):
     if pieces != want:
         fails.append("digest")
         print("MISMATCH digest n_frag", n_frag, "pieces", len(pieces), "want", len(want), flush=True)
+
+
+def walk_leg(rng, fails):
+    """The 9-mer index in walk order against the plain table of the same random proteome (ragged fragments, odd bytes, repeated
+    fragments under other taxa): the fused surface-B pipeline (random strategy, fragments per read, seedextend) and the window get(),
+    on reads that follow the proteome, deviate from it, or are random -- bit for bit."""
+    import ctypes as C
+    from umgap_amd import _lib
+    from umgap_amd.api import Index, _dev_ptr
+    L = _lib.load()
+    letters = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    n_ids = int(rng.choice([15, 120, 900]))
+    ids = np.arange(1, n_ids + 1, dtype=np.uint32)
+    par = np.maximum(1, ids // int(rng.choice([2, 3, 5]))).astype(np.uint32)
+    tx = api.Taxonomy(ids, par)
+    frags = []
+    for _ in range(int(rng.integers(5, 3000))):
+        n = int(rng.choice([0, 4, 9, 10, 17, 50, 50, 64, 100, 130]))
+        f = bytearray(rng.choice(letters[:int(rng.choice([3, 20]))], n).tobytes())     # a 3-letter alphabet makes duplicate 9-mers common
+        if n > 9 and rng.random() < 0.1:
+            f[int(rng.integers(0, n))] = int(rng.choice([42, 120, 64]))
+        frags.append(bytes(f))
+    frags += [frags[int(i)] for i in rng.integers(0, len(frags), len(frags) // 8)]
+    n_frag = len(frags)
+    n_win = int(sum(max(0, len(f) - 8) for f in frags))
+    if n_win == 0:
+        return
+    data, offs = api._concat(frags)
+    taxa = rng.choice(ids, n_frag).astype(np.uint32)
+    d_p, d_po = torch.from_numpy(data.copy()).cuda(), torch.from_numpy(offs.view(np.int64)).cuda()
+    d_pt = torch.from_numpy(taxa.view(np.int32)).cuda()
+    max_len = max(len(f) for f in frags)
+    hp, hw = C.c_void_p(), C.c_void_p()
+    load = float(rng.choice([0.0, 0.3, 0.85]))
+    _lib.check(L.umgap_index_build_windows9_dev(_dev_ptr(d_p), _dev_ptr(d_po), _dev_ptr(d_pt), n_frag, max_len, n_win, load, 0, C.byref(hp)))
+    _lib.check(L.umgap_index_build_walk9_dev(_dev_ptr(d_p), _dev_ptr(d_po), _dev_ptr(d_pt), n_frag, max_len, n_win, load, 0, C.byref(hw)))
+    plain, walk = Index(hp.value), Index(hw.value)
+    F, n_reads = int(rng.choice([1, 2, 3, 7])), int(rng.integers(1, 600))
+    mut = float(rng.choice([0.0, 0.01, 0.05, 0.3]))
+    rfr = []
+    for _ in range(n_reads * F):
+        c = rng.random()
+        if c < 0.75:
+            f = bytearray(frags[int(rng.integers(0, n_frag))])
+            for k in range(len(f)):
+                if rng.random() < mut:
+                    f[k] = int(rng.choice(letters))
+            a, b = (0, len(f)) if rng.random() < 0.5 else sorted(rng.integers(0, len(f) + 1, 2).tolist())
+            rfr.append(bytes(f[a:b][:60]))
+        else:
+            rfr.append(rng.choice(letters, int(rng.integers(0, 60))).tobytes())
+    rdata, roffs = api._concat(rfr)
+    d_r = torch.from_numpy(rdata.copy()).cuda() if len(rdata) else torch.zeros(1, dtype=torch.uint8, device="cuda")
+    d_ro = torch.from_numpy(roffs.view(np.int64)).cuda()
+    oo = np.zeros(len(rfr) + 1, np.int64)
+    oo[1:] = np.cumsum([max(0, len(f) - 8) for f in rfr])
+    d_oo = torch.from_numpy(oo).cuda()
+    if oo[-1]:
+        h0 = torch.full((int(oo[-1]),), -3, dtype=torch.int32, device="cuda")
+        h1 = torch.full_like(h0, -5)
+        plain.lookup_prot9_dev(d_r, d_ro, d_oo, h0, miss_value=0)
+        walk.lookup_prot9_dev(d_r, d_ro, d_oo, h1, miss_value=0)
+        torch.cuda.synchronize()
+        if not torch.equal(h0, h1):
+            fails.append("walk get"); print("MISMATCH walk index: lookup_prot9 differs from the plain table", n_frag, n_reads, F, mut, flush=True)
+    method, strategy = MODES[int(rng.integers(0, 5))]
+    kw = dict(method=method, strategy=strategy, factor=float(rng.choice([0.1, 0.25, 0.6])), lower_bound=float(rng.choice([0.0, 1.0, 2.0])),
+              seedextend=bool(rng.integers(0, 2)), min_seed_size=int(rng.choice([2, 3])), max_gap_size=int(rng.choice([0, 1])))
+    outs = []
+    for ix in (plain, walk):
+        t = torch.full((n_reads,), -1, dtype=torch.int32, device="cuda")
+        st = torch.full_like(t, -1)
+        api.classify_prot9_dev(ix, tx, d_r, d_ro, n_reads, F, t, st, **kw)
+        outs.append((t, st))
+    torch.cuda.synchronize()
+    if not (torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])):
+        fails.append("walk fused"); print("MISMATCH walk index: fused pipeline differs from the plain table", n_frag, n_reads, F, mut, kw, flush=True)
+    walk_leg.checks = getattr(walk_leg, "checks", 0) + n_reads + int(oo[-1])
 
 
 def protein_legs(rng, fails):
@@ -358,6 +437,8 @@ def main():
                         n_checks += 1
         digest_leg(rng, fails)
         protein_legs(rng, fails)
+        walk_leg(rng, fails)
+        n_checks += 2
         n_checks += 3
         if it % 4 == 0:
             sharded_leg(rng, fails)
