@@ -413,7 +413,7 @@ int umgap_index_build_windows9_dev(const uint8_t* d_bytes, const uint64_t* d_off
  * beside the low key bits and a "continues the previous window" flag.  A run of read windows that follows the proteome is then
  * answered by one probe plus the few sectors of the walk array behind the position it returned, each step verified (exact: the
  * key of an entry is determined by its predecessor's); where the read leaves the walk the next window is probed again.
- * Served by umgap_classify_prot9[_strategy]_dev (walking), umgap_index_lookup_prot9_dev and umgap_index_lookup9_dev (position
+ * Served by umgap_classify_prot9[_strategy]_dev (walking; umgap_index_bind_taxonomy applies), umgap_index_lookup_prot9_dev and umgap_index_lookup9_dev (position
  * from the table, taxon from the walk array); the other entry points want a kind-9 table.  Fewer than 2^32 - 1 windows.
  * Measured (tools/bench_surface_b.py --walk, 2.1 G-key proteome index, profiles/r03_walk_index.json): reads that are proteome
  * fragments with 0 / 1 / 3 / 6 % of their residues changed classify 1.67 / 1.38 / 1.19 / 1.06 times as fast as over the plain table

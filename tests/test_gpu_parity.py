@@ -1563,8 +1563,21 @@ def test_walk_index_matches_plain_table(api, torch_cuda, mutations_per_mille):
     # entry points that want a plain table say so
     with pytest.raises(api.UmgapError):
         api.classify9_dev(walk, w.taxonomy, q[:84], 1, 84, torch.empty(1, dtype=torch.int32, device="cuda"), torch.empty(1, dtype=torch.int32, device="cuda"))
+    # bound to the taxonomy (the walk array's taxa become interval codes, the table of window numbers stays): same answers, and
+    # the plain get() calls are refused while bound, as for the plain table
+    walk.bind(w.taxonomy)
+    for method, strategy, lb, se in (("tree", "lca*", 2.0, False), ("rmq", "mrtl", 1.0, True), ("tree", "hybrid", 0.0, False)):
+        t0 = torch.full((n_reads,), -1, dtype=torch.int32, device="cuda")
+        s0 = torch.full_like(t0, -1)
+        t1, s1 = torch.full_like(t0, -2), torch.full_like(t0, -2)
+        api.classify_prot9_dev(plain, w.taxonomy, d_r, d_ro, n_reads, F, t0, s0, method=method, strategy=strategy, factor=0.25, lower_bound=lb, seedextend=se, min_seed_size=2, max_gap_size=1)
+        api.classify_prot9_dev(walk, w.taxonomy, d_r, d_ro, n_reads, F, t1, s1, method=method, strategy=strategy, factor=0.25, lower_bound=lb, seedextend=se, min_seed_size=2, max_gap_size=1)
+        torch.cuda.synchronize()
+        assert torch.equal(t0, t1) and torch.equal(s0, s1), (method, strategy, "bound walk")
     with pytest.raises(api.UmgapError):
-        walk.bind(w.taxonomy)
+        walk.lookup9_dev(q)
+    walk.unbind(w.taxonomy)
+    assert torch.equal(plain.lookup9_dev(q, miss_value=7), walk.lookup9_dev(q, miss_value=7))
 
 
 def test_classify_prot9_ragged_fragments(api, torch_cuda):

@@ -60,6 +60,8 @@ if WALK:
     # reference answers of the plain table (unbound) for the first batch, every leg
     res.update({"layout": "walk order: table of window numbers + walk array (umgap_index_build_walk9_dev)", "walk_setup_s": round(walk_setup, 1),
                 "walk_table_GB": round(wx.table_bytes / 1e9, 2), "walk_array_GB": round(n_frag * (flen - 8) * 8 / 1e9, 2)})
+    wx.bind(w.taxonomy)     # the walk array's taxa as interval codes (the reference answers below come from the plain, unbound table)
+    res["table_bound_to_taxonomy"] = True
 else:
     ix.bind(w.taxonomy)     # values = preorder interval codes: the aggregate stage gathers nothing by id
     res["table_bound_to_taxonomy"] = True

@@ -57,6 +57,41 @@ __global__ __launch_bounds__(256) void k_unbind(uint64_t* __restrict__ slots, si
     }
 }
 
+// a walk-order index (kind 10, index_walk.hip) keeps its taxa in the walk array: entry = taxon | (low key bits | continues << 31) << 32;
+// entries of windows that hold no 9-mer (low key bits all ones) carry no taxon
+__device__ __forceinline__ bool walk_entry_has_taxon(uint64_t e) { return ((uint32_t)(e >> 32) & 0x7FFFFFFFu) != 0x7FFFFFFFu; }
+__global__ __launch_bounds__(256) void k_bind_check_walk(const uint64_t* __restrict__ E, size_t n, const uint2* __restrict__ by_id, uint32_t len, unsigned long long* bad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    unsigned long long mine = 0;
+    for (size_t k = i; k < n; k += stride) {
+        const uint64_t e = E[k];
+        if (!walk_entry_has_taxon(e)) continue;
+        const uint32_t t = (uint32_t)e;
+        if (t >= len || by_id[t].x == UMGAP_NONE) mine++;
+    }
+    if (mine) atomicAdd(bad, mine);
+}
+__global__ __launch_bounds__(256) void k_bind_walk(uint64_t* __restrict__ E, size_t n, const uint2* __restrict__ by_id) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = i; k < n; k += stride) {
+        const uint64_t e = E[k];
+        if (!walk_entry_has_taxon(e)) continue;
+        const uint2 pl = by_id[(uint32_t)e];
+        E[k] = (e & 0xFFFFFFFF00000000ull) | bound::encode(pl.x, pl.y - pl.x);
+    }
+}
+__global__ __launch_bounds__(256) void k_unbind_walk(uint64_t* __restrict__ E, size_t n, const uint32_t* __restrict__ id_of_pre) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t k = i; k < n; k += stride) {
+        const uint64_t e = E[k];
+        if (!walk_entry_has_taxon(e)) continue;
+        E[k] = (e & 0xFFFFFFFF00000000ull) | id_of_pre[bound::pre_of((uint32_t)e)];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -65,7 +100,8 @@ int umgap_index_is_bound(const umgap_index* ix) { return ix && ix->bound_to ? 1 
 
 int umgap_index_bind_taxonomy(umgap_index* ix, umgap_taxonomy* tx) {
     if (!ix || !tx) return fail(UMGAP_ERR_INVALID, "umgap_index_bind_taxonomy: null argument");
-    if (ix->kind != 9) return fail(UMGAP_ERR_INVALID, "umgap_index_bind_taxonomy: only the 9-mer table can be bound");
+    if (ix->kind != 9 && ix->kind != 10) return fail(UMGAP_ERR_INVALID, "umgap_index_bind_taxonomy: only the 9-mer tables can be bound");
+    const bool walk = ix->kind == 10;
     if (ix->bound_to) return fail(UMGAP_ERR_INVALID, "umgap_index_bind_taxonomy: the index is already bound");
     if (ix->device != tx->device) return fail(UMGAP_ERR_INVALID, "umgap_index_bind_taxonomy: index and taxonomy live on different devices");
     if (tx->n_reach > bound::MAX_REACH) return fail(UMGAP_ERR_INVALID, "umgap_index_bind_taxonomy: more than 2^22 - 2 reachable taxa");
@@ -80,14 +116,16 @@ int umgap_index_bind_taxonomy(umgap_index* ix, umgap_taxonomy* tx) {
     hipError_t e = hipMemsetAsync(d_bad, 0, sizeof(unsigned long long), ix->stream);
     unsigned long long bad = 0;
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_bind_check, dim3(256 * 8), dim3(256), 0, ix->stream, ix->d_slots, nslots, ix->d_stash_vals, ix->n_stash, tx->d_by_id, tx->len, d_bad);
+        if (walk) hipLaunchKernelGGL(k_bind_check_walk, dim3(256 * 8), dim3(256), 0, ix->stream, ix->d_walk, (size_t)ix->n_walk, tx->d_by_id, tx->len, d_bad);
+        else hipLaunchKernelGGL(k_bind_check, dim3(256 * 8), dim3(256), 0, ix->stream, ix->d_slots, nslots, ix->d_stash_vals, ix->n_stash, tx->d_by_id, tx->len, d_bad);
         e = hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, ix->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
     (void)hipFree(d_bad);
     if (e != hipSuccess) return fail(UMGAP_ERR_DEVICE, std::string("umgap_index_bind_taxonomy: ") + hipGetErrorString(e));
     if (bad) return fail(UMGAP_ERR_BUILD, "umgap_index_bind_taxonomy: " + std::to_string(bad) + " table values are not taxa of this taxonomy (the unbound kernels report them per read)");
-    hipLaunchKernelGGL(k_bind, dim3(256 * 8), dim3(256), 0, ix->stream, ix->d_slots, nslots, ix->d_stash_vals, ix->n_stash, tx->d_by_id);
+    if (walk) hipLaunchKernelGGL(k_bind_walk, dim3(256 * 8), dim3(256), 0, ix->stream, ix->d_walk, (size_t)ix->n_walk, tx->d_by_id);   // the table holds window numbers: untouched
+    else hipLaunchKernelGGL(k_bind, dim3(256 * 8), dim3(256), 0, ix->stream, ix->d_slots, nslots, ix->d_stash_vals, ix->n_stash, tx->d_by_id);
     UMGAP_HIP(hipGetLastError());
     UMGAP_HIP(hipStreamSynchronize(ix->stream));
     ix->bound_to = tx;
@@ -103,7 +141,8 @@ int umgap_index_unbind_taxonomy(umgap_index* ix, umgap_taxonomy* tx) {
     if (rc) return rc;
     UMGAP_HIP(hipDeviceSynchronize());   // as in bind: no kernel of any stream may be reading the slots
     const size_t nslots = (size_t)ix->view.n_resident * SLOTS;
-    hipLaunchKernelGGL(k_unbind, dim3(256 * 8), dim3(256), 0, ix->stream, ix->d_slots, nslots, ix->d_stash_vals, ix->n_stash, tx->d_id_of_pre);
+    if (ix->kind == 10) hipLaunchKernelGGL(k_unbind_walk, dim3(256 * 8), dim3(256), 0, ix->stream, ix->d_walk, (size_t)ix->n_walk, tx->d_id_of_pre);
+    else hipLaunchKernelGGL(k_unbind, dim3(256 * 8), dim3(256), 0, ix->stream, ix->d_slots, nslots, ix->d_stash_vals, ix->n_stash, tx->d_id_of_pre);
     UMGAP_HIP(hipGetLastError());
     UMGAP_HIP(hipStreamSynchronize(ix->stream));
     ix->bound_to = nullptr;

@@ -819,7 +819,10 @@ extern "C" int umgap_classify_prot9_strategy_dev(umgap_index* ix, umgap_taxonomy
         hipLaunchKernelGGL(kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, strategy, factor, d_bytes,
                            d_frag_offsets, n_reads, fragments_per_read, seedextend ? 1u : 0u, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status, WK);
     };
-    if (walk) { if (general) launch(k_classify_prot9<false, true, true>); else launch(k_classify_prot9<false, false, true>); }
+    if (walk) {
+        if (general) { if (bound) launch(k_classify_prot9<true, true, true>); else launch(k_classify_prot9<false, true, true>); }
+        else { if (bound) launch(k_classify_prot9<true, false, true>); else launch(k_classify_prot9<false, false, true>); }
+    }
     else if (general) { if (bound) launch(k_classify_prot9<true, true, false>); else launch(k_classify_prot9<false, true, false>); }
     else { if (bound) launch(k_classify_prot9<true, false, false>); else launch(k_classify_prot9<false, false, false>); }
     UMGAP_HIP(hipGetLastError());
