@@ -416,8 +416,8 @@ int umgap_index_build_windows9_dev(const uint8_t* d_bytes, const uint64_t* d_off
  * Served by umgap_classify_prot9[_strategy]_dev (walking; umgap_index_bind_taxonomy applies), umgap_index_lookup_prot9_dev and umgap_index_lookup9_dev (position
  * from the table, taxon from the walk array); the other entry points want a kind-9 table.  Fewer than 2^32 - 1 windows.
  * Measured (tools/bench_surface_b.py --walk, 2.1 G-key proteome index, profiles/r03_walk_index.json): reads that are proteome
- * fragments with 0 / 1 / 3 / 6 % of their residues changed classify 1.67 / 1.38 / 1.19 / 1.06 times as fast as over the plain table
- * (0.31 - 0.53 requests per window instead of 1.04 - 1.12); at 20 % the plain table is 1.24 times faster: a walk index is for reads
+ * fragments with 0 / 1 / 3 / 6 % of their residues changed classify 1.9 / 1.5 / 1.3 / 1.1 times as fast as over the plain table
+ * (0.31 - 0.53 requests per window instead of 1.04 - 1.12); at 20 % the plain table is 1.2 times faster: a walk index is for reads
  * close to the proteome it was built from. */
 int umgap_index_build_walk9_dev(const uint8_t* d_bytes, const uint64_t* d_offsets, const uint32_t* d_taxa,
                                 size_t n_fragments, uint32_t max_fragment_len, uint64_t expected_keys,
