@@ -581,6 +581,20 @@ def main():
             out["tryptic_pipeline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         torch.cuda.empty_cache()
         try:
+            # surface B (protein fragments in) over the plain table and over the same proteome's index in walk order (index_walk.hip): reads
+            # that are proteome fragments with 3 % of their residues changed; the walk answers checked bit for bit (tools/bench_surface_b.py)
+            import bench_surface_b
+            legs = bench_surface_b.ALL_LEGS[:2]
+            plain = bench_surface_b.run(50_000_000, 10_000_000, 30, walk=False, steps=3, workload=w, legs=legs)
+            torch.cuda.empty_cache()
+            walk = bench_surface_b.run(50_000_000, 10_000_000, 30, walk=True, steps=3, workload=w, legs=legs)
+            out["surface_b"] = {"index_keys": plain["index_keys"], "reads": "10 M pairs of 2 x 50 residues, proteome fragments with 3 % of the residues changed",
+                                "plain_table": {k: plain[k] for k, *_ in legs}, "walk_order_index": {k: walk[k] for k, *_ in legs},
+                                "walk_tables_GB": [walk["walk_table_GB"], walk["walk_array_GB"]], "plain_table_GB": plain["table_GB"]}
+        except Exception as e:  # noqa: BLE001
+            out["surface_b"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+        try:
             import end_to_end
             out["end_to_end"], out["cpu_baseline_end_to_end"] = end_to_end.run()
         except Exception as e:  # noqa: BLE001
