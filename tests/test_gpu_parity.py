@@ -1500,7 +1500,8 @@ def test_walk_index_matches_plain_table(api, torch_cuda, mutations_per_mille):
     plain, walk = Index(hp.value), Index(hw.value)
     assert plain.kind == 9 and walk.kind == 10 and walk.num_keys == plain.num_keys
     # reads: mutated copies of the 50-residue fragments, plus ragged reads cut from the proteome and random ones
-    long_ids = np.array([i for i, f in enumerate(frags) if len(f) == 50 and all(65 <= c <= 90 for c in f)], np.int64)
+    # (lengths 73 and 120: runs of up to 16 windows per lane with room behind a substituted residue for the walk to pick up again)
+    long_ids = np.array([i for i, f in enumerate(frags) if len(f) >= 50 and all(65 <= c <= 90 for c in f)], np.int64)
     n_reads, F = 3000, 2
     rfr = []
     for r in range(n_reads * F):
@@ -1510,6 +1511,18 @@ def test_walk_index_matches_plain_table(api, torch_cuda, mutations_per_mille):
             for k in range(len(f)):
                 if rng.random() * 1000 < mutations_per_mille:
                     f[k] = int(rng.choice(letters))
+            if mutations_per_mille and len(f) > 20:
+                e = rng.random()
+                k = int(rng.integers(1, len(f) - 1))
+                if e < 0.12:
+                    del f[k]                                                   # a deletion: the walk's offset no longer fits behind it
+                elif e < 0.24:
+                    f.insert(k, int(rng.choice(letters)))                      # an insertion
+                elif e < 0.34:
+                    g = frags[int(rng.choice(long_ids))]                       # a chimera: the read goes on in another protein
+                    f = f[:k] + bytearray(g[min(k, len(g)):])
+                elif e < 0.40:
+                    f[k] = 42                                                  # '*': nine windows without a key
             a, b = (0, len(f)) if rng.random() < 0.6 else sorted(rng.integers(0, len(f) + 1, 2).tolist())
             rfr.append(bytes(f[a:b]))
         elif c < 0.85:

@@ -128,6 +128,15 @@ def walk_leg(rng, fails):
             for k in range(len(f)):
                 if rng.random() < mut:
                     f[k] = int(rng.choice(letters))
+            if len(f) > 12 and rng.random() < 0.3:                    # one residue lost or gained, or the read goes on in another fragment
+                k, e = int(rng.integers(1, len(f) - 1)), rng.random()
+                if e < 0.33:
+                    del f[k]
+                elif e < 0.66:
+                    f.insert(k, int(rng.choice(letters)))
+                else:
+                    g = frags[int(rng.integers(0, n_frag))]
+                    f = f[:k] + bytearray(g[min(k, len(g)):])
             a, b = (0, len(f)) if rng.random() < 0.5 else sorted(rng.integers(0, len(f) + 1, 2).tolist())
             rfr.append(bytes(f[a:b][:60]))
         else:
