@@ -412,9 +412,12 @@ int umgap_index_build_windows9_dev(const uint8_t* d_bytes, const uint64_t* d_off
  * maps a 9-mer to the number of the first window that holds it and a walk array keeps, per window of the proteome, the taxon
  * beside the low key bits and a "continues the previous window" flag.  A run of read windows that follows the proteome is then
  * answered by one probe plus the few sectors of the walk array behind the position it returned, each step verified (exact: the
- * key of an entry is determined by its predecessor's); where the read leaves the walk the next window is probed again.
- * Served by umgap_classify_prot9[_strategy]_dev (walking; umgap_index_bind_taxonomy applies), umgap_index_lookup_prot9_dev and umgap_index_lookup9_dev (position
- * from the table, taxon from the walk array); the other entry points want a kind-9 table.  Fewer than 2^32 - 1 windows.
+ * low key bits of entries t and t - 3, or of entry t next to a verified t - 1, pin all nine residues of window t); a substituted
+ * residue costs the nine windows that hold it, which are probed one by one, and the walk goes on behind them.
+ * Served by umgap_classify_prot9[_strategy]_dev (walking; umgap_index_bind_taxonomy applies) and umgap_index_lookup_prot9_dev;
+ * umgap_index_lookup9[_dev], umgap_classify_records and umgap_index_dump9 take the position from the table and the taxon from the
+ * walk array (same answers as the plain table, no gain); umgap_index_save / umgap_index_open keep it (UMGAPIX1 kind 10: the walk
+ * array follows the stash), so every command of `umgap` runs on such a file.  Not sharded.  Fewer than 2^32 - 1 windows.
  * Measured (tools/bench_surface_b.py --walk, 2.1 G-key proteome index, profiles/r03_walk_index.json): reads that are proteome
  * fragments with 0 / 1 / 3 / 6 % of their residues changed classify 1.9 / 1.5 / 1.3 / 1.1 times as fast as over the plain table
  * (0.31 - 0.53 requests per window instead of 1.04 - 1.12); at 20 % the plain table is 1.2 times faster: a walk index is for reads

@@ -1591,6 +1591,47 @@ def test_walk_index_matches_plain_table(api, torch_cuda, mutations_per_mille):
         walk.lookup9_dev(q)
     walk.unbind(w.taxonomy)
     assert torch.equal(plain.lookup9_dev(q, miss_value=7), walk.lookup9_dev(q, miss_value=7))
+    # the file (UMGAPIX1 kind 10): saved, opened, and every entry point of the commands on it -- get() of host keys, the record
+    # path of prot2kmer2agg, the dump behind printindex -- answers as the plain table does; so do the commands themselves
+    import subprocess
+    import tempfile
+    from umgap_amd.api import classify_records
+    with tempfile.TemporaryDirectory() as td:
+        fp, fw = os.path.join(td, "plain.ix"), os.path.join(td, "walk.ix")
+        plain.save(fp)
+        walk.save(fw)
+        assert os.path.getsize(fw) == os.path.getsize(fp) + 8 * n_win
+        walk2 = Index.open(fw)
+        assert walk2.kind == 10 and walk2.num_keys == plain.num_keys
+        with pytest.raises(api.UmgapError):
+            Index.open(fw, shard=0, n_shards=2)
+        assert torch.equal(plain.lookup9_dev(q, miss_value=7), walk2.lookup9_dev(q, miss_value=7))
+        hq = q.cpu().numpy().view(np.uint64)
+        assert np.array_equal(plain.lookup9(hq, miss_value=3), walk2.lookup9(hq, miss_value=3))
+        t2, s2 = torch.full((n_reads,), -1, dtype=torch.int32, device="cuda"), torch.full((n_reads,), -1, dtype=torch.int32, device="cuda")
+        t3, s3 = torch.full_like(t2, -2), torch.full_like(t2, -2)
+        api.classify_prot9_dev(plain, w.taxonomy, d_r, d_ro, n_reads, F, t2, s2, method="tree", strategy="lca*", lower_bound=2.0)
+        api.classify_prot9_dev(walk2, w.taxonomy, d_r, d_ro, n_reads, F, t3, s3, method="tree", strategy="lca*", lower_bound=2.0)
+        torch.cuda.synchronize()
+        assert torch.equal(t2, t3) and torch.equal(s2, s3)
+        rf = np.arange(0, len(rfr) + 1, F, dtype=np.uint64)
+        for se in (False, True):
+            a = classify_records(plain, w.taxonomy, rfr, rf, method="rmq", strategy="mrtl", lower_bound=1.0, seedextend=se, min_seed_size=2, max_gap_size=1)
+            b = classify_records(walk2, w.taxonomy, rfr, rf, method="rmq", strategy="mrtl", lower_bound=1.0, seedextend=se, min_seed_size=2, max_gap_size=1)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        walk2.close()
+        umgap = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "umgap_amd", "bin", "umgap")
+        fasta = b"".join(b">r%d\n%s\n" % (i, f) for i, f in enumerate(rfr[:1500]))
+        for args in (["prot2kmer2lca", "-o"], ["prot2kmer2lca"], ["printindex"]):
+            outs = []
+            for f in (fp, fw):
+                r = subprocess.run([umgap] + args + [f], input=b"" if args[0] == "printindex" else fasta, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+                assert r.returncode == 0, r.stderr
+                outs.append(r.stdout)
+            if args[0] == "printindex":
+                assert sorted(outs[0].splitlines()) == sorted(outs[1].splitlines()) and len(outs[0]) > 0
+            else:
+                assert outs[0] == outs[1] and len(outs[0]) > 0, args
 
 
 def test_classify_prot9_ragged_fragments(api, torch_cuda):

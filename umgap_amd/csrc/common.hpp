@@ -89,14 +89,14 @@ struct TableView {
 struct IndexFileHeader {
     char magic[8];
     uint32_t version;   // 1
-    uint32_t kind;      // 9 = 9-mer table
+    uint32_t kind;      // 9 = 9-mer table; 10 = 9-mer table in walk order (values = window numbers; the walk array follows the stash)
     uint64_t n_keys;
     uint32_t m;
     uint32_t nb;
     uint64_t mix_c1, mix_c2;
     uint32_t r_bits, slots;
     uint64_t n_stash;  // followed (after the buckets) by n_stash x {u64 key, u64 taxon}
-    uint64_t reserved;
+    uint64_t reserved;  // kind 10: entries of the walk array (u64 each); 0 otherwise
 };
 
 }  // namespace umgap

@@ -590,7 +590,7 @@ int cmd_prot2kmer2lca(const std::vector<std::string>& args) {
     // A packed 9-mer table answers k = 9; any other k can only miss there (its keys are 9 residues long), which the fast
     // path emits without asking the device.  A byte-string (variable-length) table serves EVERY k like the reference's fst
     // does (src/commands/prot2kmer2lca.rs:71-73,172-179): all windows of k residues through umgap_index_lookup_var.
-    const bool var_index = !gang && umgap_index_kind(ix) != 9;
+    const bool var_index = !gang && umgap_index_kind(ix) == 2;
     auto stream = [&](FILE* in, FILE* outf) {
         if (gang) { stream_lookup(in, outf, [&](const uint64_t* keys, size_t n, uint32_t* taxa) { gang->lookup(keys, n, taxa); }, o, true, k, chunk); return; }
         if (!var_index) { stream_lookup(in, outf, ix, o, true, k, chunk); return; }
@@ -1168,7 +1168,7 @@ int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
     const bool timing = getenv("UMGAP_TIMING") != nullptr;   // phase times on stderr
     const double t_begin = now();
     umgap_index* ix = open_index(p.positional[0]);
-    if (umgap_index_kind(ix) != 9) throw CliError("prot2kmer2agg needs a 9-mer index");
+    if (umgap_index_kind(ix) == 2) throw CliError("prot2kmer2agg needs a 9-mer index");
     umgap_taxonomy* tx = load_taxonomy(p.positional[1]);
     if (method == UMGAP_METHOD_RMQ && strategy == UMGAP_STRATEGY_HYBRID)
         fprintf(stderr, "Warning: this is a hybrid between LCA/MRTL, not LCA*/MRTL\n");
@@ -1488,7 +1488,7 @@ int cmd_printindex(const std::vector<std::string>& args) {
     umgap_index* ix = open_index(path);
     Out out(stdout);
     size_t n = 0;
-    if (umgap_index_kind(ix) == 9) {
+    if (umgap_index_kind(ix) != 2) {
         size_t cap = (size_t)umgap_index_num_keys(ix);
         std::vector<uint64_t> keys(cap);
         std::vector<uint32_t> taxa(cap);

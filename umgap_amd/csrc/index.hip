@@ -815,7 +815,6 @@ int umgap_index_device(const umgap_index* ix) { return ix ? ix->device : -1; }
 int umgap_index_save(const umgap_index* ix, const char* path) {
     if (!ix || !path) return fail(UMGAP_ERR_INVALID, "umgap_index_save: null argument");
     if (ix->bound_to) return fail(UMGAP_ERR_INVALID, "the index is bound to a taxonomy (umgap_index_bind_taxonomy): its values are interval codes, not taxon ids; unbind it first");
-    if (ix->kind == 10) return fail(UMGAP_ERR_INVALID, "umgap_index_save: a walk-order index has no file format yet (rebuild it from the proteome)");
     if (ix->kind == 2) {
         int rcv = use_device(ix->device);
         if (rcv) return rcv;
@@ -832,7 +831,8 @@ int umgap_index_save(const umgap_index* ix, const char* path) {
     if (!f) return fail(UMGAP_ERR_IO, std::string("cannot create ") + path + ": " + strerror(errno));
     IndexFileHeader h{};
     memcpy(h.magic, "UMGAPIX1", 8);
-    h.version = 1; h.kind = 9; h.n_keys = ix->n_keys; h.m = ix->view.m; h.nb = ix->view.nb;
+    h.version = 1; h.kind = (uint32_t)ix->kind; h.n_keys = ix->n_keys; h.m = ix->view.m; h.nb = ix->view.nb;
+    h.reserved = ix->kind == 10 ? ix->n_walk : 0;   // kind 10 (walk order): the walk array, n_walk x u64, follows the stash
     h.mix_c1 = MIX_C1; h.mix_c2 = MIX_C2; h.r_bits = R_BITS; h.slots = SLOTS;
     h.n_stash = ix->n_stash;
     bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
@@ -851,6 +851,14 @@ int umgap_index_save(const umgap_index* ix, const char* path) {
              hipMemcpy(v.data(), ix->d_stash_vals, v.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
         for (size_t i = 0; i < k.size(); i++) { kv[2 * i] = k[i]; kv[2 * i + 1] = v[i]; }
         ok = ok && fwrite(kv.data(), 8, kv.size(), f) == kv.size();
+    }
+    if (ix->kind == 10) {
+        total = (size_t)ix->n_walk * 8;
+        for (size_t off = 0; ok && off < total; off += chunk) {
+            size_t len = std::min(chunk, total - off);
+            if (hipMemcpy(buf.data(), (const char*)ix->d_walk + off, len, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
+            ok = fwrite(buf.data(), 1, len, f) == len;
+        }
     }
     ok = (fclose(f) == 0) && ok;
     if (!ok) return fail(UMGAP_ERR_IO, std::string("error writing ") + path);
@@ -928,11 +936,13 @@ int umgap_index_open_shard(const char* path, uint32_t device_mask, uint32_t shar
         *out = vx;
         return UMGAP_OK;
     }
-    if (h.version != 1 || h.kind != 9 || h.r_bits != R_BITS || h.slots != SLOTS || h.mix_c1 != MIX_C1 || h.mix_c2 != MIX_C2 ||
+    if (h.version != 1 || (h.kind != 9 && h.kind != 10) || h.r_bits != R_BITS || h.slots != SLOTS || h.mix_c1 != MIX_C1 || h.mix_c2 != MIX_C2 ||
         h.m == 0 || h.nb != ((uint64_t)h.m << A_BITS)) {
         fclose(f);
         return fail(UMGAP_ERR_FORMAT, std::string(path) + ": unsupported UMGAPIX1 parameters");
     }
+    if (h.kind == 10 && n_shards != 1) { fclose(f); return fail(UMGAP_ERR_INVALID, "a walk-order index cannot be sharded"); }
+    if (h.kind == 10 && h.reserved >= 0xFFFFFFFFull) { fclose(f); return fail(UMGAP_ERR_FORMAT, std::string(path) + ": walk array too long"); }
     umgap_index* ix = nullptr;
     int rc = new_handle(device, &ix);
     if (rc) { fclose(f); return rc; }
@@ -963,6 +973,12 @@ int umgap_index_open_shard(const char* path, uint32_t device_mask, uint32_t shar
             for (size_t i = 0; i < h.n_stash; i++) entries[i] = {kv[2 * i], kv[2 * i + 1]};
             if (set_stash(ix, entries)) { fclose(f); umgap_index_free(ix); return UMGAP_ERR_FORMAT; }
         }
+    }
+    if (ok && h.kind == 10) {   // the walk array behind the stash
+        ix->kind = 10;
+        ix->n_walk = h.reserved;
+        if (hipMalloc((void**)&ix->d_walk, std::max<uint64_t>(ix->n_walk, 1) * 8) != hipSuccess) { fclose(f); umgap_index_free(ix); return fail(UMGAP_ERR_NOMEM, "hipMalloc of the walk array failed"); }
+        ok = load_file_range(fd, (off_t)(sizeof(h) + (uint64_t)h.nb * 64 + h.n_stash * 16), (size_t)ix->n_walk * 8, ix->d_walk, device);
     }
     fclose(f);
     if (!ok) { umgap_index_free(ix); return fail(UMGAP_ERR_IO, std::string(path) + ": truncated or unreadable table"); }
@@ -1115,7 +1131,8 @@ int umgap_index_lookup_prot9_dev(umgap_index* ix, const uint8_t* d_bytes, const 
 int umgap_index_lookup9(umgap_index* ix, const uint64_t* keys, size_t n, uint32_t miss, uint32_t* out) {
     if (!ix || (n && (!keys || !out))) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup9: null argument");
     if (ix->bound_to) return fail(UMGAP_ERR_INVALID, "the index is bound to a taxonomy (umgap_index_bind_taxonomy): its values are interval codes, not taxon ids; unbind it first");
-    if (ix->kind != 9) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup9: not a 9-mer index");
+    if (ix->kind != 9 && ix->kind != 10) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup9: not a 9-mer index");
+    const bool walk = ix->kind == 10;   // the table holds window numbers: the taxa come from the walk array in a second pass
     int rc = use_device(ix->device);
     if (rc) return rc;
     rc = ensure_stage(ix);
@@ -1142,7 +1159,8 @@ int umgap_index_lookup9(umgap_index* ix, const uint64_t* keys, size_t n, uint32_
         uint64_t* dk = (uint64_t*)ix->d_stage[slot];
         uint32_t* dout = (uint32_t*)((char*)ix->d_stage[slot] + cap * 8);
         UMGAP_HIP(hipMemcpyAsync(dk, ix->h_stage[slot], len * 8, hipMemcpyHostToDevice, ix->stream));
-        hipLaunchKernelGGL(k_lookup9, dim3(grid_for(len)), dim3(256), 0, ix->stream, dk, len, miss, dout, ix->view);
+        hipLaunchKernelGGL(k_lookup9, dim3(grid_for(len)), dim3(256), 0, ix->stream, dk, len, walk ? UMGAP_NONE : miss, dout, ix->view);
+        if (walk && (rc = walk_map_positions(ix, dout, len, miss, ix->stream))) break;
         UMGAP_HIP(hipMemcpyAsync((char*)ix->h_stage[slot] + cap * 8, dout, len * 4, hipMemcpyDeviceToHost, ix->stream));
         UMGAP_HIP(hipEventRecord(done[slot], ix->stream));
         pending_off[slot] = off;
@@ -1172,7 +1190,7 @@ inline uint64_t unmix45(uint64_t h) {    // inverse of mix45 (common.hpp)
 }  // namespace
 
 int umgap_index_dump9(const umgap_index* ix, uint64_t* keys45, uint32_t* taxa, size_t cap, size_t* n_out) {
-    if (!ix || ix->kind != 9 || !n_out) return fail(UMGAP_ERR_INVALID, "umgap_index_dump9: not a 9-mer index");
+    if (!ix || (ix->kind != 9 && ix->kind != 10) || !n_out) return fail(UMGAP_ERR_INVALID, "umgap_index_dump9: not a 9-mer index");
     if (ix->bound_to) return fail(UMGAP_ERR_INVALID, "the index is bound to a taxonomy (umgap_index_bind_taxonomy): its values are interval codes, not taxon ids; unbind it first");
     if (ix->view.home_lo != 0 || ix->view.home_hi != ix->view.nb) return fail(UMGAP_ERR_INVALID, "umgap_index_dump9: handle holds a shard");
     int rc = use_device(ix->device);
@@ -1206,6 +1224,20 @@ int umgap_index_dump9(const umgap_index* ix, uint64_t* keys45, uint32_t* taxa, s
         }
     }
     *n_out = n;
+    if (ix->kind == 10) {   // taxa[] holds window numbers: through the walk array, a chunk at a time
+        const size_t have = std::min(n, cap), step = 16u << 20;
+        uint32_t* d_tmp = nullptr;
+        if (have && hipMalloc((void**)&d_tmp, std::min(have, step) * 4) != hipSuccess) return fail(UMGAP_ERR_NOMEM, "umgap_index_dump9: hipMalloc failed");
+        for (size_t o = 0; o < have && !rc; o += step) {
+            const size_t len = std::min(step, have - o);
+            if (hipMemcpyAsync(d_tmp, taxa + o, len * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess) rc = fail(UMGAP_ERR_DEVICE, "umgap_index_dump9: copy failed");
+            if (!rc) rc = walk_map_positions(ix, d_tmp, len, 0u, ix->stream);
+            if (!rc && (hipMemcpyAsync(taxa + o, d_tmp, len * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess || hipStreamSynchronize(ix->stream) != hipSuccess))
+                rc = fail(UMGAP_ERR_DEVICE, "umgap_index_dump9: copy failed");
+        }
+        if (d_tmp) (void)hipFree(d_tmp);
+        return rc;
+    }
     return UMGAP_OK;
 }
 

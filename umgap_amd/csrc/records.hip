@@ -23,6 +23,7 @@
 #include <vector>
 
 namespace umgap {
+int walk_map_positions(const umgap_index* ix, uint32_t* d_vals, size_t n, uint32_t miss, hipStream_t s);   // index_walk.hip
 int mark_seedextend_panics(const uint32_t* d_kept, const uint64_t* d_read_frags, size_t n_reads, uint32_t* d_out_taxon, uint32_t* d_out_status,
                            hipStream_t stream);
 }
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) void k_frag_prepare(const uint64_t* __restrict
 // a window, 0 elsewhere.  A wave takes 128 consecutive positions per step: their 136 bytes are staged in the wave's LDS
 // strip, two probe batches of 64 go out back to back (8 sectors in flight per quad), results land coalesced.
 __global__ __launch_bounds__(256) void k_lookup_bytes9(TableView T, const uint8_t* __restrict__ bytes, const uint32_t* __restrict__ tails,
-                                                       uint32_t n_bytes, uint32_t* __restrict__ hits) {
+                                                       uint32_t n_bytes, uint32_t* __restrict__ hits, uint32_t miss) {
     __shared__ uint8_t lds[4][144];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
     uint8_t* wb = lds[wv];
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void k_lookup_bytes9(TableView T, const uint8_
             if (ok) valid = locate(T, key, local, tag) ? 1u : 0u;
             probe_issue(T, local, tag | (valid << 31), lane, B[h]);
         }
-        probe_eval_multi<2>(T, B, 0u, lane, res);
+        probe_eval_multi<2>(T, B, miss, lane, res);
         if (j == 0) {
 #pragma unroll
             for (int h = 0; h < 2; h++)
@@ -169,7 +170,8 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
     if (!ix || !tx || (n_reads && (!read_frags || !out_taxon || !out_status)) || (n_fragments && !frag_offsets))
         return fail(UMGAP_ERR_INVALID, "umgap_classify_records: null argument");
     if (ix->bound_to) return fail(UMGAP_ERR_INVALID, "the index is bound to a taxonomy (umgap_index_bind_taxonomy): its values are interval codes, not taxon ids; unbind it first");
-    if (ix->kind != 9) return fail(UMGAP_ERR_INVALID, "umgap_classify_records: not a 9-mer index");
+    if (ix->kind != 9 && ix->kind != 10) return fail(UMGAP_ERR_INVALID, "umgap_classify_records: not a 9-mer index");
+    const bool walk = ix->kind == 10;   // window numbers -> taxa through the walk array (index_walk.hip) before the hits are used
     if (ix->device != tx->device) return fail(UMGAP_ERR_INVALID, "umgap_classify_records: index and taxonomy live on different devices");
     if (method != UMGAP_METHOD_TREE && method != UMGAP_METHOD_RMQ) return fail(UMGAP_ERR_INVALID, "unknown method");
     if (strategy < 0 || strategy > 2) return fail(UMGAP_ERR_INVALID, "unknown strategy");
@@ -271,7 +273,8 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
         if (nf) hipLaunchKernelGGL(k_frag_prepare, dim3(gf), dim3(256), 0, s, L.off, (size_t)nf, base + b0, (uint32_t)nb, L.fstart, L.flen, L.tails, L.bad);
         if (nb) {
             const unsigned gb = (unsigned)std::min<uint64_t>((nb + 511) / 512, 2048);
-            hipLaunchKernelGGL(k_lookup_bytes9, dim3(gb), dim3(256), 0, s, T, L.bytes, L.tails, (uint32_t)nb, L.hits);
+            hipLaunchKernelGGL(k_lookup_bytes9, dim3(gb), dim3(256), 0, s, T, L.bytes, L.tails, (uint32_t)nb, L.hits, walk ? UMGAP_NONE : 0u);
+            if (walk && (rc = walk_map_positions(ix, L.hits, (size_t)nb, 0u, s))) break;
         }
         if (seedextend && nf)
             hipLaunchKernelGGL(k_seedextend_frags, dim3(gf), dim3(256), 0, s, L.fstart, L.flen, (size_t)nf, min_seed_size, max_gap_size, L.hits, L.kept);
