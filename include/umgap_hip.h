@@ -408,9 +408,10 @@ int umgap_index_build_windows9_dev(const uint8_t* d_bytes, const uint64_t* d_off
                                    double load_factor, int device, umgap_index** out);
 /* The same index in WALK order (round 3; umgap_index_kind() = 10).  Consecutive 9-mers of a protein share eight residues, but a
  * hash table sends each to a bucket of its own: one 64-byte request per window.  Built from the proteome itself -- fragments in
- * the order given, as umgap_index_build_windows9_dev takes them, same values (smallest taxon on duplicate 9-mers) -- the table
- * maps a 9-mer to the number of the first window that holds it and a walk array keeps, per window of the proteome, the taxon
- * beside the low key bits and a "continues the previous window" flag.  A run of read windows that follows the proteome is then
+ * the order given, as umgap_index_build_windows9_dev takes them, same values (smallest taxon on duplicate 9-mers) -- a walk array
+ * lists every distinct 9-mer once, at the first window of the proteome that holds it, in proteome order: the taxon beside the low
+ * key bits and a "the entry in front is the previous window of the same fragment" flag; the table maps a 9-mer to the number of
+ * its entry (umgap_walk_builder_* below is the general form: values from any 9-mer table).  A run of read windows that follows the proteome is then
  * answered by one probe plus the few sectors of the walk array behind the position it returned, each step verified (exact: the
  * low key bits of entries t and t - 3, or of entry t next to a verified t - 1, pin all nine residues of window t); a substituted
  * residue costs the nine windows that hold it, which are probed one by one, and the walk goes on behind them.
@@ -425,6 +426,22 @@ int umgap_index_build_windows9_dev(const uint8_t* d_bytes, const uint64_t* d_off
 int umgap_index_build_walk9_dev(const uint8_t* d_bytes, const uint64_t* d_offsets, const uint32_t* d_taxa,
                                 size_t n_fragments, uint32_t max_fragment_len, uint64_t expected_keys,
                                 double load_factor, int device, umgap_index** out);
+/* The general builder of a walk-order index: VALUES from any whole, unbound kind-9 table (e.g. the one umgap_index_builder_* /
+ * `umgap buildindex` make from the reference's TSV, src/commands/buildindex.rs:32-48), ORDER from a proteome handed over in chunks,
+ * in order (device arrays as for umgap_index_build_windows9_dev; fewer than 2^32 - 1 windows per chunk; a chunk's temporary table
+ * costs 16 bytes per window of the chunk).  The walk array lists every key of the values table ONCE: at the first window of the
+ * proteome that holds it, in proteome order, and the keys the proteome never showed behind them as walks of one -- 8 bytes per
+ * distinct key, whatever the redundancy of the proteome; a run of at most 8 repeated 9-mers between two listed windows of a
+ * fragment keeps entries of its own (nothing points at them: they keep a walk through the fragment in one piece), as long as these
+ * stay within an eighth of the keys; windows of the proteome whose 9-mer the values table does not hold get no entry (a miss stays
+ * a miss).  Every answer is that of the values table.  Fewer than 2^32 - 2^22 keys.  `values` must outlive
+ * the builder (it is only read); finish consumes the builder. */
+typedef struct umgap_walk_builder umgap_walk_builder;
+int umgap_walk_builder_new(const umgap_index* values, double load_factor, umgap_walk_builder** out);
+int umgap_walk_builder_add_dev(umgap_walk_builder* b, const uint8_t* d_bytes, const uint64_t* d_offsets, size_t n_fragments,
+                               uint32_t max_fragment_len);
+int umgap_walk_builder_finish(umgap_walk_builder* b, umgap_index** out);
+void umgap_walk_builder_free(umgap_walk_builder* b);
 int umgap_synth_prot_reads_dev(const uint8_t* d_proteome, uint64_t n_proteome_fragments, uint32_t fragment_len,
                                uint64_t seed, uint64_t first_read, size_t n_reads, uint32_t fragments_per_read,
                                uint32_t mutations_per_mille, uint8_t* d_out, int device, void* stream);

@@ -1600,7 +1600,8 @@ def test_walk_index_matches_plain_table(api, torch_cuda, mutations_per_mille):
         fp, fw = os.path.join(td, "plain.ix"), os.path.join(td, "walk.ix")
         plain.save(fp)
         walk.save(fw)
-        assert os.path.getsize(fw) == os.path.getsize(fp) + 8 * n_win
+        n_entries = (os.path.getsize(fw) - os.path.getsize(fp)) // 8      # the walk array: one entry per distinct 9-mer + kept repeats
+        assert 0 < n_entries <= n_win and (os.path.getsize(fw) - os.path.getsize(fp)) % 8 == 0
         walk2 = Index.open(fw)
         assert walk2.kind == 10 and walk2.num_keys == plain.num_keys
         with pytest.raises(api.UmgapError):
@@ -1629,9 +1630,120 @@ def test_walk_index_matches_plain_table(api, torch_cuda, mutations_per_mille):
                 assert r.returncode == 0, r.stderr
                 outs.append(r.stdout)
             if args[0] == "printindex":
-                assert sorted(outs[0].splitlines()) == sorted(outs[1].splitlines()) and len(outs[0]) > 0
+                assert sorted(outs[0].splitlines()) == sorted(outs[1].splitlines()) and len(outs[0].splitlines()) <= n_entries <= len(outs[0].splitlines()) * 9 // 8 + 1
             else:
                 assert outs[0] == outs[1] and len(outs[0]) > 0, args
+
+
+@pytest.mark.parametrize("n_chunks,load", [(1, 0.0), (3, 0.0), (5, 0.9)])
+def test_walk_builder_values_from_a_table_order_from_a_proteome(api, torch_cuda, n_chunks, load):
+    """umgap_walk_builder_*: the values come from a kind-9 table (what `umgap buildindex` makes from the reference's TSV), the order
+    from a proteome handed over in chunks.  The table holds only part of the proteome's 9-mers (the others must miss) and keys the
+    proteome never shows (appended as walks of one); fragments repeat within and across chunks (every key is listed once, at its
+    first window).  Every answer -- get() of keys, the windows of reads, the fused pipeline -- is the values table's, bit for bit;
+    the walk array has one entry per key, plus those of short runs of repeats inside a fragment (at most an eighth more; at the
+    high load factor some keys go through the stash and may get a second)."""
+    torch = torch_cuda
+    from umgap_amd.api import Index
+    from umgap_amd.synth import SyntheticWorkload
+    rng = np.random.default_rng(100 + n_chunks)
+    letters = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    w = SyntheticWorkload(n_tax=3000, n_keys=1000, build_index=False)
+    frags = []
+    for i in range(12_000):
+        n = int(rng.choice([0, 5, 9, 12, 30, 50, 50, 80, 200]))
+        f = bytearray(rng.choice(letters[:int(rng.choice([2, 20, 20]))], n).tobytes())      # two-letter stretches: repeated 9-mers, equal low key bits
+        if n > 12 and rng.random() < 0.05:
+            f[int(rng.integers(0, n))] = int(rng.choice([42, 120]))
+        frags.append(bytes(f))
+    frags += [frags[int(i)] for i in rng.integers(0, len(frags), 4000)]
+    order = rng.permutation(len(frags))
+    frags = [frags[int(i)] for i in order]
+    def keys_of(f):
+        out = []
+        for i in range(max(0, len(f) - 8)):
+            k, ok = 0, True
+            for c in f[i:i + 9]:
+                ok = ok and 65 <= c <= 90
+                k = (k << 5) | ((c - 65) & 31)
+            if ok:
+                out.append(k)
+        return out
+    prot_keys = np.unique(np.array([k for f in frags for k in keys_of(f)], np.uint64))
+    keep = prot_keys[rng.random(len(prot_keys)) < 0.8]
+    extra = np.setdiff1d(np.unique(rng.integers(0, 20 ** 9, 6000, dtype=np.uint64) * 7 % (1 << 45)), prot_keys)
+    extra = extra[[all(((int(k) >> (5 * j)) & 31) < 26 for j in range(9)) for k in extra]]
+    vkeys = np.concatenate([keep, extra])
+    vtaxa = rng.choice(w.ids, len(vkeys)).astype(np.uint32)
+    values = Index.build(vkeys, vtaxa, load_factor=load)
+    cuts = np.linspace(0, len(frags), n_chunks + 1).astype(int)
+    chunks, keepalive = [], []
+    for c in range(n_chunks):
+        part = frags[cuts[c]:cuts[c + 1]]
+        data, offs = api._concat(part)
+        d_b = torch.from_numpy(np.concatenate([data, np.zeros(1, np.uint8)])).cuda()
+        d_o = torch.from_numpy(offs.view(np.int64).copy()).cuda()
+        chunks.append((d_b, d_o, max(9, max((len(f) for f in part), default=9))))
+    walk = Index.build_walk(values, chunks, load_factor=load)
+    assert walk.kind == 10 and walk.num_keys == len(vkeys)
+    # get(): every key of the table, the proteome's keys the table does not hold, random keys
+    q = np.concatenate([vkeys, np.setdiff1d(prot_keys, keep), np.unique(rng.integers(0, 1 << 45, 3000, dtype=np.uint64))])
+    ref = dict(zip(vkeys.tolist(), vtaxa.tolist()))
+    want = np.array([ref.get(int(k), 7) for k in q], np.uint32)
+    d_q = torch.from_numpy(q.view(np.int64)).cuda()
+    got_plain = values.lookup9_dev(d_q, miss_value=7).cpu().numpy().view(np.uint32)
+    got_walk = walk.lookup9_dev(d_q, miss_value=7).cpu().numpy().view(np.uint32)
+    assert np.array_equal(got_plain, want) and np.array_equal(got_walk, want)
+    assert np.array_equal(walk.lookup9(q, miss_value=7), want)
+    # the dump lists every key once with its taxon
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        fw = os.path.join(td, "w.ix")
+        walk.save(fw)
+        with open(fw, "rb") as f:
+            hdr = f.read(72)
+        n_walk = int(np.frombuffer(hdr[64:72], np.uint64)[0])
+        assert len(vkeys) <= n_walk <= len(vkeys) + len(vkeys) // 8 + (0 if load < 0.8 else len(vkeys) // 50), (n_walk, len(vkeys))
+        again = Index.open(fw)
+        assert np.array_equal(again.lookup9(q, miss_value=7), want)
+        again.close()
+    # reads cut from the proteome (with a changed residue now and then): windows and the fused pipeline
+    n_reads, F = 2500, 2
+    rfr = []
+    for r in range(n_reads * F):
+        f = bytearray(frags[int(rng.integers(0, len(frags)))])
+        if len(f) > 0 and rng.random() < 0.5:
+            f[int(rng.integers(0, len(f)))] = int(rng.choice(letters))
+        a, b = (0, len(f)) if rng.random() < 0.6 else sorted(rng.integers(0, len(f) + 1, 2).tolist())
+        rfr.append(bytes(f[a:min(b, a + 60)]))
+    rdata = np.frombuffer(b"".join(rfr) + b"A", np.uint8)[:-1]
+    roffs = np.zeros(len(rfr) + 1, np.int64)
+    roffs[1:] = np.cumsum([len(f) for f in rfr])
+    d_r, d_ro = torch.from_numpy(rdata.copy()).cuda(), torch.from_numpy(roffs).cuda()
+    ooffs = np.zeros(len(rfr) + 1, np.int64)
+    ooffs[1:] = np.cumsum([max(0, len(f) - 8) for f in rfr])
+    d_oo = torch.from_numpy(ooffs).cuda()
+    h0 = torch.full((int(ooffs[-1]),), -3, dtype=torch.int32, device="cuda")
+    h1 = torch.full_like(h0, -5)
+    values.lookup_prot9_dev(d_r, d_ro, d_oo, h0, miss_value=0)
+    walk.lookup_prot9_dev(d_r, d_ro, d_oo, h1, miss_value=0)
+    torch.cuda.synchronize()
+    assert torch.equal(h0, h1) and 0.2 < (h0 != 0).float().mean().item() < 0.95
+    for method, strategy, lb, se in (("tree", "lca*", 2.0, False), ("rmq", "mrtl", 1.0, True), ("tree", "hybrid", 0.0, True)):
+        outs = []
+        for ix in (values, walk):
+            t = torch.full((n_reads,), -1, dtype=torch.int32, device="cuda")
+            st = torch.full_like(t, -1)
+            api.classify_prot9_dev(ix, w.taxonomy, d_r, d_ro, n_reads, F, t, st, method=method, strategy=strategy, factor=0.25, lower_bound=lb,
+                                   seedextend=se, min_seed_size=2, max_gap_size=1)
+            outs.append((t, st))
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][0], outs[1][0]), (method, strategy)
+    # a second builder over a bound or sharded values table is refused
+    values.bind(w.taxonomy)
+    with pytest.raises(api.UmgapError):
+        Index.build_walk(values, chunks[:1])
+    values.unbind(w.taxonomy)
 
 
 def test_classify_prot9_ragged_fragments(api, torch_cuda):

@@ -119,6 +119,25 @@ class Index:
         return cls(h.value)
 
     @classmethod
+    def build_walk(cls, values, chunks, load_factor=0.0):
+        """The walk-order form (kind 10) of the kind-9 index `values`: order from a proteome given as an iterable of chunks
+        (d_bytes uint8, d_offsets int64, both torch CUDA tensors; max_fragment_len), in proteome order (include/umgap_hip.h:
+        umgap_walk_builder_*).  Same answers as `values`."""
+        L = _lib.load()
+        b = C.c_void_p()
+        check(L.umgap_walk_builder_new(values._h, load_factor, C.byref(b)))
+        try:
+            for d_bytes, d_offsets, max_len in chunks:
+                check(L.umgap_walk_builder_add_dev(b, _dev_ptr(d_bytes), _dev_ptr(d_offsets), d_offsets.numel() - 1, max_len))
+            h = C.c_void_p()
+            check(L.umgap_walk_builder_finish(b, C.byref(h)))
+            b = None
+            return cls(h.value)
+        finally:
+            if b is not None:
+                L.umgap_walk_builder_free(b)
+
+    @classmethod
     def open(cls, path, device=0, shard=0, n_shards=1):
         h = C.c_void_p()
         check(_lib.load().umgap_index_open_shard(str(path).encode(), 1 << device, shard, n_shards, C.byref(h)))

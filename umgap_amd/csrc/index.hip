@@ -17,8 +17,6 @@
 namespace umgap {
 void var_free(umgap_var_index* v);
 // index_walk.hip
-int walk_fill(umgap_index* t1, const uint8_t* d_bytes, const uint64_t* d_offsets, const uint64_t* d_wbase, size_t n_fragments, uint32_t max_fragment_len,
-              uint64_t* d_E, hipStream_t s);
 int walk_map_positions(const umgap_index* ix, uint32_t* d_vals, size_t n, uint32_t miss, hipStream_t s);
 int walk_lookup_prot9(const umgap_index* ix, const uint8_t* d_bytes, const uint64_t* d_offsets, const uint64_t* d_out_offsets, size_t n_prot, size_t n_windows,
                       uint32_t miss, uint32_t* d_out, hipStream_t s);
@@ -305,6 +303,207 @@ __global__ __launch_bounds__(256) void k_insert_windows(uint64_t* __restrict__ s
     }
 }
 
+// ---- the walk-order index (kind 10, index_walk.hip) built from a VALUES table and a proteome handed over in chunks ----
+constexpr uint32_t WALK_KEEP_REPEATS = 8;   // a run of up to that many repeated 9-mers inside a fragment keeps its entries (one sector of the walk array)
+// T = the position table under construction (whole table, no halo yet: chains wrap; its stash is still a raw list, so a key that
+// went there is not seen here -- umgap_walk_builder_finish keeps the first of the entries such a key then gets).
+__device__ __forceinline__ uint32_t lane_get_wrap(const uint64_t* __restrict__ slots, uint32_t m, uint32_t nb, uint64_t key, uint32_t miss) {
+    uint32_t b, tag;
+    probe_of_key(key, m, b, tag);
+    for (uint32_t d = 0; d <= MAX_DISP; d++) {
+        uint32_t bucket = b + d;
+        if (bucket >= nb) bucket -= nb;
+        const uint4* p = reinterpret_cast<const uint4*>(slots + (size_t)bucket * SLOTS);
+        const uint4 e0 = p[0], e1 = p[1], e2 = p[2], e3 = p[3];
+        const uint32_t want = tag | (d << R_BITS);
+#define UMGAP_CMP(E)                                   \
+    if ((E.x & TAG_MASK) == want) return E.y;          \
+    if ((E.z & TAG_MASK) == want) return E.w;
+        UMGAP_CMP(e0) UMGAP_CMP(e1) UMGAP_CMP(e2) UMGAP_CMP(e3)
+#undef UMGAP_CMP
+        if (!(e0.x != 0xFFFFFFFFu && (e0.x >> 31))) return miss;
+    }
+    return miss;
+}
+// key of the window at bytes[at .. at + 9); false: a byte outside 'A'..'Z'
+__device__ __forceinline__ bool window_key9(const uint8_t* __restrict__ bytes, uint64_t at, uint64_t& key) {
+    key = 0;
+    bool ok = true;
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+        const uint32_t ch = (uint32_t)bytes[at + c] - 'A';
+        ok = ok && ch < 26u;
+        key = (key << 5) | (ch & 31u);
+    }
+    return ok;
+}
+// pass 1: the chunk's temporary table C, key -> smallest window number (local to the chunk) among the windows whose key the values
+// table holds and the position table does not hold yet: the chunk's candidates for "first window of the proteome with that key"
+__global__ __launch_bounds__(256) void k_walk_candidates(uint64_t* __restrict__ slots, uint32_t m, uint32_t nb, const uint8_t* __restrict__ bytes,
+                                                         const uint64_t* __restrict__ off, const uint64_t* __restrict__ wbase, size_t n_frag, uint32_t max_len,
+                                                         BuildFlags* flags, TableView V, const uint64_t* __restrict__ t_slots, uint32_t t_m, uint32_t t_nb) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, total = n_frag * max_len;
+    for (; g < total; g += stride) {
+        const size_t i = g / max_len;
+        const uint32_t w = (uint32_t)(g % max_len);
+        const uint64_t o = off[i], len = off[i + 1] - o;
+        if (len < 9 || w + 9 > len) continue;
+        uint64_t key;
+        if (!window_key9(bytes, o + w, key)) continue;
+        if (lane_get(V, key, UMGAP_NONE) == UMGAP_NONE) continue;                      // not a key of the index: answered by a miss of the table
+        if (lane_get_wrap(t_slots, t_m, t_nb, key, UMGAP_NONE) != UMGAP_NONE) continue; // an earlier chunk listed it
+        const uint32_t val = (uint32_t)(wbase[i] + w);
+        uint32_t b, tag;
+        probe_of_key(key, m, b, tag);
+        bool done = false;
+        for (uint32_t d = 0; d <= MAX_DISP && !done; d++) {
+            uint32_t bucket = b + d;
+            if (bucket >= nb) bucket -= nb;
+            uint64_t* s = slots + (size_t)bucket * SLOTS;
+            const uint32_t lo = tag | (d << R_BITS);
+            const uint64_t entry = ((uint64_t)val << 32) | lo;
+            for (uint32_t k = 0; k < SLOTS && !done; k++) {
+                unsigned long long old = atomicCAS((unsigned long long*)(s + k), (unsigned long long)EMPTY_SLOT, (unsigned long long)entry);
+                if (old == EMPTY_SLOT) done = true;
+                else if (((uint32_t)old & TAG_MASK) == lo) { atomicMin(reinterpret_cast<uint32_t*>(s + k) + 1, val); done = true; }
+            }
+            if (!done) atomicOr((unsigned long long*)s, (unsigned long long)OVF_BIT);
+        }
+        if (!done) atomicAdd(&flags->too_full, 1ull);
+    }
+}
+// pass 2: flag[local window] = 1 where the window is the one C names for its key (so: a key of the index, new, first in the chunk);
+// 3 where it holds a key of the index that is listed elsewhere (a repeat: pass 3 decides whether it keeps an entry of its own)
+__global__ __launch_bounds__(256) void k_walk_flags(TableView C, TableView V, const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ off, const uint64_t* __restrict__ wbase,
+                                                    size_t n_frag, uint32_t max_len, uint8_t* __restrict__ flag) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, total = n_frag * max_len;
+    for (; g < total; g += stride) {
+        const size_t i = g / max_len;
+        const uint32_t w = (uint32_t)(g % max_len);
+        const uint64_t o = off[i], len = off[i + 1] - o;
+        if (len < 9 || w + 9 > len) continue;
+        const uint32_t local = (uint32_t)(wbase[i] + w);
+        uint64_t key;
+        uint8_t fl = 0;
+        if (window_key9(bytes, o + w, key)) {
+            if (lane_get(C, key, UMGAP_NONE) == local) fl = 1;
+            else if (lane_get(V, key, UMGAP_NONE) != UMGAP_NONE) fl = 3;
+        }
+        flag[local] = fl;
+    }
+}
+// pass 3: a run of at most `gap` repeats between two listed windows of a fragment KEEPS its entries (flag 2: an entry nothing points
+// at, there so that a walk through the fragment is not cut by a 9-mer that happens to occur earlier in the proteome); longer runs,
+// and runs at the ends of a fragment, are dropped (flag 0: the walk array stays near one entry per key however redundant the
+// proteome).  gap = 0 drops every repeat, kept ones of an earlier call included.  cnt[f] = entries of fragment f.
+__global__ __launch_bounds__(256) void k_walk_keep_short_repeats(uint8_t* __restrict__ flag, const uint64_t* __restrict__ wbase, size_t n_frag, uint32_t gap, uint32_t* __restrict__ cnt,
+                                                                 unsigned long long* __restrict__ n_kept) {
+    size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; f < n_frag; f += step) {
+        const uint64_t p0 = wbase[f], p1 = wbase[f + 1];
+        uint32_t c = 0, kept = 0;
+        uint64_t p = p0;
+        while (p < p1) {
+            const uint8_t fl = flag[p];
+            if (fl == 1) { c++; p++; continue; }
+            if (fl == 0) { p++; continue; }
+            uint64_t q = p;                                   // a run of repeats (3, or 2 from an earlier call) [p, q)
+            while (q < p1 && flag[q] >= 2) q++;
+            const bool keep = gap && q - p <= gap && p > p0 && flag[p - 1] != 0 && q < p1 && flag[q] == 1;
+            for (uint64_t t = p; t < q; t++) flag[t] = keep ? 2 : 0;
+            if (keep) { c += (uint32_t)(q - p); kept += (uint32_t)(q - p); }
+            p = q;
+        }
+        cnt[f] = c;
+        if (kept) atomicAdd(n_kept, (unsigned long long)kept);
+    }
+}
+// pass 4: a thread walks its fragment; every flagged window gets the next entry of the walk array (taxon from the values table,
+// low key bits, "continues" iff the previous window of the fragment was flagged too, i.e. is the entry in front) and, when it is
+// the key's first, goes into the position table under that entry's number
+__global__ __launch_bounds__(256) void k_walk_emit(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ off, const uint64_t* __restrict__ wbase,
+                                                   const uint64_t* __restrict__ fbase, const uint8_t* __restrict__ flag, size_t n_frag, TableView V,
+                                                   uint64_t* __restrict__ E, uint64_t e0, uint64_t* __restrict__ t_slots, uint32_t t_m, uint32_t t_nb,
+                                                   BuildFlags* flags, uint64_t* __restrict__ stash) {
+    size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; f < n_frag; f += step) {
+        const uint64_t p0 = wbase[f], nw = wbase[f + 1] - p0, o = off[f];
+        uint64_t at = e0 + fbase[f];
+        bool prev = false;
+        for (uint64_t w = 0; w < nw; w++) {
+            if (!flag[p0 + w]) { prev = false; continue; }
+            uint64_t key;
+            (void)window_key9(bytes, o + w, key);
+            const uint32_t taxon = lane_get(V, key, 0u);
+            const uint32_t lo = ((uint32_t)key & 0x7FFFFFFFu) | (prev ? 0x80000000u : 0u);
+            E[at] = (uint64_t)taxon | ((uint64_t)lo << 32);
+            if (flag[p0 + w] == 1) insert_one(t_slots, t_m, t_nb, 0u, t_nb, key, (uint32_t)at, flags, stash);   // (2: a kept repeat, listed elsewhere)
+            at++;
+            prev = true;
+        }
+    }
+}
+// inverse of mix45 (common.hpp) with the inverses of its two odd constants handed in
+__device__ __forceinline__ uint64_t unmix45_dev(uint64_t h, uint64_t inv_c1, uint64_t inv_c2) {
+    h ^= h >> 24;
+    h = (h * inv_c2) & MASK45;
+    h ^= (h >> 21) ^ (h >> 42);
+    h = (h * inv_c1) & MASK45;
+    h ^= h >> 23;
+    return h;
+}
+// the keys of the values table (slots, then its stash) that the position table does not hold: the proteome never showed them.
+// keys == nullptr: count only.
+__global__ __launch_bounds__(256) void k_walk_leftovers(TableView V, TableView T, uint64_t inv_c1, uint64_t inv_c2, uint64_t* __restrict__ keys,
+                                                        uint32_t* __restrict__ taxa, unsigned long long* __restrict__ n_out) {
+    const size_t n_slots = (size_t)V.nb * SLOTS, total = n_slots + V.n_stash;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < total; i += step) {
+        uint64_t h;
+        uint32_t taxon;
+        if (i < n_slots) {
+            const uint64_t e = V.slots[i];
+            if (e == EMPTY_SLOT) continue;
+            const uint32_t lo = (uint32_t)e, d = (lo >> R_BITS) & 7u, r = lo & R_MASK;
+            const uint64_t bucket = i / SLOTS, home = (bucket + V.nb - d) % V.nb;
+            h = ((home / V.m) << R_BITS) | r;
+            taxon = (uint32_t)(e >> 32);
+        } else {
+            const uint64_t sk = V.stash_keys[i - n_slots];
+            h = (((sk >> R_BITS) / V.m) << R_BITS) | (sk & R_MASK);
+            taxon = V.stash_vals[i - n_slots];
+        }
+        const uint64_t key = unmix45_dev(h, inv_c1, inv_c2);
+        if (lane_get(T, key, UMGAP_NONE) != UMGAP_NONE) continue;
+        const unsigned long long at = atomicAdd(n_out, 1ull);
+        if (keys) { keys[at] = key; taxa[at] = taxon; }
+    }
+}
+// the leftovers as walks of one entry each behind the proteome's
+__global__ __launch_bounds__(256) void k_walk_append(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ taxa, size_t n, uint64_t* __restrict__ E, uint64_t e0,
+                                                     uint32_t* __restrict__ pos) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) {
+        E[e0 + i] = (uint64_t)taxa[i] | ((uint64_t)((uint32_t)keys[i] & 0x7FFFFFFFu) << 32);
+        pos[i] = (uint32_t)(e0 + i);
+    }
+}
+// first fragment whose windows start at or behind c * per (chunk cuts of a proteome by window count)
+__global__ void k_walk_cuts(const uint64_t* __restrict__ wbase, size_t n_frag, uint64_t per, uint32_t n_cuts, uint64_t* __restrict__ cuts) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cuts) return;
+    const uint64_t target = (uint64_t)c * per;
+    size_t lo = 0, hi = n_frag;
+    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (wbase[mid] < target) lo = mid + 1; else hi = mid; }
+    cuts[c] = lo;
+}
+
 // Partition a batch of keys by owner shard for the all-to-all exchange: key i goes to slot
 // perm[i] = owner*cap + position of `send`; `cursor[o]` counts arrivals per owner.
 // A workgroup handles a tile of 4096 keys: positions inside the tile are handed out through LDS
@@ -456,6 +655,11 @@ __global__ void k_fill(uint64_t* p, size_t n, uint64_t v) {
     for (; i < n; i += stride) p[i] = v;
 }
 
+inline uint64_t inv_odd45(uint64_t c) {  // inverse of an odd constant modulo 2^45 (Newton)
+    uint64_t x = c;
+    for (int i = 0; i < 6; i++) x *= 2 - c * x;
+    return x & MASK45;
+}
 inline int grid_for(size_t n, int per_block = 256, int max_blocks = 256 * 8) {
     size_t g = (n + per_block - 1) / per_block;
     if (g < 1) g = 1;
@@ -1028,49 +1232,236 @@ int umgap_index_build_windows9_dev(const uint8_t* d_bytes, const uint64_t* d_off
     return UMGAP_OK;
 }
 
-// The 9-mer index of a proteome in WALK order (index_walk.hip): the table maps a 9-mer to the number p of the first window of
-// the proteome that holds it, and E[p] holds the taxon (smallest taxon over the fragments that hold the 9-mer, as
-// umgap_index_build_windows9_dev) beside the low key bits and a "continues the previous window" flag.
+// ---- The 9-mer index in WALK order (kind 10, index_walk.hip), built from a VALUES table (key -> taxon: any kind-9 index, e.g. the
+// one `umgap buildindex` makes from the reference's TSV) and a proteome handed over in chunks, in order.  The position table maps a
+// key to the number p of its entry E[p] in the walk array; E lists every key ONCE, at the first window of the proteome that holds
+// it, in proteome order ("continues" = the entry in front is the previous window of the same protein), and the keys the proteome
+// never showed behind them as walks of one.  Keys of the proteome that the values table does not hold get no entry: they miss.
+}  // extern "C"
+struct umgap_walk_builder {
+    const umgap_index* values = nullptr;   // not owned
+    umgap_index* ix = nullptr;             // position table + walk array under construction
+    BuildFlags* d_flags = nullptr;
+    uint64_t* d_stash = nullptr;
+    uint64_t cap_walk = 0, n_walk = 0;
+    uint64_t slack = 0, n_kept = 0;        // entries the array may spend on kept repeats (k_walk_keep_short_repeats), and has
+};
+namespace {
+// the raw stash list of a table under construction -> its sorted stash (a key that went there twice -- see lane_get_wrap -- keeps
+// its first entry) and the halo
+int walk_finalize_table(umgap_walk_builder* b) {
+    umgap_index* x = b->ix;
+    BuildFlags h{};
+    hipError_t e = hipMemcpyAsync(&h, b->d_flags, sizeof(h), hipMemcpyDeviceToHost, x->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(x->stream);
+    if (e != hipSuccess) return fail(UMGAP_ERR_DEVICE, std::string("walk index build: ") + hipGetErrorString(e));
+    if (h.bad_key || h.duplicate) return fail(UMGAP_ERR_BUILD, "walk index build: internal error (a key was listed twice)");
+    if (h.too_full) return fail(UMGAP_ERR_BUILD, "walk index build: position table too full");
+    std::vector<uint64_t> raw(2 * (size_t)h.n_stash);
+    if (h.n_stash && hipMemcpy(raw.data(), b->d_stash, raw.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(UMGAP_ERR_DEVICE, "walk index build: stash copy failed");
+    std::vector<std::pair<uint64_t, uint64_t>> entries(h.n_stash);
+    for (size_t i = 0; i < h.n_stash; i++) entries[i] = {raw[2 * i], raw[2 * i + 1]};
+    std::sort(entries.begin(), entries.end());
+    entries.erase(std::unique(entries.begin(), entries.end(), [](const std::pair<uint64_t, uint64_t>& p, const std::pair<uint64_t, uint64_t>& q) { return p.first == q.first; }), entries.end());
+    int rc = set_stash(x, entries);
+    if (!rc) rc = finish_halo(x);
+    return rc;
+}
+}  // namespace
+extern "C" {
+
+void umgap_walk_builder_free(umgap_walk_builder* b) {
+    if (!b) return;
+    if (b->ix) { (void)use_device(b->ix->device); (void)hipStreamSynchronize(b->ix->stream); }
+    if (b->d_flags) (void)hipFree(b->d_flags);
+    if (b->d_stash) (void)hipFree(b->d_stash);
+    if (b->ix) umgap_index_free(b->ix);
+    delete b;
+}
+
+int umgap_walk_builder_new(const umgap_index* values, double load, umgap_walk_builder** out) {
+    if (!values || !out) return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_new: null argument");
+    if (values->kind != 9 || values->bound_to || values->view.home_lo != 0 || values->view.home_hi != values->view.nb)
+        return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_new: the values must be a whole, unbound 9-mer table");
+    if (values->n_keys + STASH_CAP >= 0xFFFFFFFFull) return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_new: a walk index numbers its entries with 32 bits (fewer than 2^32 - 2^22 keys)");
+    umgap_walk_builder* b = new umgap_walk_builder();
+    b->values = values;
+    int rc = new_handle(values->device, &b->ix);
+    if (rc) { delete b; return rc; }
+    auto bail = [&](int code) { umgap_walk_builder_free(b); return code; };
+    rc = alloc_table(b->ix, choose_m(std::max<uint64_t>(values->n_keys, 1), load), 0, 1);
+    if (rc) return bail(rc);
+    b->slack = std::min<uint64_t>(values->n_keys / 8, 0xFFFFFFFEull - values->n_keys - STASH_CAP);
+    b->cap_walk = values->n_keys + STASH_CAP + b->slack;    // every key once, the second entries of keys that went to the stash, kept repeats
+    if (hipMalloc((void**)&b->d_flags, sizeof(BuildFlags)) != hipSuccess || hipMalloc((void**)&b->d_stash, (size_t)STASH_CAP * 16) != hipSuccess ||
+        hipMalloc((void**)&b->ix->d_walk, b->cap_walk * 8) != hipSuccess)
+        return bail(fail(UMGAP_ERR_NOMEM, "umgap_walk_builder_new: hipMalloc failed"));
+    const size_t nslots = (size_t)b->ix->view.n_resident * SLOTS;
+    hipLaunchKernelGGL(k_fill, dim3(grid_for(nslots)), dim3(256), 0, b->ix->stream, b->ix->d_slots, nslots, EMPTY_SLOT);
+    if (hipMemsetAsync(b->d_flags, 0, sizeof(BuildFlags), b->ix->stream) != hipSuccess) return bail(fail(UMGAP_ERR_DEVICE, "umgap_walk_builder_new: memset failed"));
+    *out = b;
+    return UMGAP_OK;
+}
+
+// the next chunk of the proteome (fragments in order; d_offsets[0 .. n_fragments] index d_bytes; fewer than 2^32 - 1 windows per chunk)
+int umgap_walk_builder_add_dev(umgap_walk_builder* b, const uint8_t* d_bytes, const uint64_t* d_offsets, size_t n_fragments, uint32_t max_fragment_len) {
+    if (!b || !b->ix || (n_fragments && (!d_bytes || !d_offsets))) return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_add_dev: null argument");
+    if (!n_fragments || max_fragment_len < 9) return UMGAP_OK;
+    umgap_index* x = b->ix;
+    int rc = use_device(x->device);
+    if (rc) return rc;
+    UMGAP_HIP(hipDeviceSynchronize());   // the caller's arrays are read on the builder's stream
+    umgap_index* c = nullptr;
+    uint32_t* d_cnt = nullptr;
+    uint8_t* d_flag = nullptr;
+    uint64_t *d_wbase = nullptr, *d_fbase = nullptr, *d_total = nullptr;
+    auto done = [&](int code) {
+        for (void* p : {(void*)d_cnt, (void*)d_flag, (void*)d_wbase, (void*)d_fbase, (void*)d_total}) if (p) (void)hipFree(p);
+        if (c) umgap_index_free(c);
+        return code;
+    };
+    if (hipMalloc((void**)&d_cnt, n_fragments * 4) != hipSuccess || hipMalloc((void**)&d_wbase, (n_fragments + 1) * 8) != hipSuccess ||
+        hipMalloc((void**)&d_fbase, (n_fragments + 1) * 8) != hipSuccess || hipMalloc((void**)&d_total, 24) != hipSuccess)
+        return done(fail(UMGAP_ERR_NOMEM, "umgap_walk_builder_add_dev: hipMalloc failed"));
+    // the chunk's windows numbered fragment by fragment
+    hipLaunchKernelGGL(k_window_counts, dim3(grid_for(n_fragments)), dim3(256), 0, x->stream, d_offsets, n_fragments, d_cnt);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, x->stream, d_cnt, n_fragments, d_wbase, d_total);
+    uint64_t n_local = 0;
+    hipError_t e = hipMemcpyAsync(&n_local, d_total, 8, hipMemcpyDeviceToHost, x->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(x->stream);
+    if (e != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, std::string("umgap_walk_builder_add_dev: ") + hipGetErrorString(e)));
+    if (n_local >= 0xFFFFFFFFull) return done(fail(UMGAP_ERR_INVALID, "umgap_walk_builder_add_dev: a chunk must hold fewer than 2^32 - 1 windows"));
+    if (!n_local) return done(UMGAP_OK);
+    // C: the chunk's candidates (new keys of the index -> their first window in the chunk)
+    rc = new_handle(x->device, &c);
+    if (rc) return done(rc);
+    const size_t iter = n_fragments * (size_t)max_fragment_len;
+    const TableView V = b->values->view;
+    rc = build_with(c, std::min<uint64_t>(n_local, std::max<uint64_t>(b->values->n_keys, 1)), 0.5, 0, 1, [&](umgap_index* t, BuildFlags* f, uint64_t*) {
+        hipLaunchKernelGGL(k_walk_candidates, dim3(grid_for(iter, 256, 256 * 16)), dim3(256), 0, t->stream, t->d_slots, t->view.m, t->view.nb, d_bytes, d_offsets,
+                           (const uint64_t*)d_wbase, n_fragments, max_fragment_len, f, V, (const uint64_t*)x->d_slots, x->view.m, x->view.nb);
+        return UMGAP_OK;
+    });
+    if (rc) return done(rc);
+    if (hipMalloc((void**)&d_flag, n_local) != hipSuccess) return done(fail(UMGAP_ERR_NOMEM, "umgap_walk_builder_add_dev: hipMalloc failed"));
+    hipLaunchKernelGGL(k_walk_flags, dim3(grid_for(iter, 256, 256 * 16)), dim3(256), 0, x->stream, c->view, V, d_bytes, d_offsets, (const uint64_t*)d_wbase, n_fragments,
+                       max_fragment_len, d_flag);
+    uint64_t n_new = 0, n_keep = 0;
+    for (uint32_t gap : {WALK_KEEP_REPEATS, 0u}) {   // short runs of repeats keep their entries while the array has room for them
+        UMGAP_HIP(hipMemsetAsync(d_total + 2, 0, 8, x->stream));
+        hipLaunchKernelGGL(k_walk_keep_short_repeats, dim3(grid_for(n_fragments)), dim3(256), 0, x->stream, d_flag, (const uint64_t*)d_wbase, n_fragments, gap, d_cnt,
+                           (unsigned long long*)(d_total + 2));
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, x->stream, d_cnt, n_fragments, d_fbase, d_total + 1);
+        uint64_t two[2] = {0, 0};
+        e = hipMemcpyAsync(two, d_total + 1, 16, hipMemcpyDeviceToHost, x->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(x->stream);
+        if (e != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, std::string("umgap_walk_builder_add_dev: ") + hipGetErrorString(e)));
+        n_new = two[0];
+        n_keep = two[1];
+        if (b->n_kept + n_keep <= b->slack) break;
+    }
+    b->n_kept += n_keep;
+    if (b->n_walk + n_new > b->cap_walk) return done(fail(UMGAP_ERR_BUILD, "umgap_walk_builder_add_dev: more entries than the values table has keys (internal error)"));
+    if (n_new)
+        hipLaunchKernelGGL(k_walk_emit, dim3(grid_for(n_fragments)), dim3(256), 0, x->stream, d_bytes, d_offsets, (const uint64_t*)d_wbase, (const uint64_t*)d_fbase,
+                           (const uint8_t*)d_flag, n_fragments, V, x->d_walk, b->n_walk, x->d_slots, x->view.m, x->view.nb, b->d_flags, b->d_stash);
+    e = hipStreamSynchronize(x->stream);
+    if (e != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, std::string("umgap_walk_builder_add_dev: ") + hipGetErrorString(e)));
+    b->n_walk += n_new;
+    return done(UMGAP_OK);
+}
+
+int umgap_walk_builder_finish(umgap_walk_builder* b, umgap_index** out) {
+    if (!b || !b->ix || !out) return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_finish: null argument");
+    umgap_index* x = b->ix;
+    int rc = use_device(x->device);
+    if (rc) return rc;
+    rc = walk_finalize_table(b);
+    if (rc) return rc;
+    // the keys the proteome never showed: appended as walks of one
+    unsigned long long* d_n = nullptr;
+    uint64_t* d_keys = nullptr;
+    uint32_t *d_taxa = nullptr, *d_pos = nullptr;
+    auto done = [&](int code) {
+        for (void* p : {(void*)d_n, (void*)d_keys, (void*)d_taxa, (void*)d_pos}) if (p) (void)hipFree(p);
+        return code;
+    };
+    if (hipMalloc((void**)&d_n, 8) != hipSuccess) return done(fail(UMGAP_ERR_NOMEM, "umgap_walk_builder_finish: hipMalloc failed"));
+    const TableView V = b->values->view;
+    const uint64_t inv1 = inv_odd45(MIX_C1), inv2 = inv_odd45(MIX_C2);
+    const size_t scan = (size_t)V.nb * SLOTS + V.n_stash;
+    unsigned long long n_left = 0;
+    UMGAP_HIP(hipMemsetAsync(d_n, 0, 8, x->stream));
+    hipLaunchKernelGGL(k_walk_leftovers, dim3(grid_for(scan, 256, 256 * 16)), dim3(256), 0, x->stream, V, x->view, inv1, inv2, (uint64_t*)nullptr, (uint32_t*)nullptr, d_n);
+    hipError_t e = hipMemcpyAsync(&n_left, d_n, 8, hipMemcpyDeviceToHost, x->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(x->stream);
+    if (e != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, std::string("umgap_walk_builder_finish: ") + hipGetErrorString(e)));
+    if (n_left) {
+        if (b->n_walk + n_left > b->cap_walk) return done(fail(UMGAP_ERR_BUILD, "umgap_walk_builder_finish: more entries than the values table has keys (internal error)"));
+        if (hipMalloc((void**)&d_keys, n_left * 8) != hipSuccess || hipMalloc((void**)&d_taxa, n_left * 4) != hipSuccess || hipMalloc((void**)&d_pos, n_left * 4) != hipSuccess)
+            return done(fail(UMGAP_ERR_NOMEM, "umgap_walk_builder_finish: hipMalloc failed"));
+        UMGAP_HIP(hipMemsetAsync(d_n, 0, 8, x->stream));
+        hipLaunchKernelGGL(k_walk_leftovers, dim3(grid_for(scan, 256, 256 * 16)), dim3(256), 0, x->stream, V, x->view, inv1, inv2, d_keys, d_taxa, d_n);
+        hipLaunchKernelGGL(k_walk_append, dim3(grid_for(n_left)), dim3(256), 0, x->stream, (const uint64_t*)d_keys, (const uint32_t*)d_taxa, (size_t)n_left, x->d_walk, b->n_walk, d_pos);
+        hipLaunchKernelGGL(k_insert, dim3(grid_for(n_left)), dim3(256), 0, x->stream, x->d_slots, x->view.m, x->view.nb, 0u, x->view.nb, (const uint64_t*)d_keys,
+                           (const uint32_t*)d_pos, (size_t)n_left, b->d_flags, b->d_stash);
+        b->n_walk += n_left;
+        rc = walk_finalize_table(b);   // the stash list and the halo again, now with the appended keys
+        if (rc) return done(rc);
+    }
+    x->kind = 10;
+    x->n_walk = b->n_walk;
+    x->n_keys = b->values->n_keys;
+    *out = x;
+    b->ix = nullptr;
+    umgap_walk_builder_free(b);
+    return done(UMGAP_OK);
+}
+
+// A proteome's own index in walk order: values as umgap_index_build_windows9_dev (the smallest taxon over the fragments that hold
+// a 9-mer), the proteome handed to the builder in chunks of at most 2^29 windows (the chunk's temporary table stays small).
 int umgap_index_build_walk9_dev(const uint8_t* d_bytes, const uint64_t* d_offsets, const uint32_t* d_taxa, size_t n_fragments,
                                 uint32_t max_fragment_len, uint64_t expected_keys, double load, int device, umgap_index** out) {
     if (!out || !n_fragments || !d_bytes || !d_offsets || !d_taxa || max_fragment_len < 9) return fail(UMGAP_ERR_INVALID, "umgap_index_build_walk9_dev: bad argument");
     umgap_index* t1 = nullptr;
     int rc = umgap_index_build_windows9_dev(d_bytes, d_offsets, d_taxa, n_fragments, max_fragment_len, expected_keys, load, device, &t1);   // the values
     if (rc) return rc;
-    umgap_index* ix = nullptr;
+    umgap_walk_builder* b = nullptr;
     uint32_t* d_cnt = nullptr;
-    uint64_t *d_wbase = nullptr, *d_total = nullptr;
+    uint64_t *d_wbase = nullptr, *d_cuts = nullptr;
     auto done = [&](int code) {
-        for (void* p : {(void*)d_cnt, (void*)d_wbase, (void*)d_total}) if (p) (void)hipFree(p);
+        for (void* p : {(void*)d_cnt, (void*)d_wbase, (void*)d_cuts}) if (p) (void)hipFree(p);
+        if (b) umgap_walk_builder_free(b);
         umgap_index_free(t1);
-        if (code && ix) umgap_index_free(ix);
         return code;
     };
-    rc = new_handle(device, &ix);
+    rc = umgap_walk_builder_new(t1, load, &b);
     if (rc) return done(rc);
-    if (hipMalloc((void**)&d_cnt, n_fragments * 4) != hipSuccess || hipMalloc((void**)&d_wbase, (n_fragments + 1) * 8) != hipSuccess || hipMalloc((void**)&d_total, 8) != hipSuccess)
+    hipStream_t s = b->ix->stream;
+    if (hipMalloc((void**)&d_cnt, n_fragments * 4) != hipSuccess || hipMalloc((void**)&d_wbase, (n_fragments + 2) * 8) != hipSuccess)
         return done(fail(UMGAP_ERR_NOMEM, "umgap_index_build_walk9_dev: hipMalloc failed"));
-    // number the windows: fragment f owns windows [wbase[f], wbase[f + 1])
-    hipLaunchKernelGGL(k_window_counts, dim3(grid_for(n_fragments)), dim3(256), 0, ix->stream, d_offsets, n_fragments, d_cnt);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, ix->stream, d_cnt, n_fragments, d_wbase, d_total);
+    hipLaunchKernelGGL(k_window_counts, dim3(grid_for(n_fragments)), dim3(256), 0, s, d_offsets, n_fragments, d_cnt);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, s, d_cnt, n_fragments, d_wbase, d_wbase + n_fragments + 1);
     uint64_t n_windows = 0;
-    hipError_t e = hipMemcpyAsync(&n_windows, d_total, 8, hipMemcpyDeviceToHost, ix->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ix->stream);
+    hipError_t e = hipMemcpyAsync(&n_windows, d_wbase + n_fragments + 1, 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, std::string("umgap_index_build_walk9_dev: ") + hipGetErrorString(e)));
-    if (n_windows >= 0xFFFFFFFFull) return done(fail(UMGAP_ERR_INVALID, "umgap_index_build_walk9_dev: a walk index numbers its windows with 32 bits (fewer than 2^32 - 1 windows)"));
-    rc = build_with(ix, expected_keys, load, 0, 1, [&](umgap_index* x, BuildFlags* f, uint64_t*) {
-        hipLaunchKernelGGL(k_insert_windows, dim3(grid_for(n_fragments * (size_t)max_fragment_len, 256, 256 * 16)), dim3(256), 0, x->stream,
-                           x->d_slots, x->view.m, x->view.nb, d_bytes, d_offsets, (const uint32_t*)nullptr, n_fragments, max_fragment_len, f, (const uint64_t*)d_wbase);
-        return UMGAP_OK;
-    });
+    const uint64_t per = 1ull << 29;
+    const uint32_t n_chunks = (uint32_t)std::max<uint64_t>(1, (n_windows + per - 1) / per);
+    std::vector<uint64_t> cuts(n_chunks + 1, 0);
+    if (hipMalloc((void**)&d_cuts, (n_chunks + 1) * 8) != hipSuccess) return done(fail(UMGAP_ERR_NOMEM, "umgap_index_build_walk9_dev: hipMalloc failed"));
+    hipLaunchKernelGGL(k_walk_cuts, dim3((n_chunks + 255) / 256), dim3(256), 0, s, (const uint64_t*)d_wbase, n_fragments, per, n_chunks, d_cuts);
+    e = hipMemcpyAsync(cuts.data(), d_cuts, n_chunks * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, std::string("umgap_index_build_walk9_dev: ") + hipGetErrorString(e)));
+    cuts[n_chunks] = n_fragments;
+    for (uint32_t c = 0; c < n_chunks && !rc; c++)
+        if (cuts[c + 1] > cuts[c]) rc = umgap_walk_builder_add_dev(b, d_bytes, d_offsets + cuts[c], (size_t)(cuts[c + 1] - cuts[c]), max_fragment_len);
     if (rc) return done(rc);
-    if (hipMalloc((void**)&ix->d_walk, std::max<uint64_t>(n_windows, 1) * 8) != hipSuccess) return done(fail(UMGAP_ERR_NOMEM, "umgap_index_build_walk9_dev: hipMalloc of the walk array failed"));
-    ix->n_walk = n_windows;
-    rc = walk_fill(t1, d_bytes, d_offsets, d_wbase, n_fragments, max_fragment_len, ix->d_walk, ix->stream);
-    if (!rc && hipStreamSynchronize(ix->stream) != hipSuccess) rc = fail(UMGAP_ERR_DEVICE, "umgap_index_build_walk9_dev: the fill failed");
+    umgap_index* ix = nullptr;
+    rc = umgap_walk_builder_finish(b, &ix);
     if (rc) return done(rc);
-    ix->kind = 10;
-    ix->n_keys = t1->n_keys;
+    b = nullptr;   // consumed
     *out = ix;
     return done(UMGAP_OK);
 }
@@ -1174,11 +1565,6 @@ int umgap_index_lookup9(umgap_index* ix, const uint64_t* keys, size_t n, uint32_
 
 // ---- dump (printindex): every (key, taxon) of the table back on the host ------------------------
 namespace {
-inline uint64_t inv_odd45(uint64_t c) {  // inverse of an odd constant modulo 2^45 (Newton)
-    uint64_t x = c;
-    for (int i = 0; i < 6; i++) x *= 2 - c * x;
-    return x & MASK45;
-}
 inline uint64_t unmix45(uint64_t h) {    // inverse of mix45 (common.hpp)
     h ^= h >> 24;
     h = (h * inv_odd45(MIX_C2)) & MASK45;

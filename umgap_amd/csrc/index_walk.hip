@@ -28,28 +28,6 @@ using namespace umgap::probe;
 
 namespace {
 
-__device__ __forceinline__ uint32_t lane_get(const TableView& T, uint64_t key, uint32_t miss) {
-    uint32_t local, tag, res = miss;
-    if (!locate(T, key, local, tag)) return miss;
-    const uint4* p = reinterpret_cast<const uint4*>(T.slots) + (size_t)local * 4;
-    uint32_t want = tag;
-    for (uint32_t d = 0;; d++) {
-        const uint4 e0 = p[0], e1 = p[1], e2 = p[2], e3 = p[3];
-        bool hit = false;
-#define UMGAP_CMP(E)                                                  \
-    if ((E.x & TAG_MASK) == want) { res = E.y; hit = true; }          \
-    if ((E.z & TAG_MASK) == want) { res = E.w; hit = true; }
-        UMGAP_CMP(e0) UMGAP_CMP(e1) UMGAP_CMP(e2) UMGAP_CMP(e3)
-#undef UMGAP_CMP
-        const bool ovf = e0.x != 0xFFFFFFFFu && (e0.x >> 31);
-        if (hit || !ovf) break;
-        if (d == MAX_DISP) { if (T.n_stash) res = stash_lookup(T, local + T.home_lo, tag, miss); break; }
-        p += 4;
-        want += 1u << R_BITS;
-    }
-    return res;
-}
-
 // key of window w of fragment f (fragments of flen bytes back to back); false: a byte outside 'A'..'Z'
 __device__ __forceinline__ bool window_key(const uint8_t* __restrict__ bytes, uint64_t f, uint32_t w, uint32_t flen, uint64_t& key) {
     const uint8_t* p = bytes + f * flen + w;
@@ -62,31 +40,6 @@ __device__ __forceinline__ bool window_key(const uint8_t* __restrict__ bytes, ui
         key = (key << 5) | (ch & 31u);
     }
     return ok;
-}
-
-// E for every window of the proteome: iteration space as k_insert_windows (fragment i, window w < max_len)
-__global__ __launch_bounds__(256) void k_walk_fill(TableView T1, const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ off, const uint64_t* __restrict__ wbase,
-                                                   size_t n_frag, uint32_t max_len, uint64_t* __restrict__ E) {
-    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t stride = (size_t)gridDim.x * blockDim.x, total = n_frag * max_len;
-    for (; g < total; g += stride) {
-        const size_t i = g / max_len;
-        const uint32_t w = (uint32_t)(g % max_len);
-        const uint64_t o = off[i], len = off[i + 1] - o;
-        if (len < 9 || w + 9 > len) continue;
-        uint64_t key = 0;
-        bool ok = true;
-#pragma unroll
-        for (int c = 0; c < 9; c++) {
-            const uint32_t ch = (uint32_t)bytes[o + w + c] - 'A';
-            ok = ok && ch < 26u;
-            key = (key << 5) | (ch & 31u);
-        }
-        uint32_t taxon = 0, lo = 0x7FFFFFFFu;       // low bits 31 (no residue has that code): matches no window
-        if (ok) { taxon = lane_get(T1, key, 0u); lo = (uint32_t)key & 0x7FFFFFFFu; }
-        if (w > 0) lo |= 0x80000000u;
-        E[wbase[i] + w] = (uint64_t)taxon | ((uint64_t)lo << 32);
-    }
 }
 
 // positions (the table's values) -> taxa
@@ -233,14 +186,6 @@ __global__ __launch_bounds__(256) void k_walk_lookup_prot9(TableView H2, const u
 }  // namespace
 
 namespace umgap {
-int walk_fill(umgap_index* t1, const uint8_t* d_bytes, const uint64_t* d_offsets, const uint64_t* d_wbase, size_t n_fragments, uint32_t max_fragment_len,
-              uint64_t* d_E, hipStream_t s) {
-    size_t g = (n_fragments * (size_t)max_fragment_len + 255) / 256;
-    g = std::max<size_t>(1, std::min<size_t>(g, 256 * 16));
-    hipLaunchKernelGGL(k_walk_fill, dim3((unsigned)g), dim3(256), 0, s, t1->view, d_bytes, d_offsets, d_wbase, n_fragments, max_fragment_len, d_E);
-    UMGAP_HIP(hipGetLastError());
-    return UMGAP_OK;
-}
 int walk_lookup_prot9(const umgap_index* ix, const uint8_t* d_bytes, const uint64_t* d_offsets, const uint64_t* d_out_offsets, size_t n_prot, size_t n_windows,
                       uint32_t miss, uint32_t* d_out, hipStream_t s) {
     if (n_windows) hipLaunchKernelGGL(k_walk_lookup_prot9, dim3((unsigned)std::max<size_t>(1, std::min<size_t>((n_windows + 255) / 256, 256 * 8))), dim3(256), 0, s, ix->view,

@@ -144,5 +144,28 @@ __device__ __forceinline__ void wave_probe64_vals(const TableView& T, uint32_t l
     probe_eval(T, B, miss, lane, res);
 }
 
+// one key by ONE lane (build passes, scattered look-ups): the chain walked bucket by bucket, the stash behind it
+__device__ __forceinline__ uint32_t lane_get(const TableView& T, uint64_t key, uint32_t miss) {
+    uint32_t local, tag, res = miss;
+    if (!locate(T, key, local, tag)) return miss;
+    const uint4* p = reinterpret_cast<const uint4*>(T.slots) + (size_t)local * 4;
+    uint32_t want = tag;
+    for (uint32_t d = 0;; d++) {
+        const uint4 e0 = p[0], e1 = p[1], e2 = p[2], e3 = p[3];
+        bool hit = false;
+#define UMGAP_CMP(E)                                                  \
+    if ((E.x & TAG_MASK) == want) { res = E.y; hit = true; }          \
+    if ((E.z & TAG_MASK) == want) { res = E.w; hit = true; }
+        UMGAP_CMP(e0) UMGAP_CMP(e1) UMGAP_CMP(e2) UMGAP_CMP(e3)
+#undef UMGAP_CMP
+        const bool ovf = e0.x != 0xFFFFFFFFu && (e0.x >> 31);
+        if (hit || !ovf) break;
+        if (d == MAX_DISP) { if (T.n_stash) res = stash_lookup(T, local + T.home_lo, tag, miss); break; }
+        p += 4;
+        want += 1u << R_BITS;
+    }
+    return res;
+}
+
 }  // namespace probe
 }  // namespace umgap
