@@ -440,6 +440,8 @@ typedef struct umgap_walk_builder umgap_walk_builder;
 int umgap_walk_builder_new(const umgap_index* values, double load_factor, umgap_walk_builder** out);
 int umgap_walk_builder_add_dev(umgap_walk_builder* b, const uint8_t* d_bytes, const uint64_t* d_offsets, size_t n_fragments,
                                uint32_t max_fragment_len);
+int umgap_walk_builder_add(umgap_walk_builder* b, const uint8_t* bytes, const uint64_t* offsets, size_t n_fragments,
+                           uint32_t max_fragment_len);   /* the same from host memory */
 int umgap_walk_builder_finish(umgap_walk_builder* b, umgap_index** out);
 void umgap_walk_builder_free(umgap_walk_builder* b);
 int umgap_synth_prot_reads_dev(const uint8_t* d_proteome, uint64_t n_proteome_fragments, uint32_t fragment_len,

@@ -980,3 +980,70 @@ def test_buildindex_streaming(tmp_path, block, threads, piped):
         for bad in (lines[:at] + [lines[at - 1]] + lines[at:], lines[:at - 1] + [lines[at], lines[at - 1]] + lines[at + 1:]):
             p = subprocess.run([UMGAP, "buildindex"], input="".join(bad).encode(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
             assert p.returncode == 1 and (b"duplicate key" in p.stderr or b"out-of-order key" in p.stderr), p.stderr
+
+
+def test_buildindex_proteome_gives_a_walk_order_file_with_the_same_answers(world, tmp_path):
+    """`umgap buildindex --proteome proteins.fa` (not in the reference: include/umgap_hip.h, umgap_walk_builder_*): keys and values
+    from the TSV on stdin as always, the file laid out in walk order along the proteins.  Every command must print the same bytes
+    from it as from the plain file, and as the oracle from the TSV: the proteins hold some of the index's 9-mers (overlapping, so
+    walks exist), many 9-mers the index does not hold, wrapped sequence lines, and most of the index's keys never occur in them."""
+    rng = np.random.default_rng(11)
+    kmers = world["kmers"]
+    proteins = []
+    for i in range(300):
+        parts = []
+        for _ in range(int(rng.integers(1, 6))):
+            c = rng.random()
+            if c < 0.5:
+                parts.append(kmers[int(rng.integers(0, len(kmers)))])
+            else:
+                parts.append("".join(rng.choice(list(LETTERS), int(rng.integers(0, 40)))))
+        proteins.append("".join(parts))
+    proteins += proteins[:40]                                          # repeated proteins: every key still listed once
+    # an index whose keys also cover whole stretches of some proteins (consecutive windows: walks of more than one entry)
+    extra = {}
+    for prot in proteins[:120]:
+        for i in range(0, max(0, len(prot) - 8)):
+            if all(c in LETTERS for c in prot[i:i + 9]):
+                extra[prot[i:i + 9]] = int(rng.choice(world["ids"]))
+    tsv_lines = {}
+    with open(world["idx_tsv"]) as f:
+        for line in f:
+            k, v = line.rstrip("\n").split("\t")
+            tsv_lines[k] = int(v)
+    tsv_lines.update({k: v for k, v in extra.items() if k not in tsv_lines})
+    idx_tsv = str(tmp_path / "index2.tsv")
+    with open(idx_tsv, "w") as f:
+        for k in sorted(tsv_lines):
+            f.write("%s\t%d\n" % (k, tsv_lines[k]))
+    fa = str(tmp_path / "proteins.fa")
+    with open(fa, "w") as f:
+        for i, prot in enumerate(proteins):
+            f.write(">sp|P%05d|X\n" % i)
+            for o in range(0, len(prot), 60):                          # wrapped at 60 columns like UniProt's files
+                f.write(prot[o:o + 60] + "\n")
+    plain, walk = str(tmp_path / "plain.ix"), str(tmp_path / "walk.ix")
+    for out, args in ((plain, ["buildindex"]), (walk, ["buildindex", "--proteome", fa])):
+        with open(idx_tsv, "rb") as fin, open(out, "wb") as fout:
+            p = subprocess.run([UMGAP] + args, stdin=fin, stdout=fout, stderr=subprocess.PIPE)
+        assert p.returncode == 0, p.stderr
+    assert os.path.getsize(walk) >= os.path.getsize(plain) + 8 * len(tsv_lines)
+    rc, out, _ = run(["printindex", walk])
+    assert rc == 0 and sorted(out.decode().splitlines()) == ["%s\t%d" % (k, tsv_lines[k]) for k in sorted(tsv_lines)]
+    reads = "".join(">r%d\n%s\n" % (i, proteins[int(rng.integers(0, len(proteins)))][int(rng.integers(0, 5)):]) for i in range(400)).encode()
+    for args in (["prot2kmer2lca", "-o"], ["prot2kmer2lca"], ["prot2kmer2lca", "-m", "-o"]):
+        rc0, out0, _ = run(args + [plain], reads)
+        rc1, out1, err1 = run(args + [walk], reads)
+        orc, oout, _ = O.run_cli(args + [idx_tsv], reads)
+        assert rc0 == rc1 == orc == 0 and out0 == out1 == oout, (args, err1)
+    pep = _peptide_fasta({"kmers": sorted(tsv_lines)}, 200, rng)
+    for flags in ([], ["-o"]):
+        rc0, out0, _ = run(["pept2lca"] + flags + [plain], pep)
+        rc1, out1, _ = run(["pept2lca"] + flags + [walk], pep)
+        assert rc0 == rc1 == 0 and out0 == out1
+    rc0, out0, _ = run(["prot2kmer2agg", "-l", "1", plain, world["tsv"]], reads)
+    rc1, out1, err1 = run(["prot2kmer2agg", "-l", "1", walk, world["tsv"]], reads)
+    assert rc0 == rc1 == 0 and out0 == out1 and len(out0) > 0, err1
+    rc, _, err = run(["buildindex", "--proteome", "/nonexistent"], b"")
+    assert rc == 1 and err.startswith(b"Error: ")
+

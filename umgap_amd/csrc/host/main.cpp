@@ -1405,9 +1405,18 @@ void parse_index_part(const char* d, size_t begin, size_t end, int pass, bool wa
 }
 
 int cmd_buildindex(const std::vector<std::string>& args) {
-    Parsed p = parse_args(args, {{'l', "load-factor", true}});
+    Parsed p = parse_args(args, {{'l', "load-factor", true}, {'p', "proteome", true}});
     float load = opt_f32(p, "load-factor", 0.0f);
     const unsigned T = worker_count();
+    // -p / --proteome FILE (not in the reference): a protein FASTA; the 9-mer index is then laid out in WALK order along it
+    // (include/umgap_hip.h: umgap_walk_builder_*) -- same keys, same values, same answers from every command
+    const bool walk = p.has("proteome");
+    FILE* proteome = nullptr;
+    if (walk) {
+        const std::string path = p.get("proteome").value_or("");
+        proteome = fopen(path.c_str(), "rb");
+        if (!proteome) throw CliError("cannot open " + path + ": " + strerror(errno));
+    }
     // pass 1 (spooling unless stdin can be rewound)
     const bool seekable = lseek(fileno(stdin), 0, SEEK_CUR) != (off_t)-1;
     FILE* spool = nullptr;
@@ -1476,6 +1485,44 @@ int cmd_buildindex(const std::vector<std::string>& args) {
         LIB(umgap_index_build_var(strs.bytes.data(), strs.offsets.data(), vals.data(), vals.size(), load, 0, &ix));
     }
     if (spool) fclose(spool);
+    if (walk) {
+        if (umgap_index_kind(ix) != 9) { umgap_index_free(ix); throw CliError("--proteome needs an index of 9-mers"); }
+        umgap_walk_builder* wb = nullptr;
+        umgap_index* wx = nullptr;
+        try {
+            LIB(umgap_walk_builder_new(ix, load, &wb));
+            FastaReader fr(proteome, true);
+            Record rec;
+            std::vector<uint8_t> bytes;
+            std::vector<uint64_t> offs{0};
+            uint32_t max_len = 9;
+            auto flush = [&]() {
+                if (offs.size() > 1) LIB(umgap_walk_builder_add(wb, bytes.data(), offs.data(), offs.size() - 1, max_len));
+                bytes.clear();
+                offs.assign(1, 0);
+                max_len = 9;
+            };
+            while (fr.read_record(rec)) {
+                const std::string& sq = rec.sequence[0];
+                if (sq.size() >= 0xFFFFFF00ull) throw CliError("a protein of 4 GiB or more");
+                if (bytes.size() + sq.size() > (256u << 20)) flush();
+                bytes.insert(bytes.end(), sq.begin(), sq.end());
+                offs.push_back(bytes.size());
+                max_len = std::max<uint32_t>(max_len, (uint32_t)sq.size());
+            }
+            flush();
+            LIB(umgap_walk_builder_finish(wb, &wx));
+            wb = nullptr;
+        } catch (...) {
+            if (wb) umgap_walk_builder_free(wb);
+            umgap_index_free(ix);
+            fclose(proteome);
+            throw;
+        }
+        fclose(proteome);
+        umgap_index_free(ix);
+        ix = wx;
+    }
     LIB(umgap_index_save(ix, "/dev/stdout"));
     umgap_index_free(ix);
     return 0;

@@ -1371,6 +1371,32 @@ int umgap_walk_builder_add_dev(umgap_walk_builder* b, const uint8_t* d_bytes, co
     return done(UMGAP_OK);
 }
 
+// the same from host memory (the chunk is copied to the device for the call)
+int umgap_walk_builder_add(umgap_walk_builder* b, const uint8_t* bytes, const uint64_t* offsets, size_t n_fragments, uint32_t max_fragment_len) {
+    if (!b || !b->ix || (n_fragments && (!bytes || !offsets))) return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_add: null argument");
+    if (!n_fragments) return UMGAP_OK;
+    int rc = use_device(b->ix->device);
+    if (rc) return rc;
+    const uint64_t base = offsets[0], total = offsets[n_fragments] - base;
+    std::vector<uint64_t> rel(n_fragments + 1);
+    for (size_t i = 0; i <= n_fragments; i++) {
+        if (offsets[i] < base || (i && offsets[i] < offsets[i - 1])) return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_add: offsets must not decrease");
+        rel[i] = offsets[i] - base;
+    }
+    uint8_t* d_bytes = nullptr;
+    uint64_t* d_off = nullptr;
+    if (hipMalloc((void**)&d_bytes, total + 16) != hipSuccess || hipMalloc((void**)&d_off, rel.size() * 8) != hipSuccess) {
+        if (d_bytes) (void)hipFree(d_bytes);
+        return fail(UMGAP_ERR_NOMEM, "umgap_walk_builder_add: hipMalloc failed");
+    }
+    if ((total && hipMemcpy(d_bytes, bytes + base, total, hipMemcpyHostToDevice) != hipSuccess) || hipMemcpy(d_off, rel.data(), rel.size() * 8, hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(UMGAP_ERR_DEVICE, "umgap_walk_builder_add: copy failed");
+    if (!rc) rc = umgap_walk_builder_add_dev(b, d_bytes, d_off, n_fragments, max_fragment_len);
+    (void)hipFree(d_bytes);
+    (void)hipFree(d_off);
+    return rc;
+}
+
 int umgap_walk_builder_finish(umgap_walk_builder* b, umgap_index** out) {
     if (!b || !b->ix || !out) return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_finish: null argument");
     umgap_index* x = b->ix;
