@@ -2,12 +2,14 @@
 //
 // Consecutive 9-mers of a protein fragment share eight residues, yet a hash table sends each of them to a bucket of its own: one
 // 64-byte request per window, and ~50 G requests/s is the chip's ceiling.  When the index is built from a
-// proteome (umgap_index_build_walk9_dev; UMGAP's own index is derived from UniProt proteins), "the order in which the proteome
-// lists its windows" is a ready-made walk order:
-//     E[p]   = taxon of the key (the table's answer: smallest taxon over the fragments that hold the 9-mer)
-//              | (low 31 key bits | continues << 31) << 32                                  8 bytes, p = number of the window
-//              ("continues": window p - 1 is the previous window of the same fragment, so key(p) = key(p - 1) << 5 | last residue)
-//     table  = the exact hash table of common.hpp with value = p of the FIRST window that holds the key
+// proteome (umgap_walk_builder_* in index.hip: values from any 9-mer table, order from the proteins; UMGAP's own index is derived
+// from UniProt proteins), "the order in which the proteome lists its windows" is a ready-made walk order:
+//     E[p]   = taxon of the key | (low 31 key bits | continues << 31) << 32                   8 bytes per entry
+//              one entry per key of the index, at the FIRST window of the proteome that holds it, in proteome order (plus short
+//              runs of repeated 9-mers inside a protein, which keep entries nothing points at so that the walk is not cut, and
+//              the keys no protein shows as walks of one at the end)
+//              ("continues": entry p - 1 is the previous window of the same protein, so key(p) = key(p - 1) << 5 | last residue)
+//     table  = the exact hash table of common.hpp with value = p of the key's entry
 // A read fragment whose windows follow the proteome is then answered by ONE probe (its first window, the anchor, gives p) plus the
 // few sectors of E[p + 1 ..]: window j behind the anchor is answered by E[p + j] iff every entry on the way continues its
 // predecessor and carries the window's low key bits -- by induction its key then EQUALS the window's, so the answer is exact (no
