@@ -412,9 +412,9 @@ int umgap_index_build_windows9_dev(const uint8_t* d_bytes, const uint64_t* d_off
  * lists every distinct 9-mer once, at the first window of the proteome that holds it, in proteome order: the taxon beside the low
  * key bits and a "the entry in front is the previous window of the same fragment" flag; the table maps a 9-mer to the number of
  * its entry (umgap_walk_builder_* below is the general form: values from any 9-mer table).  A run of read windows that follows the proteome is then
- * answered by one probe plus the few sectors of the walk array behind the position it returned, each step verified (exact: the
- * low key bits of entries t and t - 3, or of entry t next to a verified t - 1, pin all nine residues of window t); a substituted
- * residue costs the nine windows that hold it, which are probed one by one, and the walk goes on behind them.
+ * answered by one probe plus the few sectors of the walk array behind the position it returned, each step verified (exact: an
+ * entry that continues a verified predecessor and carries the window's low key bits has the window's key); the windows behind a
+ * break -- a changed residue, a 9-mer listed elsewhere -- are probed one by one.
  * Served by umgap_classify_prot9[_strategy]_dev (walking; umgap_index_bind_taxonomy applies) and umgap_index_lookup_prot9_dev;
  * umgap_index_lookup9[_dev], umgap_classify_records and umgap_index_dump9 take the position from the table and the taxon from the
  * walk array (same answers as the plain table, no gain); umgap_index_save / umgap_index_open keep it (UMGAPIX1 kind 10: the walk

@@ -350,9 +350,8 @@ struct ProtScratch<true> {
 // through general_group -- the reads of a group sit at a fixed stride of 128 in the strip instead of back to back.
 // WALK (a kind-10 index, index_walk.hip): the table's values are window numbers of the proteome and the taxa live in the walk array E.
 // A lane's run of consecutive windows is then answered by ONE probe -- its first window -- plus the entries E[p + 1 ..] behind the
-// position p the probe returned, wherever the entries carry the windows' low key bits over enough residues to make the keys EQUAL
-// (rules at the walk loop: exact, no fingerprints); the windows the walk could not vouch for are probed one by one afterwards.
-constexpr uint32_t WALK_CHUNK = 8;
+// position p the probe returned, as long as each entry continues its predecessor and carries the window's low key bits (by
+// induction its key equals the window's: exact); where the chain breaks, that window is probed and the walk goes on from there.
 struct WalkView {
     const uint64_t* E = nullptr;   // taxon | (low 31 key bits | continues << 31) << 32
     uint64_t n = 0;
@@ -473,8 +472,7 @@ __global__ __launch_bounds__(256, GENERAL ? 3 : 4) void k_classify_prot9(TableVi
         }
         if constexpr (WALK) {
             // ---- phase 1: the first window of every run is its ANCHOR: one quad-probe batch (lane = key), then the walk ----
-            // bit t: window t of the run has its answer in the strip (windows from 64 on -- runs that long are rare -- always go to phase 2)
-            uint64_t ans = 0;
+            uint32_t done_n = 0;                                   // windows [0, done_n) of the run have their answer in the strip
             {
                 uint64_t akey = 0;
                 uint32_t apoison = 0;
@@ -499,27 +497,19 @@ __global__ __launch_bounds__(256, GENERAL ? 3 : 4) void k_classify_prot9(TableVi
                 const uint32_t r4 = lane >> 4;
                 const uint32_t pos = r4 == 0 ? v0 : (r4 == 1 ? v1 : (r4 == 2 ? v2 : v3));
                 if (run_cnt) {
-                    if (!valid || pos == NONE || pos >= WK.n) { wtaxa[sb] = 0u; ans = 1; }   // the anchor is not in the table: no hit
+                    if (!valid || pos == NONE || pos >= WK.n) { wtaxa[sb] = 0u; done_n = 1; }   // the anchor is not in the table: no hit
                     else {
-                        // the walk: entries pos, pos + 1, ... WALK_CHUNK at a time (consecutive: they share one or two sectors).  Window t of
-                        // the run (read residues r[t .. t+8]) against entry pos + t (proteome residues P[t .. t+8]):
-                        //   m[t]  = the entry carries the window's low 31 key bits, i.e. r[t+3 .. t+8] = P[t+3 .. t+8]   (6 residues + 1 bit)
-                        //   c[t]  = the entry continues its predecessor (same fragment of the proteome)
-                        // and the window EQUALS the proteome's, so the entry's taxon is its exact answer, when
-                        //   m[t] & c[t] & (window t - 1 equals)                          induction: eight residues shared, the ninth in the low bits
-                        //   m[t] & m[t-3] & c[t] & c[t-1] & c[t-2]                       r[t .. t+5] from entry t - 3, r[t+3 .. t+8] from entry t
-                        // The second rule needs nothing before t - 3: a substituted residue costs the nine windows that hold it (probed in
-                        // phase 2) and the walk carries on behind them at the same offset.  Twelve entries in a row without their window's
-                        // low bits: the read has left this stretch of the proteome (an insertion, a deletion, another protein), the walk ends.
+                        // the walk: entries pos, pos + 1, ... four at a time (consecutive: the next four mostly lie in a sector already fetched),
+                        // each verified against the rolling key
                         uint64_t wkey = akey;
-                        uint32_t wpoison = 0, mh = 1u, ch = 0u, bad = 0;          // mh bit i = m[t-1-i], ch bit i = c[t-1-i]
-                        bool ver = true, go = true;
-                        for (uint32_t c0 = 0; go && c0 < run_cnt; c0 += WALK_CHUNK) {
-                            uint64_t e[WALK_CHUNK];
+                        uint32_t wpoison = 0;
+                        bool go = true;
+                        for (uint32_t c0 = 0; go && c0 < run_cnt; c0 += 4) {
+                            uint64_t e[4];
 #pragma unroll
-                            for (uint32_t k = 0; k < WALK_CHUNK; k++) e[k] = (c0 + k < run_cnt && (uint64_t)pos + c0 + k < WK.n) ? WK.E[(uint64_t)pos + c0 + k] : 0x7FFFFFFF00000000ull;   // (past the end: low bits that match no window)
+                            for (uint32_t k = 0; k < 4; k++) e[k] = (c0 + k < run_cnt && (uint64_t)pos + c0 + k < WK.n) ? WK.E[(uint64_t)pos + c0 + k] : 0x7FFFFFFF00000000ull;   // (past the end: low bits that match no window)
 #pragma unroll
-                            for (uint32_t k = 0; k < WALK_CHUNK; k++) {
+                            for (uint32_t k = 0; k < 4; k++) {
                                 const uint32_t t = c0 + k;
                                 if (go && t < run_cnt) {
                                     bool ok = true;
@@ -527,16 +517,11 @@ __global__ __launch_bounds__(256, GENERAL ? 3 : 4) void k_classify_prot9(TableVi
                                         const uint32_t code = (uint32_t)wbytes[bo + t + 8] - 'A';
                                         wkey = ((wkey << 5) | (code & 31u)) & MASK45;
                                         wpoison = code >= 26u ? 9u : (wpoison ? wpoison - 1u : 0u);
-                                        const uint32_t ey = (uint32_t)(e[k] >> 32), c = ey >> 31;
-                                        const uint32_t m = (wpoison == 0 && (ey & 0x7FFFFFFFu) == ((uint32_t)wkey & 0x7FFFFFFFu)) ? 1u : 0u;
-                                        ok = m && c && (ver || (((mh >> 2) & 1u) && (ch & 3u) == 3u));
-                                        ver = ok;
-                                        mh = (mh << 1) | m;
-                                        ch = (ch << 1) | c;
-                                        bad = m ? 0u : bad + 1u;
-                                        if (bad >= 12u) go = false;
+                                        const uint32_t ey = (uint32_t)(e[k] >> 32);
+                                        ok = wpoison == 0 && (ey >> 31) && (ey & 0x7FFFFFFFu) == ((uint32_t)wkey & 0x7FFFFFFFu);
                                     }
-                                    if (ok) { wtaxa[sb + t] = (uint32_t)e[k]; if (t < 64u) ans |= 1ull << t; }
+                                    if (ok) { wtaxa[sb + t] = (uint32_t)e[k]; done_n = t + 1; }
+                                    else go = false;
                                 }
                             }
                         }
@@ -548,24 +533,16 @@ __global__ __launch_bounds__(256, GENERAL ? 3 : 4) void k_classify_prot9(TableVi
             // lane = list item -- dense batches instead of one sparse step per window of the longest hole; a hit takes its taxon from
             // the walk array ----
             {
-                const uint64_t todo = ~ans & (run_cnt >= 64u ? ~0ull : (1ull << run_cnt) - 1ull);     // unanswered windows below 64 ...
-                const uint32_t late = run_cnt > 64u ? run_cnt - 64u : 0u;                                // ... and all from 64 on
-                const uint32_t mine_n = (uint32_t)__builtin_popcountll(todo) + late;
+                const uint32_t mine_n = run_cnt - done_n;
                 uint32_t incl2 = mine_n;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) { const uint32_t tt = (uint32_t)__shfl_up((int)incl2, o, 64); if (lane >= (uint32_t)o) incl2 += tt; }
                 const uint32_t my_first = incl2 - mine_n, U = (uint32_t)__shfl((int)incl2, 63, 64);       // U = unanswered windows of the group (wave-uniform)
                 uint32_t* list = wkeys;                                  // 512 words: keys[256] and cnt[256] lie back to back
                 for (uint32_t l0 = 0; l0 < U; l0 += 512) {               // wave-uniform; one trip unless more than half the strip is unanswered
-                    {
-                        uint64_t u = todo;
-                        for (uint32_t x = 0; x < mine_n; x++) {
-                            uint32_t t;
-                            if (u) { t = (uint32_t)__builtin_ctzll(u); u &= u - 1; }
-                            else t = 64u + (x - (mine_n - late));
-                            const uint32_t at = my_first + x;
-                            if (at >= l0 && at < l0 + 512) list[at - l0] = (sb + t) | ((bo + t) << 10);
-                        }
+                    for (uint32_t x = 0; x < mine_n; x++) {
+                        const uint32_t at = my_first + x;
+                        if (at >= l0 && at < l0 + 512) list[at - l0] = (sb + done_n + x) | ((bo + done_n + x) << 10);
                     }
                     wave_lds_sync();
                     const uint32_t n_here = U - l0 < 512u ? U - l0 : 512u;

@@ -1279,7 +1279,10 @@ void umgap_walk_builder_free(umgap_walk_builder* b) {
     delete b;
 }
 
-int umgap_walk_builder_new(const umgap_index* values, double load, umgap_walk_builder** out) {
+}  // extern "C"
+namespace {
+// m = 0: the position table sized for the values table's key count at `load`; otherwise m sub-buckets per superblock
+int walk_builder_create(const umgap_index* values, double load, uint32_t m, umgap_walk_builder** out) {
     if (!values || !out) return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_new: null argument");
     if (values->kind != 9 || values->bound_to || values->view.home_lo != 0 || values->view.home_hi != values->view.nb)
         return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_new: the values must be a whole, unbound 9-mer table");
@@ -1289,7 +1292,7 @@ int umgap_walk_builder_new(const umgap_index* values, double load, umgap_walk_bu
     int rc = new_handle(values->device, &b->ix);
     if (rc) { delete b; return rc; }
     auto bail = [&](int code) { umgap_walk_builder_free(b); return code; };
-    rc = alloc_table(b->ix, choose_m(std::max<uint64_t>(values->n_keys, 1), load), 0, 1);
+    rc = alloc_table(b->ix, m ? m : choose_m(std::max<uint64_t>(values->n_keys, 1), load), 0, 1);
     if (rc) return bail(rc);
     b->slack = std::min<uint64_t>(values->n_keys / 8, 0xFFFFFFFEull - values->n_keys - STASH_CAP);
     b->cap_walk = values->n_keys + STASH_CAP + b->slack;    // every key once, the second entries of keys that went to the stash, kept repeats
@@ -1302,6 +1305,10 @@ int umgap_walk_builder_new(const umgap_index* values, double load, umgap_walk_bu
     *out = b;
     return UMGAP_OK;
 }
+}  // namespace
+extern "C" {
+
+int umgap_walk_builder_new(const umgap_index* values, double load, umgap_walk_builder** out) { return walk_builder_create(values, load, 0, out); }
 
 // the next chunk of the proteome (fragments in order; d_offsets[0 .. n_fragments] index d_bytes; fewer than 2^32 - 1 windows per chunk)
 int umgap_walk_builder_add_dev(umgap_walk_builder* b, const uint8_t* d_bytes, const uint64_t* d_offsets, size_t n_fragments, uint32_t max_fragment_len) {
@@ -1461,7 +1468,7 @@ int umgap_index_build_walk9_dev(const uint8_t* d_bytes, const uint64_t* d_offset
         umgap_index_free(t1);
         return code;
     };
-    rc = umgap_walk_builder_new(t1, load, &b);
+    rc = walk_builder_create(t1, load, t1->view.m, &b);   // the position table holds the same keys as the values table: same geometry
     if (rc) return done(rc);
     hipStream_t s = b->ix->stream;
     if (hipMalloc((void**)&d_cnt, n_fragments * 4) != hipSuccess || hipMalloc((void**)&d_wbase, (n_fragments + 2) * 8) != hipSuccess)
