@@ -315,6 +315,11 @@ int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int method, int 
                            const uint64_t* frag_offsets, size_t n_fragments, const uint64_t* read_frags,
                            size_t n_reads, int seedextend, uint32_t min_seed_size, uint32_t max_gap_size,
                            uint32_t* out_taxon, uint32_t* out_status);
+/* Which kernels the last umgap_classify_records of the calling thread ran: 1 = one fused launch per chunk (every read of the call
+ * has the same number of fragments, at most 16, and fits the limits of umgap_classify_prot9_strategy_dev: what paired reads look
+ * like), 0 = the general kernels (a hit per byte position in HBM between probe, seedextend and aggregate), 2 = the fused ones and
+ * then, a read not fitting, the general ones.  Same answers either way; UMGAP_RECORDS_FUSED=0 in the environment forces 0. */
+int umgap_records_last_route(void);
 
 /* ---- the index sharded over the GPUs of one node (BASELINE.json north_star; replaces the single resident
  * `umgap prot2kmer2lca -m -o -s <socket>` server of scripts/umgap-analyse.sh:257-264) ----------------------------------

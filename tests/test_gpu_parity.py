@@ -1998,6 +1998,95 @@ def test_classify_records_long_ragged_reads(api, torch_cuda):
             assert (s == 0).mean() > 0.5
 
 
+@pytest.mark.parametrize("F,misfit", [(2, None), (1, None), (6, None), (2, "long read"), (2, "ragged"), (3, "many taxa")])
+def test_classify_records_fused_route(api, torch_cuda, F, misfit):
+    """umgap_classify_records takes a call whose reads all have F fragments through ONE fused launch per chunk (k_classify_prot9;
+    records.hip: k_records_fit) and falls back to its general kernels for the whole call when a read does not fit the fused kernel
+    (too long, another number of fragments, more distinct taxa than its scratch holds): either way the answers must be those of
+    the general kernels (UMGAP_RECORDS_FUSED=0) and of the oracle stages -- every strategy, seedextend on and off, min_seed_size 1
+    (where the reference's seedextend can panic) included."""
+    rng = np.random.default_rng(500 + F + (len(misfit) if misfit else 0))
+    letters = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    from umgap_amd import _lib
+    from umgap_amd.synth import synthetic_taxonomy
+    ids, par, valid, rank = synthetic_taxonomy(3000, 5000, max_depth=14, seed=22)
+    tx = api.Taxonomy(ids, par, valid, rank)
+    otx = O.Taxonomy.from_arrays(ids, par, valid, rank)
+    proteins, table = [], {}
+    for _ in range(150):
+        prot = rng.choice(letters, int(rng.integers(40, 200)) if misfit != "many taxa" else 400).tobytes()
+        t = int(rng.choice(ids))
+        proteins.append(prot)
+        for i in range(len(prot) - 8):
+            table.setdefault(prot[i:i + 9], int(rng.choice(ids)) if misfit == "many taxa" else t)
+    kmers = sorted(table)
+    keys, _ = api.pack9_array(kmers)
+    ix = api.Index.build(keys, np.array([table[k] for k in kmers], np.uint32))
+    n_reads = 900
+    frags, read_frags = [], [0]
+    for r in range(n_reads):
+        nf = F
+        if misfit == "ragged" and r == 611:
+            nf = F + 1
+        for k in range(nf):
+            prot = proteins[int(rng.integers(0, len(proteins)))]
+            a = int(rng.integers(0, max(1, len(prot) - 9)))
+            n = int(rng.choice([0, 5, 9, 20, 33, 50] if F < 4 else [0, 5, 9, 20, 28]))      # (at most 128 windows per read)
+            if misfit == "long read" and r == 77 and k == 0:
+                n, a = 150, 0
+                prot = prot + prot + prot
+            if misfit == "many taxa":
+                n = 50                                # 126 windows per read, each 9-mer under a taxon of its own
+            f = bytearray(prot[a:a + n])
+            for i in range(len(f)):
+                if rng.random() < 0.03:
+                    f[i] = int(rng.choice([int(rng.choice(letters)), 42]))
+            frags.append(bytes(f))
+        read_frags.append(len(frags))
+    if misfit == "long read":
+        assert sum(len(f) for f in frags[read_frags[77]:read_frags[78]]) > 128 + 8 * F
+    for se, ms in ((False, 2), (True, 3), (True, 1)):
+        hits, roffs, panics = [], [0], set()
+        for r in range(n_reads):
+            for f in frags[read_frags[r]:read_frags[r + 1]]:
+                h = np.array([table.get(f[i:i + 9], 0) for i in range(max(0, len(f) - 8))], np.uint32)
+                if se and len(h):
+                    h = O.seedextend_record(h, ms, 1)
+                    if h is None:           # the reference's slice panic (src/commands/seedextend.rs:169-173)
+                        panics.add(r)
+                        h = np.zeros(0, np.uint32)
+                hits += h.tolist()
+            roffs.append(len(hits))
+        hits, roffs = np.array(hits, np.uint32), np.array(roffs, np.uint64)
+        for method, strategy, lb in (("tree", "lca*", 2.0), ("tree", "hybrid", 0.0), ("rmq", "mrtl", 1.0)):
+            kw = dict(method=method, strategy=strategy, factor=0.25, lower_bound=lb, seedextend=se, min_seed_size=ms, max_gap_size=1)
+            os.environ["UMGAP_RECORDS_FUSED"] = "0"
+            try:
+                t0, s0 = api.classify_records(ix, tx, frags, read_frags, **kw)
+            finally:
+                del os.environ["UMGAP_RECORDS_FUSED"]
+            assert _lib.load().umgap_records_last_route() == 0
+            t1, s1 = api.classify_records(ix, tx, frags, read_frags, **kw)
+            route = _lib.load().umgap_records_last_route()
+            if misfit is None:
+                assert route == 1
+            elif misfit == "ragged":
+                assert route == 0              # the totals already say so
+            elif misfit == "long read" or (strategy != "lca*" and not se):
+                # (many taxa: ~95 distinct ones in a read where the fused general kernel holds 64; seedextend leaves none of them)
+                assert route == 2, (misfit, strategy, route, np.bincount(s1, minlength=5))
+            same = (s0 == s1) & ((t0 == t1) | (s0 != 0))
+            if strategy == "hybrid":          # ties between children may be broken either way (tie sets: the oracle check below)
+                same |= (s0 == s1)
+            assert same.all(), (se, ms, method, strategy, np.flatnonzero(~same)[:5])
+            agg = O.Aggregator(otx, method, strategy, factor=0.25)
+            nbad, bad, wt, ws = agg.taxa2agg_check(hits, roffs, t1, s1, lower_bound=lb, nthreads=8)
+            bad = np.array([b for b in np.asarray(bad).astype(int).tolist() if b not in panics], int)
+            assert len(bad) == 0, (se, ms, method, strategy, bad[:5], t1[bad[:5]], wt[bad[:5]])
+            for r in panics:
+                assert s1[r] == s0[r] == 3, (r, s1[r])      # UMGAP_READ_PANIC
+
+
 # ---------------------------------------------------------------------------------------------
 # BASELINE.json configs[2] at full size: 50 M pairs (5 x 10 M), 8 G-key table, size-independent properties
 # ---------------------------------------------------------------------------------------------

@@ -19,6 +19,7 @@
 #include "agg_group.hpp"
 #include "bound.hpp"
 #include "probe_common.hpp"
+#include "prot_limits.hpp"
 #include "shard_wire.hpp"
 
 using namespace umgap;
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(256) void k_classify9_group(TableView T, TaxView V,
 // chunks of 128 (two batches in flight) into a dense strip, then seedextend per fragment and LCA* per read as in
 // k_classify9.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t PROT_MAX_FRAGS = 16, PROT_MAX_BYTES = 384, PROT_MAX_WINDOWS = 128, PROT_GROUP = STRIP / PROT_MAX_WINDOWS;  // 8 reads
+constexpr uint32_t PROT_GROUP = STRIP / PROT_MAX_WINDOWS;  // 8 reads (limits per read: prot_limits.hpp)
 
 // per-wave aggregate scratch of k_classify_prot9: LCA* wants the count table only (its LcaView lies over the byte staging
 // area), the other strategies the group scratch of agg_group.hpp (whose count table comes first)
@@ -355,6 +356,7 @@ struct ProtScratch<true> {
 struct WalkView {
     const uint64_t* E = nullptr;   // taxon | (low 31 key bits | continues << 31) << 32
     uint64_t n = 0;
+    const uint32_t* gate = nullptr;   // non-null: two words; the kernel does nothing when either is set (records.hip: the chunk failed its checks)
 };
 
 template <bool BOUND, bool GENERAL, bool WALK>
@@ -367,6 +369,7 @@ __global__ __launch_bounds__(256, GENERAL ? 3 : 4) void k_classify_prot9(TableVi
     __shared__ uint32_t lds_fstart[4][64], lds_fwin[4][64], lds_fbyte[4][64], lds_total[4][PROT_GROUP];
     __shared__ __attribute__((aligned(16))) uint8_t lds_bytes[4][PROT_GROUP * PROT_MAX_BYTES];   // also the LCA scratch of the aggregate stage (u32 arrays)
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
+    if (WK.gate && (WK.gate[0] | WK.gate[1])) return;
     uint32_t* wtaxa = lds_taxa[wv];
     uint32_t* wkeys = lds_scratch[wv].keys;
     uint32_t* wcnt = lds_scratch[wv].cnt;
@@ -799,6 +802,14 @@ extern "C" int umgap_classify_prot9_strategy_dev(umgap_index* ix, umgap_taxonomy
                                                  int ranked_only, const uint8_t* d_bytes, const uint64_t* d_frag_offsets, size_t n_reads,
                                                  uint32_t fragments_per_read, int seedextend, uint32_t min_seed_size, uint32_t max_gap_size,
                                                  uint32_t* d_out_taxon, uint32_t* d_out_status, void* stream) {
+    return umgap::classify_prot9_gated(ix, tx, method, strategy, factor, lower_bound, ranked_only, d_bytes, d_frag_offsets, n_reads, fragments_per_read, seedextend,
+                                       min_seed_size, max_gap_size, d_out_taxon, d_out_status, nullptr, stream);
+}
+// `gate` (device, two words, nullable): the launch does nothing when either word is set by the time it runs (records.hip)
+int umgap::classify_prot9_gated(umgap_index* ix, umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound,
+                                int ranked_only, const uint8_t* d_bytes, const uint64_t* d_frag_offsets, size_t n_reads,
+                                uint32_t fragments_per_read, int seedextend, uint32_t min_seed_size, uint32_t max_gap_size,
+                                uint32_t* d_out_taxon, uint32_t* d_out_status, const uint32_t* gate, void* stream) {
     if (!ix || !tx || (n_reads && (!d_bytes || !d_frag_offsets || !d_out_taxon || !d_out_status))) return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: null argument");
     if (ix->bound_to && ix->bound_to != tx) return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: the index is bound to another taxonomy");
     if (ix->kind != 9 && ix->kind != 10) return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: needs a 9-mer index");
@@ -814,7 +825,7 @@ extern "C" int umgap_classify_prot9_strategy_dev(umgap_index* ix, umgap_taxonomy
     size_t g = ((n_reads + G - 1) / G + 3) / 4;
     if (g > 256 * 8) g = 256 * 8;
     const bool general = strategy != UMGAP_STRATEGY_LCA_STAR, bound = ix->bound_to != nullptr, walk = ix->kind == 10;
-    const WalkView WK{ix->d_walk, ix->n_walk};
+    const WalkView WK{ix->d_walk, ix->n_walk, gate};
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, strategy, factor, d_bytes,
                            d_frag_offsets, n_reads, fragments_per_read, seedextend ? 1u : 0u, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status, WK);

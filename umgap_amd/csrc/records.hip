@@ -12,10 +12,13 @@
 // for full PCIe rate) on one stream while chunk c runs on the other.  On the device the hit of the window that
 // STARTS at byte b lives at hits[b] -- fragment f owns hits[off[f] .. off[f+1]), its last 8 positions (no window
 // starts there) stay 0, which taxa2agg drops (src/commands/taxa2agg.rs:169) -- so no window prefix sums are needed:
+// (Round 3: a call whose reads all have the same number of fragments and fit the fused surface-B kernel takes ONE launch per chunk
+// instead -- k_records_fit + k_classify_prot9, further down; what follows is the general route.)
 //   k_frag_prepare   fragment -> {start, length} (validated) + the tail positions marked in a bitmap
 //   k_lookup_bytes9  every unmarked byte position: 9 residues packed from LDS -> quad probe -> hits[b]
 //   k_seedextend_frags / k_read_offsets / the aggregate kernels / k_mark_seed_panics
 #include "probe_common.hpp"
+#include "prot_limits.hpp"
 #include "seedextend.hpp"
 #include "taxonomy.hpp"
 
@@ -137,11 +140,54 @@ __global__ __launch_bounds__(256) void k_read_offsets(const uint64_t* __restrict
     }
 }
 
+// The FUSED route of the record path: when every read of the call has the same number of fragments and fits the fused surface-B
+// kernel (prot_limits.hpp), a chunk is ONE launch of k_classify_prot9 (classify.hip: bytes staged in LDS, rolling keys, probe,
+// seedextend and aggregate in one kernel; over a walk-order index the walking variant) instead of the six kernels above with a hit
+// per byte position in HBM between them.  This kernel checks what the host did not look at -- offsets non-decreasing and inside the
+// chunk (flags[0], as k_frag_prepare / k_read_offsets), every read of exactly F fragments within the limits (flags[1]) -- and
+// writes the fragment offsets relative to the chunk's first byte; the fused launch is gated on both flags.
+__global__ __launch_bounds__(256) void k_records_fit(const uint64_t* __restrict__ off, size_t n_frag, const uint64_t* __restrict__ rf, size_t n_reads, uint64_t f0,
+                                                     uint32_t F, uint64_t base, uint32_t chunk_bytes, uint64_t* __restrict__ rel, uint32_t* __restrict__ flags) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (size_t f = i; f <= n_frag; f += step) {
+        const uint64_t a = off[f];
+        const bool ok = a >= base && a - base <= chunk_bytes && (f == 0 || off[f - 1] <= a);
+        if (!ok) atomicExch(flags, 1u);
+        rel[f] = ok ? a - base : 0;
+    }
+    for (size_t r = i; r < n_reads; r += step) {
+        const uint64_t ga = rf[r], gb = rf[r + 1];
+        if (ga < f0 || gb < ga || gb - f0 > n_frag) { atomicExch(flags, 1u); continue; }
+        if (gb - ga != F) { atomicExch(flags + 1, 1u); continue; }
+        const uint64_t fa = ga - f0;
+        uint64_t windows = 0;
+        bool sane = true;
+        for (uint32_t t = 0; t < F; t++) {
+            const uint64_t a = off[fa + t], b = off[fa + t + 1];
+            sane = sane && b >= a;
+            if (b >= a + 9) windows += b - a - 8;
+        }
+        const uint64_t a0 = off[fa], b0 = off[fa + F];
+        if (!sane || b0 < a0 || b0 - a0 > PROT_MAX_BYTES || windows > PROT_MAX_WINDOWS) atomicExch(flags + 1, 1u);
+    }
+}
+// a read the fused kernel could not take after all (hybrid / MRTL: more distinct taxa than its scratch holds) sends the call
+// through the general kernels
+__global__ __launch_bounds__(256) void k_records_any_unsupported(const uint32_t* __restrict__ status, size_t n, uint32_t* __restrict__ flags) {
+    if (flags[0] | flags[1]) return;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    bool any = false;
+    for (; i < n; i += step) any = any || status[i] == UMGAP_READ_UNSUPPORTED;
+    if (any) atomicExch(flags + 1, 1u);
+}
+
 struct Slot {
     hipStream_t stream = nullptr;
     hipEvent_t done = nullptr;
     uint8_t* bytes = nullptr;
-    uint64_t *off = nullptr, *rf = nullptr, *roff = nullptr, *rfl = nullptr;
+    uint64_t *off = nullptr, *off_rel = nullptr, *rf = nullptr, *roff = nullptr, *rfl = nullptr;
     uint32_t *fstart = nullptr, *flen = nullptr, *tails = nullptr, *hits = nullptr, *kept = nullptr, *ot = nullptr, *os = nullptr, *bad = nullptr;
 };
 
@@ -162,6 +208,8 @@ extern "C" int umgap_host_alloc(size_t bytes, void** out) {
 extern "C" void umgap_host_free(void* p) {
     if (p) (void)hipHostFree(p);
 }
+
+static thread_local int g_last_route = 0;
 
 extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound,
                                       int ranked_only, const uint8_t* bytes, const uint64_t* frag_offsets, size_t n_fragments,
@@ -186,6 +234,13 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
     const uint64_t n_bytes = n_fragments ? frag_offsets[n_fragments] - base : 0;
     if (n_bytes && !bytes) return fail(UMGAP_ERR_INVALID, "umgap_classify_records: null bytes");
 
+    // the fused route (k_records_fit): every read of F fragments, F from the first read and the totals; UMGAP_RECORDS_FUSED=0 keeps
+    // the general kernels
+    uint32_t F_all = 0;
+    if (n_reads && read_frags[1] >= 1 && read_frags[1] <= PROT_MAX_FRAGS && n_fragments == (uint64_t)read_frags[1] * n_reads) F_all = (uint32_t)read_frags[1];
+    if (const char* env = getenv("UMGAP_RECORDS_FUSED")) if (env[0] == '0') F_all = 0;
+    bool unfit = false;
+    auto run = [&](const bool fused) -> int {
     // ---- chunk plan: whole reads, at most CH residues / FH fragments / RH reads each (a single read may exceed them) ----
     const uint64_t CH = 32ull << 20;
     const size_t FH = 4u << 20, RH = 2u << 20;
@@ -218,7 +273,7 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
     // ---- device staging: two slots inside the taxonomy handle's staging block ----
     const size_t b_bytes = pad256(max_b + 160), b_off = pad256((max_f + 1) * 8), b_rf = pad256((max_r + 1) * 8), b_f32 = pad256((max_f + 1) * 4),
                  b_tails = pad256((max_b / 32 + 8) * 4), b_hits = pad256((max_b + 16) * 4), b_out = pad256(max_r * 4 + 4);
-    const size_t per_slot = b_bytes + b_off + 3 * b_rf + 2 * b_f32 + b_tails + b_hits + (want_kept ? b_f32 : 0) + 2 * b_out + 256;
+    const size_t per_slot = b_bytes + 2 * b_off + 3 * b_rf + 2 * b_f32 + b_tails + b_hits + (want_kept ? b_f32 : 0) + 2 * b_out + 256;
     const size_t need = 2 * per_slot;
     if (need > tx->d_stage_bytes) {
         if (tx->d_stage) (void)hipFree(tx->d_stage);
@@ -234,14 +289,15 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
     if (!tx->stream2) e = hipStreamCreateWithFlags(&tx->stream2, hipStreamNonBlocking);
     if (e != hipSuccess) return fail(UMGAP_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     S[1].stream = tx->stream2;
-    if (!tx->h_flags) e = hipHostMalloc((void**)&tx->h_flags, 2 * sizeof(uint32_t), hipHostMallocDefault);
+    if (!tx->h_flags) e = hipHostMalloc((void**)&tx->h_flags, 4 * sizeof(uint32_t), hipHostMallocDefault);
     if (e != hipSuccess) { tx->h_flags = nullptr; return fail(UMGAP_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
-    volatile uint32_t* h_bad = tx->h_flags;
-    h_bad[0] = h_bad[1] = 0;
+    volatile uint32_t* h_bad = tx->h_flags;    // per slot: {offsets bad, reads unfit for the fused kernel}
+    h_bad[0] = h_bad[1] = h_bad[2] = h_bad[3] = 0;
     for (int k = 0; k < 2; k++) {
         char* p = (char*)tx->d_stage + (size_t)k * per_slot;
         S[k].bytes = (uint8_t*)p; p += b_bytes;
         S[k].off = (uint64_t*)p; p += b_off;
+        S[k].off_rel = (uint64_t*)p; p += b_off;
         S[k].rf = (uint64_t*)p; p += b_rf;
         S[k].roff = (uint64_t*)p; p += b_rf;
         S[k].rfl = (uint64_t*)p; p += b_rf;
@@ -263,13 +319,24 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
         const uint64_t f0 = frag_of(r0), nf = frag_of(cuts[c + 1]) - f0;
         const uint64_t b0 = byte_of(r0), nb = byte_of(cuts[c + 1]) - b0;
         // slot reuse is ordered by its stream: chunk c-2's copies back were enqueued there before anything below
-        UMGAP_HIP(hipMemsetAsync(L.bad, 0, 4, s));
-        UMGAP_HIP(hipMemsetAsync(L.tails, 0, (nb / 32 + 8) * 4, s));
+        UMGAP_HIP(hipMemsetAsync(L.bad, 0, 8, s));
+        if (!fused) UMGAP_HIP(hipMemsetAsync(L.tails, 0, (nb / 32 + 8) * 4, s));
         if (nb) UMGAP_HIP(hipMemcpyAsync(L.bytes, bytes + base + b0, nb, hipMemcpyHostToDevice, s));
         UMGAP_HIP(hipMemsetAsync(L.bytes + nb, 0, 144, s));   // the packer may look 8 bytes past the chunk
         if (nf) UMGAP_HIP(hipMemcpyAsync(L.off, frag_offsets + f0, (nf + 1) * 8, hipMemcpyHostToDevice, s));
         UMGAP_HIP(hipMemcpyAsync(L.rf, read_frags + r0, (nr + 1) * 8, hipMemcpyHostToDevice, s));
         const unsigned gf = (unsigned)std::min<size_t>((nf + 255) / 256 + 1, 2048), gr = (unsigned)std::min<size_t>((nr + 256) / 256 + 1, 2048);
+        if (fused) {
+            if (!nf) UMGAP_HIP(hipMemsetAsync(L.off, 0, 8, s));
+            hipLaunchKernelGGL(k_records_fit, dim3(std::max(gf, gr)), dim3(256), 0, s, (const uint64_t*)L.off, (size_t)nf, (const uint64_t*)L.rf, nr, f0, F_all, base + b0,
+                               (uint32_t)nb, L.off_rel, L.bad);
+            UMGAP_HIP(hipGetLastError());
+            rc = classify_prot9_gated(ix, tx, method, strategy, factor, lower_bound, ranked_only, L.bytes, L.off_rel, nr, F_all, seedextend, min_seed_size, max_gap_size, L.ot, L.os,
+                                      L.bad, s);
+            if (rc) break;
+            hipLaunchKernelGGL(k_records_any_unsupported, dim3(gr), dim3(256), 0, s, (const uint32_t*)L.os, nr, L.bad);
+            UMGAP_HIP(hipGetLastError());
+        } else {
         if (nf) hipLaunchKernelGGL(k_frag_prepare, dim3(gf), dim3(256), 0, s, L.off, (size_t)nf, base + b0, (uint32_t)nb, L.fstart, L.flen, L.tails, L.bad);
         if (nb) {
             const unsigned gb = (unsigned)std::min<uint64_t>((nb + 511) / 512, 2048);
@@ -283,19 +350,34 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
         rc = umgap_aggregate_dev(tx, method, strategy, factor, lower_bound, ranked_only, L.hits, nullptr, L.roff, nr, L.ot, L.os, s);
         if (!rc && want_kept && nf) rc = mark_seedextend_panics(L.kept, L.rfl, nr, L.ot, L.os, s);
         if (rc) break;
+        }
         UMGAP_HIP(hipMemcpyAsync(out_taxon + r0, L.ot, nr * 4, hipMemcpyDeviceToHost, s));
         UMGAP_HIP(hipMemcpyAsync(out_status + r0, L.os, nr * 4, hipMemcpyDeviceToHost, s));
-        UMGAP_HIP(hipMemcpyAsync(tx->h_flags + (c & 1), L.bad, 4, hipMemcpyDeviceToHost, s));
+        UMGAP_HIP(hipMemcpyAsync(tx->h_flags + 2 * (c & 1), L.bad, 8, hipMemcpyDeviceToHost, s));
         // before this slot is refilled (chunk c+2) the host must have seen its flag: wait for chunk c-1 now, which also
         // keeps at most two chunks in flight
         if (c >= 1) {
             UMGAP_HIP(hipStreamSynchronize(S[(c - 1) & 1].stream));
-            if (h_bad[(c - 1) & 1]) { rc = fail(UMGAP_ERR_INVALID, "umgap_classify_records: frag_offsets / read_frags are not non-decreasing offsets into the block"); break; }
+            if (h_bad[2 * ((c - 1) & 1)]) { rc = fail(UMGAP_ERR_INVALID, "umgap_classify_records: frag_offsets / read_frags are not non-decreasing offsets into the block"); break; }
+            if (h_bad[2 * ((c - 1) & 1) + 1]) { unfit = true; break; }    // a read the fused kernel does not take: the caller runs the general kernels
         }
     }
     hipError_t e0 = hipStreamSynchronize(S[0].stream), e1 = hipStreamSynchronize(S[1].stream);
     if (rc) return rc;
     if (e0 != hipSuccess || e1 != hipSuccess) return fail(UMGAP_ERR_DEVICE, std::string("umgap_classify_records: ") + hipGetErrorString(e0 != hipSuccess ? e0 : e1));
-    if (h_bad[0] || h_bad[1]) return fail(UMGAP_ERR_INVALID, "umgap_classify_records: frag_offsets / read_frags are not non-decreasing offsets into the block");
+    if (h_bad[0] || h_bad[2]) return fail(UMGAP_ERR_INVALID, "umgap_classify_records: frag_offsets / read_frags are not non-decreasing offsets into the block");
+    if (h_bad[1] || h_bad[3]) unfit = true;
     return UMGAP_OK;
+    };   // run
+    if (F_all) {
+        g_last_route = 1;
+        rc = run(true);
+        if (rc || !unfit) return rc;
+        g_last_route = 2;
+    } else g_last_route = 0;
+    return run(false);
 }
+
+// which kernels the last umgap_classify_records of this thread ran: 0 the general ones, 1 the fused one, 2 the fused one and then,
+// a read not fitting it, the general ones (tests and benchmarks)
+extern "C" int umgap_records_last_route(void) { return g_last_route; }
