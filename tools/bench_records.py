@@ -37,6 +37,17 @@ def run(n_frag=50_000_000, n_pairs=10_000_000, steps=3):
     torch.cuda.synchronize()
     res = {"pairs": n_pairs, "bytes_in_per_pair": F * flen + F * 8 + 8, "bytes_out_per_pair": 8, "index_keys": n_frag * (flen - 8),
            "pipeline": "prot2kmer2lca | seedextend -g1 -s3 | taxa2agg -l2 -a lca* on host arrays (umgap_classify_records)"}
+    # the link alone: the same bytes copied from pinned memory, in 32 MB pieces on one stream and in one piece
+    src = torch.empty(n_pairs * res["bytes_in_per_pair"], dtype=torch.uint8, pin_memory=True)
+    dst = torch.empty_like(src, device=dev)
+    for label, piece in (("h2d_pinned_32MB_pieces_GBps", 32 << 20), ("h2d_pinned_one_piece_GBps", src.numel())):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for o in range(0, src.numel(), piece):
+            dst[o:o + piece].copy_(src[o:o + piece], non_blocking=True)
+        torch.cuda.synchronize()
+        res[label] = round(src.numel() / (time.perf_counter() - t0) / 1e9, 2)
+    del src, dst
     for name, pinned in (("pinned", True), ("pageable", False)):
         h_bytes = torch.empty(r.numel() + 16, dtype=torch.uint8, pin_memory=pinned)
         h_bytes[:r.numel()].copy_(r.cpu())

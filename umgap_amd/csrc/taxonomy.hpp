@@ -49,8 +49,8 @@ struct umgap_taxonomy {
     uint64_t* d_sparse8 = nullptr;                    // [levels8][n_blocks8] packed (depth << 32 | pos) minima over 8-blocks: per-lane O(1) LCA
     uint32_t n_blocks8 = 0, n_levels8 = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;     // second lane of umgap_classify_records (chunk c+1 uploads while chunk c computes)
-    uint32_t* h_flags = nullptr;       // pinned: per-lane "bad offsets" flags of umgap_classify_records
+    hipStream_t stream2 = nullptr;     // the upload lane of umgap_classify_records (chunks c+1, c+2 upload while chunk c computes on `stream`)
+    uint32_t* h_flags = nullptr;       // pinned: per-slot {bad offsets, unfit read} flags of umgap_classify_records
     // staging for the host-pointer umgap_aggregate
     void* d_stage = nullptr;
     size_t d_stage_bytes = 0;
