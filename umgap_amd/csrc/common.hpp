@@ -117,9 +117,10 @@ struct umgap_index {
     umgap::TableView view{};
     hipStream_t stream = nullptr;
     // pinned staging for the host-pointer entry points
-    void* h_stage[2] = {nullptr, nullptr};
-    void* d_stage[2] = {nullptr, nullptr};
+    void* h_stage[3] = {nullptr, nullptr, nullptr};
+    void* d_stage[3] = {nullptr, nullptr, nullptr};
     size_t stage_cap = 0;  // keys per staging buffer
+    hipStream_t up_stream = nullptr;   // the upload lane of umgap_index_lookup9 (chunks c+1, c+2 upload while chunk c is probed on `stream`)
     // non-null: the slot values are not taxon ids but codes bound to that taxonomy (bound.hpp); only the bound
     // fused kernel understands them
     const void* bound_to = nullptr;

@@ -793,10 +793,11 @@ int build_with(umgap_index* ix, uint64_t n, double load, uint32_t shard, uint32_
 int ensure_stage(umgap_index* ix) {
     if (ix->stage_cap) return UMGAP_OK;
     const size_t cap = 4u << 20;  // keys per chunk: 32 MiB keys + 16 MiB results
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < 3; i++) {
         UMGAP_HIP(hipHostMalloc(&ix->h_stage[i], cap * 12, hipHostMallocDefault));
         UMGAP_HIP(hipMalloc(&ix->d_stage[i], cap * 12));
     }
+    if (!ix->up_stream) UMGAP_HIP(hipStreamCreateWithFlags(&ix->up_stream, hipStreamNonBlocking));
     ix->stage_cap = cap;
     return UMGAP_OK;
 }
@@ -1000,10 +1001,11 @@ void umgap_index_free(umgap_index* ix) {
     if (ix->d_slots) (void)hipFree(ix->d_slots);
     if (ix->d_stash_keys) (void)hipFree(ix->d_stash_keys);
     if (ix->d_stash_vals) (void)hipFree(ix->d_stash_vals);
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < 3; i++) {
         if (ix->h_stage[i]) (void)hipHostFree(ix->h_stage[i]);
         if (ix->d_stage[i]) (void)hipFree(ix->d_stage[i]);
     }
+    if (ix->up_stream) (void)hipStreamDestroy(ix->up_stream);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
     delete ix;
 }
@@ -1561,38 +1563,56 @@ int umgap_index_lookup9(umgap_index* ix, const uint64_t* keys, size_t n, uint32_
     if (rc) return rc;
     rc = ensure_stage(ix);
     if (rc) return rc;
-    // two staging slots ping-pong on the handle's stream: H2D(k) -> probe(k) -> D2H(k); the host
-    // copies chunk k+1 into the other pinned slot while chunk k is in flight.
+    // An UPLOAD lane and a PROBE lane tied by events per staging slot (three slots): the keys of chunks c + 1 and c + 2 cross the
+    // link while chunk c is probed and its answers go back.  Arrays in pinned memory (umgap_host_alloc, hipHostMalloc, a registered
+    // range) are copied from / to directly; pageable ones go through the handle's pinned staging buffers with a host memcpy.
     const size_t cap = ix->stage_cap;
-    hipEvent_t done[2];
-    for (int i = 0; i < 2; i++) UMGAP_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
-    size_t pending_off[2] = {0, 0}, pending_len[2] = {0, 0};
-    int slot = 0;
-    auto drain = [&](int s) -> int {
+    constexpr int NS = 3;
+    auto pinned = [](const void* p) {
+        hipPointerAttribute_t a{};
+        if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return a.type == hipMemoryTypeHost;
+    };
+    const bool in_pinned = n && pinned(keys) && pinned(keys + n - 1), out_pinned = n && pinned(out) && pinned(out + n - 1);
+    struct Events {
+        hipEvent_t uploaded[NS] = {}, done[NS] = {};
+        ~Events() { for (hipEvent_t x : uploaded) if (x) (void)hipEventDestroy(x); for (hipEvent_t x : done) if (x) (void)hipEventDestroy(x); }
+    } ev;
+    for (int i = 0; i < NS; i++) {
+        UMGAP_HIP(hipEventCreateWithFlags(&ev.uploaded[i], hipEventDisableTiming));
+        UMGAP_HIP(hipEventCreateWithFlags(&ev.done[i], hipEventDisableTiming));
+    }
+    const hipStream_t up = ix->up_stream, run = ix->stream;
+    size_t pending_off[NS] = {}, pending_len[NS] = {};
+    auto drain = [&](int s) -> int {          // the answers of the slot's last chunk: waited for, and copied out when they went through staging
         if (!pending_len[s]) return UMGAP_OK;
-        UMGAP_HIP(hipEventSynchronize(done[s]));
-        memcpy(out + pending_off[s], (char*)ix->h_stage[s] + cap * 8, pending_len[s] * 4);
+        UMGAP_HIP(hipEventSynchronize(ev.done[s]));
+        if (!out_pinned) memcpy(out + pending_off[s], (char*)ix->h_stage[s] + cap * 8, pending_len[s] * 4);
         pending_len[s] = 0;
         return UMGAP_OK;
     };
-    for (size_t off = 0; off < n; off += cap, slot ^= 1) {
-        size_t len = std::min(cap, n - off);
-        rc = drain(slot);
+    size_t c = 0;
+    for (size_t off = 0; off < n; off += cap, c++) {
+        const int slot = (int)(c % NS);
+        const size_t len = std::min(cap, n - off);
+        rc = drain(slot);                     // the slot's previous tenant is through (upload included: done follows uploaded)
         if (rc) break;
-        memcpy(ix->h_stage[slot], keys + off, len * 8);
         uint64_t* dk = (uint64_t*)ix->d_stage[slot];
         uint32_t* dout = (uint32_t*)((char*)ix->d_stage[slot] + cap * 8);
-        UMGAP_HIP(hipMemcpyAsync(dk, ix->h_stage[slot], len * 8, hipMemcpyHostToDevice, ix->stream));
-        hipLaunchKernelGGL(k_lookup9, dim3(grid_for(len)), dim3(256), 0, ix->stream, dk, len, walk ? UMGAP_NONE : miss, dout, ix->view);
-        if (walk && (rc = walk_map_positions(ix, dout, len, miss, ix->stream))) break;
-        UMGAP_HIP(hipMemcpyAsync((char*)ix->h_stage[slot] + cap * 8, dout, len * 4, hipMemcpyDeviceToHost, ix->stream));
-        UMGAP_HIP(hipEventRecord(done[slot], ix->stream));
+        const uint64_t* src = keys + off;
+        if (!in_pinned) { memcpy(ix->h_stage[slot], keys + off, len * 8); src = (const uint64_t*)ix->h_stage[slot]; }
+        UMGAP_HIP(hipMemcpyAsync(dk, src, len * 8, hipMemcpyHostToDevice, up));
+        UMGAP_HIP(hipEventRecord(ev.uploaded[slot], up));
+        UMGAP_HIP(hipStreamWaitEvent(run, ev.uploaded[slot], 0));
+        hipLaunchKernelGGL(k_lookup9, dim3(grid_for(len)), dim3(256), 0, run, dk, len, walk ? UMGAP_NONE : miss, dout, ix->view);
+        if (walk && (rc = walk_map_positions(ix, dout, len, miss, run))) break;
+        UMGAP_HIP(hipMemcpyAsync(out_pinned ? (void*)(out + off) : (void*)((char*)ix->h_stage[slot] + cap * 8), dout, len * 4, hipMemcpyDeviceToHost, run));
+        UMGAP_HIP(hipEventRecord(ev.done[slot], run));
         pending_off[slot] = off;
         pending_len[slot] = len;
     }
-    if (!rc) rc = drain(0);
-    if (!rc) rc = drain(1);
-    for (int i = 0; i < 2; i++) (void)hipEventDestroy(done[i]);
+    for (int i = 0; i < NS; i++) { const int r2 = drain(i); if (!rc) rc = r2; }
+    if (rc) { (void)hipStreamSynchronize(up); (void)hipStreamSynchronize(run); }
     return rc;
 }
 
