@@ -18,6 +18,7 @@ namespace umgap {
 void var_free(umgap_var_index* v);
 // index_walk.hip
 int walk_map_positions(const umgap_index* ix, uint32_t* d_vals, size_t n, uint32_t miss, hipStream_t s);
+int ensure_stage(umgap_index* ix);
 int walk_lookup_prot9(const umgap_index* ix, const uint8_t* d_bytes, const uint64_t* d_offsets, const uint64_t* d_out_offsets, size_t n_prot, size_t n_windows,
                       uint32_t miss, uint32_t* d_out, hipStream_t s);
 uint64_t var_table_bytes(const umgap_var_index* v);   // slots + heap
@@ -790,7 +791,9 @@ int build_with(umgap_index* ix, uint64_t n, double load, uint32_t shard, uint32_
     return rc;
 }
 
-int ensure_stage(umgap_index* ix) {
+}  // namespace
+// three pinned + three device staging buffers of 48 MB each and the upload stream of the host-pointer look-ups (also index_var.hip)
+int umgap::ensure_stage(umgap_index* ix) {
     if (ix->stage_cap) return UMGAP_OK;
     const size_t cap = 4u << 20;  // keys per chunk: 32 MiB keys + 16 MiB results
     for (int i = 0; i < 3; i++) {
@@ -801,6 +804,7 @@ int ensure_stage(umgap_index* ix) {
     ix->stage_cap = cap;
     return UMGAP_OK;
 }
+namespace {
 
 }  // namespace
 
