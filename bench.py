@@ -595,6 +595,21 @@ def main():
             out["surface_b"] = {"error": "%s: %s" % (type(e).__name__, e)}
         torch.cuda.empty_cache()
         try:
+            # the host-pointer entry points a Rust host binds, the PCIe link included (never `value`): pinned arrays in, pinned arrays out
+            import bench_host_lookup
+            import bench_records
+            hl = bench_host_lookup.run(2_000_000_000, 200_000_000, steps=3)
+            torch.cuda.empty_cache()
+            hr = bench_records.run(50_000_000, 10_000_000, steps=3)
+            out["host_fed"] = {"umgap_index_lookup9": {"G_lookups_per_s": hl["pinned"]["G_lookups_per_s"], "GB_per_s_in": hl["pinned"]["GB_per_s_in"],
+                                                       "pageable_G_lookups_per_s": hl["pageable"]["G_lookups_per_s"], "queries": hl["queries"]},
+                               "umgap_classify_records": {"pairs_per_s": hr["pinned"]["pairs_per_s"], "GB_per_s_in": hr["pinned"]["GB_per_s_in"],
+                                                          "pageable_pairs_per_s": hr["pageable"]["pairs_per_s"], "pairs": hr["pairs"], "pipeline": hr["pipeline"]},
+                               "link_GBps_bare_copy": hr["h2d_pinned_32MB_pieces_GBps"]}
+        except Exception as e:  # noqa: BLE001
+            out["host_fed"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+        try:
             import end_to_end
             out["end_to_end"], out["cpu_baseline_end_to_end"] = end_to_end.run()
         except Exception as e:  # noqa: BLE001

@@ -800,7 +800,10 @@ int umgap::ensure_stage(umgap_index* ix) {
         UMGAP_HIP(hipHostMalloc(&ix->h_stage[i], cap * 12, hipHostMallocDefault));
         UMGAP_HIP(hipMalloc(&ix->d_stage[i], cap * 12));
     }
-    if (!ix->up_stream) UMGAP_HIP(hipStreamCreateWithFlags(&ix->up_stream, hipStreamNonBlocking));
+    if (!ix->up_stream) {
+        UMGAP_HIP(hipStreamCreateWithFlags(&ix->up_stream, hipStreamNonBlocking));
+        UMGAP_HIP(hipStreamCreateWithFlags(&ix->run_stream, hipStreamNonBlocking));
+    }
     ix->stage_cap = cap;
     return UMGAP_OK;
 }
@@ -1010,6 +1013,7 @@ void umgap_index_free(umgap_index* ix) {
         if (ix->d_stage[i]) (void)hipFree(ix->d_stage[i]);
     }
     if (ix->up_stream) (void)hipStreamDestroy(ix->up_stream);
+    if (ix->run_stream) (void)hipStreamDestroy(ix->run_stream);
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
     delete ix;
 }
@@ -1586,7 +1590,7 @@ int umgap_index_lookup9(umgap_index* ix, const uint64_t* keys, size_t n, uint32_
         UMGAP_HIP(hipEventCreateWithFlags(&ev.uploaded[i], hipEventDisableTiming));
         UMGAP_HIP(hipEventCreateWithFlags(&ev.done[i], hipEventDisableTiming));
     }
-    const hipStream_t up = ix->up_stream, run = ix->stream;
+    const hipStream_t up = ix->up_stream, run = ix->run_stream;
     size_t pending_off[NS] = {}, pending_len[NS] = {};
     auto drain = [&](int s) -> int {          // the answers of the slot's last chunk: waited for, and copied out when they went through staging
         if (!pending_len[s]) return UMGAP_OK;

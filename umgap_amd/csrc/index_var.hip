@@ -811,7 +811,7 @@ int umgap_index_lookup_var(umgap_index* ix, const uint8_t* bytes, const uint64_t
         UMGAP_HIP(hipEventCreateWithFlags(&ev.uploaded[i], hipEventDisableTiming));
         UMGAP_HIP(hipEventCreateWithFlags(&ev.done[i], hipEventDisableTiming));
     }
-    const hipStream_t up = ix->up_stream, run = ix->stream;
+    const hipStream_t up = ix->up_stream, run = ix->run_stream;
     size_t pending_at[NS] = {}, pending_len[NS] = {};
     auto h_bytes = [&](int s) { return (uint8_t*)ix->h_stage[s] + PAD; };
     auto h_off = [&](int s) { return (uint64_t*)((char*)ix->h_stage[s] + PAD + CAPB + PAD); };

@@ -285,12 +285,15 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
     }
     Slot S[NS];
     hipError_t e = hipSuccess;
-    if (!tx->stream2) e = hipStreamCreateWithFlags(&tx->stream2, hipStreamNonBlocking);
+    if (!tx->stream2) {
+        e = hipStreamCreateWithFlags(&tx->stream2, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&tx->stream3, hipStreamNonBlocking);
+    }
     if (e != hipSuccess) return fail(UMGAP_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     // an UPLOAD lane and a COMPUTE lane, tied by events per slot: with one lane per chunk (rounds 2-3) the two lanes fell into step --
     // both uploading, then both computing -- and the link idled while the kernels ran (rocprofv3 --memory-copy-trace: 2.2 ms per
     // two chunks instead of 1.4)
-    const hipStream_t up = tx->stream2, run_on = tx->stream;
+    const hipStream_t up = tx->stream2, run_on = tx->stream3;
     if (!tx->h_flags) e = hipHostMalloc((void**)&tx->h_flags, 2 * NS * sizeof(uint32_t), hipHostMallocDefault);
     if (e != hipSuccess) { tx->h_flags = nullptr; return fail(UMGAP_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
     volatile uint32_t* h_bad = tx->h_flags;    // per slot: {offsets bad, reads unfit for the fused kernel}

@@ -284,6 +284,7 @@ void umgap_taxonomy_free(umgap_taxonomy* tx) {
     if (tx->d_big_scratch) (void)hipFree(tx->d_big_scratch);
     if (tx->stream) (void)hipStreamDestroy(tx->stream);
     if (tx->stream2) (void)hipStreamDestroy(tx->stream2);
+    if (tx->stream3) (void)hipStreamDestroy(tx->stream3);
     if (tx->h_flags) (void)hipHostFree(tx->h_flags);
     delete tx;
 }

@@ -49,7 +49,10 @@ struct umgap_taxonomy {
     uint64_t* d_sparse8 = nullptr;                    // [levels8][n_blocks8] packed (depth << 32 | pos) minima over 8-blocks: per-lane O(1) LCA
     uint32_t n_blocks8 = 0, n_levels8 = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;     // the upload lane of umgap_classify_records (chunks c+1, c+2 upload while chunk c computes on `stream`)
+    // the upload lane and the compute lane of umgap_classify_records (chunks c+1, c+2 upload while chunk c computes).  Created TOGETHER,
+    // one right after the other: the runtime spreads streams over a handful of hardware queues, and two lanes that land on the same
+    // queue do not overlap at all (seen inside bench.py, where dozens of streams exist by then: 193 instead of 360 M pairs/s)
+    hipStream_t stream2 = nullptr, stream3 = nullptr;
     uint32_t* h_flags = nullptr;       // pinned: per-slot {bad offsets, unfit read} flags of umgap_classify_records
     // staging for the host-pointer umgap_aggregate
     void* d_stage = nullptr;
