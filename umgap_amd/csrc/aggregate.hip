@@ -242,6 +242,19 @@ int umgap_aggregate_strided_dev(umgap_taxonomy* tx, int method, int strategy, fl
     return launch(tx, method, strategy, factor, lower_bound, ranked_only, d_taxa, nullptr, nullptr, stride, n_reads, d_out_taxon, d_out_status, (hipStream_t)stream);
 }
 
+}  // extern "C"
+namespace {
+__global__ __launch_bounds__(256) void k_rebase_read_offsets(uint64_t* __restrict__ off, size_t n, uint64_t base) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) off[i] -= base;
+}
+}  // namespace
+extern "C" {
+
+// Host arrays in, host arrays out, the link included: chunks of whole reads (at most 8 M taxa / 1 M reads) through three staging
+// slots, an upload lane and a compute lane tied by events per slot (records.hip tells why the lanes are created together); the
+// caller's arrays are copied from / to directly (pin them with umgap_host_alloc for the full rate of the link).
 int umgap_aggregate(umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound, int ranked_only,
                     const uint32_t* taxa, const float* scores, const uint64_t* read_offsets, size_t n_reads,
                     uint32_t* out_taxon, uint32_t* out_status) {
@@ -251,10 +264,29 @@ int umgap_aggregate(umgap_taxonomy* tx, int method, int strategy, float factor, 
     if (!n_reads) return UMGAP_OK;
     const uint64_t base = read_offsets[0], total = read_offsets[n_reads] - base;
     if (total && !taxa) return fail(UMGAP_ERR_INVALID, "umgap_aggregate: null taxa");
-    // device staging: taxa | scores | offsets | out_taxon | out_status
-    size_t b_taxa = (total * 4 + 15) & ~(size_t)15, b_sc = scores ? b_taxa : 0, b_off = ((n_reads + 1) * 8 + 15) & ~(size_t)15,
-           b_out = (n_reads * 4 + 15) & ~(size_t)15;
-    size_t need = b_taxa + b_sc + b_off + 2 * b_out;
+    constexpr int NS = 3;
+    constexpr uint64_t CAPT = 8u << 20;     // taxa per chunk (a single read may exceed it: it is a chunk of its own)
+    constexpr size_t CAPR = 1u << 20;       // reads per chunk
+    // chunk plan: whole reads
+    std::vector<size_t> cuts{0};
+    uint64_t max_t = 0;
+    size_t max_r = 0;
+    while (cuts.back() < n_reads) {
+        const size_t r0 = cuts.back();
+        size_t lo = r0 + 1, hi = std::min(n_reads, r0 + CAPR);
+        const uint64_t t0 = read_offsets[r0];
+        while (lo < hi) {
+            const size_t mid = lo + (hi - lo + 1) / 2;
+            if (read_offsets[mid] >= t0 && read_offsets[mid] - t0 <= CAPT) lo = mid; else hi = mid - 1;
+        }
+        if (read_offsets[lo] < t0) return fail(UMGAP_ERR_INVALID, "umgap_aggregate: read_offsets must not decrease");
+        max_t = std::max(max_t, read_offsets[lo] - t0);
+        max_r = std::max(max_r, lo - r0);
+        cuts.push_back(lo);
+    }
+    // device staging per slot: taxa | scores | offsets | out_taxon | out_status
+    const size_t b_taxa = (max_t * 4 + 255) & ~(size_t)255, b_sc = scores ? b_taxa : 0, b_off = ((max_r + 1) * 8 + 255) & ~(size_t)255, b_out = (max_r * 4 + 255) & ~(size_t)255;
+    const size_t per_slot = b_taxa + b_sc + b_off + 2 * b_out, need = NS * per_slot;
     if (need > tx->d_stage_bytes) {
         if (tx->d_stage) (void)hipFree(tx->d_stage);
         tx->d_stage = nullptr;
@@ -263,22 +295,48 @@ int umgap_aggregate(umgap_taxonomy* tx, int method, int strategy, float factor, 
         if (e != hipSuccess) return fail(UMGAP_ERR_NOMEM, std::string("hipMalloc(aggregate staging): ") + hipGetErrorString(e));
         tx->d_stage_bytes = need;
     }
-    char* p = (char*)tx->d_stage;
-    uint32_t* d_taxa = (uint32_t*)p; p += b_taxa;
-    float* d_sc = scores ? (float*)p : nullptr; p += b_sc;
-    uint64_t* d_off = (uint64_t*)p; p += b_off;
-    uint32_t* d_ot = (uint32_t*)p; p += b_out;
-    uint32_t* d_os = (uint32_t*)p;
-    std::vector<uint64_t> rel(n_reads + 1);
-    for (size_t i = 0; i <= n_reads; i++) rel[i] = read_offsets[i] - base;
-    if (total) UMGAP_HIP(hipMemcpyAsync(d_taxa, taxa + base, total * 4, hipMemcpyHostToDevice, tx->stream));
-    if (scores && total) UMGAP_HIP(hipMemcpyAsync(d_sc, scores + base, total * 4, hipMemcpyHostToDevice, tx->stream));
-    UMGAP_HIP(hipMemcpyAsync(d_off, rel.data(), (n_reads + 1) * 8, hipMemcpyHostToDevice, tx->stream));
-    rc = launch(tx, method, strategy, factor, lower_bound, ranked_only, d_taxa, d_sc, d_off, 0, n_reads, d_ot, d_os, tx->stream);
-    if (rc) { (void)hipStreamSynchronize(tx->stream); return rc; }
-    UMGAP_HIP(hipMemcpyAsync(out_taxon, d_ot, n_reads * 4, hipMemcpyDeviceToHost, tx->stream));
-    UMGAP_HIP(hipMemcpyAsync(out_status, d_os, n_reads * 4, hipMemcpyDeviceToHost, tx->stream));
-    UMGAP_HIP(hipStreamSynchronize(tx->stream));
+    if (!tx->stream2) {
+        hipError_t e = hipStreamCreateWithFlags(&tx->stream2, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&tx->stream3, hipStreamNonBlocking);
+        if (e != hipSuccess) return fail(UMGAP_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    }
+    const hipStream_t up = tx->stream2, run = tx->stream3;
+    struct Events {
+        hipEvent_t uploaded[NS] = {}, done[NS] = {};
+        ~Events() { for (hipEvent_t x : uploaded) if (x) (void)hipEventDestroy(x); for (hipEvent_t x : done) if (x) (void)hipEventDestroy(x); }
+    } ev;
+    for (int i = 0; i < NS; i++) {
+        UMGAP_HIP(hipEventCreateWithFlags(&ev.uploaded[i], hipEventDisableTiming));
+        UMGAP_HIP(hipEventCreateWithFlags(&ev.done[i], hipEventDisableTiming));
+    }
+    for (size_t c = 0; c + 1 < cuts.size() && !rc; c++) {
+        const int slot = (int)(c % NS);
+        const size_t r0 = cuts[c], nr = cuts[c + 1] - r0;
+        const uint64_t t0 = read_offsets[r0], nt = read_offsets[cuts[c + 1]] - t0;
+        char* p = (char*)tx->d_stage + (size_t)slot * per_slot;
+        uint32_t* d_taxa = (uint32_t*)p; p += b_taxa;
+        float* d_sc = scores ? (float*)p : nullptr; p += b_sc;
+        uint64_t* d_off = (uint64_t*)p; p += b_off;
+        uint32_t* d_ot = (uint32_t*)p; p += b_out;
+        uint32_t* d_os = (uint32_t*)p;
+        if (c >= (size_t)NS) {                 // the slot's previous tenant is through (its results have left)
+            UMGAP_HIP(hipEventSynchronize(ev.done[slot]));
+        }
+        if (nt) UMGAP_HIP(hipMemcpyAsync(d_taxa, taxa + t0, nt * 4, hipMemcpyHostToDevice, up));
+        if (scores && nt) UMGAP_HIP(hipMemcpyAsync(d_sc, scores + t0, nt * 4, hipMemcpyHostToDevice, up));
+        UMGAP_HIP(hipMemcpyAsync(d_off, read_offsets + r0, (nr + 1) * 8, hipMemcpyHostToDevice, up));
+        UMGAP_HIP(hipEventRecord(ev.uploaded[slot], up));
+        UMGAP_HIP(hipStreamWaitEvent(run, ev.uploaded[slot], 0));
+        hipLaunchKernelGGL(k_rebase_read_offsets, dim3((unsigned)std::min<size_t>((nr + 256) / 256, 1024)), dim3(256), 0, run, d_off, nr + 1, t0);
+        rc = launch(tx, method, strategy, factor, lower_bound, ranked_only, d_taxa, d_sc, d_off, 0, nr, d_ot, d_os, run);
+        if (rc) break;
+        UMGAP_HIP(hipMemcpyAsync(out_taxon + r0, d_ot, nr * 4, hipMemcpyDeviceToHost, run));
+        UMGAP_HIP(hipMemcpyAsync(out_status + r0, d_os, nr * 4, hipMemcpyDeviceToHost, run));
+        UMGAP_HIP(hipEventRecord(ev.done[slot], run));
+    }
+    const hipError_t e0 = hipStreamSynchronize(up), e1 = hipStreamSynchronize(run);
+    if (rc) return rc;
+    if (e0 != hipSuccess || e1 != hipSuccess) return fail(UMGAP_ERR_DEVICE, std::string("umgap_aggregate: ") + hipGetErrorString(e0 != hipSuccess ? e0 : e1));
     return UMGAP_OK;
 }
 
