@@ -10,6 +10,7 @@
 #include <thread>
 #include <vector>
 
+#include "host_copy.hpp"
 #include "probe_common.hpp"
 #include "window_locate.hpp"
 #include "taxonomy.hpp"
@@ -1595,7 +1596,7 @@ int umgap_index_lookup9(umgap_index* ix, const uint64_t* keys, size_t n, uint32_
     auto drain = [&](int s) -> int {          // the answers of the slot's last chunk: waited for, and copied out when they went through staging
         if (!pending_len[s]) return UMGAP_OK;
         UMGAP_HIP(hipEventSynchronize(ev.done[s]));
-        if (!out_pinned) memcpy(out + pending_off[s], (char*)ix->h_stage[s] + cap * 8, pending_len[s] * 4);
+        if (!out_pinned) par_memcpy(out + pending_off[s], (char*)ix->h_stage[s] + cap * 8, pending_len[s] * 4);
         pending_len[s] = 0;
         return UMGAP_OK;
     };
@@ -1608,7 +1609,7 @@ int umgap_index_lookup9(umgap_index* ix, const uint64_t* keys, size_t n, uint32_
         uint64_t* dk = (uint64_t*)ix->d_stage[slot];
         uint32_t* dout = (uint32_t*)((char*)ix->d_stage[slot] + cap * 8);
         const uint64_t* src = keys + off;
-        if (!in_pinned) { memcpy(ix->h_stage[slot], keys + off, len * 8); src = (const uint64_t*)ix->h_stage[slot]; }
+        if (!in_pinned) { par_memcpy(ix->h_stage[slot], keys + off, len * 8); src = (const uint64_t*)ix->h_stage[slot]; }
         UMGAP_HIP(hipMemcpyAsync(dk, src, len * 8, hipMemcpyHostToDevice, up));
         UMGAP_HIP(hipEventRecord(ev.uploaded[slot], up));
         UMGAP_HIP(hipStreamWaitEvent(run, ev.uploaded[slot], 0));

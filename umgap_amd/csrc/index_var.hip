@@ -18,6 +18,7 @@
 #include <cmath>
 #include <vector>
 
+#include "host_copy.hpp"
 #include "var_index.hpp"
 
 using namespace umgap;
@@ -822,7 +823,7 @@ int umgap_index_lookup_var(umgap_index* ix, const uint8_t* bytes, const uint64_t
     auto drain = [&](int s) -> int {
         if (!pending_len[s]) return UMGAP_OK;
         UMGAP_HIP(hipEventSynchronize(ev.done[s]));
-        if (!out_pinned) memcpy(out + pending_at[s], h_out(s), pending_len[s] * 4);
+        if (!out_pinned) par_memcpy(out + pending_at[s], h_out(s), pending_len[s] * 4);
         pending_len[s] = 0;
         return UMGAP_OK;
     };
@@ -844,8 +845,8 @@ int umgap_index_lookup_var(umgap_index* ix, const uint8_t* bytes, const uint64_t
         const uint8_t* src_b = bytes + b0;
         const uint64_t* src_o = offsets + i0;
         if (!in_pinned) {
-            memcpy(h_bytes(slot), src_b, nb);
-            memcpy(h_off(slot), src_o, (len + 1) * 8);
+            par_memcpy(h_bytes(slot), src_b, nb);
+            par_memcpy(h_off(slot), src_o, (len + 1) * 8);
             src_b = h_bytes(slot);
             src_o = h_off(slot);
         }
