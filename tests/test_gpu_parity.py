@@ -2087,6 +2087,95 @@ def test_classify_records_fused_route(api, torch_cuda, F, misfit):
                 assert s1[r] == s0[r] == 3, (r, s1[r])      # UMGAP_READ_PANIC
 
 
+def test_host_pointer_calls_across_chunk_seams(api, torch_cuda):
+    """The host-pointer entry points cut a call into chunks that travel over an upload lane while earlier chunks compute
+    (records.hip, index.hip, index_var.hip, aggregate.hip): the answers must not depend on where the seams fall.  Each call is
+    made on inputs that span several chunks -- from pageable and from pinned arrays -- and compared with the device-pointer call
+    on the same data."""
+    torch = torch_cuda
+    from umgap_amd import _lib
+    from umgap_amd.api import METHODS, STRATEGIES, Index, check, classify_records
+    from umgap_amd.synth import SyntheticWorkload
+    L = _lib.load()
+    rng = np.random.default_rng(77)
+    w = SyntheticWorkload(n_tax=20_000, n_keys=3_000_000, build_index=True)
+    # -- get(): 17.6 M keys = five chunks of 4 M
+    d_q = w.reads(0, 210_000)
+    want = w.index.lookup9_dev(d_q, miss_value=5).cpu()
+    for pin in (False, True):
+        h_q = torch.empty(d_q.numel(), dtype=torch.int64, pin_memory=pin)
+        h_q.copy_(d_q.cpu())
+        h_o = torch.full((d_q.numel(),), -1, dtype=torch.int32, pin_memory=pin)
+        check(L.umgap_index_lookup9(w.index._h, h_q.data_ptr(), d_q.numel(), 5, h_o.data_ptr()))
+        assert torch.equal(h_o, want), pin
+    # -- aggregate: 17 M taxa in ragged reads = three chunks of 8 M taxa
+    d_t = w.index.lookup9_dev(d_q, miss_value=0)
+    lens = rng.integers(0, 170, 300_000)
+    offs = np.zeros(len(lens) + 1, np.int64)
+    offs[1:] = np.cumsum(lens)
+    n_reads = int(np.searchsorted(offs, d_t.numel(), side="right") - 1)
+    offs = offs[:n_reads + 1]
+    assert offs[-1] > 16_800_000
+    d_o = torch.from_numpy(offs).cuda()
+    for method, strategy, lb in (("tree", "lca*", 2.0), ("rmq", "mrtl", 1.0), ("tree", "hybrid", 0.0)):
+        t0 = torch.full((n_reads,), -1, dtype=torch.int32, device="cuda")
+        s0 = torch.full_like(t0, -1)
+        w.taxonomy.aggregate_dev(d_t, d_o, t0, s0, method=method, strategy=strategy, factor=0.25, lower_bound=lb)
+        torch.cuda.synchronize()
+        for pin in (False, True):
+            h_t = torch.empty(d_t.numel(), dtype=torch.int32, pin_memory=pin)
+            h_t.copy_(d_t.cpu())
+            h_off = torch.from_numpy(offs.copy())
+            o_t, o_s = torch.full((n_reads,), -2, dtype=torch.int32), torch.full((n_reads,), -2, dtype=torch.int32)
+            if pin:
+                h_off, o_t, o_s = h_off.pin_memory(), o_t.pin_memory(), o_s.pin_memory()
+            check(L.umgap_aggregate(w.taxonomy._h, METHODS[method], STRATEGIES[strategy], 0.25, lb, 0, h_t.data_ptr(), None, h_off.data_ptr(), n_reads, o_t.data_ptr(), o_s.data_ptr()))
+            assert torch.equal(o_s, s0.cpu()), (strategy, pin)
+            same = (o_t == t0.cpu()) | (o_s != 0)
+            assert same.all() if strategy != "hybrid" else same.float().mean() > 0.99, (strategy, pin)     # (hybrid: ties between children)
+    # -- records: 6 MB of residues in chunks of 1 MB, both routes, against one chunk
+    letters = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    prot = [rng.choice(letters, 60).tobytes() for _ in range(3000)]
+    table = {}
+    for i, p in enumerate(prot):
+        for k in range(len(p) - 8):
+            table.setdefault(p[k:k + 9], int(w.ids[i % len(w.ids)]))
+    kmers = sorted(table)
+    keys, _ = api.pack9_array(kmers)
+    ix = Index.build(keys, np.array([table[k] for k in kmers], np.uint32))
+    frags = []
+    for r in range(60_000):
+        for _ in range(2):
+            f = bytearray(prot[int(rng.integers(0, len(prot)))][int(rng.integers(0, 8)):][:50])
+            if rng.random() < 0.3:
+                f[int(rng.integers(0, len(f)))] = int(rng.choice(letters))
+            frags.append(bytes(f))
+    rf = np.arange(0, len(frags) + 1, 2, dtype=np.uint64)
+    kw = dict(method="tree", strategy="lca*", lower_bound=2.0, seedextend=True, min_seed_size=3, max_gap_size=1)
+    ref = classify_records(ix, w.taxonomy, frags, rf, **kw)
+    assert L.umgap_records_last_route() == 1 and (ref[1] == 0).mean() > 0.5
+    for fused in ("1", "0"):
+        os.environ["UMGAP_RECORDS_CHUNK_MB"], os.environ["UMGAP_RECORDS_FUSED"] = "1", fused
+        try:
+            got = classify_records(ix, w.taxonomy, frags, rf, **kw)
+        finally:
+            del os.environ["UMGAP_RECORDS_CHUNK_MB"], os.environ["UMGAP_RECORDS_FUSED"]
+        assert np.array_equal(got[0], ref[0]) and np.array_equal(got[1], ref[1]), fused
+    # -- tryptic get(): 2.5 M peptides = three chunks of 1 M
+    pep = [prot[int(i)][int(a):int(a) + int(n)] for i, a, n in zip(rng.integers(0, len(prot), 40_000), rng.integers(0, 20, 40_000), rng.integers(5, 40, 40_000))]
+    pep = sorted(set(pep))
+    vx = Index.build_var(pep, rng.choice(w.ids, len(pep)).astype(np.uint32))
+    pick, miss = rng.integers(0, len(pep), 2_500_000).tolist(), (rng.random(2_500_000) >= 0.7).tolist()
+    q = [pep[i][::-1] + b"W" if m else pep[i] for i, m in zip(pick, miss)]             # (reversed + one residue: mostly absent)
+    data, qo = api._concat(q)
+    d_b, d_qo = torch.from_numpy(np.concatenate([data, np.zeros(64, np.uint8)])).cuda(), torch.from_numpy(qo.view(np.int64).copy()).cuda()
+    wv = torch.full((len(q),), -1, dtype=torch.int32, device="cuda")
+    vx.lookup_var_dev(d_b, d_qo, wv, miss_value=9)
+    torch.cuda.synchronize()
+    got = vx.lookup_var(q, miss_value=9)
+    assert np.array_equal(np.asarray(got).view(np.int32), wv.cpu().numpy())
+
+
 # ---------------------------------------------------------------------------------------------
 # BASELINE.json configs[2] at full size: 50 M pairs (5 x 10 M), 8 G-key table, size-independent properties
 # ---------------------------------------------------------------------------------------------
