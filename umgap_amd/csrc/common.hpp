@@ -120,8 +120,8 @@ struct umgap_index {
     void* h_stage[3] = {nullptr, nullptr, nullptr};
     void* d_stage[3] = {nullptr, nullptr, nullptr};
     size_t stage_cap = 0;  // keys per staging buffer
-    // the upload lane and the probe lane of the host-pointer look-ups (chunks c+1, c+2 upload while chunk c is probed); created
-    // together, so that they land on different hardware queues (taxonomy.hpp)
+    // the upload lane (copies only: taxonomy.hpp) and the probe lane of the host-pointer look-ups (chunks c+1, c+2 upload while
+    // chunk c is probed)
     hipStream_t up_stream = nullptr, run_stream = nullptr;
     // non-null: the slot values are not taxon ids but codes bound to that taxonomy (bound.hpp); only the bound
     // fused kernel understands them

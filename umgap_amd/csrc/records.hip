@@ -17,6 +17,7 @@
 //   k_frag_prepare   fragment -> {start, length} (validated) + the tail positions marked in a bitmap
 //   k_lookup_bytes9  every unmarked byte position: 9 residues packed from LDS -> quad probe -> hits[b]
 //   k_seedextend_frags / k_read_offsets / the aggregate kernels / k_mark_seed_panics
+#include "host_copy.hpp"
 #include "probe_common.hpp"
 #include "prot_limits.hpp"
 #include "seedextend.hpp"
@@ -283,6 +284,42 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
         if (e != hipSuccess) return fail(UMGAP_ERR_NOMEM, std::string("hipMalloc(record staging): ") + hipGetErrorString(e));
         tx->d_stage_bytes = need + need / 8;
     }
+    // callers with pageable arrays: the chunks go through pinned staging with a threaded memcpy (host_copy.hpp), the results come
+    // back through it too -- an asynchronous copy from / to pageable memory blocks the host until it is done, which would keep the
+    // upload lane from running ahead
+    auto is_pinned = [](const void* p0, const void* p1) {
+        hipPointerAttribute_t a{};
+        for (const void* p : {p0, p1}) {
+            if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+            if (a.type != hipMemoryTypeHost) return false;
+        }
+        return true;
+    };
+    const bool in_pinned = (!n_bytes || is_pinned(bytes + base, bytes + base + n_bytes - 1)) && (!n_fragments || is_pinned(frag_offsets, frag_offsets + n_fragments)) &&
+                           is_pinned(read_frags, read_frags + n_reads);
+    const bool out_pinned = is_pinned(out_taxon, out_taxon + n_reads - 1) && is_pinned(out_status, out_status + n_reads - 1);
+    const size_t hb_bytes = pad256(max_b + 16), hb_off = pad256((max_f + 1) * 8), hb_rf = pad256((max_r + 1) * 8), hb_out = pad256(max_r * 4 + 4);
+    const size_t h_per_slot = (in_pinned ? 0 : hb_bytes + hb_off + hb_rf) + (out_pinned ? 0 : 2 * hb_out);
+    if (NS * h_per_slot > tx->h_stage_bytes) {
+        if (tx->h_stage) (void)hipHostFree(tx->h_stage);
+        tx->h_stage = nullptr;
+        tx->h_stage_bytes = 0;
+        if (hipHostMalloc(&tx->h_stage, NS * h_per_slot, hipHostMallocDefault) != hipSuccess) return fail(UMGAP_ERR_NOMEM, "umgap_classify_records: hipHostMalloc of the staging failed");
+        tx->h_stage_bytes = NS * h_per_slot;
+    }
+    struct HostSlot { uint8_t* bytes = nullptr; uint64_t *off = nullptr, *rf = nullptr; uint32_t *ot = nullptr, *os = nullptr; } H[NS];
+    for (int k = 0; k < NS; k++) {
+        char* p = (char*)tx->h_stage + (size_t)k * h_per_slot;
+        if (!in_pinned) { H[k].bytes = (uint8_t*)p; p += hb_bytes; H[k].off = (uint64_t*)p; p += hb_off; H[k].rf = (uint64_t*)p; p += hb_rf; }
+        if (!out_pinned) { H[k].ot = (uint32_t*)p; p += hb_out; H[k].os = (uint32_t*)p; }
+    }
+    size_t out_at[NS] = {}, out_n[NS] = {};       // results of the slot's chunk still in the staging (pageable outputs)
+    auto drain_out = [&](int k) {
+        if (!out_n[k]) return;
+        memcpy(out_taxon + out_at[k], H[k].ot, out_n[k] * 4);
+        memcpy(out_status + out_at[k], H[k].os, out_n[k] * 4);
+        out_n[k] = 0;
+    };
     Slot S[NS];
     hipError_t e = hipSuccess;
     if (!tx->stream2) {
@@ -331,18 +368,28 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
         const size_t r0 = cuts[c], nr = cuts[c + 1] - r0;
         const uint64_t f0 = frag_of(r0), nf = frag_of(cuts[c + 1]) - f0;
         const uint64_t b0 = byte_of(r0), nb = byte_of(cuts[c + 1]) - b0;
-        // ---- upload lane: the slot's previous tenant (chunk c - NS) must be through ----
-        if (c >= (size_t)NS) UMGAP_HIP(hipStreamWaitEvent(up, ev.done[slot], 0));
-        UMGAP_HIP(hipMemsetAsync(L.bad, 0, 8, up));
-        if (!fused) UMGAP_HIP(hipMemsetAsync(L.tails, 0, (nb / 32 + 8) * 4, up));
-        if (nb) UMGAP_HIP(hipMemcpyAsync(L.bytes, bytes + base + b0, nb, hipMemcpyHostToDevice, up));
-        UMGAP_HIP(hipMemsetAsync(L.bytes + nb, 0, 144, up));   // the packer may look 8 bytes past the chunk
-        if (nf) UMGAP_HIP(hipMemcpyAsync(L.off, frag_offsets + f0, (nf + 1) * 8, hipMemcpyHostToDevice, up));
-        UMGAP_HIP(hipMemcpyAsync(L.rf, read_frags + r0, (nr + 1) * 8, hipMemcpyHostToDevice, up));
+        // ---- upload lane: COPIES ONLY.  The slot's previous tenant (chunk c - NS) is through: the host waited for it below.  No fill,
+        // no wait on an event here: those are packets of a compute queue, the runtime folds a process's streams onto four of them
+        // (tools/native/queue_probe.hip: streams 0..9 -> queues 0 1 2 3 3 2 1 0 3 2), and on a queue shared with the compute lane such
+        // a packet -- and every upload behind it -- waits for the running kernel ----
+        const uint8_t* src_b = bytes + base + b0;
+        const uint64_t *src_o = frag_offsets + f0, *src_r = read_frags + r0;
+        if (!in_pinned) {          // (the slot's previous upload is long through: the host waited for that chunk's results below)
+            if (nb) par_memcpy(H[slot].bytes, src_b, nb);
+            if (nf) par_memcpy(H[slot].off, src_o, (nf + 1) * 8);
+            par_memcpy(H[slot].rf, src_r, (nr + 1) * 8);
+            src_b = H[slot].bytes; src_o = H[slot].off; src_r = H[slot].rf;
+        }
+        if (nb) UMGAP_HIP(hipMemcpyAsync(L.bytes, src_b, nb, hipMemcpyHostToDevice, up));
+        if (nf) UMGAP_HIP(hipMemcpyAsync(L.off, src_o, (nf + 1) * 8, hipMemcpyHostToDevice, up));
+        UMGAP_HIP(hipMemcpyAsync(L.rf, src_r, (nr + 1) * 8, hipMemcpyHostToDevice, up));
         UMGAP_HIP(hipEventRecord(ev.uploaded[slot], up));
         // ---- compute lane ----
         const hipStream_t s = run_on;
         UMGAP_HIP(hipStreamWaitEvent(s, ev.uploaded[slot], 0));
+        UMGAP_HIP(hipMemsetAsync(L.bad, 0, 8, s));
+        if (!fused) UMGAP_HIP(hipMemsetAsync(L.tails, 0, (nb / 32 + 8) * 4, s));
+        UMGAP_HIP(hipMemsetAsync(L.bytes + nb, 0, 144, s));   // the packer may look 8 bytes past the chunk
         const unsigned gf = (unsigned)std::min<size_t>((nf + 255) / 256 + 1, 2048), gr = (unsigned)std::min<size_t>((nr + 256) / 256 + 1, 2048);
         if (fused) {
             if (!nf) UMGAP_HIP(hipMemsetAsync(L.off, 0, 8, s));
@@ -369,19 +416,22 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
         if (!rc && want_kept && nf) rc = mark_seedextend_panics(L.kept, L.rfl, nr, L.ot, L.os, s);
         if (rc) break;
         }
-        UMGAP_HIP(hipMemcpyAsync(out_taxon + r0, L.ot, nr * 4, hipMemcpyDeviceToHost, s));
-        UMGAP_HIP(hipMemcpyAsync(out_status + r0, L.os, nr * 4, hipMemcpyDeviceToHost, s));
+        UMGAP_HIP(hipMemcpyAsync(out_pinned ? out_taxon + r0 : H[slot].ot, L.ot, nr * 4, hipMemcpyDeviceToHost, s));
+        UMGAP_HIP(hipMemcpyAsync(out_pinned ? out_status + r0 : H[slot].os, L.os, nr * 4, hipMemcpyDeviceToHost, s));
+        if (!out_pinned) { out_at[slot] = r0; out_n[slot] = nr; }
         UMGAP_HIP(hipMemcpyAsync(tx->h_flags + 2 * slot, L.bad, 8, hipMemcpyDeviceToHost, s));
         UMGAP_HIP(hipEventRecord(ev.done[slot], s));
         // the host stays at most NS chunks ahead, and looks at the flags of the chunk whose slot the next one takes
         if (c + 1 >= (size_t)NS) {
             const int w = (int)((c + 1 - NS) % NS);
             UMGAP_HIP(hipEventSynchronize(ev.done[w]));
+            drain_out(w);
             if (h_bad[2 * w]) { rc = fail(UMGAP_ERR_INVALID, "umgap_classify_records: frag_offsets / read_frags are not non-decreasing offsets into the block"); break; }
             if (h_bad[2 * w + 1]) { unfit = true; break; }    // a read the fused kernel does not take: the caller runs the general kernels
         }
     }
     hipError_t e0 = hipStreamSynchronize(up), e1 = hipStreamSynchronize(run_on);
+    if (!rc && !unfit && e0 == hipSuccess && e1 == hipSuccess) for (int k = 0; k < NS; k++) drain_out(k);
     if (rc) return rc;
     if (e0 != hipSuccess || e1 != hipSuccess) return fail(UMGAP_ERR_DEVICE, std::string("umgap_classify_records: ") + hipGetErrorString(e0 != hipSuccess ? e0 : e1));
     for (int k = 0; k < NS; k++) {
@@ -395,6 +445,7 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
         rc = run(true);
         if (rc || !unfit) return rc;
         g_last_route = 2;
+        unfit = false;
     } else g_last_route = 0;
     return run(false);
 }

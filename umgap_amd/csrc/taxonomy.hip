@@ -286,6 +286,7 @@ void umgap_taxonomy_free(umgap_taxonomy* tx) {
     if (tx->stream2) (void)hipStreamDestroy(tx->stream2);
     if (tx->stream3) (void)hipStreamDestroy(tx->stream3);
     if (tx->h_flags) (void)hipHostFree(tx->h_flags);
+    if (tx->h_stage) (void)hipHostFree(tx->h_stage);
     delete tx;
 }
 

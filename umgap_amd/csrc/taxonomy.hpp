@@ -49,11 +49,14 @@ struct umgap_taxonomy {
     uint64_t* d_sparse8 = nullptr;                    // [levels8][n_blocks8] packed (depth << 32 | pos) minima over 8-blocks: per-lane O(1) LCA
     uint32_t n_blocks8 = 0, n_levels8 = 0;
     hipStream_t stream = nullptr;
-    // the upload lane and the compute lane of umgap_classify_records (chunks c+1, c+2 upload while chunk c computes).  Created TOGETHER,
-    // one right after the other: the runtime spreads streams over a handful of hardware queues, and two lanes that land on the same
-    // queue do not overlap at all (seen inside bench.py, where dozens of streams exist by then: 193 instead of 360 M pairs/s)
+    // the upload lane and the compute lane of umgap_classify_records / umgap_aggregate (chunks c+1, c+2 upload while chunk c computes).
+    // The upload lane carries COPIES ONLY: the runtime folds a process's streams onto four hardware compute queues, and a fill or an
+    // event wait on a lane that shares its queue with the compute lane waits -- with every upload behind it -- for the running kernel
+    // (tools/native/queue_probe.hip; seen inside bench.py: 193 instead of 360 M pairs/s)
     hipStream_t stream2 = nullptr, stream3 = nullptr;
     uint32_t* h_flags = nullptr;       // pinned: per-slot {bad offsets, unfit read} flags of umgap_classify_records
+    void* h_stage = nullptr;           // pinned staging of umgap_classify_records for callers whose arrays are pageable (grow-only)
+    size_t h_stage_bytes = 0;
     // staging for the host-pointer umgap_aggregate
     void* d_stage = nullptr;
     size_t d_stage_bytes = 0;
