@@ -19,6 +19,7 @@
 //   h' = smallest-preorder surviving taxon that is NOT an ancestor-or-self of M (last[h] < pre[M]);
 //   LCA* = M if there is no h', else LCA(h', M) = first node on M's parent chain with pre <= pre[h'].
 #include "agg_common.hpp"
+#include "host_copy.hpp"
 
 using namespace umgap;
 
@@ -301,6 +302,39 @@ int umgap_aggregate(umgap_taxonomy* tx, int method, int strategy, float factor, 
         if (e != hipSuccess) return fail(UMGAP_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
     }
     const hipStream_t up = tx->stream2, run = tx->stream3;
+    // pageable arrays travel through pinned staging with a threaded memcpy, both ways (records.hip tells why)
+    auto is_pinned = [](const void* p0, const void* p1) {
+        hipPointerAttribute_t a{};
+        for (const void* p : {p0, p1}) {
+            if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+            if (a.type != hipMemoryTypeHost) return false;
+        }
+        return true;
+    };
+    const bool in_pinned = (!total || (is_pinned(taxa + base, taxa + base + total - 1) && (!scores || is_pinned(scores + base, scores + base + total - 1)))) &&
+                           is_pinned(read_offsets, read_offsets + n_reads);
+    const bool out_pinned = is_pinned(out_taxon, out_taxon + n_reads - 1) && is_pinned(out_status, out_status + n_reads - 1);
+    const size_t h_per_slot = (in_pinned ? 0 : b_taxa + b_sc + b_off) + (out_pinned ? 0 : 2 * b_out);
+    if (NS * h_per_slot > tx->h_stage_bytes) {
+        if (tx->h_stage) (void)hipHostFree(tx->h_stage);
+        tx->h_stage = nullptr;
+        tx->h_stage_bytes = 0;
+        if (hipHostMalloc(&tx->h_stage, NS * h_per_slot, hipHostMallocDefault) != hipSuccess) return fail(UMGAP_ERR_NOMEM, "umgap_aggregate: hipHostMalloc of the staging failed");
+        tx->h_stage_bytes = NS * h_per_slot;
+    }
+    struct HostSlot { uint32_t* taxa = nullptr; float* sc = nullptr; uint64_t* off = nullptr; uint32_t *ot = nullptr, *os = nullptr; } H[NS];
+    for (int k = 0; k < NS; k++) {
+        char* p = (char*)tx->h_stage + (size_t)k * h_per_slot;
+        if (!in_pinned) { H[k].taxa = (uint32_t*)p; p += b_taxa; if (scores) { H[k].sc = (float*)p; p += b_sc; } H[k].off = (uint64_t*)p; p += b_off; }
+        if (!out_pinned) { H[k].ot = (uint32_t*)p; p += b_out; H[k].os = (uint32_t*)p; }
+    }
+    size_t out_at[NS] = {}, out_n[NS] = {};
+    auto drain_out = [&](int k) {
+        if (!out_n[k]) return;
+        memcpy(out_taxon + out_at[k], H[k].ot, out_n[k] * 4);
+        memcpy(out_status + out_at[k], H[k].os, out_n[k] * 4);
+        out_n[k] = 0;
+    };
     struct Events {
         hipEvent_t uploaded[NS] = {}, done[NS] = {};
         ~Events() { for (hipEvent_t x : uploaded) if (x) (void)hipEventDestroy(x); for (hipEvent_t x : done) if (x) (void)hipEventDestroy(x); }
@@ -321,20 +355,32 @@ int umgap_aggregate(umgap_taxonomy* tx, int method, int strategy, float factor, 
         uint32_t* d_os = (uint32_t*)p;
         if (c >= (size_t)NS) {                 // the slot's previous tenant is through (its results have left)
             UMGAP_HIP(hipEventSynchronize(ev.done[slot]));
+            drain_out(slot);
         }
-        if (nt) UMGAP_HIP(hipMemcpyAsync(d_taxa, taxa + t0, nt * 4, hipMemcpyHostToDevice, up));
-        if (scores && nt) UMGAP_HIP(hipMemcpyAsync(d_sc, scores + t0, nt * 4, hipMemcpyHostToDevice, up));
-        UMGAP_HIP(hipMemcpyAsync(d_off, read_offsets + r0, (nr + 1) * 8, hipMemcpyHostToDevice, up));
+        const uint32_t* src_t = taxa + t0;
+        const float* src_s = scores ? scores + t0 : nullptr;
+        const uint64_t* src_o = read_offsets + r0;
+        if (!in_pinned) {
+            if (nt) par_memcpy(H[slot].taxa, src_t, nt * 4);
+            if (scores && nt) par_memcpy(H[slot].sc, src_s, nt * 4);
+            par_memcpy(H[slot].off, src_o, (nr + 1) * 8);
+            src_t = H[slot].taxa; src_s = H[slot].sc; src_o = H[slot].off;
+        }
+        if (nt) UMGAP_HIP(hipMemcpyAsync(d_taxa, src_t, nt * 4, hipMemcpyHostToDevice, up));
+        if (scores && nt) UMGAP_HIP(hipMemcpyAsync(d_sc, src_s, nt * 4, hipMemcpyHostToDevice, up));
+        UMGAP_HIP(hipMemcpyAsync(d_off, src_o, (nr + 1) * 8, hipMemcpyHostToDevice, up));
         UMGAP_HIP(hipEventRecord(ev.uploaded[slot], up));
         UMGAP_HIP(hipStreamWaitEvent(run, ev.uploaded[slot], 0));
         hipLaunchKernelGGL(k_rebase_read_offsets, dim3((unsigned)std::min<size_t>((nr + 256) / 256, 1024)), dim3(256), 0, run, d_off, nr + 1, t0);
         rc = launch(tx, method, strategy, factor, lower_bound, ranked_only, d_taxa, d_sc, d_off, 0, nr, d_ot, d_os, run);
         if (rc) break;
-        UMGAP_HIP(hipMemcpyAsync(out_taxon + r0, d_ot, nr * 4, hipMemcpyDeviceToHost, run));
-        UMGAP_HIP(hipMemcpyAsync(out_status + r0, d_os, nr * 4, hipMemcpyDeviceToHost, run));
+        UMGAP_HIP(hipMemcpyAsync(out_pinned ? out_taxon + r0 : H[slot].ot, d_ot, nr * 4, hipMemcpyDeviceToHost, run));
+        UMGAP_HIP(hipMemcpyAsync(out_pinned ? out_status + r0 : H[slot].os, d_os, nr * 4, hipMemcpyDeviceToHost, run));
+        if (!out_pinned) { out_at[slot] = r0; out_n[slot] = nr; }
         UMGAP_HIP(hipEventRecord(ev.done[slot], run));
     }
     const hipError_t e0 = hipStreamSynchronize(up), e1 = hipStreamSynchronize(run);
+    if (!rc && e0 == hipSuccess && e1 == hipSuccess) for (int k = 0; k < NS; k++) drain_out(k);
     if (rc) return rc;
     if (e0 != hipSuccess || e1 != hipSuccess) return fail(UMGAP_ERR_DEVICE, std::string("umgap_aggregate: ") + hipGetErrorString(e0 != hipSuccess ? e0 : e1));
     return UMGAP_OK;
