@@ -86,5 +86,45 @@ int main(int argc, char** argv) {
         }
         printf("\n");
     }
+    // the pipeline of umgap_index_lookup9: 16 chunks of {32 MB up on a; wait, 0.1 ms kernel, 16 MB down on b}, three slots, events
+    // per slot -- and the same with the download on a third stream c = (b + 1) % N
+    {
+        const size_t up_b = 32u << 20, dn_b = 16u << 20;
+        hipEvent_t upl[3], done[3], kdone[3];
+        for (int i = 0; i < 3; i++) { hipEventCreateWithFlags(&upl[i], hipEventDisableTiming); hipEventCreateWithFlags(&done[i], hipEventDisableTiming); hipEventCreateWithFlags(&kdone[i], hipEventDisableTiming); }
+        for (int three = 0; three < 2; three++) {
+            printf(three ? "pipeline, download on a third stream\n" : "pipeline, download on the kernel's stream\n");
+            for (int a = 0; a < N; a++) {
+                printf("a%-2d", a);
+                for (int b = 0; b < N; b++) {
+                    if (a == b) { printf("      -"); continue; }
+                    int c3 = (b + 1) % N;
+                    if (c3 == a) c3 = (c3 + 1) % N;
+                    double best = 1e9;
+                    for (int r = 0; r < 2; r++) {
+                        hipDeviceSynchronize();
+                        const double t0 = now();
+                        for (int c = 0; c < 16; c++) {
+                            const int sl = c % 3;
+                            if (c >= 3) hipEventSynchronize(done[sl]);
+                            hipMemcpyAsync((char*)d + (size_t)sl * (16u << 20), h, up_b / 2, hipMemcpyHostToDevice, st[a]);
+                            hipMemcpyAsync((char*)d + (size_t)sl * (16u << 20), h, up_b / 2, hipMemcpyHostToDevice, st[a]);
+                            hipEventRecord(upl[sl], st[a]);
+                            hipStreamWaitEvent(st[b], upl[sl], 0);
+                            hipLaunchKernelGGL(spin, dim3(256 * 4), dim3(256), 0, st[b], 10000ull, (int*)nullptr);
+                            hipStream_t ds = st[b];
+                            if (three) { hipEventRecord(kdone[sl], st[b]); hipStreamWaitEvent(st[c3], kdone[sl], 0); ds = st[c3]; }
+                            hipMemcpyAsync((char*)h + (32u << 20), (char*)d + (size_t)sl * (16u << 20), dn_b, hipMemcpyDeviceToHost, ds);
+                            hipEventRecord(done[sl], ds);
+                        }
+                        hipDeviceSynchronize();
+                        best = std::min(best, now() - t0);
+                    }
+                    printf(" %6.2f", best);
+                }
+                printf("\n");
+            }
+        }
+    }
     return 0;
 }
