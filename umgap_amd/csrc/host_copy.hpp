@@ -17,7 +17,13 @@ inline void par_memcpy(void* dst, const void* src, size_t n) {
     for (unsigned i = 1; i < t; i++) {
         const size_t o = (size_t)i * per;
         if (o >= n) break;
-        th[started++] = std::thread([=] { memcpy((char*)dst + o, (const char*)src + o, std::min(per, n - o)); });
+        try {
+            th[started] = std::thread([=] { memcpy((char*)dst + o, (const char*)src + o, std::min(per, n - o)); });
+            started++;
+        } catch (...) {       // no thread to be had: this one copies the rest (nothing throws across the C ABI)
+            memcpy((char*)dst + o, (const char*)src + o, n - o);
+            break;
+        }
     }
     memcpy(dst, src, std::min(per, n));
     for (unsigned i = 0; i < started; i++) th[i].join();
