@@ -175,13 +175,18 @@ struct LookupPart {
     std::vector<uint32_t> hdr_len, n_items;  // per record; n_items = items (pept2lca) or windows (prot2kmer2lca)
     std::vector<uint8_t> emit;               // per record: printed at all? (prot2kmer2lca drops reads shorter than k)
     std::vector<uint64_t> keys;              // packed keys of the `known` items, in order
+    StringBatch strs;                        // string mode (a byte-string index): the items themselves, every one of them `known`
     std::vector<uint8_t> known;              // per item / window
     size_t key_base = 0;
     bool bad_utf8 = false, panic = false;    // the range stops at the record where this happened
     std::string out;
 };
 
-void parse_lookup_part(const char* d, size_t begin, size_t end, bool kmer_mode, size_t k, LookupPart& P) {
+// string mode: what one sequence line of a record contributes to the batch (pept2lca on a byte-string index: the line itself;
+// prot2tryp2lca: its tryptic peptides).  Called from several threads at once.
+using LineExpand = std::function<void(std::string_view, StringBatch&)>;
+
+void parse_lookup_part(const char* d, size_t begin, size_t end, bool kmer_mode, size_t k, LookupPart& P, const LineExpand* expand = nullptr) {
     LineCursor lc{d + begin, d + end};
     std::string_view line;
     std::string scratch;
@@ -235,6 +240,12 @@ void parse_lookup_part(const char* d, size_t begin, size_t end, bool kmer_mode, 
             if (n_lines == 0) seq1 = line;
             else { if (n_lines == 1) scratch.assign(seq1); scratch.append(line); }
             n_lines++;
+        } else if (expand) {
+            const size_t before = P.strs.size();
+            (*expand)(line, P.strs);
+            const size_t n = P.strs.size() - before;
+            P.n_items.back() += (uint32_t)n;
+            P.known.insert(P.known.end(), n, (uint8_t)1);
         } else {
             uint64_t key;
             bool ok = line.size() == 9 && umgap_pack9(line.data(), &key);
@@ -282,7 +293,10 @@ using LookupFn = std::function<void(const uint64_t* keys, size_t n, uint32_t* ta
 // Two stages per block, overlapped: while block n is looked up on the device, formatted and written (stage B, on a helper
 // thread), block n + 1 is read and tokenized (stage A).  Stage B runs for one block at a time and in input order, so the
 // chunk bookkeeping (`held`, `g0`) and the order of output and errors are those of the plain loop.
-void stream_lookup(FILE* in, FILE* outf, const LookupFn& lookup, bool one_on_one, bool kmer_mode, size_t k, size_t chunk) {
+// String mode (`expand` and `var_ix` given): the items are byte strings looked up in a byte-string index with ONE
+// umgap_index_lookup_var per block; everything else -- ranges, chunks, errors, the two overlapped stages -- is the same.
+void stream_lookup(FILE* in, FILE* outf, const LookupFn& lookup, bool one_on_one, bool kmer_mode, size_t k, size_t chunk, const LineExpand* expand = nullptr,
+                   umgap_index* var_ix = nullptr) {
     if (chunk == 0) chunk = 1;
     BlockReader blocks(in);
     blocks.keep_previous_block();
@@ -290,6 +304,8 @@ void stream_lookup(FILE* in, FILE* outf, const LookupFn& lookup, bool one_on_one
     const char* d;
     size_t len;
     std::vector<uint64_t> keys;
+    std::vector<uint8_t> str_bytes;        // string mode: the block's batch
+    std::vector<uint64_t> str_offsets;
     std::vector<uint32_t> taxa;
     std::string held;          // formatted records [held_from, g0): the still open chunk
     size_t g0 = 0;             // global index of the block's first record
@@ -308,7 +324,14 @@ void stream_lookup(FILE* in, FILE* outf, const LookupFn& lookup, bool one_on_one
         const bool failed = parts[used - 1].bad_utf8 || parts[used - 1].panic;
         size_t total = 0, n_rec = 0;
         std::vector<size_t> rec_base(used + 1, 0);
-        for (size_t i = 0; i < used; i++) { parts[i].key_base = total; total += parts[i].keys.size(); rec_base[i] = n_rec; n_rec += parts[i].hdr_off.size(); }
+        std::vector<uint64_t> byte_base(used + 1, 0);
+        for (size_t i = 0; i < used; i++) {
+            parts[i].key_base = total;
+            total += expand ? parts[i].strs.size() : parts[i].keys.size();
+            byte_base[i + 1] = byte_base[i] + parts[i].strs.bytes.size();
+            rec_base[i] = n_rec;
+            n_rec += parts[i].hdr_off.size();
+        }
         rec_base[used] = n_rec;
         // records of this block to print now: global indices [g0, limit)
         size_t limit;
@@ -320,11 +343,25 @@ void stream_lookup(FILE* in, FILE* outf, const LookupFn& lookup, bool one_on_one
             limit = (g0 + n_rec) / chunk * chunk;   // the open chunk at the end is held back (released at EOF below)
         }
         double t0 = now();
-        keys.resize(total);
-        parallel_for(used, [&](size_t i) { if (!parts[i].keys.empty()) memcpy(keys.data() + parts[i].key_base, parts[i].keys.data(), parts[i].keys.size() * 8); });
+        if (expand) {       // the block's batch: the parts' strings back to back
+            str_bytes.resize(byte_base[used] + 64);
+            str_offsets.resize(total + 1);
+            parallel_for(used, [&](size_t i) {
+                const StringBatch& b = parts[i].strs;
+                if (!b.bytes.empty()) memcpy(str_bytes.data() + byte_base[i], b.bytes.data(), b.bytes.size());
+                for (size_t j = 0; j < b.size(); j++) str_offsets[parts[i].key_base + j] = byte_base[i] + b.offsets[j];
+            });
+            str_offsets[total] = byte_base[used];
+        } else {
+            keys.resize(total);
+            parallel_for(used, [&](size_t i) { if (!parts[i].keys.empty()) memcpy(keys.data() + parts[i].key_base, parts[i].keys.data(), parts[i].keys.size() * 8); });
+        }
         taxa.resize(total);
         t_keys += now() - t0; t0 = now();
-        if (total) lookup(keys.data(), total, taxa.data());
+        if (total) {
+            if (expand) LIB(umgap_index_lookup_var(var_ix, str_bytes.data(), str_offsets.data(), total, 0u, taxa.data()));
+            else lookup(keys.data(), total, taxa.data());
+        }
         t_lookup += now() - t0; t0 = now();
         // per part: records below `limit` go to P.out, the rest to the tail (held back)
         std::vector<std::string> tails(used);
@@ -368,7 +405,7 @@ void stream_lookup(FILE* in, FILE* outf, const LookupFn& lookup, bool one_on_one
             J.d = d;
             J.parts.clear();
             J.parts.resize(np);
-            parallel_for(np, [&](size_t i) { parse_lookup_part(d, cuts[i], cuts[i + 1], kmer_mode, k, J.parts[i]); });
+            parallel_for(np, [&](size_t i) { parse_lookup_part(d, cuts[i], cuts[i + 1], kmer_mode, k, J.parts[i], expand); });
             t_parse += now() - t0; t0 = now();
             join_helper();                         // stage B of the previous block is done (and has thrown here if it failed)
             t_wait += now() - t0;
@@ -522,8 +559,10 @@ int cmd_pept2lca(const std::vector<std::string>& args) {
     size_t chunk = (size_t)opt_usize(p, "chunksize", 240);  // decides what is printed before an error (see stream_lookup)
     std::string path = need_positional(p, "fst-file");
     umgap_index* ix = open_index(path);  // -m: the table is always resident (in HBM)
-    if (umgap_index_kind(ix) == 2) stream_strings(stdin, stdout, ix, p.has("one-on-one"), chunk, [](const std::string& s, StringBatch& b) { b.add(s); });
-    else stream_lookup(stdin, stdout, ix, p.has("one-on-one"), false, 9, chunk);
+    if (umgap_index_kind(ix) == 2) {
+        const LineExpand whole = [](std::string_view line, StringBatch& b) { b.add(line); };
+        stream_lookup(stdin, stdout, LookupFn(), p.has("one-on-one"), false, 9, chunk, &whole, ix);
+    } else stream_lookup(stdin, stdout, ix, p.has("one-on-one"), false, 9, chunk);
     umgap_index_free(ix);
     return 0;
 }
@@ -548,12 +587,12 @@ int cmd_prot2tryp2lca(const std::vector<std::string>& args) {
     }
     std::string path = need_positional(p, "fst-file");
     umgap_index* ix = open_index(path);
-    auto expand = [&](const std::string& seq_in, StringBatch& b) {
+    auto expand = [&](std::string_view seq_in, StringBatch& b) {
         std::string cut;
         if (!default_pattern) {
-            cut = std::regex_replace(std::regex_replace(seq_in, custom, "$1\n$2"), custom, "$1\n$2");   // twice: a letter can end one match and start the next
+            cut = std::regex_replace(std::regex_replace(std::string(seq_in), custom, "$1\n$2"), custom, "$1\n$2");   // twice: a letter can end one match and start the next
         }
-        const std::string& seq = default_pattern ? seq_in : cut;
+        const std::string_view seq = default_pattern ? seq_in : std::string_view(cut);
         size_t st = 0;
         auto emit = [&](size_t a, size_t e) {
             std::string_view pep(seq.data() + a, e - a);
@@ -572,7 +611,12 @@ int cmd_prot2tryp2lca(const std::vector<std::string>& args) {
         }
         emit(st, seq.size());
     };
-    stream_strings(stdin, stdout, ix, p.has("one-on-one"), chunk, expand);
+    // a byte-string index (what tryptic peptides live in): block-parallel, one look-up per block; a packed 9-mer table: the
+    // record-at-a-time loop (only peptides of nine residues could hit there)
+    if (umgap_index_kind(ix) == 2) {
+        const LineExpand per_line = expand;
+        stream_lookup(stdin, stdout, LookupFn(), p.has("one-on-one"), false, 9, chunk, &per_line, ix);
+    } else stream_strings(stdin, stdout, ix, p.has("one-on-one"), chunk, [&](const std::string& s, StringBatch& b) { expand(s, b); });
     umgap_index_free(ix);
     return 0;
 }
