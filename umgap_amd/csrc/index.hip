@@ -793,10 +793,10 @@ int build_with(umgap_index* ix, uint64_t n, double load, uint32_t shard, uint32_
 }
 
 }  // namespace
-// three pinned + three device staging buffers of 48 MB each and the upload stream of the host-pointer look-ups (also index_var.hip)
+// three pinned + three device staging buffers of 24 MB each and the upload stream of the host-pointer look-ups (also index_var.hip)
 int umgap::ensure_stage(umgap_index* ix) {
     if (ix->stage_cap) return UMGAP_OK;
-    const size_t cap = 4u << 20;  // keys per chunk: 32 MiB keys + 16 MiB results
+    const size_t cap = 2u << 20;  // keys per chunk: 16 MiB keys + 8 MiB results (three slots: 72 MiB pinned, allocated at the first host-pointer call)
     for (int i = 0; i < 3; i++) {
         UMGAP_HIP(hipHostMalloc(&ix->h_stage[i], cap * 12, hipHostMallocDefault));
         UMGAP_HIP(hipMalloc(&ix->d_stage[i], cap * 12));

@@ -782,7 +782,7 @@ __global__ __launch_bounds__(256) void k_rebase_offsets(uint64_t* __restrict__ o
 }  // namespace
 extern "C" {
 
-// Host arrays in, host array out, the link included: chunks of at most 1 M peptides / 32 MB of residues through the handle's three
+// Host arrays in, host array out, the link included: chunks of at most 512 K peptides / 17 MB of residues through the handle's three
 // staging slots -- an upload lane and a probe lane tied by events, as umgap_index_lookup9 (index.hip); arrays in pinned memory
 // are copied from / to directly, pageable ones through the pinned staging buffers with a host memcpy.  (Until late round 3: three
 // hipMallocs, one upload of everything, one launch, one download and three hipFrees per call: 0.32 G look-ups/s.)
@@ -795,8 +795,8 @@ int umgap_index_lookup_var(umgap_index* ix, const uint8_t* bytes, const uint64_t
     rc = ensure_stage(ix);
     if (rc) return rc;
     constexpr int NS = 3;
-    constexpr size_t CAPN = 1u << 20, CAPB = 32u << 20, PAD = 256;     // a slot (48 MB): [pad | bytes | pad][offsets][answers]
-    static_assert(PAD + CAPB + PAD + (CAPN + 1) * 8 + CAPN * 4 <= (size_t)(4u << 20) * 12, "a chunk must fit a staging slot");
+    constexpr size_t CAPN = 1u << 19, CAPB = 17u << 20, PAD = 256;     // a slot (24 MB): [pad | bytes | pad][offsets][answers]
+    static_assert(PAD + CAPB + PAD + (CAPN + 1) * 8 + CAPN * 4 <= (size_t)(2u << 20) * 12, "a chunk must fit a staging slot");
     auto pinned = [](const void* p) {
         hipPointerAttribute_t a{};
         if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
@@ -832,7 +832,7 @@ int umgap_index_lookup_var(umgap_index* ix, const uint8_t* bytes, const uint64_t
         // the chunk: as many whole peptides as fit (a peptide beyond VAR_MAX_LEN cannot be a key; one beyond CAPB is refused)
         size_t lo = i0 + 1, hi = std::min(n, i0 + CAPN);
         const uint64_t b0 = offsets[i0];
-        if (offsets[i0 + 1] < b0 || offsets[i0 + 1] - b0 > CAPB) { rc = fail(UMGAP_ERR_INVALID, "umgap_index_lookup_var: offsets must not decrease, and a single query is limited to 32 MB"); break; }
+        if (offsets[i0 + 1] < b0 || offsets[i0 + 1] - b0 > CAPB) { rc = fail(UMGAP_ERR_INVALID, "umgap_index_lookup_var: offsets must not decrease, and a single query is limited to 17 MB"); break; }
         while (lo < hi) {
             const size_t mid = lo + (hi - lo + 1) / 2;
             if (offsets[mid] >= b0 && offsets[mid] - b0 <= CAPB) lo = mid; else hi = mid - 1;
