@@ -206,6 +206,11 @@ void parse_lookup_part(const char* d, size_t begin, size_t end, bool kmer_mode, 
             for (size_t i = 0; i + k <= seq.size(); i++)
                 if (((unsigned char)seq[i] & 0xC0) == 0x80 || (i + k < seq.size() && ((unsigned char)seq[i + k] & 0xC0) == 0x80)) { P.panic = true; P.emit.back() = 0; P.n_items.back() = 0; return; }
         }
+        if (expand) {      // a byte-string index serves every k (src/commands/prot2kmer2lca.rs:71-73): the windows themselves are looked up
+            for (size_t i = 0; i + k <= seq.size(); i++) P.strs.add(seq.substr(i, k));
+            P.known.insert(P.known.end(), windows, (uint8_t)1);
+            return;
+        }
         uint64_t key = 0;
         uint32_t run = 0;
         for (size_t i = 0; i < seq.size(); i++) {
@@ -638,6 +643,11 @@ int cmd_prot2kmer2lca(const std::vector<std::string>& args) {
     auto stream = [&](FILE* in, FILE* outf) {
         if (gang) { stream_lookup(in, outf, [&](const uint64_t* keys, size_t n, uint32_t* taxa) { gang->lookup(keys, n, taxa); }, o, true, k, chunk); return; }
         if (!var_index) { stream_lookup(in, outf, ix, o, true, k, chunk); return; }
+        if (k >= 1) {      // block-parallel, the windows of k residues as strings (parse_lookup_part)
+            const LineExpand windows = [](std::string_view, StringBatch&) {};   // (its presence selects the string mode; k-mer mode cuts the windows itself)
+            stream_lookup(in, outf, LookupFn(), o, true, k, chunk, &windows, ix);
+            return;
+        }
         stream_strings(in, outf, ix, o, chunk,
                        [&](const std::string& seq, StringBatch& b) {
                            for (size_t i = 0; i + k <= seq.size(); i++) {
