@@ -1190,8 +1190,10 @@ def test_sharded_table_local_ranks_match_whole_table(api, torch_cuda, world, pie
             assert torch.equal(got[(r, m)][0], want[(r, m)][0]), (world, r, m, "taxon")
 
 
-@pytest.mark.parametrize("world,stride,frags,pieces", [(3, 128, 0, 2), (2, 40, 2, 3), (4, 7, 0, 1), (2, 64, 64, 2), (5, 1, 0, 2), (2, 33, 33, 1)])
-def test_sharded_runs_other_strides_and_deferred_reads(api, torch_cuda, world, stride, frags, pieces):
+@pytest.mark.parametrize("world,stride,frags,pieces,own_share", [(3, 128, 0, 2, "probed in place"), (2, 40, 2, 3, "probed in place"), (4, 7, 0, 1, "probed in place"),
+                                                                 (2, 64, 64, 2, "probed in place"), (5, 1, 0, 2, "probed in place"), (2, 33, 33, 1, "probed in place"),
+                                                                 (1, 84, 2, 2, "packed"), (3, 84, 0, 2, "packed"), (2, 40, 2, 3, "packed")])
+def test_sharded_runs_other_strides_and_deferred_reads(api, torch_cuda, world, stride, frags, pieces, own_share, monkeypatch):
     """The exchange stores no per-key slot: pack and consumer walk the same RUNS of reads (the consumer's group: it depends on the
     k-mers and fragments per read) and recompute every key's slot.  Other run geometries than the benchmark's, reads with more
     than 64 distinct taxa (the large-scratch pass finds a deferred read inside its run), keys that are not packed 9-mers, and
@@ -1200,6 +1202,9 @@ def test_sharded_runs_other_strides_and_deferred_reads(api, torch_cuda, world, s
     from umgap_amd.api import Index, Taxonomy
     from umgap_amd.dist import Comm, Sharded
     from umgap_amd.synth import synthetic_taxonomy
+    # "packed" (UMGAP_SHARD_NO_LOCAL=1): no key is the rank's own -- and a key that is no packed 9-mer has NO owner either, which
+    # must not pass for "own" (it was probed with its high bits masked off, out of the shard's bounds at world > 1)
+    monkeypatch.setenv("UMGAP_SHARD_NO_LOCAL", "1" if own_share == "packed" else "0")
     ids, par, valid, rank = synthetic_taxonomy(5000, 8000, max_depth=12, seed=9)
     tx = Taxonomy(ids, par, valid, rank)
     rng = np.random.default_rng(1000 * world + stride)
@@ -1216,6 +1221,8 @@ def test_sharded_runs_other_strides_and_deferred_reads(api, torch_cuda, world, s
         miss = rng.random(len(q)) < 0.2
         q[miss] = rng.integers(0, 1 << 45, int(miss.sum()), dtype=np.uint64)
         q[rng.random(len(q)) < 0.01] = np.uint64((1 << 45) + 12345)                      # not a packed 9-mer: never sent, a miss
+        bad = rng.random(len(q)) < 0.01                                                  # ... nor is a PRESENT key with a bit above 45 set:
+        q[bad] = keys[rng.integers(0, n_keys, int(bad.sum()))] | np.uint64(1 << 45)      # masked to 45 bits it would hit
         qs.append(torch.from_numpy(q.view(np.int64)).cuda())
     max_keys = (max(n_reads) + pieces) // pieces * pieces * stride
     modes = [("tree", "lca*", 0.0), ("tree", "hybrid", 0.0), ("rmq", "mrtl", 1.0), ("rmq", "hybrid", 0.0)]

@@ -278,6 +278,9 @@ def sharded_leg(rng, fails):
     n_reads = [int(rng.integers(1, 3000)) for _ in range(world)]
     max_keys = (max(n_reads) + pieces) // pieces * pieces * stride
     keys = [w.reads(int(rng.integers(0, 1 << 20)), n_reads[r], kmers_per_pair=stride) for r in range(world)]
+    for k in keys:   # keys that are no packed 9-mers (a bit above 45 set on an otherwise present key): no owner, never sent, a miss
+        bad = torch.rand(k.numel(), device="cuda") < 0.01
+        k[bad] |= int(rng.integers(1, 1 << 18)) << 45
     method, strategy = MODES[int(rng.integers(0, 5))]
     lb, factor = float(rng.choice([0.0, 1.0, 2.0])), float(rng.choice([0.25, 0.6]))
     frags = int(rng.choice([f for f in (0, 1, 2, 3) if f == 0 or stride % f == 0]))

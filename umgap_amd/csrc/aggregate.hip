@@ -296,11 +296,7 @@ int umgap_aggregate(umgap_taxonomy* tx, int method, int strategy, float factor, 
         if (e != hipSuccess) return fail(UMGAP_ERR_NOMEM, std::string("hipMalloc(aggregate staging): ") + hipGetErrorString(e));
         tx->d_stage_bytes = need;
     }
-    if (!tx->stream2) {
-        hipError_t e = hipStreamCreateWithFlags(&tx->stream2, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&tx->stream3, hipStreamNonBlocking);
-        if (e != hipSuccess) return fail(UMGAP_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
-    }
+    if (int lanes = ensure_lanes(tx)) return lanes;
     const hipStream_t up = tx->stream2, run = tx->stream3;
     // pageable arrays travel through pinned staging with a threaded memcpy, both ways (records.hip tells why)
     auto is_pinned = [](const void* p0, const void* p1) {
@@ -354,7 +350,7 @@ int umgap_aggregate(umgap_taxonomy* tx, int method, int strategy, float factor, 
         uint32_t* d_ot = (uint32_t*)p; p += b_out;
         uint32_t* d_os = (uint32_t*)p;
         if (c >= (size_t)NS) {                 // the slot's previous tenant is through (its results have left)
-            UMGAP_HIP(hipEventSynchronize(ev.done[slot]));
+            UMGAP_HIP_BREAK(hipEventSynchronize(ev.done[slot]));
             drain_out(slot);
         }
         const uint32_t* src_t = taxa + t0;
@@ -366,18 +362,18 @@ int umgap_aggregate(umgap_taxonomy* tx, int method, int strategy, float factor, 
             par_memcpy(H[slot].off, src_o, (nr + 1) * 8);
             src_t = H[slot].taxa; src_s = H[slot].sc; src_o = H[slot].off;
         }
-        if (nt) UMGAP_HIP(hipMemcpyAsync(d_taxa, src_t, nt * 4, hipMemcpyHostToDevice, up));
-        if (scores && nt) UMGAP_HIP(hipMemcpyAsync(d_sc, src_s, nt * 4, hipMemcpyHostToDevice, up));
-        UMGAP_HIP(hipMemcpyAsync(d_off, src_o, (nr + 1) * 8, hipMemcpyHostToDevice, up));
-        UMGAP_HIP(hipEventRecord(ev.uploaded[slot], up));
-        UMGAP_HIP(hipStreamWaitEvent(run, ev.uploaded[slot], 0));
+        if (nt) UMGAP_HIP_BREAK(hipMemcpyAsync(d_taxa, src_t, nt * 4, hipMemcpyHostToDevice, up));
+        if (scores && nt) UMGAP_HIP_BREAK(hipMemcpyAsync(d_sc, src_s, nt * 4, hipMemcpyHostToDevice, up));
+        UMGAP_HIP_BREAK(hipMemcpyAsync(d_off, src_o, (nr + 1) * 8, hipMemcpyHostToDevice, up));
+        UMGAP_HIP_BREAK(hipEventRecord(ev.uploaded[slot], up));
+        UMGAP_HIP_BREAK(hipStreamWaitEvent(run, ev.uploaded[slot], 0));
         hipLaunchKernelGGL(k_rebase_read_offsets, dim3((unsigned)std::min<size_t>((nr + 256) / 256, 1024)), dim3(256), 0, run, d_off, nr + 1, t0);
         rc = launch(tx, method, strategy, factor, lower_bound, ranked_only, d_taxa, d_sc, d_off, 0, nr, d_ot, d_os, run);
         if (rc) break;
-        UMGAP_HIP(hipMemcpyAsync(out_pinned ? out_taxon + r0 : H[slot].ot, d_ot, nr * 4, hipMemcpyDeviceToHost, run));
-        UMGAP_HIP(hipMemcpyAsync(out_pinned ? out_status + r0 : H[slot].os, d_os, nr * 4, hipMemcpyDeviceToHost, run));
+        UMGAP_HIP_BREAK(hipMemcpyAsync(out_pinned ? out_taxon + r0 : H[slot].ot, d_ot, nr * 4, hipMemcpyDeviceToHost, run));
+        UMGAP_HIP_BREAK(hipMemcpyAsync(out_pinned ? out_status + r0 : H[slot].os, d_os, nr * 4, hipMemcpyDeviceToHost, run));
         if (!out_pinned) { out_at[slot] = r0; out_n[slot] = nr; }
-        UMGAP_HIP(hipEventRecord(ev.done[slot], run));
+        UMGAP_HIP_BREAK(hipEventRecord(ev.done[slot], run));
     }
     const hipError_t e0 = hipStreamSynchronize(up), e1 = hipStreamSynchronize(run);
     if (!rc && e0 == hipSuccess && e1 == hipSuccess) for (int k = 0; k < NS; k++) drain_out(k);

@@ -21,6 +21,17 @@ int fail(int code, const std::string& msg);
         if (e__ != hipSuccess)                                                                   \
             return ::umgap::fail(UMGAP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__)); \
     } while (0)
+// inside a chunk loop whose tail synchronises the lanes before it returns: record the error in `rc` and leave the LOOP, not the
+// function (copies into the caller's arrays and the pinned staging may still be in flight)
+#define UMGAP_HIP_BREAK(expr)                                                                                   \
+    {                                                                                                          \
+        hipError_t e__ = (expr);                                                                               \
+        if (e__ != hipSuccess) {                                                                               \
+            rc = ::umgap::fail(UMGAP_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__));           \
+            break;                                                                                             \
+        }                                                                                                      \
+    }
+
 
 // Selects `device` after checking that a GPU exists at all.
 int use_device(int device);

@@ -9,6 +9,8 @@
 #include <cmath>
 #include <thread>
 #include <vector>
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
 
 #include "host_copy.hpp"
 #include "probe_common.hpp"
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(256) void k_walk_candidates(uint64_t* __restrict__ 
         const size_t i = g / max_len;
         const uint32_t w = (uint32_t)(g % max_len);
         const uint64_t o = off[i], len = off[i + 1] - o;
-        if (len < 9 || w + 9 > len) continue;
+        if (off[i + 1] < o || len >= 0xFFFFFFFFull || len < 9 || w + 9 > len) continue;   // k_window_counts gave such a fragment no windows
         uint64_t key;
         if (!window_key9(bytes, o + w, key)) continue;
         if (lane_get(V, key, UMGAP_NONE) == UMGAP_NONE) continue;                      // not a key of the index: answered by a miss of the table
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(256) void k_walk_flags(TableView C, TableView V, co
         const size_t i = g / max_len;
         const uint32_t w = (uint32_t)(g % max_len);
         const uint64_t o = off[i], len = off[i + 1] - o;
-        if (len < 9 || w + 9 > len) continue;
+        if (off[i + 1] < o || len >= 0xFFFFFFFFull || len < 9 || w + 9 > len) continue;
         const uint32_t local = (uint32_t)(wbase[i] + w);
         uint64_t key;
         uint8_t fl = 0;
@@ -1207,6 +1209,7 @@ int umgap_index_open(const char* path, uint32_t device_mask, umgap_index** out) 
 
 int umgap_index_set_shard(umgap_index* ix, uint32_t shard, uint32_t n_shards) {
     if (!ix || n_shards == 0 || shard >= n_shards) return fail(UMGAP_ERR_INVALID, "umgap_index_set_shard: bad argument");
+    if (ix->kind != 9) return fail(UMGAP_ERR_INVALID, "umgap_index_set_shard: only the plain 9-mer table is sharded (a walk-order index answers through its walk array, which is not)");
     if (ix->view.first_bucket != 0 || ix->view.n_resident != ix->view.nb + MAX_DISP) return fail(UMGAP_ERR_INVALID, "umgap_index_set_shard: handle does not hold the whole table");
     uint32_t nb = ix->view.nb;
     // the whole table stays resident; only the owned home range shrinks (slots pointer is kept at
@@ -1362,6 +1365,9 @@ int umgap_walk_builder_add_dev(umgap_walk_builder* b, const uint8_t* d_bytes, co
     });
     if (rc) return done(rc);
     if (hipMalloc((void**)&d_flag, n_local) != hipSuccess) return done(fail(UMGAP_ERR_NOMEM, "umgap_walk_builder_add_dev: hipMalloc failed"));
+    // a window beyond max_fragment_len is never visited by the flag pass: it must read as "no entry" (its key then follows as a
+    // walk of one), not as whatever the allocation held
+    UMGAP_HIP(hipMemsetAsync(d_flag, 0, n_local, x->stream));
     hipLaunchKernelGGL(k_walk_flags, dim3(grid_for(iter, 256, 256 * 16)), dim3(256), 0, x->stream, c->view, V, d_bytes, d_offsets, (const uint64_t*)d_wbase, n_fragments,
                        max_fragment_len, d_flag);
     uint64_t n_new = 0, n_keep = 0;
@@ -1446,6 +1452,23 @@ int umgap_walk_builder_finish(umgap_walk_builder* b, umgap_index** out) {
             return done(fail(UMGAP_ERR_NOMEM, "umgap_walk_builder_finish: hipMalloc failed"));
         UMGAP_HIP(hipMemsetAsync(d_n, 0, 8, x->stream));
         hipLaunchKernelGGL(k_walk_leftovers, dim3(grid_for(scan, 256, 256 * 16)), dim3(256), 0, x->stream, V, x->view, inv1, inv2, d_keys, d_taxa, d_n);
+        // the slots came from an atomic counter: sorted by key, so that the same input gives the same file, byte for byte
+        {
+            uint64_t* d_keys2 = nullptr;
+            uint32_t* d_taxa2 = nullptr;
+            void* d_tmp = nullptr;
+            size_t tmp_bytes = 0;
+            auto drop = [&]() { for (void* p : {(void*)d_keys2, (void*)d_taxa2, d_tmp}) if (p) (void)hipFree(p); };
+            if (hipMalloc((void**)&d_keys2, n_left * 8) != hipSuccess || hipMalloc((void**)&d_taxa2, n_left * 4) != hipSuccess) { drop(); return done(fail(UMGAP_ERR_NOMEM, "umgap_walk_builder_finish: hipMalloc failed")); }
+            hipError_t se = rocprim::radix_sort_pairs(nullptr, tmp_bytes, d_keys, d_keys2, d_taxa, d_taxa2, (size_t)n_left, 0u, 45u, x->stream);
+            if (se == hipSuccess) se = hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 8);
+            if (se == hipSuccess) se = rocprim::radix_sort_pairs(d_tmp, tmp_bytes, d_keys, d_keys2, d_taxa, d_taxa2, (size_t)n_left, 0u, 45u, x->stream);
+            if (se == hipSuccess) se = hipStreamSynchronize(x->stream);
+            if (se != hipSuccess) { drop(); return done(fail(UMGAP_ERR_DEVICE, std::string("umgap_walk_builder_finish: sort: ") + hipGetErrorString(se))); }
+            std::swap(d_keys, d_keys2);
+            std::swap(d_taxa, d_taxa2);
+            drop();
+        }
         hipLaunchKernelGGL(k_walk_append, dim3(grid_for(n_left)), dim3(256), 0, x->stream, (const uint64_t*)d_keys, (const uint32_t*)d_taxa, (size_t)n_left, x->d_walk, b->n_walk, d_pos);
         hipLaunchKernelGGL(k_insert, dim3(grid_for(n_left)), dim3(256), 0, x->stream, x->d_slots, x->view.m, x->view.nb, 0u, x->view.nb, (const uint64_t*)d_keys,
                            (const uint32_t*)d_pos, (size_t)n_left, b->d_flags, b->d_stash);
@@ -1610,13 +1633,13 @@ int umgap_index_lookup9(umgap_index* ix, const uint64_t* keys, size_t n, uint32_
         uint32_t* dout = (uint32_t*)((char*)ix->d_stage[slot] + cap * 8);
         const uint64_t* src = keys + off;
         if (!in_pinned) { par_memcpy(ix->h_stage[slot], keys + off, len * 8); src = (const uint64_t*)ix->h_stage[slot]; }
-        UMGAP_HIP(hipMemcpyAsync(dk, src, len * 8, hipMemcpyHostToDevice, up));
-        UMGAP_HIP(hipEventRecord(ev.uploaded[slot], up));
-        UMGAP_HIP(hipStreamWaitEvent(run, ev.uploaded[slot], 0));
+        UMGAP_HIP_BREAK(hipMemcpyAsync(dk, src, len * 8, hipMemcpyHostToDevice, up));
+        UMGAP_HIP_BREAK(hipEventRecord(ev.uploaded[slot], up));
+        UMGAP_HIP_BREAK(hipStreamWaitEvent(run, ev.uploaded[slot], 0));
         hipLaunchKernelGGL(k_lookup9, dim3(grid_for(len)), dim3(256), 0, run, dk, len, walk ? UMGAP_NONE : miss, dout, ix->view);
         if (walk && (rc = walk_map_positions(ix, dout, len, miss, run))) break;
-        UMGAP_HIP(hipMemcpyAsync(out_pinned ? (void*)(out + off) : (void*)((char*)ix->h_stage[slot] + cap * 8), dout, len * 4, hipMemcpyDeviceToHost, run));
-        UMGAP_HIP(hipEventRecord(ev.done[slot], run));
+        UMGAP_HIP_BREAK(hipMemcpyAsync(out_pinned ? (void*)(out + off) : (void*)((char*)ix->h_stage[slot] + cap * 8), dout, len * 4, hipMemcpyDeviceToHost, run));
+        UMGAP_HIP_BREAK(hipEventRecord(ev.done[slot], run));
         pending_off[slot] = off;
         pending_len[slot] = len;
     }

@@ -850,15 +850,15 @@ int umgap_index_lookup_var(umgap_index* ix, const uint8_t* bytes, const uint64_t
             src_b = h_bytes(slot);
             src_o = h_off(slot);
         }
-        if (nb) UMGAP_HIP(hipMemcpyAsync(d_bytes(slot), src_b, nb, hipMemcpyHostToDevice, up));
-        UMGAP_HIP(hipMemcpyAsync(d_off(slot), src_o, (len + 1) * 8, hipMemcpyHostToDevice, up));
-        UMGAP_HIP(hipEventRecord(ev.uploaded[slot], up));
-        UMGAP_HIP(hipStreamWaitEvent(run, ev.uploaded[slot], 0));
+        if (nb) UMGAP_HIP_BREAK(hipMemcpyAsync(d_bytes(slot), src_b, nb, hipMemcpyHostToDevice, up));
+        UMGAP_HIP_BREAK(hipMemcpyAsync(d_off(slot), src_o, (len + 1) * 8, hipMemcpyHostToDevice, up));
+        UMGAP_HIP_BREAK(hipEventRecord(ev.uploaded[slot], up));
+        UMGAP_HIP_BREAK(hipStreamWaitEvent(run, ev.uploaded[slot], 0));
         hipLaunchKernelGGL(k_rebase_offsets, dim3((unsigned)std::min<size_t>((len + 256) / 256, 1024)), dim3(256), 0, run, d_off(slot), len + 1, b0);
         rc = var_lookup_dev(ix->var, d_bytes(slot), d_off(slot), len, miss_value, d_out(slot), run, 1u, VAR_MAX_LEN);
         if (rc) break;
-        UMGAP_HIP(hipMemcpyAsync(out_pinned ? (void*)(out + i0) : (void*)h_out(slot), d_out(slot), len * 4, hipMemcpyDeviceToHost, run));
-        UMGAP_HIP(hipEventRecord(ev.done[slot], run));
+        UMGAP_HIP_BREAK(hipMemcpyAsync(out_pinned ? (void*)(out + i0) : (void*)h_out(slot), d_out(slot), len * 4, hipMemcpyDeviceToHost, run));
+        UMGAP_HIP_BREAK(hipEventRecord(ev.done[slot], run));
         pending_at[slot] = i0;
         pending_len[slot] = len;
         i0 = i1;

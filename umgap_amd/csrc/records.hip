@@ -322,11 +322,7 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
     };
     Slot S[NS];
     hipError_t e = hipSuccess;
-    if (!tx->stream2) {
-        e = hipStreamCreateWithFlags(&tx->stream2, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&tx->stream3, hipStreamNonBlocking);
-    }
-    if (e != hipSuccess) return fail(UMGAP_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e));
+    if (int lanes = ensure_lanes(tx)) return lanes;
     // an UPLOAD lane and a COMPUTE lane, tied by events per slot: with one lane per chunk (rounds 2-3) the two lanes fell into step --
     // both uploading, then both computing -- and the link idled while the kernels ran (rocprofv3 --memory-copy-trace: 2.2 ms per
     // two chunks instead of 1.4)
@@ -380,27 +376,27 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
             par_memcpy(H[slot].rf, src_r, (nr + 1) * 8);
             src_b = H[slot].bytes; src_o = H[slot].off; src_r = H[slot].rf;
         }
-        if (nb) UMGAP_HIP(hipMemcpyAsync(L.bytes, src_b, nb, hipMemcpyHostToDevice, up));
-        if (nf) UMGAP_HIP(hipMemcpyAsync(L.off, src_o, (nf + 1) * 8, hipMemcpyHostToDevice, up));
-        UMGAP_HIP(hipMemcpyAsync(L.rf, src_r, (nr + 1) * 8, hipMemcpyHostToDevice, up));
-        UMGAP_HIP(hipEventRecord(ev.uploaded[slot], up));
+        if (nb) UMGAP_HIP_BREAK(hipMemcpyAsync(L.bytes, src_b, nb, hipMemcpyHostToDevice, up));
+        if (nf) UMGAP_HIP_BREAK(hipMemcpyAsync(L.off, src_o, (nf + 1) * 8, hipMemcpyHostToDevice, up));
+        UMGAP_HIP_BREAK(hipMemcpyAsync(L.rf, src_r, (nr + 1) * 8, hipMemcpyHostToDevice, up));
+        UMGAP_HIP_BREAK(hipEventRecord(ev.uploaded[slot], up));
         // ---- compute lane ----
         const hipStream_t s = run_on;
-        UMGAP_HIP(hipStreamWaitEvent(s, ev.uploaded[slot], 0));
-        UMGAP_HIP(hipMemsetAsync(L.bad, 0, 8, s));
-        if (!fused) UMGAP_HIP(hipMemsetAsync(L.tails, 0, (nb / 32 + 8) * 4, s));
-        UMGAP_HIP(hipMemsetAsync(L.bytes + nb, 0, 144, s));   // the packer may look 8 bytes past the chunk
+        UMGAP_HIP_BREAK(hipStreamWaitEvent(s, ev.uploaded[slot], 0));
+        UMGAP_HIP_BREAK(hipMemsetAsync(L.bad, 0, 8, s));
+        if (!fused) UMGAP_HIP_BREAK(hipMemsetAsync(L.tails, 0, (nb / 32 + 8) * 4, s));
+        UMGAP_HIP_BREAK(hipMemsetAsync(L.bytes + nb, 0, 144, s));   // the packer may look 8 bytes past the chunk
         const unsigned gf = (unsigned)std::min<size_t>((nf + 255) / 256 + 1, 2048), gr = (unsigned)std::min<size_t>((nr + 256) / 256 + 1, 2048);
         if (fused) {
-            if (!nf) UMGAP_HIP(hipMemsetAsync(L.off, 0, 8, s));
+            if (!nf) UMGAP_HIP_BREAK(hipMemsetAsync(L.off, 0, 8, s));
             hipLaunchKernelGGL(k_records_fit, dim3(std::max(gf, gr)), dim3(256), 0, s, (const uint64_t*)L.off, (size_t)nf, (const uint64_t*)L.rf, nr, f0, F_all, base + b0,
                                (uint32_t)nb, L.off_rel, L.bad);
-            UMGAP_HIP(hipGetLastError());
+            UMGAP_HIP_BREAK(hipGetLastError());
             rc = classify_prot9_gated(ix, tx, method, strategy, factor, lower_bound, ranked_only, L.bytes, L.off_rel, nr, F_all, seedextend, min_seed_size, max_gap_size, L.ot, L.os,
                                       L.bad, s);
             if (rc) break;
             hipLaunchKernelGGL(k_records_any_unsupported, dim3(gr), dim3(256), 0, s, (const uint32_t*)L.os, nr, L.bad);
-            UMGAP_HIP(hipGetLastError());
+            UMGAP_HIP_BREAK(hipGetLastError());
         } else {
         if (nf) hipLaunchKernelGGL(k_frag_prepare, dim3(gf), dim3(256), 0, s, L.off, (size_t)nf, base + b0, (uint32_t)nb, L.fstart, L.flen, L.tails, L.bad);
         if (nb) {
@@ -411,20 +407,20 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
         if (seedextend && nf)
             hipLaunchKernelGGL(k_seedextend_frags, dim3(gf), dim3(256), 0, s, L.fstart, L.flen, (size_t)nf, min_seed_size, max_gap_size, L.hits, L.kept);
         hipLaunchKernelGGL(k_read_offsets, dim3(gr), dim3(256), 0, s, L.rf, nr, f0, (size_t)nf, L.fstart, (uint32_t)nb, L.roff, L.rfl, L.bad);
-        UMGAP_HIP(hipGetLastError());
+        UMGAP_HIP_BREAK(hipGetLastError());
         rc = umgap_aggregate_dev(tx, method, strategy, factor, lower_bound, ranked_only, L.hits, nullptr, L.roff, nr, L.ot, L.os, s);
         if (!rc && want_kept && nf) rc = mark_seedextend_panics(L.kept, L.rfl, nr, L.ot, L.os, s);
         if (rc) break;
         }
-        UMGAP_HIP(hipMemcpyAsync(out_pinned ? out_taxon + r0 : H[slot].ot, L.ot, nr * 4, hipMemcpyDeviceToHost, s));
-        UMGAP_HIP(hipMemcpyAsync(out_pinned ? out_status + r0 : H[slot].os, L.os, nr * 4, hipMemcpyDeviceToHost, s));
+        UMGAP_HIP_BREAK(hipMemcpyAsync(out_pinned ? out_taxon + r0 : H[slot].ot, L.ot, nr * 4, hipMemcpyDeviceToHost, s));
+        UMGAP_HIP_BREAK(hipMemcpyAsync(out_pinned ? out_status + r0 : H[slot].os, L.os, nr * 4, hipMemcpyDeviceToHost, s));
         if (!out_pinned) { out_at[slot] = r0; out_n[slot] = nr; }
-        UMGAP_HIP(hipMemcpyAsync(tx->h_flags + 2 * slot, L.bad, 8, hipMemcpyDeviceToHost, s));
-        UMGAP_HIP(hipEventRecord(ev.done[slot], s));
+        UMGAP_HIP_BREAK(hipMemcpyAsync(tx->h_flags + 2 * slot, L.bad, 8, hipMemcpyDeviceToHost, s));
+        UMGAP_HIP_BREAK(hipEventRecord(ev.done[slot], s));
         // the host stays at most NS chunks ahead, and looks at the flags of the chunk whose slot the next one takes
         if (c + 1 >= (size_t)NS) {
             const int w = (int)((c + 1 - NS) % NS);
-            UMGAP_HIP(hipEventSynchronize(ev.done[w]));
+            UMGAP_HIP_BREAK(hipEventSynchronize(ev.done[w]));
             drain_out(w);
             if (h_bad[2 * w]) { rc = fail(UMGAP_ERR_INVALID, "umgap_classify_records: frag_offsets / read_frags are not non-decreasing offsets into the block"); break; }
             if (h_bad[2 * w + 1]) { unfit = true; break; }    // a read the fused kernel does not take: the caller runs the general kernels

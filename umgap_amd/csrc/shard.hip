@@ -464,7 +464,7 @@ int stage_pack(umgap_sharded* sh, uint64_t t, const uint64_t* d_keys, size_t nk,
     unsigned g = (unsigned)std::min<size_t>((n_runs + 3) / 4, 256 * 8);   // persistent: a grid of short workgroups holds up the other streams' kernels (k_shard_probe)
     if (g < 1) g = 1;
     hipLaunchKernelGGL(k_shard_pack, dim3(g), dim3(256), 0, s, d_keys, nk, run_len, T.m, T.nb, W, (double)W / (double)T.nb, sh->cap, S.send_keys, sh->bases[t % NPERM],
-                       S.cursor, sh->d_overflow, sh->local_bypass ? (uint32_t)sh->comm->rank : wire::NO_OWNER);
+                       S.cursor, sh->d_overflow, sh->local_bypass ? (uint32_t)sh->comm->rank : wire::NO_SELF);
     hipLaunchKernelGGL(k_shard_pad, dim3(64, W), dim3(256), 0, s, S.send_keys, S.cursor, sh->cap);
     UMGAP_HIP(hipGetLastError());
     UMGAP_HIP(hipEventRecord(S.filled, s));
@@ -519,7 +519,7 @@ HitSource hit_source(umgap_sharded* sh, uint64_t t, const uint64_t* d_piece_keys
     H.keys = d_piece_keys;
     H.value_bytes = sh->value_bytes;
     H.world = (uint32_t)sh->comm->world;
-    H.self = sh->local_bypass ? (uint32_t)sh->comm->rank : wire::NO_OWNER;
+    H.self = sh->local_bypass ? (uint32_t)sh->comm->rank : wire::NO_SELF;
     H.run = run_len;
     H.cap = sh->cap;
     return H;

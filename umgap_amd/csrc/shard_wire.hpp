@@ -31,7 +31,7 @@ struct HitSource {
     const uint32_t* bases = nullptr;  // [run][world]: first slot (within region o) of the run's keys owned by o
     const uint64_t* keys = nullptr;   // the piece's packed 9-mers
     uint32_t value_bytes = 4;
-    uint32_t world = 1, self = 0;     // self = this rank, or wire::NO_OWNER when the rank's own keys travel like the others
+    uint32_t world = 1, self = 0;     // self = this rank, or wire::NO_SELF when the rank's own keys travel like the others
                                       // (UMGAP_SHARD_NO_LOCAL=1: region `self` is then packed, probed and gathered too)
     uint32_t run = 1024;              // keys per run
     uint64_t cap = 0;                 // slots per region
@@ -47,6 +47,7 @@ inline uint32_t classify9_group_reads(uint32_t kmers_per_read, uint32_t fragment
 namespace wire {
 
 constexpr uint32_t NO_OWNER = 0xFFFFFFFFu;   // not a packed 9-mer: never sent, answered with a miss
+constexpr uint32_t NO_SELF = 0xFFFFFFFEu;    // "this rank keeps no key to itself" (UMGAP_SHARD_NO_LOCAL=1): equals no owner, NO_OWNER included
 constexpr uint32_t HI_NOKEY = 0xFFFFu;
 
 __host__ __device__ inline uint32_t miss_raw(uint32_t value_bytes) { return value_bytes == 3 ? 0xFFFFFFu : 0xFFFFFFFFu; }

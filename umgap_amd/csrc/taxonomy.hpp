@@ -79,6 +79,16 @@ uint32_t* defer_list_for(umgap_taxonomy* tx, hipStream_t stream, size_t bytes);
 // memory: BIG_SLOTS reads at a time, up to BIG_CAP distinct taxa each; beyond that UMGAP_READ_UNSUPPORTED.
 constexpr uint32_t BIG_SLOTS = 16, BIG_CAP = 1u << 15, BIG_HCAP = 1u << 16;
 uint32_t* big_scratch_for(umgap_taxonomy* tx);
+// the upload lane and the compute lane of the host-pointer calls, each made under its own check: a handle whose second lane failed
+// to come up must not run its kernels on the null stream next time
+inline int ensure_lanes(umgap_taxonomy* tx) {
+    for (hipStream_t* s : {&tx->stream2, &tx->stream3}) {
+        if (*s) continue;
+        const hipError_t e = hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+        if (e != hipSuccess) { *s = nullptr; return fail(UMGAP_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    }
+    return UMGAP_OK;
+}
 
 struct TaxView {
     const uint2* by_id;
