@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--pieces", type=int, default=8, help="pipelined pieces of a sharded step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--no-sharded", action="store_true", help="one GPU: skip the sharded leg (a child process with a process group of one over RCCL)")
     ap.add_argument("--no-extras", action="store_true", help="headline only: no seedextend / other pipelines / workload sweep / end-to-end legs")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--seedextend", action="store_true", help="insert seedextend -g1 -s3 per fragment between lookup and aggregate")
@@ -258,7 +259,10 @@ def sharded_child(args):
 
 def sharded_section(args, w, keys, rank, world, device, B, d_taxon, d_status, want_first):
     """One sharded step = umgap_sharded_classify9_dev over the rank's B pairs (pack -> RCCL exchange -> probe on the owner ->
-    RCCL exchange back -> gather + LCA*), `pieces` pipelined pieces; checked bit for bit against the replica's answers."""
+    RCCL exchange back -> gather + LCA*), `pieces` pipelined pieces; checked bit for bit against the replica's answers.  Timed as
+    shipped (a rank's own 1/N of the keys are probed in place by the consuming kernel) and, at world 1, once more with
+    UMGAP_SHARD_NO_LOCAL=1, where EVERY key goes through pack -> exchange -> probe -> gather: what the (N-1)/N of the keys that
+    belong to other ranks cost per rank at N > 1."""
     import torch
     import torch.distributed as dist
     from umgap_amd import synth
@@ -268,37 +272,59 @@ def sharded_section(args, w, keys, rank, world, device, B, d_taxon, d_status, wa
         w.index.close()
         w.index = None
     torch.cuda.empty_cache()
+    seen = torch.ones(1, dtype=torch.int64, device=device)
+    dist.all_reduce(seen)       # RCCL: every rank of the sharded group is really there
     shard = Index.synthetic(args.n_keys, w.d_taxon_of_row, synth.MUL_A, synth.ADD_B, args.load_factor, rank, world)
     comm = Comm.from_torch_distributed(device.index or 0)
     comm.selftest(1 << 20)      # RCCL send/recv group to every rank (itself included), contents checked
     per_piece = -(-B // args.pieces)
-    sh = Sharded(shard, w.taxonomy, comm, per_piece * args.pieces * KMERS, pieces=args.pieces)
     steps = max(2, min(5, args.steps))
 
-    def one(i):
-        sh.classify9(keys[i % len(keys)], B, KMERS, d_taxon, d_status, method="tree", strategy="lca*", lower_bound=2.0)
+    def leg(no_local):
+        os.environ["UMGAP_SHARD_NO_LOCAL"] = "1" if no_local else "0"     # read when the group is created
+        sh = Sharded(shard, w.taxonomy, comm, per_piece * args.pieces * KMERS, pieces=args.pieces)
 
-    one(0)
-    sh.check()
-    same = bool(torch.equal(d_taxon, want_first[0]) and torch.equal(d_status, want_first[1]))
-    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        one(i + 1)
-    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
-    dist.all_reduce(el, op=dist.ReduceOp.MAX)
-    sh.check()
-    ok = torch.tensor([int(same)], device=device)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-    out_b, back_b = sh.wire_bytes_per_step_and_peer()
-    res = {"value": round(world * steps * B / float(el.item()), 1), "unit": "pairs/s", "steps": steps,
-           "ms_per_step": round(1e3 * float(el.item()) / steps, 3), "shard_table_GB": round(shard.table_bytes / 1e9, 2),
-           "probe_kernel_ms_first_piece": round(sh.probe_ms(), 3), "pieces": sh.pieces, "value_bytes": sh.value_bytes,
-           "bit_identical_to_replica": bool(ok.item()),
+        def one(i):
+            sh.classify9(keys[i % len(keys)], B, KMERS, d_taxon, d_status, method="tree", strategy="lca*", lower_bound=2.0)
+
+        d_taxon.fill_(-1)
+        d_status.fill_(-1)
+        one(0)
+        sh.check()
+        same = bool(torch.equal(d_taxon, want_first[0]) and torch.equal(d_status, want_first[1]))
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            one(i + 1)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        sh.check()
+        ok = torch.tensor([int(same)], device=device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        r = {"ms_per_step": round(1e3 * float(el.item()) / steps, 3), "value": round(world * steps * B / float(el.item()), 1), "bit_identical_to_replica": bool(ok.item()),
+             "probe_kernel_ms_first_piece": round(sh.probe_ms(), 3), "pieces": sh.pieces, "value_bytes": sh.value_bytes, "wire": sh.wire_bytes_per_step_and_peer()}
+        sh.close()
+        return r
+
+    shipped = leg(False)
+    out_b, back_b = shipped["wire"]
+    res = {"value": shipped["value"], "unit": "pairs/s", "steps": steps, "ms_per_step": shipped["ms_per_step"], "shard_table_GB": round(shard.table_bytes / 1e9, 2),
+           "probe_kernel_ms_first_piece": shipped["probe_kernel_ms_first_piece"], "pieces": shipped["pieces"], "value_bytes": shipped["value_bytes"],
+           "bit_identical_to_replica": shipped["bit_identical_to_replica"], "ranks_seen": int(seen.item()), "transport": "RCCL (process group of %d)" % world,
            "exchange": "RCCL send/recv groups inside libumgap_hip.so: 6 B per k-mer out, %d B per hit back; per step and peer %.1f MB out + %.1f MB back "
-                       "(%d k-mers per rank and step, %d pieces over 3 streams)" % (sh.value_bytes, out_b / 1e6, back_b / 1e6, B * KMERS, sh.pieces)}
-    sh.close()
+                       "(%d k-mers per rank and step, %d pieces over 3 streams)" % (shipped["value_bytes"], out_b / 1e6, back_b / 1e6, B * KMERS, shipped["pieces"])}
+    if world == 1:
+        every = leg(True)
+        res["all_keys_exchanged_ms"] = every["ms_per_step"]
+        res["all_keys_exchanged"] = {"ms_per_step": every["ms_per_step"], "value": every["value"], "bit_identical_to_replica": every["bit_identical_to_replica"],
+                                     "probe_kernel_ms_first_piece": every["probe_kernel_ms_first_piece"],
+                                     "what": "UMGAP_SHARD_NO_LOCAL=1: every key packed, sent (to this rank itself, over RCCL), probed by the owner-side kernel and gathered -- "
+                                             "the per-rank compute of the (N-1)/N keys that belong to other ranks at N > 1"}
+        res["bit_identical_to_replica"] = bool(res["bit_identical_to_replica"] and every["bit_identical_to_replica"])
+        n8 = 8
+        res["per_rank_compute_model_ms_at_8_ranks"] = round(shipped["ms_per_step"] / n8 + every["ms_per_step"] * (1 - 1 / n8), 2)
+    shard.close()
     comm.close()
     return res
 
@@ -547,7 +573,16 @@ def main():
         out["roofline"]["measured_gather_GBps"] = ceil
         out["roofline"]["frac_of_measured_64B_gather"] = round(lookups * 64 / (kernel_ms * 1e-3) / 1e9 / ceil["64"], 4)
     sharded_failed = False
-    if multi and args.mode != "replica":
+    # one GPU, default run: the sharded step still runs -- in a child with a process group of one over RCCL -- so that the line carries
+    # driver-timed evidence of the exchange path (as shipped and with every key exchanged)
+    solo_sharded = not multi and world == 1 and args.mode != "replica" and fused and not args.seedextend and not args.no_sharded and not args.no_extras
+    if solo_sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:
+            from umgap_amd.dist import free_port
+            os.environ["MASTER_PORT"] = str(free_port())
+        os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local_rank))
+    if (multi or solo_sharded) and args.mode != "replica":
         # the replica has done its job: its HBM goes to the child's shard and exchange buffers
         if w.index is not None:
             w.index.close()

@@ -264,8 +264,10 @@ int umgap_classify9_dev(umgap_index* ix, umgap_taxonomy* tx, int method, float l
  * ids to {preorder index, subtree size code}, so that umgap_classify9_dev with the SAME taxonomy handle aggregates
  * without gathering the by-id table (fewer random requests; results unchanged).  Refused, with the table left as
  * it was, when some value is not a reachable taxon of that taxonomy (the unbound kernels report those per read)
- * or the taxonomy has more than 2^22 - 2 reachable taxa.  While bound, every other lookup / dump / save entry
- * point refuses the handle; umgap_index_unbind_taxonomy restores the taxon ids. */
+ * or the taxonomy has more than 2^22 - 2 reachable taxa.  The fused calls -- umgap_classify9[_strategy]_dev,
+ * umgap_classify_prot9[_strategy]_dev and umgap_classify_records (what `umgap prot2kmer2agg` runs: it binds once at
+ * start-up) -- take a handle bound to the taxonomy they are given; while bound, every other lookup / dump / save
+ * entry point refuses the handle; umgap_index_unbind_taxonomy restores the taxon ids. */
 int umgap_index_bind_taxonomy(umgap_index* ix, umgap_taxonomy* tx);
 int umgap_index_unbind_taxonomy(umgap_index* ix, umgap_taxonomy* tx);
 int umgap_index_is_bound(const umgap_index* ix);

@@ -518,9 +518,9 @@ def test_seedextend_panic_cases_vs_oracle(api, torch_cuda):
 # ---------------------------------------------------------------------------------------------
 # the synthetic 9-mer high-precision pipeline: lookup -> (seedextend) -> LCA* with -l 2
 # ---------------------------------------------------------------------------------------------
-def _pipeline_check(api, torch, n_tax, n_keys, n_pairs, with_seedextend):
+def _pipeline_check(api, torch, n_tax, n_keys, n_pairs, with_seedextend, w=None):
     from umgap_amd.synth import ADD_B, KMERS_PER_PAIR, MUL_A, SyntheticWorkload
-    w = SyntheticWorkload(n_tax=n_tax, n_keys=n_keys)
+    w = w or SyntheticWorkload(n_tax=n_tax, n_keys=n_keys)
     d_keys = w.reads(0, n_pairs)
     d_hits = w.index.lookup9_dev(d_keys, miss_value=0)
     torch.cuda.synchronize()
@@ -827,10 +827,7 @@ def test_synth_pipeline_small_with_seedextend(api, torch_cuda):
     _pipeline_check(api, torch_cuda, n_tax=20_000, n_keys=1_000_000, n_pairs=20_000, with_seedextend=True)
 
 
-def test_synth_pipeline_config2_one_million_pairs(api, torch_cuda):
-    """BASELINE.json configs[1]: 1 M synthetic pairs, bit-exact vs the CPU oracle (84 M lookups)."""
-    t, s = _pipeline_check(api, torch_cuda, n_tax=2_500_000, n_keys=256_000_000, n_pairs=1_000_000, with_seedextend=False)
-    assert (s == 0).mean() > 0.9
+# (BASELINE.json configs[1], 1 M pairs against the FULL 8 G-key index, both surfaces: with the full-size tests at the end of the file)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -2092,6 +2089,20 @@ def test_classify_records_fused_route(api, torch_cuda, F, misfit):
             assert len(bad) == 0, (se, ms, method, strategy, bad[:5], t1[bad[:5]], wt[bad[:5]])
             for r in panics:
                 assert s1[r] == s0[r] == 3, (r, s1[r])      # UMGAP_READ_PANIC
+            # the table bound to the taxonomy (how `umgap prot2kmer2agg` runs it): both routes, bit for bit the unbound answers
+            ix.bind(tx)
+            try:
+                os.environ["UMGAP_RECORDS_FUSED"] = "0"
+                try:
+                    tb0, sb0 = api.classify_records(ix, tx, frags, read_frags, **kw)
+                finally:
+                    del os.environ["UMGAP_RECORDS_FUSED"]
+                tb1, sb1 = api.classify_records(ix, tx, frags, read_frags, **kw)
+                assert _lib.load().umgap_records_last_route() == route
+            finally:
+                ix.unbind(tx)
+            assert (tb0 == t0).all() and (sb0 == s0).all(), (se, ms, method, strategy, "general route, bound")
+            assert (tb1 == t1).all() and (sb1 == s1).all(), (se, ms, method, strategy, "fused route, bound")
 
 
 def test_host_pointer_calls_across_chunk_seams(api, torch_cuda):
@@ -2186,15 +2197,177 @@ def test_host_pointer_calls_across_chunk_seams(api, torch_cuda):
 # ---------------------------------------------------------------------------------------------
 # BASELINE.json configs[2] at full size: 50 M pairs (5 x 10 M), 8 G-key table, size-independent properties
 # ---------------------------------------------------------------------------------------------
-def test_full_size_50M_pairs_properties(api, torch_cuda):
+FULL_N_TAX, FULL_N_KEYS = 2_500_000, 8_000_000_000
+
+
+@pytest.fixture(scope="module")
+def full_size(api, torch_cuda):
+    """The benchmark's index and taxonomy as BASELINE.json names them: 8 G keys (128 GB of table), 2.5 M taxa.  Built once (1.1 s on the
+    device) for the tests below, which are the last of the file; released when the module is through."""
+    import gc
     torch = torch_cuda
-    from umgap_amd.synth import ADD_B, KMERS_PER_PAIR, MUL_A, SyntheticWorkload
+    from umgap_amd.synth import SyntheticWorkload
+    gc.collect()
+    torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info()
     if free < 200e9:
         pytest.skip("needs ~150 GB of free HBM")
-    n_tax, n_keys, B = 2_500_000, 8_000_000_000, 10_000_000
-    w = SyntheticWorkload(n_tax=n_tax, n_keys=n_keys, id_space=int(n_tax * 1.4), load_factor=0.5)
+    w = SyntheticWorkload(n_tax=FULL_N_TAX, n_keys=FULL_N_KEYS, id_space=int(FULL_N_TAX * 1.4), load_factor=0.5)
     assert 120e9 < w.index.table_bytes < 135e9          # 16 B/key at load 0.5: no grow-retries
+    yield w
+    w.index.close()
+    w.taxonomy.close()
+    torch.cuda.empty_cache()
+
+
+def test_config2_one_million_pairs_full_index_surface_a(api, torch_cuda, full_size):
+    """BASELINE.json configs[1] as written: 1 M synthetic pairs against the FULL 9-mer index (8 G keys), every read bit-exact vs the
+    CPU oracle -- surface A (`pept2lca` form, packed 9-mers): all 84 M lookups against the closed-form index, every pair's LCA*
+    (-l2) against the literal aggregator; then the fused kernel, unbound and bound to the taxonomy, bit for bit the same."""
+    torch = torch_cuda
+    from umgap_amd.synth import KMERS_PER_PAIR
+    w, n_pairs = full_size, 1_000_000
+    t, s = _pipeline_check(api, torch, FULL_N_TAX, FULL_N_KEYS, n_pairs, with_seedextend=False, w=w)
+    assert (s == 0).mean() > 0.9
+    d_keys = w.reads(0, n_pairs)
+    d_t = torch.empty(n_pairs, dtype=torch.int32, device="cuda")
+    d_s = torch.empty_like(d_t)
+    for bound in (False, True):
+        if bound:
+            w.index.bind(w.taxonomy)
+        d_t.fill_(-1)
+        d_s.fill_(-1)
+        try:
+            api.classify9_dev(w.index, w.taxonomy, d_keys, n_pairs, KMERS_PER_PAIR, d_t, d_s, method="tree", lower_bound=2.0)
+            torch.cuda.synchronize()
+        finally:
+            if bound:
+                w.index.unbind(w.taxonomy)
+        assert (d_t.cpu().numpy().view(np.uint32) == t).all() and (d_s.cpu().numpy().view(np.uint32) == s).all(), bound
+
+
+def _fragments_from_kmers(torch, d_keys, n_pairs):
+    """Surface B of the same reads (SURVEY.md 8d "two surfaces from the same data"): each end of a pair becomes ONE 50-residue
+    fragment whose windows at offsets 0, 9, 18, 27 and 36 are the end's k-mers 0, 9, 18, 27, 36 spelled out (members of the index or
+    not, as the generator chose them) and whose last 5 residues come from k-mer 41; the 37 windows in between straddle two k-mers
+    and are whatever they are (1.6 % of random 9-mers are members of the 8 G-key index)."""
+    k = d_keys.view(n_pairs * 2, 42)[:, [0, 9, 18, 27, 36, 41]]                          # [n_frag, 6]
+    shifts = torch.arange(8, -1, -1, device=k.device, dtype=torch.int64) * 5
+    codes = (k.unsqueeze(-1) >> shifts) & 31                                              # [n_frag, 6, 9]
+    letters = (codes + 65).to(torch.uint8).reshape(n_pairs * 2, 54)
+    return letters[:, :50].contiguous().reshape(-1)
+
+
+def test_config2_one_million_pairs_full_index_surface_b(api, torch_cuda, full_size):
+    """BASELINE.json configs[1], surface B (`prot2kmer2lca` form: one 50-residue line per end) against the same full index: the
+    84 M windows of 1 M pairs -- umgap_index_lookup_prot9_dev -- against the closed-form oracle, and every pair's taxon (LCA*, -l2)
+    from (i) the fused device kernel, unbound and bound, and (ii) umgap_classify_records fed from host arrays (what the command
+    runs) against the literal aggregator."""
+    torch = torch_cuda
+    from umgap_amd.synth import ADD_B, MUL_A
+    w, n_pairs, F, flen = full_size, 1_000_000, 2, 50
+    per = flen - 8
+    d_keys = w.reads(5_000_000, n_pairs)
+    frags = _fragments_from_kmers(torch, d_keys, n_pairs)
+    roffs = torch.arange(0, (n_pairs * F + 1) * flen, flen, dtype=torch.int64, device="cuda")
+    # oracle: every window packed on the host, looked up in closed form
+    host = frags.cpu().numpy()
+    rk, rok = _pack_windows(host.reshape(n_pairs * F, flen))
+    rk = rk.ravel()
+    rk[~rok.ravel()] = np.uint64(1 << 45)                                                 # a byte outside 'A'..'Z': no key, a miss
+    want_hits = O.synth_lookup9(O.SynthIndexParams(FULL_N_KEYS, FULL_N_TAX, MUL_A, ADD_B), w.taxon_of_row, rk, 0)
+    designed = want_hits.reshape(n_pairs * F, per)[:, [0, 9, 18, 27, 36]]
+    assert 0.55 < (designed != 0).mean() < 0.85 and 0.05 < (want_hits != 0).mean() < 0.2
+    oo = torch.arange(0, (n_pairs * F + 1) * per, per, dtype=torch.int64, device="cuda")
+    d_hits = torch.empty(n_pairs * F * per, dtype=torch.int32, device="cuda")
+    w.index.lookup_prot9_dev(frags, roffs, oo, d_hits)
+    torch.cuda.synchronize()
+    assert (d_hits.cpu().numpy().view(np.uint32) == want_hits).all()
+    del d_hits
+    agg = O.Aggregator(O.Taxonomy.from_arrays(w.ids, w.parents, w.valid, w.rank), "tree", "lca*")
+    offs = np.arange(n_pairs + 1, dtype=np.uint64) * (F * per)
+    d_t = torch.empty(n_pairs, dtype=torch.int32, device="cuda")
+    d_s = torch.empty_like(d_t)
+    api.classify_prot9_dev(w.index, w.taxonomy, frags, roffs, n_pairs, F, d_t, d_s, method="tree", strategy="lca*", lower_bound=2.0)
+    torch.cuda.synchronize()
+    t, s = d_t.cpu().numpy().view(np.uint32), d_s.cpu().numpy().view(np.uint32)
+    nbad, bad, wt, ws = agg.taxa2agg_check(want_hits, offs, t, s, lower_bound=2.0, nthreads=8)
+    assert nbad == 0, (bad, t[bad.astype(int)], wt[bad.astype(int)])
+    assert (s == 0).mean() > 0.3 and len(np.unique(t)) > 10_000
+    w.index.bind(w.taxonomy)
+    try:
+        d_t2, d_s2 = torch.full_like(d_t, -1), torch.full_like(d_s, -1)
+        api.classify_prot9_dev(w.index, w.taxonomy, frags, roffs, n_pairs, F, d_t2, d_s2, method="tree", strategy="lca*", lower_bound=2.0)
+        torch.cuda.synchronize()
+    finally:
+        w.index.unbind(w.taxonomy)
+    assert torch.equal(d_t, d_t2) and torch.equal(d_s, d_s2)
+    # the host-pointer call of the command (umgap prot2kmer2agg): records in host memory in, one taxon per read in host memory out
+    ht, hs = api.classify_records_arrays(w.index, w.taxonomy, host, roffs.cpu().numpy().view(np.uint64), np.arange(0, n_pairs * F + 1, F, dtype=np.uint64),
+                                         method="tree", strategy="lca*", lower_bound=2.0, seedextend=False)
+    assert (ht == t).all() and (hs == s).all()
+
+
+def test_config2_one_million_pairs_proteome_index_plain_and_walk_order(api, torch_cuda):
+    """Surface B over an index built from a proteome (umgap_index_build_windows9_dev: the smallest taxon over the fragments that hold
+    a 9-mer), in the plain layout and in walk order: 1 M pairs of 2 x 50 residues cut from the proteome with 3 % of the residues
+    changed, LCA* -l2, every pair against the oracle = a sorted array of the distinct 9-mers + the literal aggregator."""
+    torch = torch_cuda
+    import ctypes as C
+    from umgap_amd import _lib
+    from umgap_amd.api import Index, _dev_ptr, _stream_ptr
+    from umgap_amd.synth import SyntheticWorkload
+    L = _lib.load()
+    n_tax, n_frag, flen, n_reads, F = 200_000, 500_000, 50, 1_000_000, 2
+    per = flen - 8
+    w = SyntheticWorkload(n_tax=n_tax, n_keys=1000, build_index=False)
+    prot, poffs, ptaxa = _proteome(torch, w, n_frag, flen)
+    reads = torch.empty(n_reads * F * flen, dtype=torch.uint8, device="cuda")
+    _lib.check(L.umgap_synth_prot_reads_dev(_dev_ptr(prot), n_frag, flen, 44, 0, n_reads, F, 30, _dev_ptr(reads), 0, _stream_ptr(None)))
+    roffs = torch.arange(0, (n_reads * F + 1) * flen, flen, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    pk, pok = _pack_windows(prot.cpu().numpy().reshape(n_frag, flen))
+    assert pok.all()
+    pt = np.repeat(ptaxa.cpu().numpy().view(np.uint32), per)
+    order = np.lexsort((pt, pk.ravel()))
+    ks, ts = pk.ravel()[order], pt[order]
+    first = np.concatenate([[True], ks[1:] != ks[:-1]])
+    sorted_index = O.SortedIndex(ks[first], ts[first])                                    # smallest taxon per distinct 9-mer
+    del pk, pt, order, ks, ts, first
+    rk, rok = _pack_windows(reads.cpu().numpy().reshape(n_reads * F, flen))
+    rk = rk.ravel()
+    rk[~rok.ravel()] = np.uint64(1 << 45)
+    want_hits = sorted_index.lookup9(rk, 0, nthreads=8)
+    assert 0.3 < (want_hits != 0).mean() < 0.95
+    agg = O.Aggregator(O.Taxonomy.from_arrays(w.ids, w.parents, w.valid, w.rank), "tree", "lca*")
+    offs = np.arange(n_reads + 1, dtype=np.uint64) * (F * per)
+    got = {}
+    for layout in ("plain", "walk order"):
+        h = C.c_void_p()
+        if layout == "plain":
+            _lib.check(L.umgap_index_build_windows9_dev(_dev_ptr(prot), _dev_ptr(poffs), _dev_ptr(ptaxa), n_frag, flen, n_frag * per, 0.0, 0, C.byref(h)))
+        else:
+            _lib.check(L.umgap_index_build_walk9_dev(_dev_ptr(prot), _dev_ptr(poffs), _dev_ptr(ptaxa), n_frag, flen, n_frag * per, 0.0, 0, C.byref(h)))
+        ix = Index(h.value)
+        assert ix.kind == (9 if layout == "plain" else 10)
+        d_t = torch.empty(n_reads, dtype=torch.int32, device="cuda")
+        d_s = torch.empty_like(d_t)
+        api.classify_prot9_dev(ix, w.taxonomy, reads, roffs, n_reads, F, d_t, d_s, method="tree", strategy="lca*", lower_bound=2.0)
+        torch.cuda.synchronize()
+        t, s = d_t.cpu().numpy().view(np.uint32), d_s.cpu().numpy().view(np.uint32)
+        nbad, bad, wt, ws = agg.taxa2agg_check(want_hits, offs, t, s, lower_bound=2.0, nthreads=8)
+        assert nbad == 0, (layout, bad, t[bad.astype(int)], wt[bad.astype(int)])
+        assert (s == 0).mean() > 0.5
+        got[layout] = (t, s)
+        ix.close()
+    assert (got["plain"][0] == got["walk order"][0]).all() and (got["plain"][1] == got["walk order"][1]).all()
+
+
+def test_full_size_50M_pairs_properties(api, torch_cuda, full_size):
+    torch = torch_cuda
+    from umgap_amd.synth import ADD_B, KMERS_PER_PAIR, MUL_A
+    w = full_size
+    n_tax, n_keys, B = FULL_N_TAX, FULL_N_KEYS, 10_000_000
     snap = w.taxonomy.snapping(False)
     ot = O.Taxonomy.from_arrays(w.ids, w.parents, w.valid, w.rank)
     agg = O.Aggregator(ot, "tree", "lca*")

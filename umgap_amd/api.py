@@ -425,6 +425,21 @@ def classify_records(index, taxonomy, fragments, read_frags, method="tree", stra
     return out_t, out_s
 
 
+def classify_records_arrays(index, taxonomy, data, frag_offsets, read_frags, method="tree", strategy="hybrid", factor=0.25, lower_bound=0.0,
+                            ranked_only=False, seedextend=True, min_seed_size=2, max_gap_size=0):
+    """umgap_classify_records on arrays as a host program holds them: `data` uint8 residues, `frag_offsets` uint64 [n_fragments + 1],
+    `read_frags` uint64 [n_reads + 1].  Returns (out_taxon, out_status)."""
+    data = np.ascontiguousarray(data, dtype=np.uint8)
+    offs = np.ascontiguousarray(frag_offsets, dtype=np.uint64)
+    rf = np.ascontiguousarray(read_frags, dtype=np.uint64)
+    n = len(rf) - 1
+    out_t, out_s = np.empty(n, np.uint32), np.empty(n, np.uint32)
+    check(_lib.load().umgap_classify_records(index._h, taxonomy._h, METHODS[method], STRATEGIES[strategy], factor, lower_bound, int(ranked_only),
+                                             _np_ptr(data), _np_ptr(offs), len(offs) - 1, _np_ptr(rf), n, int(seedextend), min_seed_size,
+                                             max_gap_size, _np_ptr(out_t), _np_ptr(out_s)))
+    return out_t, out_s
+
+
 def seedextend_dev(d_taxa, d_offsets=None, stride=None, n_records=None, min_seed_size=2, max_gap_size=0, d_kept=None, stream=None):
     """seedextend (unranked) in place on a torch CUDA int32 tensor (src/commands/seedextend.rs:99-148)."""
     L = _lib.load()

@@ -1228,6 +1228,15 @@ int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
         fprintf(stderr, "Warning: this is a hybrid between LCA/MRTL, not LCA*/MRTL\n");
     if (method == UMGAP_METHOD_TREE && strategy == UMGAP_STRATEGY_MRTL)
         throw CliError("Invalid invocation: Tree and MaximumRootToLeafPath cannot be combined");
+    // index and taxonomy are both here: the table is bound to the taxonomy once (values = preorder interval codes, 0.3 s for a 128 GB
+    // table), which is how the fused kernel runs fastest -- the configuration bench.py's headline times.  A table some value of which
+    // is no taxon of this taxonomy stays unbound (the unbound kernels report such hits per read, like the reference); UMGAP_BIND=0
+    // keeps the taxon ids (A/B).
+    {
+        const char* env = getenv("UMGAP_BIND");
+        if (!(env && env[0] == '0') && umgap_index_bind_taxonomy(ix, tx) != UMGAP_OK && timing)
+            fprintf(stderr, "prot2kmer2agg: table not bound to the taxonomy: %s\n", umgap_last_error());
+    }
     const double t_start = now();
     const unsigned T = worker_count();
     auto stream = [&](FILE* in, FILE* outf) {

@@ -17,6 +17,7 @@
 //   k_frag_prepare   fragment -> {start, length} (validated) + the tail positions marked in a bitmap
 //   k_lookup_bytes9  every unmarked byte position: 9 residues packed from LDS -> quad probe -> hits[b]
 //   k_seedextend_frags / k_read_offsets / the aggregate kernels / k_mark_seed_panics
+#include "bound.hpp"
 #include "host_copy.hpp"
 #include "probe_common.hpp"
 #include "prot_limits.hpp"
@@ -184,6 +185,17 @@ __global__ __launch_bounds__(256) void k_records_any_unsupported(const uint32_t*
     if (any) atomicExch(flags + 1, 1u);
 }
 
+// the general route on a table bound to the taxonomy: the probe returned interval codes (bound.hpp; 0 = miss), the kernels behind it
+// want taxon ids
+__global__ __launch_bounds__(256) void k_codes_to_ids(uint32_t* __restrict__ hits, size_t n, const uint32_t* __restrict__ id_of_pre) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) {
+        const uint32_t v = hits[i];
+        if (v) hits[i] = id_of_pre[bound::pre_of(v)];
+    }
+}
+
 struct Slot {
     uint8_t* bytes = nullptr;
     uint64_t *off = nullptr, *off_rel = nullptr, *rf = nullptr, *roff = nullptr, *rfl = nullptr;
@@ -216,7 +228,10 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
                                       uint32_t max_gap_size, uint32_t* out_taxon, uint32_t* out_status) {
     if (!ix || !tx || (n_reads && (!read_frags || !out_taxon || !out_status)) || (n_fragments && !frag_offsets))
         return fail(UMGAP_ERR_INVALID, "umgap_classify_records: null argument");
-    if (ix->bound_to) return fail(UMGAP_ERR_INVALID, "the index is bound to a taxonomy (umgap_index_bind_taxonomy): its values are interval codes, not taxon ids; unbind it first");
+    // a table bound to THIS taxonomy (umgap_index_bind_taxonomy: values = preorder interval codes) is what the fused route wants -- no
+    // by-id gathers in the aggregate; the general route turns the codes back into taxon ids behind its probe (k_codes_to_ids)
+    if (ix->bound_to && ix->bound_to != tx) return fail(UMGAP_ERR_INVALID, "umgap_classify_records: the index is bound to another taxonomy");
+    const bool bound = ix->bound_to != nullptr;
     if (ix->kind != 9 && ix->kind != 10) return fail(UMGAP_ERR_INVALID, "umgap_classify_records: not a 9-mer index");
     const bool walk = ix->kind == 10;   // window numbers -> taxa through the walk array (index_walk.hip) before the hits are used
     if (ix->device != tx->device) return fail(UMGAP_ERR_INVALID, "umgap_classify_records: index and taxonomy live on different devices");
@@ -403,6 +418,7 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
             const unsigned gb = (unsigned)std::min<uint64_t>((nb + 511) / 512, 2048);
             hipLaunchKernelGGL(k_lookup_bytes9, dim3(gb), dim3(256), 0, s, T, L.bytes, L.tails, (uint32_t)nb, L.hits, walk ? UMGAP_NONE : 0u);
             if (walk && (rc = walk_map_positions(ix, L.hits, (size_t)nb, 0u, s))) break;
+            if (bound) hipLaunchKernelGGL(k_codes_to_ids, dim3(gb), dim3(256), 0, s, L.hits, (size_t)nb, (const uint32_t*)tx->d_id_of_pre);
         }
         if (seedextend && nf)
             hipLaunchKernelGGL(k_seedextend_frags, dim3(gf), dim3(256), 0, s, L.fstart, L.flen, (size_t)nf, min_seed_size, max_gap_size, L.hits, L.kept);
