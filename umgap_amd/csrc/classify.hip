@@ -149,8 +149,31 @@ __device__ __forceinline__ void gather_run_to_strip(const TableView& T, const Hi
             travelled[u] = wanted[u] && R[u].owner != wire::NO_OWNER && R[u].owner != H.self && pos < H.cap;
             slot[u] = (uint64_t)R[u].owner * H.cap + pos;
         }
+        // the four values in ONE round trip: every lane loads (slot 0 where it has nothing to fetch) and the format is told apart
+        // outside the four loads -- a load under `travelled` or under the per-slot format test is followed by its own wait
 #pragma unroll
-        for (int u = 0; u < 4; u++) val[u] = travelled[u] ? wire::load_value(H.ret, slot[u], H.value_bytes) : 0u;
+        for (int u = 0; u < 4; u++) if (!travelled[u]) slot[u] = 0;
+        if (H.value_bytes == 3) {
+            uint32_t w0[4], w1[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t* w = H.ret + (size_t)(slot[u] >> 2) * 3 + (((uint32_t)slot[u] & 3u) >> 1);
+                w0[u] = w[0];
+                w1[u] = w[1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t i = (uint32_t)slot[u] & 3u;
+                const uint32_t v = (i == 0 ? w0[u] : (i == 1 ? ((w0[u] >> 24) | (w1[u] << 8)) : (i == 2 ? ((w0[u] >> 16) | (w1[u] << 16)) : (w1[u] >> 8)))) & 0xFFFFFFu;
+                val[u] = (travelled[u] && v != 0xFFFFFFu) ? v : 0u;
+            }
+        } else {
+            uint32_t w0[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) w0[u] = H.ret[slot[u]];
+#pragma unroll
+            for (int u = 0; u < 4; u++) val[u] = (travelled[u] && w0[u] != 0xFFFFFFFFu) ? w0[u] : 0u;
+        }
 #pragma unroll
         for (int u = 0; u < 4; u++) { const uint32_t i = i0 + 64 * u + lane; if (wanted[u] && !local[u]) wtaxa[i - want_lo] = val[u]; }
         // the rank's own keys: probed here, two rounds in flight (keys that travelled take no part: no request is issued for them)

@@ -211,13 +211,19 @@ __global__ __launch_bounds__(256) void k_shard_pack(const uint64_t* __restrict__
         uint64_t h[PACK_ROUNDS];
         uint32_t meta[PACK_ROUNDS];   // owner | rank << 8, all-ones = not sent
         uint32_t seen = 0;
+        // the run's keys, all loads in flight together (inside the loop below each load was followed by its own wait: 16 dependent
+        // round trips per run)
 #pragma unroll
         for (int r = 0; r < PACK_ROUNDS; r++) {
-            h[r] = 0;
+            const uint32_t i = 64u * r + lane;
+            h[r] = i < len ? __builtin_nontemporal_load(keys + k0 + i) : 0ull;
+        }
+#pragma unroll
+        for (int r = 0; r < PACK_ROUNDS; r++) {
             meta[r] = 0xFFFFFFFFu;
             if (64u * r >= len) continue;   // wave-uniform
             const uint32_t i = 64u * r + lane;
-            const uint64_t key = i < len ? __builtin_nontemporal_load(keys + k0 + i) : 0ull;
+            const uint64_t key = h[r];
             const wire::Routed R = wire::route(key, i < len, m, nb, world, world_over_nb);
             const uint32_t owner = R.owner == local_owner ? wire::NO_OWNER : R.owner;   // this rank's own key: probed where it is consumed
             const uint32_t rank = wire::run_rank(owner, world, lane, seen);
@@ -289,21 +295,24 @@ __global__ __launch_bounds__(256) void k_shard_probe(TableView T, const uint8_t*
     const uint16_t* hi = reinterpret_cast<const uint16_t*>(rb + cap * 4) + pos0;
     ProbeBatch B[2];
     uint32_t res[2][4];
+    // the four key words of both batches in ONE round trip: a load the compiler can sink under `hh < 2^13` becomes a dependent trip
+    // of its own, and its wait drains the other batch's bucket loads (the first version: five dependent trips per step, not two)
+    uint32_t kl[2], kh[2];
 #pragma unroll
     for (int b = 0; b < 2; b++) {
-        const uint32_t l = __builtin_nontemporal_load(lo + 64 * b + lane);
-        const uint32_t hh = __builtin_nontemporal_load(hi + 64 * b + lane);
-        uint32_t local = 0, tag = 0, valid = 0;
-        if (hh < (1u << 13)) {
-            const uint64_t h = ((uint64_t)hh << 32) | l;
-            const uint32_t a = (uint32_t)(h >> R_BITS);
-            tag = (uint32_t)h & R_MASK;
-            const uint32_t bkt = a * T.m + (uint32_t)(((uint64_t)tag * T.m) >> R_BITS);
-            local = bkt - T.home_lo;
-            valid = (bkt >= T.home_lo && bkt < T.home_hi) ? 1u : 0u;   // a key this shard does not own is a miss
-        }
-        probe_issue(T, local, tag | (valid << 31), lane, B[b]);
+        kl[b] = __builtin_nontemporal_load(lo + 64 * b + lane);
+        kh[b] = __builtin_nontemporal_load(hi + 64 * b + lane);
     }
+#pragma unroll
+    for (int b = 0; b < 2; b++) {
+        const uint64_t h = ((uint64_t)(kh[b] & 0x1FFFu) << 32) | kl[b];
+        const uint32_t a = (uint32_t)(h >> R_BITS);
+        const uint32_t tag = (uint32_t)h & R_MASK;
+        const uint32_t bkt = a * T.m + (uint32_t)(((uint64_t)tag * T.m) >> R_BITS);
+        const uint32_t valid = (kh[b] < (1u << 13) && bkt >= T.home_lo && bkt < T.home_hi) ? 1u : 0u;   // no key in the slot, or a key this shard does not own: a miss
+        probe_issue(T, valid ? bkt - T.home_lo : 0u, tag | (valid << 31), lane, B[b]);
+    }
+    __builtin_amdgcn_sched_barrier(0);   // all eight sector loads are out before the first is evaluated (the scheduler otherwise starts on batch 0 with half of batch 1 unissued)
     probe_eval_multi<2>(T, B, MISS, lane, res);
     uint32_t* wl = lds_out[wv];
 #pragma unroll
