@@ -154,3 +154,20 @@ def test_async_io_consumer_that_leaves_early(tmp_path):
         a.stdout.close()
         rc = a.wait(timeout=60)
     assert len(first) == 100 and rc != 0
+
+
+def test_fused_command_tokenizer_against_line_by_line_restatement(tmp_path):
+    """The block tokenizer of `umgap prot2kmer2agg` (umgap_amd/csrc/host/fuse_parse.hpp: 64 bytes at a time off newline and
+    high-bit masks) against a plain line-by-line restatement of the rules of src/io/fasta.rs:38-67 + src/commands/
+    prot2kmer2lca.rs:172-179 on random FASTA-like byte soup (CRs, empty lines, lines around the 64-byte stretches, valid and
+    broken UTF-8, a missing last newline), built with AddressSanitizer + UBSan (tests/native/fuse_parse_check.cpp)."""
+    import shutil
+    import subprocess
+    cxx = shutil.which("g++") or shutil.which("clang++")
+    if not cxx:
+        pytest.skip("no C++ compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "fuse_parse_check")
+    subprocess.run([cxx, "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-o", exe, os.path.join(root, "tests", "native", "fuse_parse_check.cpp")], check=True)
+    p = subprocess.run([exe, "6000", "11"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert p.returncode == 0, p.stdout.decode()[-2000:]

@@ -13,6 +13,10 @@
 // UTF-8 ends the stream with an error AFTER the record that was being read has been emitted
 // truncated at the bad line (the Peekable stops at the Err, the next read_record returns it).
 #pragma once
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <functional>
 #include <thread>
@@ -35,7 +39,7 @@ inline unsigned worker_count() {
 // Reads `f` in blocks that end right before a record start (or at EOF).
 class BlockReader {
   public:
-    explicit BlockReader(FILE* f, size_t block = default_block()) : f_(f), buf_(block) {}
+    explicit BlockReader(FILE* f, size_t block = default_block()) : f_(f), block_(block) {}
     // The view handed out by next() then stays valid until the call AFTER the next one (two buffers take turns): a caller can
     // still format block n from its bytes while block n + 1 is being read and parsed.
     void keep_previous_block() { keep_previous_ = true; }
@@ -44,9 +48,56 @@ class BlockReader {
         if (env && *env) { long v = atol(env); if (v >= 16) return (size_t)v; }
         return 64u << 20;
     }
+    ~BlockReader() { if (map_) munmap(map_, map_len_); }
+    BlockReader(const BlockReader&) = delete;
+    BlockReader& operator=(const BlockReader&) = delete;
+    // When the stream is a regular file (`umgap ... < reads.fa`; the command's stdin, wrapped or not, sits on descriptor 0) the
+    // rest of the file is mapped and next() hands out views of the mapping: no read(), no copy, and the page faults are taken by
+    // the worker threads that tokenize the block.  Call before the first next().  UMGAP_MMAP=0 keeps the reads (A/B).  (A file
+    // that is truncated by somebody else while the command runs ends it with SIGBUS instead of a short read.)
+    void map_regular_file() {
+        const char* env = getenv("UMGAP_MMAP");
+        if (env && env[0] == '0') return;
+        const int fd = f_ == stdin ? 0 : fileno(f_);
+        if (fd < 0) return;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) return;
+        const off_t at = lseek(fd, 0, SEEK_CUR);
+        if (at < 0 || at >= st.st_size) return;                    // (an empty rest of file: the ordinary path says "exhausted")
+        const long page = sysconf(_SC_PAGESIZE);
+        const off_t base = at / page * page;
+        void* m = mmap(nullptr, (size_t)(st.st_size - base), PROT_READ, MAP_PRIVATE, fd, base);
+        if (m == MAP_FAILED) return;
+        (void)madvise(m, (size_t)(st.st_size - base), MADV_SEQUENTIAL);
+        map_ = m;
+        map_len_ = (size_t)(st.st_size - base);
+        mdata_ = (const char*)m + (at - base);
+        mlen_ = (size_t)(st.st_size - at);
+    }
     // Returns false when the stream is exhausted.  [data, data+len) holds whole records; the view
     // stays valid until the next call.
     bool next(const char*& data, size_t& len) {
+        if (map_) {
+            if (mpos_ >= mlen_) return false;
+            const char* b = mdata_ + mpos_;
+            const size_t left = mlen_ - mpos_;
+            if (first_) {
+                if (!lines_only_ && b[0] != '>') first_line_error_ = true;   // src/io/fasta.rs:44-49
+                first_ = false;
+            }
+            size_t take = left;
+            for (size_t want = block_; want < left; want *= 2) {         // the last record start strictly inside the first `want` bytes
+                size_t cut = 0;
+                for (size_t p = want; p-- > 1;)
+                    if (b[p - 1] == '\n' && (lines_only_ || b[p] == '>')) { cut = p; break; }
+                if (cut) { take = cut; break; }
+            }
+            data = b;
+            len = take;
+            mpos_ += take;
+            return true;
+        }
+        if (buf_.empty()) buf_.resize(block_);   // (not before the first read: a mapped file needs no buffer)
         if (keep_previous_) {
             if (other_.size() < buf_.size()) other_.resize(buf_.size());
             if (carry_) memcpy(other_.data(), buf_.data() + carry_off_, carry_);
@@ -90,8 +141,12 @@ class BlockReader {
 
   private:
     FILE* f_;
+    size_t block_;
     std::vector<char> buf_, other_;
     size_t carry_ = 0, carry_off_ = 0;
+    void* map_ = nullptr;            // map_regular_file(): the mapping, and the stream inside it
+    size_t map_len_ = 0, mlen_ = 0, mpos_ = 0;
+    const char* mdata_ = nullptr;
     bool eof_ = false, first_ = true, first_line_error_ = false, lines_only_ = false, keep_previous_ = false;
 };
 

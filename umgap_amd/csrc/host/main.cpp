@@ -21,6 +21,7 @@
 #include "../../../include/umgap_hip.h"
 #include "async_io.hpp"
 #include "fastpath.hpp"
+#include "fuse_parse.hpp"
 #include "text.hpp"
 
 using namespace umgap_host;
@@ -170,7 +171,10 @@ void lookup_strings(umgap_index* ix, const StringBatch& b, std::vector<uint32_t>
 // Block-parallel (fastpath.hpp): workers tokenize record-aligned ranges of a block and pack the
 // 9-mers, ONE device lookup serves the block, workers format their ranges, output in input order.
 // Peptides / windows that are not [A-Z]{9} cannot be in the table: they miss without a device call.
-struct LookupPart {
+// (the per-range structs of the block-parallel commands are aligned to two cache lines: they sit side by side in one array, each is
+// filled by its own thread with a push_back per item, and the vectors' end pointers live in the struct -- unaligned, neighbouring
+// threads fought over those lines and 16 threads tokenized at a quarter of the single-thread rate each)
+struct alignas(128) LookupPart {
     std::vector<size_t> hdr_off;
     std::vector<uint32_t> hdr_len, n_items;  // per record; n_items = items (pept2lca) or windows (prot2kmer2lca)
     std::vector<uint8_t> emit;               // per record: printed at all? (prot2kmer2lca drops reads shorter than k)
@@ -729,7 +733,7 @@ int cmd_taxa2agg(const std::vector<std::string>& args) {
         throw CliError("Invalid invocation: Tree and MaximumRootToLeafPath cannot be combined");  // :134-138
 
     // block-parallel record loop (fastpath.hpp): parse -> ONE umgap_aggregate per block -> format
-    struct AggPart {
+    struct alignas(128) AggPart {
         std::vector<size_t> hdr_off;
         std::vector<uint32_t> hdr_len;
         std::vector<uint64_t> offsets{0};
@@ -897,7 +901,7 @@ int cmd_seedextend(const std::vector<std::string>& args) {
     // host restatement of the record state machine for the text filter (the device kernels
     // umgap_seedextend_dev / umgap_classify9_dev serve the fused pipeline), block-parallel over
     // records.  src/commands/seedextend.rs:99-148
-    struct SePart { std::string out; std::optional<CliError> error; bool panic = false; };
+    struct alignas(128) SePart { std::string out; std::optional<CliError> error; bool panic = false; };
     BlockReader blocks(stdin);
     const unsigned T = worker_count();
     const char* d;
@@ -998,7 +1002,7 @@ int cmd_uniq(const std::vector<std::string>& args) {
         // block-parallel tokenization into record descriptors; the merge of consecutive equal headers is a
         // serial pass over descriptors; a record body is copied verbatim (items are already "item\n")
         struct Rec { size_t hdr_off; uint32_t hdr_len; size_t body_off, body_len; uint32_t n_items; bool verbatim; };
-        struct UPart { std::vector<Rec> recs; bool bad_utf8 = false; };
+        struct alignas(128) UPart { std::vector<Rec> recs; bool bad_utf8 = false; };
         BlockReader blocks(stdin);
         const unsigned T = worker_count();
         const char* d;
@@ -1097,67 +1101,7 @@ int cmd_uniq(const std::vector<std::string>& args) {
 // four-stage pipe accepts it prints the same bytes as the pipe (tests/test_cli_gpu.py); the hits stay on the
 // device (umgap_classify_records).  Deliberate differences, all on error paths: a failing record (invalid UTF-8,
 // a window cutting a character, an unknown taxon) ends the run after the reads that precede it were printed.
-struct FusePart {
-    // per emitted record (sequence >= 9 residues): its header as `uniq` sees it (two more CRs stripped by the readers of
-    // seedextend and uniq, cut at the delimiter) and its sequence length
-    std::vector<size_t> hdr_off;
-    std::vector<uint32_t> hdr_len;
-    std::vector<uint64_t> frag_len;
-    std::vector<uint32_t> gstart;   // records that open a new `uniq` group inside this range (record 0 always does)
-    std::vector<uint8_t> bytes;
-    bool bad_utf8 = false, panic = false;
-    size_t rec_base = 0, byte_base = 0, group_base = 0, hdr_base = 0, hdr_bytes = 0;
-    bool merged = false;            // record 0 continues the group that was open before this range
-    std::string_view header(const char* d, size_t r) const { return std::string_view(d + hdr_off[r], hdr_len[r]); }
-};
-
-void parse_fuse_part(const char* d, size_t begin, size_t end, const std::optional<std::string>& delim, FusePart& P) {
-    LineCursor lc{d + begin, d + end};
-    std::string_view line;
-    bool open = false;
-    size_t rec_start = 0;
-    std::string_view cur;
-    P.bytes.reserve(end - begin);
-    auto finish = [&]() {
-        if (!open) return;
-        open = false;
-        size_t n = P.bytes.size() - rec_start;
-        if (n < 9) { P.bytes.resize(rec_start); return; }   // src/commands/prot2kmer2lca.rs:172: dropped, header and all
-        const uint8_t* q = P.bytes.data() + rec_start;
-        bool ascii = true;
-        for (size_t i = 0; i < n; i++) if (q[i] >= 0x80) { ascii = false; break; }
-        if (!ascii)  // &seq[i..i + k] panics when a window edge falls inside a character (:175)
-            for (size_t i = 0; i + 9 <= n; i++)
-                if ((q[i] & 0xC0) == 0x80 || (i + 9 < n && (q[i + 9] & 0xC0) == 0x80)) { P.panic = true; P.bytes.resize(rec_start); return; }
-        std::string_view h = cur;
-        // every reader of the pipe strips one trailing CR from a line (BufRead::lines): seedextend's and uniq's here
-        for (int k = 0; k < 2 && !h.empty() && h.back() == '\r'; k++) h.remove_suffix(1);
-        if (delim) { size_t at = h.find(*delim); if (at != std::string_view::npos) h = h.substr(0, at); }
-        size_t r = P.hdr_off.size();
-        if (r == 0 || h != P.header(d, r - 1)) { P.gstart.push_back((uint32_t)r); P.hdr_bytes += h.size(); }   // src/commands/uniq.rs:70-77
-        P.hdr_off.push_back((size_t)(h.data() - d));
-        P.hdr_len.push_back((uint32_t)h.size());
-        P.frag_len.push_back(n);
-    };
-    while (lc.next(line)) {
-        bool utf8 = line_utf8_ok(line);
-        if (!line.empty() && line[0] == '>' && utf8) {
-            finish();
-            if (P.panic) return;
-            cur = line.substr(1);
-            rec_start = P.bytes.size();
-            open = true;
-            continue;
-        }
-        if (!utf8) {
-            P.bad_utf8 = true;
-            if (open) P.bytes.resize(rec_start);
-            return;
-        }
-        P.bytes.insert(P.bytes.end(), line.begin(), line.end());   // unwrap: lines of a record are concatenated (src/io/fasta.rs:62-64)
-    }
-    finish();
-}
+// (FusePart and its tokenizer, parse_fuse_part: fuse_parse.hpp)
 
 // one block's worth of reads, self-contained (nothing points into the block buffer)
 // Grow-only array in page-locked host memory (umgap_host_alloc): what umgap_classify_records copies from / to at full
@@ -1196,6 +1140,7 @@ struct FuseJob {
     std::vector<uint64_t> hdr_end;    // n_reads + 1
     size_t n_reads = 0;
     PinnedVec<uint32_t> out_taxon, out_status;
+    std::vector<std::string> outs;    // formatted output of the job, one string per formatting thread
 };
 
 int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
@@ -1255,7 +1200,9 @@ int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
         for (size_t r = 0; r < J.n_reads; r++)
             if (J.out_status[r] == UMGAP_READ_UNKNOWN_TAXON || J.out_status[r] == UMGAP_READ_PANIC || J.out_status[r] == 4u) { bad = r; break; }
         const size_t nt = std::max<size_t>(1, std::min<size_t>(T / 2, bad / 4096 + 1));
-        std::vector<std::string> outs(nt);
+        std::vector<std::string>& outs = J.outs;   // (kept with the job: the strings keep their memory from block to block)
+        if (outs.size() < nt) outs.resize(nt);
+        for (auto& o : outs) o.clear();
         parallel_for(nt, [&](size_t t) {
             size_t lo = bad * t / nt, hi = bad * (t + 1) / nt;
             outs[t].reserve((hi - lo) * 12 + (size_t)(J.hdr_end[hi] - J.hdr_end[lo]));
@@ -1285,7 +1232,9 @@ int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
 
     // the group `uniq` is still merging when a block ends (src/commands/uniq.rs:66-79): carried into the next block
     struct Carry { bool have = false; std::string hdr; std::vector<uint8_t> bytes; std::vector<uint64_t> frag_len; } carry;
+    std::vector<FusePart> parts;
     BlockReader blocks(in);
+    blocks.map_regular_file();   // a file on stdin is mapped: blocks are views of the page cache, nothing is copied by this thread
     for (;;) {
         const char* d = nullptr;
         size_t len = 0;
@@ -1295,7 +1244,7 @@ int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
         if (more && blocks.first_line_error()) { join_worker(); throw CliError("Expected > at beginning of fasta header."); }
         std::vector<size_t> cuts = more ? split_records(d, len, T) : std::vector<size_t>{0};
         const size_t np = cuts.size() - 1;
-        std::vector<FusePart> parts(np);
+        if (parts.size() < np) parts.resize(np);   // the parts keep their buffers from block to block (fresh pages cost more than the parse)
         parallel_for(np, [&](size_t i) { parse_fuse_part(d, cuts[i], cuts[i + 1], delim, parts[i]); });
         t_parse += now() - t0; t0 = now();
         size_t used = np;
@@ -1310,7 +1259,7 @@ int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
         for (size_t i = 0; i < used; i++) {
             FusePart& P = parts[i];
             P.rec_base = n_frag; P.byte_base = n_bytes; P.group_base = n_groups; P.hdr_base = n_hdr;
-            n_frag += P.frag_len.size(); n_bytes += P.bytes.size();
+            n_frag += P.frag_len.size(); n_bytes += P.n_bytes;
             if (P.hdr_off.empty()) continue;
             P.merged = have_prev && P.header(d, 0) == prev;
             n_groups += P.gstart.size() - (P.merged ? 1 : 0);
@@ -1330,7 +1279,7 @@ int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
         if (carry.have) { J.read_frags[0] = 0; J.hdr_end[0] = 0; memcpy(J.hdrs.data(), carry.hdr.data(), carry_hdr); }
         parallel_for(used, [&](size_t i) {
             const FusePart& P = parts[i];
-            if (!P.bytes.empty()) memcpy(J.bytes.data() + P.byte_base, P.bytes.data(), P.bytes.size());
+            if (P.n_bytes) memcpy(J.bytes.data() + P.byte_base, P.bytes.get(), P.n_bytes);
             uint64_t o = P.byte_base;
             for (size_t r = 0; r < P.frag_len.size(); r++) { o += P.frag_len[r]; J.frag_off[P.rec_base + r + 1] = o; }
             size_t gi = P.group_base, ho = carry_hdr + P.hdr_base;
@@ -1416,8 +1365,14 @@ int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
         }
     }
     stream(stdin, stdout);
+    const double t_streamed = now();
+    fflush(stdout);
+    umgap_host::AsyncIo::drain_all();
+    const double t_drained = now();
     umgap_taxonomy_free(tx);
     umgap_index_free(ix);
+    if (timing) fprintf(stderr, "prot2kmer2agg: stream %.3f s, output drained after %.3f s more, handles freed after %.3f s more\n", t_streamed - t_start, t_drained - t_streamed,
+                        now() - t_drained);
     return 0;
 }
 
@@ -1427,7 +1382,7 @@ int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
 //          syntax; stdin is re-read if it is a seekable file, otherwise it is spooled to a temporary file on the way;
 //   pass 2 packs the 9-mers and streams them into the device table (umgap_index_builder_*).
 // If some key is not [A-Z]{9} the variable-length table is built instead (in memory: tryptic indexes are small).
-struct BuildPart {
+struct alignas(128) BuildPart {
     size_t n = 0;
     bool all9 = true;
     std::string first, last;                 // first / last key of the range (order check across ranges)
