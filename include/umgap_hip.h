@@ -319,6 +319,14 @@ int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int method, int 
                            const uint64_t* frag_offsets, size_t n_fragments, const uint64_t* read_frags,
                            size_t n_reads, int seedextend, uint32_t min_seed_size, uint32_t max_gap_size,
                            uint32_t* out_taxon, uint32_t* out_status);
+/* What `prot2kmer2lca` does per record (src/commands/prot2kmer2lca.rs:172-179: every 9-residue window of the record through
+ * fst::Map::get) for a whole block of records in ONE call, the windows cut on the device: fragment f = bytes[frag_offsets[f] ..
+ * frag_offsets[f+1]) (host memory; pinned arrays are copied from / to directly), out_hits[b - frag_offsets[0]] = value of the 9-mer
+ * that starts at byte b for every b with b + 9 <= end of its fragment, miss_value where that window is not [A-Z]{9} or not a key,
+ * and at the positions that start no window (the last 8 of a fragment).  1.2 bytes per window cross the link instead of an 8-byte
+ * packed key, and the host does no per-window work.  `umgap prot2kmer2lca` on a 9-mer index runs on this call. */
+int umgap_index_lookup_records(umgap_index* ix, const uint8_t* bytes, const uint64_t* frag_offsets, size_t n_fragments,
+                               uint32_t miss_value, uint32_t* out_hits);
 /* Which kernels the last umgap_classify_records of the calling thread ran: 1 = one fused launch per chunk (every read of the call
  * has the same number of fragments, at most 16, and fits the limits of umgap_classify_prot9_strategy_dev: what paired reads look
  * like), 0 = the general kernels (a hit per byte position in HBM between probe, seedextend and aggregate), 2 = the fused ones and

@@ -2105,6 +2105,68 @@ def test_classify_records_fused_route(api, torch_cuda, F, misfit):
             assert (tb1 == t1).all() and (sb1 == s1).all(), (se, ms, method, strategy, "fused route, bound")
 
 
+@pytest.mark.parametrize("layout", ["plain", "walk order"])
+def test_lookup_records_cuts_the_windows_on_the_device(api, torch_cuda, layout):
+    """umgap_index_lookup_records (what `umgap prot2kmer2lca` runs on): residues in host memory in, the hit of every window out,
+    indexed by the byte position the window starts at.  Against a dict on fragments of every length (empty, shorter than 9, odd
+    bytes inside), more short fragments than a chunk's offset table holds, and one fragment longer than a chunk (the chunks then
+    cut inside it and bring 8 bytes of lookahead along), from pageable and from pinned arrays."""
+    torch = torch_cuda
+    rng = np.random.default_rng(31)
+    letters = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    n_tax = 5000
+    prot = rng.choice(letters, 600_000).astype(np.uint8)
+    table = {}
+    pk, pok = _pack_windows(prot.reshape(1, -1))
+    vals = rng.integers(1, n_tax, pk.shape[1]).astype(np.uint32)
+    for k, v in zip(pk[0].tolist(), vals.tolist()):
+        table.setdefault(k, v)
+    keys = np.array(sorted(table), np.uint64)
+    kv = np.array([table[int(k)] for k in keys], np.uint32)
+    if layout == "plain":
+        ix = api.Index.build(keys, kv)
+    else:
+        values = api.Index.build(keys, kv)
+        d_prot = torch.from_numpy(prot).cuda()
+        d_off = torch.tensor([0, len(prot)], dtype=torch.int64, device="cuda")
+        ix = api.Index.build_walk(values, [(d_prot, d_off, len(prot))])
+        assert ix.kind == 10
+    # fragments: slices of the proteome (hits) and random residues (misses), every length; then 300 k tiny ones; then one of 9 MB
+    frags = []
+    for _ in range(3000):
+        n = int(rng.choice([0, 1, 8, 9, 10, 17, 50, 50, 200]))
+        a = int(rng.integers(0, len(prot) - 200))
+        f = prot[a:a + n].copy() if rng.random() < 0.7 else rng.choice(letters, n).astype(np.uint8)
+        if n > 10 and rng.random() < 0.1:
+            f[int(rng.integers(0, n))] = int(rng.choice([42, 120, 0xC3]))
+        frags.append(f)
+    frags += [prot[a:a + int(n)] for a, n in zip(rng.integers(0, len(prot) - 12, 300_000), rng.integers(0, 12, 300_000))]
+    frags.append(np.tile(prot, 15))
+    frags += [prot[5:60], np.zeros(0, np.uint8), prot[100:109]]
+    lens = np.array([len(f) for f in frags], np.uint64)
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint64) + np.uint64(7)          # (the first fragment need not start at 0)
+    data = np.concatenate([np.zeros(7, np.uint8)] + frags)
+    got = ix.lookup_records(data, offs, miss_value=0)
+    # expected: per fragment, per window
+    want = np.zeros(len(data) - 7, np.uint32)
+    for f, o in zip(frags, (offs[:-1] - np.uint64(7)).tolist()):
+        if len(f) < 9:
+            continue
+        k, ok = _pack_windows(f.reshape(1, -1))
+        pos = np.searchsorted(keys, k[0])
+        pos[pos >= len(keys)] = 0
+        want[o:o + len(f) - 8] = np.where(ok[0] & (keys[pos] == k[0]), kv[pos], 0)
+    assert (got == want).all(), np.flatnonzero(got != want)[:10]
+    assert (want != 0).mean() > 0.3
+    # pinned arrays in and out: copied from / to directly
+    h_data = torch.from_numpy(data).pin_memory()
+    h_offs = torch.from_numpy(offs.view(np.int64)).pin_memory()
+    h_out = torch.empty(len(want), dtype=torch.int32).pin_memory()
+    from umgap_amd import _lib
+    _lib.check(_lib.load().umgap_index_lookup_records(ix._h, h_data.data_ptr(), h_offs.data_ptr(), len(frags), 5, h_out.data_ptr()))
+    assert (h_out.numpy().view(np.uint32) == np.where(want == 0, 5, want)).all()
+
+
 def test_host_pointer_calls_across_chunk_seams(api, torch_cuda):
     """The host-pointer entry points cut a call into chunks that travel over an upload lane while earlier chunks compute
     (records.hip, index.hip, index_var.hip, aggregate.hip): the answers must not depend on where the seams fall.  Each call is

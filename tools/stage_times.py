@@ -73,12 +73,16 @@ for i, (name, args) in enumerate(stages):
     t0 = time.perf_counter()
     subprocess.run([E.UMGAP] + args, stdin=subprocess.DEVNULL, stdout=subprocess.DEVNULL, check=True)
     t_start = time.perf_counter() - t0
+    import resource
+    r0 = resource.getrusage(resource.RUSAGE_CHILDREN)
     t0 = time.perf_counter()
     with open(src, "rb") as fi, open(dst, "wb") as fo:
         subprocess.run([E.UMGAP] + args, stdin=fi, stdout=fo, check=True)
     dt = time.perf_counter() - t0
+    r1 = resource.getrusage(resource.RUSAGE_CHILDREN)
     run = max(dt - t_start, 1e-9)
-    res["stages"].append({"stage": name, "s": round(dt, 3), "start_up_s": round(t_start, 3), "in_MB": round(os.path.getsize(src) / 1e6, 1),
+    res["stages"].append({"stage": name, "s": round(dt, 3), "start_up_s": round(t_start, 3), "cpu_user_s": round(r1.ru_utime - r0.ru_utime, 3),
+                          "cpu_sys_s": round(r1.ru_stime - r0.ru_stime, 3), "in_MB": round(os.path.getsize(src) / 1e6, 1),
                           "out_MB": round(os.path.getsize(dst) / 1e6, 1), "in_MB_per_s": round(os.path.getsize(src) / 1e6 / run, 1),
                           "pairs_per_s": round(n_pairs / run, 1)})
     src = dst

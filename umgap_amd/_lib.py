@@ -75,6 +75,7 @@ def load():
         "umgap_index_table_bytes": (u64, [vp]),
         "umgap_index_device": (i32, [vp]),
         "umgap_index_lookup9": (i32, [vp, vp, sz, u32, vp]),
+        "umgap_index_lookup_records": (i32, [vp, vp, vp, sz, u32, vp]),
         "umgap_index_lookup9_dev": (i32, [vp, vp, sz, u32, vp, vp]),
         "umgap_index_lookup9_lane_dev": (i32, [vp, vp, sz, u32, vp, vp]),
         "umgap_index_lookup_prot9_dev": (i32, [vp, vp, vp, vp, sz, u32, vp, vp]),

@@ -234,6 +234,16 @@ class Index:
         check(_lib.load().umgap_index_lookup9(self._h, _np_ptr(keys), len(keys), miss_value, _np_ptr(out)))
         return out
 
+    def lookup_records(self, data, frag_offsets, miss_value=0):
+        """The windows of protein records cut and looked up on the device (umgap_index_lookup_records): `data` uint8 residues,
+        `frag_offsets` uint64 [n + 1]; returns a uint32 array with one entry per byte position of [frag_offsets[0], frag_offsets[n])
+        -- the hit of the 9-mer that starts there, miss_value where none does."""
+        data = np.ascontiguousarray(data, dtype=np.uint8)
+        offs = np.ascontiguousarray(frag_offsets, dtype=np.uint64)
+        out = np.full(int(offs[-1] - offs[0]) if len(offs) else 0, 0xABABABAB, np.uint32)
+        check(_lib.load().umgap_index_lookup_records(self._h, _np_ptr(data), _np_ptr(offs), len(offs) - 1, miss_value, _np_ptr(out)))
+        return out
+
     def lookup9_dev(self, d_keys45, d_out=None, miss_value=0, stream=None, variant="quad"):
         """torch CUDA tensors (int64 keys, int32 out); enqueues on `stream` (current stream if None)."""
         import torch

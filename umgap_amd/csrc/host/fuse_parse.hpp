@@ -60,6 +60,39 @@ inline Masks scan64(const char* p) {
 inline uint64_t below(unsigned k) { return k >= 64 ? ~0ull : ((1ull << k) - 1ull); }   // bits [0, k)
 }  // namespace fuse_detail
 
+// The lines of d[begin, end), handed to line(s, e, high) in order: [s, e) is the line without its '\n' (a trailing '\r' is the
+// callee's business), high = some byte of it has bit 7 set (only then can it be anything but ASCII).  A last line without '\n'
+// counts (BufRead::lines); `stop` set by the callee ends the scan.
+template <class LineFn>
+inline void scan_lines(const char* d, size_t begin, size_t end, bool& stop, LineFn&& line) {
+    using namespace fuse_detail;
+    size_t pos = begin, line_start = begin;
+    bool line_high = false;   // the current line has a high byte in a stretch already scanned
+    while (!stop && pos + 64 <= end) {
+        const Masks m = scan64(d + pos);
+        uint64_t nl = m.nl, done = 0;   // done: bits of this stretch that belong to lines already handed out
+        while (nl) {
+            const unsigned k = (unsigned)__builtin_ctzll(nl);
+            nl &= nl - 1;
+            const bool high = line_high || (m.hi & below(k) & ~done) != 0;
+            line(line_start, pos + k, high);
+            if (stop) break;
+            line_start = pos + k + 1;
+            done = below(k + 1);
+            line_high = false;
+        }
+        line_high = line_high || (m.hi & ~done) != 0;
+        pos += 64;
+    }
+    while (!stop && pos < end) {   // the last < 64 bytes
+        const unsigned char c = (unsigned char)d[pos];
+        if (c == '\n') { line(line_start, pos, line_high); line_start = pos + 1; line_high = false; }
+        else if (c >= 0x80) line_high = true;
+        pos++;
+    }
+    if (!stop && line_start < end) line(line_start, end, line_high);   // a last line without '\n'
+}
+
 inline void parse_fuse_part(const char* d, size_t begin, size_t end, const std::optional<std::string>& delim, FusePart& P) {
     using namespace fuse_detail;
     const size_t len = end - begin;
@@ -132,37 +165,90 @@ inline void parse_fuse_part(const char* d, size_t begin, size_t end, const std::
         rec_high = rec_high || high;
     };
 
-    size_t pos = begin, line_start = begin;
-    bool line_high = false;   // the current line has a high byte in a stretch already scanned
-    while (!stop && pos + 64 <= end) {
-        const Masks m = scan64(d + pos);
-        uint64_t nl = m.nl, done = 0;   // done: bits of this stretch that belong to lines already handed out
-        while (nl) {
-            const unsigned k = (unsigned)__builtin_ctzll(nl);
-            nl &= nl - 1;
-            const bool high = line_high || (m.hi & below(k) & ~done) != 0;
-            line(line_start, pos + k, high);
-            if (stop) break;
-            line_start = pos + k + 1;
-            done = below(k + 1);
-            line_high = false;
-        }
-        line_high = line_high || (m.hi & ~done) != 0;
-        pos += 64;
-    }
-    while (!stop && pos < end) {   // the last < 64 bytes
-        const unsigned char c = (unsigned char)d[pos];
-        if (c == '\n') { line(line_start, pos, line_high); line_start = pos + 1; line_high = false; }
-        else if (c >= 0x80) line_high = true;
-        pos++;
-    }
-    if (!stop && line_start < end) line(line_start, end, line_high);   // a last line without '\n'
+    scan_lines(d, begin, end, stop, line);
     if (!stop) finish();
     P.n_bytes = out_n;
     P.hdr_bytes = hdr_bytes;
     P.panic = panic;
     P.bad_utf8 = bad_utf8;
     P.hdr_off = std::move(hdr_off); P.hdr_len = std::move(hdr_len); P.frag_len = std::move(frag_len); P.gstart = std::move(gstart);
+}
+
+// ---- the records of `umgap prot2kmer2lca` (k = 9, a 9-mer index): the tokenizer behind umgap_index_lookup_records ----------------
+// Per record of the range, in input order: its header as printed (the line behind '>', one CR stripped by the reader), whether it
+// is printed at all (a sequence shorter than 9 is dropped, header and all: src/commands/prot2kmer2lca.rs:172 -- but still counts as
+// a record of its chunk, src/io/fasta.rs:118-137) and the length of its sequence in the part's byte buffer (0 when dropped).
+// Invalid UTF-8: the record read so far is emitted, then the stream errors out (bad_utf8); a window edge inside a multi-byte
+// character: the reference's slicing panic (:175), the range ends with that record (panic; the record is listed, not printed).
+struct alignas(128) KmerPart {
+    std::vector<size_t> hdr_off;
+    std::vector<uint32_t> hdr_len;
+    std::vector<uint64_t> seq_len;      // residues of the record in `bytes` (0: not printed)
+    std::vector<uint8_t> emit;
+    std::unique_ptr<uint8_t[]> bytes;
+    size_t n_bytes = 0, cap_bytes = 0;
+    bool bad_utf8 = false, panic = false;
+    size_t rec_base = 0, byte_base = 0;
+    std::string out;
+};
+
+inline void parse_kmer_part(const char* d, size_t begin, size_t end, KmerPart& P) {
+    const size_t len = end - begin;
+    if (P.cap_bytes < len + 16) { P.cap_bytes = len + len / 8 + 4096; P.bytes.reset(new uint8_t[P.cap_bytes]); }
+    uint8_t* out = P.bytes.get();
+    size_t out_n = 0;
+    P.n_bytes = 0; P.bad_utf8 = P.panic = false;
+    P.rec_base = P.byte_base = 0;
+    std::vector<size_t> hdr_off = std::move(P.hdr_off);
+    std::vector<uint32_t> hdr_len = std::move(P.hdr_len);
+    std::vector<uint64_t> seq_len = std::move(P.seq_len);
+    std::vector<uint8_t> emit = std::move(P.emit);
+    hdr_off.clear(); hdr_len.clear(); seq_len.clear(); emit.clear();
+    {
+        const size_t guess = len / 64 + 16;
+        hdr_off.reserve(guess); hdr_len.reserve(guess); seq_len.reserve(guess); emit.reserve(guess);
+    }
+    bool have_rec = false, rec_high = false, stop = false, panic = false, bad_utf8 = false;
+    size_t rec_start = 0;
+    auto finish = [&]() {
+        if (!have_rec) return;
+        const size_t n = out_n - rec_start;
+        if (n < 9) { out_n = rec_start; emit.back() = 0; seq_len.back() = 0; return; }
+        if (rec_high) {
+            const uint8_t* q = out + rec_start;
+            for (size_t i = 0; i + 9 <= n; i++)
+                if ((q[i] & 0xC0) == 0x80 || (i + 9 < n && (q[i + 9] & 0xC0) == 0x80)) { panic = true; out_n = rec_start; emit.back() = 0; seq_len.back() = 0; return; }
+        }
+        seq_len.back() = n;
+    };
+    auto line = [&](size_t s, size_t e, bool high) {
+        size_t le = e;
+        if (le > s && d[le - 1] == '\r') le--;
+        const bool utf8 = !high || valid_utf8(std::string_view(d + s, le - s));
+        if (le > s && d[s] == '>' && utf8) {
+            finish();
+            if (panic) { stop = true; return; }
+            hdr_off.push_back(s + 1);
+            hdr_len.push_back((uint32_t)(le - s - 1));
+            seq_len.push_back(0);
+            emit.push_back(1);
+            have_rec = true;
+            rec_start = out_n;
+            rec_high = false;
+            return;
+        }
+        if (!utf8) { bad_utf8 = true; stop = true; return; }   // the record read so far is emitted below, then the stream errors out
+        if (!have_rec) return;
+        memcpy(out + out_n, d + s, le - s);
+        out_n += le - s;
+        rec_high = rec_high || high;
+    };
+    scan_lines(d, begin, end, stop, line);
+    if (!panic) finish();
+    P.n_bytes = out_n;
+    P.panic = panic;
+    P.bad_utf8 = bad_utf8;
+    P.hdr_off = std::move(hdr_off); P.hdr_len = std::move(hdr_len); P.seq_len = std::move(seq_len); P.emit = std::move(emit);
 }
 
 }  // namespace umgap_host

@@ -167,6 +167,36 @@ void lookup_strings(umgap_index* ix, const StringBatch& b, std::vector<uint32_t>
     for (size_t k = 0; k < keys.size(); k++) out[where[k]] = t[k];
 }
 
+// Grow-only array in page-locked host memory (umgap_host_alloc): what umgap_classify_records copies from / to at full
+// PCIe rate and without blocking the calling thread.  resize() keeps no old contents.
+template <class T>
+struct PinnedVec {
+    T* p = nullptr;
+    size_t n = 0, cap = 0;
+    PinnedVec() = default;
+    PinnedVec(const PinnedVec&) = delete;
+    PinnedVec& operator=(const PinnedVec&) = delete;
+    ~PinnedVec() { umgap_host_free(p); }
+    void resize(size_t m) {
+        if (m > cap) {
+            umgap_host_free(p);
+            p = nullptr;
+            cap = 0;
+            void* q = nullptr;
+            const size_t want = m + m / 4 + 1024;
+            if (umgap_host_alloc(want * sizeof(T), &q) != UMGAP_OK) throw CliError(umgap_last_error());
+            p = (T*)q;
+            cap = want;
+        }
+        n = m;
+    }
+    T* data() { return p; }
+    T* begin() { return p; }
+    size_t size() const { return n; }
+    T& operator[](size_t i) { return p[i]; }
+};
+
+
 // ---- pept2lca / prot2kmer2lca on the packed 9-mer table -------------------------------------
 // Block-parallel (fastpath.hpp): workers tokenize record-aligned ranges of a block and pack the
 // 9-mers, ONE device lookup serves the block, workers format their ranges, output in input order.
@@ -440,6 +470,167 @@ void stream_lookup(FILE* in, FILE* outf, umgap_index* ix, bool one_on_one, bool 
     stream_lookup(in, outf, [ix](const uint64_t* keys, size_t n, uint32_t* taxa) { LIB(umgap_index_lookup9(ix, keys, n, 0u, taxa)); }, one_on_one, kmer_mode, k, chunk);
 }
 
+// `prot2kmer2lca` with k = 9 on a 9-mer index held by one GPU: the records' residues go to the device as they are and the windows
+// are cut there (umgap_index_lookup_records) -- the host packs no keys and touches no window until it prints its hit.  Ranges,
+// chunk bookkeeping (src/io/fasta.rs:118-137: output per completed chunk of `chunk` records, an error or a panic drops the open
+// chunk), error order and the two overlapped stages are those of stream_lookup above, which keeps the other cases (any other k,
+// a byte-string index, the table sharded over several GPUs).
+void stream_kmer_records(FILE* in, FILE* outf, umgap_index* ix, bool one_on_one, size_t chunk) {
+    if (chunk == 0) chunk = 1;
+    BlockReader blocks(in);
+    blocks.keep_previous_block();
+    blocks.map_regular_file();
+    const unsigned T = worker_count();
+    struct Job {
+        const char* d = nullptr;
+        std::vector<KmerPart> parts;
+        size_t np = 0;
+        PinnedVec<uint8_t> bytes;
+        PinnedVec<uint64_t> frag_off;
+        PinnedVec<uint32_t> hits;
+        std::vector<std::string> tails;
+    };
+    std::string held;          // formatted records of the still open chunk
+    size_t g0 = 0;             // global index of the block's first record
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const bool timing = getenv("UMGAP_TIMING") != nullptr;
+    double t_read = 0, t_parse = 0, t_wait = 0, t_gather = 0, t_lookup = 0, t_format = 0, t_write = 0;
+    // records [rb, re) of a part: header, then one line per window that hit (or every window with -o, misses as 0: src/commands/
+    // prot2kmer2lca.rs:176-178); consecutive windows mostly carry the same taxon, whose line is kept and appended again
+    auto format_part = [&](const char* d, const KmerPart& P, const uint32_t* hits, const uint64_t* frag_off, size_t rb, size_t re, std::string& out) {
+        size_t f = P.rec_base;                     // fragment number (emitted records only) of record rb
+        for (size_t r = 0; r < rb; r++) f += P.emit[r];
+        char last_line[24];
+        size_t last_len = 0;
+        uint32_t last_t = 0;
+        for (size_t r = rb; r < re; r++) {
+            if (!P.emit[r]) continue;
+            out.push_back('>'); out.append(d + P.hdr_off[r], P.hdr_len[r]); out.push_back('\n');
+            const uint32_t* h = hits + frag_off[f];
+            const size_t windows = (size_t)P.seq_len[r] - 8;
+            f++;
+            for (size_t i = 0; i < windows; i++) {
+                const uint32_t t = h[i];
+                if (t == 0 && !one_on_one) continue;
+                if (t != last_t || !last_len) {
+                    const size_t before = out.size();
+                    append_uint(out, t);
+                    out.push_back('\n');
+                    last_len = out.size() - before;
+                    memcpy(last_line, out.data() + before, last_len);
+                    last_t = t;
+                } else out.append(last_line, last_len);
+            }
+        }
+    };
+    auto stage_b = [&](Job& J) {
+        const char* d = J.d;
+        std::vector<KmerPart>& parts = J.parts;
+        const size_t np = J.np;
+        size_t used = np;
+        for (size_t i = 0; i < np; i++)
+            if (parts[i].bad_utf8 || parts[i].panic) { used = i + 1; break; }
+        const bool failed = parts[used - 1].bad_utf8 || parts[used - 1].panic;
+        size_t n_rec = 0, n_frag = 0, n_bytes = 0;
+        std::vector<size_t> rec_first(used + 1, 0);
+        for (size_t i = 0; i < used; i++) {
+            KmerPart& P = parts[i];
+            rec_first[i] = n_rec;
+            n_rec += P.hdr_off.size();
+            P.rec_base = n_frag;                  // (first FRAGMENT of the part: emitted records only)
+            P.byte_base = n_bytes;
+            for (uint8_t e : P.emit) n_frag += e;
+            n_bytes += P.n_bytes;
+        }
+        rec_first[used] = n_rec;
+        size_t limit;
+        if (failed) {
+            // bad UTF-8: the error surfaces when the NEXT record is read, after n_rec good ones; panic: inside the last record
+            const size_t e = parts[used - 1].panic ? g0 + n_rec - 1 : g0 + n_rec;
+            limit = e / chunk * chunk;
+        } else limit = (g0 + n_rec) / chunk * chunk;   // the open chunk at the end is held back (released at EOF below)
+        double t0 = now();
+        J.bytes.resize(n_bytes + 16);
+        J.frag_off.resize(n_frag + 1);
+        J.hits.resize(n_bytes + 16);
+        J.frag_off[0] = 0;
+        parallel_for(used, [&](size_t i) {
+            const KmerPart& P = parts[i];
+            if (P.n_bytes) memcpy(J.bytes.data() + P.byte_base, P.bytes.get(), P.n_bytes);
+            uint64_t o = P.byte_base;
+            size_t f = P.rec_base;
+            for (size_t r = 0; r < P.emit.size(); r++)
+                if (P.emit[r]) { o += P.seq_len[r]; J.frag_off[++f] = o; }
+        });
+        t_gather += now() - t0; t0 = now();
+        if (n_frag) LIB(umgap_index_lookup_records(ix, J.bytes.data(), J.frag_off.data(), n_frag, 0u, J.hits.data()));
+        t_lookup += now() - t0; t0 = now();
+        if (J.tails.size() < used) J.tails.resize(used);
+        parallel_for(used, [&](size_t i) {
+            KmerPart& P = parts[i];
+            const size_t nr = P.hdr_off.size(), lo = g0 + rec_first[i];
+            const size_t cut = limit <= lo ? 0 : std::min(nr, limit - lo);
+            P.out.clear();
+            J.tails[i].clear();
+            P.out.reserve(nr * 24 + P.n_bytes * 8);
+            format_part(d, P, J.hits.data(), J.frag_off.data(), 0, cut, P.out);
+            if (cut < nr && !failed) format_part(d, P, J.hits.data(), J.frag_off.data(), cut, nr, J.tails[i]);
+        });
+        t_format += now() - t0; t0 = now();
+        const size_t held_from = g0 / chunk * chunk;
+        if (!held.empty() && limit > held_from) { fwrite(held.data(), 1, held.size(), outf); held.clear(); }
+        for (size_t i = 0; i < used; i++) fwrite(parts[i].out.data(), 1, parts[i].out.size(), outf);
+        t_write += now() - t0;
+        if (failed) {
+            fflush(outf);
+            if (parts[used - 1].panic) throw CliPanic("byte index is not a char boundary");
+            throw CliError("stream did not contain valid UTF-8");
+        }
+        for (size_t i = 0; i < used; i++) held.append(J.tails[i]);
+        g0 += n_rec;
+    };
+    Job jobs[2];
+    int cur = 0;
+    std::thread helper;
+    std::exception_ptr helper_err;
+    auto join_helper = [&]() {
+        if (helper.joinable()) helper.join();
+        if (helper_err) { std::exception_ptr e = helper_err; helper_err = nullptr; std::rethrow_exception(e); }
+    };
+    try {
+        const char* d;
+        size_t len;
+        for (;;) {
+            double t0 = now();
+            if (!blocks.next(d, len)) break;
+            t_read += now() - t0; t0 = now();
+            if (blocks.first_line_error()) { join_helper(); throw CliError("Expected > at beginning of fasta header."); }
+            Job& J = jobs[cur];
+            std::vector<size_t> cuts = split_records(d, len, T);
+            J.np = cuts.size() - 1;
+            J.d = d;
+            if (J.parts.size() < J.np) J.parts.resize(J.np);
+            parallel_for(J.np, [&](size_t i) { parse_kmer_part(d, cuts[i], cuts[i + 1], J.parts[i]); });
+            t_parse += now() - t0; t0 = now();
+            join_helper();                         // stage B of the previous block is done (and has thrown here if it failed)
+            t_wait += now() - t0;
+            bool failing = false;
+            for (size_t i = 0; i < J.np; i++) failing = failing || J.parts[i].bad_utf8 || J.parts[i].panic;
+            if (failing) { stage_b(J); continue; }
+            helper = std::thread([&stage_b, &helper_err, &J]() { try { stage_b(J); } catch (...) { helper_err = std::current_exception(); } });
+            cur ^= 1;
+        }
+        join_helper();
+    } catch (...) {
+        if (helper.joinable()) helper.join();
+        throw;
+    }
+    fwrite(held.data(), 1, held.size(), outf);   // EOF closes the last chunk
+    fflush(outf);
+    if (timing) fprintf(stderr, "stream_kmer_records: stage A: read %.3f, parse %.3f, wait for stage B %.3f | stage B: gather %.3f, lookup %.3f, format %.3f, write %.3f\n",
+                        t_read, t_parse, t_wait, t_gather, t_lookup, t_format, t_write);
+}
+
 // --shards N: the index sharded by bucket range over N GPUs inside this one process (one host thread per GPU), the exchange
 // over RCCL -- what the resident `umgap prot2kmer2lca -m -o -s <socket>` server of scripts/umgap-analyse.sh:257-264 becomes
 // when the index outgrows one GPU.  Rank r holds shard r (umgap_index_open_shard) on GPU r and looks up the r-th slice of every
@@ -646,6 +837,7 @@ int cmd_prot2kmer2lca(const std::vector<std::string>& args) {
     const bool var_index = !gang && umgap_index_kind(ix) == 2;
     auto stream = [&](FILE* in, FILE* outf) {
         if (gang) { stream_lookup(in, outf, [&](const uint64_t* keys, size_t n, uint32_t* taxa) { gang->lookup(keys, n, taxa); }, o, true, k, chunk); return; }
+        if (!var_index && k == 9 && !getenv("UMGAP_KMER_KEYS")) { stream_kmer_records(in, outf, ix, o, chunk); return; }   // (UMGAP_KMER_KEYS=1: keys packed on the host, A/B)
         if (!var_index) { stream_lookup(in, outf, ix, o, true, k, chunk); return; }
         if (k >= 1) {      // block-parallel, the windows of k residues as strings (parse_lookup_part)
             const LineExpand windows = [](std::string_view, StringBatch&) {};   // (its presence selects the string mode; k-mer mode cuts the windows itself)
@@ -732,92 +924,129 @@ int cmd_taxa2agg(const std::vector<std::string>& args) {
     if (method == UMGAP_METHOD_TREE && strategy == UMGAP_STRATEGY_MRTL)
         throw CliError("Invalid invocation: Tree and MaximumRootToLeafPath cannot be combined");  // :134-138
 
-    // block-parallel record loop (fastpath.hpp): parse -> ONE umgap_aggregate per block -> format
+    // block-parallel record loop (fastpath.hpp), two overlapped stages: while block n is aggregated on the device, formatted and
+    // written (stage B, a helper thread), block n + 1 is read and tokenized (stage A).  Stage B runs one block at a time, in input
+    // order, so output and errors come as from the plain loop of src/commands/taxa2agg.rs:160-180.
     struct alignas(128) AggPart {
         std::vector<size_t> hdr_off;
         std::vector<uint32_t> hdr_len;
-        std::vector<uint64_t> offsets{0};
+        std::vector<uint64_t> offsets;     // n_records + 1, relative to the part's first taxon
         std::vector<uint32_t> taxa;
         std::vector<float> scores;
         std::vector<uint64_t> big;         // ids that do not fit 32 bits, for the message
         std::optional<CliError> error;     // stops the stream after the records parsed so far
-        size_t rec_base = 0;
+        size_t rec_base = 0, tax_base = 0;
         std::string out;
     };
-    BlockReader blocks(stdin);
-    const unsigned T = worker_count();
-    const char* d;
-    size_t len;
-    std::vector<uint32_t> taxa, out_taxon, out_status;
-    std::vector<float> scores;
-    std::vector<uint64_t> offsets;
-    while (blocks.next(d, len)) {
-        if (blocks.first_line_error()) throw CliError("Expected > at beginning of fasta header.");
-        std::vector<size_t> cuts = split_records(d, len, T);
-        const size_t np = cuts.size() - 1;
-        std::vector<AggPart> parts(np);
-        parallel_for(np, [&](size_t pi) {
-            AggPart& P = parts[pi];
-            LineCursor lc{d + cuts[pi], d + cuts[pi + 1]};
-            std::string_view line;
-            bool open = false;  // a record is being read
-            auto close = [&]() { if (open) { P.offsets.push_back(P.taxa.size()); open = false; } };
-            try {
-                while (lc.next(line)) {
-                    if (!line_utf8_ok(line)) {  // the record read so far still counts, then the stream errors
-                        close();
-                        P.error = CliError("stream did not contain valid UTF-8");
-                        return;
-                    }
-                    if (!line.empty() && line[0] == '>') {
-                        close();
-                        P.hdr_off.push_back((size_t)(line.data() - d) + 1);
-                        P.hdr_len.push_back((uint32_t)line.size() - 1);
-                        open = true;
-                        continue;
-                    }
-                    uint64_t t;
-                    if (scored) {  // with_score, src/commands/taxa2agg.rs:142-148
-                        size_t eq = line.find('=');
-                        if (eq == std::string_view::npos || line.find('=', eq + 1) != std::string_view::npos) throw CliError("Taxon without score");
-                        t = parse_usize(line.substr(0, eq));
-                        P.scores.push_back(parse_f32(line.substr(eq + 1)));
-                    } else {
-                        t = parse_usize(line);
-                    }
-                    if (t >= 0xFFFFFFFEull) { P.big.push_back(t); t = 0xFFFFFFFEull; }
-                    P.taxa.push_back((uint32_t)t);
-                }
+    auto parse_part = [&](const char* d, size_t begin, size_t end, AggPart& P) {
+        // (the vectors are filled on this thread's stack and handed back: see LookupPart)
+        std::vector<size_t> hdr_off = std::move(P.hdr_off);
+        std::vector<uint32_t> hdr_len = std::move(P.hdr_len), taxa = std::move(P.taxa);
+        std::vector<uint64_t> offsets = std::move(P.offsets), big = std::move(P.big);
+        std::vector<float> scores = std::move(P.scores);
+        hdr_off.clear(); hdr_len.clear(); taxa.clear(); offsets.clear(); big.clear(); scores.clear();
+        offsets.push_back(0);
+        taxa.reserve((end - begin) / 4 + 16);
+        P.error.reset();
+        P.out.clear();
+        bool open = false, stop = false;
+        auto close = [&]() { if (open) { offsets.push_back(taxa.size()); open = false; } };
+        auto line = [&](size_t s, size_t e, bool high) {
+            size_t le = e;
+            if (le > s && d[le - 1] == '\r') le--;
+            if (high && !valid_utf8(std::string_view(d + s, le - s))) {   // the record read so far still counts, then the stream errors
                 close();
-            } catch (CliError& e) {
-                // the failing record is dropped; everything before it is still aggregated and printed
-                P.error = e;
-                P.hdr_off.pop_back();
-                P.hdr_len.pop_back();
-                P.taxa.resize(P.offsets.back());
-                if (scored) P.scores.resize(P.offsets.back());
+                P.error = CliError("stream did not contain valid UTF-8");
+                stop = true;
+                return;
             }
-        });
+            if (le > s && d[s] == '>') {
+                close();
+                hdr_off.push_back(s + 1);
+                hdr_len.push_back((uint32_t)(le - s - 1));
+                open = true;
+                return;
+            }
+            try {
+                uint64_t t = 0;
+                const size_t n = le - s;
+                bool fast = !scored && n >= 1 && n <= 18;     // the common line: a few decimal digits
+                for (size_t i = 0; fast && i < n; i++) {
+                    const unsigned c = (unsigned char)d[s + i] - '0';
+                    if (c > 9) fast = false; else t = t * 10 + c;
+                }
+                if (!fast) {
+                    const std::string_view l(d + s, n);
+                    if (scored) {  // with_score, src/commands/taxa2agg.rs:142-148
+                        const size_t eq = l.find('=');
+                        if (eq == std::string_view::npos || l.find('=', eq + 1) != std::string_view::npos) throw CliError("Taxon without score");
+                        t = parse_usize(l.substr(0, eq));
+                        scores.push_back(parse_f32(l.substr(eq + 1)));
+                    } else t = parse_usize(l);
+                }
+                if (t >= 0xFFFFFFFEull) { big.push_back(t); t = 0xFFFFFFFEull; }
+                taxa.push_back((uint32_t)t);
+            } catch (CliError& err) {
+                // the failing record is dropped; everything before it is still aggregated and printed
+                P.error = err;
+                hdr_off.pop_back();
+                hdr_len.pop_back();
+                taxa.resize(offsets.back());
+                if (scored) scores.resize(offsets.back());
+                open = false;
+                stop = true;
+            }
+        };
+        scan_lines(d, begin, end, stop, line);
+        if (!stop) close();
+        P.hdr_off = std::move(hdr_off); P.hdr_len = std::move(hdr_len); P.taxa = std::move(taxa);
+        P.offsets = std::move(offsets); P.big = std::move(big); P.scores = std::move(scores);
+    };
+    struct Job {
+        const char* d = nullptr;
+        std::vector<AggPart> parts;
+        size_t np = 0;
+        PinnedVec<uint32_t> taxa, out_taxon, out_status;
+        PinnedVec<float> scores;
+        PinnedVec<uint64_t> offsets;
+    };
+    BlockReader blocks(stdin);
+    blocks.keep_previous_block();
+    blocks.map_regular_file();
+    const unsigned T = worker_count();
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const bool timing = getenv("UMGAP_TIMING") != nullptr;
+    double t_read = 0, t_parse = 0, t_wait = 0, t_gather = 0, t_dev = 0, t_format = 0, t_write = 0;
+    auto stage_b = [&](Job& J) {
+        const char* d = J.d;
+        std::vector<AggPart>& parts = J.parts;
+        const size_t np = J.np;
         size_t used = np;
         for (size_t i = 0; i < np; i++)
             if (parts[i].error) { used = i + 1; break; }
         size_t n_rec = 0, n_tax = 0;
-        for (size_t i = 0; i < used; i++) { parts[i].rec_base = n_rec; n_rec += parts[i].hdr_off.size(); n_tax += parts[i].taxa.size(); }
-        taxa.clear(); scores.clear(); offsets.assign(1, 0);
-        taxa.reserve(n_tax); offsets.reserve(n_rec + 1);
-        for (size_t i = 0; i < used; i++) {
-            size_t base = taxa.size();
-            taxa.insert(taxa.end(), parts[i].taxa.begin(), parts[i].taxa.end());
-            if (scored) scores.insert(scores.end(), parts[i].scores.begin(), parts[i].scores.end());
-            for (size_t r = 1; r < parts[i].offsets.size(); r++) offsets.push_back(base + parts[i].offsets[r]);
-        }
-        out_taxon.resize(n_rec); out_status.resize(n_rec);
-        if (n_rec) LIB(umgap_aggregate(tx, method, strategy, factor, lower_bound, ranked ? 1 : 0, taxa.data(), scored ? scores.data() : nullptr,
-                                       offsets.data(), n_rec, out_taxon.data(), out_status.data()));
+        for (size_t i = 0; i < used; i++) { parts[i].rec_base = n_rec; parts[i].tax_base = n_tax; n_rec += parts[i].hdr_off.size(); n_tax += parts[i].taxa.size(); }
+        double t0 = now();
+        J.taxa.resize(n_tax + 1);
+        if (scored) J.scores.resize(n_tax + 1);
+        J.offsets.resize(n_rec + 1);
+        J.out_taxon.resize(n_rec + 1);
+        J.out_status.resize(n_rec + 1);
+        J.offsets[0] = 0;
+        parallel_for(used, [&](size_t i) {
+            const AggPart& P = parts[i];
+            if (!P.taxa.empty()) memcpy(J.taxa.data() + P.tax_base, P.taxa.data(), P.taxa.size() * 4);
+            if (scored && !P.scores.empty()) memcpy(J.scores.data() + P.tax_base, P.scores.data(), P.scores.size() * 4);
+            for (size_t r = 0; r < P.hdr_off.size(); r++) J.offsets[P.rec_base + r + 1] = P.tax_base + P.offsets[r + 1];
+        });
+        t_gather += now() - t0; t0 = now();
+        if (n_rec) LIB(umgap_aggregate(tx, method, strategy, factor, lower_bound, ranked ? 1 : 0, J.taxa.data(), scored ? J.scores.data() : nullptr,
+                                       J.offsets.data(), n_rec, J.out_taxon.data(), J.out_status.data()));
+        t_dev += now() - t0; t0 = now();
         // the first failing record (if any) ends the output
         size_t bad = n_rec;
         for (size_t r = 0; r < n_rec; r++)
-            if (out_status[r] == UMGAP_READ_UNKNOWN_TAXON || out_status[r] == UMGAP_READ_PANIC || out_status[r] == 4u) { bad = r; break; }
+            if (J.out_status[r] == UMGAP_READ_UNKNOWN_TAXON || J.out_status[r] == UMGAP_READ_PANIC || J.out_status[r] == 4u) { bad = r; break; }
         parallel_for(used, [&](size_t pi) {
             AggPart& P = parts[pi];
             P.out.reserve(P.hdr_off.size() * 32);
@@ -825,24 +1054,64 @@ int cmd_taxa2agg(const std::vector<std::string>& args) {
                 P.out.push_back('>');
                 P.out.append(d + P.hdr_off[r], P.hdr_len[r]);
                 P.out.push_back('\n');
-                append_uint(P.out, out_taxon[P.rec_base + r]);
+                append_uint(P.out, J.out_taxon[P.rec_base + r]);
                 P.out.push_back('\n');
             }
         });
+        t_format += now() - t0; t0 = now();
         for (size_t i = 0; i < used; i++) fwrite(parts[i].out.data(), 1, parts[i].out.size(), stdout);
+        t_write += now() - t0;
         if (bad < n_rec) {
             fflush(stdout);
-            if (out_status[bad] == UMGAP_READ_UNKNOWN_TAXON) {
-                uint64_t t = out_taxon[bad];
+            if (J.out_status[bad] == UMGAP_READ_UNKNOWN_TAXON) {
+                uint64_t t = J.out_taxon[bad];
                 if (t == 0xFFFFFFFEu)
                     for (size_t i = 0; i < used; i++) if (!parts[i].big.empty()) { t = parts[i].big[0]; break; }
                 throw CliError("Unknown Taxon ID: " + std::to_string(t));
             }
-            if (out_status[bad] == 4u) throw CliError("a read holds more than 1024 distinct taxa: not supported by the device aggregator");
+            if (J.out_status[bad] == 4u) throw CliError("a read holds more than 1024 distinct taxa: not supported by the device aggregator");
             throw CliPanic("index out of bounds");
         }
         if (used < np || parts[used - 1].error) { fflush(stdout); throw *parts[used - 1].error; }
+    };
+    Job jobs[2];
+    int cur = 0;
+    std::thread helper;
+    std::exception_ptr helper_err;
+    auto join_helper = [&]() {
+        if (helper.joinable()) helper.join();
+        if (helper_err) { std::exception_ptr e = helper_err; helper_err = nullptr; std::rethrow_exception(e); }
+    };
+    try {
+        const char* d;
+        size_t len;
+        for (;;) {
+            double t0 = now();
+            if (!blocks.next(d, len)) break;
+            t_read += now() - t0; t0 = now();
+            if (blocks.first_line_error()) { join_helper(); throw CliError("Expected > at beginning of fasta header."); }
+            Job& J = jobs[cur];
+            std::vector<size_t> cuts = split_records(d, len, T);
+            J.np = cuts.size() - 1;
+            J.d = d;
+            if (J.parts.size() < J.np) J.parts.resize(J.np);
+            parallel_for(J.np, [&](size_t pi) { parse_part(d, cuts[pi], cuts[pi + 1], J.parts[pi]); });
+            t_parse += now() - t0; t0 = now();
+            join_helper();                         // stage B of the previous block is done (and has thrown here if it failed)
+            t_wait += now() - t0;
+            bool failing = false;
+            for (size_t i = 0; i < J.np; i++) failing = failing || J.parts[i].error.has_value();
+            if (failing) { stage_b(J); continue; }  // the stream ends in this block
+            helper = std::thread([&stage_b, &helper_err, &J]() { try { stage_b(J); } catch (...) { helper_err = std::current_exception(); } });
+            cur ^= 1;
+        }
+        join_helper();
+    } catch (...) {
+        if (helper.joinable()) helper.join();
+        throw;
     }
+    if (timing) fprintf(stderr, "taxa2agg: stage A: read %.3f, parse %.3f, wait for stage B %.3f | stage B: gather %.3f, aggregate %.3f, format %.3f, write %.3f\n",
+                        t_read, t_parse, t_wait, t_gather, t_dev, t_format, t_write);
     fflush(stdout);
     umgap_taxonomy_free(tx);
     return 0;
@@ -906,14 +1175,19 @@ int cmd_seedextend(const std::vector<std::string>& args) {
     const unsigned T = worker_count();
     const char* d;
     size_t len;
+    blocks.map_regular_file();
+    std::vector<SePart> parts;             // (kept from block to block: the output strings keep their memory)
     while (blocks.next(d, len)) {
         if (blocks.first_line_error()) throw CliError("Expected > at beginning of fasta header.");
         std::vector<size_t> cuts = split_records(d, len, T);
         const size_t np = cuts.size() - 1;
-        std::vector<SePart> parts(np);
+        if (parts.size() < np) parts.resize(np);
         parallel_for(np, [&](size_t pi) {
             SePart& P = parts[pi];
-            P.out.reserve((cuts[pi + 1] - cuts[pi]) / 2 + 64);
+            P.out.clear();
+            P.error.reset();
+            P.panic = false;
+            P.out.reserve((cuts[pi + 1] - cuts[pi]) + 64);
             LineCursor lc{d + cuts[pi], d + cuts[pi + 1]};
             std::string_view line, header;
             std::vector<uint64_t> t;
@@ -968,7 +1242,22 @@ int cmd_seedextend(const std::vector<std::string>& args) {
                 plain = true;
             };
             try {
-                while (lc.next(line) && !P.panic) {
+                for (;;) {
+                    // the common line -- a canonical decimal number directly followed by '\n' -- is read where it stands: the digits
+                    // give the value and the line's end in one pass (a memchr per 8-byte line was most of this command's time)
+                    while (lc.p < lc.end && !P.panic) {
+                        const char* q = lc.p;
+                        uint64_t v = 0;
+                        unsigned c;
+                        while (q < lc.end && (c = (unsigned)(unsigned char)*q - '0') <= 9) { v = v * 10 + c; q++; }
+                        const size_t nd = (size_t)(q - lc.p);
+                        if (nd < 1 || nd > 18 || q >= lc.end || *q != '\n' || (nd > 1 && *lc.p == '0')) break;   // anything else: the general line below
+                        t.push_back(v);
+                        if (at.empty()) at.push_back(lc.p);
+                        at.push_back(q + 1);
+                        lc.p = q + 1;
+                    }
+                    if (!lc.next(line) || P.panic) break;
                     if (!line_utf8_ok(line)) { flush_record(); P.error = CliError("stream did not contain valid UTF-8"); return; }
                     if (!line.empty() && line[0] == '>') { flush_record(); header = line.substr(1); open = true; continue; }
                     t.push_back(parse_usize(line));
@@ -1008,37 +1297,51 @@ int cmd_uniq(const std::vector<std::string>& args) {
         const char* d;
         size_t len;
         std::string out, cur_hdr;          // the record being merged (survives block boundaries)
-        std::string cur_body;
-        uint64_t cur_items = 0;
-        bool have_cur = false;
-        auto write_cur = [&]() {
-            if (!have_cur) return;
-            out.push_back('>'); out.append(cur_hdr); out.push_back('\n');
-            // items.join("\n") is empty iff there is no item or a single empty one (src/io/fasta.rs:168,176-178)
-            if (!(cur_items == 0 || (cur_items == 1 && cur_body.size() == 1))) out.append(cur_body);
-            have_cur = false;
+        // The body of the open group goes straight to `out` behind its header line -- except while it is still at most ONE item of
+        // no bytes, which the writer prints as nothing at all: items.join("\n") is empty iff there is no item or a single empty
+        // one (src/io/fasta.rs:168,176-178); that single "\n" waits in `cur_small` until a second item decides.
+        uint64_t cur_items = 0, cur_bytes = 0;
+        size_t cur_mark = 0;               // where the open group starts in `out`: what lies behind is not final (a read error drops it)
+        bool have_cur = false, cur_small = false;
+        auto write_cur = [&]() { have_cur = false; cur_small = false; };     // (a group that ends while `cur_small` is pending prints no body)
+        auto add_body = [&](const char* b, size_t n, uint64_t items) {
+            if (cur_items + items <= 1 && cur_bytes + n <= 1) { cur_small = cur_small || n == 1; }
+            else { if (cur_small) { out.push_back('\n'); cur_small = false; } out.append(b, n); }
+            cur_items += items;
+            cur_bytes += n;
         };
+        blocks.map_regular_file();
+        std::vector<UPart> parts;
         while (blocks.next(d, len)) {
             if (blocks.first_line_error()) throw CliError("Expected > at beginning of fasta header.");
             std::vector<size_t> cuts = split_records(d, len, T);
             const size_t np = cuts.size() - 1;
-            std::vector<UPart> parts(np);
+            if (parts.size() < np) parts.resize(np);
             parallel_for(np, [&](size_t pi) {
                 UPart& P = parts[pi];
-                LineCursor lc{d + cuts[pi], d + cuts[pi + 1]};
-                std::string_view line;
-                while (lc.next(line)) {
-                    if (!line_utf8_ok(line)) { P.bad_utf8 = true; return; }
-                    if (!line.empty() && line[0] == '>') {
-                        P.recs.push_back(Rec{(size_t)(line.data() - d) + 1, (uint32_t)line.size() - 1, (size_t)(lc.p - d), 0, 0, true});
-                        continue;
+                P.recs.clear();
+                P.bad_utf8 = false;
+                std::vector<Rec> recs = std::move(P.recs);   // (filled on this thread's stack: see LookupPart)
+                recs.clear();
+                const size_t range_end = cuts[pi + 1];
+                bool stop = false;
+                scan_lines(d, cuts[pi], range_end, stop, [&](size_t ls, size_t e, bool high) {
+                    size_t le = e;
+                    const bool cr = le > ls && d[le - 1] == '\r';
+                    if (cr) le--;
+                    if (high && !valid_utf8(std::string_view(d + ls, le - ls))) { P.bad_utf8 = true; stop = true; return; }
+                    const size_t next = e < range_end ? e + 1 : range_end;      // start of the next line
+                    if (le > ls && d[ls] == '>') {
+                        recs.push_back(Rec{ls + 1, (uint32_t)(le - ls - 1), next, 0, 0, true});
+                        return;
                     }
-                    Rec& r = P.recs.back();
+                    Rec& r = recs.back();
                     r.n_items++;
-                    r.body_len = (size_t)(lc.p - d) - r.body_off;
+                    r.body_len = next - r.body_off;
                     // verbatim copy needs "item\n" exactly: no stripped '\r', newline-terminated
-                    if ((line.data() + line.size() < d + len && line.data()[line.size()] == '\r') || lc.p[-1] != '\n') r.verbatim = false;
-                }
+                    if (cr || e >= range_end) r.verbatim = false;
+                });
+                P.recs = std::move(recs);
             });
             bool stop = false;
             for (size_t pi = 0; pi < np && !stop; pi++) {
@@ -1047,26 +1350,31 @@ int cmd_uniq(const std::vector<std::string>& args) {
                     if (delim) { size_t at = h.find(*delim); if (at != std::string_view::npos) h = h.substr(0, at); }
                     if (!(have_cur && h == std::string_view(cur_hdr))) {          // src/commands/uniq.rs:70-77
                         write_cur();
-                        cur_hdr.assign(h); cur_body.clear(); cur_items = 0; have_cur = true;
+                        cur_hdr.assign(h); cur_items = 0; cur_bytes = 0; have_cur = true;
+                        cur_mark = out.size();
+                        out.push_back('>'); out.append(cur_hdr); out.push_back('\n');
                     }
-                    cur_items += r.n_items;
-                    if (r.verbatim) cur_body.append(d + r.body_off, r.body_len);
+                    if (r.verbatim) add_body(d + r.body_off, r.body_len, r.n_items);
                     else {
                         LineCursor lc{d + r.body_off, d + r.body_off + r.body_len};
                         std::string_view line;
-                        while (lc.next(line)) { cur_body.append(line); cur_body.push_back('\n'); }
+                        std::string one;
+                        while (lc.next(line)) { one.assign(line); one.push_back('\n'); add_body(one.data(), one.size(), 1); }
                     }
                 }
                 if (parts[pi].bad_utf8) stop = true;
             }
-            if (out.size() > (1u << 22) || stop) { fwrite(out.data(), 1, out.size(), stdout); out.clear(); }
+            {   // the completed groups leave; the open one stays behind (the reference still holds it in `last`: a read error drops it)
+                const size_t done = have_cur ? cur_mark : out.size();
+                if (done > (1u << 22) || stop) { fwrite(out.data(), 1, done, stdout); out.erase(0, done); cur_mark = 0; }
+            }
             if (stop) {
                 // the record read so far is NOT written by the reference (it is still held in `last`): only completed ones are
                 fflush(stdout);
                 throw CliError("stream did not contain valid UTF-8");
             }
         }
-        write_cur();
+        write_cur();                       // EOF completes the open group
         fwrite(out.data(), 1, out.size(), stdout);
         fflush(stdout);
         return 0;
@@ -1104,35 +1412,6 @@ int cmd_uniq(const std::vector<std::string>& args) {
 // (FusePart and its tokenizer, parse_fuse_part: fuse_parse.hpp)
 
 // one block's worth of reads, self-contained (nothing points into the block buffer)
-// Grow-only array in page-locked host memory (umgap_host_alloc): what umgap_classify_records copies from / to at full
-// PCIe rate and without blocking the calling thread.  resize() keeps no old contents.
-template <class T>
-struct PinnedVec {
-    T* p = nullptr;
-    size_t n = 0, cap = 0;
-    PinnedVec() = default;
-    PinnedVec(const PinnedVec&) = delete;
-    PinnedVec& operator=(const PinnedVec&) = delete;
-    ~PinnedVec() { umgap_host_free(p); }
-    void resize(size_t m) {
-        if (m > cap) {
-            umgap_host_free(p);
-            p = nullptr;
-            cap = 0;
-            void* q = nullptr;
-            const size_t want = m + m / 4 + 1024;
-            if (umgap_host_alloc(want * sizeof(T), &q) != UMGAP_OK) throw CliError(umgap_last_error());
-            p = (T*)q;
-            cap = want;
-        }
-        n = m;
-    }
-    T* data() { return p; }
-    T* begin() { return p; }
-    size_t size() const { return n; }
-    T& operator[](size_t i) { return p[i]; }
-};
-
 struct FuseJob {
     PinnedVec<uint8_t> bytes;
     PinnedVec<uint64_t> frag_off, read_frags;

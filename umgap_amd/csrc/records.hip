@@ -28,6 +28,7 @@
 #include <vector>
 
 namespace umgap {
+int ensure_stage(umgap_index* ix);   // index.hip
 int walk_map_positions(const umgap_index* ix, uint32_t* d_vals, size_t n, uint32_t miss, hipStream_t s);   // index_walk.hip
 int mark_seedextend_panics(const uint32_t* d_kept, const uint64_t* d_read_frags, size_t n_reads, uint32_t* d_out_taxon, uint32_t* d_out_status,
                            hipStream_t stream);
@@ -67,15 +68,16 @@ __global__ __launch_bounds__(256) void k_frag_prepare(const uint64_t* __restrict
 // src/commands/prot2kmer2lca.rs:172-179 + the packing convention of include/umgap_hip.h) for every position that starts
 // a window, 0 elsewhere.  A wave takes 128 consecutive positions per step: their 136 bytes are staged in the wave's LDS
 // strip, two probe batches of 64 go out back to back (8 sectors in flight per quad), results land coalesced.
+// n_avail >= n_bytes: bytes that may be read (a chunk cut inside a fragment brings the 8 bytes behind its last position along).
 __global__ __launch_bounds__(256) void k_lookup_bytes9(TableView T, const uint8_t* __restrict__ bytes, const uint32_t* __restrict__ tails,
-                                                       uint32_t n_bytes, uint32_t* __restrict__ hits, uint32_t miss) {
+                                                       uint32_t n_bytes, uint32_t n_avail, uint32_t* __restrict__ hits, uint32_t miss) {
     __shared__ uint8_t lds[4][144];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
     uint8_t* wb = lds[wv];
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
     for (uint32_t p0 = wave * 128; p0 < n_bytes; p0 += nwaves * 128) {
         // stage bytes [p0, p0 + 136)
-        for (uint32_t i = lane; i < 136; i += 64) wb[i] = p0 + i < n_bytes ? bytes[p0 + i] : (uint8_t)0;
+        for (uint32_t i = lane; i < 136; i += 64) wb[i] = p0 + i < n_avail ? bytes[p0 + i] : (uint8_t)0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         const uint32_t tw0 = tails[(p0 >> 5) + (lane >> 5)], tw1 = p0 + 64 < n_bytes ? tails[((p0 + 64) >> 5) + (lane >> 5)] : 0xFFFFFFFFu;
@@ -185,6 +187,21 @@ __global__ __launch_bounds__(256) void k_records_any_unsupported(const uint32_t*
     if (any) atomicExch(flags + 1, 1u);
 }
 
+// umgap_index_lookup_records: the fragments [off[f], off[f + 1]) that touch the byte range [c0, c1) of the call; the last min(len, 8)
+// positions of each start no window: marked in `tails` (bit p - c0)
+__global__ __launch_bounds__(256) void k_mark_tails(const uint64_t* __restrict__ off, size_t n_frag, uint64_t c0, uint64_t c1, uint32_t* __restrict__ tails) {
+    size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; f < n_frag; f += step) {
+        const uint64_t a = off[f], b = off[f + 1];
+        if (b <= a) continue;
+        uint64_t t0 = b - a > 8 ? b - 8 : a, t1 = b;
+        if (t0 < c0) t0 = c0;
+        if (t1 > c1) t1 = c1;
+        for (uint64_t p = t0; p < t1; p++) atomicOr(&tails[(p - c0) >> 5], 1u << ((p - c0) & 31));
+    }
+}
+
 // the general route on a table bound to the taxonomy: the probe returned interval codes (bound.hpp; 0 = miss), the kernels behind it
 // want taxon ids
 __global__ __launch_bounds__(256) void k_codes_to_ids(uint32_t* __restrict__ hits, size_t n, const uint32_t* __restrict__ id_of_pre) {
@@ -218,6 +235,107 @@ extern "C" int umgap_host_alloc(size_t bytes, void** out) {
 }
 extern "C" void umgap_host_free(void* p) {
     if (p) (void)hipHostFree(p);
+}
+
+// The windows of protein records, looked up where the bytes are: what `prot2kmer2lca` does per record (src/commands/prot2kmer2lca.rs:
+// 172-179) for a whole block of records in one call.  The host hands over the residues (1.2 bytes per window instead of an 8-byte
+// packed key per window, and no per-window work on the host at all); out_hits[b - frag_offsets[0]] = value of the 9-mer that starts
+// at byte b, for every b that starts a window of its fragment (b + 9 <= end of the fragment); miss_value where the window is not
+// [A-Z]{9} or not a key; positions that start no window hold miss_value too.  Chunks of ~3.5 MB of residues over the upload lane
+// and the probe lane of the handle (three staging slots); a chunk may end inside a fragment (it brings 8 bytes of lookahead along).
+extern "C" int umgap_index_lookup_records(umgap_index* ix, const uint8_t* bytes, const uint64_t* frag_offsets, size_t n_fragments, uint32_t miss_value,
+                                          uint32_t* out_hits) {
+    if (!ix || (n_fragments && (!frag_offsets || !out_hits))) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup_records: null argument");
+    if (ix->bound_to) return fail(UMGAP_ERR_INVALID, "the index is bound to a taxonomy (umgap_index_bind_taxonomy): its values are interval codes, not taxon ids; unbind it first");
+    if (ix->kind != 9 && ix->kind != 10) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup_records: not a 9-mer index");
+    if (!n_fragments) return UMGAP_OK;
+    const bool walk = ix->kind == 10;
+    const uint64_t base = frag_offsets[0];
+    for (size_t f = 0; f < n_fragments; f++)
+        if (frag_offsets[f + 1] < frag_offsets[f]) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup_records: frag_offsets must not decrease");
+    const uint64_t total = frag_offsets[n_fragments] - base;
+    if (!total) return UMGAP_OK;
+    if (!bytes) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup_records: null bytes");
+    int rc = use_device(ix->device);
+    if (rc) return rc;
+    rc = ensure_stage(ix);
+    if (rc) return rc;
+    // a staging slot (24 MiB): [hits 14 MiB][bytes 3.5 MiB + lookahead][offsets 2 MiB][tails 0.5 MiB]
+    constexpr int NS = 3;
+    constexpr size_t CB = 3584u << 10, CF = (256u << 10) - 1, O_BYTES = CB * 4, O_OFF = O_BYTES + CB + 4096, O_TAILS = O_OFF + (CF + 1) * 8, SLOT = O_TAILS + CB / 8 + 4096;
+    static_assert(SLOT <= (size_t)(2u << 20) * 12, "a chunk must fit a staging slot");
+    auto pinned = [](const void* p) {
+        hipPointerAttribute_t a{};
+        if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return a.type == hipMemoryTypeHost;
+    };
+    const bool in_pinned = pinned(bytes + base) && pinned(bytes + base + total - 1) && pinned(frag_offsets) && pinned(frag_offsets + n_fragments);
+    const bool out_pinned = pinned(out_hits) && pinned(out_hits + total - 1);
+    struct Events {
+        hipEvent_t uploaded[NS] = {}, done[NS] = {};
+        ~Events() { for (hipEvent_t x : uploaded) if (x) (void)hipEventDestroy(x); for (hipEvent_t x : done) if (x) (void)hipEventDestroy(x); }
+    } ev;
+    for (int i = 0; i < NS; i++) {
+        UMGAP_HIP(hipEventCreateWithFlags(&ev.uploaded[i], hipEventDisableTiming));
+        UMGAP_HIP(hipEventCreateWithFlags(&ev.done[i], hipEventDisableTiming));
+    }
+    const hipStream_t up = ix->up_stream, run = ix->run_stream;
+    size_t pending_at[NS] = {}, pending_len[NS] = {};
+    auto drain = [&](int k) -> int {
+        if (!pending_len[k]) return UMGAP_OK;
+        UMGAP_HIP(hipEventSynchronize(ev.done[k]));
+        if (!out_pinned) par_memcpy(out_hits + pending_at[k], ix->h_stage[k], pending_len[k] * 4);
+        pending_len[k] = 0;
+        return UMGAP_OK;
+    };
+    const TableView T = ix->view;
+    size_t f_lo = 0;          // first fragment that ends behind the chunk's first byte
+    size_t c = 0;
+    for (uint64_t c0 = 0; c0 < total; c++) {
+        const int slot = (int)(c % NS);
+        while (f_lo < n_fragments && frag_offsets[f_lo + 1] - base <= c0) f_lo++;
+        uint64_t c1 = std::min<uint64_t>(total, c0 + CB);
+        // fragments that touch [c0, c1): [f_lo, f_hi)
+        size_t f_hi = (size_t)(std::lower_bound(frag_offsets + f_lo, frag_offsets + n_fragments, base + c1) - frag_offsets);
+        if (f_hi - f_lo > CF) { f_hi = f_lo + CF; c1 = frag_offsets[f_hi] - base; }      // many short fragments: the chunk ends with fragment f_hi - 1
+        if (c1 <= c0) { c0 = c1 = frag_offsets[f_hi] - base; continue; }                   // (CF empty fragments in a row)
+        const uint64_t nb = c1 - c0, navail = std::min<uint64_t>(total - c0, nb + 8);
+        const size_t nf = f_hi - f_lo;
+        rc = drain(slot);
+        if (rc) break;
+        char* D = (char*)ix->d_stage[slot];
+        uint32_t* d_hits = (uint32_t*)D;
+        uint8_t* d_bytes = (uint8_t*)(D + O_BYTES);
+        uint64_t* d_off = (uint64_t*)(D + O_OFF);
+        uint32_t* d_tails = (uint32_t*)(D + O_TAILS);
+        const uint8_t* src_b = bytes + base + c0;
+        const uint64_t* src_o = frag_offsets + f_lo;
+        if (!in_pinned) {          // the pinned slot holds [bytes | offsets] on the way up (the answers of its last tenant have been drained)
+            char* H = (char*)ix->h_stage[slot];
+            memcpy(H, src_b, navail);
+            memcpy(H + CB + 4096, src_o, (nf + 1) * 8);
+            src_b = (const uint8_t*)H;
+            src_o = (const uint64_t*)(H + CB + 4096);
+        }
+        UMGAP_HIP_BREAK(hipMemcpyAsync(d_bytes, src_b, navail, hipMemcpyHostToDevice, up));
+        UMGAP_HIP_BREAK(hipMemcpyAsync(d_off, src_o, (nf + 1) * 8, hipMemcpyHostToDevice, up));
+        UMGAP_HIP_BREAK(hipEventRecord(ev.uploaded[slot], up));
+        UMGAP_HIP_BREAK(hipStreamWaitEvent(run, ev.uploaded[slot], 0));
+        UMGAP_HIP_BREAK(hipMemsetAsync(d_tails, 0, (nb / 32 + 8) * 4, run));
+        hipLaunchKernelGGL(k_mark_tails, dim3((unsigned)std::min<size_t>((nf + 255) / 256, 1024)), dim3(256), 0, run, (const uint64_t*)d_off, nf, base + c0, base + c1, d_tails);
+        hipLaunchKernelGGL(k_lookup_bytes9, dim3((unsigned)std::min<uint64_t>((nb + 511) / 512, 2048)), dim3(256), 0, run, T, (const uint8_t*)d_bytes, (const uint32_t*)d_tails,
+                           (uint32_t)nb, (uint32_t)navail, d_hits, walk ? UMGAP_NONE : miss_value);
+        if (walk && (rc = walk_map_positions(ix, d_hits, (size_t)nb, miss_value, run))) break;
+        UMGAP_HIP_BREAK(hipGetLastError());
+        UMGAP_HIP_BREAK(hipMemcpyAsync(out_pinned ? (void*)(out_hits + c0) : ix->h_stage[slot], d_hits, nb * 4, hipMemcpyDeviceToHost, run));
+        UMGAP_HIP_BREAK(hipEventRecord(ev.done[slot], run));
+        pending_at[slot] = c0;
+        pending_len[slot] = nb;
+        c0 = c1;
+    }
+    for (int i = 0; i < NS; i++) { const int r2 = drain(i); if (!rc) rc = r2; }
+    if (rc) { (void)hipStreamSynchronize(up); (void)hipStreamSynchronize(run); }
+    return rc;
 }
 
 static thread_local int g_last_route = 0;
@@ -416,7 +534,7 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
         if (nf) hipLaunchKernelGGL(k_frag_prepare, dim3(gf), dim3(256), 0, s, L.off, (size_t)nf, base + b0, (uint32_t)nb, L.fstart, L.flen, L.tails, L.bad);
         if (nb) {
             const unsigned gb = (unsigned)std::min<uint64_t>((nb + 511) / 512, 2048);
-            hipLaunchKernelGGL(k_lookup_bytes9, dim3(gb), dim3(256), 0, s, T, L.bytes, L.tails, (uint32_t)nb, L.hits, walk ? UMGAP_NONE : 0u);
+            hipLaunchKernelGGL(k_lookup_bytes9, dim3(gb), dim3(256), 0, s, T, L.bytes, L.tails, (uint32_t)nb, (uint32_t)nb, L.hits, walk ? UMGAP_NONE : 0u);
             if (walk && (rc = walk_map_positions(ix, L.hits, (size_t)nb, 0u, s))) break;
             if (bound) hipLaunchKernelGGL(k_codes_to_ids, dim3(gb), dim3(256), 0, s, L.hits, (size_t)nb, (const uint32_t*)tx->d_id_of_pre);
         }
