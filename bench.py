@@ -646,7 +646,7 @@ def main():
         torch.cuda.empty_cache()
         try:
             import end_to_end
-            out["end_to_end"], out["cpu_baseline_end_to_end"] = end_to_end.run()
+            out["end_to_end"], out["cpu_baseline_end_to_end"] = end_to_end.run(8_000_000, 200_000)
         except Exception as e:  # noqa: BLE001
             out["end_to_end"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:

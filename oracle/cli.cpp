@@ -3,7 +3,7 @@
 // umgap_oracle.hpp).  Minimal flag parsing: tests always pass flags in separated form.
 //
 //   pept2lca      [-o] <index.tsv>            src/commands/pept2lca.rs
-//   prot2kmer2lca [-o] [-k K] <index.tsv>     src/commands/prot2kmer2lca.rs
+//   prot2kmer2lca [-o] [-k K] [-j THREADS] <index.tsv>     src/commands/prot2kmer2lca.rs (-j: the lookup on N threads, as rayon does)
 //   prot2tryp2lca [-o] [-l N] [-L N] [-k SET] [-d SET] <index.tsv>   src/commands/prot2tryp2lca.rs
 //   taxa2agg      [-s] [-r] [-m M] [-a A] [-f F] [-l L] <taxons.tsv>   src/commands/taxa2agg.rs
 //   seedextend    [-s N] [-g N] [-r taxons.tsv] [-p N]                 src/commands/seedextend.rs
@@ -53,9 +53,11 @@ int main(int argc, char** argv) {
             if (auto v = opt("-c")) c = parse_usize(*v);
             size_t k = 9;
             if (auto v = opt("-k")) k = parse_usize(*v);
+            unsigned threads = 1;      // -j N: chunks looked up on N threads (the reference's rayon par_bridge); not a reference flag
+            if (auto v = opt("-j")) threads = (unsigned)parse_usize(*v);
             if (a.size() != 2) throw Error(ErrKind::InvalidInvocation, "usage");
             SortedIndex ix = load_index(a[1]);
-            prot2kmer2lca(std::cin, std::cout, ix, k, o, c);
+            prot2kmer2lca_threads(std::cin, std::cout, ix, k, o, c, threads);
         } else if (cmd == "prot2tryp2lca") {
             bool o = flag("-o");
             flag("-m");

@@ -22,6 +22,8 @@
 // ============================================================================
 #pragma once
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cstdint>
 #include <cstring>
 #include <deque>
@@ -1052,6 +1054,61 @@ inline void prot2kmer2lca(std::istream& in, std::ostream& out, const Index& inde
             }
         }
         out << chunk_output;
+    }
+}
+
+// The same loop with the chunks looked up on `threads` threads, as the reference does with rayon's par_bridge
+// (src/commands/prot2kmer2lca.rs:163-192).  The reference prints a chunk when it is done (completion order); this restatement
+// keeps INPUT order (= the reference under RAYON_NUM_THREADS=1, the parity target), so its bytes are those of the loop above.
+// Used by bench.py's cpu_baseline_end_to_end so that the CPU twin's lookup stage gets every core the reference's would.
+inline void prot2kmer2lca_threads(std::istream& in, std::ostream& out, const Index& index, size_t k, bool one_on_one, size_t chunk_size,
+                                  unsigned threads) {
+    if (threads <= 1) { prot2kmer2lca(in, out, index, k, one_on_one, chunk_size); return; }
+    std::optional<uint64_t> dflt;
+    if (one_on_one) dflt = 0;
+    FastaReader reader(in, true);
+    const size_t batch = (size_t)threads * 8;
+    std::vector<std::vector<Record>> chunks(batch);
+    std::vector<std::string> outs(batch);
+    std::vector<int> state(batch);          // 0 ok, 1 panic
+    bool more = true;
+    while (more) {
+        size_t n = 0;
+        std::exception_ptr read_error;
+        try {
+            while (n < batch && (more = next_chunk(reader, chunk_size, chunks[n]))) n++;
+        } catch (...) { read_error = std::current_exception(); more = false; }   // an Err ends the iteration: the open chunk is dropped (src/io/fasta.rs:118-137)
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (size_t c; (c = next.fetch_add(1)) < n;) {
+                std::string& o = outs[c];
+                o.clear();
+                state[c] = 0;
+                try {
+                    for (auto& read : chunks[c]) {
+                        if (read.sequence.empty() || read.sequence[0].size() < k) continue;
+                        const std::string& prot = read.sequence[0];
+                        o += ">" + read.header + "\n";
+                        for (size_t i = 0; i + k <= prot.size(); i++) {
+                            if (((unsigned char)prot[i] & 0xC0) == 0x80 || (i + k < prot.size() && ((unsigned char)prot[i + k] & 0xC0) == 0x80))
+                                throw Panic("byte index is not a char boundary");
+                            std::optional<uint64_t> lca = index.get(prot.substr(i, k));
+                            if (!lca) lca = dflt;
+                            if (lca) o += std::to_string(*lca) + "\n";
+                        }
+                    }
+                } catch (Panic&) { state[c] = 1; }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (unsigned t = 1; t < threads; t++) pool.emplace_back(work);
+        work();
+        for (auto& t : pool) t.join();
+        for (size_t c = 0; c < n; c++) {
+            if (state[c]) throw Panic("byte index is not a char boundary");
+            out << outs[c];
+        }
+        if (read_error) std::rethrow_exception(read_error);
     }
 }
 

@@ -171,3 +171,27 @@ def test_fused_command_tokenizer_against_line_by_line_restatement(tmp_path):
     subprocess.run([cxx, "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-o", exe, os.path.join(root, "tests", "native", "fuse_parse_check.cpp")], check=True)
     p = subprocess.run([exe, "6000", "11"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     assert p.returncode == 0, p.stdout.decode()[-2000:]
+
+
+def test_oracle_lookup_stage_on_threads_prints_the_same_bytes(tmp_path):
+    """The CPU twin of the end-to-end measurement looks its chunks up on several threads (oracle CLI `prot2kmer2lca -j N`, the
+    stand-in for the reference's rayon par_bridge, src/commands/prot2kmer2lca.rs:163-192) and keeps input order: same bytes as the
+    plain loop, errors and panics included."""
+    rng = np.random.default_rng(3)
+    letters = b"ACDEFGHIKLMNPQRSTVWY"
+    idx = tmp_path / "ix.tsv"
+    kmers = sorted({bytes(rng.choice(list(letters), 9).tolist()) for _ in range(300)})
+    idx.write_bytes(b"".join(k + b"\t%d\n" % (i + 2) for i, k in enumerate(kmers)))
+    recs = []
+    for r in range(700):
+        n = int(rng.choice([0, 5, 9, 30, 60]))
+        seq = bytearray(rng.choice(list(letters), n).tolist())
+        if n >= 30:
+            seq[3:12] = kmers[int(rng.integers(0, len(kmers)))]
+        recs.append(b">r%d\n" % r + bytes(seq) + b"\n")
+    good = b"".join(recs)
+    for text in (good, good + b">bad\nACDEFGHIK\xffACD\nAAAAAAAAAAAA\n", good[:9000] + ">x\nACéDEFGHIKLMNP\n".encode() + good[9000:]):
+        a = O.run_cli(["prot2kmer2lca", "-o", "-c", "7", str(idx)], text)
+        b = O.run_cli(["prot2kmer2lca", "-o", "-c", "7", "-j", "4", str(idx)], text)
+        assert a[0] == b[0] and a[1] == b[1], (a[0], b[0], len(a[1]), len(b[1]))
+    assert len(O.run_cli(["prot2kmer2lca", "-o", "-j", "3", str(idx)], good)[1]) > 5000

@@ -5,8 +5,8 @@ sample  <proteins> | nc -NU socket | umgap seedextend -g1 -s3 | umgap uniq -d / 
 text in, text out, four processes, beside
   * the same four stages of the CPU oracle (oracle/_build/umgap_oracle, one thread per stage) on a bounded sample, and
   * the fused `umgap prot2kmer2agg` (one process, same output bytes).
-`nc` is not in the image: a few lines of Python play its part (copy the file into the socket, copy the answer into the
-pipe).  run() is imported by bench.py (extras "end_to_end" / "cpu_baseline_end_to_end"); as a script it prints one JSON line.
+`nc` is not in the image: tools/native/unixcat.c plays its part (stdin into the socket, the answer into the pipe; a Python loop
+when there is no C compiler).  run() is imported by bench.py (extras "end_to_end" / "cpu_baseline_end_to_end"); as a script it prints one JSON line.
     python tools/end_to_end.py [n_pairs_gpu] [n_pairs_cpu]"""
 import json
 import os
@@ -78,10 +78,18 @@ def _socket_pipeline(sock_path, fasta, tsv, out_path, exe=UMGAP):
         p1 = subprocess.Popen([exe, "seedextend", "-g", "1", "-s", "3"], stdin=subprocess.PIPE, stdout=p2.stdin)
         p3.stdin.close()
         p2.stdin.close()
-        s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        nc = _unixcat()
+        if nc:                           # `nc -NU socket`: stdin -> socket (sending side shut at EOF), socket -> stdout
+            with open(fasta, "rb") as fi:
+                p0 = subprocess.Popen([nc, sock_path], stdin=fi, stdout=p1.stdin)
+            p1.stdin.close()
+            rcs = [p.wait() for p in (p0, p1, p2, p3)]
+            assert rcs == [0, 0, 0, 0], rcs
+            return time.perf_counter() - t0
+        s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)     # no C compiler: a Python loop plays nc (slower than the chain)
         s.connect(sock_path)
 
-        def feed():                      # nc: stdin -> socket, then shut the sending side (-N)
+        def feed():
             with open(fasta, "rb") as f:
                 while True:
                     b = f.read(1 << 22)
@@ -91,7 +99,7 @@ def _socket_pipeline(sock_path, fasta, tsv, out_path, exe=UMGAP):
             s.shutdown(socket.SHUT_WR)
         th = threading.Thread(target=feed)
         th.start()
-        while True:                      # nc: socket -> stdout
+        while True:
             b = s.recv(1 << 22)
             if not b:
                 break
@@ -104,10 +112,41 @@ def _socket_pipeline(sock_path, fasta, tsv, out_path, exe=UMGAP):
     return time.perf_counter() - t0
 
 
-def _plain_pipeline(exe, index, fasta, tsv, out_path):
+def _unixcat():
+    """tools/native/unixcat (built on first use): the part `nc -NU` plays in the script.  None without a C compiler."""
+    import shutil
+    exe = os.path.join(ROOT, "tools", "native", "unixcat")
+    src = exe + ".c"
+    if os.path.exists(exe) and os.path.getmtime(exe) >= os.path.getmtime(src):
+        return exe
+    cc = shutil.which("cc") or shutil.which("gcc")
+    if not cc:
+        return None
+    try:
+        subprocess.run([cc, "-O2", "-pthread", "-o", exe, src], check=True)
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    return exe
+
+
+def _usable_cores():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def _plain_pipeline(exe, index, fasta, tsv, out_path, lookup_threads=0):
     t0 = time.perf_counter()
-    cmd = "%s prot2kmer2lca -o %s < %s | %s seedextend -g 1 -s 3 | %s uniq -d / | %s taxa2agg -l 2 -a 'lca*' %s > %s" % (
-        exe, index, fasta, exe, exe, exe, tsv, out_path)
+    cmd = "%s prot2kmer2lca -o %s%s < %s | %s seedextend -g 1 -s 3 | %s uniq -d / | %s taxa2agg -l 2 -a 'lca*' %s > %s" % (
+        exe, "-j %d " % lookup_threads if lookup_threads else "", index, fasta, exe, exe, exe, tsv, out_path)
     subprocess.run(cmd, shell=True, check=True)
     return time.perf_counter() - t0
 
@@ -139,13 +178,21 @@ def run(n_pairs_gpu=1_000_000, n_pairs_cpu=40_000, n_frag=250_000, work="/tmp/um
         server.wait()
     # ---- the fused command on the same input ----
     fused = os.path.join(work, "out.fused")
+    env = dict(os.environ, UMGAP_TIMING="1")
     for _ in range(2):
         t0 = time.perf_counter()
         with open(fasta, "rb") as fi, open(fused, "wb") as fo:
-            subprocess.run([UMGAP, "prot2kmer2agg", "-g", "1", "-s", "3", "-d", "/", "-l", "2", "-a", "lca*", idx, tsv], stdin=fi, stdout=fo, check=True)
+            p = subprocess.run([UMGAP, "prot2kmer2agg", "-g", "1", "-s", "3", "-d", "/", "-l", "2", "-a", "lca*", idx, tsv], stdin=fi, stdout=fo, stderr=subprocess.PIPE,
+                               env=env, check=True)
         dt = time.perf_counter() - t0
     res["fused_command"] = {"pairs": n_pairs_gpu, "s": round(dt, 3), "pairs_per_s": round(n_pairs_gpu / dt, 1), "start_up_included": True,
                             "same_output_as_four_process": open(fused, "rb").read() == open(out, "rb").read()}
+    # the command's own clock (UMGAP_TIMING): from "index and taxonomy are resident" to "the last read is written" = its steady state
+    import re
+    m = re.search(r"stream ([0-9.]+) s", p.stderr.decode(errors="replace"))
+    if m and float(m.group(1)) > 0:
+        stream_s = float(m.group(1))
+        res["fused_command"].update({"stream_s": stream_s, "start_up_s": round(dt - stream_s, 3), "steady_state_pairs_per_s": round(n_pairs_gpu / stream_s, 1)})
     # ---- the CPU twin: the oracle's four stages through the same text pipes, bounded sample; its index is the same table
     # as a TSV (what `umgap buildindex` eats).  Start-up (TSV parse) is measured on an empty sample and subtracted. ----
     idx_tsv = os.path.join(work, "ninemer.tsv")
@@ -154,15 +201,16 @@ def run(n_pairs_gpu=1_000_000, n_pairs_cpu=40_000, n_frag=250_000, work="/tmp/um
     sample = _head(fasta, 2 * n_pairs_cpu, os.path.join(work, "sample.fa"))
     empty = os.path.join(work, "empty.fa")
     open(empty, "wb").close()
-    t_empty = _plain_pipeline(ORACLE, idx_tsv, empty, tsv, os.path.join(work, "out.oracle0"))
-    t_cpu = _plain_pipeline(ORACLE, idx_tsv, sample, tsv, os.path.join(work, "out.oracle"))
+    cores = _usable_cores()
+    t_empty = _plain_pipeline(ORACLE, idx_tsv, empty, tsv, os.path.join(work, "out.oracle0"), cores)
+    t_cpu = _plain_pipeline(ORACLE, idx_tsv, sample, tsv, os.path.join(work, "out.oracle"), cores)
     prod_sample = os.path.join(work, "out.sample")
     _plain_pipeline(UMGAP, idx, sample, tsv, prod_sample)
     marginal = max(1e-6, t_cpu - t_empty)
-    cpu = {"value": round(n_pairs_cpu / marginal, 1), "unit": "pairs/s", "cores": 4, "kind": "port",
+    cpu = {"value": round(n_pairs_cpu / marginal, 1), "unit": "pairs/s", "cores": cores, "kind": "port",
            "sample": "%d pairs through the oracle's prot2kmer2lca -o | seedextend -g1 -s3 | uniq -d / | taxa2agg -l2 -a lca* as four piped processes "
-                     "(one thread each; the reference's prot2kmer2lca would use rayon): %.2f s, of which %.2f s start-up (index TSV parse) measured "
-                     "on an empty input and subtracted" % (n_pairs_cpu, t_cpu, t_empty),
+                     "(the lookup stage on %d threads, as the reference's rayon par_bridge; the three filters one thread each, as the reference's): %.2f s, "
+                     "of which %.2f s start-up (index TSV parse) measured on an empty input and subtracted" % (n_pairs_cpu, cores, t_cpu, t_empty),
            "same_output_as_product": open(prod_sample, "rb").read() == open(os.path.join(work, "out.oracle"), "rb").read()}
     res["speedup_four_process_vs_cpu_twin"] = round(res["four_process_socket"]["pairs_per_s"] / cpu["value"], 1)
     return res, cpu
