@@ -195,3 +195,47 @@ def test_oracle_lookup_stage_on_threads_prints_the_same_bytes(tmp_path):
         b = O.run_cli(["prot2kmer2lca", "-o", "-c", "7", "-j", "4", str(idx)], text)
         assert a[0] == b[0] and a[1] == b[1], (a[0], b[0], len(a[1]), len(b[1]))
     assert len(O.run_cli(["prot2kmer2lca", "-o", "-j", "3", str(idx)], good)[1]) > 5000
+
+
+def test_threaded_host_code_under_thread_sanitizer(tmp_path):
+    """The threaded host code of the command -- the reader / writer threads behind stdin / stdout (async_io.hpp, with their buffer
+    pool), the block worker pool (fastpath.hpp) and the two overlapped stages -- built with ThreadSanitizer and driven through
+    `seedextend` and `uniq` (the commands that need no GPU) over files and over pipes, small blocks so that every seam and hand-over
+    is crossed many times.  Any report fails the test (TSAN_OPTIONS exitcode)."""
+    import shutil
+    import subprocess
+    cxx = shutil.which("g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, "umgap_amd", "libumgap_hip.so")
+    if not cxx or not os.path.exists(lib):
+        pytest.skip("needs g++ and the built library")
+    exe = str(tmp_path / "umgap_tsan")
+    p = subprocess.run([cxx, "-fsanitize=thread", "-O1", "-g", "-std=c++17", "-o", exe, os.path.join(root, "umgap_amd", "csrc", "host", "main.cpp"),
+                        "-L" + os.path.dirname(lib), "-lumgap_hip", "-Wl,-rpath," + os.path.dirname(lib), "-lpthread"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if p.returncode != 0:
+        pytest.skip("no ThreadSanitizer runtime for g++ here: " + p.stdout.decode()[-300:])
+    rng = np.random.default_rng(17)
+    recs = []
+    for r in range(30_000):
+        t = int(rng.integers(1, 3_000_000))
+        vals = np.where(rng.random(42) < 0.6, t, np.where(rng.random(42) < 0.5, 0, rng.integers(1, 3_000_000, 42)))
+        recs.append(b">read%d/%d\n" % (r // 2, r % 2 + 1) + b"\n".join(b"%d" % v for v in vals) + b"\n")
+    text = b"".join(recs)
+    env = dict(os.environ, UMGAP_BLOCK_BYTES="200000", UMGAP_THREADS="5", TSAN_OPTIONS="exitcode=66 halt_on_error=0")
+    ref_env = dict(os.environ, UMGAP_BLOCK_BYTES="200000")
+    prod = os.path.join(root, "umgap_amd", "bin", "umgap")
+    want_se = subprocess.run([prod, "seedextend", "-g1", "-s3"], input=text, stdout=subprocess.PIPE, env=ref_env, check=True).stdout
+    want_un = subprocess.run([prod, "uniq", "-d", "/"], input=want_se, stdout=subprocess.PIPE, env=ref_env, check=True).stdout
+    src = tmp_path / "in.fa"
+    src.write_bytes(text)
+    with open(src, "rb") as fi:     # a file on stdin (mapped), a pipe between the two stages, a pipe out
+        p1 = subprocess.Popen([exe, "seedextend", "-g1", "-s3"], stdin=fi, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        p2 = subprocess.Popen([exe, "uniq", "-d", "/"], stdin=p1.stdout, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        p1.stdout.close()
+        out, err2 = p2.communicate()
+        err1 = p1.stderr.read()
+        p1.wait()
+    assert p1.returncode == 0 and p2.returncode == 0, (p1.returncode, p2.returncode, err1[-2000:], err2[-2000:])
+    assert out == want_un
+    p3 = subprocess.run([exe, "seedextend", "-g1", "-s3"], input=text, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)   # a pipe in
+    assert p3.returncode == 0 and p3.stdout == want_se, p3.stderr[-2000:]

@@ -48,6 +48,13 @@ class BlockReader {
         if (env && *env) { long v = atol(env); if (v >= 16) return (size_t)v; }
         return 64u << 20;
     }
+    // a pipe or a socket: a stage starts on a block only when it holds all of it, so the four stages of the script's chain keep
+    // eight blocks of stream between them before the first read comes out -- 32 MB blocks measured best there (4.6 against 4.1 M
+    // pairs/s at 64 MB, 4.4 at 16); a mapped file has no such wait and keeps 64 MB
+    static size_t piped_block(size_t block) {
+        const char* env = getenv("UMGAP_BLOCK_BYTES");
+        return (env && *env) ? block : std::min<size_t>(block, 32u << 20);
+    }
     ~BlockReader() { if (map_) munmap(map_, map_len_); }
     BlockReader(const BlockReader&) = delete;
     BlockReader& operator=(const BlockReader&) = delete;
@@ -97,7 +104,7 @@ class BlockReader {
             mpos_ += take;
             return true;
         }
-        if (buf_.empty()) buf_.resize(block_);   // (not before the first read: a mapped file needs no buffer)
+        if (buf_.empty()) buf_.resize(piped_block(block_));   // (not before the first read: a mapped file needs no buffer)
         if (keep_previous_) {
             if (other_.size() < buf_.size()) other_.resize(buf_.size());
             if (carry_) memcpy(other_.data(), buf_.data() + carry_off_, carry_);

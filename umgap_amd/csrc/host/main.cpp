@@ -997,7 +997,29 @@ int cmd_taxa2agg(const std::vector<std::string>& args) {
                 stop = true;
             }
         };
-        scan_lines(d, begin, end, stop, line);
+        // the common line -- a few decimal digits and '\n' -- is read where it stands, value and end of line in one pass; every other
+        // line (headers, scores, signs, CRs, high bytes, the unterminated last line) goes through line()
+        size_t pos = begin;
+        while (pos < end && !stop) {
+            if (!scored) {
+                while (pos < end) {
+                    size_t q = pos;
+                    uint64_t v = 0;
+                    unsigned c;
+                    while (q < end && (c = (unsigned)(unsigned char)d[q] - '0') <= 9) { v = v * 10 + c; q++; }
+                    if (q == pos || q - pos > 9 || q >= end || d[q] != '\n') break;
+                    taxa.push_back((uint32_t)v);
+                    pos = q + 1;
+                }
+                if (pos >= end) break;
+            }
+            const char* nl = (const char*)memchr(d + pos, '\n', end - pos);
+            const size_t e = nl ? (size_t)(nl - d) : end;
+            bool high = false;
+            for (size_t i = pos; i < e; i++) if ((unsigned char)d[i] >= 0x80) { high = true; break; }
+            line(pos, e, high);
+            pos = nl ? e + 1 : end;
+        }
         if (!stop) close();
         P.hdr_off = std::move(hdr_off); P.hdr_len = std::move(hdr_len); P.taxa = std::move(taxa);
         P.offsets = std::move(offsets); P.big = std::move(big); P.scores = std::move(scores);
