@@ -285,8 +285,12 @@ int umgap_classify9_strategy_dev(umgap_index* ix, umgap_taxonomy* tx, int method
  * `prot2kmer2lca` reads, src/commands/prot2kmer2lca.rs:172-179): read r owns fragments
  * [r*F, (r+1)*F) of the CSR (d_bytes, d_frag_offsets[n_reads*F + 1]); every window of 9 residues of
  * every fragment is looked up (fragments shorter than 9 have none; windows with a byte outside
- * 'A'..'Z' miss).  A read with more than 128 windows or 384 bytes gets status
- * UMGAP_READ_UNSUPPORTED (use umgap_index_lookup_prot9_dev + umgap_aggregate_dev for those). */
+ * 'A'..'Z' miss).  Reads of 1..4 fragments: a read with more than 128 windows or 384 bytes gets status
+ * UMGAP_READ_UNSUPPORTED (use umgap_index_lookup_prot9_dev + umgap_aggregate_dev for those).  Reads of 5..32 fragments -- a pair
+ * translated in all six frames (`translate -a`, scripts/umgap-analyse.sh:277-288: 12 fragments, ~500 windows) -- take the LONG
+ * variant of the kernel: up to 512 windows and 1536 bytes per read, of which at most 128 may still carry a hit when the
+ * aggregate stage is reached (after seedextend; the hits of such a read sit in the one or two frames that code), else
+ * UMGAP_READ_UNSUPPORTED. */
 int umgap_classify_prot9_dev(umgap_index* ix, umgap_taxonomy* tx, int method, float lower_bound, int ranked_only,
                              const uint8_t* d_bytes, const uint64_t* d_frag_offsets, size_t n_reads,
                              uint32_t fragments_per_read, int seedextend, uint32_t min_seed_size,
@@ -328,8 +332,9 @@ int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int method, int 
 int umgap_index_lookup_records(umgap_index* ix, const uint8_t* bytes, const uint64_t* frag_offsets, size_t n_fragments,
                                uint32_t miss_value, uint32_t* out_hits);
 /* Which kernels the last umgap_classify_records of the calling thread ran: 1 = one fused launch per chunk (every read of the call
- * has the same number of fragments, at most 16, and fits the limits of umgap_classify_prot9_strategy_dev: what paired reads look
- * like), 0 = the general kernels (a hit per byte position in HBM between probe, seedextend and aggregate), 2 = the fused ones and
+ * has the same number of fragments, at most 32, and fits the limits of umgap_classify_prot9_strategy_dev -- its short or its LONG
+ * variant, picked per chunk on the device: what paired reads look like, as gene fragments or translated in six frames),
+ * 0 = the general kernels (a hit per byte position in HBM between probe, seedextend and aggregate), 2 = the fused ones and
  * then, a read not fitting, the general ones.  Same answers either way; UMGAP_RECORDS_FUSED=0 in the environment forces 0. */
 int umgap_records_last_route(void);
 

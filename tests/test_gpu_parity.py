@@ -1397,8 +1397,11 @@ def _pack_windows(arr2d):
 
 @pytest.mark.parametrize("mode", [("tree", "lca*"), ("tree", "hybrid"), ("rmq", "hybrid"), ("rmq", "mrtl")])
 @pytest.mark.parametrize("with_seedextend", [False, True])
-def test_fused_classify_prot9_vs_oracle(api, torch_cuda, with_seedextend, mode):
-    """umgap_classify_prot9[_strategy]_dev (fragments in, one taxon per read out) against the oracle's stages, every strategy."""
+@pytest.mark.parametrize("F", [2, 12])
+def test_fused_classify_prot9_vs_oracle(api, torch_cuda, with_seedextend, mode, F):
+    """umgap_classify_prot9[_strategy]_dev (fragments in, one taxon per read out) against the oracle's stages, every strategy.
+    F = 12: a pair translated in all six frames (scripts/umgap-analyse.sh:277-288) -- 504 windows per read, the LONG variant of the
+    kernel; two of the twelve fragments come from the proteome (the frames that code), the others are random residues."""
     torch = torch_cuda
     method, strategy = mode
     import ctypes as C
@@ -1406,14 +1409,21 @@ def test_fused_classify_prot9_vs_oracle(api, torch_cuda, with_seedextend, mode):
     from umgap_amd.api import Index, _dev_ptr, _stream_ptr
     from umgap_amd.synth import SyntheticWorkload
     L = _lib.load()
-    n_tax, n_frag, flen, n_reads, F = 5000, 20_000, 50, 6000, 2
+    n_tax, n_frag, flen, n_reads = 5000, 20_000, 50, 6000 if F == 2 else 3001
     w = SyntheticWorkload(n_tax=n_tax, n_keys=1000, build_index=False)
     prot, poffs, ptaxa = _proteome(torch, w, n_frag, flen)
     h = C.c_void_p()
     _lib.check(L.umgap_index_build_windows9_dev(_dev_ptr(prot), _dev_ptr(poffs), _dev_ptr(ptaxa), n_frag, flen, n_frag * (flen - 8), 0.0, 0, C.byref(h)))
     ix = Index(h.value)
-    reads = torch.empty(n_reads * F * flen, dtype=torch.uint8, device="cuda")
-    _lib.check(L.umgap_synth_prot_reads_dev(_dev_ptr(prot), n_frag, flen, 44, 0, n_reads, F, 30, _dev_ptr(reads), 0, _stream_ptr(None)))
+    reads = torch.empty(n_reads * 2 * flen, dtype=torch.uint8, device="cuda")
+    _lib.check(L.umgap_synth_prot_reads_dev(_dev_ptr(prot), n_frag, flen, 44, 0, n_reads, 2, 30, _dev_ptr(reads), 0, _stream_ptr(None)))
+    if F != 2:     # the two coding fragments become frames 0 and F / 2 of the read; the other frames are random residues
+        letters = torch.tensor(list(b"ACDEFGHIKLMNPQRSTVWY"), dtype=torch.uint8, device="cuda")
+        g = torch.Generator(device="cuda").manual_seed(5)
+        frames = letters[torch.randint(0, 20, (n_reads, F, flen), device="cuda", generator=g)]
+        frames[:, 0, :] = reads.view(n_reads, 2, flen)[:, 0, :]
+        frames[:, F // 2, :] = reads.view(n_reads, 2, flen)[:, 1, :]
+        reads = frames.reshape(-1).contiguous()
     roffs = torch.arange(0, (n_reads * F + 1) * flen, flen, dtype=torch.int64, device="cuda")
     d_t = torch.empty(n_reads, dtype=torch.int32, device="cuda")
     d_s = torch.empty_like(d_t)
@@ -1432,7 +1442,7 @@ def test_fused_classify_prot9_vs_oracle(api, torch_cuda, with_seedextend, mode):
     pos = np.searchsorted(ukeys, rk.ravel())
     pos[pos >= len(ukeys)] = 0
     hits = np.where((ukeys[pos] == rk.ravel()) & rok.ravel(), utax[pos], 0).astype(np.uint32)
-    assert 0.3 < (hits != 0).mean() < 0.95
+    assert (0.3 if F == 2 else 0.05) < (hits != 0).mean() < 0.95
     # the unfused device path for the same bytes gives the same hits
     oo = torch.arange(0, (n_reads * F + 1) * (flen - 8), flen - 8, dtype=torch.int64, device="cuda")
     d_hits = torch.empty(n_reads * F * (flen - 8), dtype=torch.int32, device="cuda")
@@ -2002,7 +2012,8 @@ def test_classify_records_long_ragged_reads(api, torch_cuda):
             assert (s == 0).mean() > 0.5
 
 
-@pytest.mark.parametrize("F,misfit", [(2, None), (1, None), (6, None), (2, "long read"), (2, "ragged"), (3, "many taxa")])
+@pytest.mark.parametrize("F,misfit", [(2, None), (1, None), (6, None), (2, "long read"), (2, "ragged"), (3, "many taxa"), (12, "six frames"), (12, "six frames, all coding"),
+                                      (10, "six frames")])
 def test_classify_records_fused_route(api, torch_cuda, F, misfit):
     """umgap_classify_records takes a call whose reads all have F fragments through ONE fused launch per chunk (k_classify_prot9;
     records.hip: k_records_fit) and falls back to its general kernels for the whole call when a read does not fit the fused kernel
@@ -2036,9 +2047,17 @@ def test_classify_records_fused_route(api, torch_cuda, F, misfit):
             prot = proteins[int(rng.integers(0, len(proteins)))]
             a = int(rng.integers(0, max(1, len(prot) - 9)))
             n = int(rng.choice([0, 5, 9, 20, 33, 50] if F < 4 else [0, 5, 9, 20, 28]))      # (at most 128 windows per read)
-            if misfit == "long read" and r == 77 and k == 0:
-                n, a = 150, 0
-                prot = prot + prot + prot
+            if misfit and misfit.startswith("six frames"):
+                # a pair translated in all six frames (translate -a, scripts/umgap-analyse.sh:277-288): fragments of ~50 residues, ~500
+                # windows per read -- the LONG variant of the fused kernel; the hits sit in the frames that code (here: two of them, the
+                # other fragments are random residues), unless "all coding"
+                n = int(rng.choice([50, 50, 50, 41, 9, 0]))
+                if misfit == "six frames" and k % (F // 2) != 0:
+                    frags.append(rng.choice(letters, n).tobytes())
+                    continue
+            if misfit == "long read" and r == 77 and k == 0:      # longer than the LONG variant of the fused kernel takes (1536 residues)
+                n, a = 1700, 0
+                prot = prot * 50
             if misfit == "many taxa":
                 n = 50                                # 126 windows per read, each 9-mer under a taxon of its own
             f = bytearray(prot[a:a + n])
@@ -2048,7 +2067,7 @@ def test_classify_records_fused_route(api, torch_cuda, F, misfit):
             frags.append(bytes(f))
         read_frags.append(len(frags))
     if misfit == "long read":
-        assert sum(len(f) for f in frags[read_frags[77]:read_frags[78]]) > 128 + 8 * F
+        assert sum(len(f) for f in frags[read_frags[77]:read_frags[78]]) > 1536
     for se, ms in ((False, 2), (True, 3), (True, 1)):
         hits, roffs, panics = [], [0], set()
         for r in range(n_reads):
@@ -2072,8 +2091,10 @@ def test_classify_records_fused_route(api, torch_cuda, F, misfit):
             assert _lib.load().umgap_records_last_route() == 0
             t1, s1 = api.classify_records(ix, tx, frags, read_frags, **kw)
             route = _lib.load().umgap_records_last_route()
-            if misfit is None:
-                assert route == 1
+            if misfit is None or misfit == "six frames":
+                assert route == 1, (misfit, strategy, se, route, np.bincount(s1, minlength=5))
+            elif misfit == "six frames, all coding":
+                assert route == 2 or se     # ~400 hits left in a read where the aggregate stage takes 128 (seedextend may leave fewer)
             elif misfit == "ragged":
                 assert route == 0              # the totals already say so
             elif misfit == "long read" or (strategy != "lca*" and not se):

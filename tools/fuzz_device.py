@@ -212,10 +212,18 @@ def protein_legs(rng, fails):
     hits, roffs, too_long = [], [0], np.zeros(n_reads, bool)
     for r in range(n_reads):
         fr = frags[r * F:(r + 1) * F]
-        too_long[r] = sum(max(0, len(f) - 8) for f in fr) > 128 or sum(len(f) for f in fr) > 384
+        # reads of up to 4 fragments: 128 windows / 384 residues; of more (the LONG variant of the kernel): 512 / 1536, of which at most
+        # 128 may carry a hit (prot_limits.hpp)
+        lim_w, lim_b = (128, 384) if F <= 4 else (512, 1536)
+        too_long[r] = sum(max(0, len(f) - 8) for f in fr) > lim_w or sum(len(f) for f in fr) > lim_b
         if not too_long[r]:
+            mine = []
             for f in fr:
-                hits += [kd.get(f[i:i + 9], 0) for i in range(max(0, len(f) - 8))]
+                mine += [kd.get(f[i:i + 9], 0) for i in range(max(0, len(f) - 8))]
+            if F > 4 and sum(1 for h in mine if h) > 128:
+                too_long[r] = True
+            else:
+                hits += mine
         roffs.append(len(hits))
     hits, roffs = np.array(hits, np.uint32), np.array(roffs, np.uint64)
     if not ((s[too_long] == 4).all() and (t[too_long] == 0).all()):

@@ -379,20 +379,27 @@ struct ProtScratch<true> {
 struct WalkView {
     const uint64_t* E = nullptr;   // taxon | (low 31 key bits | continues << 31) << 32
     uint64_t n = 0;
-    const uint32_t* gate = nullptr;   // non-null: two words; the kernel does nothing when either is set (records.hip: the chunk failed its checks)
+    const uint32_t* gate = nullptr;   // non-null: three words {offsets bad, unfit for the short variant, unfit for the LONG one} (records.hip):
+                                      // the short variant runs when none is set, the LONG one when only word 1 is
 };
 
-template <bool BOUND, bool GENERAL, bool WALK>
+template <bool BOUND, bool GENERAL, bool WALK, bool LONG>
 __global__ __launch_bounds__(256, GENERAL ? 3 : 4) void k_classify_prot9(TableView T, TaxView V, int method, int strategy, float factor,
                                                                       const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ foff, size_t n_reads,
                                                                       uint32_t F, uint32_t do_seed, uint32_t min_seed, uint32_t max_gap, float lower_bound,
                                                                       uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status, WalkView WK) {
     __shared__ uint32_t lds_taxa[4][STRIP];
     __shared__ ProtScratch<GENERAL> lds_scratch[4];
+    // per-read limits of this variant (prot_limits.hpp); either way a group fills the strip and the byte staging area exactly
+    constexpr uint32_t LIM_W = LONG ? PROT_LONG_WINDOWS : PROT_MAX_WINDOWS, LIM_B = LONG ? PROT_LONG_BYTES : PROT_MAX_BYTES, GRP = STRIP / LIM_W;
+    static_assert(GRP * LIM_B == PROT_GROUP * PROT_MAX_BYTES, "both variants use the same staging area");
     __shared__ uint32_t lds_fstart[4][64], lds_fwin[4][64], lds_fbyte[4][64], lds_total[4][PROT_GROUP];
     __shared__ __attribute__((aligned(16))) uint8_t lds_bytes[4][PROT_GROUP * PROT_MAX_BYTES];   // also the LCA scratch of the aggregate stage (u32 arrays)
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
-    if (WK.gate && (WK.gate[0] | WK.gate[1])) return;
+    if (WK.gate) {
+        const uint32_t g0 = WK.gate[0], g1 = WK.gate[1], g2 = WK.gate[2];
+        if (LONG ? (g0 != 0u || g1 == 0u || g2 != 0u) : ((g0 | g1) != 0u)) return;
+    }
     uint32_t* wtaxa = lds_taxa[wv];
     uint32_t* wkeys = lds_scratch[wv].keys;
     uint32_t* wcnt = lds_scratch[wv].cnt;
@@ -404,8 +411,8 @@ __global__ __launch_bounds__(256, GENERAL ? 3 : 4) void k_classify_prot9(TableVi
 #pragma unroll
     for (int i = 0; i < 4; i++) { wkeys[lane + 64 * i] = 0u; wcnt[lane + 64 * i] = 0u; }
     const bool tree_like = method != UMGAP_METHOD_RMQ;
-    // group size: PROT_GROUP reads (<= 128 windows each, so the group fits the strip), at most 64 fragments (one lane each)
-    uint32_t G = PROT_GROUP;
+    // group size: GRP reads (<= LIM_W windows each, so the group fits the strip), at most 64 fragments (one lane each)
+    uint32_t G = GRP;
     if (G * F > 64) G = 64 / F;
     const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
@@ -432,10 +439,10 @@ __global__ __launch_bounds__(256, GENERAL ? 3 : 4) void k_classify_prot9(TableVi
         uint32_t rd_win = 0;
         for (uint32_t t = 0; t < F; t++) {
             uint32_t wsrc = (uint32_t)__shfl((int)my_win, (int)((k_of * F + t) & 63), 64);
-            uint32_t add = wsrc > PROT_MAX_WINDOWS ? PROT_MAX_WINDOWS + 1 : wsrc;
-            rd_win = rd_win + add > PROT_MAX_WINDOWS + 1 ? PROT_MAX_WINDOWS + 1 : rd_win + add;
+            uint32_t add = wsrc > LIM_W ? LIM_W + 1 : wsrc;
+            rd_win = rd_win + add > LIM_W + 1 ? LIM_W + 1 : rd_win + add;
         }
-        const bool unsupported = lane < nfr && (rd_bytes > PROT_MAX_BYTES || rd_win > PROT_MAX_WINDOWS);
+        const bool unsupported = lane < nfr && (rd_bytes > LIM_B || rd_win > LIM_W);
         if (unsupported || lane >= nfr) my_win = 0;
         // dense strip layout: exclusive prefix sum of the window counts
         uint32_t incl = my_win;
@@ -445,11 +452,11 @@ __global__ __launch_bounds__(256, GENERAL ? 3 : 4) void k_classify_prot9(TableVi
         const uint32_t W = (uint32_t)__shfl((int)incl, 63, 64);          // windows of the group (<= STRIP)
         if (GENERAL) {                                                   // read k starts at k * 128 (every lane shuffles)
             const uint32_t rd_start = (uint32_t)__shfl((int)my_start, (int)((k_of * F) & 63), 64);
-            my_start = k_of * PROT_MAX_WINDOWS + (my_start - rd_start);
+            my_start = k_of * LIM_W + (my_start - rd_start);
         }
         wfstart[lane] = lane < nfr ? my_start : 0xFFFFFFFFu;
         wfwin[lane] = my_win;
-        wfbyte[lane] = k_of * PROT_MAX_BYTES + my_rel;
+        wfbyte[lane] = k_of * LIM_B + my_rel;
         if (lane < nfr && lane % F == 0) lds_total[wv][k_of] = unsupported ? 0xFFFFFFFFu : rd_win;
         // ---- stage the reads' bytes (region k * PROT_MAX_BYTES per read; the loads of all reads are in flight together) ----
         for (uint32_t k = 0; k < nr; k++) {
@@ -459,7 +466,7 @@ __global__ __launch_bounds__(256, GENERAL ? 3 : 4) void k_classify_prot9(TableVi
             const bool skip = (bool)__shfl((int)unsupported, (int)src, 64);
             if (skip) continue;   // wave-uniform
             const uint8_t* gp = bytes + (((uint64_t)b_hi << 32) | b_lo);
-            for (uint32_t i = lane; i < nb_lo; i += 64) wbytes[k * PROT_MAX_BYTES + i] = gp[i];
+            for (uint32_t i = lane; i < nb_lo; i += 64) wbytes[k * LIM_B + i] = gp[i];
         }
         wave_lds_sync();
         // ---- probe: every lane walks a run of R consecutive windows of ONE fragment with a rolling key ----
@@ -667,6 +674,32 @@ __global__ __launch_bounds__(256, GENERAL ? 3 : 4) void k_classify_prot9(TableVi
             se_panic = __ballot(pk);
             wave_lds_sync();
         }
+        if constexpr (LONG) {
+            // ---- LONG reads: the hits that are left (taxa2agg drops the zeros anyway, src/commands/taxa2agg.rs:169) are moved to the
+            // front of the read's part of the strip -- for the general aggregate to k * 128, where it expects read k -- and the read goes
+            // on with at most PROT_MAX_WINDOWS of them; a read with more is reported like an over-long one.  Moving towards lower
+            // addresses, read by read and 64 hits at a time, never overwrites a hit that is still to be read. ----
+            for (uint32_t k = 0; k < nr; k++) {
+                const uint32_t total = lds_total[wv][k];
+                if (total == 0xFFFFFFFFu) continue;                    // wave-uniform
+                const uint32_t src = GENERAL ? k * LIM_W : wfstart[k * F], dst = GENERAL ? k * PROT_MAX_WINDOWS : src;
+                uint32_t cnt = 0;
+                for (uint32_t c0 = 0; c0 < total; c0 += 64) {
+                    const uint32_t v = c0 + lane < total ? wtaxa[src + c0 + lane] : 0u;
+                    const uint64_t m = __ballot(v != 0u);
+                    wave_lds_sync();                                    // every lane holds its hit before the slots below it are rewritten
+                    const uint32_t at = cnt + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+                    if (v != 0u && at < PROT_MAX_WINDOWS) wtaxa[dst + at] = v;
+                    cnt += (uint32_t)__builtin_popcountll(m);
+                    wave_lds_sync();
+                }
+                if (GENERAL) {                                          // the general aggregate reads all 128 slots of a read
+                    for (uint32_t i = (cnt < PROT_MAX_WINDOWS ? cnt : PROT_MAX_WINDOWS) + lane; i < PROT_MAX_WINDOWS; i += 64) wtaxa[dst + i] = 0u;
+                }
+                if (lane == 0) lds_total[wv][k] = cnt > PROT_MAX_WINDOWS ? 0xFFFFFFFFu : cnt;
+                wave_lds_sync();
+            }
+        }
         if constexpr (GENERAL) {
             // ---- aggregate, any strategy: reads at stride 128; no large-scratch pass behind this kernel, so a read with more than
             // 64 distinct surviving taxa is reported UMGAP_READ_UNSUPPORTED like the over-long ones ----
@@ -825,25 +858,27 @@ extern "C" int umgap_classify_prot9_strategy_dev(umgap_index* ix, umgap_taxonomy
                                                  int ranked_only, const uint8_t* d_bytes, const uint64_t* d_frag_offsets, size_t n_reads,
                                                  uint32_t fragments_per_read, int seedextend, uint32_t min_seed_size, uint32_t max_gap_size,
                                                  uint32_t* d_out_taxon, uint32_t* d_out_status, void* stream) {
+    // reads of more than PROT_SHORT_FRAGS fragments (a pair in six frames: 12) take the LONG variant: 512 windows / 1536 residues per read
     return umgap::classify_prot9_gated(ix, tx, method, strategy, factor, lower_bound, ranked_only, d_bytes, d_frag_offsets, n_reads, fragments_per_read, seedextend,
-                                       min_seed_size, max_gap_size, d_out_taxon, d_out_status, nullptr, stream);
+                                       min_seed_size, max_gap_size, d_out_taxon, d_out_status, nullptr, fragments_per_read > PROT_SHORT_FRAGS ? 1 : 0, stream);
 }
-// `gate` (device, two words, nullable): the launch does nothing when either word is set by the time it runs (records.hip)
+// `gate` (device, three words, nullable) and `long_variant`: prot_limits.hpp
 int umgap::classify_prot9_gated(umgap_index* ix, umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound,
                                 int ranked_only, const uint8_t* d_bytes, const uint64_t* d_frag_offsets, size_t n_reads,
                                 uint32_t fragments_per_read, int seedextend, uint32_t min_seed_size, uint32_t max_gap_size,
-                                uint32_t* d_out_taxon, uint32_t* d_out_status, const uint32_t* gate, void* stream) {
+                                uint32_t* d_out_taxon, uint32_t* d_out_status, const uint32_t* gate, int long_variant, void* stream) {
     if (!ix || !tx || (n_reads && (!d_bytes || !d_frag_offsets || !d_out_taxon || !d_out_status))) return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: null argument");
     if (ix->bound_to && ix->bound_to != tx) return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: the index is bound to another taxonomy");
     if (ix->kind != 9 && ix->kind != 10) return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: needs a 9-mer index");
-    if (fragments_per_read == 0 || fragments_per_read > PROT_MAX_FRAGS) return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: fragments_per_read must be in 1..16");
+    if (fragments_per_read == 0 || fragments_per_read > (long_variant ? PROT_LONG_FRAGS : PROT_MAX_FRAGS))
+        return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: fragments_per_read must be in 1..32");
     if (method != UMGAP_METHOD_TREE && method != UMGAP_METHOD_RMQ) return fail(UMGAP_ERR_INVALID, "unknown method");
     if (strategy != UMGAP_STRATEGY_LCA_STAR && strategy != UMGAP_STRATEGY_HYBRID && strategy != UMGAP_STRATEGY_MRTL) return fail(UMGAP_ERR_INVALID, "unknown strategy");
     if (ix->device != tx->device) return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: index and taxonomy live on different devices");
     int rc = use_device(ix->device);
     if (rc) return rc;
     if (!n_reads) return UMGAP_OK;
-    uint32_t G = 8;
+    uint32_t G = long_variant ? STRIP / PROT_LONG_WINDOWS : STRIP / PROT_MAX_WINDOWS;
     if (G * fragments_per_read > 64) G = 64 / fragments_per_read;
     size_t g = ((n_reads + G - 1) / G + 3) / 4;
     if (g > 256 * 8) g = 256 * 8;
@@ -853,12 +888,15 @@ int umgap::classify_prot9_gated(umgap_index* ix, umgap_taxonomy* tx, int method,
         hipLaunchKernelGGL(kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, strategy, factor, d_bytes,
                            d_frag_offsets, n_reads, fragments_per_read, seedextend ? 1u : 0u, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status, WK);
     };
-    if (walk) {
-        if (general) { if (bound) launch(k_classify_prot9<true, true, true>); else launch(k_classify_prot9<false, true, true>); }
-        else { if (bound) launch(k_classify_prot9<true, false, true>); else launch(k_classify_prot9<false, false, true>); }
-    }
-    else if (general) { if (bound) launch(k_classify_prot9<true, true, false>); else launch(k_classify_prot9<false, true, false>); }
-    else { if (bound) launch(k_classify_prot9<true, false, false>); else launch(k_classify_prot9<false, false, false>); }
+#define UMGAP_PROT9(LONGV)                                                                                                                      \
+    if (walk) {                                                                                                                                \
+        if (general) { if (bound) launch(k_classify_prot9<true, true, true, LONGV>); else launch(k_classify_prot9<false, true, true, LONGV>); }      \
+        else { if (bound) launch(k_classify_prot9<true, false, true, LONGV>); else launch(k_classify_prot9<false, false, true, LONGV>); }            \
+    }                                                                                                                                          \
+    else if (general) { if (bound) launch(k_classify_prot9<true, true, false, LONGV>); else launch(k_classify_prot9<false, true, false, LONGV>); }   \
+    else { if (bound) launch(k_classify_prot9<true, false, false, LONGV>); else launch(k_classify_prot9<false, false, false, LONGV>); }
+    if (long_variant) { UMGAP_PROT9(true) } else { UMGAP_PROT9(false) }
+#undef UMGAP_PROT9
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
 }

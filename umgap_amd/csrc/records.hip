@@ -148,8 +148,9 @@ __global__ __launch_bounds__(256) void k_read_offsets(const uint64_t* __restrict
 // kernel (prot_limits.hpp), a chunk is ONE launch of k_classify_prot9 (classify.hip: bytes staged in LDS, rolling keys, probe,
 // seedextend and aggregate in one kernel; over a walk-order index the walking variant) instead of the six kernels above with a hit
 // per byte position in HBM between them.  This kernel checks what the host did not look at -- offsets non-decreasing and inside the
-// chunk (flags[0], as k_frag_prepare / k_read_offsets), every read of exactly F fragments within the limits (flags[1]) -- and
-// writes the fragment offsets relative to the chunk's first byte; the fused launch is gated on both flags.
+// chunk (flags[0], as k_frag_prepare / k_read_offsets), every read of exactly F fragments within the limits of the short variant of
+// the fused kernel (flags[1]) and of its LONG variant (flags[2]; prot_limits.hpp) -- and writes the fragment offsets relative to the
+// chunk's first byte.  BOTH variants are then launched, gated on the flags: the device picks the one that fits, no host round trip.
 __global__ __launch_bounds__(256) void k_records_fit(const uint64_t* __restrict__ off, size_t n_frag, const uint64_t* __restrict__ rf, size_t n_reads, uint64_t f0,
                                                      uint32_t F, uint64_t base, uint32_t chunk_bytes, uint64_t* __restrict__ rel, uint32_t* __restrict__ flags) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void k_records_fit(const uint64_t* __restrict_
     for (size_t r = i; r < n_reads; r += step) {
         const uint64_t ga = rf[r], gb = rf[r + 1];
         if (ga < f0 || gb < ga || gb - f0 > n_frag) { atomicExch(flags, 1u); continue; }
-        if (gb - ga != F) { atomicExch(flags + 1, 1u); continue; }
+        if (gb - ga != F) { atomicExch(flags + 1, 1u); atomicExch(flags + 2, 1u); continue; }
         const uint64_t fa = ga - f0;
         uint64_t windows = 0;
         bool sane = true;
@@ -173,18 +174,20 @@ __global__ __launch_bounds__(256) void k_records_fit(const uint64_t* __restrict_
             if (b >= a + 9) windows += b - a - 8;
         }
         const uint64_t a0 = off[fa], b0 = off[fa + F];
-        if (!sane || b0 < a0 || b0 - a0 > PROT_MAX_BYTES || windows > PROT_MAX_WINDOWS) atomicExch(flags + 1, 1u);
+        if (!sane || b0 < a0) { atomicExch(flags + 1, 1u); atomicExch(flags + 2, 1u); continue; }
+        if (b0 - a0 > PROT_MAX_BYTES || windows > PROT_MAX_WINDOWS || F > PROT_MAX_FRAGS) atomicExch(flags + 1, 1u);       // not for the short variant
+        if (b0 - a0 > PROT_LONG_BYTES || windows > PROT_LONG_WINDOWS || F > PROT_LONG_FRAGS) atomicExch(flags + 2, 1u);    // nor for the LONG one
     }
 }
 // a read the fused kernel could not take after all (hybrid / MRTL: more distinct taxa than its scratch holds) sends the call
 // through the general kernels
 __global__ __launch_bounds__(256) void k_records_any_unsupported(const uint32_t* __restrict__ status, size_t n, uint32_t* __restrict__ flags) {
-    if (flags[0] | flags[1]) return;
+    if (flags[0] | flags[2]) return;       // (no fused launch ran: the statuses are stale)
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t step = (size_t)gridDim.x * blockDim.x;
     bool any = false;
     for (; i < n; i += step) any = any || status[i] == UMGAP_READ_UNSUPPORTED;
-    if (any) atomicExch(flags + 1, 1u);
+    if (any) atomicExch(flags + 3, 1u);    // word 3: the fused launch ran and left a read to the general kernels
 }
 
 // umgap_index_lookup_records: the fragments [off[f], off[f + 1]) that touch the byte range [c0, c1) of the call; the last min(len, 8)
@@ -369,7 +372,7 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
     // the fused route (k_records_fit): every read of F fragments, F from the first read and the totals; UMGAP_RECORDS_FUSED=0 keeps
     // the general kernels
     uint32_t F_all = 0;
-    if (n_reads && read_frags[1] >= 1 && read_frags[1] <= PROT_MAX_FRAGS && n_fragments == (uint64_t)read_frags[1] * n_reads) F_all = (uint32_t)read_frags[1];
+    if (n_reads && read_frags[1] >= 1 && read_frags[1] <= PROT_LONG_FRAGS && n_fragments == (uint64_t)read_frags[1] * n_reads) F_all = (uint32_t)read_frags[1];
     if (const char* env = getenv("UMGAP_RECORDS_FUSED")) if (env[0] == '0') F_all = 0;
     bool unfit = false;
     auto run = [&](const bool fused) -> int {
@@ -460,10 +463,10 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
     // both uploading, then both computing -- and the link idled while the kernels ran (rocprofv3 --memory-copy-trace: 2.2 ms per
     // two chunks instead of 1.4)
     const hipStream_t up = tx->stream2, run_on = tx->stream3;
-    if (!tx->h_flags) e = hipHostMalloc((void**)&tx->h_flags, 2 * NS * sizeof(uint32_t), hipHostMallocDefault);
+    if (!tx->h_flags) e = hipHostMalloc((void**)&tx->h_flags, 4 * NS * sizeof(uint32_t), hipHostMallocDefault);
     if (e != hipSuccess) { tx->h_flags = nullptr; return fail(UMGAP_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
-    volatile uint32_t* h_bad = tx->h_flags;    // per slot: {offsets bad, reads unfit for the fused kernel}
-    for (int k = 0; k < 2 * NS; k++) h_bad[k] = 0;
+    volatile uint32_t* h_bad = tx->h_flags;    // per slot: {offsets bad, a read unfit for the short fused kernel, unfit for the LONG one, a read left UNSUPPORTED}
+    for (int k = 0; k < 4 * NS; k++) h_bad[k] = 0;
     struct Events {
         hipEvent_t uploaded[NS] = {}, done[NS] = {};     // per slot: the chunk's arrays are on the device / its results have left
         ~Events() { for (hipEvent_t x : uploaded) if (x) (void)hipEventDestroy(x); for (hipEvent_t x : done) if (x) (void)hipEventDestroy(x); }
@@ -516,7 +519,7 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
         // ---- compute lane ----
         const hipStream_t s = run_on;
         UMGAP_HIP_BREAK(hipStreamWaitEvent(s, ev.uploaded[slot], 0));
-        UMGAP_HIP_BREAK(hipMemsetAsync(L.bad, 0, 8, s));
+        UMGAP_HIP_BREAK(hipMemsetAsync(L.bad, 0, 16, s));
         if (!fused) UMGAP_HIP_BREAK(hipMemsetAsync(L.tails, 0, (nb / 32 + 8) * 4, s));
         UMGAP_HIP_BREAK(hipMemsetAsync(L.bytes + nb, 0, 144, s));   // the packer may look 8 bytes past the chunk
         const unsigned gf = (unsigned)std::min<size_t>((nf + 255) / 256 + 1, 2048), gr = (unsigned)std::min<size_t>((nr + 256) / 256 + 1, 2048);
@@ -525,8 +528,13 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
             hipLaunchKernelGGL(k_records_fit, dim3(std::max(gf, gr)), dim3(256), 0, s, (const uint64_t*)L.off, (size_t)nf, (const uint64_t*)L.rf, nr, f0, F_all, base + b0,
                                (uint32_t)nb, L.off_rel, L.bad);
             UMGAP_HIP_BREAK(hipGetLastError());
+            if (F_all <= PROT_MAX_FRAGS) {
+                rc = classify_prot9_gated(ix, tx, method, strategy, factor, lower_bound, ranked_only, L.bytes, L.off_rel, nr, F_all, seedextend, min_seed_size, max_gap_size, L.ot, L.os,
+                                          L.bad, 0, s);
+                if (rc) break;
+            }
             rc = classify_prot9_gated(ix, tx, method, strategy, factor, lower_bound, ranked_only, L.bytes, L.off_rel, nr, F_all, seedextend, min_seed_size, max_gap_size, L.ot, L.os,
-                                      L.bad, s);
+                                      L.bad, 1, s);
             if (rc) break;
             hipLaunchKernelGGL(k_records_any_unsupported, dim3(gr), dim3(256), 0, s, (const uint32_t*)L.os, nr, L.bad);
             UMGAP_HIP_BREAK(hipGetLastError());
@@ -549,15 +557,15 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
         UMGAP_HIP_BREAK(hipMemcpyAsync(out_pinned ? out_taxon + r0 : H[slot].ot, L.ot, nr * 4, hipMemcpyDeviceToHost, s));
         UMGAP_HIP_BREAK(hipMemcpyAsync(out_pinned ? out_status + r0 : H[slot].os, L.os, nr * 4, hipMemcpyDeviceToHost, s));
         if (!out_pinned) { out_at[slot] = r0; out_n[slot] = nr; }
-        UMGAP_HIP_BREAK(hipMemcpyAsync(tx->h_flags + 2 * slot, L.bad, 8, hipMemcpyDeviceToHost, s));
+        UMGAP_HIP_BREAK(hipMemcpyAsync(tx->h_flags + 4 * slot, L.bad, 16, hipMemcpyDeviceToHost, s));
         UMGAP_HIP_BREAK(hipEventRecord(ev.done[slot], s));
         // the host stays at most NS chunks ahead, and looks at the flags of the chunk whose slot the next one takes
         if (c + 1 >= (size_t)NS) {
             const int w = (int)((c + 1 - NS) % NS);
             UMGAP_HIP_BREAK(hipEventSynchronize(ev.done[w]));
             drain_out(w);
-            if (h_bad[2 * w]) { rc = fail(UMGAP_ERR_INVALID, "umgap_classify_records: frag_offsets / read_frags are not non-decreasing offsets into the block"); break; }
-            if (h_bad[2 * w + 1]) { unfit = true; break; }    // a read the fused kernel does not take: the caller runs the general kernels
+            if (h_bad[4 * w]) { rc = fail(UMGAP_ERR_INVALID, "umgap_classify_records: frag_offsets / read_frags are not non-decreasing offsets into the block"); break; }
+            if (fused && (h_bad[4 * w + 2] || h_bad[4 * w + 3])) { unfit = true; break; }    // a read neither variant of the fused kernel takes: the caller runs the general kernels
         }
     }
     hipError_t e0 = hipStreamSynchronize(up), e1 = hipStreamSynchronize(run_on);
@@ -565,8 +573,8 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
     if (rc) return rc;
     if (e0 != hipSuccess || e1 != hipSuccess) return fail(UMGAP_ERR_DEVICE, std::string("umgap_classify_records: ") + hipGetErrorString(e0 != hipSuccess ? e0 : e1));
     for (int k = 0; k < NS; k++) {
-        if (h_bad[2 * k]) return fail(UMGAP_ERR_INVALID, "umgap_classify_records: frag_offsets / read_frags are not non-decreasing offsets into the block");
-        if (h_bad[2 * k + 1]) unfit = true;
+        if (h_bad[4 * k]) return fail(UMGAP_ERR_INVALID, "umgap_classify_records: frag_offsets / read_frags are not non-decreasing offsets into the block");
+        if (fused && (h_bad[4 * k + 2] || h_bad[4 * k + 3])) unfit = true;
     }
     return UMGAP_OK;
     };   // run
