@@ -630,6 +630,14 @@ def main():
             out["surface_b"] = {"error": "%s: %s" % (type(e).__name__, e)}
         torch.cuda.empty_cache()
         try:
+            # a pair translated in all six frames (12 fragments, 504 windows: the sensitivity pipelines, umgap-analyse.sh:277-288) through the
+            # LONG variant of the fused kernel, beside the 2 x 50 gene-fragment form of the same pairs (tools/bench_six_frame.py)
+            import bench_six_frame
+            out["six_frame"] = bench_six_frame.run(50_000_000, 2_000_000, 30, steps=3, workload=w)
+        except Exception as e:  # noqa: BLE001
+            out["six_frame"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+        try:
             # the host-pointer entry points a Rust host binds, the PCIe link included (never `value`): pinned arrays in, pinned arrays out
             import bench_host_lookup
             import bench_records
@@ -637,9 +645,11 @@ def main():
             torch.cuda.empty_cache()
             hr = bench_records.run(50_000_000, 10_000_000, steps=3)
             out["host_fed"] = {"umgap_index_lookup9": {"G_lookups_per_s": hl["pinned"]["G_lookups_per_s"], "GB_per_s_in": hl["pinned"]["GB_per_s_in"],
-                                                       "pageable_G_lookups_per_s": hl["pageable"]["G_lookups_per_s"], "queries": hl["queries"]},
+                                                       "G_lookups_per_s_min_median_max": hl["pinned"]["G_lookups_per_s_min_median_max"],
+                                                       "pageable_G_lookups_per_s": hl["pageable"]["G_lookups_per_s"], "queries": hl["queries"], "calls": hl["pinned"]["calls"]},
                                "umgap_classify_records": {"pairs_per_s": hr["pinned"]["pairs_per_s"], "GB_per_s_in": hr["pinned"]["GB_per_s_in"],
-                                                          "pageable_pairs_per_s": hr["pageable"]["pairs_per_s"], "pairs": hr["pairs"], "pipeline": hr["pipeline"]},
+                                                          "M_pairs_per_s_min_median_max": hr["pinned"]["M_pairs_per_s_min_median_max"], "route": hr["pinned"]["route"],
+                                                          "pageable_pairs_per_s": hr["pageable"]["pairs_per_s"], "pairs": hr["pairs"], "pipeline": hr["pipeline"], "calls": hr["pinned"]["calls"]},
                                "link_GBps_bare_copy": hr["h2d_pinned_32MB_pieces_GBps"]}
         except Exception as e:  # noqa: BLE001
             out["host_fed"] = {"error": "%s: %s" % (type(e).__name__, e)}

@@ -456,7 +456,8 @@ int umgap_index_build_walk9_dev(const uint8_t* d_bytes, const uint64_t* d_offset
  * distinct key, whatever the redundancy of the proteome; a run of at most 8 repeated 9-mers between two listed windows of a
  * fragment keeps entries of its own (nothing points at them: they keep a walk through the fragment in one piece), as long as these
  * stay within an eighth of the keys; windows of the proteome whose 9-mer the values table does not hold get no entry (a miss stays
- * a miss).  Every answer is that of the values table.  Fewer than 2^32 - 2^22 keys.  `values` must outlive
+ * a miss).  Every answer is that of the values table.  Up to 2^34 entries (round 4: from 2^32 - 2^22 entries on the table holds the
+ * entry number >> 1 or >> 2 and the key's low bits pick the entry of the group, umgap_amd/csrc/walk_ref.hpp).  `values` must outlive
  * the builder (it is only read); finish consumes the builder. */
 typedef struct umgap_walk_builder umgap_walk_builder;
 int umgap_walk_builder_new(const umgap_index* values, double load_factor, umgap_walk_builder** out);
@@ -465,6 +466,10 @@ int umgap_walk_builder_add_dev(umgap_walk_builder* b, const uint8_t* d_bytes, co
 int umgap_walk_builder_add(umgap_walk_builder* b, const uint8_t* bytes, const uint64_t* offsets, size_t n_fragments,
                            uint32_t max_fragment_len);   /* the same from host memory */
 int umgap_walk_builder_finish(umgap_walk_builder* b, umgap_index** out);
+/* How a walk-order index numbers its entries: the table holds entry number >> *shift (0 below 2^32 - 2^22 entries, else 1 or 2), the
+ * walk array has *n_entries entries (padding included), and *n_exceptions keys share their low 31 bits with another key of their
+ * group of 2^shift entries (looked up through a sorted list).  Any pointer may be null. */
+int umgap_index_walk_info(const umgap_index* ix, uint32_t* shift, uint64_t* n_entries, uint32_t* n_exceptions);
 void umgap_walk_builder_free(umgap_walk_builder* b);
 int umgap_synth_prot_reads_dev(const uint8_t* d_proteome, uint64_t n_proteome_fragments, uint32_t fragment_len,
                                uint64_t seed, uint64_t first_read, size_t n_reads, uint32_t fragments_per_read,

@@ -1472,8 +1472,8 @@ def test_fused_classify_prot9_vs_oracle(api, torch_cuda, with_seedextend, mode, 
     assert torch.equal(d_t, d_t2) and torch.equal(d_s, d_s2)
 
 
-@pytest.mark.parametrize("mutations_per_mille", [0, 30, 250])
-def test_walk_index_matches_plain_table(api, torch_cuda, mutations_per_mille):
+@pytest.mark.parametrize("mutations_per_mille,shift", [(0, 0), (30, 0), (250, 0), (0, 1), (30, 1), (30, 2), (250, 2)])
+def test_walk_index_matches_plain_table(api, torch_cuda, mutations_per_mille, shift, monkeypatch):
     """The 9-mer index in walk order (umgap_index_build_walk9_dev, index_walk.hip): same proteome, same values as the plain table
     (umgap_index_build_windows9_dev: smallest taxon on duplicate 9-mers), so every answer must be bit-identical -- get() of packed
     9-mers, the windows of protein fragments, and the fused surface-B pipeline for every strategy, with and without seedextend --
@@ -1486,6 +1486,10 @@ def test_walk_index_matches_plain_table(api, torch_cuda, mutations_per_mille):
     from umgap_amd.api import Index, _dev_ptr, _stream_ptr
     from umgap_amd.synth import SyntheticWorkload
     L = _lib.load()
+    # shift > 0: the wide form of the index (round 4; what 8 G keys and more need) forced on this small one -- the table holds the entry
+    # number >> shift, a fragment's run of entries starts at a multiple of 2^shift, and the key's low bits pick the entry of the group
+    # (walk_ref.hpp); the low-complexity fragments below put keys with EQUAL low bits into one group (the exception list)
+    monkeypatch.setenv("UMGAP_WALK_SHIFT", str(shift))
     rng = np.random.default_rng(5 + mutations_per_mille)
     letters = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
     w = SyntheticWorkload(n_tax=4000, n_keys=1000, build_index=False)
@@ -1494,6 +1498,9 @@ def test_walk_index_matches_plain_table(api, torch_cuda, mutations_per_mille):
     for i in range(30_000):
         n = int(rng.choice([0, 3, 8, 9, 10, 25, 50, 50, 50, 73, 120]))
         f = bytearray(rng.choice(letters, n).tobytes())
+        if n >= 25 and rng.random() < 0.03:     # a homopolymer stretch: consecutive 9-mers that differ in their first residues only
+            a = int(rng.integers(0, n - 20))
+            f[a:a + 18] = bytes([int(rng.choice(letters))]) * 18
         if n > 12 and rng.random() < 0.05:
             f[int(rng.integers(0, n))] = int(rng.choice([42, 88 + 32, 64]))      # '*', 'x', '@'
         frags.append(bytes(f))
@@ -1513,6 +1520,9 @@ def test_walk_index_matches_plain_table(api, torch_cuda, mutations_per_mille):
     _lib.check(L.umgap_index_build_walk9_dev(_dev_ptr(d_p), _dev_ptr(d_po), _dev_ptr(d_pt), n_frag, max_len, n_win, 0.0, 0, C.byref(hw)))
     plain, walk = Index(hp.value), Index(hw.value)
     assert plain.kind == 9 and walk.kind == 10 and walk.num_keys == plain.num_keys
+    w_shift, w_entries, w_exc = walk.walk_info()
+    assert w_shift == shift and w_entries > 0
+    assert (w_exc > 0) == (shift > 0), w_exc       # the homopolymer stretches: keys with equal low bits side by side
     # reads: mutated copies of the 50-residue fragments, plus ragged reads cut from the proteome and random ones
     # (lengths 73 and 120: runs of up to 16 windows per lane with room behind a substituted residue for the walk to pick up again)
     long_ids = np.array([i for i, f in enumerate(frags) if len(f) >= 50 and all(65 <= c <= 90 for c in f)], np.int64)
@@ -1649,14 +1659,15 @@ def test_walk_index_matches_plain_table(api, torch_cuda, mutations_per_mille):
                 assert outs[0] == outs[1] and len(outs[0]) > 0, args
 
 
-@pytest.mark.parametrize("n_chunks,load", [(1, 0.0), (3, 0.0), (5, 0.9)])
-def test_walk_builder_values_from_a_table_order_from_a_proteome(api, torch_cuda, n_chunks, load):
+@pytest.mark.parametrize("n_chunks,load,shift", [(1, 0.0, 0), (3, 0.0, 0), (5, 0.9, 0), (3, 0.0, 1), (5, 0.9, 2)])
+def test_walk_builder_values_from_a_table_order_from_a_proteome(api, torch_cuda, n_chunks, load, shift, monkeypatch):
     """umgap_walk_builder_*: the values come from a kind-9 table (what `umgap buildindex` makes from the reference's TSV), the order
     from a proteome handed over in chunks.  The table holds only part of the proteome's 9-mers (the others must miss) and keys the
     proteome never shows (appended as walks of one); fragments repeat within and across chunks (every key is listed once, at its
     first window).  Every answer -- get() of keys, the windows of reads, the fused pipeline -- is the values table's, bit for bit;
     the walk array has one entry per key, plus those of short runs of repeats inside a fragment (at most an eighth more; at the
     high load factor some keys go through the stash and may get a second)."""
+    monkeypatch.setenv("UMGAP_WALK_SHIFT", str(shift))      # > 0: the wide entry numbers of walk_ref.hpp forced on this small index
     torch = torch_cuda
     from umgap_amd.api import Index
     from umgap_amd.synth import SyntheticWorkload
@@ -1716,8 +1727,11 @@ def test_walk_builder_values_from_a_table_order_from_a_proteome(api, torch_cuda,
         walk.save(fw)
         with open(fw, "rb") as f:
             hdr = f.read(72)
-        n_walk = int(np.frombuffer(hdr[64:72], np.uint64)[0])
-        assert len(vkeys) <= n_walk <= len(vkeys) + len(vkeys) // 8 + (0 if load < 0.8 else len(vkeys) // 50), (n_walk, len(vkeys))
+        reserved = int(np.frombuffer(hdr[64:72], np.uint64)[0])
+        n_walk = reserved & ((1 << 60) - 1)
+        assert reserved >> 60 == shift
+        # (with a shift every fragment's run of entries is padded to a multiple of 2^shift)
+        assert len(vkeys) <= n_walk <= len(vkeys) + len(vkeys) // 8 + (0 if load < 0.8 else len(vkeys) // 50) + ((1 << shift) - 1) * len(frags), (n_walk, len(vkeys))
         again = Index.open(fw)
         assert np.array_equal(again.lookup9(q, miss_value=7), want)
         again.close()
@@ -2280,6 +2294,71 @@ def test_host_pointer_calls_across_chunk_seams(api, torch_cuda):
 # ---------------------------------------------------------------------------------------------
 # BASELINE.json configs[2] at full size: 50 M pairs (5 x 10 M), 8 G-key table, size-independent properties
 # ---------------------------------------------------------------------------------------------
+def test_walk_index_beyond_32_bit_entry_numbers(api, torch_cuda):
+    """The walk-order index at the size class of the real 9-mer index: 4.6 G windows of a synthetic proteome -- more entries than the
+    table's 32-bit values can number, so the table holds entry number >> 1 and the key's low bits pick the entry of the pair
+    (walk_ref.hpp).  Answers of 50 M windows of reads cut from the proteome (3 % of the residues changed), of packed 9-mers, and of
+    the fused pipeline on 1 M pairs: bit for bit those of the plain table built from the same proteome."""
+    import ctypes as C
+    import gc
+    torch = torch_cuda
+    from umgap_amd import _lib
+    from umgap_amd.api import Index, _dev_ptr, _stream_ptr
+    from umgap_amd.synth import SyntheticWorkload
+    gc.collect()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 250e9:
+        pytest.skip("needs ~230 GB of free HBM")
+    L = _lib.load()
+    n_frag, flen, per = 110_000_000, 50, 42
+    w = SyntheticWorkload(n_tax=200_000, n_keys=1000, build_index=False)
+    prot, poffs, ptaxa = _proteome(torch, w, n_frag, flen)
+    hw = C.c_void_p()
+    _lib.check(L.umgap_index_build_walk9_dev(_dev_ptr(prot), _dev_ptr(poffs), _dev_ptr(ptaxa), n_frag, flen, n_frag * per, 0.5, 0, C.byref(hw)))
+    walk = Index(hw.value)
+    shift, entries, exc = walk.walk_info()
+    assert walk.kind == 10 and entries > (1 << 32) and shift == 1, (walk.num_keys, entries, shift, exc)
+    hp = C.c_void_p()
+    _lib.check(L.umgap_index_build_windows9_dev(_dev_ptr(prot), _dev_ptr(poffs), _dev_ptr(ptaxa), n_frag, flen, n_frag * per, 0.5, 0, C.byref(hp)))
+    plain = Index(hp.value)
+    assert plain.num_keys == walk.num_keys
+    n_reads, F = 600_000, 2
+    reads = torch.empty(n_reads * F * flen, dtype=torch.uint8, device="cuda")
+    _lib.check(L.umgap_synth_prot_reads_dev(_dev_ptr(prot), n_frag, flen, 44, 0, n_reads, F, 30, _dev_ptr(reads), 0, _stream_ptr(None)))
+    roffs = torch.arange(0, (n_reads * F + 1) * flen, flen, dtype=torch.int64, device="cuda")
+    oo = torch.arange(0, (n_reads * F + 1) * per, per, dtype=torch.int64, device="cuda")
+    h0 = torch.full((n_reads * F * per,), -3, dtype=torch.int32, device="cuda")
+    h1 = torch.full_like(h0, -5)
+    plain.lookup_prot9_dev(reads, roffs, oo, h0, miss_value=0)
+    walk.lookup_prot9_dev(reads, roffs, oo, h1, miss_value=0)
+    torch.cuda.synchronize()
+    assert torch.equal(h0, h1) and (h0 != 0).float().mean().item() > 0.5
+    # packed 9-mers of the proteome's LAST fragments (entry numbers beyond 2^32) and random ones
+    tail = prot[-flen * 2000:].cpu().numpy().reshape(2000, flen)
+    pk, pok = _pack_windows(tail)
+    q = np.concatenate([pk.ravel()[pok.ravel()], np.random.default_rng(3).integers(0, 1 << 45, 50_000, dtype=np.uint64)])
+    d_q = torch.from_numpy(q.view(np.int64)).cuda()
+    a, b = plain.lookup9_dev(d_q, miss_value=7), walk.lookup9_dev(d_q, miss_value=7)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and (a != 7).float().mean().item() > 0.5
+    for method, strategy, lb, se in (("tree", "lca*", 2.0, True), ("rmq", "mrtl", 1.0, False)):
+        outs = []
+        for ix in (plain, walk):
+            t = torch.full((n_reads,), -1, dtype=torch.int32, device="cuda")
+            st = torch.full_like(t, -1)
+            api.classify_prot9_dev(ix, w.taxonomy, reads, roffs, n_reads, F, t, st, method=method, strategy=strategy, factor=0.25, lower_bound=lb, seedextend=se,
+                                   min_seed_size=3, max_gap_size=1)
+            outs.append((t, st))
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]), (method, strategy)
+    walk.close()
+    plain.close()
+    del prot, poffs, ptaxa, reads, h0, h1
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
 FULL_N_TAX, FULL_N_KEYS = 2_500_000, 8_000_000_000
 
 

@@ -33,11 +33,15 @@ def run(n_keys=2_000_000_000, n_q=200_000_000, steps=3):
             check(L.umgap_index_lookup9(ix._h, h_q.data_ptr(), n, 0, h_o.data_ptr()))
         call()
         assert torch.equal(h_o, want)
-        t0 = time.perf_counter()
-        for _ in range(steps):
+        times = []
+        for _ in range(max(steps, 5)):       # every call timed on its own: min / median / max
+            t0 = time.perf_counter()
             call()
-        dt = (time.perf_counter() - t0) / steps
-        res[name] = {"s_per_call": round(dt, 4), "G_lookups_per_s": round(n / dt / 1e9, 3), "GB_per_s_in": round(n * 8 / dt / 1e9, 2)}
+            times.append(time.perf_counter() - t0)
+        times.sort()
+        dt = times[len(times) // 2]
+        res[name] = {"s_per_call": round(dt, 4), "G_lookups_per_s": round(n / dt / 1e9, 3), "GB_per_s_in": round(n * 8 / dt / 1e9, 2), "calls": len(times),
+                     "G_lookups_per_s_min_median_max": [round(n / times[-1] / 1e9, 3), round(n / dt / 1e9, 3), round(n / times[0] / 1e9, 3)]}
     return res
 
 

@@ -76,6 +76,7 @@ def load():
         "umgap_index_device": (i32, [vp]),
         "umgap_index_lookup9": (i32, [vp, vp, sz, u32, vp]),
         "umgap_index_lookup_records": (i32, [vp, vp, vp, sz, u32, vp]),
+        "umgap_index_walk_info": (i32, [vp, vp, vp, vp]),
         "umgap_index_lookup9_dev": (i32, [vp, vp, sz, u32, vp, vp]),
         "umgap_index_lookup9_lane_dev": (i32, [vp, vp, sz, u32, vp, vp]),
         "umgap_index_lookup_prot9_dev": (i32, [vp, vp, vp, vp, sz, u32, vp, vp]),

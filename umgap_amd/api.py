@@ -234,6 +234,12 @@ class Index:
         check(_lib.load().umgap_index_lookup9(self._h, _np_ptr(keys), len(keys), miss_value, _np_ptr(out)))
         return out
 
+    def walk_info(self):
+        """(shift, entries, exceptions) of a walk-order index (include/umgap_hip.h: umgap_index_walk_info)."""
+        sh, n, ex = C.c_uint32(), C.c_uint64(), C.c_uint32()
+        check(_lib.load().umgap_index_walk_info(self._h, C.byref(sh), C.byref(n), C.byref(ex)))
+        return sh.value, n.value, ex.value
+
     def lookup_records(self, data, frag_offsets, miss_value=0):
         """The windows of protein records cut and looked up on the device (umgap_index_lookup_records): `data` uint8 residues,
         `frag_offsets` uint64 [n + 1]; returns a uint32 array with one entry per byte position of [frag_offsets[0], frag_offsets[n])

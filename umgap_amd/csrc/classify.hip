@@ -21,6 +21,7 @@
 #include "probe_common.hpp"
 #include "prot_limits.hpp"
 #include "shard_wire.hpp"
+#include "walk_ref.hpp"
 
 using namespace umgap;
 using namespace umgap::agg;
@@ -377,8 +378,7 @@ struct ProtScratch<true> {
 // position p the probe returned, as long as each entry continues its predecessor and carries the window's low key bits (by
 // induction its key equals the window's: exact); where the chain breaks, that window is probed and the walk goes on from there.
 struct WalkView {
-    const uint64_t* E = nullptr;   // taxon | (low 31 key bits | continues << 31) << 32
-    uint64_t n = 0;
+    WalkRef W;                     // the walk array and how the table's values address it (walk_ref.hpp)
     const uint32_t* gate = nullptr;   // non-null: three words {offsets bad, unfit for the short variant, unfit for the LONG one} (records.hip):
                                       // the short variant runs when none is set, the LONG one when only word 1 is
 };
@@ -528,9 +528,11 @@ __global__ __launch_bounds__(256, GENERAL ? 3 : 4) void k_classify_prot9(TableVi
                 const uint32_t v0 = (uint32_t)__shfl((int)pr[0], src, 64), v1 = (uint32_t)__shfl((int)pr[1], src, 64),
                                v2 = (uint32_t)__shfl((int)pr[2], src, 64), v3 = (uint32_t)__shfl((int)pr[3], src, 64);
                 const uint32_t r4 = lane >> 4;
-                const uint32_t pos = r4 == 0 ? v0 : (r4 == 1 ? v1 : (r4 == 2 ? v2 : v3));
+                const uint32_t q32 = r4 == 0 ? v0 : (r4 == 1 ? v1 : (r4 == 2 ? v2 : v3));
+                const WalkRef& WR = WK.W;
+                const uint64_t pos = (run_cnt && valid) ? walk_position(WR, q32, akey) : WALK_NOPOS;
                 if (run_cnt) {
-                    if (!valid || pos == NONE || pos >= WK.n) { wtaxa[sb] = 0u; done_n = 1; }   // the anchor is not in the table: no hit
+                    if (pos == WALK_NOPOS) { wtaxa[sb] = 0u; done_n = 1; }   // the anchor is not in the table: no hit
                     else {
                         // the walk: entries pos, pos + 1, ... four at a time (consecutive: the next four mostly lie in a sector already fetched),
                         // each verified against the rolling key
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(256, GENERAL ? 3 : 4) void k_classify_prot9(TableVi
                         for (uint32_t c0 = 0; go && c0 < run_cnt; c0 += 4) {
                             uint64_t e[4];
 #pragma unroll
-                            for (uint32_t k = 0; k < 4; k++) e[k] = (c0 + k < run_cnt && (uint64_t)pos + c0 + k < WK.n) ? WK.E[(uint64_t)pos + c0 + k] : 0x7FFFFFFF00000000ull;   // (past the end: low bits that match no window)
+                            for (uint32_t k = 0; k < 4; k++) e[k] = (c0 + k < run_cnt && pos + c0 + k < WR.n) ? WR.E[pos + c0 + k] : WALK_PAD_ENTRY;   // (past the end: low bits that match no window)
 #pragma unroll
                             for (uint32_t k = 0; k < 4; k++) {
                                 const uint32_t t = c0 + k;
@@ -582,6 +584,7 @@ __global__ __launch_bounds__(256, GENERAL ? 3 : 4) void k_classify_prot9(TableVi
                     for (uint32_t i0 = 0; i0 < n_here; i0 += 128) {
                         ProbeBatch B[2];
                         uint32_t pr[2][4], item[2];
+                        uint64_t ikey[2] = {0, 0};
                         const bool two = i0 + 64 < n_here;
 #pragma unroll
                         for (int h = 0; h < 2; h++) {
@@ -600,6 +603,7 @@ __global__ __launch_bounds__(256, GENERAL ? 3 : 4) void k_classify_prot9(TableVi
                                     k9 = (k9 << 5) | (code & 31u);
                                 }
                                 if (ok) valid = locate(T, k9, loc, tg) ? 1u : 0u;
+                                ikey[h] = k9;
                             }
                             probe_issue(T, loc, tg | (valid << 31), lane, B[h]);
                         }
@@ -612,8 +616,8 @@ __global__ __launch_bounds__(256, GENERAL ? 3 : 4) void k_classify_prot9(TableVi
                             const uint32_t v0 = (uint32_t)__shfl((int)pr[h][0], src, 64), v1 = (uint32_t)__shfl((int)pr[h][1], src, 64),
                                            v2 = (uint32_t)__shfl((int)pr[h][2], src, 64), v3 = (uint32_t)__shfl((int)pr[h][3], src, 64);
                             const uint32_t r4 = lane >> 4;
-                            const uint32_t pos = r4 == 0 ? v0 : (r4 == 1 ? v1 : (r4 == 2 ? v2 : v3));
-                            if (item[h] != NONE) wtaxa[item[h] & 1023u] = (pos != NONE && pos < WK.n) ? (uint32_t)WK.E[pos] : 0u;
+                            const uint32_t q32 = r4 == 0 ? v0 : (r4 == 1 ? v1 : (r4 == 2 ? v2 : v3));
+                            if (item[h] != NONE) wtaxa[item[h] & 1023u] = walk_taxon(WK.W, q32, ikey[h], 0u);
                         }
                     }
                     wave_lds_sync();
@@ -883,7 +887,9 @@ int umgap::classify_prot9_gated(umgap_index* ix, umgap_taxonomy* tx, int method,
     size_t g = ((n_reads + G - 1) / G + 3) / 4;
     if (g > 256 * 8) g = 256 * 8;
     const bool general = strategy != UMGAP_STRATEGY_LCA_STAR, bound = ix->bound_to != nullptr, walk = ix->kind == 10;
-    const WalkView WK{ix->d_walk, ix->n_walk, gate};
+    WalkView WK;
+    WK.W = walk_ref_of(ix);
+    WK.gate = gate;
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, strategy, factor, d_bytes,
                            d_frag_offsets, n_reads, fragments_per_read, seedextend ? 1u : 0u, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status, WK);

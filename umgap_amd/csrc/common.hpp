@@ -119,6 +119,10 @@ struct umgap_index {
     int kind = 9;                      // 9 = packed 9-mer table, 2 = variable-length (byte string) table, 10 = 9-mer table in walk order (index_walk.hip)
     uint64_t* d_walk = nullptr;        // kind 10: E[p] = taxon | (low 31 key bits | continues << 31) << 32 for window p of the proteome; the table's values are positions
     uint64_t n_walk = 0;
+    uint32_t walk_shift = 0;           // the table holds p >> walk_shift (walk_ref.hpp: 1 from 2^32 - 2^22 entries on, 2 from 2^33 on)
+    uint32_t n_walk_exc = 0;           // keys whose group holds another entry with their low bits: sorted keys -> positions
+    uint64_t* d_walk_exc_keys = nullptr;
+    uint64_t* d_walk_exc_pos = nullptr;
     umgap_var_index* var = nullptr;    // kind 2
     uint64_t* d_slots = nullptr;  // nb * 8 slots (whole table) or the shard's range
     uint64_t n_keys = 0;

@@ -16,11 +16,12 @@
 #include "probe_common.hpp"
 #include "window_locate.hpp"
 #include "taxonomy.hpp"
+#include "walk_ref.hpp"
 
 namespace umgap {
 void var_free(umgap_var_index* v);
 // index_walk.hip
-int walk_map_positions(const umgap_index* ix, uint32_t* d_vals, size_t n, uint32_t miss, hipStream_t s);
+int walk_map_positions(const umgap_index* ix, const uint64_t* d_keys, uint32_t* d_vals, size_t n, uint32_t miss, hipStream_t s);
 int ensure_stage(umgap_index* ix);
 int walk_lookup_prot9(const umgap_index* ix, const uint8_t* d_bytes, const uint64_t* d_offsets, const uint64_t* d_out_offsets, size_t n_prot, size_t n_windows,
                       uint32_t miss, uint32_t* d_out, hipStream_t s);
@@ -402,8 +403,9 @@ __global__ __launch_bounds__(256) void k_walk_flags(TableView C, TableView V, co
 // at, there so that a walk through the fragment is not cut by a 9-mer that happens to occur earlier in the proteome); longer runs,
 // and runs at the ends of a fragment, are dropped (flag 0: the walk array stays near one entry per key however redundant the
 // proteome).  gap = 0 drops every repeat, kept ones of an earlier call included.  cnt[f] = entries of fragment f.
+// A fragment's run of entries is padded to a multiple of `group` = 2^shift entries (walk_ref.hpp): cnt[f] counts the padding.
 __global__ __launch_bounds__(256) void k_walk_keep_short_repeats(uint8_t* __restrict__ flag, const uint64_t* __restrict__ wbase, size_t n_frag, uint32_t gap, uint32_t* __restrict__ cnt,
-                                                                 unsigned long long* __restrict__ n_kept) {
+                                                                 unsigned long long* __restrict__ n_kept, uint32_t group) {
     size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t step = (size_t)gridDim.x * blockDim.x;
     for (; f < n_frag; f += step) {
@@ -421,23 +423,34 @@ __global__ __launch_bounds__(256) void k_walk_keep_short_repeats(uint8_t* __rest
             if (keep) { c += (uint32_t)(q - p); kept += (uint32_t)(q - p); }
             p = q;
         }
-        cnt[f] = c;
+        cnt[f] = (c + group - 1) & ~(group - 1);
         if (kept) atomicAdd(n_kept, (unsigned long long)kept);
     }
 }
 // pass 4: a thread walks its fragment; every flagged window gets the next entry of the walk array (taxon from the values table,
 // low key bits, "continues" iff the previous window of the fragment was flagged too, i.e. is the entry in front) and, when it is
 // the key's first, goes into the position table under that entry's number
+// With shift > 0 the table holds at >> shift and the run of a fragment starts at a multiple of 2^shift and is padded to one
+// (walk_ref.hpp): the entries of a group come from this thread, which lists every LISTED key that shares its low 31 bits with
+// another key of its group in `exc` (key, position pairs; *n_exc counts them, a list longer than exc_cap fails the build).
 __global__ __launch_bounds__(256) void k_walk_emit(const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ off, const uint64_t* __restrict__ wbase,
                                                    const uint64_t* __restrict__ fbase, const uint8_t* __restrict__ flag, size_t n_frag, TableView V,
                                                    uint64_t* __restrict__ E, uint64_t e0, uint64_t* __restrict__ t_slots, uint32_t t_m, uint32_t t_nb,
-                                                   BuildFlags* flags, uint64_t* __restrict__ stash) {
+                                                   BuildFlags* flags, uint64_t* __restrict__ stash, uint32_t shift, uint64_t* __restrict__ exc,
+                                                   unsigned long long* __restrict__ n_exc, uint64_t exc_cap) {
     size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t step = (size_t)gridDim.x * blockDim.x;
+    const uint64_t gmask = (1ull << shift) - 1ull;
+    auto note = [&](uint64_t key, uint64_t pos) {
+        const unsigned long long i = atomicAdd(n_exc, 1ull);
+        if (i < exc_cap) { exc[2 * i] = key; exc[2 * i + 1] = pos; }
+    };
     for (; f < n_frag; f += step) {
         const uint64_t p0 = wbase[f], nw = wbase[f + 1] - p0, o = off[f];
         uint64_t at = e0 + fbase[f];
         bool prev = false;
+        uint64_t gkey[3] = {0, 0, 0};      // the entries of the current group written so far (at most 2^shift - 1 = 3)
+        uint8_t glisted[3] = {0, 0, 0};
         for (uint64_t w = 0; w < nw; w++) {
             if (!flag[p0 + w]) { prev = false; continue; }
             uint64_t key;
@@ -445,10 +458,21 @@ __global__ __launch_bounds__(256) void k_walk_emit(const uint8_t* __restrict__ b
             const uint32_t taxon = lane_get(V, key, 0u);
             const uint32_t lo = ((uint32_t)key & 0x7FFFFFFFu) | (prev ? 0x80000000u : 0u);
             E[at] = (uint64_t)taxon | ((uint64_t)lo << 32);
-            if (flag[p0 + w] == 1) insert_one(t_slots, t_m, t_nb, 0u, t_nb, key, (uint32_t)at, flags, stash);   // (2: a kept repeat, listed elsewhere)
+            const bool listed = flag[p0 + w] == 1;
+            if (listed) insert_one(t_slots, t_m, t_nb, 0u, t_nb, key, (uint32_t)(at >> shift), flags, stash);   // (2: a kept repeat, listed elsewhere)
+            if (shift) {
+                const uint32_t in_group = (uint32_t)(at & gmask);
+                for (uint32_t i = 0; i < in_group; i++) {
+                    if (((uint32_t)gkey[i] & 0x7FFFFFFFu) != ((uint32_t)key & 0x7FFFFFFFu) || gkey[i] == key) continue;
+                    if (glisted[i]) note(gkey[i], at - in_group + i);
+                    if (listed) note(key, at);
+                }
+                if (in_group < 3) { gkey[in_group] = key; glisted[in_group] = listed ? 1 : 0; }
+            }
             at++;
             prev = true;
         }
+        while (at & gmask) E[at++] = WALK_PAD_ENTRY;
     }
 }
 // inverse of mix45 (common.hpp) with the inverses of its two odd constants handed in
@@ -490,12 +514,24 @@ __global__ __launch_bounds__(256) void k_walk_leftovers(TableView V, TableView T
 }
 // the leftovers as walks of one entry each behind the proteome's
 __global__ __launch_bounds__(256) void k_walk_append(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ taxa, size_t n, uint64_t* __restrict__ E, uint64_t e0,
-                                                     uint32_t* __restrict__ pos) {
+                                                     uint32_t* __restrict__ pos, uint32_t shift, uint64_t* __restrict__ exc, unsigned long long* __restrict__ n_exc,
+                                                     uint64_t exc_cap) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t step = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += step) {
-        E[e0 + i] = (uint64_t)taxa[i] | ((uint64_t)((uint32_t)keys[i] & 0x7FFFFFFFu) << 32);
-        pos[i] = (uint32_t)(e0 + i);
+        const uint64_t at = e0 + i;
+        E[at] = (uint64_t)taxa[i] | ((uint64_t)((uint32_t)keys[i] & 0x7FFFFFFFu) << 32);
+        pos[i] = (uint32_t)(at >> shift);
+        if (shift) {      // (e0 is a multiple of 2^shift: the group's other entries are leftovers too, distinct keys in sorted order)
+            const uint64_t g0 = (at >> shift) << shift;
+            bool clash = false;
+            for (uint64_t q = g0; q < g0 + (1ull << shift); q++)
+                if (q != at && q >= e0 && q - e0 < n && ((uint32_t)keys[q - e0] & 0x7FFFFFFFu) == ((uint32_t)keys[i] & 0x7FFFFFFFu)) clash = true;
+            if (clash) {
+                const unsigned long long k = atomicAdd(n_exc, 1ull);
+                if (k < exc_cap) { exc[2 * k] = keys[i]; exc[2 * k + 1] = at; }
+            }
+        }
     }
 }
 // first fragment whose windows start at or behind c * per (chunk cuts of a proteome by window count)
@@ -725,6 +761,27 @@ int set_stash(umgap_index* ix, std::vector<std::pair<uint64_t, uint64_t>>& entri
     ix->view.stash_keys = ix->d_stash_keys;
     ix->view.stash_vals = ix->d_stash_vals;
     ix->view.n_stash = ix->n_stash;
+    return UMGAP_OK;
+}
+
+// install the exception list of a walk index (walk_ref.hpp): pairs {key, position}, sorted by key
+int set_walk_exceptions(umgap_index* ix, const std::vector<std::pair<uint64_t, uint64_t>>& ex) {
+    if (ix->d_walk_exc_keys) { (void)hipFree(ix->d_walk_exc_keys); ix->d_walk_exc_keys = nullptr; }
+    if (ix->d_walk_exc_pos) { (void)hipFree(ix->d_walk_exc_pos); ix->d_walk_exc_pos = nullptr; }
+    ix->n_walk_exc = 0;
+    if (ex.empty()) return UMGAP_OK;
+    if (ex.size() >= 0xFFFFFFFFull) return fail(UMGAP_ERR_FORMAT, "walk index: exception list too long");
+    std::vector<uint64_t> k(ex.size()), v(ex.size());
+    for (size_t i = 0; i < ex.size(); i++) {
+        if (i && ex[i].first <= ex[i - 1].first) return fail(UMGAP_ERR_FORMAT, "walk index: exception list not sorted");
+        k[i] = ex[i].first;
+        v[i] = ex[i].second;
+    }
+    UMGAP_HIP(hipMalloc((void**)&ix->d_walk_exc_keys, k.size() * 8));
+    UMGAP_HIP(hipMalloc((void**)&ix->d_walk_exc_pos, v.size() * 8));
+    UMGAP_HIP(hipMemcpy(ix->d_walk_exc_keys, k.data(), k.size() * 8, hipMemcpyHostToDevice));
+    UMGAP_HIP(hipMemcpy(ix->d_walk_exc_pos, v.data(), v.size() * 8, hipMemcpyHostToDevice));
+    ix->n_walk_exc = (uint32_t)k.size();
     return UMGAP_OK;
 }
 
@@ -1007,6 +1064,8 @@ void umgap_index_free(umgap_index* ix) {
     }
     if (ix->var) var_free(ix->var);
     if (ix->d_walk) (void)hipFree(ix->d_walk);
+    if (ix->d_walk_exc_keys) (void)hipFree(ix->d_walk_exc_keys);
+    if (ix->d_walk_exc_pos) (void)hipFree(ix->d_walk_exc_pos);
     for (void* p : ix->tryp_scratch) if (p) (void)hipFree(p);
     if (ix->d_slots) (void)hipFree(ix->d_slots);
     if (ix->d_stash_keys) (void)hipFree(ix->d_stash_keys);
@@ -1049,7 +1108,9 @@ int umgap_index_save(const umgap_index* ix, const char* path) {
     IndexFileHeader h{};
     memcpy(h.magic, "UMGAPIX1", 8);
     h.version = 1; h.kind = (uint32_t)ix->kind; h.n_keys = ix->n_keys; h.m = ix->view.m; h.nb = ix->view.nb;
-    h.reserved = ix->kind == 10 ? ix->n_walk : 0;   // kind 10 (walk order): the walk array, n_walk x u64, follows the stash
+    // kind 10 (walk order): the walk array, n_walk x u64, follows the stash; bits 60-61 of `reserved` = walk_shift (walk_ref.hpp), and
+    // with a shift the exception list follows the walk array: u64 count, the sorted keys, their positions
+    h.reserved = ix->kind == 10 ? (ix->n_walk | ((uint64_t)ix->walk_shift << 60)) : 0;
     h.mix_c1 = MIX_C1; h.mix_c2 = MIX_C2; h.r_bits = R_BITS; h.slots = SLOTS;
     h.n_stash = ix->n_stash;
     bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
@@ -1075,6 +1136,15 @@ int umgap_index_save(const umgap_index* ix, const char* path) {
             size_t len = std::min(chunk, total - off);
             if (hipMemcpy(buf.data(), (const char*)ix->d_walk + off, len, hipMemcpyDeviceToHost) != hipSuccess) { ok = false; break; }
             ok = fwrite(buf.data(), 1, len, f) == len;
+        }
+        if (ok && ix->walk_shift) {
+            const uint64_t n_exc = ix->n_walk_exc;
+            std::vector<uint64_t> k(n_exc), v(n_exc);
+            ok = fwrite(&n_exc, 8, 1, f) == 1;
+            if (ok && n_exc)
+                ok = hipMemcpy(k.data(), ix->d_walk_exc_keys, n_exc * 8, hipMemcpyDeviceToHost) == hipSuccess &&
+                     hipMemcpy(v.data(), ix->d_walk_exc_pos, n_exc * 8, hipMemcpyDeviceToHost) == hipSuccess && fwrite(k.data(), 8, n_exc, f) == n_exc &&
+                     fwrite(v.data(), 8, n_exc, f) == n_exc;
         }
     }
     ok = (fclose(f) == 0) && ok;
@@ -1159,7 +1229,10 @@ int umgap_index_open_shard(const char* path, uint32_t device_mask, uint32_t shar
         return fail(UMGAP_ERR_FORMAT, std::string(path) + ": unsupported UMGAPIX1 parameters");
     }
     if (h.kind == 10 && n_shards != 1) { fclose(f); return fail(UMGAP_ERR_INVALID, "a walk-order index cannot be sharded"); }
-    if (h.kind == 10 && h.reserved >= 0xFFFFFFFFull) { fclose(f); return fail(UMGAP_ERR_FORMAT, std::string(path) + ": walk array too long"); }
+    if (h.kind == 10 && ((h.reserved >> 62) != 0 || ((h.reserved >> 60) & 3) > 2 || (h.reserved & ((1ull << 60) - 1)) >= ((0xFFFFFFFFull) << ((h.reserved >> 60) & 3)))) {
+        fclose(f);
+        return fail(UMGAP_ERR_FORMAT, std::string(path) + ": walk array too long for its entry numbers");
+    }
     umgap_index* ix = nullptr;
     int rc = new_handle(device, &ix);
     if (rc) { fclose(f); return rc; }
@@ -1193,9 +1266,22 @@ int umgap_index_open_shard(const char* path, uint32_t device_mask, uint32_t shar
     }
     if (ok && h.kind == 10) {   // the walk array behind the stash
         ix->kind = 10;
-        ix->n_walk = h.reserved;
+        ix->n_walk = h.reserved & ((1ull << 60) - 1);
+        ix->walk_shift = (uint32_t)((h.reserved >> 60) & 3);
         if (hipMalloc((void**)&ix->d_walk, std::max<uint64_t>(ix->n_walk, 1) * 8) != hipSuccess) { fclose(f); umgap_index_free(ix); return fail(UMGAP_ERR_NOMEM, "hipMalloc of the walk array failed"); }
-        ok = load_file_range(fd, (off_t)(sizeof(h) + (uint64_t)h.nb * 64 + h.n_stash * 16), (size_t)ix->n_walk * 8, ix->d_walk, device);
+        const off_t walk_at = (off_t)(sizeof(h) + (uint64_t)h.nb * 64 + h.n_stash * 16);
+        ok = load_file_range(fd, walk_at, (size_t)ix->n_walk * 8, ix->d_walk, device);
+        if (ok && ix->walk_shift) {     // the exception list behind the walk array
+            uint64_t n_exc = 0;
+            ok = fseeko(f, walk_at + (off_t)(ix->n_walk * 8), SEEK_SET) == 0 && fread(&n_exc, 8, 1, f) == 1 && n_exc < (1ull << 26);
+            std::vector<uint64_t> k(ok ? n_exc : 0), v(ok ? n_exc : 0);
+            if (ok && n_exc) ok = fread(k.data(), 8, n_exc, f) == n_exc && fread(v.data(), 8, n_exc, f) == n_exc;
+            if (ok) {
+                std::vector<std::pair<uint64_t, uint64_t>> ex(n_exc);
+                for (size_t i = 0; i < n_exc; i++) ex[i] = {k[i], v[i]};
+                if (set_walk_exceptions(ix, ex)) { fclose(f); umgap_index_free(ix); return UMGAP_ERR_FORMAT; }
+            }
+        }
     }
     fclose(f);
     if (!ok) { umgap_index_free(ix); return fail(UMGAP_ERR_IO, std::string(path) + ": truncated or unreadable table"); }
@@ -1259,7 +1345,11 @@ struct umgap_walk_builder {
     uint64_t* d_stash = nullptr;
     uint64_t cap_walk = 0, n_walk = 0;
     uint64_t slack = 0, n_kept = 0;        // entries the array may spend on kept repeats (k_walk_keep_short_repeats), and has
+    uint32_t shift = 0;                    // the table holds entry number >> shift (walk_ref.hpp)
+    uint64_t* d_exc = nullptr;             // (key, position) pairs of the exception list, in the order found
+    unsigned long long* d_exc_n = nullptr;
 };
+constexpr uint64_t WALK_EXC_CAP = 1ull << 22;
 namespace {
 // the raw stash list of a table under construction -> its sorted stash (a key that went there twice -- see lane_get_wrap -- keeps
 // its first entry) and the halo
@@ -1289,6 +1379,8 @@ void umgap_walk_builder_free(umgap_walk_builder* b) {
     if (b->ix) { (void)use_device(b->ix->device); (void)hipStreamSynchronize(b->ix->stream); }
     if (b->d_flags) (void)hipFree(b->d_flags);
     if (b->d_stash) (void)hipFree(b->d_stash);
+    if (b->d_exc) (void)hipFree(b->d_exc);
+    if (b->d_exc_n) (void)hipFree(b->d_exc_n);
     if (b->ix) umgap_index_free(b->ix);
     delete b;
 }
@@ -1300,19 +1392,33 @@ int walk_builder_create(const umgap_index* values, double load, uint32_t m, umga
     if (!values || !out) return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_new: null argument");
     if (values->kind != 9 || values->bound_to || values->view.home_lo != 0 || values->view.home_hi != values->view.nb)
         return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_new: the values must be a whole, unbound 9-mer table");
-    if (values->n_keys + STASH_CAP >= 0xFFFFFFFFull) return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_new: a walk index numbers its entries with 32 bits (fewer than 2^32 - 2^22 keys)");
+    // entries: every key once, the second entries of keys that went to the stash, kept repeats (slack), padding (shift > 0).  The
+    // table's 32-bit values hold the entry number >> shift: shift 0 up to 2^32 - 2^22 entries, 1 up to 2^33, 2 up to 2^34
+    // (UMGAP_WALK_SHIFT in the environment asks for at least that shift: tests exercise the wide form on small indexes)
+    uint32_t shift = 0;
+    if (const char* env = getenv("UMGAP_WALK_SHIFT")) { const int v = atoi(env); if (v >= 0 && v <= 2) shift = (uint32_t)v; }
+    uint64_t slack = values->n_keys / 8, cap = 0;
+    for (;; shift++) {
+        if (shift > 2) return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_new: more than 2^34 entries");
+        const uint64_t pad = shift ? ((1ull << shift) - 1ull) * (values->n_keys / 16 + 4096) : 0;
+        cap = values->n_keys + STASH_CAP + slack + pad;
+        if (cap < ((0xFFFFFFFFull - (1ull << 22)) << shift)) break;
+    }
     umgap_walk_builder* b = new umgap_walk_builder();
+    b->shift = shift;
     b->values = values;
     int rc = new_handle(values->device, &b->ix);
     if (rc) { delete b; return rc; }
     auto bail = [&](int code) { umgap_walk_builder_free(b); return code; };
     rc = alloc_table(b->ix, m ? m : choose_m(std::max<uint64_t>(values->n_keys, 1), load), 0, 1);
     if (rc) return bail(rc);
-    b->slack = std::min<uint64_t>(values->n_keys / 8, 0xFFFFFFFEull - values->n_keys - STASH_CAP);
-    b->cap_walk = values->n_keys + STASH_CAP + b->slack;    // every key once, the second entries of keys that went to the stash, kept repeats
+    b->slack = slack;
+    b->cap_walk = cap;
     if (hipMalloc((void**)&b->d_flags, sizeof(BuildFlags)) != hipSuccess || hipMalloc((void**)&b->d_stash, (size_t)STASH_CAP * 16) != hipSuccess ||
-        hipMalloc((void**)&b->ix->d_walk, b->cap_walk * 8) != hipSuccess)
+        hipMalloc((void**)&b->ix->d_walk, b->cap_walk * 8) != hipSuccess || hipMalloc((void**)&b->d_exc, WALK_EXC_CAP * 16) != hipSuccess ||
+        hipMalloc((void**)&b->d_exc_n, 8) != hipSuccess)
         return bail(fail(UMGAP_ERR_NOMEM, "umgap_walk_builder_new: hipMalloc failed"));
+    if (hipMemsetAsync(b->d_exc_n, 0, 8, b->ix->stream) != hipSuccess) return bail(fail(UMGAP_ERR_DEVICE, "umgap_walk_builder_new: memset failed"));
     const size_t nslots = (size_t)b->ix->view.n_resident * SLOTS;
     hipLaunchKernelGGL(k_fill, dim3(grid_for(nslots)), dim3(256), 0, b->ix->stream, b->ix->d_slots, nslots, EMPTY_SLOT);
     if (hipMemsetAsync(b->d_flags, 0, sizeof(BuildFlags), b->ix->stream) != hipSuccess) return bail(fail(UMGAP_ERR_DEVICE, "umgap_walk_builder_new: memset failed"));
@@ -1374,7 +1480,7 @@ int umgap_walk_builder_add_dev(umgap_walk_builder* b, const uint8_t* d_bytes, co
     for (uint32_t gap : {WALK_KEEP_REPEATS, 0u}) {   // short runs of repeats keep their entries while the array has room for them
         UMGAP_HIP(hipMemsetAsync(d_total + 2, 0, 8, x->stream));
         hipLaunchKernelGGL(k_walk_keep_short_repeats, dim3(grid_for(n_fragments)), dim3(256), 0, x->stream, d_flag, (const uint64_t*)d_wbase, n_fragments, gap, d_cnt,
-                           (unsigned long long*)(d_total + 2));
+                           (unsigned long long*)(d_total + 2), 1u << b->shift);
         hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, x->stream, d_cnt, n_fragments, d_fbase, d_total + 1);
         uint64_t two[2] = {0, 0};
         e = hipMemcpyAsync(two, d_total + 1, 16, hipMemcpyDeviceToHost, x->stream);
@@ -1385,10 +1491,11 @@ int umgap_walk_builder_add_dev(umgap_walk_builder* b, const uint8_t* d_bytes, co
         if (b->n_kept + n_keep <= b->slack) break;
     }
     b->n_kept += n_keep;
-    if (b->n_walk + n_new > b->cap_walk) return done(fail(UMGAP_ERR_BUILD, "umgap_walk_builder_add_dev: more entries than the values table has keys (internal error)"));
+    if (b->n_walk + n_new > b->cap_walk) return done(fail(UMGAP_ERR_BUILD, "umgap_walk_builder_add_dev: the walk array is full (more fragments than one per 16 keys pad their runs: internal limit)"));
     if (n_new)
         hipLaunchKernelGGL(k_walk_emit, dim3(grid_for(n_fragments)), dim3(256), 0, x->stream, d_bytes, d_offsets, (const uint64_t*)d_wbase, (const uint64_t*)d_fbase,
-                           (const uint8_t*)d_flag, n_fragments, V, x->d_walk, b->n_walk, x->d_slots, x->view.m, x->view.nb, b->d_flags, b->d_stash);
+                           (const uint8_t*)d_flag, n_fragments, V, x->d_walk, b->n_walk, x->d_slots, x->view.m, x->view.nb, b->d_flags, b->d_stash, b->shift, b->d_exc,
+                           b->d_exc_n, WALK_EXC_CAP);
     e = hipStreamSynchronize(x->stream);
     if (e != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, std::string("umgap_walk_builder_add_dev: ") + hipGetErrorString(e)));
     b->n_walk += n_new;
@@ -1469,11 +1576,27 @@ int umgap_walk_builder_finish(umgap_walk_builder* b, umgap_index** out) {
             std::swap(d_taxa, d_taxa2);
             drop();
         }
-        hipLaunchKernelGGL(k_walk_append, dim3(grid_for(n_left)), dim3(256), 0, x->stream, (const uint64_t*)d_keys, (const uint32_t*)d_taxa, (size_t)n_left, x->d_walk, b->n_walk, d_pos);
+        hipLaunchKernelGGL(k_walk_append, dim3(grid_for(n_left)), dim3(256), 0, x->stream, (const uint64_t*)d_keys, (const uint32_t*)d_taxa, (size_t)n_left, x->d_walk, b->n_walk, d_pos,
+                           b->shift, b->d_exc, b->d_exc_n, WALK_EXC_CAP);
         hipLaunchKernelGGL(k_insert, dim3(grid_for(n_left)), dim3(256), 0, x->stream, x->d_slots, x->view.m, x->view.nb, 0u, x->view.nb, (const uint64_t*)d_keys,
                            (const uint32_t*)d_pos, (size_t)n_left, b->d_flags, b->d_stash);
         b->n_walk += n_left;
         rc = walk_finalize_table(b);   // the stash list and the halo again, now with the appended keys
+        if (rc) return done(rc);
+    }
+    // the exception list (walk_ref.hpp): sorted by key, one entry per key
+    x->walk_shift = b->shift;
+    if (b->shift) {
+        unsigned long long n_exc = 0;
+        if (hipMemcpy(&n_exc, b->d_exc_n, 8, hipMemcpyDeviceToHost) != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, "umgap_walk_builder_finish: copy failed"));
+        if (n_exc > WALK_EXC_CAP) return done(fail(UMGAP_ERR_BUILD, "umgap_walk_builder_finish: more than 2^22 keys share their low bits with a neighbour (low-complexity proteome?)"));
+        std::vector<uint64_t> raw(2 * (size_t)n_exc);
+        if (n_exc && hipMemcpy(raw.data(), b->d_exc, raw.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, "umgap_walk_builder_finish: copy failed"));
+        std::vector<std::pair<uint64_t, uint64_t>> ex(n_exc);
+        for (size_t i = 0; i < n_exc; i++) ex[i] = {raw[2 * i], raw[2 * i + 1]};
+        std::sort(ex.begin(), ex.end());
+        ex.erase(std::unique(ex.begin(), ex.end(), [](const std::pair<uint64_t, uint64_t>& p, const std::pair<uint64_t, uint64_t>& q) { return p.first == q.first; }), ex.end());
+        rc = set_walk_exceptions(x, ex);
         if (rc) return done(rc);
     }
     x->kind = 10;
@@ -1553,7 +1676,7 @@ int umgap_index_lookup9_dev(umgap_index* ix, const uint64_t* d_keys, size_t n, u
     if (rc) return rc;
     if (n) hipLaunchKernelGGL(k_lookup9, dim3(grid_for(n, 256, 256 * 8)), dim3(256), 0, (hipStream_t)stream, d_keys, n, ix->kind == 10 ? UMGAP_NONE : miss, d_out, ix->view);
     UMGAP_HIP(hipGetLastError());
-    if (ix->kind == 10) return walk_map_positions(ix, d_out, n, miss, (hipStream_t)stream);
+    if (ix->kind == 10) return walk_map_positions(ix, d_keys, d_out, n, miss, (hipStream_t)stream);
     return UMGAP_OK;
 }
 
@@ -1637,7 +1760,7 @@ int umgap_index_lookup9(umgap_index* ix, const uint64_t* keys, size_t n, uint32_
         UMGAP_HIP_BREAK(hipEventRecord(ev.uploaded[slot], up));
         UMGAP_HIP_BREAK(hipStreamWaitEvent(run, ev.uploaded[slot], 0));
         hipLaunchKernelGGL(k_lookup9, dim3(grid_for(len)), dim3(256), 0, run, dk, len, walk ? UMGAP_NONE : miss, dout, ix->view);
-        if (walk && (rc = walk_map_positions(ix, dout, len, miss, run))) break;
+        if (walk && (rc = walk_map_positions(ix, dk, dout, len, miss, run))) break;
         UMGAP_HIP_BREAK(hipMemcpyAsync(out_pinned ? (void*)(out + off) : (void*)((char*)ix->h_stage[slot] + cap * 8), dout, len * 4, hipMemcpyDeviceToHost, run));
         UMGAP_HIP_BREAK(hipEventRecord(ev.done[slot], run));
         pending_off[slot] = off;
@@ -1698,15 +1821,21 @@ int umgap_index_dump9(const umgap_index* ix, uint64_t* keys45, uint32_t* taxa, s
     if (ix->kind == 10) {   // taxa[] holds window numbers: through the walk array, a chunk at a time
         const size_t have = std::min(n, cap), step = 16u << 20;
         uint32_t* d_tmp = nullptr;
-        if (have && hipMalloc((void**)&d_tmp, std::min(have, step) * 4) != hipSuccess) return fail(UMGAP_ERR_NOMEM, "umgap_index_dump9: hipMalloc failed");
+        uint64_t* d_tk = nullptr;
+        if (have && (hipMalloc((void**)&d_tmp, std::min(have, step) * 4) != hipSuccess || hipMalloc((void**)&d_tk, std::min(have, step) * 8) != hipSuccess)) {
+            if (d_tmp) (void)hipFree(d_tmp);
+            return fail(UMGAP_ERR_NOMEM, "umgap_index_dump9: hipMalloc failed");
+        }
         for (size_t o = 0; o < have && !rc; o += step) {
             const size_t len = std::min(step, have - o);
-            if (hipMemcpyAsync(d_tmp, taxa + o, len * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess) rc = fail(UMGAP_ERR_DEVICE, "umgap_index_dump9: copy failed");
-            if (!rc) rc = walk_map_positions(ix, d_tmp, len, 0u, ix->stream);
+            if (hipMemcpyAsync(d_tmp, taxa + o, len * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
+                hipMemcpyAsync(d_tk, keys45 + o, len * 8, hipMemcpyHostToDevice, ix->stream) != hipSuccess) rc = fail(UMGAP_ERR_DEVICE, "umgap_index_dump9: copy failed");
+            if (!rc) rc = walk_map_positions(ix, d_tk, d_tmp, len, 0u, ix->stream);
             if (!rc && (hipMemcpyAsync(taxa + o, d_tmp, len * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess || hipStreamSynchronize(ix->stream) != hipSuccess))
                 rc = fail(UMGAP_ERR_DEVICE, "umgap_index_dump9: copy failed");
         }
         if (d_tmp) (void)hipFree(d_tmp);
+        if (d_tk) (void)hipFree(d_tk);
         return rc;
     }
     return UMGAP_OK;

@@ -23,6 +23,7 @@
 #include <algorithm>
 
 #include "probe_common.hpp"
+#include "walk_ref.hpp"
 #include "window_locate.hpp"
 
 using namespace umgap;
@@ -44,14 +45,11 @@ __device__ __forceinline__ bool window_key(const uint8_t* __restrict__ bytes, ui
     return ok;
 }
 
-// positions (the table's values) -> taxa
-__global__ __launch_bounds__(256) void k_walk_map(const uint64_t* __restrict__ E, uint64_t n_E, uint32_t* __restrict__ vals, size_t n, uint32_t miss) {
+// the table's answers for `keys` (vals) -> taxa
+__global__ __launch_bounds__(256) void k_walk_map(WalkRef W, const uint64_t* __restrict__ keys, uint32_t* __restrict__ vals, size_t n, uint32_t miss) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t step = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += step) {
-        const uint32_t p = vals[i];
-        vals[i] = (p == UMGAP_NONE || p >= n_E) ? miss : (uint32_t)E[p];
-    }
+    for (; i < n; i += step) vals[i] = walk_taxon(W, vals[i], keys[i], miss);
 }
 
 // hits[gw] for every window gw of the reads (fragments of flen residues): a wave takes 64 consecutive windows
@@ -122,7 +120,7 @@ __device__ __forceinline__ uint32_t lane_result(const uint32_t (&res)[4], uint32
     return r4 == 0 ? v0 : (r4 == 1 ? v1 : (r4 == 2 ? v2 : v3));
 }
 
-__global__ __launch_bounds__(256) void k_walk_lookup_prot9(TableView H2, const uint64_t* __restrict__ E, uint64_t n_E, const uint8_t* __restrict__ bytes,
+__global__ __launch_bounds__(256) void k_walk_lookup_prot9(TableView H2, WalkRef W, const uint8_t* __restrict__ bytes,
                                                            const uint64_t* __restrict__ offsets, const uint64_t* __restrict__ out_offsets, size_t n_prot,
                                                            size_t n_windows, uint32_t miss, uint32_t* __restrict__ out) {
     constexpr uint32_t EVERY = 8;
@@ -158,13 +156,16 @@ __global__ __launch_bounds__(256) void k_walk_lookup_prot9(TableView H2, const u
         if (valid && j == 0) ok1 = locate(H2, key, local, tag) ? 1u : 0u;
         uint32_t res[4];
         wave_probe64_vals(H2, local, tag | (ok1 << 31), UMGAP_NONE, lane, res);
-        const uint32_t pos = lane_result(res, lane);
+        const uint64_t* E = W.E;
+        const uint64_t n_E = W.n;
+        const uint32_t q1 = lane_result(res, lane);                   // (shuffles: every lane takes part)
+        const uint64_t pos = (valid && j == 0) ? walk_position(W, q1, key) : WALK_NOPOS;
         // 2. the windows behind them
         const int a = (int)lane - (int)j;
-        const uint32_t apos = (uint32_t)__shfl((int)pos, a, 64);
-        const bool cand = g < n_windows && apos != UMGAP_NONE && (uint64_t)apos + j < n_E;
+        const uint64_t apos = (uint64_t)(uint32_t)__shfl((int)(uint32_t)pos, a, 64) | ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(pos >> 32), a, 64) << 32);
+        const bool cand = g < n_windows && apos != WALK_NOPOS && apos + j < n_E;
         uint64_t e = 0;
-        if (cand) e = E[(uint64_t)apos + j];
+        if (cand) e = E[apos + j];
         const uint32_t ey = (uint32_t)(e >> 32);
         const bool ok_self = cand && valid && (ey & 0x7FFFFFFFu) == ((uint32_t)key & 0x7FFFFFFFu) && (j == 0 || (ey >> 31));
         const uint64_t okm = __ballot(ok_self);
@@ -178,8 +179,8 @@ __global__ __launch_bounds__(256) void k_walk_lookup_prot9(TableView H2, const u
         if (walked) hit = (uint32_t)e;
         if (__any(again)) {                                            // wave-uniform
             wave_probe64_vals(H2, local2, tag2 | (ok2 << 31), UMGAP_NONE, lane, res);
-            const uint32_t p2 = lane_result(res, lane);
-            if (again && p2 != UMGAP_NONE && p2 < n_E) hit = (uint32_t)E[p2];
+            const uint32_t q2 = lane_result(res, lane);
+            if (again) hit = walk_taxon(W, q2, key, miss);
         }
         if (g < n_windows) out[g] = hit;
     }
@@ -191,12 +192,13 @@ namespace umgap {
 int walk_lookup_prot9(const umgap_index* ix, const uint8_t* d_bytes, const uint64_t* d_offsets, const uint64_t* d_out_offsets, size_t n_prot, size_t n_windows,
                       uint32_t miss, uint32_t* d_out, hipStream_t s) {
     if (n_windows) hipLaunchKernelGGL(k_walk_lookup_prot9, dim3((unsigned)std::max<size_t>(1, std::min<size_t>((n_windows + 255) / 256, 256 * 8))), dim3(256), 0, s, ix->view,
-                                      ix->d_walk, ix->n_walk, d_bytes, d_offsets, d_out_offsets, n_prot, n_windows, miss, d_out);
+                                      walk_ref_of(ix), d_bytes, d_offsets, d_out_offsets, n_prot, n_windows, miss, d_out);
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
 }
-int walk_map_positions(const umgap_index* ix, uint32_t* d_vals, size_t n, uint32_t miss, hipStream_t s) {
-    if (n) hipLaunchKernelGGL(k_walk_map, dim3((unsigned)std::max<size_t>(1, std::min<size_t>((n + 255) / 256, 256 * 16))), dim3(256), 0, s, ix->d_walk, ix->n_walk, d_vals, n, miss);
+// d_vals[i] = the table's answer for d_keys[i] (k_lookup9 with miss = UMGAP_NONE) -> the key's taxon, or `miss`
+int walk_map_positions(const umgap_index* ix, const uint64_t* d_keys, uint32_t* d_vals, size_t n, uint32_t miss, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_walk_map, dim3((unsigned)std::max<size_t>(1, std::min<size_t>((n + 255) / 256, 256 * 16))), dim3(256), 0, s, walk_ref_of(ix), d_keys, d_vals, n, miss);
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
 }
@@ -204,11 +206,21 @@ int walk_map_positions(const umgap_index* ix, uint32_t* d_vals, size_t n, uint32
 
 extern "C" {
 
+// how a walk-order index numbers its entries (walk_ref.hpp): the table's shift, the entries of the walk array, the exception list
+int umgap_index_walk_info(const umgap_index* ix, uint32_t* shift, uint64_t* n_entries, uint32_t* n_exceptions) {
+    if (!ix || ix->kind != 10) return fail(UMGAP_ERR_INVALID, "umgap_index_walk_info: not a walk-order index");
+    if (shift) *shift = ix->walk_shift;
+    if (n_entries) *n_entries = ix->n_walk;
+    if (n_exceptions) *n_exceptions = ix->n_walk_exc;
+    return UMGAP_OK;
+}
+
 // EXPERIMENT kept beside the product (tools/bench_walk_lookup.py; not in the public header): hits of every window of reads made of
 // fragments of exactly flen residues, anchors every `anchor_every` windows; d_stats (nullable): {windows answered by a walk, probes made}
 int umgap_walkproto_lookup(umgap_index* ix, const uint8_t* d_reads, uint64_t n_frag, uint32_t flen, uint32_t anchor_every,
                            uint32_t* d_hits, unsigned long long* d_stats, void* stream) {
     if (!ix || ix->kind != 10 || !d_reads || !d_hits || flen < 9 || anchor_every < 1 || anchor_every > 32) return fail(UMGAP_ERR_INVALID, "umgap_walkproto_lookup: bad argument");
+    if (ix->walk_shift) return fail(UMGAP_ERR_INVALID, "umgap_walkproto_lookup: the prototype reads 32-bit entry numbers (an index of fewer than 2^32 - 2^22 entries)");
     int rc = use_device(ix->device);
     if (rc) return rc;
     hipLaunchKernelGGL(k_walk_lookup, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, ix->view, ix->d_walk, ix->n_walk, d_reads, n_frag, flen, anchor_every, d_hits, d_stats);

@@ -23,13 +23,13 @@
 #include "prot_limits.hpp"
 #include "seedextend.hpp"
 #include "taxonomy.hpp"
+#include "walk_ref.hpp"
 
 #include <algorithm>
 #include <vector>
 
 namespace umgap {
 int ensure_stage(umgap_index* ix);   // index.hip
-int walk_map_positions(const umgap_index* ix, uint32_t* d_vals, size_t n, uint32_t miss, hipStream_t s);   // index_walk.hip
 int mark_seedextend_panics(const uint32_t* d_kept, const uint64_t* d_read_frags, size_t n_reads, uint32_t* d_out_taxon, uint32_t* d_out_status,
                            hipStream_t stream);
 }
@@ -69,8 +69,9 @@ __global__ __launch_bounds__(256) void k_frag_prepare(const uint64_t* __restrict
 // a window, 0 elsewhere.  A wave takes 128 consecutive positions per step: their 136 bytes are staged in the wave's LDS
 // strip, two probe batches of 64 go out back to back (8 sectors in flight per quad), results land coalesced.
 // n_avail >= n_bytes: bytes that may be read (a chunk cut inside a fragment brings the 8 bytes behind its last position along).
+// W.E != nullptr: a walk-order index -- the table's answer is the number of the key's entry (walk_ref.hpp) and the taxon comes from there.
 __global__ __launch_bounds__(256) void k_lookup_bytes9(TableView T, const uint8_t* __restrict__ bytes, const uint32_t* __restrict__ tails,
-                                                       uint32_t n_bytes, uint32_t n_avail, uint32_t* __restrict__ hits, uint32_t miss) {
+                                                       uint32_t n_bytes, uint32_t n_avail, uint32_t* __restrict__ hits, uint32_t miss, WalkRef W) {
     __shared__ uint8_t lds[4][144];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
     uint8_t* wb = lds[wv];
@@ -83,6 +84,7 @@ __global__ __launch_bounds__(256) void k_lookup_bytes9(TableView T, const uint8_
         const uint32_t tw0 = tails[(p0 >> 5) + (lane >> 5)], tw1 = p0 + 64 < n_bytes ? tails[((p0 + 64) >> 5) + (lane >> 5)] : 0xFFFFFFFFu;
         ProbeBatch B[2];
         uint32_t res[2][4];
+        uint64_t wkey[2];
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const uint32_t p = p0 + 64 * h + lane;
@@ -97,10 +99,21 @@ __global__ __launch_bounds__(256) void k_lookup_bytes9(TableView T, const uint8_
             }
             uint32_t local = 0, tag = 0, valid = 0;
             if (ok) valid = locate(T, key, local, tag) ? 1u : 0u;
+            wkey[h] = key;
             probe_issue(T, local, tag | (valid << 31), lane, B[h]);
         }
-        probe_eval_multi<2>(T, B, miss, lane, res);
-        if (j == 0) {
+        probe_eval_multi<2>(T, B, W.E ? UMGAP_NONE : miss, lane, res);
+        if (W.E) {      // the answer to lane L's key sits, quad-uniform, in quad L & 15 as round L >> 4: back to its lane, then through the walk array
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int src = 4 * (int)(lane & 15u);
+                const uint32_t v0 = (uint32_t)__shfl((int)res[h][0], src, 64), v1 = (uint32_t)__shfl((int)res[h][1], src, 64),
+                               v2 = (uint32_t)__shfl((int)res[h][2], src, 64), v3 = (uint32_t)__shfl((int)res[h][3], src, 64);
+                const uint32_t r4 = lane >> 4, q32 = r4 == 0 ? v0 : (r4 == 1 ? v1 : (r4 == 2 ? v2 : v3));
+                const uint32_t p = p0 + 64 * h + lane;
+                if (p < n_bytes) hits[p] = walk_taxon(W, q32, wkey[h], miss);
+            }
+        } else if (j == 0) {
 #pragma unroll
             for (int h = 0; h < 2; h++)
 #pragma unroll
@@ -327,8 +340,7 @@ extern "C" int umgap_index_lookup_records(umgap_index* ix, const uint8_t* bytes,
         UMGAP_HIP_BREAK(hipMemsetAsync(d_tails, 0, (nb / 32 + 8) * 4, run));
         hipLaunchKernelGGL(k_mark_tails, dim3((unsigned)std::min<size_t>((nf + 255) / 256, 1024)), dim3(256), 0, run, (const uint64_t*)d_off, nf, base + c0, base + c1, d_tails);
         hipLaunchKernelGGL(k_lookup_bytes9, dim3((unsigned)std::min<uint64_t>((nb + 511) / 512, 2048)), dim3(256), 0, run, T, (const uint8_t*)d_bytes, (const uint32_t*)d_tails,
-                           (uint32_t)nb, (uint32_t)navail, d_hits, walk ? UMGAP_NONE : miss_value);
-        if (walk && (rc = walk_map_positions(ix, d_hits, (size_t)nb, miss_value, run))) break;
+                           (uint32_t)nb, (uint32_t)navail, d_hits, miss_value, walk ? walk_ref_of(ix) : WalkRef{});
         UMGAP_HIP_BREAK(hipGetLastError());
         UMGAP_HIP_BREAK(hipMemcpyAsync(out_pinned ? (void*)(out_hits + c0) : ix->h_stage[slot], d_hits, nb * 4, hipMemcpyDeviceToHost, run));
         UMGAP_HIP_BREAK(hipEventRecord(ev.done[slot], run));
@@ -542,8 +554,7 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
         if (nf) hipLaunchKernelGGL(k_frag_prepare, dim3(gf), dim3(256), 0, s, L.off, (size_t)nf, base + b0, (uint32_t)nb, L.fstart, L.flen, L.tails, L.bad);
         if (nb) {
             const unsigned gb = (unsigned)std::min<uint64_t>((nb + 511) / 512, 2048);
-            hipLaunchKernelGGL(k_lookup_bytes9, dim3(gb), dim3(256), 0, s, T, L.bytes, L.tails, (uint32_t)nb, (uint32_t)nb, L.hits, walk ? UMGAP_NONE : 0u);
-            if (walk && (rc = walk_map_positions(ix, L.hits, (size_t)nb, 0u, s))) break;
+            hipLaunchKernelGGL(k_lookup_bytes9, dim3(gb), dim3(256), 0, s, T, L.bytes, L.tails, (uint32_t)nb, (uint32_t)nb, L.hits, 0u, walk ? walk_ref_of(ix) : WalkRef{});
             if (bound) hipLaunchKernelGGL(k_codes_to_ids, dim3(gb), dim3(256), 0, s, L.hits, (size_t)nb, (const uint32_t*)tx->d_id_of_pre);
         }
         if (seedextend && nf)
