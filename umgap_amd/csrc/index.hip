@@ -689,6 +689,96 @@ __global__ __launch_bounds__(256) void k_gather_policy(const uint64_t* __restric
     if (t < n) out[t] = acc;
 }
 
+// What does a STREAM beside the random reads cost?  The 64-byte quad gather, 8 in flight per lane, plus -- per probe -- SR bytes read
+// from and SW bytes written to a side buffer, contiguous per wave step (128 probes: 128 * S bytes as 16-byte lanes), like the key
+// and value streams of the lookup and exchange kernels.  (Round 4: the price list behind DESIGN.md's request model.)
+template <int SR, int SW>
+__global__ __launch_bounds__(256) void k_gather_rw(const uint64_t* __restrict__ slots, uint32_t nb, size_t n, const u32x4* __restrict__ side_in, u32x4* __restrict__ side_out,
+                                                   size_t side_vecs, uint32_t* __restrict__ out) {
+    constexpr int LANES = 4, U = 8;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = ((size_t)gridDim.x * blockDim.x) / LANES;
+    const uint32_t j = threadIdx.x % LANES, lane = threadIdx.x & 63;
+    const size_t wave = t >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    uint32_t acc = 0;
+    size_t step = 0;
+    for (size_t i = t / LANES; i < n; i += stride * U, step++) {
+        u32x4 e[U];
+        u32x4 r[(SR * 8 + 63) / 64 > 0 ? (SR * 8 + 63) / 64 : 1];
+        const size_t chunk = step * nwaves + wave;            // this wave step's 128 probes
+        // (the last step of the grid runs its 8 probes per lane past n, so there are up to a step's worth more chunks than n / 128:
+        // the streams stop at the end of the side buffers)
+        const bool in_r = (chunk + 1) * (SR * 8) <= side_vecs, in_w = (chunk + 1) * (SW * 8) <= side_vecs;
+        if constexpr (SR > 0) {
+#pragma unroll
+            for (int v = 0; v < (SR * 8 + 63) / 64; v++)
+                if (in_r && v * 64 + lane < SR * 8u) r[v] = __builtin_nontemporal_load(side_in + chunk * (SR * 8) + v * 64 + lane);
+                else r[v] = u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            size_t ii = i + (size_t)u * stride;
+            uint64_t h = mix45(ii * 0x9E3779B97F4A7C15ull >> 19);
+            uint32_t bucket = __umulhi((uint32_t)h, nb);
+            e[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(slots) + ((size_t)bucket * 4 + j));
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) acc ^= e[u].x ^ e[u].y ^ e[u].z ^ e[u].w;
+        if constexpr (SR > 0) {
+#pragma unroll
+            for (int v = 0; v < (SR * 8 + 63) / 64; v++) acc ^= r[v].x ^ r[v].w;
+        }
+        if constexpr (SW > 0) {
+#pragma unroll
+            for (int v = 0; v < (SW * 8 + 63) / 64; v++)
+                if (in_w && v * 64 + lane < SW * 8u) side_out[chunk * (SW * 8) + v * 64 + lane] = u32x4{acc, acc + 1u, acc + 2u, acc + 3u};
+        }
+    }
+    if (t < n) out[t] = acc;
+}
+
+// The same write stream with the store of step t - 1 issued BEHIND the loads of step t and the wait counted so that it covers the
+// loads only (vmcnt(stores)): the wave never waits for a store's acknowledgement before its next loads are evaluated.  If the price
+// of a write stream is the in-order return of loads and stores, this gets it back.
+template <int SW>
+__global__ __launch_bounds__(256) void k_gather_w_deferred(const uint64_t* __restrict__ slots, uint32_t nb, size_t n, u32x4* __restrict__ side_out, size_t side_vecs,
+                                                           uint32_t* __restrict__ out) {
+    constexpr int LANES = 4, U = 8, NST = (SW * 8 + 63) / 64;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = ((size_t)gridDim.x * blockDim.x) / LANES;
+    const uint32_t j = threadIdx.x % LANES, lane = threadIdx.x & 63;
+    const size_t wave = t >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    uint32_t acc = 0;
+    size_t step = 0;
+    bool have_prev = false;
+    size_t prev_chunk = 0;
+    for (size_t i = t / LANES; i < n; i += stride * U, step++) {
+        u32x4 e[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            size_t ii = i + (size_t)u * stride;
+            uint64_t h = mix45(ii * 0x9E3779B97F4A7C15ull >> 19);
+            uint32_t bucket = __umulhi((uint32_t)h, nb);
+            e[u] = load_policy<1>(reinterpret_cast<const u32x4*>(slots) + ((size_t)bucket * 4 + j));
+        }
+        const u32x4 sv = u32x4{acc, acc + 1u, acc + 2u, acc + 3u};
+#pragma unroll
+        for (int v = 0; v < NST; v++) {      // the previous step's store (every lane issues NST store instructions, so the count below holds; idle lanes write to a scratch line)
+            const bool real = have_prev && (prev_chunk + 1) * (SW * 8) <= side_vecs && v * 64 + lane < SW * 8u;
+            u32x4* dst = real ? side_out + prev_chunk * (SW * 8) + v * 64 + lane : side_out + side_vecs + lane;
+            asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(dst), "v"(sv) : "memory");
+        }
+        if constexpr (NST == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < U; u++) acc ^= e[u].x ^ e[u].y ^ e[u].z ^ e[u].w;
+        have_prev = true;
+        prev_chunk = step * nwaves + wave;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (t < n) out[t] = acc;
+}
+
 __global__ void k_fill(uint64_t* p, size_t n, uint64_t v) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -1839,6 +1929,32 @@ int umgap_index_dump9(const umgap_index* ix, uint64_t* keys45, uint32_t* taxa, s
         return rc;
     }
     return UMGAP_OK;
+}
+
+// EXPERIMENT kept beside the product (tools/gather_streams.py; not in the public header): n random 64-byte quad probes with
+// read_bytes read from d_side_in and write_bytes written to d_side_out per probe (0, 4, 8 or 16; the buffers hold side_bytes each:
+// n * bytes and a little more -- the streams stop where the buffers end)
+int umgap_bench_gather_rw_dev(umgap_index* ix, size_t n, uint32_t read_bytes, uint32_t write_bytes, const void* d_side_in, void* d_side_out, size_t side_bytes,
+                              uint32_t* d_out, void* stream) {
+    if (!ix || !d_out || (read_bytes && !d_side_in) || (write_bytes && !d_side_out)) return fail(UMGAP_ERR_INVALID, "umgap_bench_gather_rw_dev: null argument");
+    int rc = use_device(ix->device);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t nb = ix->view.n_resident;
+    const int g = 256 * 8;
+    const u32x4* in = (const u32x4*)d_side_in;
+    u32x4* outp = (u32x4*)d_side_out;
+#define UMGAP_RW(SR, SW) if (read_bytes == SR && write_bytes == SW) { hipLaunchKernelGGL((k_gather_rw<SR, SW>), dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, in, outp, side_bytes / 16, d_out); UMGAP_HIP(hipGetLastError()); return UMGAP_OK; }
+    if (read_bytes == 0 && (write_bytes == 0x104 || write_bytes == 0x110)) {      // 0x100 + bytes: the deferred-store form
+        const size_t vecs = side_bytes / 16 - 64;                                  // (64 vectors at the end: where idle lanes' stores go)
+        if (write_bytes == 0x104) hipLaunchKernelGGL((k_gather_w_deferred<4>), dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, outp, vecs, d_out);
+        else hipLaunchKernelGGL((k_gather_w_deferred<16>), dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, outp, vecs, d_out);
+        UMGAP_HIP(hipGetLastError());
+        return UMGAP_OK;
+    }
+    UMGAP_RW(0, 0) UMGAP_RW(4, 0) UMGAP_RW(8, 0) UMGAP_RW(16, 0) UMGAP_RW(0, 4) UMGAP_RW(0, 8) UMGAP_RW(0, 16) UMGAP_RW(8, 4) UMGAP_RW(8, 8) UMGAP_RW(16, 16)
+#undef UMGAP_RW
+    return fail(UMGAP_ERR_INVALID, "umgap_bench_gather_rw_dev: unsupported combination");
 }
 
 int umgap_bench_gather_dev(umgap_index* ix, size_t n, uint32_t bytes_per_probe, uint32_t* d_out, void* stream) {
