@@ -3,7 +3,7 @@
 128 GB table (8 in flight per lane, nothing stored per probe: ~50 G probes/s), plus -- per probe -- R bytes read from and W bytes
 written to a side buffer, contiguous per wave step like the key and value streams of the look-up and exchange kernels.  From the
 times: the price of a streamed 64-byte read and of a streamed 64-byte write in units of one random 64-byte read (the model behind
-DESIGN.md section 6: why a sharded step that must WRITE 9 bytes per k-mer cannot run at the replica's pace).  One JSON line.
+DESIGN.md section 7: why a sharded step that must WRITE 9 bytes per k-mer cannot run at the replica's pace).  One JSON line.
     python tools/gather_streams.py [n_keys] [n_probes]"""
 import ctypes as C
 import json
