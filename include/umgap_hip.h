@@ -296,8 +296,8 @@ int umgap_classify_prot9_dev(umgap_index* ix, umgap_taxonomy* tx, int method, fl
                              uint32_t fragments_per_read, int seedextend, uint32_t min_seed_size,
                              uint32_t max_gap_size, uint32_t* d_out_taxon, uint32_t* d_out_status, void* stream);
 /* Surface B with any aggregation strategy (UMGAP_STRATEGY_LCA_STAR forwards to the call above; `factor` as in
- * umgap_aggregate).  For MRTL and the hybrids a read with more than 64 distinct taxa surviving the count filter is also
- * UMGAP_READ_UNSUPPORTED: this kernel has no large-scratch pass behind it. */
+ * umgap_aggregate).  For MRTL and the hybrids a read with more than 64 distinct taxa surviving the count filter goes through a
+ * large-scratch pass behind the first launch (round 4); more than 128 is UMGAP_READ_UNSUPPORTED. */
 int umgap_classify_prot9_strategy_dev(umgap_index* ix, umgap_taxonomy* tx, int method, int strategy, float factor,
                                       float lower_bound, int ranked_only, const uint8_t* d_bytes,
                                       const uint64_t* d_frag_offsets, size_t n_reads, uint32_t fragments_per_read,

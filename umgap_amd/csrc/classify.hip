@@ -370,6 +370,8 @@ struct ProtScratch<true> {
     uint32_t keys[256], cnt[256];
     uint32_t reads[GROUP_VIEW_READ_WORDS];   // the per-read arrays of the group scratch; its survivor arrays lie over the byte staging area
 };
+// the large-scratch pass (BIG): one read per wave, up to 128 distinct taxa (general_read, agg_general.hpp)
+using ProtBigScratch = Scratch<128, 512>;
 
 // GENERAL = false: LCA* (the kernel of umgap_classify_prot9_dev, 4 workgroups per CU; 3 for GENERAL).  GENERAL = true: MRTL and the hybrids
 // through general_group -- the reads of a group sit at a fixed stride of 128 in the strip instead of back to back.
@@ -383,43 +385,57 @@ struct WalkView {
                                       // the short variant runs when none is set, the LONG one when only word 1 is
 };
 
-template <bool BOUND, bool GENERAL, bool WALK, bool LONG>
-__global__ __launch_bounds__(256, GENERAL ? 3 : 4) void k_classify_prot9(TableView T, TaxView V, int method, int strategy, float factor,
+// BIG (round 4): the large-scratch pass behind the GENERAL variants -- a read with more than 64 distinct taxa left after the count
+// filter (MRTL, hybrids) is put on the `defer` list by the first pass and worked through here, one read per wave (LONG geometry:
+// every read the first pass took fits it), with general_read's 128-taxon scratch; `todo` = that list, *defer_count its length.
+template <bool BOUND, bool GENERAL, bool WALK, bool LONG, bool BIG = false>
+__global__ __launch_bounds__(256, BIG ? 2 : (GENERAL ? 3 : 4)) void k_classify_prot9(TableView T, TaxView V, int method, int strategy, float factor,
                                                                       const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ foff, size_t n_reads,
                                                                       uint32_t F, uint32_t do_seed, uint32_t min_seed, uint32_t max_gap, float lower_bound,
-                                                                      uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status, WalkView WK) {
+                                                                      uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status, WalkView WK,
+                                                                      uint32_t* __restrict__ defer, uint32_t* __restrict__ defer_count, const uint32_t* __restrict__ todo) {
+    static_assert(!BIG || (GENERAL && LONG), "the large-scratch pass is a GENERAL, LONG kernel");
     __shared__ uint32_t lds_taxa[4][STRIP];
-    __shared__ ProtScratch<GENERAL> lds_scratch[4];
+    __shared__ std::conditional_t<BIG, ProtBigScratch, ProtScratch<GENERAL>> lds_scratch[4];
     // per-read limits of this variant (prot_limits.hpp); either way a group fills the strip and the byte staging area exactly
     constexpr uint32_t LIM_W = LONG ? PROT_LONG_WINDOWS : PROT_MAX_WINDOWS, LIM_B = LONG ? PROT_LONG_BYTES : PROT_MAX_BYTES, GRP = STRIP / LIM_W;
     static_assert(GRP * LIM_B == PROT_GROUP * PROT_MAX_BYTES, "both variants use the same staging area");
     __shared__ uint32_t lds_fstart[4][64], lds_fwin[4][64], lds_fbyte[4][64], lds_total[4][PROT_GROUP];
     __shared__ __attribute__((aligned(16))) uint8_t lds_bytes[4][PROT_GROUP * PROT_MAX_BYTES];   // also the LCA scratch of the aggregate stage (u32 arrays)
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
-    if (WK.gate) {
+    if (WK.gate && !BIG) {     // (the large-scratch pass needs no gate: its list is empty when no first pass ran)
         const uint32_t g0 = WK.gate[0], g1 = WK.gate[1], g2 = WK.gate[2];
         if (LONG ? (g0 != 0u || g1 == 0u || g2 != 0u) : ((g0 | g1) != 0u)) return;
     }
     uint32_t* wtaxa = lds_taxa[wv];
-    uint32_t* wkeys = lds_scratch[wv].keys;
-    uint32_t* wcnt = lds_scratch[wv].cnt;
+    uint32_t *wkeys, *wcnt;
+    if constexpr (BIG) {
+        wkeys = lds_scratch[wv].hkeys;      // (512 words: also the item list of the WALK variant's second phase)
+        wcnt = lds_scratch[wv].hcnt;
+        for (uint32_t i = lane; i < 512u; i += 64) { wkeys[i] = 0u; wcnt[i] = 0u; }
+    } else {
+        wkeys = lds_scratch[wv].keys;
+        wcnt = lds_scratch[wv].cnt;
+    }
     uint8_t* wbytes = lds_bytes[wv];
     uint32_t* wfstart = lds_fstart[wv];
     uint32_t* wfwin = lds_fwin[wv];
     uint32_t* wfbyte = lds_fbyte[wv];
     uint32_t* wowner = lds_taxa[wv];   // the strip is dead until the first probe results arrive: its head holds the lane -> run table
+    if constexpr (!BIG) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) { wkeys[lane + 64 * i] = 0u; wcnt[lane + 64 * i] = 0u; }
+        for (int i = 0; i < 4; i++) { wkeys[lane + 64 * i] = 0u; wcnt[lane + 64 * i] = 0u; }
+    }
     const bool tree_like = method != UMGAP_METHOD_RMQ;
     // group size: GRP reads (<= LIM_W windows each, so the group fits the strip), at most 64 fragments (one lane each)
-    uint32_t G = GRP;
+    uint32_t G = BIG ? 1u : GRP;
     if (G * F > 64) G = 64 / F;
     const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
-    const size_t n_groups = (n_reads + G - 1) / G;
+    const size_t n_groups = BIG ? (size_t)*defer_count : (n_reads + G - 1) / G;
     for (size_t grp = wave0; grp < n_groups; grp += nwaves) {
-        const size_t r0 = grp * G;
-        const uint32_t nr = (uint32_t)min((size_t)G, n_reads - r0);
+        const size_t r0 = BIG ? (size_t)todo[grp] : grp * G;
+        const uint32_t nr = BIG ? 1u : (uint32_t)min((size_t)G, n_reads - r0);
         const uint32_t nfr = nr * F;                       // fragments of the group, lane f owns fragment f
         // ---- group layout: lane f = fragment f of the group (read k = f / F) ----
         const uint32_t k_of = lane / F;
@@ -704,14 +720,27 @@ __global__ __launch_bounds__(256, GENERAL ? 3 : 4) void k_classify_prot9(TableVi
                 wave_lds_sync();
             }
         }
-        if constexpr (GENERAL) {
-            // ---- aggregate, any strategy: reads at stride 128; no large-scratch pass behind this kernel, so a read with more than
-            // 64 distinct surviving taxa is reported UMGAP_READ_UNSUPPORTED like the over-long ones ----
+        if constexpr (BIG) {
+            // ---- the large-scratch pass: the one read of the wave through general_read (up to 128 distinct taxa) ----
+            const uint32_t total = lds_total[wv][0];
+            uint32_t res_taxon = 0, res_status = UMGAP_READ_UNSUPPORTED;
+            bool ok = false;
+            if (total != 0xFFFFFFFFu)
+                ok = general_read<false, 128, 512, BOUND>(V, lds_scratch[wv], method, strategy, factor, lower_bound, wtaxa, nullptr, PROT_MAX_WINDOWS, lane, res_taxon, res_status);
+            if (!ok) { res_taxon = 0; res_status = UMGAP_READ_UNSUPPORTED; }
+            if (se_panic & ((F >= 64 ? 0ull : (1ull << F)) - 1ull)) { res_taxon = 0; res_status = UMGAP_READ_PANIC; }
+            wave_lds_sync();
+            if (lane == 0) { out_taxon[r0] = res_taxon; out_status[r0] = res_status; }
+            wave_lds_sync();
+            continue;
+        } else if constexpr (GENERAL) {
+            // ---- aggregate, any strategy: reads at stride 128; a read with more than 64 distinct surviving taxa goes to the `defer`
+            // list (the large-scratch pass behind this kernel: BIG), over-long ones are reported UMGAP_READ_UNSUPPORTED ----
             static_assert(GROUP_VIEW_SURVIVOR_WORDS * 4 <= PROT_GROUP * PROT_MAX_BYTES, "the group scratch must fit the staging area");
             GroupView GV = group_view_over(wkeys, wcnt, reinterpret_cast<uint32_t*>(wbytes), lds_scratch[wv].reads);
-            const uint64_t too_long = __ballot(lane < nr && lds_total[wv][lane] == 0xFFFFFFFFu);
-            general_group<BOUND>(V, GV, method, strategy, factor, lower_bound, wtaxa, PROT_MAX_WINDOWS, nr, lane, se_panic, F, r0, out_taxon, out_status, nullptr, nullptr,
-                                 too_long);
+            const uint64_t unsupported_reads = __ballot(lane < nr && lds_total[wv][lane] == 0xFFFFFFFFu);
+            general_group<BOUND>(V, GV, method, strategy, factor, lower_bound, wtaxa, PROT_MAX_WINDOWS, nr, lane, se_panic, F, r0, out_taxon, out_status, defer, defer_count,
+                                 unsupported_reads);
             wave_lds_sync();
             continue;
         }
@@ -890,9 +919,27 @@ int umgap::classify_prot9_gated(umgap_index* ix, umgap_taxonomy* tx, int method,
     WalkView WK;
     WK.W = walk_ref_of(ix);
     WK.gate = gate;
+    // MRTL / hybrids: the reads with more than 64 distinct taxa go to a list (one per stream, shared by the variants of a gated pair:
+    // at most one of them runs) that the large-scratch pass works through behind the first
+    uint32_t *d_count = nullptr, *d_list = nullptr;
+    if (general) {
+        if (n_reads >= 0xFFFFFFFFull) return fail(UMGAP_ERR_INVALID, "umgap_classify_prot9_dev: at most 2^32 - 2 reads per call");
+        uint32_t* d_defer = defer_list_for(tx, (hipStream_t)stream, (n_reads + 1) * sizeof(uint32_t));
+        if (!d_defer) return UMGAP_ERR_NOMEM;
+        d_count = d_defer;
+        d_list = d_defer + 1;
+        // (a gated pair: cleared once, before its first launch -- which is the LONG one when the reads have too many fragments for the short)
+        if (!gate || !long_variant || fragments_per_read > PROT_MAX_FRAGS) UMGAP_HIP(hipMemsetAsync(d_count, 0, sizeof(uint32_t), (hipStream_t)stream));
+    }
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, strategy, factor, d_bytes,
-                           d_frag_offsets, n_reads, fragments_per_read, seedextend ? 1u : 0u, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status, WK);
+                           d_frag_offsets, n_reads, fragments_per_read, seedextend ? 1u : 0u, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status, WK,
+                           d_list, d_count, (const uint32_t*)nullptr);
+    };
+    auto launch_big = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, strategy, factor, d_bytes,
+                           d_frag_offsets, n_reads, fragments_per_read, seedextend ? 1u : 0u, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status, WK,
+                           (uint32_t*)nullptr, d_count, (const uint32_t*)d_list);
     };
 #define UMGAP_PROT9(LONGV)                                                                                                                      \
     if (walk) {                                                                                                                                \
@@ -903,6 +950,11 @@ int umgap::classify_prot9_gated(umgap_index* ix, umgap_taxonomy* tx, int method,
     else { if (bound) launch(k_classify_prot9<true, false, false, LONGV>); else launch(k_classify_prot9<false, false, false, LONGV>); }
     if (long_variant) { UMGAP_PROT9(true) } else { UMGAP_PROT9(false) }
 #undef UMGAP_PROT9
+    // the large-scratch pass: behind an ungated launch, or behind the LONG launch of a gated pair (the second of the two)
+    if (general && (!gate || long_variant)) {
+        if (walk) { if (bound) launch_big(k_classify_prot9<true, true, true, true, true>); else launch_big(k_classify_prot9<false, true, true, true, true>); }
+        else { if (bound) launch_big(k_classify_prot9<true, true, false, true, true>); else launch_big(k_classify_prot9<false, true, false, true, true>); }
+    }
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
 }
