@@ -22,7 +22,7 @@ fn.restype = C.c_int
 fn.argtypes = [C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
 
 
-def run(n_keys=8_000_000_000, n=840_000_000, reps=3):
+def run(n_keys=8_000_000_000, n=840_000_000, reps=3, legs=None):
     dev = torch.device("cuda", 0)
     w = synth.SyntheticWorkload(n_tax=100_000, n_keys=1000, build_index=False)
     ix = Index.synthetic(n_keys, w.d_taxon_of_row, synth.MUL_A, synth.ADD_B, 0.5, 0, 1)
@@ -31,7 +31,7 @@ def run(n_keys=8_000_000_000, n=840_000_000, reps=3):
     side_out = torch.empty(n * 16 + (64 << 20), dtype=torch.uint8, device=dev)
     res = {"table_GB": round(ix.table_bytes / 1e9, 1), "probes": n, "legs": {}}
     base = None
-    for r, wr in ((0, 0), (4, 0), (8, 0), (16, 0), (0, 4), (0, 8), (0, 16), (8, 4), (8, 8), (16, 16), (0, 0x104), (0, 0x110)):
+    for r, wr in (legs or ((0, 0), (4, 0), (8, 0), (16, 0), (0, 4), (0, 8), (0, 16), (8, 4), (8, 8), (16, 16), (0, 0x104), (0, 0x110))):
         best = None
         for _ in range(reps + 1):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -58,5 +58,8 @@ def run(n_keys=8_000_000_000, n=840_000_000, reps=3):
 
 
 if __name__ == "__main__":
-    a = [int(x) for x in sys.argv[1:3]]
-    print(json.dumps(run(*a)))
+    if "--pmc" in sys.argv:     # under rocprofv3 --pmc: four legs, one launch each after a warm-up (tools/pmc_streams.sh)
+        print(json.dumps(run(reps=1, legs=((0, 0), (16, 0), (0, 4), (0, 16)))))
+    else:
+        a = [int(x) for x in sys.argv[1:3]]
+        print(json.dumps(run(*a)))
