@@ -31,7 +31,7 @@ def run(n_keys=8_000_000_000, n=840_000_000, reps=3, legs=None):
     side_out = torch.empty(n * 16 + (64 << 20), dtype=torch.uint8, device=dev)
     res = {"table_GB": round(ix.table_bytes / 1e9, 1), "probes": n, "legs": {}}
     base = None
-    for r, wr in (legs or ((0, 0), (4, 0), (8, 0), (16, 0), (0, 4), (0, 8), (0, 16), (8, 4), (8, 8), (16, 16), (0, 0x104), (0, 0x110))):
+    for r, wr in (legs or ((0, 0), (4, 0), (8, 0), (16, 0), (0, 4), (0, 8), (0, 16), (8, 4), (8, 8), (16, 16), (0, 0x104), (0, 0x110), (0, 0x204))):
         best = None
         for _ in range(reps + 1):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -48,6 +48,10 @@ def run(n_keys=8_000_000_000, n=840_000_000, reps=3, legs=None):
             # extra time over the pure gather, as random-read requests, per 64 bytes streamed
             extra_req = (best - base) / base * n               # in units of one random read
             leg["cost_per_64B_streamed_in_random_reads"] = round(extra_req / (n * (r + wr) / 64.0), 2)
+        if wr >= 0x200:
+            leg["cost_per_64B_streamed_in_random_reads"] = round((best - base) / base * n / (n * (wr - 0x200) / 64.0), 2)
+            res["legs"]["write %d B per probe as one no-return 8-byte atomic exchange per lane and step" % (wr - 0x200)] = leg
+            continue
         if wr >= 0x100:
             leg["cost_per_64B_streamed_in_random_reads"] = round((best - base) / base * n / (n * (wr - 0x100) / 64.0), 2)
             res["legs"]["write %d B per probe, the store issued behind the next step's loads (vmcnt excludes it)" % (wr - 0x100)] = leg

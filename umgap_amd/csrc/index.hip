@@ -779,6 +779,34 @@ __global__ __launch_bounds__(256) void k_gather_w_deferred(const uint64_t* __res
     if (t < n) out[t] = acc;
 }
 
+// The 4-byte-per-probe write stream as ONE no-return 8-byte atomic exchange per lane and wave step (512 B per 128 probes): an atomic is
+// executed at L2 and passes the vector cache as a request of its own kind -- does the write stream's price go with the store path?
+__global__ __launch_bounds__(256) void k_gather_w_atomic(const uint64_t* __restrict__ slots, uint32_t nb, size_t n, unsigned long long* __restrict__ side_out, size_t side_words,
+                                                         uint32_t* __restrict__ out) {
+    constexpr int LANES = 4, U = 8;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = ((size_t)gridDim.x * blockDim.x) / LANES;
+    const uint32_t j = threadIdx.x % LANES, lane = threadIdx.x & 63;
+    const size_t wave = t >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    uint32_t acc = 0;
+    size_t step = 0;
+    for (size_t i = t / LANES; i < n; i += stride * U, step++) {
+        u32x4 e[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            size_t ii = i + (size_t)u * stride;
+            uint64_t h = mix45(ii * 0x9E3779B97F4A7C15ull >> 19);
+            uint32_t bucket = __umulhi((uint32_t)h, nb);
+            e[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(slots) + ((size_t)bucket * 4 + j));
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) acc ^= e[u].x ^ e[u].y ^ e[u].z ^ e[u].w;
+        const size_t at = (step * nwaves + wave) * 64 + lane;
+        if (at < side_words) (void)__hip_atomic_exchange(side_out + at, ((unsigned long long)acc << 32) | acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (t < n) out[t] = acc;
+}
+
 __global__ void k_fill(uint64_t* p, size_t n, uint64_t v) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -1945,6 +1973,11 @@ int umgap_bench_gather_rw_dev(umgap_index* ix, size_t n, uint32_t read_bytes, ui
     const u32x4* in = (const u32x4*)d_side_in;
     u32x4* outp = (u32x4*)d_side_out;
 #define UMGAP_RW(SR, SW) if (read_bytes == SR && write_bytes == SW) { hipLaunchKernelGGL((k_gather_rw<SR, SW>), dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, in, outp, side_bytes / 16, d_out); UMGAP_HIP(hipGetLastError()); return UMGAP_OK; }
+    if (read_bytes == 0 && write_bytes == 0x204) {      // 0x200 + 4: the 4-byte stream as no-return 8-byte atomic exchanges
+        hipLaunchKernelGGL(k_gather_w_atomic, dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, (unsigned long long*)d_side_out, side_bytes / 8, d_out);
+        UMGAP_HIP(hipGetLastError());
+        return UMGAP_OK;
+    }
     if (read_bytes == 0 && (write_bytes == 0x104 || write_bytes == 0x110)) {      // 0x100 + bytes: the deferred-store form
         const size_t vecs = side_bytes / 16 - 64;                                  // (64 vectors at the end: where idle lanes' stores go)
         if (write_bytes == 0x104) hipLaunchKernelGGL((k_gather_w_deferred<4>), dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, outp, vecs, d_out);
