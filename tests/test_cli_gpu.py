@@ -447,15 +447,20 @@ def test_prot2tryp2lca_custom_pattern(tryptic):
     rc1, out1, err1 = run(["prot2tryp2lca", "-o", "-l", "5", "-L", "50", "-p", "([RK])([^P])", tryptic["idx"]], fasta)
     assert rc0 == 0 == rc1 and out1 == out0, err1
     table = dict(l.split("\t") for l in open(tryptic["tsv"]).read().splitlines())
-    pat = re.compile("(K)([^P])")
-    want = []
-    for r, prot in enumerate(prots):
-        want.append(">p%d" % r)
-        cut = pat.sub(r"\1\n\2", pat.sub(r"\1\n\2", prot)).replace("*", "\n")
-        want += [table.get(pep, "0") for pep in cut.split("\n") if 5 <= len(pep) <= 50]
-    rc2, out2, err2 = run(["prot2tryp2lca", "-o", "-l", "5", "-L", "50", "--pattern", "(K)([^P])", tryptic["idx"]], fasta)
-    assert rc2 == 0 and out2.decode().splitlines() == want, err2
-    assert out2 != out0
+    # (the pattern in the `regex` crate's spelling, the same in Python's): another enzyme, a class, case-insensitive, named groups
+    for rust, py in [("(K)([^P])",) * 2, ("([KRH])([^PD])",) * 2, ("(?i)([kr])([^p])",) * 2, ("(?P<cut>[KR])(?P<next>[^P])",) * 2, (r"([KR])([^P])\z", r"([KR])([^P])\Z")]:
+        pat = re.compile(py)
+        want = []
+        for r, prot in enumerate(prots):
+            want.append(">p%d" % r)
+            cut = pat.sub(r"\1\n\2", pat.sub(r"\1\n\2", prot)).replace("*", "\n")
+            want += [table.get(pep, "0") for pep in cut.split("\n") if 5 <= len(pep) <= 50]
+        rc2, out2, err2 = run(["prot2tryp2lca", "-o", "-l", "5", "-L", "50", "--pattern", rust, tryptic["idx"]], fasta)
+        assert rc2 == 0 and out2.decode().splitlines() == want, (rust, err2)
+        assert (out2 == out0) == (rust.startswith("(?") ), rust      # the two spellings of the default cut like the default
+    for refused in ("(K)(?=A)", r"(K)\1"):       # the crate has no look-around and no backreferences
+        rc, _, err = run(["prot2tryp2lca", "-p", refused, tryptic["idx"]], fasta)
+        assert rc == 1 and err.startswith(b"Error: regex parse error"), err
     rc, _, err = run(["prot2tryp2lca", "-p", "([KR", tryptic["idx"]], fasta)
     assert rc == 1 and err.startswith(b"Error: ")
 

@@ -239,3 +239,49 @@ def test_threaded_host_code_under_thread_sanitizer(tmp_path):
     assert out == want_un
     p3 = subprocess.run([exe, "seedextend", "-g1", "-s3"], input=text, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)   # a pipe in
     assert p3.returncode == 0 and p3.stdout == want_se, p3.stderr[-2000:]
+
+
+def test_cleavage_pattern_rewriter_against_python_re(tmp_path):
+    """`umgap prot2tryp2lca -p <regex>` (src/commands/prot2tryp2lca.rs:65-68,96,112-115): the pattern is written in the syntax of
+    Rust's `regex` crate and applied as replace_all(.., "$1\\n$2") twice.  umgap_amd/csrc/host/cleave_pattern.hpp rewrites it for
+    std::regex; on the subset both read, Python's `re` reads it the same way and is the checker here (ASan + UBSan build).
+    What the crate refuses (look-around, backreferences) and what this build cannot express must be refused, not misread."""
+    import re
+    import shutil
+    import subprocess
+    cxx = shutil.which("g++") or shutil.which("clang++")
+    if not cxx:
+        pytest.skip("no C++ compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "cleave_pattern_check")
+    subprocess.run([cxx, "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-o", exe, os.path.join(root, "tests", "native", "cleave_pattern_check.cpp")], check=True)
+    # (the crate's spelling, Python's spelling of the same pattern)
+    good = [("([KR])([^P])",) * 2, ("([RK])([^P])",) * 2, ("(K)([^P])",) * 2, ("([KR])(.)",) * 2, ("([KRH])([^PD])",) * 2, ("(K|R)([^P])",) * 2,
+            ("(?i)([kr])([^p])",) * 2, ("(?P<a>[KR])(?P<b>[^P])",) * 2, ("(?<a>[KR])(?<b>[^P])", "(?P<a>[KR])(?P<b>[^P])"), ("K",) * 2, ("(K)",) * 2,
+            (r"\A(M)(.)",) * 2, (r"([KR])([^P])\z", r"([KR])([^P])\Z"), ("(?:K|R)([^P])",) * 2, ("([[:upper:]])(P)", "([A-Z])(P)"), (r"(K)(\x{41})", r"(K)(\x41)"),
+            ("(K+?)(A)",) * 2, ("(K{2,3})([^P])",) * 2, ("([FWY])([^P])",) * 2, ("([]K])(A)", r"([\]K])(A)"), (r"(\w)(\*)",) * 2, ("(?m)^(M)(.)",) * 2,
+            ("([^A-J])([L-Z])",) * 2, ("(D)()",) * 2, ("()(D)",) * 2]
+    bad = ["(K)(?=A)", "(K)(?!P)", "(?<=K)(A)", r"(K)\1", "([KR", "(K", r"(\pL)(A)", "(?s)(K)(.)", "(?x)(K) (.)", "(K)([a-z&&[^p]])", "(K)((?i)a)", "(K)(A)\\", "*K"]
+    rng = np.random.default_rng(23)
+    letters = "ACDEFGHIKLMNPQRSTVWY"
+    seqs = ["", "K", "KR", "KP", "AKRPKAAKKRA", "MMKA", "A]AKA*KKKA", "kraKRPkp"]
+    seqs += ["".join(rng.choice(list(letters + "KRKRP*"), int(rng.integers(1, 80)))) for _ in range(60)]
+    feed, want = [], []
+    for rust, py in good:
+        pat = re.compile(py)
+        for s in seqs:
+            feed.append("%s\t%s\n" % (rust, s))
+            want.append(pat.sub(lambda m: (m.group(1) if pat.groups >= 1 else "") + "|" + (m.group(2) if pat.groups >= 2 else ""),
+                                pat.sub(lambda m: (m.group(1) if pat.groups >= 1 else "") + "\n" + (m.group(2) if pat.groups >= 2 else ""), s)).replace("\n", "|"))
+    for rust in bad:
+        feed.append("%s\tAKA\n" % rust)
+        want.append(None)
+    p = subprocess.run([exe], input="".join(feed).encode(), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    got = p.stdout.decode().split("\n")[:-1]
+    assert len(got) == len(want)
+    for line, g, w in zip(feed, got, want):
+        if w is None:
+            assert g.startswith("ERROR regex parse error:"), (line, g)
+        else:
+            assert g == w, (line, g, w)

@@ -20,6 +20,7 @@
 
 #include "../../../include/umgap_hip.h"
 #include "async_io.hpp"
+#include "cleave_pattern.hpp"
 #include "fastpath.hpp"
 #include "fuse_parse.hpp"
 #include "text.hpp"
@@ -778,19 +779,19 @@ int cmd_prot2tryp2lca(const std::vector<std::string>& args) {
     const std::string pattern = p.get("pattern").value_or("([KR])([^P])");
     const bool default_pattern = pattern == "([KR])([^P])";
     // -p <regex> (src/commands/prot2tryp2lca.rs:65-68,96,112-115): replace_all(pattern, "$1\n$2") applied twice, host side.
-    // The reference compiles it with Rust's `regex` crate; here it is std::regex (ECMAScript), which reads the common
-    // subset -- literals, classes, groups, alternation, quantifiers -- the same way.  The default pattern keeps the scanner below.
-    std::regex custom;
+    // The reference compiles it with Rust's `regex` crate; cleave_pattern.hpp rewrites that syntax for std::regex and refuses
+    // what the crate refuses (look-around, backreferences).  The default pattern keeps the scanner below.
+    CleavePattern custom;
     if (!default_pattern) {
-        try { custom = std::regex(pattern, std::regex::ECMAScript | std::regex::optimize); }
-        catch (const std::regex_error& e) { throw CliError(std::string("regex parse error: ") + e.what()); }
+        try { custom = compile_cleave_pattern(pattern); }
+        catch (const CleavePatternError& e) { throw CliError(e.what()); }
     }
     std::string path = need_positional(p, "fst-file");
     umgap_index* ix = open_index(path);
     auto expand = [&](std::string_view seq_in, StringBatch& b) {
         std::string cut;
         if (!default_pattern) {
-            cut = std::regex_replace(std::regex_replace(std::string(seq_in), custom, "$1\n$2"), custom, "$1\n$2");   // twice: a letter can end one match and start the next
+            cut = custom.cut(std::string(seq_in));
         }
         const std::string_view seq = default_pattern ? seq_in : std::string_view(cut);
         size_t st = 0;
