@@ -355,6 +355,13 @@ typedef struct umgap_sharded umgap_sharded;
 int umgap_comm_unique_id(uint8_t* id128);
 int umgap_comm_init_rank(const uint8_t* id128, int world, int rank, int device, umgap_comm** out);
 int umgap_comm_init_local(int world, int device, umgap_comm** out_ranks /* world handles */);
+/* The process-per-rank communicator WITHOUT RCCL: every rank is its own process (on its own GPU, or several sharing one --
+ * which RCCL refuses), the all-to-all reads the peers' send buffers through hipIpc memory handles (device-to-device copies;
+ * between GPUs they travel over xGMI peer access), the handles and the barrier live in a POSIX shared-memory block called
+ * `name` ("/something": rank 0 creates it, the others wait for it, it is unlinked once all are attached).  Collective.  Each
+ * exchange is host-synchronised (two barriers), so it is the rehearsal and fall-back transport, not the fast one.
+ * UMGAP_IPC_TIMEOUT_S (default 120): how long a rank waits for the others before it gives up (every rank then fails). */
+int umgap_comm_init_ipc(const char* name, int world, int rank, int device, umgap_comm** out);
 int umgap_comm_world(const umgap_comm* c);
 int umgap_comm_rank(const umgap_comm* c);
 /* Collective: every rank sends a known pattern of `bytes_per_peer` bytes to every rank INCLUDING itself through the transport

@@ -1314,6 +1314,7 @@ inline std::unique_ptr<Aggregator> make_aggregator(const Taxonomy& tx, Method m,
 // reference could print for this record; throws Error/Panic where every order errors.
 struct RecordOutcome {
     std::set<TaxonId> printed;       // possible outputs
+    std::set<TaxonId> raw;           // the aggregates they are the snaps of
     std::set<TaxonId> unknown;       // possible UnknownTaxon aborts
     bool may_panic = false;
     bool empty = false;              // counts.is_empty() => literal "1"
@@ -1330,7 +1331,7 @@ inline RecordOutcome taxa2agg_record(const Aggregator& agg, const std::vector<st
     ro.may_panic = ao.may_panic;
     for (TaxonId a : ao.ok) {
         if (a >= snapping.size() || !snapping[a]) ro.may_panic = true;  // snapping[aggregate].unwrap() (:178)
-        else ro.printed.insert(*snapping[a]);
+        else { ro.printed.insert(*snapping[a]); ro.raw.insert(a); }
     }
     return ro;
 }
@@ -1370,7 +1371,8 @@ inline void taxa2agg(std::istream& in, std::ostream& out, std::ostream& err, con
         if (ro.may_panic) throw Panic("index out of bounds / unwrap on None");
         Record o;
         o.header = record.header;
-        o.sequence.push_back(std::to_string(pick(ro.printed)));
+        // the product breaks a tie among the AGGREGATES (the nodes of the unsnapped tree) and snaps the winner -- not among the snaps
+        o.sequence.push_back(std::to_string(ro.empty ? *ro.printed.begin() : *snapping[pick(ro.raw)]));
         writer.write_record(o);
     }
 }

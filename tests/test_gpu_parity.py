@@ -1187,6 +1187,35 @@ def test_sharded_table_local_ranks_match_whole_table(api, torch_cuda, world, pie
             assert torch.equal(got[(r, m)][0], want[(r, m)][0]), (world, r, m, "taxon")
 
 
+@pytest.mark.parametrize("world,pieces,own_share", [(3, 2, "probed in place"), (2, 3, "packed")])
+def test_sharded_table_ranks_as_processes(api, torch_cuda, world, pieces, own_share):
+    """The N-rank protocol with every rank its own PROCESS (own HIP context, own shard of the table, own reads): what
+    `torchrun --nproc-per-node N` starts on a node, here with the ranks sharing the one GPU of the box.  RCCL refuses two ranks
+    on one device, so the exchange runs over umgap_comm_init_ipc (peers' send buffers mapped with hipIpc handles, barrier in
+    shared memory); pack / probe / gather are the shipped kernels.  Each rank checks its answers against the whole table
+    (tests/ipc_rank_worker.py) -- hits and three fused pipelines -- and the communicator's own pattern test."""
+    import subprocess
+    import sys
+    import uuid
+    here = os.path.dirname(os.path.abspath(__file__))
+    name = "/umgap-test-%s" % uuid.uuid4().hex[:12]
+    env = dict(os.environ, UMGAP_SHARD_NO_LOCAL="1" if own_share == "packed" else "0", UMGAP_IPC_TIMEOUT_S="240")
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "ipc_rank_worker.py"), name, str(world), str(r), str(pieces)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=600)[0].decode())
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, "rank %d:\n%s" % (r, out[-3000:])
+        assert "rank %d of %d" % (r, world) in out and "bit-identical" in out, out[-2000:]
+    assert not os.path.exists("/dev/shm" + name)       # the control block's name is gone once everybody is attached
+
+
 @pytest.mark.parametrize("world,stride,frags,pieces,own_share", [(3, 128, 0, 2, "probed in place"), (2, 40, 2, 3, "probed in place"), (4, 7, 0, 1, "probed in place"),
                                                                  (2, 64, 64, 2, "probed in place"), (5, 1, 0, 2, "probed in place"), (2, 33, 33, 1, "probed in place"),
                                                                  (1, 84, 2, 2, "packed"), (3, 84, 0, 2, "packed"), (2, 40, 2, 3, "packed")])

@@ -114,6 +114,7 @@ def load():
         "umgap_comm_unique_id": (i32, [vp]),
         "umgap_comm_init_rank": (i32, [vp, i32, i32, i32, pp]),
         "umgap_comm_init_local": (i32, [i32, i32, pp]),
+        "umgap_comm_init_ipc": (i32, [C.c_char_p, i32, i32, i32, pp]),
         "umgap_comm_world": (i32, [vp]),
         "umgap_synth_tryptic_dev": (i32, [vp, u64, sz, u64, vp, vp, i32, vp]),
         "umgap_digest_tryp_dev": (i32, [vp, vp, sz, vp, sz, C.POINTER(sz), i32, vp]),

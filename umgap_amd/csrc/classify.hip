@@ -400,8 +400,12 @@ __global__ __launch_bounds__(256, BIG ? 2 : (GENERAL ? 3 : 4)) void k_classify_p
     // per-read limits of this variant (prot_limits.hpp); either way a group fills the strip and the byte staging area exactly
     constexpr uint32_t LIM_W = LONG ? PROT_LONG_WINDOWS : PROT_MAX_WINDOWS, LIM_B = LONG ? PROT_LONG_BYTES : PROT_MAX_BYTES, GRP = STRIP / LIM_W;
     static_assert(GRP * LIM_B == PROT_GROUP * PROT_MAX_BYTES, "both variants use the same staging area");
+    // a read is staged at the byte alignment it has in global memory (whole dwords move: a quarter of the load / store instructions
+    // of a byte copy), so its region is four bytes longer than the longest read
+    constexpr uint32_t LIM_BS = LIM_B + 4;
+    static_assert(GRP * LIM_BS <= PROT_GROUP * (PROT_MAX_BYTES + 4), "the staging area holds the regions of both variants");
     __shared__ uint32_t lds_fstart[4][64], lds_fwin[4][64], lds_fbyte[4][64], lds_total[4][PROT_GROUP];
-    __shared__ __attribute__((aligned(16))) uint8_t lds_bytes[4][PROT_GROUP * PROT_MAX_BYTES];   // also the LCA scratch of the aggregate stage (u32 arrays)
+    __shared__ __attribute__((aligned(16))) uint8_t lds_bytes[4][PROT_GROUP * (PROT_MAX_BYTES + 4)];   // also the LCA scratch of the aggregate stage (u32 arrays)
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
     if (WK.gate && !BIG) {     // (the large-scratch pass needs no gate: its list is empty when no first pass ran)
         const uint32_t g0 = WK.gate[0], g1 = WK.gate[1], g2 = WK.gate[2];
@@ -433,19 +437,32 @@ __global__ __launch_bounds__(256, BIG ? 2 : (GENERAL ? 3 : 4)) void k_classify_p
     const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
     const size_t n_groups = BIG ? (size_t)*defer_count : (n_reads + G - 1) / G;
+    // group layout: lane f = fragment f of the group (read k = f / F).  The four fragment offsets a lane needs are fetched ONE GROUP
+    // AHEAD (they arrive while the group before is worked on: one dependent round trip less per group)
+    const uint32_t k_of = lane / F;
+    uint64_t ahead[4] = {0, 0, 0, 0};
+    auto fetch_offsets = [&](size_t r0x, uint32_t nfrx, uint64_t (&o)[4]) {
+        if (lane < nfrx) {
+            const uint64_t* fo = foff + r0x * F;
+            o[0] = fo[lane]; o[1] = fo[lane + 1]; o[2] = fo[k_of * F]; o[3] = fo[k_of * F + F];
+        }
+    };
+    if constexpr (!BIG) {
+        if (wave0 < n_groups) fetch_offsets(wave0 * G, (uint32_t)min((size_t)G, n_reads - wave0 * G) * F, ahead);
+    }
     for (size_t grp = wave0; grp < n_groups; grp += nwaves) {
         const size_t r0 = BIG ? (size_t)todo[grp] : grp * G;
         const uint32_t nr = BIG ? 1u : (uint32_t)min((size_t)G, n_reads - r0);
         const uint32_t nfr = nr * F;                       // fragments of the group, lane f owns fragment f
-        // ---- group layout: lane f = fragment f of the group (read k = f / F) ----
-        const uint32_t k_of = lane / F;
+        uint64_t off4[4] = {ahead[0], ahead[1], ahead[2], ahead[3]};
+        if constexpr (BIG) fetch_offsets(r0, nfr, off4);
+        else if (grp + nwaves < n_groups) fetch_offsets((grp + nwaves) * G, (uint32_t)min((size_t)G, n_reads - (grp + nwaves) * G) * F, ahead);
         uint32_t my_len = 0, my_rel = 0, rd_bytes = 0;
         uint64_t rd_base = 0;
         if (lane < nfr) {
-            const uint64_t* fo = foff + r0 * F;
-            const uint64_t b0 = fo[lane], b1 = fo[lane + 1];
-            rd_base = fo[k_of * F];
-            const uint64_t rb = fo[k_of * F + F] - rd_base;
+            const uint64_t b0 = off4[0], b1 = off4[1];
+            rd_base = off4[2];
+            const uint64_t rb = off4[3] - rd_base;
             rd_bytes = rb > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)rb;
             my_len = (b1 - b0) > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(b1 - b0);
             my_rel = (uint32_t)(b0 - rd_base);
@@ -472,9 +489,9 @@ __global__ __launch_bounds__(256, BIG ? 2 : (GENERAL ? 3 : 4)) void k_classify_p
         }
         wfstart[lane] = lane < nfr ? my_start : 0xFFFFFFFFu;
         wfwin[lane] = my_win;
-        wfbyte[lane] = k_of * LIM_B + my_rel;
+        wfbyte[lane] = k_of * LIM_BS + ((uint32_t)(uintptr_t)(bytes + rd_base) & 3u) + my_rel;
         if (lane < nfr && lane % F == 0) lds_total[wv][k_of] = unsupported ? 0xFFFFFFFFu : rd_win;
-        // ---- stage the reads' bytes (region k * PROT_MAX_BYTES per read; the loads of all reads are in flight together) ----
+        // ---- stage the reads' bytes (region k * LIM_BS per read; the loads of all reads are in flight together) ----
         for (uint32_t k = 0; k < nr; k++) {
             const uint32_t src = k * F;
             const uint32_t nb_lo = (uint32_t)__shfl((int)rd_bytes, (int)src, 64);
@@ -482,7 +499,11 @@ __global__ __launch_bounds__(256, BIG ? 2 : (GENERAL ? 3 : 4)) void k_classify_p
             const bool skip = (bool)__shfl((int)unsupported, (int)src, 64);
             if (skip) continue;   // wave-uniform
             const uint8_t* gp = bytes + (((uint64_t)b_hi << 32) | b_lo);
-            for (uint32_t i = lane; i < nb_lo; i += 64) wbytes[k * LIM_B + i] = gp[i];
+            const uint32_t a = (uint32_t)(uintptr_t)gp & 3u;               // (the dwords around the read's ends lie in the words its own bytes lie in)
+            const uint32_t* gw = reinterpret_cast<const uint32_t*>(gp - a);
+            uint32_t* lw = reinterpret_cast<uint32_t*>(wbytes + k * LIM_BS);
+            const uint32_t nd = (nb_lo + a + 3u) >> 2;
+            for (uint32_t i = lane; i < nd; i += 64) lw[i] = gw[i];
         }
         wave_lds_sync();
         // ---- probe: every lane walks a run of R consecutive windows of ONE fragment with a rolling key ----
@@ -555,12 +576,12 @@ __global__ __launch_bounds__(256, BIG ? 2 : (GENERAL ? 3 : 4)) void k_classify_p
                         uint64_t wkey = akey;
                         uint32_t wpoison = 0;
                         bool go = true;
-                        for (uint32_t c0 = 0; go && c0 < run_cnt; c0 += 4) {
-                            uint64_t e[4];
+                        for (uint32_t c0 = 0; go && c0 < run_cnt; c0 += 16) {
+                            uint64_t e[16];
 #pragma unroll
-                            for (uint32_t k = 0; k < 4; k++) e[k] = (c0 + k < run_cnt && pos + c0 + k < WR.n) ? WR.E[pos + c0 + k] : WALK_PAD_ENTRY;   // (past the end: low bits that match no window)
+                            for (uint32_t k = 0; k < 16; k++) e[k] = (c0 + k < run_cnt && pos + c0 + k < WR.n) ? WR.E[pos + c0 + k] : WALK_PAD_ENTRY;   // (past the end: low bits that match no window)
 #pragma unroll
-                            for (uint32_t k = 0; k < 4; k++) {
+                            for (uint32_t k = 0; k < 16; k++) {
                                 const uint32_t t = c0 + k;
                                 if (go && t < run_cnt) {
                                     bool ok = true;

@@ -23,12 +23,24 @@
 // Transports: RCCL (librccl.so.1 resolved at run time with dlopen, so the library loads without it; inside a PyTorch
 // process that is PyTorch's own copy) and a LOCAL hub -- all ranks are threads of one process on one GPU, the all-to-all is
 // device-to-device copies ordered with events -- which lets the whole N-rank protocol be checked on a single-GPU box.
+// And an IPC hub: the ranks are separate PROCESSES (one per GPU, or several sharing one GPU) that map each other's send
+// buffers with hipIpc memory handles and copy their share out of them; a block of POSIX shared memory carries the handles and
+// the barrier.  No RCCL involved: it is how the process-per-rank protocol is run where RCCL refuses (two ranks on one GPU).
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <rccl/rccl.h>
+#include <sched.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <cstdlib>
+#include <map>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -122,12 +134,88 @@ struct LocalHub {
     }
 };
 
+// the control block of an IPC communicator, in POSIX shared memory (rank 0 creates and initialises it)
+struct IpcCtl {
+    std::atomic<uint32_t> ready;                  // 1: the block is initialised
+    std::atomic<uint32_t> arrived, generation;    // the barrier
+    std::atomic<uint32_t> failed;                 // a rank gave up: every barrier from here on fails
+    struct Slot {
+        hipIpcMemHandle_t mem;      // the allocation the rank's send buffer lies in
+        uint64_t offset, alloc_bytes, alloc_base;
+        uint32_t val;
+        uint32_t pad;
+    } slot[64];
+};
+static_assert(std::atomic<uint32_t>::is_always_lock_free, "the barrier words are shared between processes");
+
+// one rank's end of it
+struct IpcHub {
+    IpcCtl* ctl = nullptr;
+    int world = 0, rank = 0;
+    double timeout_s = 120.0;
+    std::map<const void*, hipIpcMemHandle_t> mine;             // allocation base -> its handle
+    std::vector<std::map<std::string, void*>> opened;          // per peer: handle (+ base, size) -> where it is mapped here
+    int barrier() {
+        const uint32_t g = ctl->generation.load(std::memory_order_acquire);
+        if (ctl->failed.load(std::memory_order_acquire)) return fail(UMGAP_ERR_DEVICE, "ipc communicator: another rank has failed");
+        if (ctl->arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == (uint32_t)world) {
+            ctl->arrived.store(0, std::memory_order_relaxed);
+            ctl->generation.fetch_add(1, std::memory_order_release);
+            return UMGAP_OK;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spins = 0; ctl->generation.load(std::memory_order_acquire) == g; spins++) {
+            if (ctl->failed.load(std::memory_order_acquire)) return fail(UMGAP_ERR_DEVICE, "ipc communicator: another rank has failed");
+            if (spins < 2000) { sched_yield(); continue; }
+            usleep(50);
+            if ((spins & 1023u) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) {
+                ctl->failed.store(1, std::memory_order_release);
+                return fail(UMGAP_ERR_DEVICE, "ipc communicator: rank " + std::to_string(rank) + " waited " + std::to_string((int)timeout_s) + " s at a barrier (UMGAP_IPC_TIMEOUT_S)");
+            }
+        }
+        return UMGAP_OK;
+    }
+    // where peer p's published buffer is mapped in this process
+    int peer_buffer(int p, const char** out) {
+        const IpcCtl::Slot& S = ctl->slot[p];
+        std::string key((const char*)&S.mem, sizeof(S.mem));
+        key.append((const char*)&S.alloc_base, 8).append((const char*)&S.alloc_bytes, 8);
+        auto it = opened[p].find(key);
+        if (it == opened[p].end()) {
+            void* ptr = nullptr;
+            hipError_t e = hipIpcOpenMemHandle(&ptr, S.mem, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) return fail(UMGAP_ERR_DEVICE, std::string("hipIpcOpenMemHandle (rank ") + std::to_string(p) + "'s buffer): " + hipGetErrorString(e));
+            it = opened[p].emplace(key, ptr).first;
+        }
+        *out = (const char*)it->second + S.offset;
+        return UMGAP_OK;
+    }
+    int publish(const void* send) {
+        void* base = nullptr;
+        size_t size = 0;
+        UMGAP_HIP(hipMemGetAddressRange((hipDeviceptr_t*)&base, &size, (hipDeviceptr_t)send));
+        auto it = mine.find(base);
+        if (it == mine.end()) {
+            hipIpcMemHandle_t h;
+            UMGAP_HIP(hipIpcGetMemHandle(&h, base));
+            it = mine.emplace(base, h).first;
+        }
+        IpcCtl::Slot& S = ctl->slot[rank];
+        S.mem = it->second;
+        S.offset = (uint64_t)((const char*)send - (const char*)base);
+        S.alloc_bytes = size;
+        S.alloc_base = (uint64_t)(uintptr_t)base;
+        return UMGAP_OK;
+    }
+};
+
 }  // namespace
 
 struct umgap_comm {
     int world = 1, rank = 0, device = 0;
     ncclComm_t nccl = nullptr;   // RCCL transport
     LocalHub* hub = nullptr;     // local transport
+    IpcHub* ipc = nullptr;       // process-per-rank transport over hipIpc handles
 };
 
 namespace {
@@ -153,6 +241,24 @@ int comm_alltoall(umgap_comm* c, const void* send, void* recv, size_t bytes, hip
         H.barrier();   // nobody re-records an event before every wait on it is enqueued
         return UMGAP_OK;
     }
+    if (c->ipc) {
+        // host-synchronised: the send buffer is complete before anybody reads it, and everybody has read it before it is rewritten
+        IpcHub& H = *c->ipc;
+        auto gave_up = [&](int code) { H.ctl->failed.store(1, std::memory_order_release); return code; };   // the other ranks leave their barriers
+        auto hip_ok = [&](hipError_t e, const char* what) { return e == hipSuccess ? UMGAP_OK : gave_up(fail(UMGAP_ERR_DEVICE, std::string("ipc exchange, ") + what + ": " + hipGetErrorString(e))); };
+        int rc = H.publish(send);
+        if (rc) return gave_up(rc);
+        if ((rc = hip_ok(hipStreamSynchronize(s), "the send side"))) return rc;
+        if ((rc = H.barrier())) return rc;
+        for (int p = 0; p < c->world; p++) {
+            if (p == c->rank && !with_self) continue;
+            const char* from = (const char*)send;
+            if (p != c->rank && (rc = H.peer_buffer(p, &from))) return gave_up(rc);
+            if ((rc = hip_ok(hipMemcpyAsync((char*)recv + (size_t)p * bytes, from + (size_t)c->rank * bytes, bytes, hipMemcpyDeviceToDevice, s), "copy from a peer"))) return rc;
+        }
+        if ((rc = hip_ok(hipStreamSynchronize(s), "the copies"))) return rc;
+        return H.barrier();
+    }
     Rccl* R = rccl();
     UMGAP_NCCL(R->GroupStart());
     for (int p = 0; p < c->world; p++) {
@@ -173,6 +279,17 @@ int comm_max_u32(umgap_comm* c, uint32_t* v) {
         uint32_t m = 0;
         for (uint32_t x : H.vals) m = x > m ? x : m;
         H.barrier();
+        *v = m;
+        return UMGAP_OK;
+    }
+    if (c->ipc) {
+        IpcHub& H = *c->ipc;
+        H.ctl->slot[c->rank].val = *v;
+        int rc = H.barrier();
+        if (rc) return rc;
+        uint32_t m = 0;
+        for (int p = 0; p < c->world; p++) m = std::max(m, H.ctl->slot[p].val);
+        if ((rc = H.barrier())) return rc;
         *v = m;
         return UMGAP_OK;
     }
@@ -616,6 +733,59 @@ int umgap_comm_init_local(int world, int device, umgap_comm** out_ranks) {
     return UMGAP_OK;
 }
 
+int umgap_comm_init_ipc(const char* name, int world, int rank, int device, umgap_comm** out) {
+    if (!name || !out) return fail(UMGAP_ERR_INVALID, "umgap_comm_init_ipc: null argument");
+    if (name[0] != '/' || strchr(name + 1, '/') || strlen(name) < 2 || strlen(name) > 200) return fail(UMGAP_ERR_INVALID, "umgap_comm_init_ipc: the name must look like \"/something\" (shm_open)");
+    if (world < 1 || world > 64 || rank < 0 || rank >= world) return fail(UMGAP_ERR_INVALID, "umgap_comm_init_ipc: need 0 <= rank < world <= 64");
+    int rc = use_device(device);
+    if (rc) return rc;
+    double timeout_s = 120.0;
+    if (const char* t = getenv("UMGAP_IPC_TIMEOUT_S")) { const double v = atof(t); if (v > 0) timeout_s = v; }
+    const auto t0 = std::chrono::steady_clock::now();
+    auto waited = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    int fd = -1;
+    if (rank == 0) {
+        fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0) return fail(UMGAP_ERR_IO, std::string("umgap_comm_init_ipc: shm_open(") + name + "): " + strerror(errno));
+        if (ftruncate(fd, sizeof(IpcCtl)) != 0) { const int e = errno; close(fd); shm_unlink(name); return fail(UMGAP_ERR_IO, std::string("umgap_comm_init_ipc: ftruncate: ") + strerror(e)); }
+    } else {
+        for (;;) {     // until rank 0 has created it at its full size
+            fd = shm_open(name, O_RDWR, 0600);
+            struct stat st;
+            if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(IpcCtl)) break;
+            if (fd >= 0) close(fd);
+            if (waited() > timeout_s) return fail(UMGAP_ERR_IO, std::string("umgap_comm_init_ipc: rank 0 did not create ") + name + " (UMGAP_IPC_TIMEOUT_S)");
+            usleep(1000);
+        }
+    }
+    void* mem = mmap(nullptr, sizeof(IpcCtl), PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    close(fd);
+    if (mem == MAP_FAILED) { if (rank == 0) shm_unlink(name); return fail(UMGAP_ERR_IO, std::string("umgap_comm_init_ipc: mmap: ") + strerror(errno)); }
+    IpcCtl* ctl = static_cast<IpcCtl*>(mem);       // (a fresh shm object is zero-filled: counters 0, nobody failed)
+    if (rank == 0) ctl->ready.store(1, std::memory_order_release);
+    else
+        while (!ctl->ready.load(std::memory_order_acquire)) {
+            if (waited() > timeout_s) { munmap(mem, sizeof(IpcCtl)); return fail(UMGAP_ERR_IO, "umgap_comm_init_ipc: rank 0 did not initialise the control block"); }
+            usleep(200);
+        }
+    IpcHub* H = new IpcHub();
+    H->ctl = ctl;
+    H->world = world;
+    H->rank = rank;
+    H->timeout_s = timeout_s;
+    H->opened.resize(world);
+    rc = H->barrier();                              // everybody is attached: the name can go (nothing is left behind by a crash later)
+    if (rank == 0) shm_unlink(name);
+    if (rc) { munmap(mem, sizeof(IpcCtl)); delete H; return rc; }
+    umgap_comm* c = new umgap_comm();
+    c->world = world;
+    c->rank = rank;
+    c->device = device;
+    c->ipc = H;
+    *out = c;
+    return UMGAP_OK;
+}
+
 int umgap_comm_world(const umgap_comm* c) { return c ? c->world : 0; }
 int umgap_comm_rank(const umgap_comm* c) { return c ? c->rank : -1; }
 
@@ -657,6 +827,12 @@ void umgap_comm_free(umgap_comm* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->nccl) (void)rccl()->CommDestroy(c->nccl);
+    if (c->ipc) {
+        for (auto& peer : c->ipc->opened)
+            for (auto& kv : peer) (void)hipIpcCloseMemHandle(kv.second);
+        munmap(c->ipc->ctl, sizeof(IpcCtl));
+        delete c->ipc;
+    }
     if (c->hub) {
         bool last;
         { std::lock_guard<std::mutex> g(c->hub->m); last = --c->hub->refs == 0; }

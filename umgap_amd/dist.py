@@ -62,6 +62,13 @@ class Comm:
         check(_lib.load().umgap_comm_init_local(world, device, arr))
         return [cls(arr[r], "local") for r in range(world)]
 
+    @classmethod
+    def ipc(cls, name, world, rank, device=0):
+        """Collective over `world` PROCESSES (one GPU each, or sharing one): hipIpc memory handles, no RCCL.  `name` = "/something"."""
+        h = C.c_void_p()
+        check(_lib.load().umgap_comm_init_ipc(name.encode(), world, rank, device, C.byref(h)))
+        return cls(h.value, "ipc")
+
     def selftest(self, bytes_per_peer=1 << 20):
         """Collective: a known pattern through the lookup's own transport, to every rank including this one."""
         check(_lib.load().umgap_comm_selftest(self._h, bytes_per_peer))
