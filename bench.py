@@ -61,6 +61,10 @@ def parse():
     ap.add_argument("--rehearse-cpu", action="store_true", help="CPU/gloo rehearsal of the multi-rank plumbing (no GPU, no kernels)")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds before self-launched ranks are killed")
     ap.add_argument("--sharded-child", default=None, help=argparse.SUPPRESS)   # internal: run the sharded section in this (child) process
+    ap.add_argument("--ipc-child", default=None, help=argparse.SUPPRESS)       # internal: one rank of the two-process leg (file base)
+    ap.add_argument("--ipc-name", default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--ipc-world", type=int, default=2, help=argparse.SUPPRESS)
+    ap.add_argument("--ipc-rank", type=int, default=0, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -227,6 +231,105 @@ def run_sharded_child(args, rank, world, want_first):
     return {"error": "the sharded child ended with %s" % (status,), "output_tail": tail}
 
 
+def run_ipc_children(args, want_first, local_rank, world=2):
+    """The N-rank protocol with every rank its OWN PROCESS on the one GPU of the box (RCCL refuses two ranks on a device, so the
+    exchange runs over umgap_comm_init_ipc: peers' send buffers mapped with hipIpc handles, host-synchronised).  Rank r holds shard
+    r of `world` and classifies the r-th part of the step's pairs; each checks its answers against the replica's.  The ranks
+    time-share the GPU, so the figure says what the protocol costs here -- not what N GPUs would do."""
+    import subprocess
+    import tempfile
+    import uuid
+
+    import torch
+    base = os.path.join(tempfile.gettempdir(), "umgap_ipc_%d_%s" % (os.getpid(), uuid.uuid4().hex[:8]))
+    torch.save((want_first[0].cpu(), want_first[1].cpu()), base + ".want.pt")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "TORCHELASTIC_USE_AGENT_STORE")}
+    env["UMGAP_SHARD_NO_LOCAL"] = "0"
+    name = "/umgap-bench-%s" % uuid.uuid4().hex[:12]
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--ipc-child", base, "--ipc-name", name, "--ipc-world", str(world), "--ipc-rank", str(r),
+                               "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--pairs-per-step", str(args.pairs_per_step),
+                               "--batches", str(args.batches), "--n-keys", str(args.n_keys), "--n-tax", str(args.n_tax), "--load-factor", str(args.load_factor),
+                               "--pieces", str(args.pieces)], env=dict(env, UMGAP_BENCH_DEVICE=str(local_rank)), stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(world)]
+    tails, status = [], []
+    for pr in procs:
+        try:
+            out_b = pr.communicate(timeout=420)[0]
+            status.append(pr.returncode)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            out_b = pr.communicate()[0]
+            status.append("no answer within 420 s")
+        tails.append(out_b.decode(errors="replace")[-300:])
+    res = None
+    if all(st == 0 for st in status):
+        per = [json.load(open("%s.rank%d.json" % (base, r))) for r in range(world)]
+        ms = max(x["ms_per_step"] for x in per)
+        res = {"ranks": world, "transport": "hipIpc memory handles between %d processes on one GPU (umgap_comm_init_ipc)" % world, "pairs_per_step": sum(x["pairs"] for x in per),
+               "ms_per_step": ms, "value": round(sum(x["pairs"] for x in per) / (ms * 1e-3), 1), "unit": "pairs/s", "steps": per[0]["steps"],
+               "bit_identical_to_replica": all(x["bit_identical_to_replica"] for x in per), "shard_table_GB_per_rank": per[0]["shard_table_GB"],
+               "keys_exchanged_fraction": round(1.0 - 1.0 / world, 3),
+               "what": "every rank its own process, shard and reads; the ranks share the GPU, so this is the protocol under the driver's clock, not a scaling figure"}
+    else:
+        res = {"error": "rank exit status %s" % (status,), "output_tail": tails}
+    for f in [base + ".want.pt"] + ["%s.rank%d.json" % (base, r) for r in range(world)]:
+        try:
+            os.remove(f)
+        except OSError:
+            pass
+    return res
+
+
+def ipc_child(args):
+    """One rank of run_ipc_children."""
+    import torch
+
+    from umgap_amd import synth
+    from umgap_amd.api import Index
+    from umgap_amd.dist import Comm, Sharded
+    r, world = args.ipc_rank, args.ipc_world
+    dev = int(os.environ.get("UMGAP_BENCH_DEVICE", "0"))
+    torch.cuda.set_device(dev)
+    device = torch.device("cuda", dev)
+    w = synth.SyntheticWorkload(n_tax=args.n_tax, n_keys=args.n_keys, id_space=int(args.n_tax * 1.4), load_factor=args.load_factor, device=dev, build_index=False)
+    B = args.pairs_per_step
+    lo, hi = B * r // world, B * (r + 1) // world
+    n_batches = max(1, min(args.batches, args.steps + args.warmup))
+    keys = [w.reads(b * B + lo, hi - lo) for b in range(n_batches)]            # the r-th part of the replica's batches
+    want = torch.load(args.ipc_child + ".want.pt")
+    want_t, want_s = want[0][lo:hi].to(device), want[1][lo:hi].to(device)
+    shard = Index.synthetic(args.n_keys, w.d_taxon_of_row, synth.MUL_A, synth.ADD_B, args.load_factor, r, world)
+    comm = Comm.ipc(args.ipc_name, world, r, dev)
+    comm.selftest(1 << 20)
+    per_piece = -(-(B - B * (world - 1) // world) // args.pieces)
+    sh = Sharded(shard, w.taxonomy, comm, per_piece * args.pieces * KMERS, pieces=args.pieces)
+    d_taxon = torch.full((hi - lo,), -1, dtype=torch.int32, device=device)
+    d_status = torch.full_like(d_taxon, -1)
+    steps = max(2, min(5, args.steps))
+
+    def one(i):
+        sh.classify9(keys[i % len(keys)], hi - lo, KMERS, d_taxon, d_status, method="tree", strategy="lca*", lower_bound=2.0)
+
+    one(0)
+    sh.check()
+    torch.cuda.synchronize()
+    same = bool(torch.equal(d_taxon, want_t) and torch.equal(d_status, want_s))
+    comm.selftest(64)               # collective: everybody starts the timed steps together
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(i + 1)
+    torch.cuda.synchronize()
+    comm.selftest(64)               # ... and the clock stops when the last rank is through
+    el = time.perf_counter() - t0
+    sh.check()
+    with open("%s.rank%d.json" % (args.ipc_child, r), "w") as f:
+        json.dump({"ms_per_step": round(1e3 * el / steps, 3), "pairs": hi - lo, "steps": steps, "bit_identical_to_replica": same,
+                   "shard_table_GB": round(shard.table_bytes / 1e9, 2)}, f)
+    sh.close()
+    shard.close()
+    comm.close()
+
+
 def sharded_child(args):
     """Entry of the child started by run_sharded_child: same rank / world / device as its parent (environment), own process group."""
     import torch
@@ -340,6 +443,8 @@ def main():
         sys.exit(rc)
     if args.sharded_child:
         return sharded_child(args)
+    if args.ipc_child:
+        return ipc_child(args)
     if args.rehearse_cpu:
         return rehearse_cpu(args)
     import numpy as np
@@ -593,6 +698,8 @@ def main():
         if rank == 0:
             out["sharded"] = res
             sharded_failed = "value" not in res
+        if solo_sharded and not sharded_failed:
+            out["sharded"]["two_processes_one_gpu"] = run_ipc_children(args, want_first, local_rank)
         if rank == 0 and args.mode == "sharded" and "value" in out["sharded"]:
             out["replica"] = {"value": out["value"], "ms_per_step": out["ms_per_step"]}
             out["value"], out["ms_per_step"] = out["sharded"]["value"], out["sharded"]["ms_per_step"]
