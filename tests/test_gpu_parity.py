@@ -1996,6 +1996,74 @@ def test_classify_tryp_dev_vs_oracle(api, torch_cuda, mode):
     nine = api.Index.build(np.array([5], np.uint64), np.array([7], np.uint32))
     with pytest.raises(api.UmgapError, match="variable-length"):
         api.classify_tryp_dev(nine, tx, d_bytes, d_offs, 1, 1, d_t, d_s)
+    with pytest.raises(api.UmgapError, match="packed peptide table"):
+        ix.bind(tx)                                                      # the `*` key keeps this table in the heap layout
+
+
+@pytest.mark.parametrize("mode", [("tree", "hybrid", 0.25, 0.0), ("rmq", "mrtl", 0.0, 1.0), ("tree", "lca*", 0.0, 2.0), ("rmq", "hybrid", 0.4, 1.0), ("rmq", "mrtl", 0.0, 5.0)])
+def test_classify_tryp_dev_on_a_bound_peptide_table(api, torch_cuda, mode):
+    """umgap_index_bind_taxonomy on the packed peptide table: the header slots' taxa become preorder-interval codes and
+    umgap_classify_tryp_dev aggregates them with no by-id gather.  Same answers, read for read, as on the unbound table (and so as
+    the oracle, test above) -- short reads, reads of hundreds of peptides (the large-scratch passes, which get ids back), every
+    strategy; the plain look-ups refuse a bound table; unbinding gives the table back byte for byte."""
+    torch = torch_cuda
+    method, strategy, factor, lb = mode
+    rng = np.random.default_rng(29)
+    letters = np.frombuffer(b"ACDEFGHILMNPQSTVWY", np.uint8)
+
+    def peptide():
+        k = int(rng.integers(2, 30))
+        p = bytearray(rng.choice(letters, k).tobytes())
+        p[-1] = ord("K") if rng.random() < 0.5 else ord("R")
+        if p[0] == ord("P"):
+            p[0] = ord("A")
+        return bytes(p)
+    peps = sorted({peptide() for _ in range(6000)})
+    ids = np.arange(1, 3000, dtype=np.uint32)
+    par = np.maximum(1, ids // 2).astype(np.uint32)
+    tx = api.Taxonomy(ids, par)
+    vals = rng.choice(ids, len(peps)).astype(np.uint32)
+    ix = api.Index.build_var(peps, vals)
+    assert ix.var_layout == 1
+    before = ix.dump_var()
+    pool, wide = peps[:60], peps[:1500]
+    for F, (lo, hi), long_reads in ((2, (5, 50), False), (1, (1, 63), True), (3, (9, 45), False)):
+        n_reads = 600
+        frags = []
+        for i in range(n_reads * F):
+            n_parts = int(rng.integers(0, 7))
+            src = pool
+            if long_reads and i % 50 == 0:
+                n_parts, src = int(rng.integers(100, 400)), wide          # > 64 distinct taxa and / or > 128 hits: the deferred passes
+            parts = []
+            for _k in range(n_parts):
+                u = rng.random()
+                parts.append(src[int(rng.integers(0, len(src)))] if u < 0.7 else (peptide() if u < 0.9 else b"*"))
+            frags.append(b"".join(parts))
+        data, offs = api._concat(frags)
+        d_bytes, d_offs = torch.from_numpy(np.concatenate([data, np.zeros(1, np.uint8)])).cuda(), torch.from_numpy(offs.view(np.int64)).cuda()
+        got = []
+        for bound in (False, True):
+            if bound:
+                ix.bind(tx)
+            d_t = torch.full((n_reads,), -1, dtype=torch.int32, device="cuda")
+            d_s = torch.full_like(d_t, -1)
+            n_pieces = api.classify_tryp_dev(ix, tx, d_bytes, d_offs, n_reads, F, d_t, d_s, method=method, strategy=strategy, factor=factor, lower_bound=lb,
+                                             min_len=lo, max_len=hi)
+            got.append((n_pieces, d_t.cpu().numpy().copy(), d_s.cpu().numpy().copy()))
+            if bound:
+                with pytest.raises(api.UmgapError, match="unbind it first"):
+                    ix.lookup_var([peps[0]])
+                ix.unbind(tx)
+        assert got[0][0] == got[1][0]
+        assert np.array_equal(got[0][2], got[1][2]), (F, "status")
+        assert np.array_equal(got[0][1], got[1][1]), (F, "taxon")
+        assert lb >= 2 or (got[0][2] == 0).mean() > 0.3
+    after = ix.dump_var()
+    assert all(np.array_equal(a, b) for a, b in zip(before, after))
+    other = api.Taxonomy(ids[:100], par[:100])
+    with pytest.raises(api.UmgapError, match="not taxa of this taxonomy"):
+        ix.bind(other)
 
 
 def test_classify_records_long_ragged_reads(api, torch_cuda):

@@ -92,21 +92,42 @@ def run(n_keys=1_000_000_000, n_pairs=10_000_000, steps=3, workload=None):
     assert po.numel() - 1 == n_pairs * F * PEPS, (po.numel() - 1, n_pairs * F * PEPS)
     del po
     # (tryptic-precision is the same call with -l5; a pair of this workload has four peptides, so it would only time empty reads)
-    for name, lb in (("tryptic_sensitivity_mrtl_l1", 1.0), ("tryptic_mrtl_l2", 2.0), ("max_sensitivity_tree_hybrid_f0.25_l1", 1.0)):
-        kw = dict(method="rmq", strategy="mrtl", lower_bound=lb, min_len=9, max_len=45)
-        if "hybrid" in name:
-            kw.update(method="tree", strategy="hybrid", factor=0.25)
-        classify_tryp_dev(ix, w.taxonomy, batches[0][0], batches[0][1], n_pairs, F, d_t, d_s, **kw)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            n_pieces = classify_tryp_dev(ix, w.taxonomy, batches[i][0], batches[i][1], n_pairs, F, d_t, d_s, **kw)
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / steps * 1e3
-        st = d_s.cpu()
-        res[name] = {"pairs_per_s": round(n_pairs / ms * 1e3, 1), "ms_per_step": round(ms, 3), "pieces_per_step": n_pieces,
-                     "G_pieces_per_s": round(n_pieces / ms / 1e6, 2), "status_ok_frac": round(float((st == 0).float().mean()), 3),
-                     "status_empty_frac": round(float((st == 1).float().mean()), 3)}
+    presets = (("tryptic_sensitivity_mrtl_l1", 1.0), ("tryptic_mrtl_l2", 2.0), ("max_sensitivity_tree_hybrid_f0.25_l1", 1.0))
+
+    def time_presets(out, check=None):
+        answers = {}
+        for name, lb in presets:
+            kw = dict(method="rmq", strategy="mrtl", lower_bound=lb, min_len=9, max_len=45)
+            if "hybrid" in name:
+                kw.update(method="tree", strategy="hybrid", factor=0.25)
+            classify_tryp_dev(ix, w.taxonomy, batches[0][0], batches[0][1], n_pairs, F, d_t, d_s, **kw)
+            torch.cuda.synchronize()
+            answers[name] = (d_t.clone(), d_s.clone())
+            t0 = time.perf_counter()
+            for i in range(steps):
+                n_pieces = classify_tryp_dev(ix, w.taxonomy, batches[i][0], batches[i][1], n_pairs, F, d_t, d_s, **kw)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t0) / steps * 1e3
+            st = d_s.cpu()
+            out[name] = {"pairs_per_s": round(n_pairs / ms * 1e3, 1), "ms_per_step": round(ms, 3), "pieces_per_step": n_pieces,
+                         "G_pieces_per_s": round(n_pieces / ms / 1e6, 2), "status_ok_frac": round(float((st == 0).float().mean()), 3),
+                         "status_empty_frac": round(float((st == 1).float().mean()), 3)}
+            if check is not None:
+                out[name]["bit_identical_to_unbound_table"] = bool(torch.equal(answers[name][0], check[name][0]) and torch.equal(answers[name][1], check[name][1]))
+        return answers
+
+    # the table as built (taxon ids in the slots: the aggregate gathers {pre, last} by id), then BOUND to the taxonomy
+    # (umgap_index_bind_taxonomy: interval codes in the slots, no gather) -- the headline figures are the bound ones
+    unbound = {}
+    plain_answers = time_presets(unbound)
+    t0 = time.perf_counter()
+    ix.bind(w.taxonomy)
+    torch.cuda.synchronize()
+    res["bind_s"] = round(time.perf_counter() - t0, 2)
+    res["table_bound_to_taxonomy"] = True
+    time_presets(res, plain_answers)
+    res["unbound_table"] = unbound
+    ix.unbind(w.taxonomy)
     ix.close()
     return res
 

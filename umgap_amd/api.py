@@ -181,6 +181,17 @@ class Index:
                                                      _dev_ptr(d_out), _stream_ptr(stream)))
         return d_out
 
+    def dump_var(self):
+        """(key bytes, offsets, lengths, taxa) of a byte-string table, in table order (umgap_index_dump_var: what printindex walks)."""
+        L = _lib.load()
+        n, hb = C.c_size_t(), C.c_uint64()
+        check(L.umgap_index_dump_var(self._h, None, 0, None, None, None, 0, C.byref(n), C.byref(hb)))
+        cap = n.value
+        heap, offs = np.zeros(max(hb.value, 1), np.uint8), np.zeros(max(cap, 1), np.uint64)
+        lens, taxa = np.zeros(max(cap, 1), np.uint32), np.zeros(max(cap, 1), np.uint32)
+        check(L.umgap_index_dump_var(self._h, _np_ptr(heap), hb.value, _np_ptr(offs), _np_ptr(lens), _np_ptr(taxa), cap, C.byref(n), C.byref(hb)))
+        return heap[:hb.value], offs[:cap], lens[:cap], taxa[:cap]
+
     def save(self, path):
         check(_lib.load().umgap_index_save(self._h, str(path).encode()))
 

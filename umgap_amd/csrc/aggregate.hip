@@ -19,6 +19,7 @@
 //   h' = smallest-preorder surviving taxon that is NOT an ancestor-or-self of M (last[h] < pre[M]);
 //   LCA* = M if there is no h', else LCA(h', M) = first node on M's parent chain with pre <= pre[h'].
 #include "agg_common.hpp"
+#include "bound.hpp"
 #include "host_copy.hpp"
 
 using namespace umgap;
@@ -26,7 +27,8 @@ using namespace umgap;
 namespace umgap {
 int launch_general(const TaxView& V, int method, int strategy, float factor, float lower_bound, const uint32_t* d_taxa,
                    const float* d_scores, const uint64_t* d_offsets, uint32_t stride, size_t n_reads, uint32_t* d_out_taxon,
-                   uint32_t* d_out_status, uint32_t* d_defer, uint32_t* d_big, hipStream_t stream);
+                   uint32_t* d_out_status, uint32_t* d_defer, uint32_t* d_big, hipStream_t stream, uint32_t* bound_codes = nullptr,
+                   const uint32_t* d_id_of_pre = nullptr);
 int launch_strided_group(const TaxView& V, int method, int strategy, float factor, float lower_bound, const uint32_t* d_taxa, uint32_t stride,
                          size_t n_reads, uint32_t* d_out_taxon, uint32_t* d_out_status, uint32_t* d_list, uint32_t* d_count, hipStream_t stream);
 }
@@ -188,6 +190,16 @@ __global__ __launch_bounds__(256) void k_agg_lca(TaxView V, int method, const ui
     }
 }
 
+// interval codes (bound.hpp) -> taxon ids, in place; 0 = no hit stays
+__global__ __launch_bounds__(256) void k_all_codes_to_ids(uint32_t* __restrict__ hits, uint64_t n, const uint32_t* __restrict__ id_of_pre) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t step = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) {
+        const uint32_t v = hits[i];
+        if (v) hits[i] = id_of_pre[umgap::bound::pre_of(v)];
+    }
+}
+
 inline int agg_grid(size_t n_reads) {
     size_t g = (n_reads + 3) / 4;
     if (g < 1) g = 1;
@@ -195,9 +207,10 @@ inline int agg_grid(size_t n_reads) {
     return (int)g;
 }
 
+// bound_codes / n_hits (umgap::aggregate_csr_bound_dev): the hits are interval codes of a table bound to tx, writable, n_hits of them
 int launch(umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound, int ranked_only,
            const uint32_t* d_taxa, const float* d_scores, const uint64_t* d_offsets, uint32_t stride, size_t n_reads,
-           uint32_t* d_out_taxon, uint32_t* d_out_status, hipStream_t stream) {
+           uint32_t* d_out_taxon, uint32_t* d_out_status, hipStream_t stream, uint32_t* bound_codes = nullptr, uint64_t n_hits = 0) {
     if (method != UMGAP_METHOD_TREE && method != UMGAP_METHOD_RMQ) return fail(UMGAP_ERR_INVALID, "unknown method");
     if (strategy < 0 || strategy > 2) return fail(UMGAP_ERR_INVALID, "unknown strategy");
     if (method == UMGAP_METHOD_TREE && strategy == UMGAP_STRATEGY_MRTL)
@@ -208,6 +221,8 @@ int launch(umgap_taxonomy* tx, int method, int strategy, float factor, float low
     // (LCA*: the one-read-per-wave kernel below already spends a single round trip per stage; the group form of
     //  aggregate_group.hip measured 5 % slower on 16-hit reads, so it stays with the strategies that gain 2-3x from it)
     if (strategy == UMGAP_STRATEGY_LCA_STAR) {
+        // (the per-read LCA* kernel knows taxon ids only: bound hits are turned back first)
+        if (bound_codes && n_hits) hipLaunchKernelGGL(k_all_codes_to_ids, dim3((unsigned)std::min<uint64_t>((n_hits + 255) / 256, 256 * 8)), dim3(256), 0, stream, bound_codes, n_hits, (const uint32_t*)tx->d_id_of_pre);
         if (d_scores) hipLaunchKernelGGL(k_agg_lca<true>, grid, block, 0, stream, V, method, d_taxa, d_scores, d_offsets, stride, n_reads, lower_bound, d_out_taxon, d_out_status);
         else hipLaunchKernelGGL(k_agg_lca<false>, grid, block, 0, stream, V, method, d_taxa, d_scores, d_offsets, stride, n_reads, lower_bound, d_out_taxon, d_out_status);
     } else {
@@ -215,13 +230,22 @@ int launch(umgap_taxonomy* tx, int method, int strategy, float factor, float low
         uint32_t* d_big = big_scratch_for(tx);
         if (!d_defer || !d_big) return UMGAP_ERR_NOMEM;
         return launch_general(V, method, strategy, factor, lower_bound, d_taxa, d_scores, d_offsets, stride, n_reads, d_out_taxon,
-                              d_out_status, d_defer, d_big, stream);
+                              d_out_status, d_defer, d_big, stream, bound_codes, tx->d_id_of_pre);
     }
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
 }
 
 }  // extern "C"
+
+namespace umgap {
+// umgap_aggregate_dev for unscored CSR reads whose n_hits hits are the interval codes of a table BOUND to tx (tryptic.hip); the codes may
+// be rewritten (to taxon ids, where a pass needs those)
+int aggregate_csr_bound_dev(umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound, int ranked_only, uint32_t* d_codes,
+                            uint64_t n_hits, const uint64_t* d_read_offsets, size_t n_reads, uint32_t* d_out_taxon, uint32_t* d_out_status, hipStream_t stream) {
+    return launch(tx, method, strategy, factor, lower_bound, ranked_only, d_codes, nullptr, d_read_offsets, 0, n_reads, d_out_taxon, d_out_status, stream, d_codes, n_hits);
+}
+}  // namespace umgap
 
 extern "C" {
 

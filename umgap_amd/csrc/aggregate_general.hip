@@ -24,6 +24,7 @@
 // Reads with more than CAP distinct taxa are deferred to a second launch of the same kernel with a
 // large scratch (1 wave per workgroup); beyond that the read is flagged UMGAP_READ_UNSUPPORTED.
 #include "agg_general.hpp"
+#include "bound.hpp"
 
 using namespace umgap;
 using namespace umgap::agg;
@@ -31,6 +32,21 @@ using namespace umgap::agg;
 
 
 namespace {
+
+// the reads on the defer list: interval codes -> taxon ids, in place (one wave per read)
+__global__ __launch_bounds__(256) void k_deferred_codes_to_ids(const uint32_t* __restrict__ todo, const uint32_t* __restrict__ todo_count, const uint64_t* __restrict__ offsets,
+                                                               uint32_t* __restrict__ hits, const uint32_t* __restrict__ id_of_pre) {
+    const uint32_t lane = threadIdx.x & 63;
+    const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const size_t n = (size_t)*todo_count;
+    for (size_t w = wave0; w < n; w += nwaves) {
+        const size_t r = todo[w];
+        for (uint64_t i = offsets[r] + lane; i < offsets[r + 1]; i += 64) {
+            const uint32_t v = hits[i];
+            if (v) hits[i] = id_of_pre[umgap::bound::pre_of(v)];
+        }
+    }
+}
 
 template <bool SCORED, int CAP, int HCAP, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_agg_general(TaxView V, int method, int strategy, float factor,
@@ -110,14 +126,18 @@ namespace umgap {
 int launch_strided_group(const TaxView& V, int method, int strategy, float factor, float lower_bound, const uint32_t* d_taxa, uint32_t stride,
                          size_t n_reads, uint32_t* d_out_taxon, uint32_t* d_out_status, uint32_t* d_list, uint32_t* d_count, hipStream_t stream);
 int launch_csr_group(const TaxView& V, int method, int strategy, float factor, float lower_bound, const uint32_t* d_taxa, const uint64_t* d_offsets,
-                     size_t n_reads, uint32_t* d_out_taxon, uint32_t* d_out_status, uint32_t* d_list, uint32_t* d_count, hipStream_t stream);
+                     size_t n_reads, uint32_t* d_out_taxon, uint32_t* d_out_status, uint32_t* d_list, uint32_t* d_count, hipStream_t stream, bool bound_hits);
 
 // Launches the general aggregation: the compact-scratch pass over all reads, the large-scratch pass over whatever it
 // deferred (> 64 distinct taxa), and the global-memory pass over what that one deferred (> 1024).  `d_defer` must hold
 // 2 * (n_reads + 1) u32; d_big = BIG_SLOTS read scratches of ScratchGlobal::words(BIG_CAP, BIG_HCAP) words, hash parts zero.
+// bound_codes (non-null: the hits again, writable): they are interval codes of a table bound to the taxonomy.  The group pass works
+// on the codes; the reads it defers (more than 64 distinct taxa or 128 hits -- a tryptic read has a handful) get their codes turned
+// back into taxon ids in place before the large-scratch passes, which know ids only.
 int launch_general(const TaxView& V, int method, int strategy, float factor, float lower_bound, const uint32_t* d_taxa,
                    const float* d_scores, const uint64_t* d_offsets, uint32_t stride, size_t n_reads, uint32_t* d_out_taxon,
-                   uint32_t* d_out_status, uint32_t* d_defer, uint32_t* d_big, hipStream_t stream) {
+                   uint32_t* d_out_status, uint32_t* d_defer, uint32_t* d_big, hipStream_t stream, uint32_t* bound_codes, const uint32_t* d_id_of_pre) {
+    if (bound_codes && (d_scores || !d_offsets)) return fail(UMGAP_ERR_INVALID, "launch_general: bound hits come as unscored CSR reads");
     uint32_t* d_count = d_defer;      // [0] = number of deferred reads
     uint32_t* d_list = d_defer + 1;
     uint32_t* d_count2 = d_defer + n_reads + 1;
@@ -145,8 +165,9 @@ int launch_general(const TaxView& V, int method, int strategy, float factor, flo
                            lower_bound, d_out_taxon, d_out_status, (const uint32_t*)d_list2, (const uint32_t*)d_count2, d_big, BIG_CAP, BIG_HCAP);
     } else if (d_offsets) {
         // unscored CSR: the first pass batched over groups of reads (aggregate_group.hip), the rest as above
-        int rc = launch_csr_group(V, method, strategy, factor, lower_bound, d_taxa, d_offsets, n_reads, d_out_taxon, d_out_status, d_list, d_count, stream);
+        int rc = launch_csr_group(V, method, strategy, factor, lower_bound, d_taxa, d_offsets, n_reads, d_out_taxon, d_out_status, d_list, d_count, stream, bound_codes != nullptr);
         if (rc) return rc;
+        if (bound_codes) hipLaunchKernelGGL(k_deferred_codes_to_ids, dim3(64), dim3(256), 0, stream, (const uint32_t*)d_list, (const uint32_t*)d_count, d_offsets, bound_codes, d_id_of_pre);
         hipLaunchKernelGGL((k_agg_general<false, 1024, 4096, 1>), big_grid, big_block, 0, stream, V, method, strategy, factor, d_taxa, d_scores, d_offsets,
                            stride, n_reads, lower_bound, d_out_taxon, d_out_status, (const uint32_t*)d_list, (const uint32_t*)d_count, d_list2, d_count2);
         hipLaunchKernelGGL(k_agg_general_big<false>, dim3(BIG_SLOTS), dim3(64), 0, stream, V, method, strategy, factor, d_taxa, d_scores, d_offsets, stride,

@@ -44,6 +44,8 @@ __global__ __launch_bounds__(256) void k_agg_strided_group(TaxView V, int method
 // power of two that holds the longest read still to do (at most 128; longer reads go to the defer list), as many reads as then fit
 // the strip are laid out at that stride -- every strip slot fetches its own taxon, the span coming from the owning lane by
 // ds_bpermute -- and aggregated together.  Short reads (tryptic: 4-20 hits) run 32-64 to a sub-round instead of one per wave.
+// BOUND: the hits are interval codes of a table bound to the taxonomy (bound.hpp) -- no by-id gather per distinct taxon.
+template <bool BOUND>
 __global__ __launch_bounds__(256) void k_agg_csr_group(TaxView V, int method, int strategy, float factor, const uint32_t* __restrict__ taxa,
                                                        const uint64_t* __restrict__ offsets, size_t n_reads, float lower_bound, uint32_t* __restrict__ out_taxon,
                                                        uint32_t* __restrict__ out_status, uint32_t* __restrict__ defer, uint32_t* __restrict__ defer_count) {
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(256) void k_agg_csr_group(TaxView V, int method, in
             }
             wave_sync();
             const uint64_t too_long = (__ballot(big) >> k0) & (nr >= 64 ? ~0ull : ((1ull << nr) - 1ull));
-            general_group<false>(V, S, method, strategy, factor, lower_bound, wtaxa, stride, nr, lane, 0ull, 0u, r0 + k0, out_taxon, out_status, defer, defer_count, 0ull,
+            general_group<BOUND>(V, S, method, strategy, factor, lower_bound, wtaxa, stride, nr, lane, 0ull, 0u, r0 + k0, out_taxon, out_status, defer, defer_count, 0ull,
                                  too_long);
             wave_sync();
             k0 += nr;
@@ -99,13 +101,15 @@ __global__ __launch_bounds__(256) void k_agg_csr_group(TaxView V, int method, in
 namespace umgap {
 
 int launch_csr_group(const TaxView& V, int method, int strategy, float factor, float lower_bound, const uint32_t* d_taxa, const uint64_t* d_offsets,
-                     size_t n_reads, uint32_t* d_out_taxon, uint32_t* d_out_status, uint32_t* d_list, uint32_t* d_count, hipStream_t stream) {
+                     size_t n_reads, uint32_t* d_out_taxon, uint32_t* d_out_status, uint32_t* d_list, uint32_t* d_count, hipStream_t stream, bool bound_hits) {
     size_t g = ((n_reads + 63) / 64 + 3) / 4;
     if (g > 256 * 8) g = 256 * 8;
     if (g < 1) g = 1;
     if (strategy == UMGAP_STRATEGY_LCA_STAR) return fail(UMGAP_ERR_INVALID, "launch_csr_group: LCA* has its own kernel");
-    hipLaunchKernelGGL(k_agg_csr_group, dim3((unsigned)g), dim3(256), 0, stream, V, method, strategy, factor, d_taxa, d_offsets, n_reads, lower_bound, d_out_taxon,
-                       d_out_status, d_list, d_count);
+    if (bound_hits) hipLaunchKernelGGL(k_agg_csr_group<true>, dim3((unsigned)g), dim3(256), 0, stream, V, method, strategy, factor, d_taxa, d_offsets, n_reads, lower_bound,
+                                       d_out_taxon, d_out_status, d_list, d_count);
+    else hipLaunchKernelGGL(k_agg_csr_group<false>, dim3((unsigned)g), dim3(256), 0, stream, V, method, strategy, factor, d_taxa, d_offsets, n_reads, lower_bound, d_out_taxon,
+                            d_out_status, d_list, d_count);
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
 }

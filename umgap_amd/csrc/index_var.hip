@@ -719,6 +719,7 @@ int umgap_index_build_var(const uint8_t* bytes, const uint64_t* offsets, const u
 int umgap_index_dump_var(const umgap_index* ix, uint8_t* heap_out, uint64_t heap_cap, uint64_t* offsets_out, uint32_t* lens_out,
                          uint32_t* taxa_out, size_t cap, size_t* n_out, uint64_t* heap_bytes_out) {
     if (!ix || ix->kind != 2 || !ix->var || !n_out || !heap_bytes_out) return fail(UMGAP_ERR_INVALID, "umgap_index_dump_var: not a variable-length index");
+    if (ix->bound_to) return fail(UMGAP_ERR_INVALID, "the index is bound to a taxonomy (umgap_index_bind_taxonomy): its values are interval codes, not taxon ids; unbind it first");
     int rc = use_device(ix->device);
     if (rc) return rc;
     const umgap_var_index* v = ix->var;
@@ -766,6 +767,7 @@ int umgap_index_lookup_var_dev(umgap_index* ix, const uint8_t* d_bytes, const ui
                                uint32_t* d_out, void* stream) {
     if (!ix || ix->kind != 2 || !ix->var) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup_var_dev: not a variable-length index");
     if (n && (!d_bytes || !d_offsets || !d_out)) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup_var_dev: null argument");
+    if (ix->bound_to) return fail(UMGAP_ERR_INVALID, "the index is bound to a taxonomy (umgap_index_bind_taxonomy): its values are interval codes, not taxon ids; unbind it first");
     int rc = use_device(ix->device);
     if (rc) return rc;
     return var_lookup_dev(ix->var, d_bytes, d_offsets, n, miss_value, d_out, (hipStream_t)stream, 1u, VAR_MAX_LEN);
@@ -789,6 +791,7 @@ extern "C" {
 int umgap_index_lookup_var(umgap_index* ix, const uint8_t* bytes, const uint64_t* offsets, size_t n, uint32_t miss_value, uint32_t* out) {
     if (!ix || ix->kind != 2 || !ix->var) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup_var: not a variable-length index");
     if (n && (!bytes || !offsets || !out)) return fail(UMGAP_ERR_INVALID, "umgap_index_lookup_var: null argument");
+    if (ix->bound_to) return fail(UMGAP_ERR_INVALID, "the index is bound to a taxonomy (umgap_index_bind_taxonomy): its values are interval codes, not taxon ids; unbind it first");
     int rc = use_device(ix->device);
     if (rc) return rc;
     if (!n) return UMGAP_OK;

@@ -11,7 +11,7 @@
 //
 //   k_tryp_mark     fragment starts -> one bit per byte                                     (n_fragments threads)
 //   k_tryp_count    piece starts per tile of 8 KB, the flags kept (1 bit per byte)            (reads the bytes, once)
-//   k_tryp_scan     exclusive scan of the tile counts                                        (one workgroup)
+//   k_tryp_scan     exclusive scan of the tile counts, two levels                             (a workgroup per 16384 tiles + one)
 //   k_tryp_write    the starts, in order: offsets[rank] = position                           (reads the flags)
 //   k_tryp_reads    first piece of every read = the rank of its first byte among the starts   (n_reads threads, three loads each)
 // then k_lookup_var_pipe over the pieces and the CSR aggregate over the hits of each read.
@@ -25,6 +25,8 @@ namespace umgap {
 int use_device(int device);
 int var_lookup_dev(const umgap_var_index* v, const uint8_t* d_bytes, const uint64_t* d_off, size_t n, uint32_t miss, uint32_t* d_out, hipStream_t s,
                    uint32_t min_len, uint32_t max_len);
+int aggregate_csr_bound_dev(umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound, int ranked_only, uint32_t* d_codes,
+                            uint64_t n_hits, const uint64_t* d_read_offsets, size_t n_reads, uint32_t* d_out_taxon, uint32_t* d_out_status, hipStream_t stream);
 }  // namespace umgap
 
 using namespace umgap;
@@ -89,47 +91,127 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t v, uint32_t* l
     return before + incl - v;
 }
 
-// also keeps every thread's 32 flags (one bit per byte of input): k_tryp_write reads those instead of the bytes again
-// ... and how many pieces start in the tile before the thread's 32 bytes (16 bits: a tile has 8192 bytes): with the tile bases that
-// is the rank of any byte among the piece starts in three loads (k_tryp_reads)
+// the piece-start flags of 16 bytes held in two little-endian words (lo = bytes 0..7), `prev` = the byte before them: 16 bits
+__device__ __forceinline__ uint32_t piece_start_mask16(uint64_t lo, uint64_t hi, uint8_t prev) {
+    uint32_t m = 0;
+    const uint64_t v2[2] = {lo, hi};
+#pragma unroll
+    for (int w = 0; w < 2; w++) {
+        const uint64_t v = v2[w];
+        const uint64_t star = bytes_equal_to(v, '*'), kr = bytes_equal_to(v, 'K') | bytes_equal_to(v, 'R'), isp = bytes_equal_to(v, 'P');
+        const uint64_t prev_star = (star << 8) | (prev == '*' ? 0x80ull : 0ull), prev_kr = (kr << 8) | ((prev == 'K' || prev == 'R') ? 0x80ull : 0ull);
+        const uint64_t start = star | prev_star | (prev_kr & ~isp);
+        m |= (uint32_t)(((start >> 7) * 0x0102040810204080ull) >> 56) << (8 * w);
+        prev = (uint8_t)(v >> 56);
+    }
+    return m;
+}
+
+// Piece starts per tile of 8 KB.  Also keeps the 32 flags of every 32-byte group (one bit per byte of input: k_tryp_write reads those
+// instead of the bytes again) and how many pieces start in the tile before the group (16 bits: a tile has 8192 bytes): with the tile
+// bases that is the rank of any byte among the piece starts in three loads (k_tryp_reads).
+// The bytes are read 16 per lane, a wave a whole KB per instruction (round 4; 32 bytes per thread as four 8-byte loads left three
+// quarters of every request unused: 3.3 TB/s); the byte before a lane's 16 comes from the lane below, two lanes make a group, and
+// the groups' flags meet in LDS for the tile's scan.
 __global__ __launch_bounds__(256) void k_tryp_count(const uint8_t* __restrict__ base, const uint32_t* __restrict__ bits, uint64_t n, uint32_t* __restrict__ tile_counts,
                                                     uint32_t* __restrict__ masks, uint16_t* __restrict__ before) {
     __shared__ uint32_t sums[4];
-    const uint64_t rel = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * PER_THREAD;
-    const uint32_t mask = piece_start_mask(base, bits, rel, n);
-    masks[(uint64_t)blockIdx.x * 256 + threadIdx.x] = mask;
+    __shared__ uint32_t gmask[256];
+    const uint32_t t = threadIdx.x, lane = t & 63;
+    const uint64_t tile0 = (uint64_t)blockIdx.x * TILE;
+    typedef uint64_t __attribute__((ext_vector_type(2))) u64x2;
+    typedef u64x2 __attribute__((aligned(1))) u64x2_unaligned;        // (the range starts wherever the first fragment does)
+#pragma unroll
+    for (uint32_t r = 0; r < 2; r++) {
+        const uint64_t rel = tile0 + (uint64_t)(r * 256 + t) * 16;
+        uint64_t lo = 0, hi = 0;
+        if (rel + 16 <= n) {
+            const u64x2 v = *reinterpret_cast<const u64x2_unaligned*>(base + rel);
+            lo = v.x; hi = v.y;
+        } else if (rel < n) {                                          // the tail of the range
+            for (uint32_t k = 0; k < 16 && rel + k < n; k++) {
+                const uint64_t b = base[rel + k];
+                if (k < 8) lo |= b << (8 * k); else hi |= b << (8 * (k - 8));
+            }
+        }
+        // the byte before the lane's 16: the last byte of the lane below; lane 0 of a wave reads it (before the range's first byte:
+        // any separator -- that byte opens a fragment anyway)
+        uint32_t prev = (uint32_t)__shfl_up((int)(uint32_t)(hi >> 56), 1, 64);
+        if (lane == 0) prev = rel && rel <= n ? base[rel - 1] : (uint32_t)'*';
+        uint32_t m16 = rel < n ? piece_start_mask16(lo, hi, (uint8_t)prev) : 0u;
+        if (rel < n && n - rel < 16) m16 &= (1u << (uint32_t)(n - rel)) - 1u;      // bytes past the end open nothing
+        const uint32_t up = (uint32_t)__shfl_down((int)m16, 1, 64);               // the odd lane's half of the group
+        if (!(t & 1u)) gmask[r * 128 + (t >> 1)] = m16 | (up << 16);
+    }
+    __syncthreads();
+    const uint64_t grel = tile0 + (uint64_t)t * PER_THREAD;           // thread t: group t of the tile
+    const uint32_t mask = grel < n ? (gmask[t] | bits[grel >> 5]) : 0u;      // (+ the fragment-start bits of the group: one word)
+    masks[(uint64_t)blockIdx.x * 256 + t] = mask;
     const uint32_t cnt = (uint32_t)__builtin_popcount(mask);
     uint32_t total;
-    before[(uint64_t)blockIdx.x * 256 + threadIdx.x] = (uint16_t)block_exclusive_scan(cnt, sums, total);
-    if (threadIdx.x == 0) tile_counts[blockIdx.x] = total;
+    before[(uint64_t)blockIdx.x * 256 + t] = (uint16_t)block_exclusive_scan(cnt, sums, total);
+    if (t == 0) tile_counts[blockIdx.x] = total;
 }
 
-// exclusive scan of the n_tiles counts -> 64-bit bases; one workgroup of 1024 threads walks the list in slabs of 4096 counts (four
-// consecutive counts per thread, so the loads and stores are coalesced; a slab costs two barriers)
-__global__ __launch_bounds__(1024) void k_tryp_scan(const uint32_t* __restrict__ tile_counts, size_t n_tiles, uint64_t* __restrict__ tile_base, uint64_t* __restrict__ total) {
+// Exclusive scan of the n_tiles counts in two levels (round 4; one workgroup walking the whole list was held to one CU's memory
+// bandwidth: 0.11 ms for the 160 K tiles of a 10 M-pair batch).  Level 1: a workgroup of 1024 threads per SLAB of 16384 tiles (sixteen
+// consecutive counts per thread as four 16-byte loads) -> tile_base[i] = pieces of the slab before tile i, slab_total[b].
+// Level 2: one workgroup scans the slab totals -> slab_base[b], *total.  A tile's base is tile_base[i] + slab_base[i / SLAB].
+constexpr uint32_t SCAN_PER = 16, SLAB = 1024 * SCAN_PER;
+__global__ __launch_bounds__(1024) void k_tryp_scan(const uint32_t* __restrict__ tile_counts, size_t n_tiles, uint32_t* __restrict__ tile_base, uint64_t* __restrict__ slab_total) {
     __shared__ uint32_t sums[16];
+    const size_t i = (size_t)blockIdx.x * SLAB + (size_t)threadIdx.x * SCAN_PER;
+    uint32_t v[SCAN_PER], mine = 0;
+    if (i + SCAN_PER <= n_tiles) {               // (the scratch is carved at 256-byte boundaries: 16-byte loads are aligned)
+#pragma unroll
+        for (uint32_t k = 0; k < SCAN_PER; k += 4) {
+            const uint4 q = *reinterpret_cast<const uint4*>(tile_counts + i + k);
+            v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w;
+        }
+    } else {
+#pragma unroll
+        for (uint32_t k = 0; k < SCAN_PER; k++) v[k] = i + k < n_tiles ? tile_counts[i + k] : 0u;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < SCAN_PER; k++) mine += v[k];
+    uint32_t total;                              // (a slab holds 16384 tiles x 8192 bytes: its pieces fit 32 bits)
+    uint32_t at = block_exclusive_scan(mine, sums, total);
+#pragma unroll
+    for (uint32_t k = 0; k < SCAN_PER; k++) { if (i + k < n_tiles) tile_base[i + k] = at; at += v[k]; }
+    if (threadIdx.x == 0) slab_total[blockIdx.x] = total;
+}
+__global__ __launch_bounds__(1024) void k_tryp_scan_slabs(const uint64_t* __restrict__ slab_total, size_t n_slabs, uint64_t* __restrict__ slab_base, uint64_t* __restrict__ total) {
+    __shared__ uint64_t wsum[16];
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint64_t run = 0;
-    for (size_t s0 = 0; s0 < n_tiles; s0 += 4096) {
-        const size_t i = s0 + (size_t)threadIdx.x * 4;
-        uint32_t v[4];
+    for (size_t s0 = 0; s0 < n_slabs; s0 += 1024) {
+        const size_t i = s0 + threadIdx.x;
+        const uint64_t v = i < n_slabs ? slab_total[i] : 0ull;
+        uint64_t incl = v;
 #pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = i + k < n_tiles ? tile_counts[i + k] : 0u;
-        uint32_t slab_total;
-        uint32_t at = block_exclusive_scan(v[0] + v[1] + v[2] + v[3], sums, slab_total);
-#pragma unroll
-        for (int k = 0; k < 4; k++) { if (i + k < n_tiles) tile_base[i + k] = run + at; at += v[k]; }
-        run += slab_total;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint64_t t = ((uint64_t)(uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), o, 64) << 32) | (uint32_t)__shfl_up((int)(uint32_t)incl, o, 64);
+            if (lane >= (uint32_t)o) incl += t;
+        }
+        if (lane == 63) wsum[wv] = incl;
+        __syncthreads();
+        uint64_t before = 0, all = 0;
+        for (uint32_t w = 0; w < 16; w++) { const uint64_t x = wsum[w]; if (w < wv) before += x; all += x; }
+        __syncthreads();
+        if (i < n_slabs) slab_base[i] = run + before + incl - v;
+        run += all;
     }
     if (threadIdx.x == 0) *total = run;
 }
 
 __global__ __launch_bounds__(256) void k_tryp_write(const uint32_t* __restrict__ masks, uint64_t n, uint64_t b0,
-                                                    const uint64_t* __restrict__ tile_base, uint64_t total, uint64_t cap, uint64_t* __restrict__ offsets) {
+                                                    const uint32_t* __restrict__ tile_base, const uint64_t* __restrict__ slab_base, uint64_t total, uint64_t cap,
+                                                    uint64_t* __restrict__ offsets) {
     __shared__ uint32_t sums[4];
     const uint64_t rel = (uint64_t)blockIdx.x * TILE + (uint64_t)threadIdx.x * PER_THREAD;
     uint32_t m = rel < n ? masks[(uint64_t)blockIdx.x * 256 + threadIdx.x] : 0u;
     uint32_t blk_total;
-    uint64_t at = tile_base[blockIdx.x] + block_exclusive_scan((uint32_t)__builtin_popcount(m), sums, blk_total);
+    uint64_t at = slab_base[blockIdx.x / SLAB] + tile_base[blockIdx.x] + block_exclusive_scan((uint32_t)__builtin_popcount(m), sums, blk_total);
     while (m) {
         const uint32_t k = (uint32_t)__builtin_ctz(m);
         m &= m - 1;
@@ -143,7 +225,8 @@ __global__ __launch_bounds__(256) void k_tryp_write(const uint32_t* __restrict__
 // piece starts before that byte: tile base + starts before the byte's 32-byte group in the tile + starts below it in the group
 // (the binary search over the 40 M offsets this replaces took 0.31 ms per 10 M reads, a quarter of the digest)
 __global__ __launch_bounds__(256) void k_tryp_reads(const uint64_t* __restrict__ foff, size_t n_reads, uint32_t F, uint64_t b0, uint64_t n,
-                                                    const uint64_t* __restrict__ tile_base, const uint16_t* __restrict__ before, const uint32_t* __restrict__ masks,
+                                                    const uint32_t* __restrict__ tile_base, const uint64_t* __restrict__ slab_base, const uint16_t* __restrict__ before,
+                                                    const uint32_t* __restrict__ masks,
                                                     uint64_t total, uint64_t* __restrict__ read_pieces) {
     size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t step = (size_t)gridDim.x * blockDim.x;
@@ -154,7 +237,8 @@ __global__ __launch_bounds__(256) void k_tryp_reads(const uint64_t* __restrict__
             if (target <= b0) at = 0;
             else if (target - b0 < n) {
                 const uint64_t rel = target - b0, g = rel >> 5;          // group of 32 bytes = one thread of k_tryp_count
-                at = tile_base[rel / TILE] + before[g] + (uint64_t)__builtin_popcount(masks[g] & ((1u << (rel & 31u)) - 1u));
+                const uint64_t tile = rel / TILE;
+                at = slab_base[tile / SLAB] + tile_base[tile] + before[g] + (uint64_t)__builtin_popcount(masks[g] & ((1u << (rel & 31u)) - 1u));
             }
         }
         read_pieces[r] = at;
@@ -178,7 +262,10 @@ inline unsigned grid_for(size_t n) {
 struct Digest {
     uint32_t* bits = nullptr;
     uint32_t* tile_counts = nullptr;
-    uint64_t* tile_base = nullptr;
+    uint32_t* tile_base = nullptr;       // pieces of the tile's slab before the tile
+    uint64_t* slab_total = nullptr;
+    uint64_t* slab_base = nullptr;
+    size_t n_slabs = 0;
     uint64_t* d_total = nullptr;
     unsigned long long* d_bad = nullptr;
     uint32_t* masks = nullptr;
@@ -228,25 +315,29 @@ int digest_count(const uint8_t* d_bytes, const uint64_t* d_foff, size_t n_frag, 
     D.n_tiles = (size_t)((D.n + TILE - 1) / TILE);
     if (D.n_tiles > 0x7FFFFFFFull) return fail(UMGAP_ERR_INVALID, "tryptic digest: more than 4 TB of fragments in one call");
     const size_t words = (size_t)(D.n / 32) + 2, tiles = std::max<size_t>(D.n_tiles, 1);
-    const size_t b_bits = align256(words * 4), b_cnt = align256(tiles * 4), b_base = align256(tiles * 8), b_masks = align256(tiles * 256 * 4), b_before = align256(tiles * 256 * 2);
+    D.n_slabs = (tiles + SLAB - 1) / SLAB;
+    const size_t b_bits = align256(words * 4), b_cnt = align256(tiles * 4), b_base = align256(tiles * 4), b_masks = align256(tiles * 256 * 4), b_before = align256(tiles * 256 * 2),
+                 b_slab = align256(D.n_slabs * 8);
     void* mem = nullptr;
-    int rc = scratch_get(D.cache, D.cache_bytes, b_bits + b_cnt + b_base + b_masks + b_before + 512, s, &mem, &D.owned);
+    int rc = scratch_get(D.cache, D.cache_bytes, b_bits + b_cnt + b_base + b_masks + b_before + 2 * b_slab + 512, s, &mem, &D.owned);
     if (rc) return rc;
     char* p = (char*)mem;
     D.bits = (uint32_t*)p; p += b_bits;
     D.tile_counts = (uint32_t*)p; p += b_cnt;
-    D.tile_base = (uint64_t*)p; p += b_base;
+    D.tile_base = (uint32_t*)p; p += b_base;
+    D.slab_total = (uint64_t*)p; p += b_slab;
+    D.slab_base = (uint64_t*)p; p += b_slab;
     D.masks = (uint32_t*)p; p += b_masks;
     D.before = (uint16_t*)p; p += b_before;
-    D.d_total = (uint64_t*)p; p += 256;
+    D.d_total = (uint64_t*)p; p += 8;
     D.d_bad = (unsigned long long*)p;
     UMGAP_HIP(hipMemsetAsync(D.bits, 0, words * 4, s));
-    UMGAP_HIP(hipMemsetAsync(D.d_bad, 0, 8, s));
-    UMGAP_HIP(hipMemsetAsync(D.d_total, 0, 8, s));
+    UMGAP_HIP(hipMemsetAsync(D.d_total, 0, 16, s));      // ... and d_bad behind it
     hipLaunchKernelGGL(k_tryp_mark, dim3(grid_for(n_frag)), dim3(256), 0, s, d_foff, n_frag, D.b0, ends[1], D.bits, D.d_bad);
     if (D.n_tiles) {
         hipLaunchKernelGGL(k_tryp_count, dim3((unsigned)D.n_tiles), dim3(256), 0, s, d_bytes + D.b0, D.bits, D.n, D.tile_counts, D.masks, D.before);
-        hipLaunchKernelGGL(k_tryp_scan, dim3(1), dim3(1024), 0, s, D.tile_counts, D.n_tiles, D.tile_base, D.d_total);
+        hipLaunchKernelGGL(k_tryp_scan, dim3((unsigned)D.n_slabs), dim3(1024), 0, s, D.tile_counts, D.n_tiles, D.tile_base, D.slab_total);
+        hipLaunchKernelGGL(k_tryp_scan_slabs, dim3(1), dim3(1024), 0, s, D.slab_total, D.n_slabs, D.slab_base, D.d_total);
     }
     unsigned long long bad = 0;
     UMGAP_HIP(hipMemcpyAsync(&D.total, D.d_total, 8, hipMemcpyDeviceToHost, s));
@@ -258,7 +349,7 @@ int digest_count(const uint8_t* d_bytes, const uint64_t* d_foff, size_t n_frag, 
 
 // d_offsets holds cap + 1 entries, cap >= D.total (with no bytes at all the one block only writes the end: offsets[0] = b0)
 int digest_write(hipStream_t s, const Digest& D, uint64_t* d_offsets, uint64_t cap) {
-    hipLaunchKernelGGL(k_tryp_write, dim3((unsigned)std::max<size_t>(D.n_tiles, 1)), dim3(256), 0, s, D.masks, D.n, D.b0, D.tile_base, D.total, cap, d_offsets);
+    hipLaunchKernelGGL(k_tryp_write, dim3((unsigned)std::max<size_t>(D.n_tiles, 1)), dim3(256), 0, s, D.masks, D.n, D.b0, D.tile_base, D.slab_base, D.total, cap, d_offsets);
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
 }
@@ -294,6 +385,8 @@ int umgap_classify_tryp_dev(umgap_index* ix, umgap_taxonomy* tx, int method, int
     if (!ix || !tx || (n_reads && (!d_bytes || !d_frag_offsets || !d_out_taxon || !d_out_status))) return fail(UMGAP_ERR_INVALID, "umgap_classify_tryp_dev: null argument");
     if (ix->kind != 2 || !ix->var) return fail(UMGAP_ERR_INVALID, "umgap_classify_tryp_dev: needs a variable-length (tryptic) index");
     if (ix->device != tx->device) return fail(UMGAP_ERR_INVALID, "umgap_classify_tryp_dev: index and taxonomy live on different devices");
+    // a table bound to THIS taxonomy (umgap_index_bind_taxonomy): the hits are interval codes and the aggregate gathers nothing by id
+    if (ix->bound_to && ix->bound_to != tx) return fail(UMGAP_ERR_INVALID, "umgap_classify_tryp_dev: the index is bound to another taxonomy");
     if (!fragments_per_read) return fail(UMGAP_ERR_INVALID, "umgap_classify_tryp_dev: fragments_per_read must be at least 1");
     if (min_len < 1 || max_len < min_len) return fail(UMGAP_ERR_INVALID, "umgap_classify_tryp_dev: need 1 <= min_len <= max_len");
     int rc = use_device(ix->device);
@@ -325,14 +418,15 @@ int umgap_classify_tryp_dev(umgap_index* ix, umgap_taxonomy* tx, int method, int
     }
     rc = digest_write(s, D, d_offsets, D.total);
     if (rc) return done(rc);
-    hipLaunchKernelGGL(k_tryp_reads, dim3(grid_for(n_reads + 1)), dim3(256), 0, s, d_frag_offsets, n_reads, fragments_per_read, D.b0, D.n, D.tile_base, D.before, D.masks, D.total, d_read_pieces);
+    hipLaunchKernelGGL(k_tryp_reads, dim3(grid_for(n_reads + 1)), dim3(256), 0, s, d_frag_offsets, n_reads, fragments_per_read, D.b0, D.n, D.tile_base, D.slab_base, D.before, D.masks, D.total, d_read_pieces);
     if (D.total) {
         rc = var_lookup_dev(ix->var, d_bytes, d_offsets, (size_t)D.total, 0u, d_hits, s, min_len, max_len);
         if (rc) return done(rc);
         if (min_len <= 1) hipLaunchKernelGGL(k_tryp_drop_stars, dim3(grid_for((size_t)D.total)), dim3(256), 0, s, d_bytes, d_offsets, D.total, 0u, d_hits);
     }
     if (hipGetLastError() != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, "umgap_classify_tryp_dev: a launch failed"));
-    rc = umgap_aggregate_dev(tx, method, strategy, factor, lower_bound, ranked_only, d_hits, nullptr, d_read_pieces, n_reads, d_out_taxon, d_out_status, stream);
+    if (ix->bound_to) rc = aggregate_csr_bound_dev(tx, method, strategy, factor, lower_bound, ranked_only, d_hits, D.total, d_read_pieces, n_reads, d_out_taxon, d_out_status, s);
+    else rc = umgap_aggregate_dev(tx, method, strategy, factor, lower_bound, ranked_only, d_hits, nullptr, d_read_pieces, n_reads, d_out_taxon, d_out_status, stream);
     return done(rc);
 }
 
