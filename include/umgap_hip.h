@@ -267,7 +267,10 @@ int umgap_classify9_dev(umgap_index* ix, umgap_taxonomy* tx, int method, float l
  * or the taxonomy has more than 2^22 - 2 reachable taxa.  The fused calls -- umgap_classify9[_strategy]_dev,
  * umgap_classify_prot9[_strategy]_dev and umgap_classify_records (what `umgap prot2kmer2agg` runs: it binds once at
  * start-up) -- take a handle bound to the taxonomy they are given; while bound, every other lookup / dump / save
- * entry point refuses the handle; umgap_index_unbind_taxonomy restores the taxon ids. */
+ * entry point refuses the handle; umgap_index_unbind_taxonomy restores the taxon ids.
+ * Also the peptide table in its packed layout (umgap_index_var_layout() == 1: every key a word over 'A'..'Z'; round 4): the taxon
+ * word of every entry becomes the code, umgap_classify_tryp_dev then aggregates without a by-id gather (reads its first pass
+ * defers get taxon ids back for the large-scratch passes), the plain look-ups and the dump refuse the handle until it is unbound. */
 int umgap_index_bind_taxonomy(umgap_index* ix, umgap_taxonomy* tx);
 int umgap_index_unbind_taxonomy(umgap_index* ix, umgap_taxonomy* tx);
 int umgap_index_is_bound(const umgap_index* ix);
