@@ -450,11 +450,15 @@ int umgap_index_build_windows9_dev(const uint8_t* d_bytes, const uint64_t* d_off
  * Served by umgap_classify_prot9[_strategy]_dev (walking; umgap_index_bind_taxonomy applies) and umgap_index_lookup_prot9_dev;
  * umgap_index_lookup9[_dev], umgap_classify_records and umgap_index_dump9 take the position from the table and the taxon from the
  * walk array (same answers as the plain table, no gain); umgap_index_save / umgap_index_open keep it (UMGAPIX1 kind 10: the walk
- * array follows the stash), so every command of `umgap` runs on such a file.  Not sharded.  Fewer than 2^32 - 1 windows.
+ * array follows the stash), so every command of `umgap` runs on such a file.  Not sharded.  Up to 2^34 entries (walk_ref.hpp).
  * Measured (tools/bench_surface_b.py --walk, 2.1 G-key proteome index, profiles/r03_walk_index.json): reads that are proteome
  * fragments with 0 / 1 / 3 / 6 % of their residues changed classify 1.9 / 1.5 / 1.3 / 1.1 times as fast as over the plain table
  * (0.31 - 0.53 requests per window instead of 1.04 - 1.12); at 20 % the plain table is 1.2 times faster: a walk index is for reads
- * close to the proteome it was built from. */
+ * close to the proteome it was built from.
+ * Round 4: built WITHOUT a values table beside the index under construction (entries take the taxon of the fragment that lists them; a
+ * last pass over the proteome lowers each to the smallest taxon of the fragments that hold its 9-mer), so the proteome's 9-mer count
+ * is bounded by what the index itself needs: 8.4 G windows build on one 288 GB GPU in 16 s (profiles/r04_walk_8g_build.json).
+ * expected_keys bounds the distinct 9-mers (0: the number of windows); umgap_index_num_keys reports it as given. */
 int umgap_index_build_walk9_dev(const uint8_t* d_bytes, const uint64_t* d_offsets, const uint32_t* d_taxa,
                                 size_t n_fragments, uint32_t max_fragment_len, uint64_t expected_keys,
                                 double load_factor, int device, umgap_index** out);

@@ -2459,6 +2459,69 @@ def test_walk_index_beyond_32_bit_entry_numbers(api, torch_cuda):
     torch.cuda.empty_cache()
 
 
+def test_walk_index_of_eight_billion_keys_builds_on_one_gpu(api, torch_cuda):
+    """The walk-order index at the size of the real 9-mer index (BASELINE configs[1]: >= 8 G keys): 200 M fragments = 8.4 G windows
+    through umgap_index_build_walk9_dev on the one GPU -- no values table beside the index under construction (round 4; that table
+    was what did not fit), the values set by a last pass over the proteome.  The plain table of the same proteome answers a sample of
+    reads first and is freed (both do not fit together); the walk index must give the same hits, window for window, and the same
+    fused answers.  Entry numbers need 34 bits here: the table holds entry number >> 1."""
+    import ctypes as C
+    import gc
+    torch = torch_cuda
+    from umgap_amd import _lib
+    from umgap_amd.api import Index, _dev_ptr, _stream_ptr
+    from umgap_amd.synth import SyntheticWorkload
+    gc.collect()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 270e9:
+        pytest.skip("needs ~250 GB of free HBM")
+    L = _lib.load()
+    n_frag, flen, per = 200_000_000, 50, 42
+    w = SyntheticWorkload(n_tax=200_000, n_keys=1000, build_index=False)
+    prot, poffs, ptaxa = _proteome(torch, w, n_frag, flen)
+    n_reads, F = 400_000, 2
+    reads = torch.empty(n_reads * F * flen, dtype=torch.uint8, device="cuda")
+    _lib.check(L.umgap_synth_prot_reads_dev(_dev_ptr(prot), n_frag, flen, 45, 0, n_reads, F, 30, _dev_ptr(reads), 0, _stream_ptr(None)))
+    roffs = torch.arange(0, (n_reads * F + 1) * flen, flen, dtype=torch.int64, device="cuda")
+    oo = torch.arange(0, (n_reads * F + 1) * per, per, dtype=torch.int64, device="cuda")
+    tail = prot[-flen * 2000:].cpu().numpy().reshape(2000, flen)        # the proteome's LAST fragments: the highest entry numbers
+    pk, pok = _pack_windows(tail)
+    d_q = torch.from_numpy(np.concatenate([pk.ravel()[pok.ravel()], np.random.default_rng(3).integers(0, 1 << 45, 50_000, dtype=np.uint64)]).view(np.int64)).cuda()
+
+    def answers(ix):
+        h = torch.full((n_reads * F * per,), -3, dtype=torch.int32, device="cuda")
+        ix.lookup_prot9_dev(reads, roffs, oo, h, miss_value=0)
+        a = ix.lookup9_dev(d_q, miss_value=7).clone()
+        t = torch.full((n_reads,), -1, dtype=torch.int32, device="cuda")
+        st = torch.full_like(t, -1)
+        api.classify_prot9_dev(ix, w.taxonomy, reads, roffs, n_reads, F, t, st, method="tree", strategy="lca*", lower_bound=2.0, seedextend=True, min_seed_size=3, max_gap_size=1)
+        torch.cuda.synchronize()
+        return h, a, t, st
+
+    hp = C.c_void_p()
+    _lib.check(L.umgap_index_build_windows9_dev(_dev_ptr(prot), _dev_ptr(poffs), _dev_ptr(ptaxa), n_frag, flen, n_frag * per, 0.5, 0, C.byref(hp)))
+    plain = Index(hp.value)
+    n_keys = plain.num_keys
+    want = answers(plain)
+    plain.close()
+    gc.collect()
+    torch.cuda.empty_cache()
+    hw = C.c_void_p()
+    _lib.check(L.umgap_index_build_walk9_dev(_dev_ptr(prot), _dev_ptr(poffs), _dev_ptr(ptaxa), n_frag, flen, n_frag * per, 0.5, 0, C.byref(hw)))
+    walk = Index(hw.value)
+    shift, entries, exc = walk.walk_info()
+    assert walk.kind == 10 and walk.num_keys == n_keys and n_keys > 8_000_000_000 and entries > 8_000_000_000 and shift >= 1, (n_keys, walk.num_keys, entries, shift, exc)
+    got = answers(walk)
+    assert torch.equal(want[0], got[0]) and (got[0] != 0).float().mean().item() > 0.5
+    assert torch.equal(want[1], got[1]) and (got[1] != 7).float().mean().item() > 0.5
+    assert torch.equal(want[2], got[2]) and torch.equal(want[3], got[3])
+    walk.close()
+    del prot, poffs, ptaxa, reads
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
 FULL_N_TAX, FULL_N_KEYS = 2_500_000, 8_000_000_000
 
 

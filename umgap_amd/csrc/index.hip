@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void k_owner9(const uint64_t* __restrict__ key
 // ------------------------------------------------------------------------------------------
 // build kernels
 // ------------------------------------------------------------------------------------------
-struct BuildFlags { unsigned long long too_full, duplicate, bad_key, n_stash; };
+struct BuildFlags { unsigned long long too_full, duplicate, bad_key, n_stash, n_kept_noted; };
 constexpr uint32_t STASH_CAP = 1u << 22;  // entries the build may divert before the table is grown
 
 // `slots` points at bucket `lo`.  Whole table: lo = 0, hi = nb, chains wrap to bucket 0 (the halo
@@ -346,7 +346,8 @@ __device__ __forceinline__ bool window_key9(const uint8_t* __restrict__ bytes, u
 // table holds and the position table does not hold yet: the chunk's candidates for "first window of the proteome with that key"
 __global__ __launch_bounds__(256) void k_walk_candidates(uint64_t* __restrict__ slots, uint32_t m, uint32_t nb, const uint8_t* __restrict__ bytes,
                                                          const uint64_t* __restrict__ off, const uint64_t* __restrict__ wbase, size_t n_frag, uint32_t max_len,
-                                                         BuildFlags* flags, TableView V, const uint64_t* __restrict__ t_slots, uint32_t t_m, uint32_t t_nb) {
+                                                         BuildFlags* flags, TableView V, const uint64_t* __restrict__ t_slots, uint32_t t_m, uint32_t t_nb,
+                                                         const uint32_t* __restrict__ frag_taxa) {
     size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x, total = n_frag * max_len;
     for (; g < total; g += stride) {
@@ -356,7 +357,8 @@ __global__ __launch_bounds__(256) void k_walk_candidates(uint64_t* __restrict__ 
         if (off[i + 1] < o || len >= 0xFFFFFFFFull || len < 9 || w + 9 > len) continue;   // k_window_counts gave such a fragment no windows
         uint64_t key;
         if (!window_key9(bytes, o + w, key)) continue;
-        if (lane_get(V, key, UMGAP_NONE) == UMGAP_NONE) continue;                      // not a key of the index: answered by a miss of the table
+        if (!frag_taxa && lane_get(V, key, UMGAP_NONE) == UMGAP_NONE) continue;        // not a key of the index: answered by a miss of the table
+                                                                                       // (frag_taxa: no values table -- every 9-mer of the proteome is a key)
         if (lane_get_wrap(t_slots, t_m, t_nb, key, UMGAP_NONE) != UMGAP_NONE) continue; // an earlier chunk listed it
         const uint32_t val = (uint32_t)(wbase[i] + w);
         uint32_t b, tag;
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(256) void k_walk_candidates(uint64_t* __restrict__ 
 // pass 2: flag[local window] = 1 where the window is the one C names for its key (so: a key of the index, new, first in the chunk);
 // 3 where it holds a key of the index that is listed elsewhere (a repeat: pass 3 decides whether it keeps an entry of its own)
 __global__ __launch_bounds__(256) void k_walk_flags(TableView C, TableView V, const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ off, const uint64_t* __restrict__ wbase,
-                                                    size_t n_frag, uint32_t max_len, uint8_t* __restrict__ flag) {
+                                                    size_t n_frag, uint32_t max_len, uint8_t* __restrict__ flag, const uint32_t* __restrict__ frag_taxa) {
     size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t)gridDim.x * blockDim.x, total = n_frag * max_len;
     for (; g < total; g += stride) {
@@ -394,7 +396,7 @@ __global__ __launch_bounds__(256) void k_walk_flags(TableView C, TableView V, co
         uint8_t fl = 0;
         if (window_key9(bytes, o + w, key)) {
             if (lane_get(C, key, UMGAP_NONE) == local) fl = 1;
-            else if (lane_get(V, key, UMGAP_NONE) != UMGAP_NONE) fl = 3;
+            else if (frag_taxa || lane_get(V, key, UMGAP_NONE) != UMGAP_NONE) fl = 3;
         }
         flag[local] = fl;
     }
@@ -437,7 +439,8 @@ __global__ __launch_bounds__(256) void k_walk_emit(const uint8_t* __restrict__ b
                                                    const uint64_t* __restrict__ fbase, const uint8_t* __restrict__ flag, size_t n_frag, TableView V,
                                                    uint64_t* __restrict__ E, uint64_t e0, uint64_t* __restrict__ t_slots, uint32_t t_m, uint32_t t_nb,
                                                    BuildFlags* flags, uint64_t* __restrict__ stash, uint32_t shift, uint64_t* __restrict__ exc,
-                                                   unsigned long long* __restrict__ n_exc, uint64_t exc_cap) {
+                                                   unsigned long long* __restrict__ n_exc, uint64_t exc_cap, const uint32_t* __restrict__ frag_taxa,
+                                                   uint64_t* __restrict__ kept_list, uint64_t kept_cap) {
     size_t f = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t step = (size_t)gridDim.x * blockDim.x;
     const uint64_t gmask = (1ull << shift) - 1ull;
@@ -455,10 +458,15 @@ __global__ __launch_bounds__(256) void k_walk_emit(const uint8_t* __restrict__ b
             if (!flag[p0 + w]) { prev = false; continue; }
             uint64_t key;
             (void)window_key9(bytes, o + w, key);
-            const uint32_t taxon = lane_get(V, key, 0u);
+            // (frag_taxa: the fragment's own taxon for now; k_walk_min_taxa puts the smallest over all fragments that hold the key)
+            const uint32_t taxon = frag_taxa ? frag_taxa[f] : lane_get(V, key, 0u);
             const uint32_t lo = ((uint32_t)key & 0x7FFFFFFFu) | (prev ? 0x80000000u : 0u);
             E[at] = (uint64_t)taxon | ((uint64_t)lo << 32);
             const bool listed = flag[p0 + w] == 1;
+            if (!listed && kept_list) {            // a kept repeat: nothing points at it, so its taxon is copied from the key's own entry at the end
+                const unsigned long long i = atomicAdd(&flags->n_kept_noted, 1ull);
+                if (i < kept_cap) { kept_list[2 * i] = key; kept_list[2 * i + 1] = at; }
+            }
             if (listed) insert_one(t_slots, t_m, t_nb, 0u, t_nb, key, (uint32_t)(at >> shift), flags, stash);   // (2: a kept repeat, listed elsewhere)
             if (shift) {
                 const uint32_t in_group = (uint32_t)(at & gmask);
@@ -473,6 +481,55 @@ __global__ __launch_bounds__(256) void k_walk_emit(const uint8_t* __restrict__ b
             prev = true;
         }
         while (at & gmask) E[at++] = WALK_PAD_ENTRY;
+    }
+}
+// Builders without a values table, after the index is complete: every window of the proteome lowers the taxon of its key's entry to
+// its fragment's (a 32-bit atomic minimum on the entry's low word) -- the value umgap_index_build_windows9_dev keeps on duplicates.
+__global__ __launch_bounds__(256) void k_walk_min_taxa(TableView T, WalkRef W, const uint8_t* __restrict__ bytes, const uint64_t* __restrict__ off,
+                                                       const uint32_t* __restrict__ frag_taxa, size_t n_frag, uint32_t max_len) {
+    size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x, total = n_frag * max_len;
+    uint32_t* E32 = reinterpret_cast<uint32_t*>(const_cast<uint64_t*>(W.E));
+    for (; g < total; g += stride) {
+        const size_t i = g / max_len;
+        const uint32_t w = (uint32_t)(g % max_len);
+        const uint64_t o = off[i], len = off[i + 1] - o;
+        if (off[i + 1] < o || len >= 0xFFFFFFFFull || len < 9 || w + 9 > len) continue;
+        uint64_t key;
+        if (!window_key9(bytes, o + w, key)) continue;
+        const uint32_t q = lane_get(T, key, UMGAP_NONE);
+        if (q == UMGAP_NONE) continue;
+        const uint64_t p = walk_position(W, q, key);
+        if (p != WALK_NOPOS) atomicMin(E32 + 2 * p, frag_taxa[i]);
+    }
+}
+// ... and the kept repeats (entries nothing points at; list of (key, entry)) take the taxon of their key's own entry
+__global__ __launch_bounds__(256) void k_walk_settle_kept(TableView T, WalkRef W, const uint64_t* __restrict__ list, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    uint32_t* E32 = reinterpret_cast<uint32_t*>(const_cast<uint64_t*>(W.E));
+    for (; i < n; i += step) {
+        const uint64_t key = list[2 * i], at = list[2 * i + 1];
+        const uint32_t q = lane_get(T, key, UMGAP_NONE);
+        if (q == UMGAP_NONE) continue;
+        const uint64_t p = walk_position(W, q, key);
+        if (p != WALK_NOPOS) E32[2 * at] = E32[2 * p];
+    }
+}
+__device__ __forceinline__ uint64_t unmix45_dev(uint64_t h, uint64_t inv_c1, uint64_t inv_c2);
+// ... and so do the second entries of keys that a full chain sent to the stash twice (list of (stash key form, table value))
+__global__ __launch_bounds__(256) void k_walk_settle_dropped(TableView T, WalkRef W, const uint64_t* __restrict__ list, size_t n, uint64_t inv_c1, uint64_t inv_c2) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    uint32_t* E32 = reinterpret_cast<uint32_t*>(const_cast<uint64_t*>(W.E));
+    for (; i < n; i += step) {
+        const uint64_t sk = list[2 * i];
+        const uint64_t key = unmix45_dev((((sk >> R_BITS) / T.m) << R_BITS) | (sk & R_MASK), inv_c1, inv_c2);
+        const uint64_t at = walk_position(W, (uint32_t)list[2 * i + 1], key);
+        const uint32_t q = lane_get(T, key, UMGAP_NONE);
+        if (q == UMGAP_NONE || at == WALK_NOPOS) continue;
+        const uint64_t p = walk_position(W, q, key);
+        if (p != WALK_NOPOS) E32[2 * at] = E32[2 * p];
     }
 }
 // inverse of mix45 (common.hpp) with the inverses of its two odd constants handed in
@@ -1457,7 +1514,11 @@ int umgap_index_build_windows9_dev(const uint8_t* d_bytes, const uint64_t* d_off
 // never showed behind them as walks of one.  Keys of the proteome that the values table does not hold get no entry: they miss.
 }  // extern "C"
 struct umgap_walk_builder {
-    const umgap_index* values = nullptr;   // not owned
+    const umgap_index* values = nullptr;   // not owned; null: the values are the proteome's own taxa (umgap_index_build_walk9_dev)
+    uint64_t expected_keys = 0;            // values == null: an upper bound on the distinct 9-mers
+    std::vector<std::pair<uint64_t*, uint64_t>> kept_lists;   // values == null: per chunk, (key, entry) of the kept repeats (device, count)
+    uint64_t stash_dups = 0;               // entries walk_finalize_table dropped (a key that went to the stash twice)
+    std::vector<std::pair<uint64_t, uint64_t>> dropped;   // ... and which (stash key form, table value): their entries stay in the walk array
     umgap_index* ix = nullptr;             // position table + walk array under construction
     BuildFlags* d_flags = nullptr;
     uint64_t* d_stash = nullptr;
@@ -1484,7 +1545,10 @@ int walk_finalize_table(umgap_walk_builder* b) {
     std::vector<std::pair<uint64_t, uint64_t>> entries(h.n_stash);
     for (size_t i = 0; i < h.n_stash; i++) entries[i] = {raw[2 * i], raw[2 * i + 1]};
     std::sort(entries.begin(), entries.end());
+    b->dropped.clear();
+    for (size_t i = 1; i < entries.size(); i++) if (entries[i].first == entries[i - 1].first) b->dropped.push_back(entries[i]);
     entries.erase(std::unique(entries.begin(), entries.end(), [](const std::pair<uint64_t, uint64_t>& p, const std::pair<uint64_t, uint64_t>& q) { return p.first == q.first; }), entries.end());
+    b->stash_dups = (uint64_t)h.n_stash - entries.size();
     int rc = set_stash(x, entries);
     if (!rc) rc = finish_halo(x);
     return rc;
@@ -1499,6 +1563,7 @@ void umgap_walk_builder_free(umgap_walk_builder* b) {
     if (b->d_stash) (void)hipFree(b->d_stash);
     if (b->d_exc) (void)hipFree(b->d_exc);
     if (b->d_exc_n) (void)hipFree(b->d_exc_n);
+    for (auto& kl : b->kept_lists) if (kl.first) (void)hipFree(kl.first);
     if (b->ix) umgap_index_free(b->ix);
     delete b;
 }
@@ -1506,29 +1571,33 @@ void umgap_walk_builder_free(umgap_walk_builder* b) {
 }  // extern "C"
 namespace {
 // m = 0: the position table sized for the values table's key count at `load`; otherwise m sub-buckets per superblock
-int walk_builder_create(const umgap_index* values, double load, uint32_t m, umgap_walk_builder** out) {
-    if (!values || !out) return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_new: null argument");
-    if (values->kind != 9 || values->bound_to || values->view.home_lo != 0 || values->view.home_hi != values->view.nb)
+// values == null: no values table -- every 9-mer of the proteome is a key (at most expected_keys of them, on `device`), its value the
+// smallest taxon of the fragments that hold it (walk_add_chunk's frag_taxa, k_walk_min_taxa at the end)
+int walk_builder_create(const umgap_index* values, double load, uint32_t m, umgap_walk_builder** out, uint64_t expected_keys = 0, int device = 0) {
+    if (!out || (!values && !expected_keys)) return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_new: null argument");
+    if (values && (values->kind != 9 || values->bound_to || values->view.home_lo != 0 || values->view.home_hi != values->view.nb))
         return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_new: the values must be a whole, unbound 9-mer table");
+    const uint64_t n_keys = values ? values->n_keys : expected_keys;
     // entries: every key once, the second entries of keys that went to the stash, kept repeats (slack), padding (shift > 0).  The
     // table's 32-bit values hold the entry number >> shift: shift 0 up to 2^32 - 2^22 entries, 1 up to 2^33, 2 up to 2^34
     // (UMGAP_WALK_SHIFT in the environment asks for at least that shift: tests exercise the wide form on small indexes)
     uint32_t shift = 0;
     if (const char* env = getenv("UMGAP_WALK_SHIFT")) { const int v = atoi(env); if (v >= 0 && v <= 2) shift = (uint32_t)v; }
-    uint64_t slack = values->n_keys / 8, cap = 0;
+    uint64_t slack = n_keys / 8, cap = 0;
     for (;; shift++) {
         if (shift > 2) return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_new: more than 2^34 entries");
-        const uint64_t pad = shift ? ((1ull << shift) - 1ull) * (values->n_keys / 16 + 4096) : 0;
-        cap = values->n_keys + STASH_CAP + slack + pad;
+        const uint64_t pad = shift ? ((1ull << shift) - 1ull) * (n_keys / 16 + 4096) : 0;
+        cap = n_keys + STASH_CAP + slack + pad;
         if (cap < ((0xFFFFFFFFull - (1ull << 22)) << shift)) break;
     }
     umgap_walk_builder* b = new umgap_walk_builder();
     b->shift = shift;
     b->values = values;
-    int rc = new_handle(values->device, &b->ix);
+    b->expected_keys = n_keys;
+    int rc = new_handle(values ? values->device : device, &b->ix);
     if (rc) { delete b; return rc; }
     auto bail = [&](int code) { umgap_walk_builder_free(b); return code; };
-    rc = alloc_table(b->ix, m ? m : choose_m(std::max<uint64_t>(values->n_keys, 1), load), 0, 1);
+    rc = alloc_table(b->ix, m ? m : choose_m(std::max<uint64_t>(n_keys, 1), load), 0, 1);
     if (rc) return bail(rc);
     b->slack = slack;
     b->cap_walk = cap;
@@ -1548,9 +1617,21 @@ extern "C" {
 
 int umgap_walk_builder_new(const umgap_index* values, double load, umgap_walk_builder** out) { return walk_builder_create(values, load, 0, out); }
 
+}  // extern "C"
+namespace {
+int walk_add_chunk(umgap_walk_builder* b, const uint8_t* d_bytes, const uint64_t* d_offsets, size_t n_fragments, uint32_t max_fragment_len, const uint32_t* d_frag_taxa);
+}
+extern "C" {
 // the next chunk of the proteome (fragments in order; d_offsets[0 .. n_fragments] index d_bytes; fewer than 2^32 - 1 windows per chunk)
 int umgap_walk_builder_add_dev(umgap_walk_builder* b, const uint8_t* d_bytes, const uint64_t* d_offsets, size_t n_fragments, uint32_t max_fragment_len) {
-    if (!b || !b->ix || (n_fragments && (!d_bytes || !d_offsets))) return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_add_dev: null argument");
+    if (b && !b->values) return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_add_dev: this builder takes its values from the proteome (internal)");
+    return walk_add_chunk(b, d_bytes, d_offsets, n_fragments, max_fragment_len, nullptr);
+}
+}  // extern "C"
+namespace {
+// d_frag_taxa (builders without a values table): the taxon of every fragment of the chunk
+int walk_add_chunk(umgap_walk_builder* b, const uint8_t* d_bytes, const uint64_t* d_offsets, size_t n_fragments, uint32_t max_fragment_len, const uint32_t* d_frag_taxa) {
+    if (!b || !b->ix || (n_fragments && (!d_bytes || !d_offsets)) || (!b->values && !d_frag_taxa)) return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_add_dev: null argument");
     if (!n_fragments || max_fragment_len < 9) return UMGAP_OK;
     umgap_index* x = b->ix;
     int rc = use_device(x->device);
@@ -1581,10 +1662,10 @@ int umgap_walk_builder_add_dev(umgap_walk_builder* b, const uint8_t* d_bytes, co
     rc = new_handle(x->device, &c);
     if (rc) return done(rc);
     const size_t iter = n_fragments * (size_t)max_fragment_len;
-    const TableView V = b->values->view;
-    rc = build_with(c, std::min<uint64_t>(n_local, std::max<uint64_t>(b->values->n_keys, 1)), 0.5, 0, 1, [&](umgap_index* t, BuildFlags* f, uint64_t*) {
+    const TableView V = b->values ? b->values->view : TableView{};
+    rc = build_with(c, std::min<uint64_t>(n_local, std::max<uint64_t>(b->expected_keys, 1)), 0.5, 0, 1, [&](umgap_index* t, BuildFlags* f, uint64_t*) {
         hipLaunchKernelGGL(k_walk_candidates, dim3(grid_for(iter, 256, 256 * 16)), dim3(256), 0, t->stream, t->d_slots, t->view.m, t->view.nb, d_bytes, d_offsets,
-                           (const uint64_t*)d_wbase, n_fragments, max_fragment_len, f, V, (const uint64_t*)x->d_slots, x->view.m, x->view.nb);
+                           (const uint64_t*)d_wbase, n_fragments, max_fragment_len, f, V, (const uint64_t*)x->d_slots, x->view.m, x->view.nb, d_frag_taxa);
         return UMGAP_OK;
     });
     if (rc) return done(rc);
@@ -1593,7 +1674,7 @@ int umgap_walk_builder_add_dev(umgap_walk_builder* b, const uint8_t* d_bytes, co
     // walk of one), not as whatever the allocation held
     UMGAP_HIP(hipMemsetAsync(d_flag, 0, n_local, x->stream));
     hipLaunchKernelGGL(k_walk_flags, dim3(grid_for(iter, 256, 256 * 16)), dim3(256), 0, x->stream, c->view, V, d_bytes, d_offsets, (const uint64_t*)d_wbase, n_fragments,
-                       max_fragment_len, d_flag);
+                       max_fragment_len, d_flag, d_frag_taxa);
     uint64_t n_new = 0, n_keep = 0;
     for (uint32_t gap : {WALK_KEEP_REPEATS, 0u}) {   // short runs of repeats keep their entries while the array has room for them
         UMGAP_HIP(hipMemsetAsync(d_total + 2, 0, 8, x->stream));
@@ -1610,15 +1691,23 @@ int umgap_walk_builder_add_dev(umgap_walk_builder* b, const uint8_t* d_bytes, co
     }
     b->n_kept += n_keep;
     if (b->n_walk + n_new > b->cap_walk) return done(fail(UMGAP_ERR_BUILD, "umgap_walk_builder_add_dev: the walk array is full (more fragments than one per 16 keys pad their runs: internal limit)"));
+    uint64_t* d_kept = nullptr;       // without a values table: where the chunk's kept repeats went (their taxa are settled at the end)
+    if (d_frag_taxa && n_keep) {
+        if (hipMalloc((void**)&d_kept, n_keep * 16) != hipSuccess) return done(fail(UMGAP_ERR_NOMEM, "umgap_index_build_walk9_dev: hipMalloc failed"));
+        b->kept_lists.emplace_back(d_kept, n_keep);
+        UMGAP_HIP(hipMemsetAsync(&b->d_flags->n_kept_noted, 0, 8, x->stream));
+    }
     if (n_new)
         hipLaunchKernelGGL(k_walk_emit, dim3(grid_for(n_fragments)), dim3(256), 0, x->stream, d_bytes, d_offsets, (const uint64_t*)d_wbase, (const uint64_t*)d_fbase,
                            (const uint8_t*)d_flag, n_fragments, V, x->d_walk, b->n_walk, x->d_slots, x->view.m, x->view.nb, b->d_flags, b->d_stash, b->shift, b->d_exc,
-                           b->d_exc_n, WALK_EXC_CAP);
+                           b->d_exc_n, WALK_EXC_CAP, d_frag_taxa, d_kept, (uint64_t)n_keep);
     e = hipStreamSynchronize(x->stream);
     if (e != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, std::string("umgap_walk_builder_add_dev: ") + hipGetErrorString(e)));
     b->n_walk += n_new;
     return done(UMGAP_OK);
 }
+}  // namespace
+extern "C" {
 
 // the same from host memory (the chunk is copied to the device for the call)
 int umgap_walk_builder_add(umgap_walk_builder* b, const uint8_t* bytes, const uint64_t* offsets, size_t n_fragments, uint32_t max_fragment_len) {
@@ -1646,13 +1735,21 @@ int umgap_walk_builder_add(umgap_walk_builder* b, const uint8_t* bytes, const ui
     return rc;
 }
 
-int umgap_walk_builder_finish(umgap_walk_builder* b, umgap_index** out) {
+}  // extern "C"
+namespace { int walk_finish(umgap_walk_builder* b, umgap_index** out, std::vector<std::pair<uint64_t, uint64_t>>* dropped_out); }
+extern "C" {
+int umgap_walk_builder_finish(umgap_walk_builder* b, umgap_index** out) { return walk_finish(b, out, nullptr); }
+}  // extern "C"
+namespace {
+// dropped_out: receives the stash entries that were dropped as duplicates (builders without a values table settle their taxa)
+int walk_finish(umgap_walk_builder* b, umgap_index** out, std::vector<std::pair<uint64_t, uint64_t>>* dropped_out) {
     if (!b || !b->ix || !out) return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_finish: null argument");
     umgap_index* x = b->ix;
     int rc = use_device(x->device);
     if (rc) return rc;
     rc = walk_finalize_table(b);
     if (rc) return rc;
+    if (dropped_out) *dropped_out = b->dropped;
     // the keys the proteome never showed: appended as walks of one
     unsigned long long* d_n = nullptr;
     uint64_t* d_keys = nullptr;
@@ -1662,15 +1759,18 @@ int umgap_walk_builder_finish(umgap_walk_builder* b, umgap_index** out) {
         return code;
     };
     if (hipMalloc((void**)&d_n, 8) != hipSuccess) return done(fail(UMGAP_ERR_NOMEM, "umgap_walk_builder_finish: hipMalloc failed"));
-    const TableView V = b->values->view;
+    const TableView V = b->values ? b->values->view : TableView{};
     const uint64_t inv1 = inv_odd45(MIX_C1), inv2 = inv_odd45(MIX_C2);
     const size_t scan = (size_t)V.nb * SLOTS + V.n_stash;
     unsigned long long n_left = 0;
-    UMGAP_HIP(hipMemsetAsync(d_n, 0, 8, x->stream));
-    hipLaunchKernelGGL(k_walk_leftovers, dim3(grid_for(scan, 256, 256 * 16)), dim3(256), 0, x->stream, V, x->view, inv1, inv2, (uint64_t*)nullptr, (uint32_t*)nullptr, d_n);
-    hipError_t e = hipMemcpyAsync(&n_left, d_n, 8, hipMemcpyDeviceToHost, x->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(x->stream);
-    if (e != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, std::string("umgap_walk_builder_finish: ") + hipGetErrorString(e)));
+    hipError_t e = hipSuccess;
+    if (b->values) {        // (without a values table there is nothing the proteome did not show)
+        UMGAP_HIP(hipMemsetAsync(d_n, 0, 8, x->stream));
+        hipLaunchKernelGGL(k_walk_leftovers, dim3(grid_for(scan, 256, 256 * 16)), dim3(256), 0, x->stream, V, x->view, inv1, inv2, (uint64_t*)nullptr, (uint32_t*)nullptr, d_n);
+        e = hipMemcpyAsync(&n_left, d_n, 8, hipMemcpyDeviceToHost, x->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(x->stream);
+        if (e != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, std::string("umgap_walk_builder_finish: ") + hipGetErrorString(e)));
+    }
     if (n_left) {
         if (b->n_walk + n_left > b->cap_walk) return done(fail(UMGAP_ERR_BUILD, "umgap_walk_builder_finish: more entries than the values table has keys (internal error)"));
         if (hipMalloc((void**)&d_keys, n_left * 8) != hipSuccess || hipMalloc((void**)&d_taxa, n_left * 4) != hipSuccess || hipMalloc((void**)&d_pos, n_left * 4) != hipSuccess)
@@ -1719,31 +1819,38 @@ int umgap_walk_builder_finish(umgap_walk_builder* b, umgap_index** out) {
     }
     x->kind = 10;
     x->n_walk = b->n_walk;
-    x->n_keys = b->values->n_keys;
+    x->n_keys = b->values ? b->values->n_keys : b->expected_keys;     // (as announced, like umgap_index_build_windows9_dev's own count)
     *out = x;
     b->ix = nullptr;
     umgap_walk_builder_free(b);
     return done(UMGAP_OK);
 }
+}  // namespace
+extern "C" {
 
 // A proteome's own index in walk order: values as umgap_index_build_windows9_dev (the smallest taxon over the fragments that hold
 // a 9-mer), the proteome handed to the builder in chunks of at most 2^29 windows (the chunk's temporary table stays small).
 int umgap_index_build_walk9_dev(const uint8_t* d_bytes, const uint64_t* d_offsets, const uint32_t* d_taxa, size_t n_fragments,
                                 uint32_t max_fragment_len, uint64_t expected_keys, double load, int device, umgap_index** out) {
     if (!out || !n_fragments || !d_bytes || !d_offsets || !d_taxa || max_fragment_len < 9) return fail(UMGAP_ERR_INVALID, "umgap_index_build_walk9_dev: bad argument");
-    umgap_index* t1 = nullptr;
-    int rc = umgap_index_build_windows9_dev(d_bytes, d_offsets, d_taxa, n_fragments, max_fragment_len, expected_keys, load, device, &t1);   // the values
+    // Round 4: no values table beside the index under construction (that table -- 164 GB for 8.4 G keys -- was what kept an index of the
+    // real size class from being built on one GPU).  Every 9-mer of the proteome is a key; an entry is written with the taxon of the
+    // fragment that lists it, and a last pass over the proteome lowers it to the smallest taxon of all fragments that hold the key.
+    int rc = use_device(device);
     if (rc) return rc;
     umgap_walk_builder* b = nullptr;
     uint32_t* d_cnt = nullptr;
     uint64_t *d_wbase = nullptr, *d_cuts = nullptr;
+    umgap_index* ix = nullptr;
     auto done = [&](int code) {
         for (void* p : {(void*)d_cnt, (void*)d_wbase, (void*)d_cuts}) if (p) (void)hipFree(p);
         if (b) umgap_walk_builder_free(b);
-        umgap_index_free(t1);
+        if (code && ix) umgap_index_free(ix);
         return code;
     };
-    rc = walk_builder_create(t1, load, t1->view.m, &b);   // the position table holds the same keys as the values table: same geometry
+    UMGAP_HIP(hipDeviceSynchronize());   // the caller's arrays may have been produced on any stream
+    if (!expected_keys) expected_keys = (uint64_t)n_fragments * (max_fragment_len - 8);
+    rc = walk_builder_create(nullptr, load, 0, &b, expected_keys, device);
     if (rc) return done(rc);
     hipStream_t s = b->ix->stream;
     if (hipMalloc((void**)&d_cnt, n_fragments * 4) != hipSuccess || hipMalloc((void**)&d_wbase, (n_fragments + 2) * 8) != hipSuccess)
@@ -1754,6 +1861,7 @@ int umgap_index_build_walk9_dev(const uint8_t* d_bytes, const uint64_t* d_offset
     hipError_t e = hipMemcpyAsync(&n_windows, d_wbase + n_fragments + 1, 8, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, std::string("umgap_index_build_walk9_dev: ") + hipGetErrorString(e)));
+    if (n_windows > expected_keys + expected_keys / 8) return done(fail(UMGAP_ERR_BUILD, "umgap_index_build_walk9_dev: the proteome has more windows than expected_keys allows for"));
     const uint64_t per = 1ull << 29;
     const uint32_t n_chunks = (uint32_t)std::max<uint64_t>(1, (n_windows + per - 1) / per);
     std::vector<uint64_t> cuts(n_chunks + 1, 0);
@@ -1763,13 +1871,41 @@ int umgap_index_build_walk9_dev(const uint8_t* d_bytes, const uint64_t* d_offset
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, std::string("umgap_index_build_walk9_dev: ") + hipGetErrorString(e)));
     cuts[n_chunks] = n_fragments;
+    for (void** p : {(void**)&d_cnt, (void**)&d_wbase, (void**)&d_cuts}) { (void)hipFree(*p); *p = nullptr; }
     for (uint32_t c = 0; c < n_chunks && !rc; c++)
-        if (cuts[c + 1] > cuts[c]) rc = umgap_walk_builder_add_dev(b, d_bytes, d_offsets + cuts[c], (size_t)(cuts[c + 1] - cuts[c]), max_fragment_len);
+        if (cuts[c + 1] > cuts[c]) rc = walk_add_chunk(b, d_bytes, d_offsets + cuts[c], (size_t)(cuts[c + 1] - cuts[c]), max_fragment_len, d_taxa + cuts[c]);
     if (rc) return done(rc);
-    umgap_index* ix = nullptr;
-    rc = umgap_walk_builder_finish(b, &ix);
-    if (rc) return done(rc);
+    std::vector<std::pair<uint64_t*, uint64_t>> kept;
+    kept.swap(b->kept_lists);            // (finish frees the builder)
+    std::vector<std::pair<uint64_t, uint64_t>> dropped;
+    auto drop_kept = [&]() { for (auto& kl : kept) if (kl.first) (void)hipFree(kl.first); kept.clear(); };
+    rc = walk_finish(b, &ix, &dropped);
+    if (rc) { drop_kept(); return done(rc); }
     b = nullptr;   // consumed
+    // the values: every window of the proteome lowers its key's entry to its fragment's taxon; then the kept repeats copy theirs
+    s = ix->stream;
+    const WalkRef W = walk_ref_of(ix);
+    hipLaunchKernelGGL(k_walk_min_taxa, dim3(grid_for(n_fragments * (size_t)max_fragment_len, 256, 256 * 16)), dim3(256), 0, s, ix->view, W, d_bytes, d_offsets, d_taxa, n_fragments,
+                       max_fragment_len);
+    for (auto& kl : kept)
+        hipLaunchKernelGGL(k_walk_settle_kept, dim3(grid_for(kl.second)), dim3(256), 0, s, ix->view, W, (const uint64_t*)kl.first, (size_t)kl.second);
+    uint64_t* d_dropped = nullptr;
+    if (!dropped.empty()) {
+        std::vector<uint64_t> raw(2 * dropped.size());
+        for (size_t i = 0; i < dropped.size(); i++) { raw[2 * i] = dropped[i].first; raw[2 * i + 1] = dropped[i].second; }
+        if (hipMalloc((void**)&d_dropped, raw.size() * 8) != hipSuccess || hipMemcpyAsync(d_dropped, raw.data(), raw.size() * 8, hipMemcpyHostToDevice, s) != hipSuccess) {
+            if (d_dropped) (void)hipFree(d_dropped);
+            drop_kept();
+            return done(fail(UMGAP_ERR_NOMEM, "umgap_index_build_walk9_dev: hipMalloc failed"));
+        }
+        hipLaunchKernelGGL(k_walk_settle_dropped, dim3(grid_for(dropped.size())), dim3(256), 0, s, ix->view, W, (const uint64_t*)d_dropped, dropped.size(), inv_odd45(MIX_C1), inv_odd45(MIX_C2));
+        e = hipStreamSynchronize(s);      // (raw is read by the copy)
+    }
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (d_dropped) (void)hipFree(d_dropped);
+    drop_kept();
+    if (e != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, std::string("umgap_index_build_walk9_dev: ") + hipGetErrorString(e)));
     *out = ix;
     return done(UMGAP_OK);
 }
