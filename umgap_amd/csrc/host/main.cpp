@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <functional>
 #include <map>
+#include <atomic>
 #include <memory>
 #include <regex>
 
@@ -28,6 +29,12 @@
 using namespace umgap_host;
 
 namespace {
+// an uninitialised, grow-only byte buffer
+struct RawBuf {
+    std::unique_ptr<char[]> p;
+    size_t cap = 0, n = 0;
+    void need(size_t bytes) { if (cap < bytes) { cap = bytes + bytes / 4; p.reset(new char[cap]); } n = 0; }
+};
 
 [[noreturn]] void lib_fail(int rc) {
     (void)rc;
@@ -501,12 +508,23 @@ void stream_kmer_records(FILE* in, FILE* outf, umgap_index* ix, bool one_on_one,
     auto format_part = [&](const char* d, const KmerPart& P, const uint32_t* hits, const uint64_t* frag_off, size_t rb, size_t re, std::string& out) {
         size_t f = P.rec_base;                     // fragment number (emitted records only) of record rb
         for (size_t r = 0; r < rb; r++) f += P.emit[r];
-        char last_line[24];
+        // written through a raw pointer into a scratch buffer of the thread that is big enough for the range (no capacity check per
+        // line), then appended to `out` in one piece
+        size_t bound = 32;
+        for (size_t r = rb; r < re; r++)
+            if (P.emit[r]) bound += 2 + P.hdr_len[r] + ((size_t)P.seq_len[r] - 8) * 11;
+        static thread_local RawBuf scratch;
+        scratch.need(bound);
+        char* w = scratch.p.get();
+        char last_line[24] = {0};
         size_t last_len = 0;
         uint32_t last_t = 0;
         for (size_t r = rb; r < re; r++) {
             if (!P.emit[r]) continue;
-            out.push_back('>'); out.append(d + P.hdr_off[r], P.hdr_len[r]); out.push_back('\n');
+            *w++ = '>';
+            memcpy(w, d + P.hdr_off[r], P.hdr_len[r]);
+            w += P.hdr_len[r];
+            *w++ = '\n';
             const uint32_t* h = hits + frag_off[f];
             const size_t windows = (size_t)P.seq_len[r] - 8;
             f++;
@@ -514,15 +532,19 @@ void stream_kmer_records(FILE* in, FILE* outf, umgap_index* ix, bool one_on_one,
                 const uint32_t t = h[i];
                 if (t == 0 && !one_on_one) continue;
                 if (t != last_t || !last_len) {
-                    const size_t before = out.size();
-                    append_uint(out, t);
-                    out.push_back('\n');
-                    last_len = out.size() - before;
-                    memcpy(last_line, out.data() + before, last_len);
+                    char* const b0 = w;
+                    w = write_uint(w, t);
+                    *w++ = '\n';
+                    last_len = (size_t)(w - b0);
+                    memcpy(last_line, b0, last_len);
                     last_t = t;
-                } else out.append(last_line, last_len);
+                } else {
+                    memcpy(w, last_line, 16);      // (a line is at most 11 bytes; the buffer has the slack)
+                    w += last_len;
+                }
             }
         }
+        out.append(scratch.p.get(), (size_t)(w - scratch.p.get()));
     };
     auto stage_b = [&](Job& J) {
         const char* d = J.d;
@@ -1442,7 +1464,7 @@ struct FuseJob {
     std::vector<uint64_t> hdr_end;    // n_reads + 1
     size_t n_reads = 0;
     PinnedVec<uint32_t> out_taxon, out_status;
-    std::vector<std::string> outs;    // formatted output of the job, one string per formatting thread
+    std::vector<RawBuf> outs;         // formatted output of the job, one buffer per formatting thread
 };
 
 int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
@@ -1502,18 +1524,28 @@ int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
         for (size_t r = 0; r < J.n_reads; r++)
             if (J.out_status[r] == UMGAP_READ_UNKNOWN_TAXON || J.out_status[r] == UMGAP_READ_PANIC || J.out_status[r] == 4u) { bad = r; break; }
         const size_t nt = std::max<size_t>(1, std::min<size_t>(T / 2, bad / 4096 + 1));
-        std::vector<std::string>& outs = J.outs;   // (kept with the job: the strings keep their memory from block to block)
+        // every formatting thread writes its range straight into a buffer of its own that is big enough for it (no per-byte capacity
+        // checks); the buffers keep their memory from block to block
+        std::vector<RawBuf>& outs = J.outs;
         if (outs.size() < nt) outs.resize(nt);
-        for (auto& o : outs) o.clear();
         parallel_for(nt, [&](size_t t) {
-            size_t lo = bad * t / nt, hi = bad * (t + 1) / nt;
-            outs[t].reserve((hi - lo) * 12 + (size_t)(J.hdr_end[hi] - J.hdr_end[lo]));
+            const size_t lo = bad * t / nt, hi = bad * (t + 1) / nt;
+            RawBuf& o = outs[t];
+            o.need((hi - lo) * 13 + (size_t)(J.hdr_end[hi] - J.hdr_end[lo]) + 16);      // '>' + header + '\n' + at most 10 digits + '\n'
+            char* w = o.p.get();
+            const char* hdrs = J.hdrs.data();
             for (size_t r = lo; r < hi; r++) {
-                outs[t].push_back('>'); outs[t].append(J.hdrs.data() + J.hdr_end[r], J.hdr_end[r + 1] - J.hdr_end[r]); outs[t].push_back('\n');
-                append_uint(outs[t], J.out_taxon[r]); outs[t].push_back('\n');
+                const size_t hl = (size_t)(J.hdr_end[r + 1] - J.hdr_end[r]);
+                *w++ = '>';
+                memcpy(w, hdrs + J.hdr_end[r], hl);
+                w += hl;
+                *w++ = '\n';
+                w = write_uint(w, J.out_taxon[r]);
+                *w++ = '\n';
             }
+            o.n = (size_t)(w - o.p.get());
         });
-        for (auto& o : outs) fwrite(o.data(), 1, o.size(), outf);
+        for (size_t t = 0; t < nt; t++) fwrite(outs[t].p.get(), 1, outs[t].n, outf);
         t_fmt += now() - t0;
         if (bad < J.n_reads) {
             fflush(outf);
@@ -1606,8 +1638,19 @@ int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
             for (size_t f = f0; f < n_frag; f++) next.frag_len.push_back(J.frag_off[f + 1] - J.frag_off[f]);
         }
         J.n_reads = n_now;
-        // taxa2agg's reader strips one more CR from the header line it prints
-        for (size_t r = 0; r < n_now; r++)
+        // taxa2agg's reader strips one more CR from the header line it prints (looked for by all threads: 16 M reads per second and
+        // thread otherwise stood in front of every block)
+        std::atomic<bool> any_cr{false};
+        {
+            const size_t nt = std::max<size_t>(1, std::min<size_t>(T, n_now / 65536 + 1));
+            parallel_for(nt, [&](size_t t) {
+                bool cr = false;
+                for (size_t r = n_now * t / nt, hi = n_now * (t + 1) / nt; r < hi && !cr; r++)
+                    cr = J.hdr_end[r + 1] > J.hdr_end[r] && J.hdrs[J.hdr_end[r + 1] - 1] == '\r';
+                if (cr) any_cr.store(true, std::memory_order_relaxed);
+            });
+        }
+        for (size_t r = 0; any_cr.load() && r < n_now; r++)
             if (J.hdr_end[r + 1] > J.hdr_end[r] && J.hdrs[J.hdr_end[r + 1] - 1] == '\r') {
                 // rare: rebuild the header table without those bytes
                 std::string h2; std::vector<uint64_t> e2(n_groups + 1, 0);
