@@ -285,3 +285,29 @@ def test_cleavage_pattern_rewriter_against_python_re(tmp_path):
             assert g.startswith("ERROR regex parse error:"), (line, g)
         else:
             assert g == w, (line, g, w)
+
+
+def test_seedextend_and_uniq_on_a_stream_of_many_blocks(tmp_path):
+    """The text filters on a stream big enough for their block machinery to turn over several times -- blocks cut ahead of the
+    caller by the filler thread (piped stdin), output buffers handed to the writer thread without a copy and reused two blocks later,
+    uniq's output flushed in 4 MB pieces while a group is open across the flush -- byte for byte like the oracle's commands."""
+    import subprocess
+    rng = np.random.default_rng(77)
+    recs = []
+    taxa = [0, 0, 7, 7, 7, 12, 12, 9, 1, 433, 433, 433, 433]
+    for r in range(220_000):
+        hdr = b">r%d/%d" % (r // 2, 1 + r % 2)
+        n = int(rng.integers(0, 40))
+        items = rng.choice(taxa, n)
+        recs.append(hdr + b"\n" + b"".join(b"%d\n" % t for t in items))
+    data = b"".join(recs)
+    assert len(data) > 12 << 20
+    env = dict(os.environ, UMGAP_BLOCK_BYTES=str(1 << 20), UMGAP_THREADS="4")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    umgap = os.path.join(root, "umgap_amd", "bin", "umgap")
+    if not os.path.exists(umgap):
+        pytest.skip("the umgap command is not built")
+    for args in (["seedextend", "-g", "1", "-s", "3"], ["uniq", "-d", "/"], ["uniq"]):
+        p = subprocess.run([umgap] + args, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        orc, oout, _ = O.run_cli(args, data)
+        assert p.returncode == orc == 0 and p.stdout == oout, (args, p.returncode, len(p.stdout), len(oout), p.stderr[-300:])

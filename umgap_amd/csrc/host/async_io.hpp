@@ -20,6 +20,7 @@
 
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -81,13 +82,33 @@ class AsyncIo {
                 auto& r = registry();
                 for (size_t i = 0; i < r.size(); i++)
                     if (r[i] == *p) { r.erase(r.begin() + (long)i); break; }
+                auto& bf = by_file();
+                for (size_t i = 0; i < bf.size(); i++)
+                    if (bf[i].second == *p) { bf.erase(bf.begin() + (long)i); break; }
             }
             delete p;
             return 0;
         };
         FILE* f = fopencookie(new std::shared_ptr<Out>(st), "wb", io);
-        if (f) setvbuf(f, nullptr, _IOFBF, 1 << 16);
+        if (f) {
+            setvbuf(f, nullptr, _IOFBF, 1 << 16);
+            std::lock_guard<std::mutex> g(registry_mutex());
+            by_file().emplace_back(f, st);
+        }
         return f;
+    }
+    // [p, p + n) written to `f` without a copy, behind everything written to f so far: true if f is one of these writers -- on_done then
+    // runs (on the writer thread) when the bytes are out and the caller may touch them again; false: nothing was done
+    static bool write_owned(FILE* f, const char* p, size_t n, std::function<void()> on_done) {
+        std::shared_ptr<Out> o;
+        {
+            std::lock_guard<std::mutex> g(registry_mutex());
+            for (auto& e : by_file()) if (e.first == f) { o = e.second; break; }
+        }
+        if (!o) return false;
+        fflush(f);                      // what stdio still holds goes first
+        o->write_owned(p, n, std::move(on_done));
+        return true;
     }
     // everything handed to any writer so far has reached its descriptor (call after fflush)
     static void drain_all() {
@@ -119,15 +140,23 @@ class AsyncIo {
     static Pool& pool() { static Pool* p = new Pool(); return *p; }   // (never destroyed: detached reader threads may outlive main)
     struct Chunk {
         char* p = nullptr;
-        size_t n = 0, off = 0, cap = 0;   // cap == CHUNK: the buffer came from the pool and goes back to it
+        size_t n = 0, off = 0, cap = 0;   // cap == CHUNK: the buffer came from the pool and goes back to it; cap == 0 with p set: the caller's
+        std::function<void()> on_done;    // memory (write_owned), not freed here -- on_done tells the caller when the writer is through with it
         Chunk() = default;
         Chunk(const Chunk&) = delete;
         Chunk& operator=(const Chunk&) = delete;
-        Chunk(Chunk&& o) noexcept : p(o.p), n(o.n), off(o.off), cap(o.cap) { o.p = nullptr; }
-        Chunk& operator=(Chunk&& o) noexcept { if (this != &o) { release(); p = o.p; n = o.n; off = o.off; cap = o.cap; o.p = nullptr; } return *this; }
+        Chunk(Chunk&& o) noexcept : p(o.p), n(o.n), off(o.off), cap(o.cap), on_done(std::move(o.on_done)) { o.p = nullptr; o.on_done = nullptr; }
+        Chunk& operator=(Chunk&& o) noexcept {
+            if (this != &o) { release(); p = o.p; n = o.n; off = o.off; cap = o.cap; on_done = std::move(o.on_done); o.p = nullptr; o.on_done = nullptr; }
+            return *this;
+        }
         ~Chunk() { release(); }
         void alloc(size_t bytes) { release(); if (bytes <= CHUNK) { p = pool().get(); cap = CHUNK; } else { p = new char[bytes]; cap = bytes; } }
-        void release() { if (!p) return; if (cap == CHUNK) pool().put(p); else delete[] p; p = nullptr; }
+        void release() {
+            if (p && cap) { if (cap == CHUNK) pool().put(p); else delete[] p; }
+            p = nullptr;
+            if (on_done) { auto f = std::move(on_done); on_done = nullptr; f(); }
+        }
         char* get() const { return p; }
     };
     struct In {
@@ -214,12 +243,28 @@ class AsyncIo {
                     if (w < 0) { if (errno == EINTR) continue; err = errno; break; }
                     off += (size_t)w;
                 }
+                const size_t n_done = c.n;
+                c.release();                      // (the caller's memory is its own again: before the queue reads as idle)
                 std::lock_guard<std::mutex> lk(m);
-                queued -= c.n;
+                queued -= n_done;
                 busy = false;
                 space.notify_all();
                 if (q.empty()) idle.notify_all();
             }
+        }
+        // the caller's bytes [p, p + n) go out as they lie (no copy); on_done runs on the writer thread when they are out (or dropped
+        // after a write error) -- until then the caller must leave them alone
+        void write_owned(const char* p, size_t n, std::function<void()> on_done) {
+            std::unique_lock<std::mutex> lk(m);
+            space.wait(lk, [&] { return queued < WRITE_BEHIND; });
+            Chunk c;
+            c.p = const_cast<char*>(p);
+            c.n = n;
+            c.cap = 0;
+            c.on_done = std::move(on_done);
+            q.push_back(std::move(c));
+            queued += n;
+            data.notify_all();
         }
         ssize_t write(const char* buf, size_t n) {
             std::unique_lock<std::mutex> lk(m);
@@ -227,7 +272,7 @@ class AsyncIo {
             space.wait(lk, [&] { return queued < WRITE_BEHIND; });
             size_t done_b = 0;
             // small writes join the last chunk while it has room
-            if (!q.empty() && q.back().off == 0 && q.back().n < CHUNK) {
+            if (!q.empty() && q.back().cap == CHUNK && q.back().off == 0 && q.back().n < CHUNK) {
                 Chunk& c = q.back();
                 const size_t take = std::min(n, CHUNK - c.n);
                 memcpy(c.p + c.n, buf, take);
@@ -264,6 +309,7 @@ class AsyncIo {
     };
     static std::mutex& registry_mutex() { static std::mutex m; return m; }
     static std::vector<std::shared_ptr<Out>>& registry() { static std::vector<std::shared_ptr<Out>> r; return r; }
+    static std::vector<std::pair<FILE*, std::shared_ptr<Out>>>& by_file() { static std::vector<std::pair<FILE*, std::shared_ptr<Out>>> r; return r; }
 };
 
 }  // namespace umgap_host

@@ -36,6 +36,26 @@ struct RawBuf {
     void need(size_t bytes) { if (cap < bytes) { cap = bytes + bytes / 4; p.reset(new char[cap]); } n = 0; }
 };
 
+// Output that leaves without a copy: the bytes of a buffer are handed to the writer thread as they lie (AsyncIo::write_owned) and the
+// latch says when the buffer is the command's own again.  Commands keep two sets of output buffers and alternate.
+struct OutLatch {
+    std::mutex m;
+    std::condition_variable cv;
+    size_t pending = 0;
+    void add() { std::lock_guard<std::mutex> g(m); pending++; }
+    void done() { std::lock_guard<std::mutex> g(m); if (--pending == 0) cv.notify_all(); }
+    void wait() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return pending == 0; }); }
+    ~OutLatch() { wait(); }            // (a buffer must outlive its write: declare the latch BEHIND the buffers it guards)
+};
+inline void write_owned_or_copy(FILE* f, const char* p, size_t n, OutLatch& latch) {
+    if (!n) return;
+    latch.add();
+    if (!AsyncIo::write_owned(f, p, n, [&latch]() { latch.done(); })) {
+        fwrite(p, 1, n, f);
+        latch.done();
+    }
+}
+
 [[noreturn]] void lib_fail(int rc) {
     (void)rc;
     throw CliError(umgap_last_error());
@@ -1221,11 +1241,17 @@ int cmd_seedextend(const std::vector<std::string>& args) {
     const char* d;
     size_t len;
     blocks.map_regular_file();
-    std::vector<SePart> parts;             // (kept from block to block: the output strings keep their memory)
-    while (blocks.next(d, len)) {
+    // (kept from block to block: the output strings keep their memory; two sets take turns, because a set's strings belong to the
+    // writer thread until it has written them -- they leave without a copy)
+    std::vector<SePart> part_sets[2];
+    OutLatch latches[2];
+    for (int turn = 0; blocks.next(d, len); turn ^= 1) {
         if (blocks.first_line_error()) throw CliError("Expected > at beginning of fasta header.");
         std::vector<size_t> cuts = split_records(d, len, T);
         const size_t np = cuts.size() - 1;
+        std::vector<SePart>& parts = part_sets[turn];
+        OutLatch& latch = latches[turn];
+        latch.wait();
         if (parts.size() < np) parts.resize(np);
         parallel_for(np, [&](size_t pi) {
             SePart& P = parts[pi];
@@ -1316,7 +1342,7 @@ int cmd_seedextend(const std::vector<std::string>& args) {
             } catch (CliError& e) { P.error = e; }   // the failing record is not printed
         });
         for (size_t i = 0; i < np; i++) {
-            fwrite(parts[i].out.data(), 1, parts[i].out.size(), stdout);
+            write_owned_or_copy(stdout, parts[i].out.data(), parts[i].out.size(), latch);
             if (parts[i].panic) { fflush(stdout); throw CliPanic("slice index out of range"); }
             if (parts[i].error) { fflush(stdout); throw *parts[i].error; }
         }
@@ -1341,7 +1367,11 @@ int cmd_uniq(const std::vector<std::string>& args) {
         const unsigned T = worker_count();
         const char* d;
         size_t len;
-        std::string out, cur_hdr;          // the record being merged (survives block boundaries)
+        // two output buffers take turns: a flushed one belongs to the writer thread until it is written (it leaves without a copy)
+        std::string out_bufs[2], cur_hdr;  // cur_hdr: the record being merged (survives block boundaries)
+        OutLatch out_latches[2];
+        int out_turn = 0;
+        std::string* out = &out_bufs[0];
         // The body of the open group goes straight to `out` behind its header line -- except while it is still at most ONE item of
         // no bytes, which the writer prints as nothing at all: items.join("\n") is empty iff there is no item or a single empty
         // one (src/io/fasta.rs:168,176-178); that single "\n" waits in `cur_small` until a second item decides.
@@ -1351,7 +1381,7 @@ int cmd_uniq(const std::vector<std::string>& args) {
         auto write_cur = [&]() { have_cur = false; cur_small = false; };     // (a group that ends while `cur_small` is pending prints no body)
         auto add_body = [&](const char* b, size_t n, uint64_t items) {
             if (cur_items + items <= 1 && cur_bytes + n <= 1) { cur_small = cur_small || n == 1; }
-            else { if (cur_small) { out.push_back('\n'); cur_small = false; } out.append(b, n); }
+            else { if (cur_small) { out->push_back('\n'); cur_small = false; } out->append(b, n); }
             cur_items += items;
             cur_bytes += n;
         };
@@ -1396,8 +1426,8 @@ int cmd_uniq(const std::vector<std::string>& args) {
                     if (!(have_cur && h == std::string_view(cur_hdr))) {          // src/commands/uniq.rs:70-77
                         write_cur();
                         cur_hdr.assign(h); cur_items = 0; cur_bytes = 0; have_cur = true;
-                        cur_mark = out.size();
-                        out.push_back('>'); out.append(cur_hdr); out.push_back('\n');
+                        cur_mark = out->size();
+                        out->push_back('>'); out->append(cur_hdr); out->push_back('\n');
                     }
                     if (r.verbatim) add_body(d + r.body_off, r.body_len, r.n_items);
                     else {
@@ -1410,8 +1440,16 @@ int cmd_uniq(const std::vector<std::string>& args) {
                 if (parts[pi].bad_utf8) stop = true;
             }
             {   // the completed groups leave; the open one stays behind (the reference still holds it in `last`: a read error drops it)
-                const size_t done = have_cur ? cur_mark : out.size();
-                if (done > (1u << 22) || stop) { fwrite(out.data(), 1, done, stdout); out.erase(0, done); cur_mark = 0; }
+                const size_t done = have_cur ? cur_mark : out->size();
+                if (done > (1u << 22) || stop) {
+                    const int other = out_turn ^ 1;
+                    out_latches[other].wait();
+                    out_bufs[other].assign(out->data() + done, out->size() - done);      // the open group moves on to the other buffer
+                    write_owned_or_copy(stdout, out->data(), done, out_latches[out_turn]);
+                    out_turn = other;
+                    out = &out_bufs[other];
+                    cur_mark = 0;
+                }
             }
             if (stop) {
                 // the record read so far is NOT written by the reference (it is still held in `last`): only completed ones are
@@ -1420,7 +1458,7 @@ int cmd_uniq(const std::vector<std::string>& args) {
             }
         }
         write_cur();                       // EOF completes the open group
-        fwrite(out.data(), 1, out.size(), stdout);
+        fwrite(out->data(), 1, out->size(), stdout);
         fflush(stdout);
         return 0;
     }
