@@ -56,10 +56,39 @@ class AsyncIo {
             if (!sp->started) { sp->started = true; auto keep = sp; std::thread([keep]() { keep->pump(); }).detach(); }
             return sp->read(buf, n);
         };
-        io.close = [](void* c) -> int { auto* p = (std::shared_ptr<In>*)c; (*p)->stop(); delete p; return 0; };
+        io.close = [](void* c) -> int {
+            auto* p = (std::shared_ptr<In>*)c;
+            (*p)->stop();
+            {
+                std::lock_guard<std::mutex> g(registry_mutex());
+                auto& r = in_by_file();
+                for (size_t i = 0; i < r.size(); i++)
+                    if (r[i].second == *p) { r.erase(r.begin() + (long)i); break; }
+            }
+            delete p;
+            return 0;
+        };
         FILE* f = fopencookie(new std::shared_ptr<In>(st), "rb", io);
-        if (f) setvbuf(f, nullptr, _IOFBF, 1 << 16);
+        if (f) {
+            setvbuf(f, nullptr, _IOFBF, 1 << 16);
+            std::lock_guard<std::mutex> g(registry_mutex());
+            in_by_file().emplace_back(f, st);
+        }
         return f;
+    }
+    // The descriptor behind a reader FILE* nothing has been read from yet: the caller reads it itself from now on (BlockReader's
+    // filler reads straight into its block buffers: no pump thread, no 1 MB chunks, no copy); -1: not such a FILE*, or already in use.
+    static int take_fd(FILE* f) {
+        std::lock_guard<std::mutex> g(registry_mutex());
+        for (auto& e : in_by_file())
+            if (e.first == f) {
+                std::lock_guard<std::mutex> lk(e.second->m);
+                if (e.second->started) return -1;
+                e.second->started = true;           // the cookie never starts its pump ...
+                e.second->eof = true;               // ... and a stray fread on the FILE* sees the end of the stream
+                return e.second->fd;
+            }
+        return -1;
     }
     // A FILE* whose bytes a background thread writes to `fd`.  fclose (or drain_all at exit) waits until everything is out.
     static FILE* writer(int fd, bool own_fd = false) {
@@ -309,6 +338,7 @@ class AsyncIo {
     };
     static std::mutex& registry_mutex() { static std::mutex m; return m; }
     static std::vector<std::shared_ptr<Out>>& registry() { static std::vector<std::shared_ptr<Out>> r; return r; }
+    static std::vector<std::pair<FILE*, std::shared_ptr<In>>>& in_by_file() { static std::vector<std::pair<FILE*, std::shared_ptr<In>>> r; return r; }
     static std::vector<std::pair<FILE*, std::shared_ptr<Out>>>& by_file() { static std::vector<std::pair<FILE*, std::shared_ptr<Out>>> r; return r; }
 };
 

@@ -24,6 +24,7 @@
 #include <mutex>
 #include <thread>
 
+#include "async_io.hpp"
 #include "text.hpp"
 
 namespace umgap_host {
@@ -180,6 +181,23 @@ class BlockReader {
     static void fill_ahead(std::shared_ptr<Ahead> A, FILE* f, size_t block, bool lines_only) {
         std::vector<char> tail;
         bool eof = false, first = true;
+        // the descriptor itself where nobody has read from the FILE* yet: read() straight into the block (no pump thread, no chunks)
+        const int fd = AsyncIo::enabled() ? AsyncIo::take_fd(f) : -1;
+        auto fill = [&](char* dst, size_t n) -> size_t {      // like fread: n bytes unless the stream ends (0 bytes: end or error)
+            if (fd < 0) {
+                const size_t got = fread(dst, 1, n, f);
+                if (got == 0 && ferror(f)) throw CliError(std::string(strerror(errno)));
+                return got;
+            }
+            size_t have = 0;
+            while (have < n) {
+                const ssize_t r = ::read(fd, dst + have, n - have);
+                if (r < 0) { if (errno == EINTR) continue; throw CliError(std::string(strerror(errno))); }
+                if (r == 0) break;
+                have += (size_t)r;
+            }
+            return have;
+        };
         try {
             for (size_t i = 0; !eof; i++) {
                 Ahead::Slot* S;
@@ -197,11 +215,8 @@ class BlockReader {
                 tail.clear();
                 for (;;) {
                     if (!eof) {
-                        const size_t got = fread(buf.data() + have, 1, buf.size() - have, f);
-                        if (got == 0) {
-                            if (ferror(f)) throw CliError(std::string(strerror(errno)));
-                            eof = true;
-                        }
+                        const size_t want = buf.size() - have, got = fill(buf.data() + have, want);
+                        if (got < want) eof = true;
                         have += got;
                     }
                     if (have == 0) break;                    // nothing left: no block
