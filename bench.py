@@ -54,6 +54,7 @@ def parse():
     ap.add_argument("--no-sharded", action="store_true", help="one GPU: skip the sharded leg (a child process with a process group of one over RCCL)")
     ap.add_argument("--no-extras", action="store_true", help="headline only: no seedextend / other pipelines / workload sweep / end-to-end legs")
     ap.add_argument("--no-end-to-end", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true", help="keep roofline.traffic from profiles/traffic.json instead of two child runs under rocprofv3 --pmc")
     ap.add_argument("--seedextend", action="store_true", help="insert seedextend -g1 -s3 per fragment between lookup and aggregate")
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (process group, barriers, sharded extra) even with one rank")
     ap.add_argument("--unfused", action="store_true", help="run lookup and aggregate as separate kernels (hits through HBM)")
@@ -229,6 +230,51 @@ def run_sharded_child(args, rank, world, want_first):
         res["isolation"] = "child process per rank"
         return res
     return {"error": "the sharded child ended with %s" % (status,), "output_tail": tail}
+
+
+def measure_traffic_live(args, kernel):
+    """HBM bytes per launch of the headline kernel, measured in THIS run: bench.py started twice more as a child under
+    `rocprofv3 --pmc` (FETCH_SIZE, then WRITE_SIZE: one counter per pass, with --kernel-trace only, as the MI355X guide prescribes;
+    KiB -> bytes; FETCH_SIZE counts 64-byte requests), two timed steps each.  The parent has released its table by now.  None when
+    rocprofv3 is not there or a pass fails (the committed profiles/traffic.json then stands in, and says so)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not prof:
+        return None
+    got = {}
+    work = tempfile.mkdtemp(prefix="umgap_pmc_", dir="/tmp")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR", "TORCHELASTIC_USE_AGENT_STORE")}
+    env["TMPDIR"] = "/tmp"
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(work, counter)
+            cmd = [prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out_dir, "-o", "pmc", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", "2", "--warmup", "1", "--batches", "2", "--no-cpu-baseline", "--no-gather", "--no-extras", "--no-sharded", "--pairs-per-step",
+                   str(args.pairs_per_step), "--n-keys", str(args.n_keys), "--n-tax", str(args.n_tax), "--load-factor", str(args.load_factor)]
+            p = subprocess.run(cmd, env=env, cwd="/tmp", timeout=300, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+            if p.returncode != 0:
+                return None
+            per_dispatch = {}
+            for path in glob.glob(os.path.join(out_dir, "**", "*counter_collection.csv"), recursive=True):
+                with open(path, newline="") as f:
+                    for row in csv.DictReader(f):
+                        name = row["Kernel_Name"]
+                        if (kernel + "<" in name or kernel + "(" in name) and row["Counter_Name"] == counter:
+                            per_dispatch[row["Dispatch_Id"]] = per_dispatch.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            if not per_dispatch:
+                return None
+            got[counter] = sum(per_dispatch.values()) / len(per_dispatch) * 1024.0
+            got[counter + "_launches"] = len(per_dispatch)
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+    return {"hbm_bytes_per_launch": int(got["FETCH_SIZE"] + got["WRITE_SIZE"]), "fetch_bytes": int(got["FETCH_SIZE"]), "write_bytes": int(got["WRITE_SIZE"]),
+            "launches_averaged": min(got["FETCH_SIZE_launches"], got["WRITE_SIZE_launches"])}
 
 
 def run_ipc_children(args, want_first, local_rank, world=2):
@@ -704,6 +750,20 @@ def main():
             out["replica"] = {"value": out["value"], "ms_per_step": out["ms_per_step"]}
             out["value"], out["ms_per_step"] = out["sharded"]["value"], out["sharded"]["ms_per_step"]
             out["config"]["parallelism"] = "sharded x%d (bucket-range shards, RCCL exchange)" % world
+    if rank == 0 and world == 1 and extras and fused and not getattr(args, "no_live_traffic", False):
+        # roofline.traffic measured in this very run (two short passes of this script under rocprofv3 --pmc; the table of this process is
+        # released by now, or is released here)
+        if w.index is not None:
+            w.index.close()
+            w.index = None
+        keys = None
+        torch.cuda.empty_cache()
+        live = measure_traffic_live(args, out["roofline"]["kernel"])
+        if live:
+            out["roofline"]["traffic"] = live["hbm_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (one pass each) over %d launches of %s "
+                                                 "in child runs of this script (fetch %d B + write %d B per launch)" % (
+                                                     live["launches_averaged"], out["roofline"]["kernel"], live["fetch_bytes"], live["write_bytes"]))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.n_tax, w.ids, w.parents, w.valid, w.rank, w.taxonomy._h, w.d_taxon_of_row, w.d_row_of_id, device)
     if rank == 0 and world == 1 and extras and not args.no_end_to_end and os.path.exists(os.path.join(ROOT, "umgap_amd", "bin", "umgap")):
