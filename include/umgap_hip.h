@@ -233,7 +233,7 @@ int umgap_aggregate_strided_dev(umgap_taxonomy* tx, int method, int strategy, fl
                                 uint32_t stride, size_t n_reads, uint32_t* d_out_taxon,
                                 uint32_t* d_out_status, void* stream);
 
-/* ---- seedextend on device (src/commands/seedextend.rs:99-148, unranked mode) ------------- */
+/* ---- seedextend on device (src/commands/seedextend.rs:99-148; ranked mode :150-163 below) ---- */
 /* In place per record r = taxa[offsets[r]..offsets[r+1]): taxa outside every extended seed
  * are overwritten with 0 (a dropped taxon and a 0 are equivalent for taxa2agg, which discards
  * zeros, src/commands/taxa2agg.rs:169).  kept[r] (nullable) receives the number of taxa the
@@ -244,6 +244,13 @@ int umgap_aggregate_strided_dev(umgap_taxonomy* tx, int method, int strategy, fl
 int umgap_seedextend_dev(const uint64_t* d_offsets, size_t n_records, uint32_t min_seed_size,
                          uint32_t max_gap_size, uint32_t* d_taxa, uint32_t* d_kept, int device,
                          void* stream);
+/* Ranked mode, `seedextend -r taxa.tsv -p penalty` (src/commands/seedextend.rs:77-83,150-163): of a record's extended seeds only
+ * the one with the highest score stays -- the last of equal ones, as Iterator::max_by_key -- a seed's score being the sum over
+ * its taxa of TaxonList::score (12 below a named rank, else None) with `penalty` (the command's default: 5) for None and for ids
+ * the taxonomy's list does not hold.  The scores come from the rows `tx` was made of (rank column); everything else as
+ * umgap_seedextend_dev.  The fused pipelines run the unranked mode (no script uses -r). */
+int umgap_seedextend_ranked_dev(umgap_taxonomy* tx, const uint64_t* d_offsets, size_t n_records, uint32_t min_seed_size,
+                                uint32_t max_gap_size, uint32_t penalty, uint32_t* d_taxa, uint32_t* d_kept, void* stream);
 /* Fixed-stride form: record r = d_taxa[r*stride .. (r+1)*stride). */
 int umgap_seedextend_strided_dev(uint32_t stride, size_t n_records, uint32_t min_seed_size,
                                  uint32_t max_gap_size, uint32_t* d_taxa, uint32_t* d_kept, int device,

@@ -515,6 +515,64 @@ def test_seedextend_panic_cases_vs_oracle(api, torch_cuda):
     assert O.seedextend_record(np.array([0, 5], np.uint32), 1, 1) is None
 
 
+def test_seedextend_ranked_dev_vs_oracle(api, torch_cuda, tmp_path):
+    """`seedextend -r taxa.tsv [-p penalty]` on the device (umgap_seedextend_ranked_dev; src/commands/seedextend.rs:77-83,150-163): of
+    a record's extended seeds only the best-scoring one stays (the last of equal ones), the score from the ranks of the taxonomy
+    the handle was made of.  Against the oracle's command on the same records as text: what it prints per record is what the
+    device leaves, panics (-s 0 / 1) included; taxa the list does not hold and the unknown taxon 0 score the penalty."""
+    torch = torch_cuda
+    from umgap_amd.synth import synthetic_taxonomy, write_taxonomy_tsv
+    ids, par, valid, rank = synthetic_taxonomy(300, 500, max_depth=8, seed=4)
+    tsv = str(tmp_path / "taxons.tsv")
+    write_taxonomy_tsv(tsv, ids, par, valid, rank)
+    tx = api.Taxonomy(ids, par, valid, rank)
+    rng = np.random.default_rng(28)
+    pool = np.concatenate([ids[:12], [0, 0, 0, 0, 499, 100000]]).astype(np.uint32)      # 499 / 100000: not in the list
+    recs = []
+    for _ in range(3000):
+        n = int(rng.integers(0, 40))
+        r = rng.choice(pool, n)
+        for _k in range(int(rng.integers(0, 4))):                                        # runs of equal taxa: seeds
+            if n > 6:
+                a = int(rng.integers(0, n - 3))
+                r[a:a + int(rng.integers(2, 6))] = rng.choice(pool)
+        recs.append(r.astype(np.uint32))
+    recs += [np.array([], np.uint32), np.array([0], np.uint32), np.array([0, 5], np.uint32)]   # (the last one panics with -s 1 -g 1)
+    taxa, offs = _csr([r.tolist() for r in recs])
+    text = b"".join(b">r%d\n" % i + b"".join(b"%d\n" % t for t in r) for i, r in enumerate(recs))
+    n_panics = n_kept = 0
+    for (s, g, pen) in ((2, 0, 5), (3, 1, 5), (2, 2, 0), (1, 1, 5), (0, 1, 30), (4, 1, 100)):
+        d_taxa = torch.from_numpy(taxa.view(np.int32).copy()).cuda()
+        d_offs = torch.from_numpy(offs.view(np.int64)).cuda()
+        d_kept = torch.zeros(len(recs), dtype=torch.int32, device="cuda")
+        api.seedextend_ranked_dev(tx, d_taxa, d_offs, min_seed_size=s, max_gap_size=g, penalty=pen, d_kept=d_kept)
+        torch.cuda.synchronize()
+        got = d_taxa.cpu().numpy().view(np.uint32)
+        kept = d_kept.cpu().numpy().view(np.uint32)
+        orc, out, _ = O.run_cli(["seedextend", "-s", str(s), "-g", str(g), "-r", tsv, "-p", str(pen)], text)
+        want = {}
+        cur = None
+        for line in out.decode().split("\n")[:-1]:
+            if line.startswith(">"):
+                cur = int(line[2:])
+                want[cur] = []
+            else:
+                want[cur].append(int(line))
+        first_panic = len(want) if orc == 101 else None          # the command dies at its first panicking record
+        assert orc in (0, 101), (s, g, orc)
+        for i, r in enumerate(recs):
+            mine = got[int(offs[i]):int(offs[i + 1])]
+            if first_panic is not None and i >= first_panic:
+                if i == first_panic:
+                    n_panics += 1
+                    assert kept[i] == 0xFFFFFFFF and not mine.any(), (s, g, r.tolist(), kept[i])
+                continue
+            assert kept[i] == len(want[i]), (s, g, pen, i, r.tolist(), want[i], mine.tolist())
+            assert mine[mine != 0].tolist() == [t for t in want[i] if t], (s, g, pen, i, r.tolist(), want[i], mine.tolist())
+            n_kept += len(want[i]) > 0
+    assert n_kept > 3000 and n_panics >= 1
+
+
 # ---------------------------------------------------------------------------------------------
 # the synthetic 9-mer high-precision pipeline: lookup -> (seedextend) -> LCA* with -l 2
 # ---------------------------------------------------------------------------------------------

@@ -143,6 +143,7 @@ def load():
         "umgap_walk_builder_free": (None, [vp]),
         "umgap_synth_prot_reads_dev": (i32, [vp, u64, u32, u64, u64, sz, u32, u32, vp, i32, vp]),
         "umgap_seedextend_dev": (i32, [vp, sz, u32, u32, vp, vp, i32, vp]),
+        "umgap_seedextend_ranked_dev": (i32, [vp, vp, sz, u32, u32, u32, vp, vp, vp]),
         "umgap_seedextend_strided_dev": (i32, [u32, sz, u32, u32, vp, vp, i32, vp]),
         "umgap_bench_gather_dev": (i32, [vp, sz, u32, vp, vp]),
         "umgap_synth_index_build": (i32, [u64, vp, u64, u64, u64, dbl, i32, pp]),

@@ -467,6 +467,12 @@ def classify_records_arrays(index, taxonomy, data, frag_offsets, read_frags, met
     return out_t, out_s
 
 
+def seedextend_ranked_dev(taxonomy, d_taxa, d_offsets, min_seed_size=2, max_gap_size=0, penalty=5, d_kept=None, stream=None):
+    """seedextend -r (only the best-scoring extended seed of a record stays, src/commands/seedextend.rs:150-163), in place."""
+    check(_lib.load().umgap_seedextend_ranked_dev(taxonomy._h, _dev_ptr(d_offsets), d_offsets.numel() - 1, min_seed_size, max_gap_size, penalty,
+                                                  _dev_ptr(d_taxa), _dev_ptr(d_kept), _stream_ptr(stream)))
+
+
 def seedextend_dev(d_taxa, d_offsets=None, stride=None, n_records=None, min_seed_size=2, max_gap_size=0, d_kept=None, stream=None):
     """seedextend (unranked) in place on a torch CUDA int32 tensor (src/commands/seedextend.rs:99-148)."""
     L = _lib.load()

@@ -48,6 +48,19 @@ __global__ __launch_bounds__(256) void k_seedextend(const uint64_t* __restrict__
     }
 }
 
+// ranked mode (`seedextend -r`): only the best-scoring extended seed of a record stays
+__global__ __launch_bounds__(256) void k_seedextend_ranked(const uint64_t* __restrict__ offsets, size_t n_records, uint32_t min_seed, uint32_t max_gap,
+                                                           const int8_t* __restrict__ scores, uint32_t n_scores, uint32_t penalty, uint32_t* __restrict__ taxa,
+                                                           uint32_t* __restrict__ kept) {
+    size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; r < n_records; r += step) {
+        const uint64_t off = offsets[r];
+        const uint32_t k = seedextend_record_ranked(taxa + off, (uint32_t)(offsets[r + 1] - off), min_seed, max_gap, scores, n_scores, penalty);
+        if (kept) kept[r] = k;
+    }
+}
+
 // Reads that hold a fragment on which seedextend panicked (kept == UMGAP_NONE) get status UMGAP_READ_PANIC: in the
 // reference's pipe the seedextend process dies at that record (exit 101) and nothing after it is printed.
 __global__ __launch_bounds__(256) void k_mark_seed_panics(const uint32_t* __restrict__ kept, const uint64_t* __restrict__ read_frags, size_t n_reads,
@@ -229,6 +242,21 @@ int umgap_seedextend_dev(const uint64_t* d_offsets, size_t n_records, uint32_t m
     int rc = use_device(device);
     if (rc) return rc;
     if (n_records) hipLaunchKernelGGL(k_seedextend, dim3(grid_for(n_records)), dim3(256), 0, (hipStream_t)stream, d_offsets, 0u, n_records, min_seed_size, max_gap_size, d_taxa, d_kept);
+    UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}
+
+int umgap_seedextend_ranked_dev(umgap_taxonomy* tx, const uint64_t* d_offsets, size_t n_records, uint32_t min_seed_size, uint32_t max_gap_size,
+                                uint32_t penalty, uint32_t* d_taxa, uint32_t* d_kept, void* stream) {
+    if (!tx || (n_records && (!d_offsets || !d_taxa))) return fail(UMGAP_ERR_INVALID, "umgap_seedextend_ranked_dev: null argument");
+    int rc = use_device(tx->device);
+    if (rc) return rc;
+    if (!tx->d_seed_score) {            // the per-id scores go up once
+        UMGAP_HIP(hipMalloc((void**)&tx->d_seed_score, tx->h_seed_score.size()));
+        UMGAP_HIP(hipMemcpy(tx->d_seed_score, tx->h_seed_score.data(), tx->h_seed_score.size(), hipMemcpyHostToDevice));
+    }
+    if (n_records) hipLaunchKernelGGL(k_seedextend_ranked, dim3(grid_for(n_records)), dim3(256), 0, (hipStream_t)stream, d_offsets, n_records, min_seed_size, max_gap_size,
+                                      (const int8_t*)tx->d_seed_score, tx->len, penalty, d_taxa, d_kept);
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
 }

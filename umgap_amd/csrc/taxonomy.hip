@@ -75,6 +75,30 @@ int umgap_taxonomy_create(const uint32_t* id, const uint32_t* parent, const uint
     tx->root = root;
     tx->len = len;
     tx->n_rows = (uint32_t)n;
+    {   // TaxonList::score over TaxonList::new_with_unknown(taxa, true) (src/commands/seedextend.rs:77-83): the first ancestor-or-self
+        // that is its own parent or carries a rank decides -- 12 under a named rank, None otherwise; an absent taxon on the way: None
+        std::vector<int8_t>& sc = tx->h_seed_score;
+        sc.assign(len, (int8_t)-2);                       // -2 = not computed
+        std::vector<uint32_t> path;
+        auto present = [&](uint32_t t) { return t < len && (row_of_id[t] != NONE || t == 0); };
+        for (uint32_t t0 = 0; t0 < len; t0++) {
+            if (sc[t0] != -2) continue;
+            path.clear();
+            int8_t res = -1;
+            uint32_t cur = t0;
+            for (size_t steps = 0; steps <= (size_t)len; steps++) {
+                if (!present(cur)) { res = -1; break; }
+                if (sc[cur] != -2) { res = sc[cur]; break; }
+                const uint32_t row = row_of_id[cur];
+                const uint32_t par = row == NONE ? 0u : parent[row];          // the added "unknown" taxon 0: its own parent, no rank
+                const uint8_t rk = row == NONE ? (uint8_t)0 : rank[row];
+                if (par == cur || rk != 0) { res = (rk != 0 && rk < 27) ? (int8_t)12 : (int8_t)-1; sc[cur] = res; break; }
+                path.push_back(cur);
+                cur = par;
+            }
+            for (uint32_t v : path) sc[v] = res;
+        }
+    }
     tx->h_pre.assign(len, NONE);
     tx->h_last.assign(len, NONE);
     tx->h_depth.assign(len, NONE);
@@ -282,6 +306,7 @@ void umgap_taxonomy_free(umgap_taxonomy* tx) {
     for (auto& kv : tx->defer_lists)
         if (kv.second.d) (void)hipFree(kv.second.d);
     if (tx->d_big_scratch) (void)hipFree(tx->d_big_scratch);
+    if (tx->d_seed_score) (void)hipFree(tx->d_seed_score);
     if (tx->stream) (void)hipStreamDestroy(tx->stream);
     if (tx->stream2) (void)hipStreamDestroy(tx->stream2);
     if (tx->stream3) (void)hipStreamDestroy(tx->stream3);

@@ -32,6 +32,8 @@ struct umgap_taxonomy {
     uint32_t root = 0, len = 0, n_reach = 0, n_rows = 0;
     // host copies (by id)
     std::vector<uint32_t> h_pre, h_last, h_depth, h_snap[2];
+    std::vector<int8_t> h_seed_score;    // TaxonList::score by id for `seedextend -r` (12 under a named rank, -1 = None), id 0 always present
+    int8_t* d_seed_score = nullptr;      // ... on the device, made at the first umgap_seedextend_ranked_dev
     // device, by id
     uint2* d_by_id = nullptr;            // {pre, last}
     uint8_t* d_err_kind = nullptr;       // 0 ok, 1 UnknownTaxon(payload), 2 panic (parent id out of bounds)
