@@ -1274,6 +1274,31 @@ def test_sharded_table_ranks_as_processes(api, torch_cuda, world, pieces, own_sh
     assert not os.path.exists("/dev/shm" + name)       # the control block's name is gone once everybody is attached
 
 
+def test_comm_ipc_rendezvous_failures(api, torch_cuda, monkeypatch):
+    """umgap_comm_init_ipc when the other ranks never come, or the arguments are wrong: an error after UMGAP_IPC_TIMEOUT_S (not a hang),
+    and no shared-memory block left behind."""
+    import time
+    import uuid
+    from umgap_amd.dist import Comm
+    monkeypatch.setenv("UMGAP_IPC_TIMEOUT_S", "2")
+    name = "/umgap-test-%s" % uuid.uuid4().hex[:12]
+    t0 = time.perf_counter()
+    with pytest.raises(api.UmgapError, match="waited"):
+        Comm.ipc(name, 2, 0, 0)                      # rank 1 never shows up
+    assert time.perf_counter() - t0 < 30 and not os.path.exists("/dev/shm" + name)
+    with pytest.raises(api.UmgapError, match="did not create"):
+        Comm.ipc(name, 2, 1, 0)                      # ... nor does rank 0
+    for bad in ("no-slash", "/a/b", "/"):
+        with pytest.raises(api.UmgapError, match="must look like"):
+            Comm.ipc(bad, 1, 0, 0)
+    with pytest.raises(api.UmgapError, match="rank < world"):
+        Comm.ipc(name, 2, 2, 0)
+    c = Comm.ipc(name, 1, 0, 0)                      # a world of one: nothing to wait for
+    c.selftest(1 << 16)
+    c.close()
+    assert not os.path.exists("/dev/shm" + name)
+
+
 @pytest.mark.parametrize("world,stride,frags,pieces,own_share", [(3, 128, 0, 2, "probed in place"), (2, 40, 2, 3, "probed in place"), (4, 7, 0, 1, "probed in place"),
                                                                  (2, 64, 64, 2, "probed in place"), (5, 1, 0, 2, "probed in place"), (2, 33, 33, 1, "probed in place"),
                                                                  (1, 84, 2, 2, "packed"), (3, 84, 0, 2, "packed"), (2, 40, 2, 3, "packed")])
