@@ -153,7 +153,6 @@ struct IpcHub {
     IpcCtl* ctl = nullptr;
     int world = 0, rank = 0;
     double timeout_s = 120.0;
-    std::map<const void*, hipIpcMemHandle_t> mine;             // allocation base -> its handle
     std::vector<std::map<std::string, void*>> opened;          // per peer: handle (+ base, size) -> where it is mapped here
     int barrier() {
         const uint32_t g = ctl->generation.load(std::memory_order_acquire);
@@ -194,14 +193,12 @@ struct IpcHub {
         void* base = nullptr;
         size_t size = 0;
         UMGAP_HIP(hipMemGetAddressRange((hipDeviceptr_t*)&base, &size, (hipDeviceptr_t)send));
-        auto it = mine.find(base);
-        if (it == mine.end()) {
-            hipIpcMemHandle_t h;
-            UMGAP_HIP(hipIpcGetMemHandle(&h, base));
-            it = mine.emplace(base, h).first;
-        }
+        // (asked for every time: an allocation that was freed and made again at the same address has another handle, and the peers tell
+        // mapped allocations apart by the handle)
+        hipIpcMemHandle_t h;
+        UMGAP_HIP(hipIpcGetMemHandle(&h, base));
         IpcCtl::Slot& S = ctl->slot[rank];
-        S.mem = it->second;
+        S.mem = h;
         S.offset = (uint64_t)((const char*)send - (const char*)base);
         S.alloc_bytes = size;
         S.alloc_base = (uint64_t)(uintptr_t)base;
