@@ -2542,6 +2542,61 @@ def test_walk_index_beyond_32_bit_entry_numbers(api, torch_cuda):
     torch.cuda.empty_cache()
 
 
+def test_walk_index_of_a_redundant_proteome(api, torch_cuda):
+    """umgap_index_build_walk9_dev on a proteome whose fragments repeat (five copies of every fragment under different taxa, the
+    copies far apart): expected_keys names the DISTINCT 9-mers, a fifth of the windows.  Every key keeps the smallest taxon of the
+    fragments that hold it (the last pass of the values-free builder) and the kept repeats carry it too: answers as the plain table's."""
+    import ctypes as C
+    torch = torch_cuda
+    from umgap_amd import _lib
+    from umgap_amd.api import Index, _dev_ptr
+    L = _lib.load()
+    rng = np.random.default_rng(41)
+    letters = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    flen, n_base = 40, 6000
+    base = rng.choice(letters, (n_base, flen))
+    order = np.concatenate([rng.permutation(n_base) for _ in range(5)])
+    frags = base[order]
+    keys, ok = _pack_windows(base)
+    distinct = int(len(np.unique(keys[ok])))
+    n_frag = len(frags)
+    ptaxa = rng.integers(2, 3000, n_frag).astype(np.uint32)
+    d_p = torch.from_numpy(frags.reshape(-1).copy()).cuda()
+    d_po = torch.arange(0, (n_frag + 1) * flen, flen, dtype=torch.int64, device="cuda")
+    d_pt = torch.from_numpy(ptaxa.view(np.int32)).cuda()
+    hp, hw = C.c_void_p(), C.c_void_p()
+    _lib.check(L.umgap_index_build_windows9_dev(_dev_ptr(d_p), _dev_ptr(d_po), _dev_ptr(d_pt), n_frag, flen, distinct, 0.0, 0, C.byref(hp)))
+    _lib.check(L.umgap_index_build_walk9_dev(_dev_ptr(d_p), _dev_ptr(d_po), _dev_ptr(d_pt), n_frag, flen, distinct, 0.0, 0, C.byref(hw)))
+    plain, walk = Index(hp.value), Index(hw.value)
+    q = np.concatenate([keys[ok].ravel(), rng.integers(0, 1 << 45, 20_000, dtype=np.uint64)])
+    d_q = torch.from_numpy(q.view(np.int64)).cuda()
+    a, b = plain.lookup9_dev(d_q, miss_value=0), walk.lookup9_dev(d_q, miss_value=0)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and (a != 0).float().mean().item() > 0.8
+    # the smallest taxon over the copies, from first principles
+    want = {}
+    kk, oo = _pack_windows(frags)
+    for f in range(n_frag):
+        for k in kk[f][oo[f]]:
+            want[int(k)] = min(want.get(int(k), 1 << 32), int(ptaxa[f]))
+    got = a.cpu().numpy().view(np.uint32)[:int(ok.sum())]
+    assert got.tolist() == [want[int(k)] for k in keys[ok].ravel()]
+    # reads that follow the proteome (walks through kept repeats) answer the same through both
+    n_reads = 3000
+    ridx = rng.integers(0, n_frag, n_reads)
+    d_r = torch.from_numpy(frags[ridx].reshape(-1).copy()).cuda()
+    d_ro = torch.arange(0, (n_reads + 1) * flen, flen, dtype=torch.int64, device="cuda")
+    d_oo = torch.arange(0, (n_reads + 1) * (flen - 8), flen - 8, dtype=torch.int64, device="cuda")
+    h0 = torch.full((n_reads * (flen - 8),), -3, dtype=torch.int32, device="cuda")
+    h1 = torch.full_like(h0, -5)
+    plain.lookup_prot9_dev(d_r, d_ro, d_oo, h0, miss_value=0)
+    walk.lookup_prot9_dev(d_r, d_ro, d_oo, h1, miss_value=0)
+    torch.cuda.synchronize()
+    assert torch.equal(h0, h1)
+    walk.close()
+    plain.close()
+
+
 def test_walk_index_of_eight_billion_keys_builds_on_one_gpu(api, torch_cuda):
     """The walk-order index at the size of the real 9-mer index (BASELINE configs[1]: >= 8 G keys): 200 M fragments = 8.4 G windows
     through umgap_index_build_walk9_dev on the one GPU -- no values table beside the index under construction (round 4; that table

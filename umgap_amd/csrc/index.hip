@@ -1861,7 +1861,6 @@ int umgap_index_build_walk9_dev(const uint8_t* d_bytes, const uint64_t* d_offset
     hipError_t e = hipMemcpyAsync(&n_windows, d_wbase + n_fragments + 1, 8, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, std::string("umgap_index_build_walk9_dev: ") + hipGetErrorString(e)));
-    if (n_windows > expected_keys + expected_keys / 8) return done(fail(UMGAP_ERR_BUILD, "umgap_index_build_walk9_dev: the proteome has more windows than expected_keys allows for"));
     const uint64_t per = 1ull << 29;
     const uint32_t n_chunks = (uint32_t)std::max<uint64_t>(1, (n_windows + per - 1) / per);
     std::vector<uint64_t> cuts(n_chunks + 1, 0);
