@@ -251,9 +251,17 @@ int umgap_seedextend_ranked_dev(umgap_taxonomy* tx, const uint64_t* d_offsets, s
     if (!tx || (n_records && (!d_offsets || !d_taxa))) return fail(UMGAP_ERR_INVALID, "umgap_seedextend_ranked_dev: null argument");
     int rc = use_device(tx->device);
     if (rc) return rc;
-    if (!tx->d_seed_score) {            // the per-id scores go up once
-        UMGAP_HIP(hipMalloc((void**)&tx->d_seed_score, tx->h_seed_score.size()));
-        UMGAP_HIP(hipMemcpy(tx->d_seed_score, tx->h_seed_score.data(), tx->h_seed_score.size(), hipMemcpyHostToDevice));
+    {                                   // the per-id scores go up once (callers on several threads meet here)
+        std::lock_guard<std::mutex> g(tx->defer_mutex);
+        if (!tx->d_seed_score) {
+            int8_t* d = nullptr;
+            UMGAP_HIP(hipMalloc((void**)&d, tx->h_seed_score.size()));
+            if (hipMemcpy(d, tx->h_seed_score.data(), tx->h_seed_score.size(), hipMemcpyHostToDevice) != hipSuccess) {
+                (void)hipFree(d);
+                return fail(UMGAP_ERR_DEVICE, "umgap_seedextend_ranked_dev: copy of the scores failed");
+            }
+            tx->d_seed_score = d;
+        }
     }
     if (n_records) hipLaunchKernelGGL(k_seedextend_ranked, dim3(grid_for(n_records)), dim3(256), 0, (hipStream_t)stream, d_offsets, n_records, min_seed_size, max_gap_size,
                                       (const int8_t*)tx->d_seed_score, tx->len, penalty, d_taxa, d_kept);
