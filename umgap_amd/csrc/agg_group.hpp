@@ -329,12 +329,39 @@ __device__ __forceinline__ void general_group(const TaxView& V, GS& G, int metho
                     }
                 }
                 wave_sync();
+            } else {
+                // rmq::mix on short lists, one lane per read as well: every candidate (the hits and the LCAs of adjacent hits) against
+                // every hit; sums of whole counts, the two products and their sum rounded as in the wave-wide form; ties to the smallest
+                // preorder index
+                if (lane < nb && G.rstat[lane] == ST_PENDING) {
+                    const uint32_t o0 = G.roff[lane], D = G.roff[lane + 1] - o0;
+                    if (D >= 2u && D <= SMALL) {
+                        const uint32_t* bp = wtaxa + base + o0;
+                        const float one_minus = __fsub_rn(1.0f, factor);
+                        float best = -__builtin_inff();
+                        uint32_t best_p = NONE;
+                        for (uint32_t cnd = 0; cnd < 2 * D - 1; cnd++) {
+                            const uint32_t pc = cnd < D ? bp[cnd] : G.lca[o0 + cnd - D];
+                            const uint32_t lc = cnd < D ? G.last[o0 + cnd] : G.dep[o0 + cnd - D];
+                            float lw = 0.0f, rw = 0.0f;
+                            for (uint32_t q = 0; q < D; q++) {
+                                const uint32_t pk = bp[q];
+                                if (pc <= pk && pk <= lc) lw = __fadd_rn(lw, G.cnt[o0 + q]);
+                                if (pk <= pc && pc <= G.last[o0 + q]) rw = __fadd_rn(rw, G.cnt[o0 + q]);
+                            }
+                            const float score = __fadd_rn(__fmul_rn(lw, factor), __fmul_rn(rw, one_minus));
+                            if (score > best || (score == best && pc < best_p)) { best = score; best_p = pc; }
+                        }
+                        G.rans[lane] = best_p;
+                    }
+                }
+                wave_sync();
             }
             for (uint32_t r = 0; r < nb; r++) {
                 if (G.rstat[r] != ST_PENDING) continue;
                 const uint32_t o0 = G.roff[r], D = G.roff[r + 1] - o0;
                 if (D == 1u) continue;
-                if (method == UMGAP_METHOD_TREE && D <= SMALL) continue;          // done above, one lane per read
+                if (D <= SMALL) continue;                                         // done above, one lane per read
                 const uint32_t* bpre = wtaxa + base + o0;
                 uint32_t ans = NONE;
                 if (method == UMGAP_METHOD_TREE) {
