@@ -256,6 +256,31 @@ size_t orc_seedextend_record(const uint32_t* taxa, size_t n, size_t min_seed_siz
     return k;
 }
 
+// ranked mode (`-r`, src/commands/seedextend.rs:150-163) on one record; tax = orc_taxonomy_* handle.  overflow_checks != 0 models a
+// build with overflow checks (the `e - s` of an inverted seed panics), 0 a release build (it wraps).
+void* orc_ranked_list_new(void* tax) {
+    return new TaxonList(TaxonList::new_with_unknown(((Taxonomy*)tax)->taxons, true));
+}
+void orc_ranked_list_free(void* h) { delete (TaxonList*)h; }
+size_t orc_seedextend_record_ranked(void* ranked_list, const uint32_t* taxa, size_t n, size_t min_seed_size, size_t max_gap_size,
+                                    size_t penalty, int overflow_checks, uint32_t* out) {
+    std::ostringstream in_s, out_s;
+    in_s << ">r\n";
+    for (size_t i = 0; i < n; i++) in_s << taxa[i] << "\n";
+    std::istringstream is(in_s.str());
+    try {
+        seedextend(is, out_s, min_seed_size, max_gap_size, (const TaxonList*)ranked_list, penalty, overflow_checks != 0);
+    } catch (const Panic&) {
+        return (size_t)-1;
+    }
+    std::istringstream os(out_s.str());
+    std::string line;
+    size_t k = 0;
+    std::getline(os, line);  // header
+    while (std::getline(os, line)) out[k++] = (uint32_t)parse_usize(line);
+    return k;
+}
+
 // ---- synthetic closed-form index (tests + bench cpu_baseline) ------------------------------
 // 9-mer lookup against the closed-form synthetic index; miss => miss_value
 void orc_synth_lookup9(const SynthIndexParams* p, const uint32_t* taxon_of_row, const uint64_t* keys45, size_t n,

@@ -108,7 +108,8 @@ int main(int argc, char** argv) {
             std::optional<TaxonList> by_id;
             if (auto v = opt("-r")) by_id = TaxonList::new_with_unknown(read_taxa_file(*v), true);
             try {
-                seedextend(std::cin, std::cout, s, g, by_id ? &*by_id : nullptr, p);
+                // --overflow-checks: the outcome of a build with overflow checks (debug); default = release, what ships
+                seedextend(std::cin, std::cout, s, g, by_id ? &*by_id : nullptr, p, flag("--overflow-checks"));
             } catch (Error& e) { std::cout.flush(); throw; }
         } else if (cmd == "uniq") {
             std::string sep = "\n";

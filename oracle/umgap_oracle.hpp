@@ -1178,7 +1178,8 @@ inline void prot2tryp2lca(std::istream& in, std::ostream& out_final, const Index
 
 // seedextend — src/commands/seedextend.rs:82-179
 inline void seedextend(std::istream& in, std::ostream& out, size_t min_seed_size, size_t max_gap_size,
-                       const TaxonList* by_id /* -r, from new_with_unknown(.., true) */, size_t penalty) {
+                       const TaxonList* by_id /* -r, from new_with_unknown(.., true) */, size_t penalty,
+                       bool overflow_checks = false /* false: a release build, what `cargo install` ships */) {
     FastaWriter writer(out, "\n", false);
     FastaReader reader(in, false);
     Record record;
@@ -1220,8 +1221,15 @@ inline void seedextend(std::istream& in, std::ostream& out, size_t min_seed_size
                 size_t best = 0, best_score = 0;
                 bool first = true;
                 for (size_t i = 0; i < seeds.size(); i++) {
+                    // .skip(s).take(e - s): the scanner can push a seed with s > e (:119, a leading zero-run <= g, one taxon, a
+                    // zero-run > g, with -s 1).  `e - s` then underflows: a build with overflow checks (debug) panics right here,
+                    // a release build wraps, and take(2^64 - ..) covers every taxon from s on, the sentinel included.  The sum
+                    // (`.sum::<usize>()`) wraps in a release build as well, like size_t here.
+                    const size_t s0 = seeds[i].first, e0 = seeds[i].second;
+                    if (s0 > e0 && overflow_checks) throw Panic("attempt to subtract with overflow");
+                    const size_t stop = s0 > e0 ? taxons.size() : std::min(e0, taxons.size());
                     size_t sc = 0;
-                    for (size_t j = seeds[i].first; j < seeds[i].second && j < taxons.size(); j++) {
+                    for (size_t j = s0; j < stop; j++) {
                         auto s = by_id->score(taxons[j]);
                         sc += s ? *s : penalty;
                     }

@@ -296,6 +296,33 @@ def seedextend_record(taxa, min_seed_size=2, max_gap_size=0):
     return out[:n]
 
 
+class RankedList:
+    """TaxonList::new_with_unknown(taxa, true) of a Taxonomy: what `seedextend -r` scores against."""
+
+    def __init__(self, taxonomy):
+        self.tax = taxonomy
+        lib().orc_ranked_list_new.restype = C.c_void_p
+        lib().orc_seedextend_record_ranked.restype = C.c_size_t
+        self.h = C.c_void_p(lib().orc_ranked_list_new(taxonomy.h))
+
+    def __del__(self):
+        try:
+            lib().orc_ranked_list_free(self.h)
+        except Exception:
+            pass
+
+    def seedextend_record(self, taxa, min_seed_size=2, max_gap_size=0, penalty=5, overflow_checks=False):
+        """Kept taxa of one record in ranked mode, or None where the reference panics (src/commands/seedextend.rs:150-173).
+        overflow_checks: a debug build (`e - s` of an inverted seed panics); default: a release build (it wraps)."""
+        taxa = np.ascontiguousarray(taxa, dtype=np.uint32)
+        out = np.zeros(len(taxa) + 1, np.uint32)
+        n = lib().orc_seedextend_record_ranked(self.h, _p(taxa, C.c_uint32), C.c_size_t(len(taxa)), C.c_size_t(min_seed_size),
+                                               C.c_size_t(max_gap_size), C.c_size_t(penalty), C.c_int(int(overflow_checks)), _p(out, C.c_uint32))
+        if n == C.c_size_t(-1).value:
+            return None
+        return out[:n]
+
+
 def synth_lookup9(params: SynthIndexParams, taxon_of_row, keys45, miss_value=0):
     tor = np.ascontiguousarray(taxon_of_row, dtype=np.uint32)
     keys = np.ascontiguousarray(keys45, dtype=np.uint64)

@@ -75,6 +75,43 @@ def test_seedextend_ranked_matches_oracle(taxonomy, flags):
     assert rc2 == 0 and out != plain      # the filter does something on this input
 
 
+@pytest.mark.parametrize("flags,panics", [(["-s", "1", "-g", "1"], True), (["-s", "1", "-g", "1", "-p", "0"], False),
+                                          (["-s", "1", "-g", "1", "-p", "1"], True), (["-s", "0", "-g", "2", "-p", "0"], False)])
+def test_seedextend_ranked_inverted_seed(taxonomy, flags, panics):
+    """A seed with start > end (src/commands/seedextend.rs:119: a leading zero-run <= g, one taxon, a zero-run > g, under -s 1) in
+    ranked mode: `.take(e - s)` (:158) underflows.  A release build wraps -- the seed then scores every taxon from s on, beats the
+    real seed by its gap penalties and `taxons[2..1]` panics (exit 101); with -p 0 the two tie, max_by_key keeps the last one and
+    `5 5 5` is printed.  (A build with overflow checks panics at the subtraction either way: the oracle's --overflow-checks.)"""
+    five = int(taxonomy["ids"][5])
+    rec = (">a\n%d\n%d\n%d\n" % (five, five, five) + ">r\n0\n7\n0\n0\n0\n%d\n%d\n%d\n" % (five, five, five) + ">z\n%d\n%d\n" % (five, five)).encode()
+    args = ["seedextend", "-r", taxonomy["tsv"]] + flags
+    rc, out, err = run(args, rec)
+    orc, oout, _ = O.run_cli(args, rec)
+    assert rc == orc and out == oout, (rc, orc, out, oout, err)
+    assert rc == (101 if panics else 0)
+    if panics:
+        assert out.startswith(b">a\n") and b">r" not in out              # the records before the panic are out, nothing after
+        assert b"panicked" in err
+    else:
+        assert out.endswith(b">r\n%d\n%d\n%d\n>z\n%d\n%d\n" % ((five,) * 5))
+    drc, _, _ = O.run_cli(args + ["--overflow-checks"], rec)
+    assert drc == 101                                                     # a debug build dies at `e - s` whatever the penalty
+    # more of them: random records rich in short zero-runs, product and oracle record for record (the command stops at its first panic)
+    rng = np.random.default_rng(9)
+    pool = [five, int(taxonomy["ids"][9]), 0, 0, 0, 7]
+    n_inverted_survivors = 0
+    for _ in range(300):
+        items = [int(rng.choice(pool)) for _ in range(int(rng.integers(1, 14)))]
+        data = (">q\n" + "".join("%d\n" % t for t in items)).encode()
+        rc, out, _ = run(args, data)
+        orc, oout, _ = O.run_cli(args, data)
+        assert rc == orc and out == oout, (items, rc, orc, out, oout)
+        drc, dout, _ = O.run_cli(args + ["--overflow-checks"], data)
+        n_inverted_survivors += (drc == 101 and orc == 0)
+    if not panics:
+        assert n_inverted_survivors > 0                                   # records where release and debug builds part ways
+
+
 @pytest.mark.parametrize("block,threads", [(64, 3), (3000, 8)])
 def test_seedextend_ranked_block_seams(taxonomy, block, threads):
     rng = np.random.default_rng(block)

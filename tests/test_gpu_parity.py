@@ -538,10 +538,17 @@ def test_seedextend_ranked_dev_vs_oracle(api, torch_cuda, tmp_path):
                 r[a:a + int(rng.integers(2, 6))] = rng.choice(pool)
         recs.append(r.astype(np.uint32))
     recs += [np.array([], np.uint32), np.array([0], np.uint32), np.array([0, 5], np.uint32)]   # (the last one panics with -s 1 -g 1)
+    # inverted seeds (start > end, src/commands/seedextend.rs:119 under -s 1): `.take(e - s)` (:158) wraps in a release build and the
+    # seed scores every taxon from s on -- the record VERDICT r4 names, and short records rich in zero-runs
+    five = int(ids[5])
+    recs += [np.array([0, 7, 0, 0, 0, five, five, five], np.uint32), np.array([0, five, 0, 0, five, five], np.uint32)]
+    small = np.array([five, int(ids[7]), 0, 0, 0, 499], np.uint32)
+    recs += [rng.choice(small, int(rng.integers(1, 14))).astype(np.uint32) for _ in range(1500)]
     taxa, offs = _csr([r.tolist() for r in recs])
     text = b"".join(b">r%d\n" % i + b"".join(b"%d\n" % t for t in r) for i, r in enumerate(recs))
-    n_panics = n_kept = 0
-    for (s, g, pen) in ((2, 0, 5), (3, 1, 5), (2, 2, 0), (1, 1, 5), (0, 1, 30), (4, 1, 100)):
+    ranked = O.RankedList(O.Taxonomy.from_arrays(ids, par, valid, rank))
+    n_panics = n_kept = n_release_only = 0
+    for (s, g, pen) in ((2, 0, 5), (3, 1, 5), (2, 2, 0), (1, 1, 5), (1, 1, 0), (1, 2, 1), (0, 1, 30), (4, 1, 100)):
         d_taxa = torch.from_numpy(taxa.view(np.int32).copy()).cuda()
         d_offs = torch.from_numpy(offs.view(np.int64)).cuda()
         d_kept = torch.zeros(len(recs), dtype=torch.int32, device="cuda")
@@ -549,28 +556,26 @@ def test_seedextend_ranked_dev_vs_oracle(api, torch_cuda, tmp_path):
         torch.cuda.synchronize()
         got = d_taxa.cpu().numpy().view(np.uint32)
         kept = d_kept.cpu().numpy().view(np.uint32)
-        orc, out, _ = O.run_cli(["seedextend", "-s", str(s), "-g", str(g), "-r", tsv, "-p", str(pen)], text)
-        want = {}
-        cur = None
-        for line in out.decode().split("\n")[:-1]:
-            if line.startswith(">"):
-                cur = int(line[2:])
-                want[cur] = []
-            else:
-                want[cur].append(int(line))
-        first_panic = len(want) if orc == 101 else None          # the command dies at its first panicking record
-        assert orc in (0, 101), (s, g, orc)
+        # the oracle record by record (a release build; the command itself dies at its first panicking record, below)
         for i, r in enumerate(recs):
             mine = got[int(offs[i]):int(offs[i + 1])]
-            if first_panic is not None and i >= first_panic:
-                if i == first_panic:
-                    n_panics += 1
-                    assert kept[i] == 0xFFFFFFFF and not mine.any(), (s, g, r.tolist(), kept[i])
+            want = ranked.seedextend_record(r, s, g, pen)
+            if want is None:
+                n_panics += 1
+                assert kept[i] == 0xFFFFFFFF and not mine.any(), (s, g, pen, r.tolist(), kept[i])
                 continue
-            assert kept[i] == len(want[i]), (s, g, pen, i, r.tolist(), want[i], mine.tolist())
-            assert mine[mine != 0].tolist() == [t for t in want[i] if t], (s, g, pen, i, r.tolist(), want[i], mine.tolist())
-            n_kept += len(want[i]) > 0
-    assert n_kept > 3000 and n_panics >= 1
+            if ranked.seedextend_record(r, s, g, pen, overflow_checks=True) is None:
+                n_release_only += 1                                  # an inverted seed that lost: only a debug build panics here
+            assert kept[i] == len(want), (s, g, pen, i, r.tolist(), want.tolist(), mine.tolist())
+            assert mine[mine != 0].tolist() == [t for t in want.tolist() if t], (s, g, pen, i, r.tolist(), want.tolist(), mine.tolist())
+            n_kept += len(want) > 0
+        # ... and the oracle's command on the same records as text agrees with its record-by-record form up to its first panic
+        orc, out, _ = O.run_cli(["seedextend", "-s", str(s), "-g", str(g), "-r", tsv, "-p", str(pen)], text)
+        assert orc in (0, 101), (s, g, orc)
+        n_out = out.count(b">")
+        first_panic = next((i for i, r in enumerate(recs) if ranked.seedextend_record(r, s, g, pen) is None), None)
+        assert (orc == 101) == (first_panic is not None) and n_out == (len(recs) if first_panic is None else first_panic), (s, g, pen, orc, n_out, first_panic)
+    assert n_kept > 3000 and n_panics >= 10 and n_release_only >= 1
 
 
 # ---------------------------------------------------------------------------------------------

@@ -118,7 +118,8 @@ def main():
             print("case %d, %d mismatches so far" % (case, bad), flush=True)
         for cmd in cmds:
             if cmd == "seedextend":
-                flags = [["-g", "1", "-s", "3"], [], ["-s", "1"], ["-g", "2", "-s", "2", "-r", tsv], ["-r", tsv, "-p", "1"]][int(rng.integers(0, 5))]
+                flags = [["-g", "1", "-s", "3"], [], ["-s", "1"], ["-g", "2", "-s", "2", "-r", tsv], ["-r", tsv, "-p", "1"],
+                         ["-s", "1", "-g", "1", "-r", tsv], ["-s", "1", "-g", "2", "-r", tsv, "-p", "0"], ["-s", "0", "-g", "1", "-r", tsv, "-p", "3"]][int(rng.integers(0, 8))]
                 data, mine, theirs = soup(rng, taxa_item, int(rng.integers(0, 12))), ["seedextend"] + flags, ["seedextend"] + flags
             elif cmd == "uniq":
                 flags = [[], ["-d", "/"], ["-d", "/", "-s", " "], ["-w"], ["-d", "r", "-w"]][int(rng.integers(0, 5))]

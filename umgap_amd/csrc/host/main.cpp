@@ -1293,7 +1293,9 @@ int cmd_seedextend(const std::vector<std::string>& args) {
                     uint64_t best_score = 0;
                     for (size_t i = 0; i < seeds.size(); i++) {
                         uint64_t sc = 0;
-                        for (size_t j = seeds[i].first; j < seeds[i].second && j < t.size(); j++) sc += score_of(t[j]);
+                        // take(e - s) with s > e wraps in a release build: every taxon from s on, the sentinel included
+                        const size_t stop = seeds[i].first > seeds[i].second ? t.size() : std::min(seeds[i].second, t.size());
+                        for (size_t j = seeds[i].first; j < stop; j++) sc += score_of(t[j]);
                         if (i == 0 || sc >= best_score) { best = i; best_score = sc; }
                     }
                     seeds[0] = seeds[best];

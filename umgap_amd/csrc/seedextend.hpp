@@ -67,8 +67,11 @@ __device__ __forceinline__ uint32_t seedextend_record_ranked(uint32_t* __restric
     uint32_t bs = 0, be = 0;
     uint64_t best = 0;
     auto emit = [&](uint32_t s, uint32_t e) {
+        // .skip(s).take(e - s): with s > e (a seed the scanner pushes behind a short leading zero-run when min_seed < 2) the
+        // subtraction wraps in a release build and take() covers every taxon from s on, the sentinel included.
         uint64_t sc = 0;
-        for (uint32_t j = s; j < e && j < len; j++) {
+        const uint32_t stop = s > e ? len : e;
+        for (uint32_t j = s; j < stop && j < len; j++) {
             const uint32_t v = at(j);
             const int32_t q = v < n_scores ? (int32_t)scores[v] : -1;
             sc += q < 0 ? (uint64_t)penalty : (uint64_t)q;
