@@ -776,9 +776,11 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         try:
             # BASELINE.json configs[4] as one device call per batch: the tryptic presets of umgap-analyse.sh:289-298 (digest -> length
-            # window -> variable-length lookup -> MRTL) over a 400 M-key tryptic index (tools/bench_tryptic_fused.py)
+            # window -> variable-length lookup -> MRTL) over a 1 G-key tryptic index (SURVEY.md §8d Config 5; tools/bench_tryptic_fused.py);
+            # outside the timed calls 20 k sampled pairs per preset go through the checker (regex digest, closed-form membership, the
+            # oracle's literal aggregator)
             import bench_tryptic_fused
-            out["tryptic_pipeline"] = bench_tryptic_fused.run(400_000_000, 10_000_000, steps=3, workload=w)
+            out["tryptic_pipeline"] = bench_tryptic_fused.run(1_000_000_000, 10_000_000, steps=3, workload=w)
         except Exception as e:  # noqa: BLE001
             out["tryptic_pipeline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         torch.cuda.empty_cache()

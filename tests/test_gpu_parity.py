@@ -2665,6 +2665,61 @@ def test_walk_index_of_eight_billion_keys_builds_on_one_gpu(api, torch_cuda):
     torch.cuda.empty_cache()
 
 
+def test_config5_tryptic_index_one_billion_keys_sampled_vs_oracle(api, torch_cuda):
+    """BASELINE.json configs[4] at size (SURVEY.md §8d Config 5; scripts/umgap-analyse.sh:289-298): a 1 G-key tryptic-peptide table
+    (packed layout, 82 GB), 10 M pairs through umgap_classify_tryp_dev -- digest, length window 9..45, variable-length lookup,
+    aggregate in one call -- in the script's presets: MRTL -l1 (tryptic-sensitivity), MRTL -l5 (tryptic-precision; on pairs of 2 x 4
+    peptides, or nothing survives the filter) and tree hybrid f = 0.25 (the max-sensitivity aggregation).  Per mode 20 000 sampled pairs
+    against the reference's digest restated (regex twice), the closed-form membership of the synthetic index and the oracle's
+    literal aggregator with tie sets honoured (tests/tryptic_check.py); whole-batch properties beside it: the table bound to the
+    taxonomy answers bit for bit like the unbound one, statuses are OK / EMPTY only, EMPTY prints the literal 1, answers are their
+    own snap."""
+    import gc
+    import tryptic_check
+    torch = torch_cuda
+    from umgap_amd.synth import SyntheticWorkload, TrypticWorkload
+    gc.collect()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 150e9:
+        pytest.skip("needs ~120 GB of free HBM")
+    n_keys, n_pairs, F = 1_000_000_000, 10_000_000, 2
+    w = SyntheticWorkload(n_tax=2_500_000, n_keys=1000, id_space=3_500_000, build_index=False)
+    otx = tryptic_check.oracle_taxonomy(w)
+    snap = w.taxonomy.snapping(False)
+    tw = TrypticWorkload(n_keys, w, F, 2)
+    ix, _ = tw.build_index()
+    assert ix.var_layout == 1 and 60e9 < ix.table_bytes < 110e9
+    rng = np.random.default_rng(55)
+    d_t = torch.empty(n_pairs, dtype=torch.int32, device="cuda")
+    d_s = torch.empty_like(d_t)
+    d_t2, d_s2 = torch.empty_like(d_t), torch.empty_like(d_t)
+    modes = (("rmq", "mrtl", 0.0, 1.0, 2, 0.9), ("rmq", "mrtl", 0.0, 5.0, 4, 0.2), ("tree", "hybrid", 0.25, 1.0, 2, 0.9))
+    for k, (method, strategy, factor, lb, peps, min_ok) in enumerate(modes):
+        twk = tw if peps == 2 else TrypticWorkload(n_keys, w, F, peps)
+        d_bytes, d_foffs, _ = twk.batch(k, n_pairs)
+        kw = dict(method=method, strategy=strategy, factor=factor, lower_bound=lb, min_len=9, max_len=45)
+        n_pieces = api.classify_tryp_dev(ix, w.taxonomy, d_bytes, d_foffs, n_pairs, F, d_t, d_s, **kw)
+        assert n_pieces == n_pairs * F * peps
+        ix.bind(w.taxonomy)
+        api.classify_tryp_dev(ix, w.taxonomy, d_bytes, d_foffs, n_pairs, F, d_t2, d_s2, **kw)
+        torch.cuda.synchronize()
+        ix.unbind(w.taxonomy)
+        assert torch.equal(d_t, d_t2) and torch.equal(d_s, d_s2), (method, strategy, lb)
+        t, s = d_t.cpu().numpy().view(np.uint32), d_s.cpu().numpy().view(np.uint32)
+        assert ((s == 0) | (s == 1)).all() and (t[s == 1] == 1).all() and (snap[t] == t).all()
+        assert (s == 0).mean() > min_ok, (method, strategy, lb, (s == 0).mean())
+        sample = np.sort(rng.choice(n_pairs, 20_000, replace=False))
+        rep = tryptic_check.check_sample(twk, k, n_pairs, sample, d_bytes.cpu().numpy(), d_foffs.cpu().numpy(), t, s, otx, method, strategy, factor, lb)
+        assert rep["reads_checked"] == 20_000 and rep["pieces"] == 20_000 * F * peps and rep["member_pieces"] > 0.6 * rep["pieces"]
+        assert rep["reads_with_an_answer"] > min_ok * 20_000
+        del d_bytes, d_foffs
+        torch.cuda.empty_cache()
+    ix.close()
+    w.taxonomy.close()
+    torch.cuda.empty_cache()
+
+
 FULL_N_TAX, FULL_N_KEYS = 2_500_000, 8_000_000_000
 
 

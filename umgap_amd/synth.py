@@ -108,3 +108,141 @@ class SyntheticWorkload:
                                                           self.n_tax, self.n_keys, MUL_A, ADD_B, SEED_READS, first_pair, n_pairs,
                                                           kmers_per_pair, path_percent, unrelated_percent, _dev_ptr(d_keys), _stream_ptr(stream)))
         return d_keys
+
+
+# ---- tryptic workload (BASELINE.json configs[4]; SURVEY.md §8d Config 5) ---------------------------------------------------------
+SEED_TRYPTIC = 43
+_M64 = (1 << 64) - 1
+
+
+def _splitmix_np(x):
+    """splitmix64 on uint64 arrays (the device generator's mixer, common.hpp)."""
+    with np.errstate(over="ignore"):
+        x = x.astype(np.uint64) + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+
+
+class TrypticWorkload:
+    """Synthetic tryptic-peptide index + reads, generated on the device from closed forms that have host twins (numpy) so a test can
+    say what any read holds without a table on the CPU.
+
+    index: peptide number i < n_keys; 14..45 residues over ACDEFGHILMNPQSTVWY, no leading P, K or R at the end and nowhere else -- a
+        tryptic digest gives it back whole (umgap_synth_tryptic_dev).  value = taxon of row (i mod n_tax).
+    reads: pair p = `fragments` fragments (read ends) of `peptides` peptides written back to back.  A pair draws a source row s; each of
+        its peptides is, 52 %: a member that carries s's taxon (number s + k * n_tax), 18 %: any member, 30 %: a stranger (number >=
+        10^12: the same generator, so still a clean tryptic peptide, but no key)."""
+
+    def __init__(self, n_keys, workload, fragments=2, peptides=2, seed=SEED_TRYPTIC):
+        self.n_keys, self.w, self.F, self.PEPS, self.seed = int(n_keys), workload, int(fragments), int(peptides), int(seed)
+        self.n_tax = workload.n_tax
+
+    # -- device side ---------------------------------------------------------------------------------------------------------------
+    def _splitmix_t(self, x):
+        import torch
+        dev = self.w.device
+        x = x + torch.tensor(-7046029254386353131, dtype=torch.int64, device=dev)  # 0x9E3779B97F4A7C15
+        x = (x ^ ((x >> 30) & 0x3FFFFFFFF)) * torch.tensor(-4658895280553007687, dtype=torch.int64, device=dev)
+        x = (x ^ ((x >> 27) & 0x1FFFFFFFFF)) * torch.tensor(-7723592293110705685, dtype=torch.int64, device=dev)
+        return x ^ ((x >> 31) & 0x1FFFFFFFF)
+
+    def _lengths_t(self, ids):
+        return 14 + (self._splitmix_t(ids ^ self.seed) & 0x7FFFFFFF) % 32          # 14..45 residues
+
+    def write_peptides(self, ids, first, n):
+        """bytes + offsets of peptides `ids` (or first .. first + n - 1), back to back, on the device"""
+        import torch
+        from . import _lib
+        from .api import _dev_ptr, _stream_ptr
+        dev = self.w.device
+        idx = ids if ids is not None else torch.arange(first, first + n, dtype=torch.int64, device=dev)
+        offs = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(self._lengths_t(idx), 0, out=offs[1:])
+        total = int(offs[-1].item())
+        data = torch.empty(total + 64, dtype=torch.uint8, device=dev)
+        _lib.check(_lib.load().umgap_synth_tryptic_dev(_dev_ptr(ids) if ids is not None else None, first, n, self.seed, _dev_ptr(offs), _dev_ptr(data),
+                                                       dev.index or 0, _stream_ptr(None)))
+        return data, offs, total
+
+    def build_index(self):
+        """The packed peptide table of all n_keys peptides; returns (Index, bytes of key text)."""
+        import ctypes as C
+        import torch
+        from . import _lib
+        from .api import Index, _dev_ptr
+        data, offs, total = self.write_peptides(None, 0, self.n_keys)
+        taxa = self.w.d_taxon_of_row[torch.arange(self.n_keys, device=self.w.device) % self.n_tax].contiguous()
+        h = C.c_void_p()
+        _lib.check(_lib.load().umgap_index_build_var_dev(_dev_ptr(data), _dev_ptr(offs), _dev_ptr(taxa), self.n_keys, total, 0.0, self.w.device.index or 0, C.byref(h)))
+        ix = Index(h.value)
+        torch.cuda.synchronize()
+        del data, offs, taxa
+        torch.cuda.empty_cache()
+        return ix, total
+
+    def batch(self, b, n_pairs):
+        """Reads of pairs [b * n_pairs, (b + 1) * n_pairs): (bytes, fragment offsets (n_pairs * F + 1), total bytes), on the device."""
+        import torch
+        dev = self.w.device
+        per = self.F * self.PEPS
+        e = torch.arange(b * n_pairs * per, (b + 1) * n_pairs * per, dtype=torch.int64, device=dev)
+        r = self._splitmix_t(e ^ 0x5DEECE66D)
+        pair = e // per
+        src = (self._splitmix_t(pair ^ 0x2545F491) & 0x7FFFFFFFFFFF) % self.n_tax
+        per_row = max(1, self.n_keys // self.n_tax)
+        same = src + ((r >> 8) & 0x7FFFFFFF) % per_row * self.n_tax
+        anym = ((r >> 8) & 0x7FFFFFFFFFFF) % self.n_keys
+        cls = (r & 0xFF) % 100
+        ids = torch.where(cls < 52, same, torch.where(cls < 70, anym, 10**12 + ((r >> 8) & 0x7FFFFFFFFFFF)))
+        ids = torch.clamp(ids, min=0)
+        d, o, tot = self.write_peptides(ids.contiguous(), 0, ids.numel())
+        foffs = o[::self.PEPS].contiguous()                     # a fragment = PEPS peptides
+        return d, foffs, tot
+
+    # -- host twins (numpy; for the checker) -----------------------------------------------------------------------------------------
+    def piece_ids_np(self, b, n_pairs, pairs):
+        """Peptide numbers of pairs `pairs` (indices inside batch b): uint64 array (len(pairs), F * PEPS)."""
+        per = self.F * self.PEPS
+        pairs = np.asarray(pairs, dtype=np.uint64)
+        e = (np.uint64(b * n_pairs) + pairs)[:, None] * np.uint64(per) + np.arange(per, dtype=np.uint64)[None, :]
+        r = _splitmix_np(e ^ np.uint64(0x5DEECE66D))
+        src = (_splitmix_np((e // np.uint64(per)) ^ np.uint64(0x2545F491)) & np.uint64(0x7FFFFFFFFFFF)) % np.uint64(self.n_tax)
+        per_row = np.uint64(max(1, self.n_keys // self.n_tax))
+        r8 = r >> np.uint64(8)
+        same = src + (r8 & np.uint64(0x7FFFFFFF)) % per_row * np.uint64(self.n_tax)
+        anym = (r8 & np.uint64(0x7FFFFFFFFFFF)) % np.uint64(self.n_keys)
+        cls = (r & np.uint64(0xFF)) % np.uint64(100)
+        return np.where(cls < 52, same, np.where(cls < 70, anym, np.uint64(10**12) + (r8 & np.uint64(0x7FFFFFFFFFFF))))
+
+    def lengths_np(self, ids):
+        ids = np.asarray(ids, dtype=np.uint64)
+        return (np.uint64(14) + (_splitmix_np(ids ^ np.uint64(self.seed)) & np.uint64(0x7FFFFFFF)) % np.uint64(32)).astype(np.int64)
+
+    def peptides_np(self, ids):
+        """The residues of peptides `ids` as a list of bytes objects (k_synth_tryptic restated)."""
+        ids = np.asarray(ids, dtype=np.uint64).reshape(-1)
+        lens = self.lengths_np(ids)
+        alphabet = np.frombuffer(b"ACDEFGHILMNPQSTVWY", np.uint8)
+        out = np.zeros((len(ids), 48), np.uint8)
+        with np.errstate(over="ignore"):
+            h = _splitmix_np(np.uint64(self.seed) ^ (ids * np.uint64(0x9E3779B97F4A7C15)))
+            for j in range(45):
+                if (j & 7) == 0 and j:
+                    h = _splitmix_np(h + np.uint64(j))
+                d = ((h >> np.uint64(8 * (j & 7))) & np.uint64(0xFF)) % np.uint64(18)
+                if j == 0:
+                    d = np.where(d == 11, np.uint64(12), d)
+                out[:, j] = alphabet[d.astype(np.int64)]
+                last = lens - 1 == j                           # the last letter: K or R off the hash state at that point
+                if last.any():
+                    out[last, j] = np.where((h[last] >> np.uint64(60)) & np.uint64(1), ord("K"), ord("R"))
+        # (the device rehashes for j = len at a multiple of 8 only inside its loop, i.e. for j < len: same as above)
+        return [out[i, :lens[i]].tobytes() for i in range(len(ids))]
+
+    def values_np(self, ids):
+        """Index value of peptide numbers `ids`: the taxon of row (i mod n_tax) for members, 0 for strangers."""
+        ids = np.asarray(ids, dtype=np.uint64)
+        member = ids < np.uint64(self.n_keys)
+        v = self.w.taxon_of_row[(ids % np.uint64(self.n_tax)).astype(np.int64)]
+        return np.where(member, v, 0).astype(np.uint32)
