@@ -390,6 +390,13 @@ void umgap_sharded_free(umgap_sharded* sh);
 uint32_t umgap_sharded_value_bytes(const umgap_sharded* sh);  /* 3 or 4 */
 uint64_t umgap_sharded_region_slots(const umgap_sharded* sh); /* slots per peer and piece: a peer receives 6 x this out, value_bytes x this back */
 uint32_t umgap_sharded_pieces(const umgap_sharded* sh);
+/* How the group exchanges: 0 = store and forward (the pack fills a send buffer, the communicator moves it: RCCL send/recv groups, or
+ * copies between the ranks of a local / IPC communicator); 1 = peer-written ("put"): the pack stores each key straight into the
+ * OWNER's receive buffer and the owner's probe stores each value straight into the REQUESTER's gather buffer, through hipIpc mappings
+ * of the peers' exchange blocks (the same mappings run over xGMI between the GPUs of a node), with per-piece counters in device memory
+ * instead of copies and host barriers.  Default between the processes of an IPC communicator (UMGAP_SHARD_PUT=0: copies); opt-in
+ * under RCCL and between thread-ranks (UMGAP_SHARD_PUT=1).  In put mode umgap_sharded_free is collective. */
+int umgap_sharded_transport(const umgap_sharded* sh);
 /* get() over the whole sharded table: as umgap_index_lookup9_dev.  Collective: every rank calls it the same number of
  * times (n may differ, 0 included); enqueues on internal streams ordered after `stream` and joins them back into it. */
 int umgap_sharded_lookup9_dev(umgap_sharded* sh, const uint64_t* d_keys45, size_t n, uint32_t miss_value,
@@ -403,7 +410,8 @@ int umgap_sharded_classify9_dev(umgap_sharded* sh, int method, int strategy, flo
                                 uint32_t fragments_per_read, uint32_t min_seed_size, uint32_t max_gap_size,
                                 uint32_t* d_out_taxon, uint32_t* d_out_status, void* stream);
 /* Waits for the device and reports (UMGAP_ERR_BUILD) whether an exchange region overflowed in any call since the last
- * check -- the affected k-mers were answered with a miss, so those calls' results are not to be used. */
+ * check -- the affected k-mers were answered with a miss, so those calls' results are not to be used -- or (UMGAP_ERR_DEVICE,
+ * put mode) whether a peer's keys or values failed to arrive within UMGAP_PUT_TIMEOUT_S (default 30 s). */
 int umgap_sharded_check(umgap_sharded* sh);
 /* Duration of the local probe kernel of the first piece of the last call (measurement: bench.py's roofline). */
 int umgap_sharded_probe_ms(umgap_sharded* sh, float* ms);

@@ -1,7 +1,7 @@
 """One rank of the process-per-rank sharded test (tests/test_gpu_parity.py::test_sharded_table_ranks_as_processes): its own
 process, its own HIP context, its own shard of the table; the exchange goes through umgap_comm_init_ipc.  Every rank builds
 the same synthetic workload, answers its own reads from the whole table first and then through the sharded path, and exits 0
-only if the two agree bit for bit.  argv: shm name, world, rank, pieces."""
+only if the two agree bit for bit.  argv: shm name, world, rank, pieces, transport ("put" / "copy": what the group must report)."""
 import os
 import sys
 
@@ -35,8 +35,10 @@ def main():
     assert comm.world == world and comm.rank == rank and comm.transport == "ipc"
     comm.selftest(3 << 16)
     sh = Sharded(shard, w.taxonomy, comm, max_keys, pieces=pieces)
+    if len(sys.argv) > 5:
+        assert sh.transport == sys.argv[5], (sh.transport, sys.argv[5])
     got_hits = torch.full_like(want_hits, -7)
-    for _ in range(2):                                          # buffer sets (and the mapped peer buffers) are reused across calls
+    for _ in range(3):                                          # buffer sets (and the mapped peer buffers, the counters) are reused across calls
         sh.lookup9(keys, got_hits, miss_value=0)
     torch.cuda.synchronize()
     assert torch.equal(got_hits, want_hits), "hits differ"

@@ -1250,20 +1250,26 @@ def test_sharded_table_local_ranks_match_whole_table(api, torch_cuda, world, pie
             assert torch.equal(got[(r, m)][0], want[(r, m)][0]), (world, r, m, "taxon")
 
 
-@pytest.mark.parametrize("world,pieces,own_share", [(3, 2, "probed in place"), (2, 3, "packed")])
-def test_sharded_table_ranks_as_processes(api, torch_cuda, world, pieces, own_share):
+@pytest.mark.parametrize("world,pieces,own_share,transport", [(3, 2, "probed in place", "put"), (2, 3, "packed", "put"), (2, 9, "probed in place", "put"),
+                                                             (3, 2, "probed in place", "copy"), (2, 3, "packed", "copy")])
+def test_sharded_table_ranks_as_processes(api, torch_cuda, world, pieces, own_share, transport):
     """The N-rank protocol with every rank its own PROCESS (own HIP context, own shard of the table, own reads): what
     `torchrun --nproc-per-node N` starts on a node, here with the ranks sharing the one GPU of the box.  RCCL refuses two ranks
     on one device, so the exchange runs over umgap_comm_init_ipc (peers' send buffers mapped with hipIpc handles, barrier in
     shared memory); pack / probe / gather are the shipped kernels.  Each rank checks its answers against the whole table
-    (tests/ipc_rank_worker.py) -- hits and three fused pipelines -- and the communicator's own pattern test."""
+    (tests/ipc_rank_worker.py) -- hits and three fused pipelines -- and the communicator's own pattern test.
+    transport "put" (the IPC communicator's default): the pack stores keys straight into the owners' receive buffers and the probe stores
+    values straight into the requesters' gather buffers through mapped exchange blocks, per-piece counters on the device instead of
+    copies and host barriers (9 pieces: the buffer sets and their counters go round more than twice per call); "copy"
+    (UMGAP_SHARD_PUT=0): store and forward with host-synchronised copies."""
     import subprocess
     import sys
     import uuid
     here = os.path.dirname(os.path.abspath(__file__))
     name = "/umgap-test-%s" % uuid.uuid4().hex[:12]
-    env = dict(os.environ, UMGAP_SHARD_NO_LOCAL="1" if own_share == "packed" else "0", UMGAP_IPC_TIMEOUT_S="240")
-    procs = [subprocess.Popen([sys.executable, os.path.join(here, "ipc_rank_worker.py"), name, str(world), str(r), str(pieces)], env=env,
+    env = dict(os.environ, UMGAP_SHARD_NO_LOCAL="1" if own_share == "packed" else "0", UMGAP_IPC_TIMEOUT_S="240", UMGAP_SHARD_PUT="1" if transport == "put" else "0",
+               UMGAP_PUT_TIMEOUT_S="20")
+    procs = [subprocess.Popen([sys.executable, os.path.join(here, "ipc_rank_worker.py"), name, str(world), str(r), str(pieces), transport], env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
     outs = []
     try:

@@ -127,6 +127,7 @@ def load():
         "umgap_sharded_value_bytes": (u32, [vp]),
         "umgap_sharded_region_slots": (u64, [vp]),
         "umgap_sharded_pieces": (u32, [vp]),
+        "umgap_sharded_transport": (i32, [vp]),
         "umgap_sharded_lookup9_dev": (i32, [vp, vp, sz, u32, vp, vp]),
         "umgap_sharded_lookup9": (i32, [vp, vp, sz, u32, vp]),
         "umgap_sharded_classify9_dev": (i32, [vp, i32, i32, f32, f32, i32, vp, sz, u32, u32, u32, u32, vp, vp, vp]),

@@ -35,6 +35,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -73,6 +74,7 @@ struct Rccl {
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string error;
 };
@@ -99,6 +101,7 @@ Rccl* rccl() {
         R.Send = (decltype(R.Send))sym("ncclSend");
         R.Recv = (decltype(R.Recv))sym("ncclRecv");
         R.AllReduce = (decltype(R.AllReduce))sym("ncclAllReduce");
+        R.AllGather = (decltype(R.AllGather))sym("ncclAllGather");
         R.GetErrorString = (decltype(R.GetErrorString))sym("ncclGetErrorString");
     });
     return &R;
@@ -106,7 +109,8 @@ Rccl* rccl() {
 
 // the pointers above carry the prototypes of <rccl/rccl.h>
 static_assert(std::is_same<decltype(Rccl::Send), decltype(&ncclSend)>::value && std::is_same<decltype(Rccl::Recv), decltype(&ncclRecv)>::value &&
-                  std::is_same<decltype(Rccl::AllReduce), decltype(&ncclAllReduce)>::value && std::is_same<decltype(Rccl::CommInitRank), decltype(&ncclCommInitRank)>::value &&
+                  std::is_same<decltype(Rccl::AllReduce), decltype(&ncclAllReduce)>::value && std::is_same<decltype(Rccl::AllGather), decltype(&ncclAllGather)>::value &&
+                  std::is_same<decltype(Rccl::CommInitRank), decltype(&ncclCommInitRank)>::value &&
                   std::is_same<decltype(Rccl::GetUniqueId), decltype(&ncclGetUniqueId)>::value,
               "RCCL binding out of step with rccl.h");
 
@@ -126,6 +130,7 @@ struct LocalHub {
     std::vector<const void*> send;
     std::vector<hipEvent_t> ready, done;
     std::vector<uint32_t> vals;
+    std::vector<std::array<uint8_t, 192>> blobs;
     void barrier() {
         std::unique_lock<std::mutex> lk(m);
         const uint64_t g = generation;
@@ -144,6 +149,7 @@ struct IpcCtl {
         uint64_t offset, alloc_bytes, alloc_base;
         uint32_t val;
         uint32_t pad;
+        uint8_t blob[192];          // comm_allgather: a rank's contribution (an exported allocation, a layout stamp)
     } slot[64];
 };
 static_assert(std::atomic<uint32_t>::is_always_lock_free, "the barrier words are shared between processes");
@@ -303,6 +309,48 @@ int comm_max_u32(umgap_comm* c, uint32_t* v) {
     return UMGAP_OK;
 }
 
+constexpr size_t BLOB_BYTES = 192;
+// every rank's `bytes` (<= BLOB_BYTES) to every rank: all[p * bytes ..] = rank p's.  Set-up time only; synchronises.
+int comm_allgather(umgap_comm* c, const void* mine, void* all, size_t bytes) {
+    if (bytes > BLOB_BYTES) return fail(UMGAP_ERR_INVALID, "comm_allgather: contribution too large");
+    if (c->hub) {
+        LocalHub& H = *c->hub;
+        memcpy(H.blobs[c->rank].data(), mine, bytes);
+        H.barrier();
+        for (int p = 0; p < c->world; p++) memcpy((char*)all + (size_t)p * bytes, H.blobs[p].data(), bytes);
+        H.barrier();
+        return UMGAP_OK;
+    }
+    if (c->ipc) {
+        IpcHub& H = *c->ipc;
+        memcpy(H.ctl->slot[c->rank].blob, mine, bytes);
+        int rc = H.barrier();
+        if (rc) return rc;
+        for (int p = 0; p < c->world; p++) memcpy((char*)all + (size_t)p * bytes, H.ctl->slot[p].blob, bytes);
+        return H.barrier();
+    }
+    uint8_t* d = nullptr;
+    const size_t W = (size_t)c->world;
+    UMGAP_HIP(hipMalloc((void**)&d, (W + 1) * bytes));
+    hipError_t e = hipMemcpy(d + W * bytes, mine, bytes, hipMemcpyHostToDevice);
+    ncclResult_t r = ncclSuccess;
+    if (e == hipSuccess) r = rccl()->AllGather(d + W * bytes, d, bytes, ncclUint8, c->nccl, nullptr);
+    if (e == hipSuccess && r == ncclSuccess) e = hipStreamSynchronize(nullptr);
+    if (e == hipSuccess && r == ncclSuccess) e = hipMemcpy(all, d, W * bytes, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (r != ncclSuccess) return fail(UMGAP_ERR_DEVICE, std::string("ncclAllGather: ") + rccl()->GetErrorString(r));
+    if (e != hipSuccess) return fail(UMGAP_ERR_DEVICE, std::string("comm_allgather: ") + hipGetErrorString(e));
+    return UMGAP_OK;
+}
+// (set-up / tear-down only)
+int comm_barrier(umgap_comm* c) {
+    if (c->world == 1) return UMGAP_OK;
+    if (c->hub) { c->hub->barrier(); return UMGAP_OK; }
+    if (c->ipc) return c->ipc->barrier();
+    uint32_t v = 0;
+    return comm_max_u32(c, &v);
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // kernels
 // ------------------------------------------------------------------------------------------------------------------
@@ -313,11 +361,14 @@ int comm_max_u32(umgap_comm* c, uint32_t* v) {
 // workgroup's range.  Keys with bits above 45 (not a packed 9-mer) are not sent, nor are the rank's own (local_owner).
 constexpr int PACK_ROUNDS = 16;
 __global__ __launch_bounds__(256) void k_shard_pack(const uint64_t* __restrict__ keys, size_t n, uint32_t run_len, uint32_t m, uint32_t nb, uint32_t world,
-                                                    double world_over_nb, uint64_t cap, uint8_t* __restrict__ send, uint32_t* __restrict__ bases,
-                                                    unsigned long long* __restrict__ cursor, uint32_t* __restrict__ overflow, uint32_t local_owner) {
+                                                    double world_over_nb, uint64_t cap, const uint64_t* __restrict__ key_dst, uint32_t* __restrict__ bases,
+                                                    unsigned long long* __restrict__ cursor, uint32_t* __restrict__ overflow, uint32_t local_owner, uint32_t put) {
     __shared__ uint32_t wcnt[4][64];
     __shared__ uint32_t wbase[4][64];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // key_dst[o]: where the region of owner o starts -- in this rank's send buffer (the exchange then moves it), or, with peer-written
+    // keys (put mode), in the OWNER's receive buffer, mapped here: the store below is the exchange.  Lane o holds the pointer of owner o.
+    const uint64_t my_dst = lane < world ? key_dst[lane] : 0ull;
     const size_t n_runs = (n + run_len - 1) / run_len;
     for (size_t run0 = (size_t)blockIdx.x * 4; run0 < n_runs; run0 += (size_t)gridDim.x * 4) {   // the same trip count for the four waves
         const size_t run = run0 + wv, k0 = run * run_len;
@@ -364,10 +415,11 @@ __global__ __launch_bounds__(256) void k_shard_pack(const uint64_t* __restrict__
             if (64u * r >= len) continue;   // wave-uniform
             const uint32_t owner = meta[r] & 0xFFu;
             const uint32_t b0 = (uint32_t)__shfl((int)base, (int)(owner & 63u), 64);
+            const uint32_t dlo = (uint32_t)__shfl((int)(uint32_t)my_dst, (int)(owner & 63u), 64), dhi = (uint32_t)__shfl((int)(uint32_t)(my_dst >> 32), (int)(owner & 63u), 64);
             if (meta[r] == 0xFFFFFFFFu) continue;
             const uint64_t pos = (uint64_t)b0 + (meta[r] >> 8);
             if (pos < cap) {
-                uint8_t* region = send + (size_t)owner * cap * 6;
+                uint8_t* region = reinterpret_cast<uint8_t*>(((uint64_t)dhi << 32) | dlo);
                 reinterpret_cast<uint32_t*>(region)[pos] = (uint32_t)h[r];
                 reinterpret_cast<uint16_t*>(region + cap * 4)[pos] = (uint16_t)(h[r] >> 32);
             } else {
@@ -376,14 +428,61 @@ __global__ __launch_bounds__(256) void k_shard_pack(const uint64_t* __restrict__
         }
         __syncthreads();   // wcnt / wbase are rewritten by the next trip
     }
+    // peer-written keys: what this wave stored is at the peers before the kernel is through (the signal that follows the kernel on its
+    // stream then tells them)
+    if (put) __threadfence_system();
 }
 
 // the unused tail of every region carries "no key"
-__global__ __launch_bounds__(256) void k_shard_pad(uint8_t* __restrict__ send, const unsigned long long* __restrict__ cursor, uint64_t cap) {
+__global__ __launch_bounds__(256) void k_shard_pad(const uint64_t* __restrict__ key_dst, const unsigned long long* __restrict__ cursor, uint64_t cap, uint32_t put) {
     const uint32_t o = blockIdx.y;
-    uint16_t* hi = reinterpret_cast<uint16_t*>(send + (size_t)o * cap * 6 + cap * 4);
+    uint16_t* hi = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(key_dst[o]) + cap * 4);
     const unsigned long long filled = cursor[o] < cap ? cursor[o] : cap;
     for (uint64_t i = filled + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) hi[i] = (uint16_t)wire::HI_NOKEY;
+    if (put) __threadfence_system();
+}
+
+// ---- peer-written exchange (put mode): flags instead of copies ------------------------------------------------------------------
+// Every rank keeps, in its own exchange block, four rows of counters per buffer set, one counter per peer; a peer writes them through
+// its mapping of the block (hipIpc), the rank polls them where they lie.  Values are piece numbers + 1 and only grow:
+//   KEYS_READY[set][p]  peer p's pack of piece t has written its keys into my receive region p             (p -> me, after its pack)
+//   KEYS_FREE [set][p]  owner p's probe of piece t has read the keys I wrote into its receive region        (p -> me, after its probe)
+//   VALS_READY[set][p]  owner p's probe of piece t has written my values into region p of my gather buffer  (p -> me, after its probe)
+//   VALS_FREE [set][p]  requester p's aggregate of piece t has read the values I wrote into its buffer      (p -> me, after its aggregate)
+// A stage that needs piece t of every peer waits (k_put_wait, one lane per peer, on the stage's own stream) for counter >= t + 1; a
+// stage that overwrites what piece t - NSETS left waits for the matching FREE counter >= t - NSETS + 1.  Every wait is for work that
+// every rank enqueues EARLIER in its (identical) issue order than the waiting stage, so the waits cannot form a cycle -- even if a
+// rank's streams shared one hardware queue.  A wait gives up after `timeout` ticks of the 100 MHz clock and raises a sticky flag
+// (umgap_sharded_check); the grid always drains.
+constexpr int FLAG_KEYS_READY = 0, FLAG_KEYS_FREE = 1, FLAG_VALS_READY = 2, FLAG_VALS_FREE = 3, FLAG_KINDS = 4;
+struct PutPeers { uint64_t base[64]; };      // rank p's exchange block as mapped in this process (own block at [self])
+
+__global__ __launch_bounds__(64) void k_put_signal(PutPeers P, uint32_t world, uint32_t self, uint64_t off_a, uint64_t off_b, uint64_t value) {
+    const uint32_t p = threadIdx.x;
+    if (p >= world || p == self) return;
+    __threadfence_system();
+    unsigned long long* a = reinterpret_cast<unsigned long long*>(P.base[p] + off_a) + self;
+    __hip_atomic_store(a, (unsigned long long)value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (off_b) {
+        unsigned long long* b = reinterpret_cast<unsigned long long*>(P.base[p] + off_b) + self;
+        __hip_atomic_store(b, (unsigned long long)value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_put_wait(const unsigned long long* __restrict__ flags_a, uint64_t want_a, const unsigned long long* __restrict__ flags_b,
+                                                 uint64_t want_b, uint32_t world, uint32_t self, uint64_t timeout, uint32_t* __restrict__ timed_out) {
+    const uint32_t p = threadIdx.x;
+    if (p < world && p != self) {
+        const uint64_t t0 = wall_clock64();
+        for (;;) {
+            const bool a_ok = !flags_a || __hip_atomic_load(flags_a + p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= want_a;
+            const bool b_ok = !flags_b || __hip_atomic_load(flags_b + p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) >= want_b;
+            if (a_ok && b_ok) break;
+            if (wall_clock64() - t0 > timeout) { atomicExch(timed_out, 1u); break; }
+            __builtin_amdgcn_s_sleep(64);
+        }
+    }
+    __threadfence_system();
 }
 
 // keys (world regions x cap slots) -> one value per slot.  Region `self` is this rank's own share: read from the send buffer
@@ -396,7 +495,7 @@ __global__ __launch_bounds__(256) void k_shard_pad(uint8_t* __restrict__ send, c
 // while a resident grid that leaves part of each CU's wave slots free lets pack, aggregate and RCCL's copies run next to it.
 template <int VB>
 __global__ __launch_bounds__(256) void k_shard_probe(TableView T, const uint8_t* __restrict__ recv, const uint8_t* __restrict__ own_send, uint32_t self,
-                                                     uint32_t skip_self, uint64_t cap, uint64_t n_slots, uint32_t* __restrict__ ret, uint32_t* __restrict__ own_ret) {
+                                                     uint32_t skip_self, uint64_t cap, uint64_t n_slots, const uint64_t* __restrict__ val_dst, uint32_t put) {
     __shared__ uint32_t lds_out[4][128];
     const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63, q = lane >> 2, j = lane & 3;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
@@ -447,11 +546,14 @@ __global__ __launch_bounds__(256) void k_shard_probe(TableView T, const uint8_t*
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // 128 slots = 96 (VB 3) or 128 (VB 4) words = 24 or 32 lanes x 16 bytes, contiguous
-    uint32_t* dst = (region == self ? own_ret : ret) + (VB == 4 ? s0 : (s0 >> 2) * 3);
+    // val_dst[region]: where slot 0 of the region's values goes -- this rank's value send buffer (region `region`), its own gather buffer
+    // (region == self), or, with peer-written values (put mode), region `self` of the REQUESTER's gather buffer, mapped here
+    uint32_t* dst = reinterpret_cast<uint32_t*>(val_dst[region]) + (VB == 4 ? pos0 : (pos0 >> 2) * 3);
     if (lane < (VB == 4 ? 32u : 24u)) reinterpret_cast<u32x4*>(dst)[lane] = reinterpret_cast<const u32x4*>(wl)[lane];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     }
+    if (put) __threadfence_system();
 }
 
 // the plain sharded get(): out[i] = value of key i, or miss_value.  A wave takes one run of the piece (shard_wire.hpp) in rounds
@@ -518,6 +620,7 @@ struct BufSet {
     uint8_t *send_keys = nullptr, *recv_keys = nullptr;
     uint32_t *ret_send = nullptr, *ret_recv = nullptr;
     unsigned long long* cursor = nullptr;
+    uint64_t *key_dst = nullptr, *val_dst = nullptr;   // [world] device tables: where the pack puts owner o's keys / the probe region r's values
 };
 
 }  // namespace
@@ -544,6 +647,15 @@ struct umgap_sharded {
     uint64_t piece_no = 0;               // pieces issued so far (event slots are reused cyclically)
     bool local_bypass = true;            // the rank's own keys are probed by the consuming kernel (UMGAP_SHARD_NO_LOCAL=1 sends them through pack / probe / gather like the rest)
     uint32_t* d_overflow = nullptr;
+    // peer-written exchange (put mode): the pack stores keys into the owners' receive buffers, the probe stores values into the requesters'
+    // gather buffers, through hipIpc mappings of the peers' exchange blocks; counters in those blocks replace the all-to-all (k_put_wait)
+    bool put = false;
+    PutPeers peers = {};                 // every rank's block as mapped here
+    std::vector<void*> peer_maps;        // what hipIpcOpenMemHandle returned (closed in umgap_sharded_free)
+    unsigned long long* flags = nullptr; // [FLAG_KINDS][NSETS][64] in this rank's block
+    uint64_t flags_off = 0;              // ... and where that is inside the block (the same on every rank)
+    uint32_t* d_put_timeout = nullptr;
+    uint64_t put_timeout_ticks = 0;
     hipEvent_t ev_in = nullptr, ev_probe0 = nullptr, ev_probe1 = nullptr;
     bool probe_timed = false;
     // staging of the host-pointer umgap_sharded_lookup9 (made on first use)
@@ -553,6 +665,10 @@ struct umgap_sharded {
 };
 
 namespace {
+
+// row `kind` of the counters of the set piece t uses: in this rank's block / as an offset into any rank's block
+inline const unsigned long long* put_flags(const umgap_sharded* sh, int kind, uint64_t t) { return sh->flags + ((size_t)kind * NSETS + t % NSETS) * 64; }
+inline uint64_t put_flags_off(const umgap_sharded* sh, int kind, uint64_t t) { return sh->flags_off + ((uint64_t)kind * NSETS + t % NSETS) * 64 * 8; }
 
 int sharded_args_ok(umgap_sharded* sh, const char* who) {
     if (!sh) return fail(UMGAP_ERR_INVALID, std::string(who) + ": null handle");
@@ -581,14 +697,19 @@ int stage_pack(umgap_sharded* sh, uint64_t t, const uint64_t* d_keys, size_t nk,
         UMGAP_HIP(hipEventRecord(S.filled, s));
         return UMGAP_OK;
     }
+    if (sh->put && W > 1 && t >= NSETS) {  // the owners' probes of piece t - NSETS have read what this rank wrote into their receive buffers
+        hipLaunchKernelGGL(k_put_wait, dim3(1), dim3(64), 0, s, put_flags(sh, FLAG_KEYS_FREE, t), t - NSETS + 1, (const unsigned long long*)nullptr, 0ull, W,
+                           (uint32_t)sh->comm->rank, sh->put_timeout_ticks, sh->d_put_timeout);
+    }
     UMGAP_HIP(hipMemsetAsync(S.cursor, 0, W * sizeof(unsigned long long), s));
     const size_t n_runs = (nk + run_len - 1) / run_len;
     if (n_runs > sh->bases_runs) return fail(UMGAP_ERR_INVALID, "sharded lookup: runs of " + std::to_string(run_len) + " k-mers do not fit the run table of this group");
     unsigned g = (unsigned)std::min<size_t>((n_runs + 3) / 4, 256 * 8);   // persistent: a grid of short workgroups holds up the other streams' kernels (k_shard_probe)
     if (g < 1) g = 1;
-    hipLaunchKernelGGL(k_shard_pack, dim3(g), dim3(256), 0, s, d_keys, nk, run_len, T.m, T.nb, W, (double)W / (double)T.nb, sh->cap, S.send_keys, sh->bases[t % NPERM],
-                       S.cursor, sh->d_overflow, sh->local_bypass ? (uint32_t)sh->comm->rank : wire::NO_SELF);
-    hipLaunchKernelGGL(k_shard_pad, dim3(64, W), dim3(256), 0, s, S.send_keys, S.cursor, sh->cap);
+    hipLaunchKernelGGL(k_shard_pack, dim3(g), dim3(256), 0, s, d_keys, nk, run_len, T.m, T.nb, W, (double)W / (double)T.nb, sh->cap, S.key_dst, sh->bases[t % NPERM],
+                       S.cursor, sh->d_overflow, sh->local_bypass ? (uint32_t)sh->comm->rank : wire::NO_SELF, sh->put ? 1u : 0u);
+    hipLaunchKernelGGL(k_shard_pad, dim3(64, W), dim3(256), 0, s, S.key_dst, S.cursor, sh->cap, sh->put ? 1u : 0u);
+    if (sh->put && W > 1) hipLaunchKernelGGL(k_put_signal, dim3(1), dim3(64), 0, s, sh->peers, W, (uint32_t)sh->comm->rank, put_flags_off(sh, FLAG_KEYS_READY, t), 0ull, t + 1);
     UMGAP_HIP(hipGetLastError());
     UMGAP_HIP(hipEventRecord(S.filled, s));
     return UMGAP_OK;
@@ -597,8 +718,10 @@ int stage_keys(umgap_sharded* sh, uint64_t t) {
     BufSet& S = sh->set[t % NSETS];
     UMGAP_HIP(hipStreamWaitEvent(sh->s_keys, S.filled, 0));
     if (t >= NSETS) UMGAP_HIP(hipStreamWaitEvent(sh->s_keys, S.probed, 0));   // recv_keys was read by the probe of piece t - NSETS
-    int rc = comm_alltoall(sh->comm, S.send_keys, S.recv_keys, (size_t)sh->cap * 6, sh->s_keys);
-    if (rc) return rc;
+    if (!sh->put) {                          // (put mode: the pack's stores were the exchange; the probe waits for the peers' counters)
+        int rc = comm_alltoall(sh->comm, S.send_keys, S.recv_keys, (size_t)sh->cap * 6, sh->s_keys);
+        if (rc) return rc;
+    }
     UMGAP_HIP(hipEventRecord(S.packed, sh->s_keys));
     return UMGAP_OK;
 }
@@ -612,9 +735,16 @@ int stage_probe(umgap_sharded* sh, uint64_t t, bool time_probe) {
     const uint64_t n_slots = sh->cap * W;
     const unsigned gp = (unsigned)std::min<uint64_t>((n_slots / 128 + 3) / 4, 256 * 3);   // resident grid, 3 workgroups per CU (2: 33.4 ms per step, 3: 30.3, 4: 31.3, 8: 31.2)
     const uint32_t self = (uint32_t)sh->comm->rank;
+    if (sh->put && W > 1) {
+        // every peer's keys of piece t have arrived, and every requester has read the values of piece t - NSETS out of its gather buffer
+        hipLaunchKernelGGL(k_put_wait, dim3(1), dim3(64), 0, s, put_flags(sh, FLAG_KEYS_READY, t), t + 1, t >= NSETS ? put_flags(sh, FLAG_VALS_FREE, t) : (const unsigned long long*)nullptr,
+                           t >= NSETS ? t - NSETS + 1 : 0ull, W, self, sh->put_timeout_ticks, sh->d_put_timeout);
+    }
     if (time_probe) UMGAP_HIP(hipEventRecord(sh->ev_probe0, s));
-    if (sh->value_bytes == 3) hipLaunchKernelGGL(k_shard_probe<3>, dim3(gp), dim3(256), 0, s, T, S.recv_keys, S.send_keys, self, sh->local_bypass ? 1u : 0u, sh->cap, n_slots, S.ret_send, S.ret_recv);
-    else hipLaunchKernelGGL(k_shard_probe<4>, dim3(gp), dim3(256), 0, s, T, S.recv_keys, S.send_keys, self, sh->local_bypass ? 1u : 0u, sh->cap, n_slots, S.ret_send, S.ret_recv);
+    const uint8_t* own_keys = sh->put ? S.recv_keys : S.send_keys;       // put mode: the rank's own region is packed into its receive buffer like a peer's
+    if (sh->value_bytes == 3) hipLaunchKernelGGL(k_shard_probe<3>, dim3(gp), dim3(256), 0, s, T, S.recv_keys, own_keys, self, sh->local_bypass ? 1u : 0u, sh->cap, n_slots, S.val_dst, sh->put ? 1u : 0u);
+    else hipLaunchKernelGGL(k_shard_probe<4>, dim3(gp), dim3(256), 0, s, T, S.recv_keys, own_keys, self, sh->local_bypass ? 1u : 0u, sh->cap, n_slots, S.val_dst, sh->put ? 1u : 0u);
+    if (sh->put && W > 1) hipLaunchKernelGGL(k_put_signal, dim3(1), dim3(64), 0, s, sh->peers, W, self, put_flags_off(sh, FLAG_KEYS_FREE, t), put_flags_off(sh, FLAG_VALS_READY, t), t + 1);
     UMGAP_HIP(hipGetLastError());
     UMGAP_HIP(hipEventRecord(S.probed, s));
     if (time_probe) { UMGAP_HIP(hipEventRecord(sh->ev_probe1, s)); sh->probe_timed = true; }
@@ -626,10 +756,22 @@ int stage_probe(umgap_sharded* sh, uint64_t t, bool time_probe) {
 int piece_back(umgap_sharded* sh, uint64_t t) {
     BufSet& S = sh->set[t % NSETS];
     UMGAP_HIP(hipStreamWaitEvent(sh->s_agg, S.probed, 0));
+    if (sh->put) {                           // the owners' probes of piece t have written this rank's values where the consumer reads them
+        if (sh->comm->world > 1) {
+            hipLaunchKernelGGL(k_put_wait, dim3(1), dim3(64), 0, sh->s_agg, put_flags(sh, FLAG_VALS_READY, t), t + 1, (const unsigned long long*)nullptr, 0ull, (uint32_t)sh->comm->world,
+                               (uint32_t)sh->comm->rank, sh->put_timeout_ticks, sh->d_put_timeout);
+            UMGAP_HIP(hipGetLastError());
+        }
+        return UMGAP_OK;
+    }
     return comm_alltoall(sh->comm, S.ret_send, S.ret_recv, (size_t)sh->cap * sh->value_bytes, sh->s_agg);
 }
 int piece_done(umgap_sharded* sh, uint64_t t) {
     UMGAP_HIP(hipEventRecord(sh->aggregated[t % NPERM], sh->s_agg));
+    if (sh->put && sh->comm->world > 1) {    // ... and tells them when it has read them
+        hipLaunchKernelGGL(k_put_signal, dim3(1), dim3(64), 0, sh->s_agg, sh->peers, (uint32_t)sh->comm->world, (uint32_t)sh->comm->rank, put_flags_off(sh, FLAG_VALS_FREE, t), 0ull, t + 1);
+        UMGAP_HIP(hipGetLastError());
+    }
     return UMGAP_OK;
 }
 
@@ -661,6 +803,99 @@ int join_streams(umgap_sharded* sh, hipStream_t caller) {
         i++;
     }
     return UMGAP_OK;
+}
+
+// Put mode or not, and the tables the kernels store through.  Collective (every rank of the communicator is inside
+// umgap_sharded_create).  Put mode: the default between the processes of an IPC communicator (UMGAP_SHARD_PUT=0 keeps the
+// host-synchronised copies), opt-in (UMGAP_SHARD_PUT=1) under RCCL -- the same peer mappings over xGMI, never run -- and between
+// the thread-ranks of a local communicator.
+struct PutBlob {
+    hipIpcMemHandle_t mem;
+    uint64_t block, block_bytes, cap, flags_off;
+    uint32_t world, value_bytes, want_put, pid;
+};
+static_assert(sizeof(PutBlob) <= BLOB_BYTES, "the contribution of a rank fits comm_allgather");
+
+int put_setup(umgap_sharded* sh) {
+    umgap_comm* c = sh->comm;
+    const uint32_t W = (uint32_t)c->world, me = (uint32_t)c->rank;
+    const char* env = getenv("UMGAP_SHARD_PUT");
+    bool want = c->ipc ? !(env && env[0] == '0') : (env && env[0] == '1');
+    double timeout_s = 30.0;                                   // how long a stage waits for a peer's counter before it gives up
+    if (const char* t = getenv("UMGAP_PUT_TIMEOUT_S")) { const double v = atof(t); if (v > 0) timeout_s = v; }
+    sh->put_timeout_ticks = (uint64_t)(timeout_s * 1e8);      // wall_clock64: 100 MHz
+    std::vector<PutBlob> all(W);
+    if (W > 1) {
+        PutBlob mine;
+        memset(&mine, 0, sizeof(mine));
+        mine.block = (uint64_t)(uintptr_t)sh->block;
+        mine.block_bytes = sh->block_bytes;
+        mine.cap = sh->cap;
+        mine.flags_off = sh->flags_off;
+        mine.world = W;
+        mine.value_bytes = sh->value_bytes;
+        mine.want_put = want ? 1u : 0u;
+        mine.pid = (uint32_t)getpid();
+        if (want && !c->hub && hipIpcGetMemHandle(&mine.mem, sh->block) != hipSuccess) { (void)hipGetLastError(); mine.want_put = 0; }
+        int rc = comm_allgather(c, &mine, all.data(), sizeof(PutBlob));
+        if (rc) return rc;
+        for (uint32_t p = 0; p < W; p++) {
+            if (all[p].block_bytes != sh->block_bytes || all[p].cap != sh->cap || all[p].flags_off != sh->flags_off || all[p].value_bytes != sh->value_bytes)
+                return fail(UMGAP_ERR_INVALID, "umgap_sharded_create: rank " + std::to_string(p) + " laid its exchange buffers out differently (max_keys_per_call, pieces and slack must agree on every rank)");
+            want = want && all[p].want_put;                 // everybody, or nobody
+        }
+    }
+    sh->put = want;
+    sh->peers.base[me] = (uint64_t)(uintptr_t)sh->block;
+    int rc = UMGAP_OK;
+    if (sh->put && W > 1) {
+        for (uint32_t p = 0; p < W && rc == UMGAP_OK; p++) {
+            if (p == me) continue;
+            if (c->hub || all[p].pid == (uint32_t)getpid()) { sh->peers.base[p] = all[p].block; continue; }   // a thread of this process: its pointer is ours
+            void* ptr = nullptr;
+            const hipError_t e = hipIpcOpenMemHandle(&ptr, all[p].mem, hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) { (void)hipGetLastError(); rc = fail(UMGAP_ERR_DEVICE, std::string("umgap_sharded_create: hipIpcOpenMemHandle (rank ") + std::to_string(p) + "'s exchange block): " + hipGetErrorString(e)); break; }
+            sh->peer_maps.push_back(ptr);
+            sh->peers.base[p] = (uint64_t)(uintptr_t)ptr;
+        }
+        // every rank has mapped every block, or every rank drops back to the copies
+        uint32_t bad = rc ? 1u : 0u;
+        const int rc2 = comm_max_u32(c, &bad);
+        if (rc2) return rc2;
+        if (bad) {
+            for (void* m : sh->peer_maps) (void)hipIpcCloseMemHandle(m);
+            sh->peer_maps.clear();
+            sh->put = false;
+            if (rc) return rc;
+        }
+    }
+    // the tables: where the pack stores owner o's keys, where the probe stores region r's values
+    std::vector<uint64_t> tab(2 * (size_t)W);
+    for (auto& S : sh->set) {
+        const uint64_t my_off_recv = (uint64_t)((char*)S.recv_keys - (char*)sh->block), my_off_ret = (uint64_t)((char*)S.ret_recv - (char*)sh->block);
+        const uint64_t vwords = sh->value_bytes == 4 ? sh->cap : (sh->cap >> 2) * 3;     // words a region's values take
+        for (uint32_t o = 0; o < W; o++) {
+            if (sh->put) {
+                tab[o] = sh->peers.base[o] + my_off_recv + (uint64_t)me * sh->cap * 6;          // region `me` of rank o's receive buffer
+                tab[W + o] = sh->peers.base[o] + my_off_ret + (uint64_t)me * vwords * 4;        // region `me` of rank o's gather buffer
+            } else {
+                tab[o] = (uint64_t)(uintptr_t)S.send_keys + (uint64_t)o * sh->cap * 6;
+                tab[W + o] = o == me ? (uint64_t)(uintptr_t)S.ret_recv + (uint64_t)me * vwords * 4 : (uint64_t)(uintptr_t)S.ret_send + (uint64_t)o * vwords * 4;
+            }
+        }
+        UMGAP_HIP(hipMemcpy(S.key_dst, tab.data(), W * 8, hipMemcpyHostToDevice));
+        UMGAP_HIP(hipMemcpy(S.val_dst, tab.data() + W, W * 8, hipMemcpyHostToDevice));
+    }
+    return UMGAP_OK;
+}
+
+// put mode: nobody frees a block a peer may still write into
+void put_teardown(umgap_sharded* sh) {
+    if (!sh->put || sh->comm->world == 1) return;
+    const bool first = comm_barrier(sh->comm) == UMGAP_OK;     // every rank has drained its streams (the caller synchronised the device)
+    for (void* m : sh->peer_maps) (void)hipIpcCloseMemHandle(m);
+    sh->peer_maps.clear();
+    if (first) (void)comm_barrier(sh->comm);                   // ... and has let go of the others' blocks
 }
 
 }  // namespace
@@ -711,6 +946,7 @@ int umgap_comm_init_local(int world, int device, umgap_comm** out_ranks) {
     H->refs = world;
     H->send.assign(world, nullptr);
     H->vals.assign(world, 0);
+    H->blobs.resize(world);
     H->ready.assign(world, nullptr);
     H->done.assign(world, nullptr);
     for (int r = 0; r < world; r++) {
@@ -892,9 +1128,10 @@ int umgap_sharded_create(umgap_index* shard, umgap_taxonomy* tx, umgap_comm* com
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
     // (the shortest run the fused kernels form is 33 k-mers: one read of 33..64 fragments of one k-mer each; stage_pack checks)
     sh->bases_runs = sh->piece_keys / 32 + 2;
-    const size_t b_keys = pad(cap * W * 6), b_vals = pad(cap * W * 4 + 64), b_bases = pad(sh->bases_runs * W * 4), b_cur = pad(W * 8);
-    const size_t per_set = 2 * b_keys + 2 * b_vals + b_cur;
-    sh->block_bytes = NSETS * per_set + NPERM * b_bases + 256;
+    const size_t b_keys = pad(cap * W * 6), b_vals = pad(cap * W * 4 + 64), b_bases = pad(sh->bases_runs * W * 4), b_cur = pad(W * 8), b_tab = pad(W * 8);
+    const size_t per_set = 2 * b_keys + 2 * b_vals + b_cur + 2 * b_tab;
+    const size_t b_flags = (size_t)FLAG_KINDS * NSETS * 64 * 8;
+    sh->block_bytes = NSETS * per_set + NPERM * b_bases + 256 + b_flags;
     e = hipMalloc(&sh->block, sh->block_bytes);
     if (e != hipSuccess) { delete sh; return fail(UMGAP_ERR_NOMEM, std::string("umgap_sharded_create: hipMalloc of the exchange buffers (") + std::to_string(sh->block_bytes >> 20) + " MiB): " + hipGetErrorString(e)); }
     char* p = (char*)sh->block;
@@ -904,6 +1141,8 @@ int umgap_sharded_create(umgap_index* shard, umgap_taxonomy* tx, umgap_comm* com
         S.ret_send = (uint32_t*)p; p += b_vals;
         S.ret_recv = (uint32_t*)p; p += b_vals;
         S.cursor = (unsigned long long*)p; p += b_cur;
+        S.key_dst = (uint64_t*)p; p += b_tab;
+        S.val_dst = (uint64_t*)p; p += b_tab;
         if (hipEventCreateWithFlags(&S.filled, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&S.packed, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&S.probed, hipEventDisableTiming) != hipSuccess) {
             umgap_sharded_free(sh);
@@ -915,7 +1154,14 @@ int umgap_sharded_create(umgap_index* shard, umgap_taxonomy* tx, umgap_comm* com
         if (hipEventCreateWithFlags(&sh->aggregated[i], hipEventDisableTiming) != hipSuccess) { umgap_sharded_free(sh); return fail(UMGAP_ERR_DEVICE, "umgap_sharded_create: event creation failed"); }
     }
     sh->d_overflow = (uint32_t*)p;
-    e = hipMemset(sh->d_overflow, 0, 4);
+    sh->d_put_timeout = sh->d_overflow + 1;
+    p += 256;
+    sh->flags = (unsigned long long*)p;
+    sh->flags_off = (uint64_t)(p - (char*)sh->block);
+    e = hipMemset(sh->d_overflow, 0, 256 + b_flags);
+    if (e == hipSuccess) e = hipDeviceSynchronize();     // the counters are zero before any peer learns where they are
+    if (e != hipSuccess) { umgap_sharded_free(sh); return fail(UMGAP_ERR_DEVICE, std::string("umgap_sharded_create: ") + hipGetErrorString(e)); }
+    if ((rc = put_setup(sh))) { umgap_sharded_free(sh); return rc; }
     for (hipStream_t* st : {&sh->s_keys, &sh->s_probe, &sh->s_agg})
         if (e == hipSuccess) e = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
     for (int i = 0; i < 3; i++)
@@ -932,6 +1178,7 @@ void umgap_sharded_free(umgap_sharded* sh) {
     if (!sh) return;
     (void)hipSetDevice(sh->device);
     (void)hipDeviceSynchronize();
+    put_teardown(sh);
     for (auto& S : sh->set) {
         if (S.filled) (void)hipEventDestroy(S.filled);
         if (S.packed) (void)hipEventDestroy(S.packed);
@@ -953,6 +1200,7 @@ void umgap_sharded_free(umgap_sharded* sh) {
 uint32_t umgap_sharded_value_bytes(const umgap_sharded* sh) { return sh ? sh->value_bytes : 0; }
 uint64_t umgap_sharded_region_slots(const umgap_sharded* sh) { return sh ? sh->cap : 0; }
 uint32_t umgap_sharded_pieces(const umgap_sharded* sh) { return sh ? sh->pieces : 0; }
+int umgap_sharded_transport(const umgap_sharded* sh) { return sh && sh->put ? 1 : 0; }
 
 int umgap_sharded_lookup9_dev(umgap_sharded* sh, const uint64_t* d_keys45, size_t n, uint32_t miss_value, uint32_t* d_out_taxa, void* stream) {
     int rc = sharded_args_ok(sh, "umgap_sharded_lookup9_dev");
@@ -1062,7 +1310,12 @@ int umgap_sharded_check(umgap_sharded* sh) {
     int rc = sharded_args_ok(sh, "umgap_sharded_check");
     if (rc) return rc;
     UMGAP_HIP(hipDeviceSynchronize());
-    uint32_t ov = 0;
+    uint32_t ov = 0, late = 0;
+    UMGAP_HIP(hipMemcpy(&late, sh->d_put_timeout, 4, hipMemcpyDeviceToHost));
+    if (late) {
+        UMGAP_HIP(hipMemset(sh->d_put_timeout, 0, 4));
+        return fail(UMGAP_ERR_DEVICE, "sharded lookup: a peer's keys or values did not arrive in time (UMGAP_PUT_TIMEOUT_S) since the last check; the answers of those calls are not valid");
+    }
     UMGAP_HIP(hipMemcpy(&ov, sh->d_overflow, 4, hipMemcpyDeviceToHost));
     if (ov) {
         UMGAP_HIP(hipMemset(sh->d_overflow, 0, 4));

@@ -107,6 +107,12 @@ class Sharded:
     def pieces(self):
         return _lib.load().umgap_sharded_pieces(self._h)
 
+    @property
+    def transport(self):
+        """"put": keys and values are stored straight into the peers' buffers (hipIpc mappings, device-side counters);
+        "copy": store and forward through the communicator (RCCL send/recv groups, or copies)."""
+        return "put" if _lib.load().umgap_sharded_transport(self._h) else "copy"
+
     def wire_bytes_per_step_and_peer(self):
         """(out, back): bytes this rank sends to EACH peer per call (keys) and gets back from it (values)."""
         return 6 * self.region_slots * self.pieces, self.value_bytes * self.region_slots * self.pieces
