@@ -279,7 +279,8 @@ def measure_traffic_live(args, kernel):
 
 def run_ipc_children(args, want_first, local_rank, world=2):
     """The N-rank protocol with every rank its OWN PROCESS on the one GPU of the box (RCCL refuses two ranks on a device, so the
-    exchange runs over umgap_comm_init_ipc: peers' send buffers mapped with hipIpc handles, host-synchronised).  Rank r holds shard
+    exchange runs over umgap_comm_init_ipc: the peers' exchange blocks mapped with hipIpc handles, keys and values stored straight into
+    them -- UMGAP_SHARD_PUT=0: host-synchronised copies instead).  Rank r holds shard
     r of `world` and classifies the r-th part of the step's pairs; each checks its answers against the replica's.  The ranks
     time-share the GPU, so the figure says what the protocol costs here -- not what N GPUs would do."""
     import subprocess
@@ -311,7 +312,10 @@ def run_ipc_children(args, want_first, local_rank, world=2):
     if all(st == 0 for st in status):
         per = [json.load(open("%s.rank%d.json" % (base, r))) for r in range(world)]
         ms = max(x["ms_per_step"] for x in per)
-        res = {"ranks": world, "transport": "hipIpc memory handles between %d processes on one GPU (umgap_comm_init_ipc)" % world, "pairs_per_step": sum(x["pairs"] for x in per),
+        how = {"put": "peer-written: the pack stores keys into the owner's receive buffer, the probe stores values into the requester's gather buffer, through "
+                      "hipIpc mappings of the exchange blocks; per-piece counters in device memory, no copies, no host barriers",
+               "copy": "store and forward: host-synchronised copies out of the peers' send buffers (hipIpc mappings)"}[per[0]["transport"]]
+        res = {"ranks": world, "transport": "%d processes on one GPU (umgap_comm_init_ipc), %s" % (world, how), "exchange": per[0]["transport"], "pairs_per_step": sum(x["pairs"] for x in per),
                "ms_per_step": ms, "value": round(sum(x["pairs"] for x in per) / (ms * 1e-3), 1), "unit": "pairs/s", "steps": per[0]["steps"],
                "bit_identical_to_replica": all(x["bit_identical_to_replica"] for x in per), "shard_table_GB_per_rank": per[0]["shard_table_GB"],
                "keys_exchanged_fraction": round(1.0 - 1.0 / world, 3),
@@ -369,7 +373,7 @@ def ipc_child(args):
     el = time.perf_counter() - t0
     sh.check()
     with open("%s.rank%d.json" % (args.ipc_child, r), "w") as f:
-        json.dump({"ms_per_step": round(1e3 * el / steps, 3), "pairs": hi - lo, "steps": steps, "bit_identical_to_replica": same,
+        json.dump({"ms_per_step": round(1e3 * el / steps, 3), "pairs": hi - lo, "steps": steps, "bit_identical_to_replica": same, "transport": sh.transport,
                    "shard_table_GB": round(shard.table_bytes / 1e9, 2)}, f)
     sh.close()
     shard.close()

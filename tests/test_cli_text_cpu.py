@@ -348,3 +348,33 @@ def test_seedextend_and_uniq_on_a_stream_of_many_blocks(tmp_path):
         p = subprocess.run([umgap] + args, input=data, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
         orc, oout, _ = O.run_cli(args, data)
         assert p.returncode == orc == 0 and p.stdout == oout, (args, p.returncode, len(p.stdout), len(oout), p.stderr[-300:])
+
+
+@pytest.mark.parametrize("cmd", [["uniq"], ["seedextend"]])
+def test_failed_write_ends_the_command_with_the_io_error(taxonomy, cmd):
+    """A write that fails ends every command of the reference with the io error and exit 1 (`writer.write_record(..)?`,
+    src/commands/uniq.rs:71-80, seedextend.rs:166-176): a full device, and a reader that hangs up (Rust ignores SIGPIPE: EPIPE, not a
+    signal).  Here the writer thread notes the failed write(), the block loop stops at its next block and main reports it."""
+    rng = np.random.default_rng(3)
+    data = _records(taxonomy["ids"], rng, 4000, unknown=False)
+    with open("/dev/full", "wb") as full:
+        p = subprocess.run([UMGAP] + cmd, input=data, stdout=full, stderr=subprocess.PIPE)
+    assert p.returncode == 1 and p.stderr.strip() == b"Error: No space left on device (os error 28)", (p.returncode, p.stderr)
+    big = data * 40                                   # several blocks at 1 MB: the loop must stop, not format the rest for nobody
+    pr = subprocess.Popen([UMGAP] + cmd, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=dict(os.environ, UMGAP_BLOCK_BYTES=str(1 << 20)))
+    import threading
+    feeder = threading.Thread(target=lambda: (_feed(pr.stdin, big)))
+    feeder.start()
+    assert pr.stdout.read(16).startswith(b">")
+    pr.stdout.close()                                 # the reader hangs up
+    err = pr.stderr.read()
+    feeder.join()
+    assert pr.wait() == 1 and err.strip() == b"Error: Broken pipe (os error 32)", (pr.returncode, err)
+
+
+def _feed(pipe, data):
+    try:
+        pipe.write(data)
+        pipe.close()
+    except (BrokenPipeError, OSError):
+        pass

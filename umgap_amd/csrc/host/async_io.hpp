@@ -18,6 +18,7 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <deque>
 #include <functional>
@@ -149,6 +150,15 @@ class AsyncIo {
         for (auto& o : all) o->drain();
     }
 
+    // errno of the first write() that failed on any writer (0: none): the reference's commands end with `Error: <io error>`, exit 1, on
+    // a failed write (writer.write_record(..)? in every command); here the writer thread notes it, the block loops stop at their next
+    // block (BlockReader::next) and main reports it
+    static int first_write_error() {
+        std::lock_guard<std::mutex> g(registry_mutex());
+        for (auto& o : registry()) if (const int e = o->err.load(std::memory_order_relaxed)) return e;
+        return 0;
+    }
+
   private:
     // 1 MB buffers are recycled: a fresh `new char[1 << 20]` per chunk is an mmap + 256 page faults + an munmap each time (glibc hands
     // blocks of that size straight to the kernel), i.e. every byte a stage reads or writes cost a zeroed page first -- a quarter of the
@@ -254,7 +264,7 @@ class AsyncIo {
         std::deque<Chunk> q;
         size_t queued = 0;
         bool done = false, busy = false, own_fd = false;
-        int err = 0;
+        std::atomic<int> err{0};          // errno of the first failed write(): set by the writer thread, read by everybody
         void pump() {
             for (;;) {
                 Chunk c;
@@ -267,9 +277,9 @@ class AsyncIo {
                     busy = true;
                 }
                 size_t off = 0;
-                while (off < c.n && !err) {
+                while (off < c.n && !err.load(std::memory_order_relaxed)) {
                     ssize_t w = ::write(fd, c.p + off, c.n - off);
-                    if (w < 0) { if (errno == EINTR) continue; err = errno; break; }
+                    if (w < 0) { if (errno == EINTR) continue; err.store(errno, std::memory_order_relaxed); break; }
                     off += (size_t)w;
                 }
                 const size_t n_done = c.n;
@@ -284,6 +294,7 @@ class AsyncIo {
         // the caller's bytes [p, p + n) go out as they lie (no copy); on_done runs on the writer thread when they are out (or dropped
         // after a write error) -- until then the caller must leave them alone
         void write_owned(const char* p, size_t n, std::function<void()> on_done) {
+            if (err.load(std::memory_order_relaxed)) { if (on_done) on_done(); return; }   // the descriptor is dead: nothing more goes out (first_write_error)
             std::unique_lock<std::mutex> lk(m);
             space.wait(lk, [&] { return queued < WRITE_BEHIND; });
             Chunk c;
@@ -297,7 +308,7 @@ class AsyncIo {
         }
         ssize_t write(const char* buf, size_t n) {
             std::unique_lock<std::mutex> lk(m);
-            if (err) { errno = err; return 0; }
+            if (const int e = err.load(std::memory_order_relaxed)) { errno = e; return 0; }
             space.wait(lk, [&] { return queued < WRITE_BEHIND; });
             size_t done_b = 0;
             // small writes join the last chunk while it has room

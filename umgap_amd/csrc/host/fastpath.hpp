@@ -91,6 +91,9 @@ class BlockReader {
     // Returns false when the stream is exhausted.  [data, data+len) holds whole records; the view
     // stays valid until the next call.
     bool next(const char*& data, size_t& len) {
+        // the output is gone (closed pipe, full disk): stop here rather than work through the rest of the input (src/commands/*.rs:
+        // every write_record(..)? ends the command with the io error)
+        if (const int werr = AsyncIo::first_write_error()) throw CliError(std::string(strerror(werr)) + " (os error " + std::to_string(werr) + ")");
         if (map_) {
             if (mpos_ >= mlen_) return false;
             const char* b = mdata_ + mpos_;

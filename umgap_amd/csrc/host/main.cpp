@@ -6,6 +6,7 @@
 //
 // Output order: the reference emits rayon chunks in completion order (src/commands/pept2lca.rs:62-68);
 // this command always emits input order (= the reference under RAYON_NUM_THREADS=1).
+#include <signal.h>
 #include <sys/socket.h>
 #include <sys/un.h>
 #include <unistd.h>
@@ -1995,9 +1996,15 @@ int main(int argc, char** argv) {
             atexit([]() { fflush(stdout); umgap_host::AsyncIo::drain_all(); });
         }
     }
-    const int rc = run_command(std::move(args));
+    signal(SIGPIPE, SIG_IGN);          // a closed pipe is a failed write (EPIPE) and an `Error: Broken pipe (os error 32)`, as in the reference, not a signal
+    int rc = run_command(std::move(args));
     fflush(stdout);
     umgap_host::AsyncIo::drain_all();
+    if (rc == 0) {
+        int werr = umgap_host::AsyncIo::first_write_error();
+        if (!werr && ferror(stdout)) werr = errno ? errno : EIO;
+        if (werr) { fprintf(stderr, "Error: %s (os error %d)\n", strerror(werr), werr); rc = 1; }
+    }
     return rc;
 }
 

@@ -949,11 +949,16 @@ int set_walk_exceptions(umgap_index* ix, const std::vector<std::pair<uint64_t, u
     std::vector<uint64_t> k(ex.size()), v(ex.size());
     for (size_t i = 0; i < ex.size(); i++) {
         if (i && ex[i].first <= ex[i - 1].first) return fail(UMGAP_ERR_FORMAT, "walk index: exception list not sorted");
+        // a listed position is an entry of the walk array (walk_taxon reads E[p]): a truncated or damaged file must not send a probe
+        // past the array
+        if (ex[i].second >= ix->n_walk) return fail(UMGAP_ERR_FORMAT, "walk index: exception list names entry " + std::to_string(ex[i].second) + " of " + std::to_string(ix->n_walk));
         k[i] = ex[i].first;
         v[i] = ex[i].second;
     }
-    UMGAP_HIP(hipMalloc((void**)&ix->d_walk_exc_keys, k.size() * 8));
-    UMGAP_HIP(hipMalloc((void**)&ix->d_walk_exc_pos, v.size() * 8));
+    if (hipMalloc((void**)&ix->d_walk_exc_keys, k.size() * 8) != hipSuccess || hipMalloc((void**)&ix->d_walk_exc_pos, v.size() * 8) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(UMGAP_ERR_NOMEM, "walk index: hipMalloc of the exception list failed");
+    }
     UMGAP_HIP(hipMemcpy(ix->d_walk_exc_keys, k.data(), k.size() * 8, hipMemcpyHostToDevice));
     UMGAP_HIP(hipMemcpy(ix->d_walk_exc_pos, v.data(), v.size() * 8, hipMemcpyHostToDevice));
     ix->n_walk_exc = (uint32_t)k.size();
@@ -1454,7 +1459,7 @@ int umgap_index_open_shard(const char* path, uint32_t device_mask, uint32_t shar
             if (ok) {
                 std::vector<std::pair<uint64_t, uint64_t>> ex(n_exc);
                 for (size_t i = 0; i < n_exc; i++) ex[i] = {k[i], v[i]};
-                if (set_walk_exceptions(ix, ex)) { fclose(f); umgap_index_free(ix); return UMGAP_ERR_FORMAT; }
+                if (const int xrc = set_walk_exceptions(ix, ex)) { fclose(f); umgap_index_free(ix); return xrc; }   // its own code: format, memory or device
             }
         }
     }
@@ -1672,12 +1677,12 @@ int walk_add_chunk(umgap_walk_builder* b, const uint8_t* d_bytes, const uint64_t
     if (hipMalloc((void**)&d_flag, n_local) != hipSuccess) return done(fail(UMGAP_ERR_NOMEM, "umgap_walk_builder_add_dev: hipMalloc failed"));
     // a window beyond max_fragment_len is never visited by the flag pass: it must read as "no entry" (its key then follows as a
     // walk of one), not as whatever the allocation held
-    UMGAP_HIP(hipMemsetAsync(d_flag, 0, n_local, x->stream));
+    if ((e = hipMemsetAsync(d_flag, 0, n_local, x->stream)) != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, std::string("umgap_walk_builder_add_dev: ") + hipGetErrorString(e)));
     hipLaunchKernelGGL(k_walk_flags, dim3(grid_for(iter, 256, 256 * 16)), dim3(256), 0, x->stream, c->view, V, d_bytes, d_offsets, (const uint64_t*)d_wbase, n_fragments,
                        max_fragment_len, d_flag, d_frag_taxa);
     uint64_t n_new = 0, n_keep = 0;
     for (uint32_t gap : {WALK_KEEP_REPEATS, 0u}) {   // short runs of repeats keep their entries while the array has room for them
-        UMGAP_HIP(hipMemsetAsync(d_total + 2, 0, 8, x->stream));
+        if ((e = hipMemsetAsync(d_total + 2, 0, 8, x->stream)) != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, std::string("umgap_walk_builder_add_dev: ") + hipGetErrorString(e)));
         hipLaunchKernelGGL(k_walk_keep_short_repeats, dim3(grid_for(n_fragments)), dim3(256), 0, x->stream, d_flag, (const uint64_t*)d_wbase, n_fragments, gap, d_cnt,
                            (unsigned long long*)(d_total + 2), 1u << b->shift);
         hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, x->stream, d_cnt, n_fragments, d_fbase, d_total + 1);
@@ -1695,7 +1700,7 @@ int walk_add_chunk(umgap_walk_builder* b, const uint8_t* d_bytes, const uint64_t
     if (d_frag_taxa && n_keep) {
         if (hipMalloc((void**)&d_kept, n_keep * 16) != hipSuccess) return done(fail(UMGAP_ERR_NOMEM, "umgap_index_build_walk9_dev: hipMalloc failed"));
         b->kept_lists.emplace_back(d_kept, n_keep);
-        UMGAP_HIP(hipMemsetAsync(&b->d_flags->n_kept_noted, 0, 8, x->stream));
+        if ((e = hipMemsetAsync(&b->d_flags->n_kept_noted, 0, 8, x->stream)) != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, std::string("umgap_walk_builder_add_dev: ") + hipGetErrorString(e)));
     }
     if (n_new)
         hipLaunchKernelGGL(k_walk_emit, dim3(grid_for(n_fragments)), dim3(256), 0, x->stream, d_bytes, d_offsets, (const uint64_t*)d_wbase, (const uint64_t*)d_fbase,
@@ -1804,6 +1809,7 @@ int walk_finish(umgap_walk_builder* b, umgap_index** out, std::vector<std::pair<
     }
     // the exception list (walk_ref.hpp): sorted by key, one entry per key
     x->walk_shift = b->shift;
+    x->n_walk = b->n_walk;            // (set_walk_exceptions checks the listed positions against it)
     if (b->shift) {
         unsigned long long n_exc = 0;
         if (hipMemcpy(&n_exc, b->d_exc_n, 8, hipMemcpyDeviceToHost) != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, "umgap_walk_builder_finish: copy failed"));

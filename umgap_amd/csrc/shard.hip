@@ -359,6 +359,12 @@ int comm_barrier(umgap_comm* c) {
 // the consumer recomputes; nothing per key is stored).  A wave takes one run (at most 1024 keys = 16 rounds of 64) and counts per
 // owner with ballots; the four waves of a workgroup add their counts up in LDS and ONE global atomic per owner reserves the
 // workgroup's range.  Keys with bits above 45 (not a packed 9-mer) are not sent, nor are the rank's own (local_owner).
+// put mode, the end of a kernel whose stores went into a peer's memory: 1 = nothing (the kernel's own end-of-kernel release and the signal
+// kernel behind it order the data before the counter), 2 = a release fence at system scope per wave (L2 write-back), 3 = release + acquire
+__device__ __forceinline__ void put_release(uint32_t put) {
+    if (put == 2) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    else if (put == 3) __threadfence_system();
+}
 constexpr int PACK_ROUNDS = 16;
 __global__ __launch_bounds__(256) void k_shard_pack(const uint64_t* __restrict__ keys, size_t n, uint32_t run_len, uint32_t m, uint32_t nb, uint32_t world,
                                                     double world_over_nb, uint64_t cap, const uint64_t* __restrict__ key_dst, uint32_t* __restrict__ bases,
@@ -430,7 +436,7 @@ __global__ __launch_bounds__(256) void k_shard_pack(const uint64_t* __restrict__
     }
     // peer-written keys: what this wave stored is at the peers before the kernel is through (the signal that follows the kernel on its
     // stream then tells them)
-    if (put) __threadfence_system();
+    put_release(put);
 }
 
 // the unused tail of every region carries "no key"
@@ -439,7 +445,7 @@ __global__ __launch_bounds__(256) void k_shard_pad(const uint64_t* __restrict__ 
     uint16_t* hi = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(key_dst[o]) + cap * 4);
     const unsigned long long filled = cursor[o] < cap ? cursor[o] : cap;
     for (uint64_t i = filled + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) hi[i] = (uint16_t)wire::HI_NOKEY;
-    if (put) __threadfence_system();
+    put_release(put);
 }
 
 // ---- peer-written exchange (put mode): flags instead of copies ------------------------------------------------------------------
@@ -553,7 +559,7 @@ __global__ __launch_bounds__(256) void k_shard_probe(TableView T, const uint8_t*
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     }
-    if (put) __threadfence_system();
+    put_release(put);
 }
 
 // the plain sharded get(): out[i] = value of key i, or miss_value.  A wave takes one run of the piece (shard_wire.hpp) in rounds
@@ -654,6 +660,7 @@ struct umgap_sharded {
     std::vector<void*> peer_maps;        // what hipIpcOpenMemHandle returned (closed in umgap_sharded_free)
     unsigned long long* flags = nullptr; // [FLAG_KINDS][NSETS][64] in this rank's block
     uint64_t flags_off = 0;              // ... and where that is inside the block (the same on every rank)
+    uint32_t put_fence = 1;              // what a kernel that stored into a peer's memory ends with (put_release)
     uint32_t* d_put_timeout = nullptr;
     uint64_t put_timeout_ticks = 0;
     hipEvent_t ev_in = nullptr, ev_probe0 = nullptr, ev_probe1 = nullptr;
@@ -707,8 +714,8 @@ int stage_pack(umgap_sharded* sh, uint64_t t, const uint64_t* d_keys, size_t nk,
     unsigned g = (unsigned)std::min<size_t>((n_runs + 3) / 4, 256 * 8);   // persistent: a grid of short workgroups holds up the other streams' kernels (k_shard_probe)
     if (g < 1) g = 1;
     hipLaunchKernelGGL(k_shard_pack, dim3(g), dim3(256), 0, s, d_keys, nk, run_len, T.m, T.nb, W, (double)W / (double)T.nb, sh->cap, S.key_dst, sh->bases[t % NPERM],
-                       S.cursor, sh->d_overflow, sh->local_bypass ? (uint32_t)sh->comm->rank : wire::NO_SELF, sh->put ? 1u : 0u);
-    hipLaunchKernelGGL(k_shard_pad, dim3(64, W), dim3(256), 0, s, S.key_dst, S.cursor, sh->cap, sh->put ? 1u : 0u);
+                       S.cursor, sh->d_overflow, sh->local_bypass ? (uint32_t)sh->comm->rank : wire::NO_SELF, sh->put ? sh->put_fence : 0u);
+    hipLaunchKernelGGL(k_shard_pad, dim3(64, W), dim3(256), 0, s, S.key_dst, S.cursor, sh->cap, sh->put ? sh->put_fence : 0u);
     if (sh->put && W > 1) hipLaunchKernelGGL(k_put_signal, dim3(1), dim3(64), 0, s, sh->peers, W, (uint32_t)sh->comm->rank, put_flags_off(sh, FLAG_KEYS_READY, t), 0ull, t + 1);
     UMGAP_HIP(hipGetLastError());
     UMGAP_HIP(hipEventRecord(S.filled, s));
@@ -742,8 +749,8 @@ int stage_probe(umgap_sharded* sh, uint64_t t, bool time_probe) {
     }
     if (time_probe) UMGAP_HIP(hipEventRecord(sh->ev_probe0, s));
     const uint8_t* own_keys = sh->put ? S.recv_keys : S.send_keys;       // put mode: the rank's own region is packed into its receive buffer like a peer's
-    if (sh->value_bytes == 3) hipLaunchKernelGGL(k_shard_probe<3>, dim3(gp), dim3(256), 0, s, T, S.recv_keys, own_keys, self, sh->local_bypass ? 1u : 0u, sh->cap, n_slots, S.val_dst, sh->put ? 1u : 0u);
-    else hipLaunchKernelGGL(k_shard_probe<4>, dim3(gp), dim3(256), 0, s, T, S.recv_keys, own_keys, self, sh->local_bypass ? 1u : 0u, sh->cap, n_slots, S.val_dst, sh->put ? 1u : 0u);
+    if (sh->value_bytes == 3) hipLaunchKernelGGL(k_shard_probe<3>, dim3(gp), dim3(256), 0, s, T, S.recv_keys, own_keys, self, sh->local_bypass ? 1u : 0u, sh->cap, n_slots, S.val_dst, sh->put ? sh->put_fence : 0u);
+    else hipLaunchKernelGGL(k_shard_probe<4>, dim3(gp), dim3(256), 0, s, T, S.recv_keys, own_keys, self, sh->local_bypass ? 1u : 0u, sh->cap, n_slots, S.val_dst, sh->put ? sh->put_fence : 0u);
     if (sh->put && W > 1) hipLaunchKernelGGL(k_put_signal, dim3(1), dim3(64), 0, s, sh->peers, W, self, put_flags_off(sh, FLAG_KEYS_FREE, t), put_flags_off(sh, FLAG_VALS_READY, t), t + 1);
     UMGAP_HIP(hipGetLastError());
     UMGAP_HIP(hipEventRecord(S.probed, s));
@@ -824,6 +831,7 @@ int put_setup(umgap_sharded* sh) {
     double timeout_s = 30.0;                                   // how long a stage waits for a peer's counter before it gives up
     if (const char* t = getenv("UMGAP_PUT_TIMEOUT_S")) { const double v = atof(t); if (v > 0) timeout_s = v; }
     sh->put_timeout_ticks = (uint64_t)(timeout_s * 1e8);      // wall_clock64: 100 MHz
+    if (const char* f = getenv("UMGAP_PUT_FENCE")) { const int v = atoi(f); if (v >= 1 && v <= 3) sh->put_fence = (uint32_t)v; }
     std::vector<PutBlob> all(W);
     if (W > 1) {
         PutBlob mine;

@@ -56,7 +56,7 @@ __device__ __forceinline__ uint64_t walk_position(const WalkRef& W, uint32_t q, 
         while (lo < hi) {
             const uint32_t mid = (lo + hi) >> 1;
             const uint64_t k = W.exc_keys[mid];
-            if (k == key) return W.exc_pos[mid];
+            if (k == key) { const uint64_t p = W.exc_pos[mid]; return p < W.n ? p : WALK_NOPOS; }   // (the loader checks the list; a second lock)
             if (k < key) lo = mid + 1; else hi = mid;
         }
     }
