@@ -297,11 +297,14 @@ def test_cleavage_pattern_rewriter_against_python_re(tmp_path):
             ("(?i)([kr])([^p])",) * 2, ("(?P<a>[KR])(?P<b>[^P])",) * 2, ("(?<a>[KR])(?<b>[^P])", "(?P<a>[KR])(?P<b>[^P])"), ("K",) * 2, ("(K)",) * 2,
             (r"\A(M)(.)",) * 2, (r"([KR])([^P])\z", r"([KR])([^P])\Z"), ("(?:K|R)([^P])",) * 2, ("([[:upper:]])(P)", "([A-Z])(P)"), (r"(K)(\x{41})", r"(K)(\x41)"),
             ("(K+?)(A)",) * 2, ("(K{2,3})([^P])",) * 2, ("([FWY])([^P])",) * 2, ("([]K])(A)", r"([\]K])(A)"), (r"(\w)(\*)",) * 2, ("(?m)^(M)(.)",) * 2,
-            ("([^A-J])([L-Z])",) * 2, ("(D)()",) * 2, ("()(D)",) * 2]
-    bad = ["(K)(?=A)", "(K)(?!P)", "(?<=K)(A)", r"(K)\1", "([KR", "(K", r"(\pL)(A)", "(?s)(K)(.)", "(?x)(K) (.)", "(K)([a-z&&[^p]])", "(K)((?i)a)", "(K)(A)\\", "*K"]
+            ("([^A-J])([L-Z])",) * 2, ("(D)()",) * 2, ("()(D)",) * 2,
+            # escapes: the crate's other spellings of a code point, the bell, its escapable punctuation; a dot that must not stop at \r
+            (r"(K)(\u{41})", r"(K)(\x41)"), (r"(K)(\u0041)", r"(K)(\x41)"), (r"(K)(\U00000041)", r"(K)(\x41)"), (r"(\a)(K)", r"(\x07)(K)"), (r"(\*)(\-|\~|\#|\&|A)", r"(\*)(-|~|#|&|A)"),
+            ("(K)(.)\r", "(?s)(K)([^\n])\r")]
+    bad = [r"(K)(\0)", r"(K)(\e)", r"(\q)(A)", r"(K)(\Q)", r"(K)(?i:a)", "(K)([a[bc]])", r"(K)(\u{1F600})", r"(K)(\u00e9)", "(K)(?=A)", "(K)(?!P)", "(?<=K)(A)", r"(K)\1", "([KR", "(K", r"(\pL)(A)", "(?s)(K)(.)", "(?x)(K) (.)", "(K)([a-z&&[^p]])", "(K)((?i)a)", "(K)(A)\\", "*K"]
     rng = np.random.default_rng(23)
     letters = "ACDEFGHIKLMNPQRSTVWY"
-    seqs = ["", "K", "KR", "KP", "AKRPKAAKKRA", "MMKA", "A]AKA*KKKA", "kraKRPkp"]
+    seqs = ["", "K", "KR", "KP", "AKRPKAAKKRA", "MMKA", "A]AKA*KKKA", "kraKRPkp", "AK\x07KA*-K~", "AKA\rKK\rA"]
     seqs += ["".join(rng.choice(list(letters + "KRKRP*"), int(rng.integers(1, 80)))) for _ in range(60)]
     feed, want = [], []
     for rust, py in good:
@@ -322,6 +325,12 @@ def test_cleavage_pattern_rewriter_against_python_re(tmp_path):
             assert g.startswith("ERROR regex parse error:"), (line, g)
         else:
             assert g == w, (line, g, w)
+    # a greedy pattern over a long protein: std::regex recurses once per residue; the cut runs on a stack sized for the sequence
+    long_seq = "A" * 150_000 + "KA" + "C" * 150_000
+    p = subprocess.run([exe], input=("(.*)([KR])\t%s\n([KR])([^P])\t%s\n" % (long_seq[:60_000] + "K", long_seq)).encode(), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    got = p.stdout.decode().split("\n")[:-1]
+    assert got[0] == long_seq[:60_000] + "|K" and got[1] == "A" * 150_000 + "K|A" + "C" * 150_000
 
 
 def test_seedextend_and_uniq_on_a_stream_of_many_blocks(tmp_path):

@@ -17,6 +17,11 @@ KMERS = 84
 
 
 def child(name, world, r, B, n_keys, pieces, steps, out_path):
+    import faulthandler
+    faulthandler.enable()
+    if os.environ.get("IPC_BENCH_GDB"):
+        import ctypes
+        ctypes.CDLL(None).prctl(0x59616d61, ctypes.c_ulong(-1 & 0xFFFFFFFFFFFFFFFF), 0, 0, 0)     # PR_SET_PTRACER, PR_SET_PTRACER_ANY
     import torch
     from umgap_amd import api, synth
     from umgap_amd.dist import Comm, Sharded
@@ -78,10 +83,27 @@ def main():
     tails = []
     for p in procs:
         try:
-            tails.append(p.communicate(timeout=300)[0].decode(errors="replace")[-400:])
+            tails.append(p.communicate(timeout=float(os.environ.get("IPC_BENCH_TIMEOUT", "300")))[0].decode(errors="replace")[-1500:])
         except subprocess.TimeoutExpired:
-            p.kill()
-            tails.append("no answer within 300 s: " + p.communicate()[0].decode(errors="replace")[-400:])
+            import signal
+            where = []
+            for tid in sorted(os.listdir("/proc/%d/task" % p.pid))[:40]:
+                try:
+                    st = open("/proc/%d/task/%s/stat" % (p.pid, tid)).read().split()
+                    where.append("%s %s %s wchan=%s syscall=%s" % (tid, st[1], st[2], open("/proc/%d/task/%s/wchan" % (p.pid, tid)).read().strip(),
+                                                                 open("/proc/%d/task/%s/syscall" % (p.pid, tid)).read().strip()[:60]))
+                except OSError as e:
+                    where.append("%s: %s" % (tid, e))
+            print("rank pid %d threads:\n  " % p.pid + "\n  ".join(w_ for k, w_ in enumerate(where) if k == 0 or "futex_do_wait" not in w_), file=sys.stderr, flush=True)
+            if os.environ.get("IPC_BENCH_GDB") and os.path.exists("/opt/rocm/bin/rocgdb"):
+                g = subprocess.run(["/opt/rocm/bin/rocgdb", "-p", str(p.pid), "-batch", "-ex", "thread 1", "-ex", "bt 40"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+                print("rocgdb:\n" + g.stdout.decode(errors="replace")[-6000:], file=sys.stderr, flush=True)
+            p.send_signal(signal.SIGABRT)           # faulthandler prints where the rank stood
+            try:
+                tails.append("no answer in time: " + p.communicate(timeout=10)[0].decode(errors="replace")[-3000:])
+            except subprocess.TimeoutExpired:
+                p.kill()
+                tails.append("no answer in time, and none to SIGABRT: " + p.communicate()[0].decode(errors="replace")[-1500:])
     if any(p.returncode != 0 for p in procs):
         print(json.dumps({"error": [p.returncode for p in procs], "tails": tails}))
         return 1

@@ -10,23 +10,47 @@
 // Refused because std::regex cannot express them (documented as the difference in DESIGN.md section 8): Unicode classes
 // \p{..}, class set operations ([a-z&&[^aeiou]]), the flags s x U u and flag groups anywhere but at the start.
 #pragma once
+#include <pthread.h>
+
 #include <cctype>
+#include <cstring>
+#include <exception>
 #include <regex>
 #include <stdexcept>
 #include <string>
 
 namespace umgap_host {
 
+struct CleavePatternError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
 struct CleavePattern {
     std::regex re;
     // replace_all(seq, "$1\n$2") run twice: a residue can end one match and start the next
     std::string cut(const std::string& seq) const {
+        // libstdc++'s matcher recurses once per character on a greedy pattern (`(.*)([KR])`): a 30 000-residue protein would run through
+        // the 8 MB stack of a worker thread.  Long sequences are cut on a thread of their own whose stack is sized for them.
+        if (seq.size() <= 4096) return cut_here(seq);
+        struct Job { const CleavePattern* self; const std::string* seq; std::string out; std::exception_ptr err; } job{this, &seq, {}, nullptr};
+        pthread_attr_t attr;
+        pthread_attr_init(&attr);
+        pthread_attr_setstacksize(&attr, (size_t)(64u << 20) + seq.size() * 1024);       // (address space: only the pages used are ever touched)
+        pthread_t th;
+        const int rc = pthread_create(&th, &attr, [](void* p) -> void* {
+            Job* j = static_cast<Job*>(p);
+            try { j->out = j->self->cut_here(*j->seq); } catch (...) { j->err = std::current_exception(); }
+            return nullptr;
+        }, &job);
+        pthread_attr_destroy(&attr);
+        if (rc != 0) throw CleavePatternError("the sequence is too long for the custom cleavage pattern (" + std::to_string(seq.size()) + " residues)");
+        pthread_join(th, nullptr);
+        if (job.err) std::rethrow_exception(job.err);
+        return std::move(job.out);
+    }
+    std::string cut_here(const std::string& seq) const {
         return std::regex_replace(std::regex_replace(seq, re, "$1\n$2"), re, "$1\n$2");
     }
-};
-
-struct CleavePatternError : std::runtime_error {
-    using std::runtime_error::runtime_error;
 };
 
 // the crate's syntax -> ECMAScript source + flags; throws CleavePatternError
@@ -71,8 +95,37 @@ inline std::string rewrite_cleave_pattern(const std::string& src, std::regex::fl
                 i = close;
                 continue;
             }
-            out += '\\'; out += e;
-            continue;
+            // \u{41} \U{41} \u0041 \U00000041: the crate's other spellings of a code point
+            if (e == 'u' || e == 'U') {
+                std::string digits;
+                size_t end = i;
+                if (i + 1 < src.size() && src[i + 1] == '{') {
+                    const size_t close = src.find('}', i + 2);
+                    if (close == std::string::npos) return fail("invalid hexadecimal digit");
+                    digits = src.substr(i + 2, close - i - 2);
+                    end = close;
+                } else {
+                    const size_t nd = e == 'u' ? 4 : 8;
+                    if (i + nd >= src.size()) return fail("incomplete escape sequence, reached end of pattern prematurely");
+                    digits = src.substr(i + 1, nd);
+                    end = i + nd;
+                }
+                unsigned long v = 0;
+                try { size_t used = 0; v = std::stoul(digits, &used, 16); if (used != digits.size() || digits.empty()) throw 0; }
+                catch (...) { return fail("invalid hexadecimal digit"); }
+                if (v > 0x7F) return fail("code points above U+007F are not supported by this build");
+                static const char* hex = "0123456789ABCDEF";
+                out += "\\x"; out += hex[v >> 4]; out += hex[v & 15];
+                i = end;
+                continue;
+            }
+            if (e == '0') return fail("backreferences are not supported");           // (octal is off in the crate: \0 is read as a backreference)
+            if (e == 'a') { out += "\\x07"; continue; }                             // bell; ECMAScript would read a literal `a`
+            // what both grammars read the same way: the Perl classes, word boundaries, control escapes, \xHH, and the crate's escapable
+            // punctuation.  Anything else the crate refuses (`\e`, `\q`, ...) or means something std::regex does not know: refused
+            // rather than misread.
+            if (std::strchr("dDwWsSbBntrfvx", e) || std::strchr("\\.+*?()|[]{}^$#&-~", e)) { out += '\\'; out += e; continue; }
+            return fail(std::string("unrecognized escape sequence \\") + e);
         }
         if (in_class) {
             if (c == '&' && i + 1 < src.size() && src[i + 1] == '&') return fail("class set operations (&&) are not supported by this build");
@@ -109,6 +162,7 @@ inline std::string rewrite_cleave_pattern(const std::string& src, std::regex::fl
             }
             return fail("flag groups are only supported at the start of the pattern by this build");
         }
+        if (c == '.') { out += "[^\\n]"; continue; }     // the crate's dot stops at \n only; ECMAScript's also at \r, U+2028 and U+2029
         out += c;
     }
     if (in_class) return fail("unclosed character class");

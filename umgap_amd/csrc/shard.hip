@@ -30,6 +30,7 @@
 #include <fcntl.h>
 #include <rccl/rccl.h>
 #include <sched.h>
+#include <signal.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -142,6 +143,7 @@ struct LocalHub {
 // the control block of an IPC communicator, in POSIX shared memory (rank 0 creates and initialises it)
 struct IpcCtl {
     std::atomic<uint32_t> ready;                  // 1: the block is initialised
+    std::atomic<uint32_t> creator_pid;            // rank 0's process: a block whose creator is gone (killed before everybody was attached) is stale
     std::atomic<uint32_t> arrived, generation;    // the barrier
     std::atomic<uint32_t> failed;                 // a rank gave up: every barrier from here on fails
     struct Slot {
@@ -187,6 +189,12 @@ struct IpcHub {
         key.append((const char*)&S.alloc_base, 8).append((const char*)&S.alloc_bytes, 8);
         auto it = opened[p].find(key);
         if (it == opened[p].end()) {
+            // the peer publishes another allocation: what was mapped of its earlier ones (freed by now, as a rule: the self-test's buffers)
+            // goes once a few have piled up, so that a long-lived communicator does not keep every buffer it ever saw pinned
+            if (opened[p].size() >= 4) {
+                for (auto& kv : opened[p]) (void)hipIpcCloseMemHandle(kv.second);
+                opened[p].clear();
+            }
             void* ptr = nullptr;
             hipError_t e = hipIpcOpenMemHandle(&ptr, S.mem, hipIpcMemLazyEnablePeerAccess);
             if (e != hipSuccess) return fail(UMGAP_ERR_DEVICE, std::string("hipIpcOpenMemHandle (rank ") + std::to_string(p) + "'s buffer): " + hipGetErrorString(e));
@@ -823,8 +831,10 @@ struct PutBlob {
 };
 static_assert(sizeof(PutBlob) <= BLOB_BYTES, "the contribution of a rank fits comm_allgather");
 
+#define PUT_TRACE(...) do { if (getenv("UMGAP_SHARD_DEBUG")) { fprintf(stderr, "[rank %d] ", sh->comm->rank); fprintf(stderr, __VA_ARGS__); fputc('\n', stderr); fflush(stderr); } } while (0)
 int put_setup(umgap_sharded* sh) {
     umgap_comm* c = sh->comm;
+    PUT_TRACE("put_setup: block %zu MB", sh->block_bytes >> 20);
     const uint32_t W = (uint32_t)c->world, me = (uint32_t)c->rank;
     const char* env = getenv("UMGAP_SHARD_PUT");
     bool want = c->ipc ? !(env && env[0] == '0') : (env && env[0] == '1');
@@ -845,7 +855,9 @@ int put_setup(umgap_sharded* sh) {
         mine.want_put = want ? 1u : 0u;
         mine.pid = (uint32_t)getpid();
         if (want && !c->hub && hipIpcGetMemHandle(&mine.mem, sh->block) != hipSuccess) { (void)hipGetLastError(); mine.want_put = 0; }
+        PUT_TRACE("allgather ...");
         int rc = comm_allgather(c, &mine, all.data(), sizeof(PutBlob));
+        PUT_TRACE("allgather done rc %d", rc);
         if (rc) return rc;
         for (uint32_t p = 0; p < W; p++) {
             if (all[p].block_bytes != sh->block_bytes || all[p].cap != sh->cap || all[p].flags_off != sh->flags_off || all[p].value_bytes != sh->value_bytes)
@@ -857,18 +869,28 @@ int put_setup(umgap_sharded* sh) {
     sh->peers.base[me] = (uint64_t)(uintptr_t)sh->block;
     int rc = UMGAP_OK;
     if (sh->put && W > 1) {
-        for (uint32_t p = 0; p < W && rc == UMGAP_OK; p++) {
+        // one rank at a time: two processes importing each other's allocation at the same moment were seen to sit in hipIpcOpenMemHandle
+        // for good (11 GB blocks, both directions at once)
+        for (uint32_t turn = 0; turn < W; turn++) {
+          if (turn == me)
+            for (uint32_t p = 0; p < W && rc == UMGAP_OK; p++) {
             if (p == me) continue;
             if (c->hub || all[p].pid == (uint32_t)getpid()) { sh->peers.base[p] = all[p].block; continue; }   // a thread of this process: its pointer is ours
             void* ptr = nullptr;
+            PUT_TRACE("open rank %u's block ...", p);
             const hipError_t e = hipIpcOpenMemHandle(&ptr, all[p].mem, hipIpcMemLazyEnablePeerAccess);
+            PUT_TRACE("open -> %d %p", (int)e, ptr);
             if (e != hipSuccess) { (void)hipGetLastError(); rc = fail(UMGAP_ERR_DEVICE, std::string("umgap_sharded_create: hipIpcOpenMemHandle (rank ") + std::to_string(p) + "'s exchange block): " + hipGetErrorString(e)); break; }
             sh->peer_maps.push_back(ptr);
             sh->peers.base[p] = (uint64_t)(uintptr_t)ptr;
+            }
+          const int brc = comm_barrier(c);
+          if (brc) return brc;
         }
         // every rank has mapped every block, or every rank drops back to the copies
         uint32_t bad = rc ? 1u : 0u;
         const int rc2 = comm_max_u32(c, &bad);
+        PUT_TRACE("agreed: bad %u", bad);
         if (rc2) return rc2;
         if (bad) {
             for (void* m : sh->peer_maps) (void)hipIpcCloseMemHandle(m);
@@ -894,6 +916,7 @@ int put_setup(umgap_sharded* sh) {
         UMGAP_HIP(hipMemcpy(S.key_dst, tab.data(), W * 8, hipMemcpyHostToDevice));
         UMGAP_HIP(hipMemcpy(S.val_dst, tab.data() + W, W * 8, hipMemcpyHostToDevice));
     }
+    PUT_TRACE("tables written, put %d", (int)sh->put);
     return UMGAP_OK;
 }
 
@@ -985,15 +1008,33 @@ int umgap_comm_init_ipc(const char* name, int world, int rank, int device, umgap
     const auto t0 = std::chrono::steady_clock::now();
     auto waited = [&]() { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
     int fd = -1;
+    // a block whose creator is dead was left behind by a rank 0 that was killed before everybody had attached (the name is unlinked at
+    // that point): nobody may rendezvous on it
+    auto stale = [&](int f) {
+        struct stat st;
+        if (fstat(f, &st) != 0 || (size_t)st.st_size < sizeof(IpcCtl)) return false;      // still being made
+        void* m = mmap(nullptr, sizeof(IpcCtl), PROT_READ, MAP_SHARED, f, 0);
+        if (m == MAP_FAILED) return false;
+        const uint32_t pid = static_cast<IpcCtl*>(m)->creator_pid.load(std::memory_order_acquire), ready = static_cast<IpcCtl*>(m)->ready.load(std::memory_order_acquire);
+        munmap(m, sizeof(IpcCtl));
+        return ready && pid && kill((pid_t)pid, 0) != 0 && errno == ESRCH;
+    };
     if (rank == 0) {
         fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (fd < 0 && errno == EEXIST) {
+            const int old = shm_open(name, O_RDWR, 0600);
+            const bool dead = old >= 0 && stale(old);
+            if (old >= 0) close(old);
+            if (dead) { shm_unlink(name); fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600); }
+            else errno = EEXIST;
+        }
         if (fd < 0) return fail(UMGAP_ERR_IO, std::string("umgap_comm_init_ipc: shm_open(") + name + "): " + strerror(errno));
         if (ftruncate(fd, sizeof(IpcCtl)) != 0) { const int e = errno; close(fd); shm_unlink(name); return fail(UMGAP_ERR_IO, std::string("umgap_comm_init_ipc: ftruncate: ") + strerror(e)); }
     } else {
         for (;;) {     // until rank 0 has created it at its full size
             fd = shm_open(name, O_RDWR, 0600);
             struct stat st;
-            if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(IpcCtl)) break;
+            if (fd >= 0 && fstat(fd, &st) == 0 && (size_t)st.st_size >= sizeof(IpcCtl) && !stale(fd)) break;
             if (fd >= 0) close(fd);
             if (waited() > timeout_s) return fail(UMGAP_ERR_IO, std::string("umgap_comm_init_ipc: rank 0 did not create ") + name + " (UMGAP_IPC_TIMEOUT_S)");
             usleep(1000);
@@ -1003,7 +1044,7 @@ int umgap_comm_init_ipc(const char* name, int world, int rank, int device, umgap
     close(fd);
     if (mem == MAP_FAILED) { if (rank == 0) shm_unlink(name); return fail(UMGAP_ERR_IO, std::string("umgap_comm_init_ipc: mmap: ") + strerror(errno)); }
     IpcCtl* ctl = static_cast<IpcCtl*>(mem);       // (a fresh shm object is zero-filled: counters 0, nobody failed)
-    if (rank == 0) ctl->ready.store(1, std::memory_order_release);
+    if (rank == 0) { ctl->creator_pid.store((uint32_t)getpid(), std::memory_order_release); ctl->ready.store(1, std::memory_order_release); }
     else
         while (!ctl->ready.load(std::memory_order_acquire)) {
             if (waited() > timeout_s) { munmap(mem, sizeof(IpcCtl)); return fail(UMGAP_ERR_IO, "umgap_comm_init_ipc: rank 0 did not initialise the control block"); }
@@ -1140,6 +1181,12 @@ int umgap_sharded_create(umgap_index* shard, umgap_taxonomy* tx, umgap_comm* com
     const size_t per_set = 2 * b_keys + 2 * b_vals + b_cur + 2 * b_tab;
     const size_t b_flags = (size_t)FLAG_KINDS * NSETS * 64 * 8;
     sh->block_bytes = NSETS * per_set + NPERM * b_bases + 256 + b_flags;
+    // The peers map this block (put mode; the IPC communicator's copies).  hipIpcOpenMemHandle of an allocation whose size has bit 31 set
+    // never comes back with the HIP / ROCr that PyTorch 2.10+rocm7.0 bundles (dmabuf IPC: the importer spins in recvmsg inside
+    // rocr::core::Runtime::IPCClientImport; /opt/rocm 7.2's copies open the same sizes at once -- tools/ipc_open_probe.py,
+    // tools/native/ipc_open_probe.hip).  So: whole 2 MB pages, and a size whose low 32 bits stay below 2^31.
+    sh->block_bytes = (sh->block_bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    if (sh->block_bytes & 0x80000000ull) sh->block_bytes = (sh->block_bytes + 0xFFFFFFFFull) & ~0xFFFFFFFFull;
     e = hipMalloc(&sh->block, sh->block_bytes);
     if (e != hipSuccess) { delete sh; return fail(UMGAP_ERR_NOMEM, std::string("umgap_sharded_create: hipMalloc of the exchange buffers (") + std::to_string(sh->block_bytes >> 20) + " MiB): " + hipGetErrorString(e)); }
     char* p = (char*)sh->block;
