@@ -447,13 +447,15 @@ __global__ __launch_bounds__(256) void k_shard_pack(const uint64_t* __restrict__
     put_release(put);
 }
 
-// the unused tail of every region carries "no key"
-__global__ __launch_bounds__(256) void k_shard_pad(const uint64_t* __restrict__ key_dst, const unsigned long long* __restrict__ cursor, uint64_t cap, uint32_t put) {
-    const uint32_t o = blockIdx.y;
-    uint16_t* hi = reinterpret_cast<uint16_t*>(reinterpret_cast<uint8_t*>(key_dst[o]) + cap * 4);
+// A region is followed by a trailer: how many of its slots hold keys (the probe answers nothing beyond; the first version padded the
+// unused tail of every region with "no key" marks, a kernel of its own per piece).  One lane per owner.
+constexpr uint64_t REGION_TRAILER = 64;
+__host__ __device__ inline uint64_t region_bytes(uint64_t cap) { return cap * 6 + REGION_TRAILER; }
+__global__ __launch_bounds__(64) void k_shard_trailer(const uint64_t* __restrict__ key_dst, const unsigned long long* __restrict__ cursor, uint64_t cap, uint32_t world) {
+    const uint32_t o = threadIdx.x;
+    if (o >= world) return;
     const unsigned long long filled = cursor[o] < cap ? cursor[o] : cap;
-    for (uint64_t i = filled + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) hi[i] = (uint16_t)wire::HI_NOKEY;
-    put_release(put);
+    *reinterpret_cast<unsigned long long*>(reinterpret_cast<uint8_t*>(key_dst[o]) + cap * 6) = filled;
 }
 
 // ---- peer-written exchange (put mode): flags instead of copies ------------------------------------------------------------------
@@ -481,6 +483,18 @@ __global__ __launch_bounds__(64) void k_put_signal(PutPeers P, uint32_t world, u
         unsigned long long* b = reinterpret_cast<unsigned long long*>(P.base[p] + off_b) + self;
         __hip_atomic_store(b, (unsigned long long)value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+}
+
+// the same behind a pack: first the trailer of every region (k_shard_trailer), the owner's copy of it through the mapping
+__global__ __launch_bounds__(64) void k_put_keys_ready(PutPeers P, const uint64_t* __restrict__ key_dst, const unsigned long long* __restrict__ cursor, uint64_t cap,
+                                                       uint32_t world, uint32_t self, uint64_t off, uint64_t value) {
+    const uint32_t p = threadIdx.x;
+    if (p >= world) return;
+    const unsigned long long filled = cursor[p] < cap ? cursor[p] : cap;
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(reinterpret_cast<uint8_t*>(key_dst[p]) + cap * 6), filled, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (p == self) return;
+    __threadfence_system();
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(P.base[p] + off) + self, (unsigned long long)value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 __global__ __launch_bounds__(64) void k_put_wait(const unsigned long long* __restrict__ flags_a, uint64_t want_a, const unsigned long long* __restrict__ flags_b,
@@ -517,7 +531,11 @@ __global__ __launch_bounds__(256) void k_shard_probe(TableView T, const uint8_t*
     for (uint64_t s0 = wave * 128; s0 < n_slots; s0 += nwaves * 128) {
     const uint64_t region = s0 / cap, pos0 = s0 - region * cap;
     if (skip_self && region == self) continue;     // the rank's own keys were not packed (they are probed by the consuming kernel)
-    const uint8_t* rb = (region == self ? own_send : recv) + region * cap * 6;
+    const uint8_t* rb = (region == self ? own_send : recv) + region * region_bytes(cap);
+    const uint64_t filled = *reinterpret_cast<const unsigned long long*>(rb + cap * 6);     // the region's trailer (wave-uniform)
+    if (pos0 >= filled) {        // nothing but unused slots: their values are never read (no run has a base up here)
+        continue;
+    }
     const uint32_t* lo = reinterpret_cast<const uint32_t*>(rb) + pos0;
     const uint16_t* hi = reinterpret_cast<const uint16_t*>(rb + cap * 4) + pos0;
     ProbeBatch B[2];
@@ -536,7 +554,7 @@ __global__ __launch_bounds__(256) void k_shard_probe(TableView T, const uint8_t*
         const uint32_t a = (uint32_t)(h >> R_BITS);
         const uint32_t tag = (uint32_t)h & R_MASK;
         const uint32_t bkt = a * T.m + (uint32_t)(((uint64_t)tag * T.m) >> R_BITS);
-        const uint32_t valid = (kh[b] < (1u << 13) && bkt >= T.home_lo && bkt < T.home_hi) ? 1u : 0u;   // no key in the slot, or a key this shard does not own: a miss
+        const uint32_t valid = (pos0 + 64 * b + lane < filled && kh[b] < (1u << 13) && bkt >= T.home_lo && bkt < T.home_hi) ? 1u : 0u;   // no key in the slot, or a key this shard does not own: a miss
         probe_issue(T, valid ? bkt - T.home_lo : 0u, tag | (valid << 31), lane, B[b]);
     }
     __builtin_amdgcn_sched_barrier(0);   // all eight sector loads are out before the first is evaluated (the scheduler otherwise starts on batch 0 with half of batch 1 unissued)
@@ -723,8 +741,8 @@ int stage_pack(umgap_sharded* sh, uint64_t t, const uint64_t* d_keys, size_t nk,
     if (g < 1) g = 1;
     hipLaunchKernelGGL(k_shard_pack, dim3(g), dim3(256), 0, s, d_keys, nk, run_len, T.m, T.nb, W, (double)W / (double)T.nb, sh->cap, S.key_dst, sh->bases[t % NPERM],
                        S.cursor, sh->d_overflow, sh->local_bypass ? (uint32_t)sh->comm->rank : wire::NO_SELF, sh->put ? sh->put_fence : 0u);
-    hipLaunchKernelGGL(k_shard_pad, dim3(64, W), dim3(256), 0, s, S.key_dst, S.cursor, sh->cap, sh->put ? sh->put_fence : 0u);
-    if (sh->put && W > 1) hipLaunchKernelGGL(k_put_signal, dim3(1), dim3(64), 0, s, sh->peers, W, (uint32_t)sh->comm->rank, put_flags_off(sh, FLAG_KEYS_READY, t), 0ull, t + 1);
+    if (sh->put && W > 1) hipLaunchKernelGGL(k_put_keys_ready, dim3(1), dim3(64), 0, s, sh->peers, S.key_dst, S.cursor, sh->cap, W, (uint32_t)sh->comm->rank, put_flags_off(sh, FLAG_KEYS_READY, t), t + 1);
+    else hipLaunchKernelGGL(k_shard_trailer, dim3(1), dim3(64), 0, s, S.key_dst, S.cursor, sh->cap, W);
     UMGAP_HIP(hipGetLastError());
     UMGAP_HIP(hipEventRecord(S.filled, s));
     return UMGAP_OK;
@@ -734,7 +752,7 @@ int stage_keys(umgap_sharded* sh, uint64_t t) {
     UMGAP_HIP(hipStreamWaitEvent(sh->s_keys, S.filled, 0));
     if (t >= NSETS) UMGAP_HIP(hipStreamWaitEvent(sh->s_keys, S.probed, 0));   // recv_keys was read by the probe of piece t - NSETS
     if (!sh->put) {                          // (put mode: the pack's stores were the exchange; the probe waits for the peers' counters)
-        int rc = comm_alltoall(sh->comm, S.send_keys, S.recv_keys, (size_t)sh->cap * 6, sh->s_keys);
+        int rc = comm_alltoall(sh->comm, S.send_keys, S.recv_keys, (size_t)region_bytes(sh->cap), sh->s_keys);
         if (rc) return rc;
     }
     UMGAP_HIP(hipEventRecord(S.packed, sh->s_keys));
@@ -906,10 +924,10 @@ int put_setup(umgap_sharded* sh) {
         const uint64_t vwords = sh->value_bytes == 4 ? sh->cap : (sh->cap >> 2) * 3;     // words a region's values take
         for (uint32_t o = 0; o < W; o++) {
             if (sh->put) {
-                tab[o] = sh->peers.base[o] + my_off_recv + (uint64_t)me * sh->cap * 6;          // region `me` of rank o's receive buffer
+                tab[o] = sh->peers.base[o] + my_off_recv + (uint64_t)me * region_bytes(sh->cap);          // region `me` of rank o's receive buffer
                 tab[W + o] = sh->peers.base[o] + my_off_ret + (uint64_t)me * vwords * 4;        // region `me` of rank o's gather buffer
             } else {
-                tab[o] = (uint64_t)(uintptr_t)S.send_keys + (uint64_t)o * sh->cap * 6;
+                tab[o] = (uint64_t)(uintptr_t)S.send_keys + (uint64_t)o * region_bytes(sh->cap);
                 tab[W + o] = o == me ? (uint64_t)(uintptr_t)S.ret_recv + (uint64_t)me * vwords * 4 : (uint64_t)(uintptr_t)S.ret_send + (uint64_t)o * vwords * 4;
             }
         }
@@ -1177,7 +1195,7 @@ int umgap_sharded_create(umgap_index* shard, umgap_taxonomy* tx, umgap_comm* com
     auto pad = [](size_t b) { return (b + 255) & ~(size_t)255; };
     // (the shortest run the fused kernels form is 33 k-mers: one read of 33..64 fragments of one k-mer each; stage_pack checks)
     sh->bases_runs = sh->piece_keys / 32 + 2;
-    const size_t b_keys = pad(cap * W * 6), b_vals = pad(cap * W * 4 + 64), b_bases = pad(sh->bases_runs * W * 4), b_cur = pad(W * 8), b_tab = pad(W * 8);
+    const size_t b_keys = pad(region_bytes(cap) * W), b_vals = pad(cap * W * 4 + 64), b_bases = pad(sh->bases_runs * W * 4), b_cur = pad(W * 8), b_tab = pad(W * 8);
     const size_t per_set = 2 * b_keys + 2 * b_vals + b_cur + 2 * b_tab;
     const size_t b_flags = (size_t)FLAG_KINDS * NSETS * 64 * 8;
     sh->block_bytes = NSETS * per_set + NPERM * b_bases + 256 + b_flags;
@@ -1217,8 +1235,22 @@ int umgap_sharded_create(umgap_index* shard, umgap_taxonomy* tx, umgap_comm* com
     if (e == hipSuccess) e = hipDeviceSynchronize();     // the counters are zero before any peer learns where they are
     if (e != hipSuccess) { umgap_sharded_free(sh); return fail(UMGAP_ERR_DEVICE, std::string("umgap_sharded_create: ") + hipGetErrorString(e)); }
     if ((rc = put_setup(sh))) { umgap_sharded_free(sh); return rc; }
-    for (hipStream_t* st : {&sh->s_keys, &sh->s_probe, &sh->s_agg})
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    {
+        // One hardware queue per stage.  Streams of one priority share a small pool of hardware queues (four by default, the null stream
+        // and the caller's among them): the kernel trace of round 5 showed the pack and the probe stream on ONE queue -- they never
+        // overlapped, and in put mode a pack that waits for a peer's counter held up the probes behind it.  Streams of different
+        // priorities come from different pools, so each stage gets a queue of its own: probe high (the stage that saturates the
+        // request path), pack normal, aggregate low.  UMGAP_SHARD_STREAM_PRIO="k,p,a" overrides (0 0 0: the shared pool).
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);        // lo = numerically largest = lowest priority
+        int prio[3] = {0, hi, lo};
+        if (const char* pe = getenv("UMGAP_SHARD_STREAM_PRIO")) { int a, b, c; if (sscanf(pe, "%d,%d,%d", &a, &b, &c) == 3) { prio[0] = a; prio[1] = b; prio[2] = c; } }
+        int k = 0;
+        for (hipStream_t* st : {&sh->s_keys, &sh->s_probe, &sh->s_agg}) {
+            const int pr = std::max(hi, std::min(lo, prio[k++]));
+            if (e == hipSuccess) e = hipStreamCreateWithPriority(st, hipStreamNonBlocking, pr);
+        }
+    }
     for (int i = 0; i < 3; i++)
         if (e == hipSuccess) e = hipEventCreateWithFlags(&sh->ev_done[i], hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&sh->ev_in, hipEventDisableTiming);
