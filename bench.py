@@ -60,6 +60,8 @@ def parse():
     ap.add_argument("--unfused", action="store_true", help="run lookup and aggregate as separate kernels (hits through HBM)")
     ap.add_argument("--no-bind", action="store_true", help="keep taxon ids in the table (the fused kernel then gathers {pre,last} by id)")
     ap.add_argument("--rehearse-cpu", action="store_true", help="CPU/gloo rehearsal of the multi-rank plumbing (no GPU, no kernels)")
+    ap.add_argument("--rehearse-ipc", action="store_true", help="the whole --gpus N control flow on ONE GPU: N processes share device 0, gloo stands in for "
+                                                               "RCCL's process group and the hipIpc communicator (peer-written keys and values) for RCCL's send/recv")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds before self-launched ranks are killed")
     ap.add_argument("--sharded-child", default=None, help=argparse.SUPPRESS)   # internal: run the sharded section in this (child) process
     ap.add_argument("--ipc-child", default=None, help=argparse.SUPPRESS)       # internal: one rank of the two-process leg (file base)
@@ -193,6 +195,26 @@ class stdout_to_stderr:
         os.close(self.saved)
 
 
+def rehearsing(args):
+    return bool(getattr(args, "rehearse_ipc", False))
+
+
+def rank_device(args, local_rank):
+    """The GPU a rank runs on: its own (LOCAL_RANK), or -- rehearsal -- the one GPU every rank shares."""
+    return 0 if rehearsing(args) else local_rank
+
+
+def init_group(args, dist, rank, world, device):
+    """RCCL (backend "nccl") between the GPUs of a node; gloo when the ranks rehearse on one GPU (RCCL refuses two ranks on a device).
+    Returns the device the bench's own all-reduces use."""
+    import torch
+    if rehearsing(args):
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        return torch.device("cpu")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    return device
+
+
 def run_sharded_child(args, rank, world, want_first):
     """The sharded section in a CHILD process per rank (own process group on another port, own RCCL communicator): a crash, a GPU
     fault or a stall in the exchange -- the one code path no one-GPU box can exercise beyond a single rank -- then costs the
@@ -211,7 +233,7 @@ def run_sharded_child(args, rank, world, want_first):
     env.pop("TORCHELASTIC_USE_AGENT_STORE", None)       # the children rendezvous among themselves, not through the launcher's store
     cmd = [sys.executable, os.path.abspath(__file__), "--sharded-child", base, "--gpus", str(args.gpus), "--steps", str(args.steps), "--warmup", str(args.warmup),
            "--pairs-per-step", str(args.pairs_per_step), "--batches", str(args.batches), "--n-keys", str(args.n_keys), "--n-tax", str(args.n_tax),
-           "--load-factor", str(args.load_factor), "--pieces", str(args.pieces)]
+           "--load-factor", str(args.load_factor), "--pieces", str(args.pieces)] + (["--rehearse-ipc"] if rehearsing(args) else [])
     tail = ""
     try:
         p = subprocess.run(cmd, env=env, timeout=420, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
@@ -388,11 +410,11 @@ def sharded_child(args):
     from umgap_amd import synth
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    local_rank = rank_device(args, int(os.environ.get("LOCAL_RANK", 0)))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    init_group(args, dist, rank, world, device)
     w = synth.SyntheticWorkload(n_tax=args.n_tax, n_keys=args.n_keys, id_space=int(args.n_tax * 1.4), load_factor=args.load_factor, device=local_rank,
                                 build_index=False)
     B = args.pairs_per_step
@@ -425,11 +447,15 @@ def sharded_section(args, w, keys, rank, world, device, B, d_taxon, d_status, wa
         w.index.close()
         w.index = None
     torch.cuda.empty_cache()
-    seen = torch.ones(1, dtype=torch.int64, device=device)
+    rdev = torch.device("cpu") if rehearsing(args) else device      # where the bench's own all-reduces run (gloo: host tensors)
+    seen = torch.ones(1, dtype=torch.int64, device=rdev)
     dist.all_reduce(seen)       # RCCL: every rank of the sharded group is really there
     shard = Index.synthetic(args.n_keys, w.d_taxon_of_row, synth.MUL_A, synth.ADD_B, args.load_factor, rank, world)
-    comm = Comm.from_torch_distributed(device.index or 0)
-    comm.selftest(1 << 20)      # RCCL send/recv group to every rank (itself included), contents checked
+    if rehearsing(args):
+        comm = Comm.ipc("/umgap-rehearse-%s" % os.environ.get("MASTER_PORT", "0"), world, rank, device.index or 0)
+    else:
+        comm = Comm.from_torch_distributed(device.index or 0)
+    comm.selftest(1 << 20)      # the transport's own send / receive to every rank (itself included), contents checked
     per_piece = -(-B // args.pieces)
     steps = max(2, min(5, args.steps))
 
@@ -450,13 +476,14 @@ def sharded_section(args, w, keys, rank, world, device, B, d_taxon, d_status, wa
         for i in range(steps):
             one(i + 1)
         torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=rdev)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         sh.check()
-        ok = torch.tensor([int(same)], device=device)
+        ok = torch.tensor([int(same)], device=rdev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         r = {"ms_per_step": round(1e3 * float(el.item()) / steps, 3), "value": round(world * steps * B / float(el.item()), 1), "bit_identical_to_replica": bool(ok.item()),
-             "probe_kernel_ms_first_piece": round(sh.probe_ms(), 3), "pieces": sh.pieces, "value_bytes": sh.value_bytes, "wire": sh.wire_bytes_per_step_and_peer()}
+             "probe_kernel_ms_first_piece": round(sh.probe_ms(), 3), "pieces": sh.pieces, "value_bytes": sh.value_bytes, "wire": sh.wire_bytes_per_step_and_peer(),
+             "exchange_mode": sh.transport}
         sh.close()
         return r
 
@@ -464,9 +491,12 @@ def sharded_section(args, w, keys, rank, world, device, B, d_taxon, d_status, wa
     out_b, back_b = shipped["wire"]
     res = {"value": shipped["value"], "unit": "pairs/s", "steps": steps, "ms_per_step": shipped["ms_per_step"], "shard_table_GB": round(shard.table_bytes / 1e9, 2),
            "probe_kernel_ms_first_piece": shipped["probe_kernel_ms_first_piece"], "pieces": shipped["pieces"], "value_bytes": shipped["value_bytes"],
-           "bit_identical_to_replica": shipped["bit_identical_to_replica"], "ranks_seen": int(seen.item()), "transport": "RCCL (process group of %d)" % world,
-           "exchange": "RCCL send/recv groups inside libumgap_hip.so: 6 B per k-mer out, %d B per hit back; per step and peer %.1f MB out + %.1f MB back "
-                       "(%d k-mers per rank and step, %d pieces over 3 streams)" % (shipped["value_bytes"], out_b / 1e6, back_b / 1e6, B * KMERS, shipped["pieces"])}
+           "bit_identical_to_replica": shipped["bit_identical_to_replica"], "ranks_seen": int(seen.item()),
+           "transport": ("REHEARSAL on one GPU: %d processes share the device, gloo process group, hipIpc communicator (exchange: %s)" % (world, shipped["exchange_mode"])) if rehearsing(args)
+                        else "RCCL (process group of %d)" % world,
+           "exchange": "%s inside libumgap_hip.so: 6 B per k-mer out, %d B per hit back; per step and peer %.1f MB out + %.1f MB back "
+                       "(%d k-mers per rank and step, %d pieces over 3 streams)" % ("keys and values stored straight into the peers' mapped buffers" if shipped["exchange_mode"] == "put" else "RCCL send/recv groups",
+                                                                                   shipped["value_bytes"], out_b / 1e6, back_b / 1e6, B * KMERS, shipped["pieces"])}
     if world == 1:
         every = leg(True)
         res["all_keys_exchanged_ms"] = every["ms_per_step"]
@@ -487,7 +517,7 @@ def main():
     if "RANK" not in os.environ and args.gpus > 1:
         # self-launch: one fresh process per rank, started before this process has touched the GPU
         from umgap_amd.dist import spawn_ranks
-        rc = spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, timeout=args.launch_timeout)
+        rc = spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus, timeout=args.launch_timeout)      # (--rehearse-ipc travels in argv)
         if rc:
             sys.stderr.write("bench.py: a rank failed or stalled (exit status %d)\n" % rc)
         sys.exit(rc)
@@ -507,16 +537,18 @@ def main():
     if world != args.gpus and rank == 0:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE is %d; running %d ranks\n" % (args.gpus, world, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    local_rank = rank_device(args, local_rank)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     multi = world > 1 or args.force_dist
     ranks_seen = 1
+    rdev = device
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
         with stdout_to_stderr():
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-            seen = torch.ones(1, dtype=torch.int64, device=device)
+            rdev = init_group(args, dist, rank, world, device)
+            seen = torch.ones(1, dtype=torch.int64, device=rdev)
             dist.all_reduce(seen)                       # RCCL: every rank is really there
             ranks_seen = int(seen.item())
     mode = args.mode
@@ -585,7 +617,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if multi:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -616,7 +648,8 @@ def main():
                                    n_batches, B, " + seedextend -g1 -s3" if args.seedextend else "", " (one fused kernel)" if fused else ""),
                    "pairs_per_step_per_gpu": B, "n_keys": args.n_keys, "n_tax": args.n_tax,
                    "table_GB": round(w.index.table_bytes / 1e9, 2), "load_factor": args.load_factor,
-                   "parallelism": ("1 GPU" if world == 1 else "replica x%d (table on every GPU, reads split, no data-path collective)" % world),
+                   "parallelism": ("1 GPU" if world == 1 else ("REHEARSAL: %d ranks share ONE GPU (the --gpus N control flow; not a scaling figure); " % world if rehearsing(args) else "") +
+                                   "replica x%d (table on every GPU, reads split, no data-path collective)" % world),
                    "setup_s": round(t_setup, 1), "table_bound_to_taxonomy": t_bind is not None, "bind_s": None if t_bind is None else round(t_bind, 3),
                    "parity": {"answers_bit_identical_to_unbound_table": bit_exact,
                               "lookup_parity": "contract-only: fst::Map::get is third-party and no reference test touches it (DESIGN.md §2); "

@@ -1285,6 +1285,34 @@ def test_sharded_table_ranks_as_processes(api, torch_cuda, world, pieces, own_sh
     assert not os.path.exists("/dev/shm" + name)       # the control block's name is gone once everybody is attached
 
 
+def test_bench_gpus_2_control_flow_rehearsed_on_one_gpu(api, torch_cuda):
+    """`python bench.py --gpus 2 --rehearse-ipc`: the WHOLE --gpus N control flow of the benchmark -- self-launch of one process per rank,
+    rendezvous on 127.0.0.1, ranks_seen by all-reduce, the replica leg with barriers and the max over ranks, then the sharded step in a
+    child process per rank (own process group, shard r of N, exchange, bit-for-bit check against the replica's answers), one JSON line
+    from rank 0 -- with both ranks on the ONE GPU of the box: gloo stands in for RCCL's process group (RCCL refuses two ranks on a
+    device) and the hipIpc communicator with peer-written keys and values for RCCL's send / receive.  What a node adds to this path is
+    ncclSend / ncclRecv (or the same peer mappings over xGMI) and one GPU per rank."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-ipc", "--steps", "3", "--warmup", "1", "--n-keys", "400000000", "--n-tax", "300000",
+           "--pairs-per-step", "1000000", "--batches", "2", "--pieces", "4", "--launch-timeout", "400"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["UMGAP_PUT_TIMEOUT_S"] = "20"
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]                     # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["steps"] == 3 and out["value"] > 0
+    assert "REHEARSAL" in out["config"]["parallelism"] and out["config"]["parity"]["answers_bit_identical_to_unbound_table"] is True
+    sh = out["sharded"]
+    assert "error" not in sh, sh
+    assert sh["ranks_seen"] == 2 and sh["bit_identical_to_replica"] is True and sh["value"] > 0 and sh["pieces"] == 4
+    assert "exchange: put" in sh["transport"] and "peers' mapped buffers" in sh["exchange"]
+
+
 def test_comm_ipc_rendezvous_failures(api, torch_cuda, monkeypatch):
     """umgap_comm_init_ipc when the other ranks never come, or the arguments are wrong: an error after UMGAP_IPC_TIMEOUT_S (not a hang),
     and no shared-memory block left behind."""
