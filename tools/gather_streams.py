@@ -48,6 +48,13 @@ def run(n_keys=8_000_000_000, n=840_000_000, reps=3, legs=None):
             # extra time over the pure gather, as random-read requests, per 64 bytes streamed
             extra_req = (best - base) / base * n               # in units of one random read
             leg["cost_per_64B_streamed_in_random_reads"] = round(extra_req / (n * (r + wr) / 64.0), 2)
+        if wr >= 0x300:
+            names = {1: "stores with sc1", 2: "stores with nt", 3: "stores with sc0 sc1", 4: "stores with sc0 sc1 nt",
+                     8: "values through LDS, ONE wave of the workgroup stores its 2 KB (three of four waves never store)",
+                     17: "2 steps' values stored together", 18: "4 steps' values stored together", 19: "8 steps' values stored together"}
+            leg["cost_per_64B_streamed_in_random_reads"] = round((best - base) / base * n / (n * 4 / 64.0), 2)
+            res["legs"]["write 4 B per probe, " + names[wr - 0x300]] = leg
+            continue
         if wr >= 0x200:
             leg["cost_per_64B_streamed_in_random_reads"] = round((best - base) / base * n / (n * (wr - 0x200) / 64.0), 2)
             res["legs"]["write %d B per probe as one no-return 8-byte atomic exchange per lane and step" % (wr - 0x200)] = leg
@@ -64,6 +71,10 @@ def run(n_keys=8_000_000_000, n=840_000_000, reps=3, legs=None):
 if __name__ == "__main__":
     if "--pmc" in sys.argv:     # under rocprofv3 --pmc: four legs, one launch each after a warm-up (tools/pmc_streams.sh)
         print(json.dumps(run(reps=1, legs=((0, 0), (16, 0), (0, 4), (0, 16)))))
+    elif "--pmc5" in sys.argv:  # round 5: the pure gather, the 4-byte write stream, its LDS-staged one-writer form and the 8-step form
+        print(json.dumps(run(reps=1, legs=((0, 0), (0, 4), (0, 0x308), (0, 0x313)))))
+    elif "--variants" in sys.argv:
+        print(json.dumps(run(legs=((0, 0), (0, 4), (0, 0x301), (0, 0x302), (0, 0x303), (0, 0x304), (0, 0x308), (0, 0x311), (0, 0x312), (0, 0x313), (0, 0)))))
     else:
         a = [int(x) for x in sys.argv[1:3]]
         print(json.dumps(run(*a)))

@@ -42,14 +42,13 @@ __device__ __forceinline__ void wave_probe64(const TableView& T, uint32_t local,
                                              uint32_t* __restrict__ out, size_t base, size_t n, uint32_t lane) {
     uint32_t res[4];
     wave_probe64_vals(T, local, tagv, miss, lane, res);
+    // res[r] is quad-uniform: lane j of quad q takes round j, i.e. key 16 j + q -- ONE store instruction for the wave's 256 bytes (it was
+    // four of 16 lanes each), and non-temporal: a plain store leaves a dirty line in L2 that is written back later, an `nt` (or sc1) store
+    // goes through -- of the 3.5 ms a 4-byte write stream costs beside 840 M random reads, 1.3 ms are that (profiles/r05_gather_stream_variants.json)
     const uint32_t q = lane >> 2, j = lane & 3;
-    if (j == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            size_t i = base + 16 * r + q;
-            if (i < n) out[i] = res[r];
-        }
-    }
+    const uint32_t v = j == 0 ? res[0] : (j == 1 ? res[1] : (j == 2 ? res[2] : res[3]));
+    const size_t i = base + 16 * j + q;
+    if (i < n) __builtin_nontemporal_store(v, out + i);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -860,6 +859,74 @@ __global__ __launch_bounds__(256) void k_gather_w_atomic(const uint64_t* __restr
         for (int u = 0; u < U; u++) acc ^= e[u].x ^ e[u].y ^ e[u].z ^ e[u].w;
         const size_t at = (step * nwaves + wave) * 64 + lane;
         if (at < side_words) (void)__hip_atomic_exchange(side_out + at, ((unsigned long long)acc << 32) | acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (t < n) out[t] = acc;
+}
+
+// ---- round 5: where does the write stream's price come from?  Three more forms of the 4-byte-per-probe write stream -------------
+// (a) MODE 1..4: the same stores with a cache policy on the instruction (sc1 / nt / sc0 sc1 / sc0 sc1 nt: the store-policy table of the
+//     MI355X guide); (b) MODE 8: a workgroup's four waves put their values into LDS and ONE wave stores the workgroup's 2 KB as whole
+//     lines -- three of four waves never issue a store; (c) MODE 16 + k: a wave keeps 2^k steps' values in registers and stores them
+//     together (the same bytes in 2^k times fewer bursts of store instructions).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_gather_w_variant(const uint64_t* __restrict__ slots, uint32_t nb, size_t n, u32x4* __restrict__ side_out, size_t side_vecs,
+                                                          uint32_t* __restrict__ out) {
+    constexpr int LANES = 4, U = 8;
+    constexpr int AGG = MODE >= 16 ? (1 << (MODE - 16)) : 1;      // steps whose values leave together
+    __shared__ u32x4 strip[MODE == 8 ? 128 : 1];                  // MODE 8: 4 waves x 32 lanes x 16 B
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = ((size_t)gridDim.x * blockDim.x) / LANES;
+    const uint32_t j = threadIdx.x % LANES, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const size_t wave = t >> 6, nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    uint32_t acc = 0;
+    size_t step = 0;
+    u32x4 held[AGG];
+    // every thread of the grid runs the SAME number of steps (MODE 8 has a workgroup barrier in the loop): the last step's probes may lie
+    // past n -- a probe is a hash of its number, any number will do
+    const size_t nsteps = (n + stride * U - 1) / (stride * U);
+    for (; step < nsteps; step++) {
+        const size_t i = t / LANES + step * stride * U;
+        u32x4 e[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            size_t ii = i + (size_t)u * stride;
+            uint64_t h = mix45(ii * 0x9E3779B97F4A7C15ull >> 19);
+            uint32_t bucket = __umulhi((uint32_t)h, nb);
+            e[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(slots) + ((size_t)bucket * 4 + j));
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) acc ^= e[u].x ^ e[u].y ^ e[u].z ^ e[u].w;
+        const u32x4 sv = u32x4{acc, acc + 1u, acc + 2u, acc + 3u};
+        const size_t chunk = step * nwaves + wave;                 // 32 vectors (512 B) per wave step
+        if constexpr (MODE >= 1 && MODE <= 4) {
+            u32x4* dst = side_out + chunk * 32 + lane;
+            if (lane < 32u && (chunk + 1) * 32 <= side_vecs) {
+                if constexpr (MODE == 1) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(sv) : "memory");
+                if constexpr (MODE == 2) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(sv) : "memory");
+                if constexpr (MODE == 3) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(dst), "v"(sv) : "memory");
+                if constexpr (MODE == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" ::"v"(dst), "v"(sv) : "memory");
+            }
+        } else if constexpr (MODE == 8) {
+            if (lane < 32u) strip[wv * 32 + lane] = sv;
+            __syncthreads();
+            // the workgroup's four chunks are consecutive (waves 4b .. 4b+3): 128 vectors = 2 KB, stored by wave 0 alone, two instructions
+            const size_t c0 = step * nwaves + (wave & ~(size_t)3);
+            if (wv == 0 && (c0 + 4) * 32 <= side_vecs) {
+                side_out[c0 * 32 + lane] = strip[lane];
+                side_out[c0 * 32 + 64 + lane] = strip[64 + lane];
+            }
+            __syncthreads();
+        } else {
+            held[step % AGG] = sv;
+            if ((step % AGG) == AGG - 1) {
+                // the wave's AGG chunks are nwaves * 32 vectors apart: AGG stores of 512 B, back to back
+#pragma unroll
+                for (int k = 0; k < AGG; k++) {
+                    const size_t ck = (step - (AGG - 1) + k) * nwaves + wave;
+                    if (lane < 32u && (ck + 1) * 32 <= side_vecs) side_out[ck * 32 + lane] = held[k];
+                }
+            }
+        }
     }
     if (t < n) out[t] = acc;
 }
@@ -2118,6 +2185,14 @@ int umgap_bench_gather_rw_dev(umgap_index* ix, size_t n, uint32_t read_bytes, ui
         hipLaunchKernelGGL(k_gather_w_atomic, dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, (unsigned long long*)d_side_out, side_bytes / 8, d_out);
         UMGAP_HIP(hipGetLastError());
         return UMGAP_OK;
+    }
+    if (read_bytes == 0 && (write_bytes >> 8) == 3) {      // 0x300 + mode: round 5's variants of the 4-byte write stream (k_gather_w_variant)
+        const uint32_t mode = write_bytes & 0xFFu;
+        const size_t vecs = side_bytes / 16;
+#define UMGAP_WV(M) if (mode == M) { hipLaunchKernelGGL((k_gather_w_variant<M>), dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, outp, vecs, d_out); UMGAP_HIP(hipGetLastError()); return UMGAP_OK; }
+        UMGAP_WV(1) UMGAP_WV(2) UMGAP_WV(3) UMGAP_WV(4) UMGAP_WV(8) UMGAP_WV(17) UMGAP_WV(18) UMGAP_WV(19)
+#undef UMGAP_WV
+        return fail(UMGAP_ERR_INVALID, "umgap_bench_gather_rw_dev: unknown write-stream variant");
     }
     if (read_bytes == 0 && (write_bytes == 0x104 || write_bytes == 0x110)) {      // 0x100 + bytes: the deferred-store form
         const size_t vecs = side_bytes / 16 - 64;                                  // (64 vectors at the end: where idle lanes' stores go)

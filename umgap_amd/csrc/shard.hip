@@ -434,8 +434,8 @@ __global__ __launch_bounds__(256) void k_shard_pack(const uint64_t* __restrict__
             const uint64_t pos = (uint64_t)b0 + (meta[r] >> 8);
             if (pos < cap) {
                 uint8_t* region = reinterpret_cast<uint8_t*>(((uint64_t)dhi << 32) | dlo);
-                reinterpret_cast<uint32_t*>(region)[pos] = (uint32_t)h[r];
-                reinterpret_cast<uint16_t*>(region + cap * 4)[pos] = (uint16_t)(h[r] >> 32);
+                __builtin_nontemporal_store((uint32_t)h[r], reinterpret_cast<uint32_t*>(region) + pos);           // (nt: index.hip wave_probe64)
+                __builtin_nontemporal_store((uint16_t)(h[r] >> 32), reinterpret_cast<uint16_t*>(region + cap * 4) + pos);
             } else {
                 atomicExch(overflow, 1u);   // sticky: umgap_sharded_check reports it; the consumer answers the key with a miss
             }
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void k_shard_probe(TableView T, const uint8_t*
     // val_dst[region]: where slot 0 of the region's values goes -- this rank's value send buffer (region `region`), its own gather buffer
     // (region == self), or, with peer-written values (put mode), region `self` of the REQUESTER's gather buffer, mapped here
     uint32_t* dst = reinterpret_cast<uint32_t*>(val_dst[region]) + (VB == 4 ? pos0 : (pos0 >> 2) * 3);
-    if (lane < (VB == 4 ? 32u : 24u)) reinterpret_cast<u32x4*>(dst)[lane] = reinterpret_cast<const u32x4*>(wl)[lane];
+    if (lane < (VB == 4 ? 32u : 24u)) __builtin_nontemporal_store(reinterpret_cast<const u32x4*>(wl)[lane], reinterpret_cast<u32x4*>(dst) + lane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     }
