@@ -326,11 +326,15 @@ def test_cleavage_pattern_rewriter_against_python_re(tmp_path):
         else:
             assert g == w, (line, g, w)
     # a greedy pattern over a long protein: std::regex recurses once per residue; the cut runs on a stack sized for the sequence
-    long_seq = "A" * 150_000 + "KA" + "C" * 150_000
-    p = subprocess.run([exe], input=("(.*)([KR])\t%s\n([KR])([^P])\t%s\n" % (long_seq[:60_000] + "K", long_seq)).encode(), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    # (the sequences end in KK so that both passes match at their first attempt: a greedy pattern that fails is quadratic in any engine)
+    long_seq = "A" * 150_000 + "KK"
+    lines = [("(.*)([KR])", long_seq), ("([KR])([^P])", "AC" * 100_000 + "KA" + "C" * 100_000)]
+    p = subprocess.run([exe], input="".join("%s\t%s\n" % ln for ln in lines).encode(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode == 0, p.stderr.decode()[-2000:]
     got = p.stdout.decode().split("\n")[:-1]
-    assert got[0] == long_seq[:60_000] + "|K" and got[1] == "A" * 150_000 + "K|A" + "C" * 150_000
+    for (pat_s, seq), g in zip(lines, got):
+        pat = re.compile(pat_s)
+        assert g == pat.sub(r"\1|\2", pat.sub(r"\1\n\2", seq)).replace("\n", "|"), pat_s
 
 
 def test_seedextend_and_uniq_on_a_stream_of_many_blocks(tmp_path):

@@ -87,6 +87,7 @@ class AsyncIo {
                 if (e.second->started) return -1;
                 e.second->started = true;           // the cookie never starts its pump ...
                 e.second->eof = true;               // ... and a stray fread on the FILE* sees the end of the stream
+                e.second->taken = true;             // (an owned descriptor is then closed by fclose itself: no pump will)
                 return e.second->fd;
             }
         return -1;
@@ -204,7 +205,7 @@ class AsyncIo {
         std::condition_variable data, space;
         std::deque<Chunk> q;
         size_t queued = 0;
-        bool eof = false, stopped = false, started = false, own_fd = false;
+        bool eof = false, stopped = false, started = false, own_fd = false, taken = false;
         int err = 0;
         void pump() {
             struct Closer { In* in; ~Closer() { if (in->own_fd) ::close(in->fd); } } closer{this};
@@ -247,7 +248,7 @@ class AsyncIo {
             {
                 std::lock_guard<std::mutex> lk(m);
                 stopped = true;
-                never_ran = !started;
+                never_ran = !started || taken;       // (taken: the caller read the descriptor itself and is through with it by now)
                 space.notify_all();
             }
             if (own_fd) {

@@ -12,6 +12,7 @@
 #pragma once
 #include <pthread.h>
 
+#include <algorithm>
 #include <cctype>
 #include <cstring>
 #include <exception>
@@ -35,7 +36,9 @@ struct CleavePattern {
         struct Job { const CleavePattern* self; const std::string* seq; std::string out; std::exception_ptr err; } job{this, &seq, {}, nullptr};
         pthread_attr_t attr;
         pthread_attr_init(&attr);
-        pthread_attr_setstacksize(&attr, (size_t)(64u << 20) + seq.size() * 1024);       // (address space: only the pages used are ever touched)
+        // (address space: only the pages used are ever touched.  The matcher nests about five frames per residue -- ~1 KB, several times
+        // that in an instrumented build)
+        pthread_attr_setstacksize(&attr, std::min<size_t>((size_t)(64u << 20) + seq.size() * 8192, (size_t)8 << 30));
         pthread_t th;
         const int rc = pthread_create(&th, &attr, [](void* p) -> void* {
             Job* j = static_cast<Job*>(p);

@@ -24,6 +24,8 @@
 #include <mutex>
 #include <thread>
 
+#include <sys/socket.h>
+
 #include "async_io.hpp"
 #include "text.hpp"
 
@@ -61,8 +63,15 @@ class BlockReader {
     }
     ~BlockReader() {
         if (map_) munmap(map_, map_len_);
-        if (ahead_) { std::lock_guard<std::mutex> g(ahead_->m); ahead_->stop = true; ahead_->cv.notify_all(); }   // (the filler is detached: see next_ahead)
+        if (ahead_) { std::lock_guard<std::mutex> g(ahead_->m); ahead_->stop = true; ahead_->cv.notify_all(); }   // (stdin's filler is detached: see next_ahead)
+        if (filler_.joinable()) {        // a connection's filler: woken out of its read() and waited for -- the descriptor is closed right after us
+            if (conn_fd_ >= 0) (void)::shutdown(conn_fd_, SHUT_RD);
+            filler_.join();
+        }
     }
+    // The stream is a connection of the socket server (not stdin): its blocks may be put together ahead of the caller as well.  The
+    // filler then belongs to this reader -- it is stopped and joined when the reader goes, whatever became of the request.
+    void connection() { connection_ = true; }
     BlockReader(const BlockReader&) = delete;
     BlockReader& operator=(const BlockReader&) = delete;
     // When the stream is a regular file (`umgap ... < reads.fa`; the command's stdin, wrapped or not, sits on descriptor 0) the
@@ -174,18 +183,23 @@ class BlockReader {
         std::exception_ptr err;
     };
     std::shared_ptr<Ahead> ahead_;
-    bool ahead_ok() const {
+    bool ahead_ok() {
         if (ahead_) return true;
-        if (f_ != stdin || started_sync_) return false;
+        if (started_sync_) return false;
         const char* e = getenv("UMGAP_BLOCK_AHEAD");
-        return !(e && e[0] == '0');
+        if (e && e[0] == '0') return false;
+        if (f_ == stdin) return true;
+        if (!connection_ || !AsyncIo::enabled()) return false;
+        conn_fd_ = AsyncIo::take_fd(f_);          // (nothing read from the FILE* yet: the filler reads the descriptor itself)
+        if (conn_fd_ < 0) { started_sync_ = true; return false; }
+        return true;
     }
     // the filler: the loop of next() below, one block after the other into the free slots
-    static void fill_ahead(std::shared_ptr<Ahead> A, FILE* f, size_t block, bool lines_only) {
+    static void fill_ahead(std::shared_ptr<Ahead> A, FILE* f, size_t block, bool lines_only, int taken_fd) {
         std::vector<char> tail;
         bool eof = false, first = true;
         // the descriptor itself where nobody has read from the FILE* yet: read() straight into the block (no pump thread, no chunks)
-        const int fd = AsyncIo::enabled() ? AsyncIo::take_fd(f) : -1;
+        const int fd = taken_fd >= 0 ? taken_fd : (AsyncIo::enabled() ? AsyncIo::take_fd(f) : -1);
         auto fill = [&](char* dst, size_t n) -> size_t {      // like fread: n bytes unless the stream ends (0 bytes: end or error)
             if (fd < 0) {
                 const size_t got = fread(dst, 1, n, f);
@@ -249,7 +263,8 @@ class BlockReader {
     bool next_ahead(const char*& data, size_t& len) {
         if (!ahead_) {
             ahead_ = std::make_shared<Ahead>();
-            std::thread(fill_ahead, ahead_, f_, piped_block(block_), lines_only_).detach();
+            if (conn_fd_ >= 0) filler_ = std::thread(fill_ahead, ahead_, f_, piped_block(block_), lines_only_, conn_fd_);
+            else std::thread(fill_ahead, ahead_, f_, piped_block(block_), lines_only_, -1).detach();
         }
         Ahead& A = *ahead_;
         std::unique_lock<std::mutex> lk(A.m);
@@ -267,7 +282,9 @@ class BlockReader {
         if (A.err) { std::exception_ptr e = A.err; A.err = nullptr; std::rethrow_exception(e); }
         return false;
     }
-    bool started_sync_ = false;
+    bool started_sync_ = false, connection_ = false;
+    int conn_fd_ = -1;
+    std::thread filler_;
     FILE* f_;
     size_t block_;
     std::vector<char> buf_, other_;

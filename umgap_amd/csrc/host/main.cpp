@@ -509,6 +509,7 @@ void stream_kmer_records(FILE* in, FILE* outf, umgap_index* ix, bool one_on_one,
     BlockReader blocks(in);
     blocks.keep_previous_block();
     blocks.map_regular_file();
+    if (in != stdin) blocks.connection();          // a connection of the -s server: blocks cut ahead by a filler thread, like stdin's
     const unsigned T = worker_count();
     struct Job {
         const char* d = nullptr;
@@ -518,6 +519,8 @@ void stream_kmer_records(FILE* in, FILE* outf, umgap_index* ix, bool one_on_one,
         PinnedVec<uint64_t> frag_off;
         PinnedVec<uint32_t> hits;
         std::vector<std::string> tails;
+        OutLatch latch;        // the parts' output strings leave without a copy: they are this job's own again when the latch is down
+                               // (declared behind `parts`: destroyed -- waited for -- before them)
     };
     std::string held;          // formatted records of the still open chunk
     size_t g0 = 0;             // global index of the block's first record
@@ -610,6 +613,7 @@ void stream_kmer_records(FILE* in, FILE* outf, umgap_index* ix, bool one_on_one,
         if (n_frag) LIB(umgap_index_lookup_records(ix, J.bytes.data(), J.frag_off.data(), n_frag, 0u, J.hits.data()));
         t_lookup += now() - t0; t0 = now();
         if (J.tails.size() < used) J.tails.resize(used);
+        J.latch.wait();                             // the writer thread is through with what this job printed two blocks ago
         parallel_for(used, [&](size_t i) {
             KmerPart& P = parts[i];
             const size_t nr = P.hdr_off.size(), lo = g0 + rec_first[i];
@@ -623,7 +627,9 @@ void stream_kmer_records(FILE* in, FILE* outf, umgap_index* ix, bool one_on_one,
         t_format += now() - t0; t0 = now();
         const size_t held_from = g0 / chunk * chunk;
         if (!held.empty() && limit > held_from) { fwrite(held.data(), 1, held.size(), outf); held.clear(); }
-        for (size_t i = 0; i < used; i++) fwrite(parts[i].out.data(), 1, parts[i].out.size(), outf);
+        // (600 bytes per pair with -o: handed to the writer thread as they lie -- copying them into its 1 MB chunks was this stage's
+        // largest single cost inside the script's chain)
+        for (size_t i = 0; i < used; i++) write_owned_or_copy(outf, parts[i].out.data(), parts[i].out.size(), J.latch);
         t_write += now() - t0;
         if (failed) {
             fflush(outf);
@@ -1612,6 +1618,7 @@ int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
     // call are not hidden, and 8 M pairs are only 16 blocks of 64 MB (stream 0.217 s against 0.152 s at 32 MB; no difference at 16 M pairs)
     BlockReader blocks(in, BlockReader::piped_block(BlockReader::default_block()));
     blocks.map_regular_file();   // a file on stdin is mapped: blocks are views of the page cache, nothing is copied by this thread
+    if (in != stdin) blocks.connection();
     for (;;) {
         const char* d = nullptr;
         size_t len = 0;
