@@ -495,6 +495,23 @@ int umgap_walk_builder_add_dev(umgap_walk_builder* b, const uint8_t* d_bytes, co
 int umgap_walk_builder_add(umgap_walk_builder* b, const uint8_t* bytes, const uint64_t* offsets, size_t n_fragments,
                            uint32_t max_fragment_len);   /* the same from host memory */
 int umgap_walk_builder_finish(umgap_walk_builder* b, umgap_index** out);
+/* The same WITHOUT a values table in HBM (round 5): the order first, the values afterwards.  The general builder above keeps three
+ * things resident -- the values table, the position table under construction and the walk array: 6.5 G keys on one 288 GB GPU -- so
+ * the real 9-mer index (8 G keys) with the reference's own values (`printindex | umgap buildindex --proteome`) did not fit.  Here
+ *   1. umgap_walk_builder_new_deferred(expected_keys = an upper bound on the distinct 9-mers of the proteome),
+ *   2. umgap_walk_builder_add[_dev] for every chunk of the proteome: EVERY 9-mer of the proteome gets an entry, valued 0 = "no key",
+ *   3. umgap_walk_builder_set_values[_dev](keys45, values) for the (key, value) pairs of the index, in chunks of any size and order
+ *      (values > 0; a key twice with the same value is fine, with two values an error at finish): a key the proteome showed has its
+ *      entry valued; the others are collected (room for expected_keys / 4 of them) and appended behind the proteome as walks of one,
+ *   4. umgap_walk_builder_finish.
+ * Resident: the position table and the walk array only (204 GB for 8.4 G proteome 9-mers) plus one chunk.  Answers: a key's value;
+ * for everything else -- 9-mers of the proteome that were given no value included -- the miss value, as from the plain table of the
+ * same (key, value) pairs; a walk runs THROUGH such a 9-mer (its entry says "no key") instead of breaking at it.
+ * umgap_index_num_keys counts the valued keys; umgap_index_dump9 lists only those; the file keeps the flag (UMGAPIX1 kind 10,
+ * bit 62 of the walk-array word of the header). */
+int umgap_walk_builder_new_deferred(uint64_t expected_keys, double load_factor, int device, umgap_walk_builder** out);
+int umgap_walk_builder_set_values_dev(umgap_walk_builder* b, const uint64_t* d_keys45, const uint32_t* d_values, size_t n);
+int umgap_walk_builder_set_values(umgap_walk_builder* b, const uint64_t* keys45, const uint32_t* values, size_t n);
 /* How a walk-order index numbers its entries: the table holds entry number >> *shift (0 below 2^32 - 2^22 entries, else 1 or 2), the
  * walk array has *n_entries entries (padding included), and *n_exceptions keys share their low 31 bits with another key of their
  * group of 2^shift entries (looked up through a sorted list).  Any pointer may be null. */

@@ -1810,14 +1810,18 @@ def test_walk_index_matches_plain_table(api, torch_cuda, mutations_per_mille, sh
                 assert outs[0] == outs[1] and len(outs[0]) > 0, args
 
 
-@pytest.mark.parametrize("n_chunks,load,shift", [(1, 0.0, 0), (3, 0.0, 0), (5, 0.9, 0), (3, 0.0, 1), (5, 0.9, 2)])
-def test_walk_builder_values_from_a_table_order_from_a_proteome(api, torch_cuda, n_chunks, load, shift, monkeypatch):
+@pytest.mark.parametrize("n_chunks,load,shift,how", [(1, 0.0, 0, "table"), (3, 0.0, 0, "table"), (5, 0.9, 0, "table"), (3, 0.0, 1, "table"), (5, 0.9, 2, "table"),
+                                                     (1, 0.0, 0, "deferred"), (3, 0.0, 1, "deferred"), (5, 0.9, 2, "deferred"), (4, 0.0, 0, "deferred")])
+def test_walk_builder_values_from_a_table_order_from_a_proteome(api, torch_cuda, n_chunks, load, shift, how, monkeypatch):
     """umgap_walk_builder_*: the values come from a kind-9 table (what `umgap buildindex` makes from the reference's TSV), the order
     from a proteome handed over in chunks.  The table holds only part of the proteome's 9-mers (the others must miss) and keys the
     proteome never shows (appended as walks of one); fragments repeat within and across chunks (every key is listed once, at its
     first window).  Every answer -- get() of keys, the windows of reads, the fused pipeline -- is the values table's, bit for bit;
     the walk array has one entry per key, plus those of short runs of repeats inside a fragment (at most an eighth more; at the
-    high load factor some keys go through the stash and may get a second)."""
+    high load factor some keys go through the stash and may get a second).
+    how = "deferred" (round 5, umgap_walk_builder_new_deferred): no values table on the device at all -- the proteome first (every
+    9-mer of it gets an entry valued "no key"), then the (key, value) pairs in shuffled chunks; the keys the proteome never showed are
+    appended; the same answers, a walk array of one entry per 9-mer of the proteome or key."""
     monkeypatch.setenv("UMGAP_WALK_SHIFT", str(shift))      # > 0: the wide entry numbers of walk_ref.hpp forced on this small index
     torch = torch_cuda
     from umgap_amd.api import Index
@@ -1860,7 +1864,14 @@ def test_walk_builder_values_from_a_table_order_from_a_proteome(api, torch_cuda,
         d_b = torch.from_numpy(np.concatenate([data, np.zeros(1, np.uint8)])).cuda()
         d_o = torch.from_numpy(offs.view(np.int64).copy()).cuda()
         chunks.append((d_b, d_o, max(9, max((len(f) for f in part), default=9))))
-    walk = Index.build_walk(values, chunks, load_factor=load)
+    if how == "table":
+        walk = Index.build_walk(values, chunks, load_factor=load)
+    else:
+        perm = rng.permutation(len(vkeys))
+        vcuts = np.linspace(0, len(vkeys), 4).astype(int)
+        vchunks = [(torch.from_numpy(vkeys[perm[a:b]].view(np.int64).copy()).cuda(), torch.from_numpy(vtaxa[perm[a:b]].view(np.int32).copy()).cuda()) for a, b in zip(vcuts[:-1], vcuts[1:])]
+        vchunks.append(vchunks[0])                                   # (a chunk twice: the same values again are fine)
+        walk = Index.build_walk_deferred(len(prot_keys) + 1000, chunks, vchunks, load_factor=load)
     assert walk.kind == 10 and walk.num_keys == len(vkeys)
     # get(): every key of the table, the proteome's keys the table does not hold, random keys
     q = np.concatenate([vkeys, np.setdiff1d(prot_keys, keep), np.unique(rng.integers(0, 1 << 45, 3000, dtype=np.uint64))])
@@ -1880,9 +1891,12 @@ def test_walk_builder_values_from_a_table_order_from_a_proteome(api, torch_cuda,
             hdr = f.read(72)
         reserved = int(np.frombuffer(hdr[64:72], np.uint64)[0])
         n_walk = reserved & ((1 << 60) - 1)
-        assert reserved >> 60 == shift
-        # (with a shift every fragment's run of entries is padded to a multiple of 2^shift)
-        assert len(vkeys) <= n_walk <= len(vkeys) + len(vkeys) // 8 + (0 if load < 0.8 else len(vkeys) // 50) + ((1 << shift) - 1) * len(frags), (n_walk, len(vkeys))
+        assert (reserved >> 60) & 3 == shift and (reserved >> 62) == (1 if how == "deferred" else 0)
+        # (with a shift every fragment's run of entries is padded to a multiple of 2^shift; deferred: an entry per 9-mer of the proteome, key or not)
+        n_ent = len(vkeys) if how == "table" else len(prot_keys) + len(extra)
+        assert n_ent <= n_walk <= n_ent + n_ent // 8 + (0 if load < 0.8 else n_ent // 50) + ((1 << shift) - 1) * len(frags), (n_walk, n_ent)
+        dk, dt = walk.dump9()
+        assert len(dk) == len(vkeys) and dict(zip(dk.tolist(), dt.tolist())) == ref
         again = Index.open(fw)
         assert np.array_equal(again.lookup9(q, miss_value=7), want)
         again.close()

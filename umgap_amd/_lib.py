@@ -141,6 +141,9 @@ def load():
         "umgap_walk_builder_add_dev": (i32, [vp, vp, vp, sz, u32]),
         "umgap_walk_builder_add": (i32, [vp, vp, vp, sz, u32]),
         "umgap_walk_builder_finish": (i32, [vp, pp]),
+        "umgap_walk_builder_new_deferred": (i32, [u64, dbl, i32, pp]),
+        "umgap_walk_builder_set_values_dev": (i32, [vp, vp, vp, sz]),
+        "umgap_walk_builder_set_values": (i32, [vp, vp, vp, sz]),
         "umgap_walk_builder_free": (None, [vp]),
         "umgap_synth_prot_reads_dev": (i32, [vp, u64, u32, u64, u64, sz, u32, u32, vp, i32, vp]),
         "umgap_seedextend_dev": (i32, [vp, sz, u32, u32, vp, vp, i32, vp]),

@@ -138,6 +138,27 @@ class Index:
                 L.umgap_walk_builder_free(b)
 
     @classmethod
+    def build_walk_deferred(cls, expected_keys, chunks, value_chunks, load_factor=0.0, device=0):
+        """A walk-order index (kind 10) built WITHOUT a values table in HBM (umgap_walk_builder_new_deferred): the order from the
+        proteome (`chunks` as for build_walk), then the values from `value_chunks`: an iterable of (d_keys45 int64, d_values int32) torch
+        CUDA tensors -- the (key, value) pairs of the index in any order.  Same answers as the plain table of those pairs."""
+        L = _lib.load()
+        b = C.c_void_p()
+        check(L.umgap_walk_builder_new_deferred(expected_keys, load_factor, device, C.byref(b)))
+        try:
+            for d_bytes, d_offsets, max_len in chunks:
+                check(L.umgap_walk_builder_add_dev(b, _dev_ptr(d_bytes), _dev_ptr(d_offsets), d_offsets.numel() - 1, max_len))
+            for d_keys, d_vals in value_chunks:
+                check(L.umgap_walk_builder_set_values_dev(b, _dev_ptr(d_keys), _dev_ptr(d_vals), d_keys.numel()))
+            h = C.c_void_p()
+            check(L.umgap_walk_builder_finish(b, C.byref(h)))
+            b = None
+            return cls(h.value)
+        finally:
+            if b is not None:
+                L.umgap_walk_builder_free(b)
+
+    @classmethod
     def open(cls, path, device=0, shard=0, n_shards=1):
         h = C.c_void_p()
         check(_lib.load().umgap_index_open_shard(str(path).encode(), 1 << device, shard, n_shards, C.byref(h)))
@@ -180,6 +201,16 @@ class Index:
         check(_lib.load().umgap_index_lookup_var_dev(self._h, _dev_ptr(d_bytes), _dev_ptr(d_offsets), d_offsets.numel() - 1, miss_value,
                                                      _dev_ptr(d_out), _stream_ptr(stream)))
         return d_out
+
+    def dump9(self):
+        """(keys45, taxa) of a 9-mer table, in table order (umgap_index_dump9: what printindex walks)."""
+        L = _lib.load()
+        n = C.c_size_t()
+        check(L.umgap_index_dump9(self._h, None, None, 0, C.byref(n)))
+        keys = np.zeros(max(1, n.value), np.uint64)
+        taxa = np.zeros(max(1, n.value), np.uint32)
+        check(L.umgap_index_dump9(self._h, _np_ptr(keys), _np_ptr(taxa), n.value, C.byref(n)))
+        return keys[:n.value], taxa[:n.value]
 
     def dump_var(self):
         """(key bytes, offsets, lengths, taxa) of a byte-string table, in table order (umgap_index_dump_var: what printindex walks)."""

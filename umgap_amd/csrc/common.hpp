@@ -120,6 +120,7 @@ struct umgap_index {
     uint64_t* d_walk = nullptr;        // kind 10: E[p] = taxon | (low 31 key bits | continues << 31) << 32 for window p of the proteome; the table's values are positions
     uint64_t n_walk = 0;
     uint32_t walk_shift = 0;           // the table holds p >> walk_shift (walk_ref.hpp: 1 from 2^32 - 2^22 entries on, 2 from 2^33 on)
+    bool walk_zero_absent = false;     // an entry whose value is 0 is a 9-mer of the proteome that is no key (umgap_walk_builder_new_deferred)
     uint32_t n_walk_exc = 0;           // keys whose group holds another entry with their low bits: sorted keys -> positions
     uint64_t* d_walk_exc_keys = nullptr;
     uint64_t* d_walk_exc_pos = nullptr;

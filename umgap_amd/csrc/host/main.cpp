@@ -1830,6 +1830,81 @@ int cmd_buildindex(const std::vector<std::string>& args) {
         proteome = fopen(path.c_str(), "rb");
         if (!proteome) throw CliError("cannot open " + path + ": " + strerror(errno));
     }
+    // --proteome, round 5: no values table on the device.  The proteome first -- every 9-mer of it gets an entry of the walk array --
+    // then the TSV, streamed ONCE, values its keys (umgap_walk_builder_new_deferred: position table + walk array resident, nothing
+    // else: the real 8 G-key index with the reference's own values fits one GPU).  UMGAP_WALK_VALUES_FIRST=1 keeps the first form
+    // (values table built first; keys must all be 9-mers either way).
+    if (walk && !getenv("UMGAP_WALK_VALUES_FIRST")) {
+        umgap_walk_builder* wb = nullptr;
+        umgap_index* wx = nullptr;
+        try {
+            // an upper bound on the distinct 9-mers of the proteome: its windows (one pass over the file, no device work)
+            uint64_t windows = 0;
+            {
+                FastaReader fr(proteome, true);
+                Record rec;
+                while (fr.read_record(rec)) { const size_t n = rec.sequence[0].size(); if (n >= 9) windows += n - 8; }
+                rewind(proteome);
+            }
+            LIB(umgap_walk_builder_new_deferred(std::max<uint64_t>(windows, 1), load, 0, &wb));
+            FastaReader fr(proteome, true);
+            Record rec;
+            std::vector<uint8_t> bytes;
+            std::vector<uint64_t> offs{0};
+            uint32_t max_len = 9;
+            auto flush = [&]() {
+                if (offs.size() > 1) LIB(umgap_walk_builder_add(wb, bytes.data(), offs.data(), offs.size() - 1, max_len));
+                bytes.clear();
+                offs.assign(1, 0);
+                max_len = 9;
+            };
+            while (fr.read_record(rec)) {
+                const std::string& sq = rec.sequence[0];
+                if (sq.size() >= 0xFFFFFF00ull) throw CliError("a protein of 4 GiB or more");
+                if (bytes.size() + sq.size() > (256u << 20)) flush();
+                bytes.insert(bytes.end(), sq.begin(), sq.end());
+                offs.push_back(bytes.size());
+                max_len = std::max<uint32_t>(max_len, (uint32_t)sq.size());
+            }
+            flush();
+            // the TSV: what fst::MapBuilder::insert checks (strictly increasing keys) + the field syntax, block-parallel, one pass
+            BlockReader blocks(stdin);
+            blocks.lines_only();
+            const char* d;
+            size_t len;
+            std::string last_key;
+            bool have_last = false;
+            while (blocks.next(d, len)) {
+                std::vector<size_t> cuts = split_lines(d, len, T);
+                const size_t np = cuts.size() - 1;
+                std::vector<BuildPart> parts(np);
+                parallel_for(np, [&](size_t i) {
+                    parse_index_part(d, cuts[i], cuts[i + 1], 1, false, parts[i]);
+                    if (!parts[i].error && parts[i].all9) { BuildPart P2; parse_index_part(d, cuts[i], cuts[i + 1], 2, false, P2); parts[i].keys.swap(P2.keys); parts[i].vals.swap(P2.vals); }
+                });
+                for (size_t i = 0; i < np; i++) {
+                    BuildPart& P = parts[i];
+                    if (P.n && have_last && !(std::string_view(last_key) < std::string_view(P.first)))
+                        throw CliError(std::string(last_key == P.first ? "Error inserting duplicate key: " : "Error inserting out-of-order key: ") + P.first);
+                    if (P.error) throw *P.error;
+                    if (!P.all9) throw CliError("--proteome needs an index of 9-mers");
+                    if (P.n) { last_key = P.last; have_last = true; }
+                    for (uint32_t v : P.vals) if (v == 0) throw CliError("--proteome: a value of 0 cannot be told from \"no key\" in a walk-order index");
+                    LIB(umgap_walk_builder_set_values(wb, P.keys.data(), P.vals.data(), P.keys.size()));
+                }
+            }
+            LIB(umgap_walk_builder_finish(wb, &wx));
+            wb = nullptr;
+        } catch (...) {
+            if (wb) umgap_walk_builder_free(wb);
+            fclose(proteome);
+            throw;
+        }
+        fclose(proteome);
+        LIB(umgap_index_save(wx, "/dev/stdout"));
+        umgap_index_free(wx);
+        return 0;
+    }
     // pass 1 (spooling unless stdin can be rewound)
     const bool seekable = lseek(fileno(stdin), 0, SEEK_CUR) != (off_t)-1;
     FILE* spool = nullptr;

@@ -502,6 +502,29 @@ __global__ __launch_bounds__(256) void k_walk_min_taxa(TableView T, WalkRef W, c
         if (p != WALK_NOPOS) atomicMin(E32 + 2 * p, frag_taxa[i]);
     }
 }
+// deferred values: entry of keys[i] <- vals[i]; a key without an entry goes to the leftover list (appended at the end as a walk of one).
+// counts: [0] leftovers, [1] entries valued for the first time, [2] keys that came with two different values
+__global__ __launch_bounds__(256) void k_walk_set_values(TableView T, WalkRef W, const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, size_t n,
+                                                         uint64_t* __restrict__ left_keys, uint32_t* __restrict__ left_vals, uint64_t left_cap,
+                                                         unsigned long long* __restrict__ counts) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    uint32_t* E32 = reinterpret_cast<uint32_t*>(const_cast<uint64_t*>(W.E));
+    for (; i < n; i += step) {
+        const uint64_t key = keys[i];
+        const uint32_t v = vals[i];
+        const uint32_t q = (key >> 45) ? UMGAP_NONE : lane_get(T, key, UMGAP_NONE);
+        const uint64_t p = q == UMGAP_NONE ? WALK_NOPOS : walk_position(W, q, key);
+        if (p != WALK_NOPOS) {
+            const uint32_t old = atomicExch(E32 + 2 * p, v);
+            if (old == 0u) atomicAdd(&counts[1], 1ull);
+            else if (old != v) atomicAdd(&counts[2], 1ull);
+        } else {
+            const unsigned long long at = atomicAdd(&counts[0], 1ull);
+            if (at < left_cap) { left_keys[at] = key; left_vals[at] = v; }
+        }
+    }
+}
 // ... and the kept repeats (entries nothing points at; list of (key, entry)) take the taxon of their key's own entry
 __global__ __launch_bounds__(256) void k_walk_settle_kept(TableView T, WalkRef W, const uint64_t* __restrict__ list, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1357,7 +1380,7 @@ int umgap_index_save(const umgap_index* ix, const char* path) {
     h.version = 1; h.kind = (uint32_t)ix->kind; h.n_keys = ix->n_keys; h.m = ix->view.m; h.nb = ix->view.nb;
     // kind 10 (walk order): the walk array, n_walk x u64, follows the stash; bits 60-61 of `reserved` = walk_shift (walk_ref.hpp), and
     // with a shift the exception list follows the walk array: u64 count, the sorted keys, their positions
-    h.reserved = ix->kind == 10 ? (ix->n_walk | ((uint64_t)ix->walk_shift << 60)) : 0;
+    h.reserved = ix->kind == 10 ? (ix->n_walk | ((uint64_t)ix->walk_shift << 60) | ((uint64_t)(ix->walk_zero_absent ? 1 : 0) << 62)) : 0;   // bit 62: an entry with value 0 is no key
     h.mix_c1 = MIX_C1; h.mix_c2 = MIX_C2; h.r_bits = R_BITS; h.slots = SLOTS;
     h.n_stash = ix->n_stash;
     bool ok = fwrite(&h, sizeof(h), 1, f) == 1;
@@ -1476,7 +1499,7 @@ int umgap_index_open_shard(const char* path, uint32_t device_mask, uint32_t shar
         return fail(UMGAP_ERR_FORMAT, std::string(path) + ": unsupported UMGAPIX1 parameters");
     }
     if (h.kind == 10 && n_shards != 1) { fclose(f); return fail(UMGAP_ERR_INVALID, "a walk-order index cannot be sharded"); }
-    if (h.kind == 10 && ((h.reserved >> 62) != 0 || ((h.reserved >> 60) & 3) > 2 || (h.reserved & ((1ull << 60) - 1)) >= ((0xFFFFFFFFull) << ((h.reserved >> 60) & 3)))) {
+    if (h.kind == 10 && ((h.reserved >> 63) != 0 || ((h.reserved >> 60) & 3) > 2 || (h.reserved & ((1ull << 60) - 1)) >= ((0xFFFFFFFFull) << ((h.reserved >> 60) & 3)))) {
         fclose(f);
         return fail(UMGAP_ERR_FORMAT, std::string(path) + ": walk array too long for its entry numbers");
     }
@@ -1515,6 +1538,7 @@ int umgap_index_open_shard(const char* path, uint32_t device_mask, uint32_t shar
         ix->kind = 10;
         ix->n_walk = h.reserved & ((1ull << 60) - 1);
         ix->walk_shift = (uint32_t)((h.reserved >> 60) & 3);
+        ix->walk_zero_absent = ((h.reserved >> 62) & 1) != 0;
         if (hipMalloc((void**)&ix->d_walk, std::max<uint64_t>(ix->n_walk, 1) * 8) != hipSuccess) { fclose(f); umgap_index_free(ix); return fail(UMGAP_ERR_NOMEM, "hipMalloc of the walk array failed"); }
         const off_t walk_at = (off_t)(sizeof(h) + (uint64_t)h.nb * 64 + h.n_stash * 16);
         ok = load_file_range(fd, walk_at, (size_t)ix->n_walk * 8, ix->d_walk, device);
@@ -1599,6 +1623,13 @@ struct umgap_walk_builder {
     uint32_t shift = 0;                    // the table holds entry number >> shift (walk_ref.hpp)
     uint64_t* d_exc = nullptr;             // (key, position) pairs of the exception list, in the order found
     unsigned long long* d_exc_n = nullptr;
+    // deferred values (umgap_walk_builder_new_deferred): no values table at all -- every 9-mer of the proteome gets an entry with
+    // value 0 ("no key"), umgap_walk_builder_set_values names the keys afterwards, keys the proteome never showed are appended
+    bool deferred = false, sealed = false;
+    uint64_t* d_left_keys = nullptr;       // (key, value) pairs set_values did not find an entry for
+    uint32_t* d_left_vals = nullptr;
+    uint64_t left_cap = 0;
+    unsigned long long* d_set_counts = nullptr;   // [0] leftovers, [1] entries valued, [2] keys given two different values
 };
 constexpr uint64_t WALK_EXC_CAP = 1ull << 22;
 namespace {
@@ -1635,6 +1666,7 @@ void umgap_walk_builder_free(umgap_walk_builder* b) {
     if (b->d_stash) (void)hipFree(b->d_stash);
     if (b->d_exc) (void)hipFree(b->d_exc);
     if (b->d_exc_n) (void)hipFree(b->d_exc_n);
+    for (void* p : {(void*)b->d_left_keys, (void*)b->d_left_vals, (void*)b->d_set_counts}) if (p) (void)hipFree(p);
     for (auto& kl : b->kept_lists) if (kl.first) (void)hipFree(kl.first);
     if (b->ix) umgap_index_free(b->ix);
     delete b;
@@ -1689,6 +1721,76 @@ extern "C" {
 
 int umgap_walk_builder_new(const umgap_index* values, double load, umgap_walk_builder** out) { return walk_builder_create(values, load, 0, out); }
 
+int umgap_walk_builder_new_deferred(uint64_t expected_keys, double load, int device, umgap_walk_builder** out) {
+    if (!out || !expected_keys) return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_new_deferred: null argument");
+    int rc = walk_builder_create(nullptr, load, 0, out, expected_keys, device);
+    if (rc) return rc;
+    (*out)->deferred = true;
+    return UMGAP_OK;
+}
+
+}  // extern "C"
+namespace {
+int walk_install_exceptions(umgap_walk_builder* b);
+// the proteome is complete: the table gets its sorted stash and its halo, the walk array its exception list -- look-ups work from here on
+int walk_seal(umgap_walk_builder* b) {
+    if (b->sealed) return UMGAP_OK;
+    umgap_index* x = b->ix;
+    int rc = walk_finalize_table(b);
+    if (rc) return rc;
+    x->walk_shift = b->shift;
+    x->n_walk = b->n_walk;
+    if ((rc = walk_install_exceptions(b))) return rc;
+    b->left_cap = std::max<uint64_t>(b->expected_keys / 4, 1u << 20);
+    if (b->n_walk + b->left_cap > b->cap_walk) b->left_cap = b->cap_walk > b->n_walk ? b->cap_walk - b->n_walk : 0;
+    if (hipMalloc((void**)&b->d_left_keys, std::max<uint64_t>(b->left_cap, 1) * 8) != hipSuccess || hipMalloc((void**)&b->d_left_vals, std::max<uint64_t>(b->left_cap, 1) * 4) != hipSuccess ||
+        hipMalloc((void**)&b->d_set_counts, 24) != hipSuccess)
+        return fail(UMGAP_ERR_NOMEM, "umgap_walk_builder_set_values: hipMalloc failed");
+    UMGAP_HIP(hipMemset(b->d_set_counts, 0, 24));
+    b->sealed = true;
+    return UMGAP_OK;
+}
+}  // namespace
+extern "C" {
+
+int umgap_walk_builder_set_values_dev(umgap_walk_builder* b, const uint64_t* d_keys45, const uint32_t* d_values, size_t n) {
+    if (!b || !b->ix || (n && (!d_keys45 || !d_values))) return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_set_values_dev: null argument");
+    if (!b->deferred) return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_set_values_dev: this builder was given its values as a table");
+    int rc = use_device(b->ix->device);
+    if (rc) return rc;
+    UMGAP_HIP(hipDeviceSynchronize());   // the caller's arrays may have been produced on any stream
+    if ((rc = walk_seal(b))) return rc;
+    umgap_index* x = b->ix;
+    if (n) hipLaunchKernelGGL(k_walk_set_values, dim3(grid_for(n)), dim3(256), 0, x->stream, x->view, walk_ref_of(x), d_keys45, d_values, n, b->d_left_keys, b->d_left_vals, b->left_cap,
+                              b->d_set_counts);
+    UMGAP_HIP(hipGetLastError());
+    UMGAP_HIP(hipStreamSynchronize(x->stream));
+    return UMGAP_OK;
+}
+
+int umgap_walk_builder_set_values(umgap_walk_builder* b, const uint64_t* keys45, const uint32_t* values, size_t n) {
+    if (!b || !b->ix || (n && (!keys45 || !values))) return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_set_values: null argument");
+    int rc = use_device(b->ix->device);
+    if (rc) return rc;
+    const size_t step = 64u << 20;
+    uint64_t* d_k = nullptr;
+    uint32_t* d_v = nullptr;
+    if (hipMalloc((void**)&d_k, std::min(std::max<size_t>(n, 1), step) * 8) != hipSuccess || hipMalloc((void**)&d_v, std::min(std::max<size_t>(n, 1), step) * 4) != hipSuccess) {
+        if (d_k) (void)hipFree(d_k);
+        return fail(UMGAP_ERR_NOMEM, "umgap_walk_builder_set_values: hipMalloc failed");
+    }
+    rc = n ? UMGAP_OK : umgap_walk_builder_set_values_dev(b, d_k, d_v, 0);      // (n == 0 still seals the builder)
+    for (size_t o = 0; o < n && !rc; o += step) {
+        const size_t len = std::min(step, n - o);
+        if (hipMemcpy(d_k, keys45 + o, len * 8, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_v, values + o, len * 4, hipMemcpyHostToDevice) != hipSuccess)
+            rc = fail(UMGAP_ERR_DEVICE, "umgap_walk_builder_set_values: copy failed");
+        if (!rc) rc = umgap_walk_builder_set_values_dev(b, d_k, d_v, len);
+    }
+    (void)hipFree(d_k);
+    (void)hipFree(d_v);
+    return rc;
+}
+
 }  // extern "C"
 namespace {
 int walk_add_chunk(umgap_walk_builder* b, const uint8_t* d_bytes, const uint64_t* d_offsets, size_t n_fragments, uint32_t max_fragment_len, const uint32_t* d_frag_taxa);
@@ -1696,7 +1798,21 @@ int walk_add_chunk(umgap_walk_builder* b, const uint8_t* d_bytes, const uint64_t
 extern "C" {
 // the next chunk of the proteome (fragments in order; d_offsets[0 .. n_fragments] index d_bytes; fewer than 2^32 - 1 windows per chunk)
 int umgap_walk_builder_add_dev(umgap_walk_builder* b, const uint8_t* d_bytes, const uint64_t* d_offsets, size_t n_fragments, uint32_t max_fragment_len) {
-    if (b && !b->values) return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_add_dev: this builder takes its values from the proteome (internal)");
+    if (b && !b->values && !b->deferred) return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_add_dev: this builder takes its values from the proteome (internal)");
+    if (b && b->deferred) {
+        if (b->sealed) return fail(UMGAP_ERR_INVALID, "umgap_walk_builder_add_dev: the proteome is complete once values are being set");
+        if (!n_fragments) return UMGAP_OK;
+        // every entry starts as "no key": a fragment taxon of 0 for all (the passes then skip their values look-up, as for a proteome's own index)
+        int rc = use_device(b->ix->device);
+        if (rc) return rc;
+        uint32_t* d_zero = nullptr;
+        if (hipMalloc((void**)&d_zero, n_fragments * 4) != hipSuccess) return fail(UMGAP_ERR_NOMEM, "umgap_walk_builder_add_dev: hipMalloc failed");
+        if (hipMemset(d_zero, 0, n_fragments * 4) != hipSuccess) { (void)hipFree(d_zero); return fail(UMGAP_ERR_DEVICE, "umgap_walk_builder_add_dev: memset failed"); }
+        rc = walk_add_chunk(b, d_bytes, d_offsets, n_fragments, max_fragment_len, d_zero);
+        (void)hipDeviceSynchronize();
+        (void)hipFree(d_zero);
+        return rc;
+    }
     return walk_add_chunk(b, d_bytes, d_offsets, n_fragments, max_fragment_len, nullptr);
 }
 }  // extern "C"
@@ -1808,7 +1924,24 @@ int umgap_walk_builder_add(umgap_walk_builder* b, const uint8_t* bytes, const ui
 }
 
 }  // extern "C"
-namespace { int walk_finish(umgap_walk_builder* b, umgap_index** out, std::vector<std::pair<uint64_t, uint64_t>>* dropped_out); }
+namespace {
+int walk_finish(umgap_walk_builder* b, umgap_index** out, std::vector<std::pair<uint64_t, uint64_t>>* dropped_out);
+// the builder's exception pairs so far -> the index's sorted exception list (walk_ref.hpp)
+int walk_install_exceptions(umgap_walk_builder* b) {
+    umgap_index* x = b->ix;
+    if (!b->shift) return UMGAP_OK;
+    unsigned long long n_exc = 0;
+    if (hipMemcpy(&n_exc, b->d_exc_n, 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(UMGAP_ERR_DEVICE, "umgap_walk_builder_finish: copy failed");
+    if (n_exc > WALK_EXC_CAP) return fail(UMGAP_ERR_BUILD, "umgap_walk_builder_finish: more than 2^22 keys share their low bits with a neighbour (low-complexity proteome?)");
+    std::vector<uint64_t> raw(2 * (size_t)n_exc);
+    if (n_exc && hipMemcpy(raw.data(), b->d_exc, raw.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return fail(UMGAP_ERR_DEVICE, "umgap_walk_builder_finish: copy failed");
+    std::vector<std::pair<uint64_t, uint64_t>> ex(n_exc);
+    for (size_t i = 0; i < n_exc; i++) ex[i] = {raw[2 * i], raw[2 * i + 1]};
+    std::sort(ex.begin(), ex.end());
+    ex.erase(std::unique(ex.begin(), ex.end(), [](const std::pair<uint64_t, uint64_t>& p, const std::pair<uint64_t, uint64_t>& q) { return p.first == q.first; }), ex.end());
+    return set_walk_exceptions(x, ex);
+}
+}
 extern "C" {
 int umgap_walk_builder_finish(umgap_walk_builder* b, umgap_index** out) { return walk_finish(b, out, nullptr); }
 }  // extern "C"
@@ -1819,7 +1952,8 @@ int walk_finish(umgap_walk_builder* b, umgap_index** out, std::vector<std::pair<
     umgap_index* x = b->ix;
     int rc = use_device(x->device);
     if (rc) return rc;
-    rc = walk_finalize_table(b);
+    if (b->deferred) rc = walk_seal(b);            // (nobody set a value: an index of misses, but a consistent one)
+    else rc = walk_finalize_table(b);
     if (rc) return rc;
     if (dropped_out) *dropped_out = b->dropped;
     // the keys the proteome never showed: appended as walks of one
@@ -1843,12 +1977,22 @@ int walk_finish(umgap_walk_builder* b, umgap_index** out, std::vector<std::pair<
         if (e == hipSuccess) e = hipStreamSynchronize(x->stream);
         if (e != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, std::string("umgap_walk_builder_finish: ") + hipGetErrorString(e)));
     }
+    unsigned long long set_counts[3] = {0, 0, 0};
+    if (b->deferred) {      // what set_values found no entry for
+        if (hipMemcpy(set_counts, b->d_set_counts, 24, hipMemcpyDeviceToHost) != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, "umgap_walk_builder_finish: copy failed"));
+        if (set_counts[2]) return done(fail(UMGAP_ERR_BUILD, "umgap_walk_builder_finish: " + std::to_string(set_counts[2]) + " keys were given two different values"));
+        if (set_counts[0] > b->left_cap)
+            return done(fail(UMGAP_ERR_BUILD, "umgap_walk_builder_finish: " + std::to_string(set_counts[0]) + " keys are not 9-mers of the proteome (room for " + std::to_string(b->left_cap) +
+                                                  "): a walk-order index wants the proteome its keys come from"));
+        n_left = set_counts[0];
+    }
     if (n_left) {
         if (b->n_walk + n_left > b->cap_walk) return done(fail(UMGAP_ERR_BUILD, "umgap_walk_builder_finish: more entries than the values table has keys (internal error)"));
-        if (hipMalloc((void**)&d_keys, n_left * 8) != hipSuccess || hipMalloc((void**)&d_taxa, n_left * 4) != hipSuccess || hipMalloc((void**)&d_pos, n_left * 4) != hipSuccess)
+        if (b->deferred) { d_keys = b->d_left_keys; d_taxa = b->d_left_vals; b->d_left_keys = nullptr; b->d_left_vals = nullptr; }     // (freed with the rest below)
+        if ((!b->deferred && (hipMalloc((void**)&d_keys, n_left * 8) != hipSuccess || hipMalloc((void**)&d_taxa, n_left * 4) != hipSuccess)) || hipMalloc((void**)&d_pos, n_left * 4) != hipSuccess)
             return done(fail(UMGAP_ERR_NOMEM, "umgap_walk_builder_finish: hipMalloc failed"));
         UMGAP_HIP(hipMemsetAsync(d_n, 0, 8, x->stream));
-        hipLaunchKernelGGL(k_walk_leftovers, dim3(grid_for(scan, 256, 256 * 16)), dim3(256), 0, x->stream, V, x->view, inv1, inv2, d_keys, d_taxa, d_n);
+        if (!b->deferred) hipLaunchKernelGGL(k_walk_leftovers, dim3(grid_for(scan, 256, 256 * 16)), dim3(256), 0, x->stream, V, x->view, inv1, inv2, d_keys, d_taxa, d_n);
         // the slots came from an atomic counter: sorted by key, so that the same input gives the same file, byte for byte
         {
             uint64_t* d_keys2 = nullptr;
@@ -1877,22 +2021,33 @@ int walk_finish(umgap_walk_builder* b, umgap_index** out, std::vector<std::pair<
     // the exception list (walk_ref.hpp): sorted by key, one entry per key
     x->walk_shift = b->shift;
     x->n_walk = b->n_walk;            // (set_walk_exceptions checks the listed positions against it)
-    if (b->shift) {
-        unsigned long long n_exc = 0;
-        if (hipMemcpy(&n_exc, b->d_exc_n, 8, hipMemcpyDeviceToHost) != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, "umgap_walk_builder_finish: copy failed"));
-        if (n_exc > WALK_EXC_CAP) return done(fail(UMGAP_ERR_BUILD, "umgap_walk_builder_finish: more than 2^22 keys share their low bits with a neighbour (low-complexity proteome?)"));
-        std::vector<uint64_t> raw(2 * (size_t)n_exc);
-        if (n_exc && hipMemcpy(raw.data(), b->d_exc, raw.size() * 8, hipMemcpyDeviceToHost) != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, "umgap_walk_builder_finish: copy failed"));
-        std::vector<std::pair<uint64_t, uint64_t>> ex(n_exc);
-        for (size_t i = 0; i < n_exc; i++) ex[i] = {raw[2 * i], raw[2 * i + 1]};
-        std::sort(ex.begin(), ex.end());
-        ex.erase(std::unique(ex.begin(), ex.end(), [](const std::pair<uint64_t, uint64_t>& p, const std::pair<uint64_t, uint64_t>& q) { return p.first == q.first; }), ex.end());
-        rc = set_walk_exceptions(x, ex);
-        if (rc) return done(rc);
-    }
+    if ((rc = walk_install_exceptions(b))) return done(rc);
     x->kind = 10;
     x->n_walk = b->n_walk;
     x->n_keys = b->values ? b->values->n_keys : b->expected_keys;     // (as announced, like umgap_index_build_windows9_dev's own count)
+    if (b->deferred) {
+        // entries nothing points at -- kept repeats, the second entries of keys a full chain sent to the stash twice -- take the value of
+        // their key's own entry (as the proteome's own builder settles them)
+        x->walk_zero_absent = true;
+        x->n_keys = set_counts[1] + set_counts[0];
+        const WalkRef W = walk_ref_of(x);
+        for (auto& kl : b->kept_lists)
+            hipLaunchKernelGGL(k_walk_settle_kept, dim3(grid_for(kl.second)), dim3(256), 0, x->stream, x->view, W, (const uint64_t*)kl.first, (size_t)kl.second);
+        uint64_t* d_dropped = nullptr;
+        hipError_t se = hipSuccess;
+        if (!b->dropped.empty()) {
+            std::vector<uint64_t> raw(2 * b->dropped.size());
+            for (size_t i = 0; i < b->dropped.size(); i++) { raw[2 * i] = b->dropped[i].first; raw[2 * i + 1] = b->dropped[i].second; }
+            se = hipMalloc((void**)&d_dropped, raw.size() * 8);
+            if (se == hipSuccess) se = hipMemcpy(d_dropped, raw.data(), raw.size() * 8, hipMemcpyHostToDevice);
+            if (se == hipSuccess) hipLaunchKernelGGL(k_walk_settle_dropped, dim3(grid_for(b->dropped.size())), dim3(256), 0, x->stream, x->view, W, (const uint64_t*)d_dropped, b->dropped.size(),
+                                                     inv_odd45(MIX_C1), inv_odd45(MIX_C2));
+        }
+        if (se == hipSuccess) se = hipGetLastError();
+        if (se == hipSuccess) se = hipStreamSynchronize(x->stream);
+        if (d_dropped) (void)hipFree(d_dropped);
+        if (se != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, std::string("umgap_walk_builder_finish: ") + hipGetErrorString(se)));
+    }
     *out = x;
     b->ix = nullptr;
     umgap_walk_builder_free(b);
@@ -2118,53 +2273,64 @@ int umgap_index_dump9(const umgap_index* ix, uint64_t* keys45, uint32_t* taxa, s
     const uint32_t m = ix->view.m, nb = ix->view.nb;
     size_t n = 0;
     const size_t chunk_buckets = 1u << 20;
-    std::vector<uint64_t> buf(chunk_buckets * SLOTS);
+    std::vector<uint64_t> buf(chunk_buckets * SLOTS), ck;
+    std::vector<uint32_t> cv;
+    // kind 10: the table's values are entry numbers; a chunk's keys go through the walk array on the device.  An index whose entries were
+    // valued after the fact (umgap_walk_builder_new_deferred) also holds the proteome's 9-mers that are no keys: value 0, left out here.
+    uint32_t* d_tmp = nullptr;
+    uint64_t* d_tk = nullptr;
+    auto done = [&](int code) { if (d_tmp) (void)hipFree(d_tmp); if (d_tk) (void)hipFree(d_tk); return code; };
+    const size_t step = chunk_buckets * SLOTS;
+    if (ix->kind == 10 && (hipMalloc((void**)&d_tmp, step * 4) != hipSuccess || hipMalloc((void**)&d_tk, step * 8) != hipSuccess))
+        return done(fail(UMGAP_ERR_NOMEM, "umgap_index_dump9: hipMalloc failed"));
+    auto flush = [&]() -> int {        // ck / cv: a chunk's keys and table values -> the output
+        if (ix->kind == 10 && !ck.empty()) {
+            if (hipMemcpyAsync(d_tmp, cv.data(), ck.size() * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
+                hipMemcpyAsync(d_tk, ck.data(), ck.size() * 8, hipMemcpyHostToDevice, ix->stream) != hipSuccess) return fail(UMGAP_ERR_DEVICE, "umgap_index_dump9: copy failed");
+            int r = walk_map_positions(ix, d_tk, d_tmp, ck.size(), 0u, ix->stream);
+            if (r) return r;
+            if (hipMemcpyAsync(cv.data(), d_tmp, ck.size() * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess || hipStreamSynchronize(ix->stream) != hipSuccess)
+                return fail(UMGAP_ERR_DEVICE, "umgap_index_dump9: copy failed");
+        }
+        for (size_t i = 0; i < ck.size(); i++) {
+            if (ix->walk_zero_absent && cv[i] == 0u) continue;
+            if (n < cap) { keys45[n] = ck[i]; taxa[n] = cv[i]; }
+            n++;
+        }
+        ck.clear();
+        cv.clear();
+        return UMGAP_OK;
+    };
     for (size_t b0 = 0; b0 < nb; b0 += chunk_buckets) {
         size_t cnt = std::min<size_t>(chunk_buckets, nb - b0);
-        UMGAP_HIP(hipMemcpy(buf.data(), ix->d_slots + b0 * SLOTS, cnt * 64, hipMemcpyDeviceToHost));
+        if (hipMemcpy(buf.data(), ix->d_slots + b0 * SLOTS, cnt * 64, hipMemcpyDeviceToHost) != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, "umgap_index_dump9: copy failed"));
         for (size_t i = 0; i < cnt * SLOTS; i++) {
             uint64_t e = buf[i];
             if (e == EMPTY_SLOT) continue;
             uint32_t lo = (uint32_t)e, d = (lo >> R_BITS) & 7u, r = lo & R_MASK;
             uint64_t bucket = b0 + i / SLOTS, home = (bucket + nb - d) % nb;
             uint64_t h = ((home / m) << R_BITS) | r;
-            if (n < cap) { keys45[n] = unmix45(h); taxa[n] = (uint32_t)(e >> 32); }
-            n++;
+            ck.push_back(unmix45(h));
+            cv.push_back((uint32_t)(e >> 32));
         }
+        if ((rc = flush())) return done(rc);
     }
     if (ix->n_stash) {
         std::vector<uint64_t> sk(ix->n_stash);
         std::vector<uint32_t> sv(ix->n_stash);
-        UMGAP_HIP(hipMemcpy(sk.data(), ix->d_stash_keys, sk.size() * 8, hipMemcpyDeviceToHost));
-        UMGAP_HIP(hipMemcpy(sv.data(), ix->d_stash_vals, sv.size() * 4, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < sk.size(); i++) {
-            uint64_t home = sk[i] >> R_BITS, r = sk[i] & R_MASK;
-            if (n < cap) { keys45[n] = unmix45(((home / m) << R_BITS) | r); taxa[n] = sv[i]; }
-            n++;
+        if (hipMemcpy(sk.data(), ix->d_stash_keys, sk.size() * 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(sv.data(), ix->d_stash_vals, sv.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            return done(fail(UMGAP_ERR_DEVICE, "umgap_index_dump9: copy failed"));
+        for (size_t i0 = 0; i0 < sk.size(); i0 += step) {
+            for (size_t i = i0; i < std::min(sk.size(), i0 + step); i++) {
+                uint64_t home = sk[i] >> R_BITS, r = sk[i] & R_MASK;
+                ck.push_back(unmix45(((home / m) << R_BITS) | r));
+                cv.push_back(sv[i]);
+            }
+            if ((rc = flush())) return done(rc);
         }
     }
     *n_out = n;
-    if (ix->kind == 10) {   // taxa[] holds window numbers: through the walk array, a chunk at a time
-        const size_t have = std::min(n, cap), step = 16u << 20;
-        uint32_t* d_tmp = nullptr;
-        uint64_t* d_tk = nullptr;
-        if (have && (hipMalloc((void**)&d_tmp, std::min(have, step) * 4) != hipSuccess || hipMalloc((void**)&d_tk, std::min(have, step) * 8) != hipSuccess)) {
-            if (d_tmp) (void)hipFree(d_tmp);
-            return fail(UMGAP_ERR_NOMEM, "umgap_index_dump9: hipMalloc failed");
-        }
-        for (size_t o = 0; o < have && !rc; o += step) {
-            const size_t len = std::min(step, have - o);
-            if (hipMemcpyAsync(d_tmp, taxa + o, len * 4, hipMemcpyHostToDevice, ix->stream) != hipSuccess ||
-                hipMemcpyAsync(d_tk, keys45 + o, len * 8, hipMemcpyHostToDevice, ix->stream) != hipSuccess) rc = fail(UMGAP_ERR_DEVICE, "umgap_index_dump9: copy failed");
-            if (!rc) rc = walk_map_positions(ix, d_tk, d_tmp, len, 0u, ix->stream);
-            if (!rc && (hipMemcpyAsync(taxa + o, d_tmp, len * 4, hipMemcpyDeviceToHost, ix->stream) != hipSuccess || hipStreamSynchronize(ix->stream) != hipSuccess))
-                rc = fail(UMGAP_ERR_DEVICE, "umgap_index_dump9: copy failed");
-        }
-        if (d_tmp) (void)hipFree(d_tmp);
-        if (d_tk) (void)hipFree(d_tk);
-        return rc;
-    }
-    return UMGAP_OK;
+    return done(UMGAP_OK);
 }
 
 // EXPERIMENT kept beside the product (tools/gather_streams.py; not in the public header): n random 64-byte quad probes with

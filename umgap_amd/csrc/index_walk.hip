@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void k_walk_lookup_prot9(TableView H2, WalkRef
         const bool again = valid && !walked && j != 0;
         if (again) ok2 = locate(H2, key, local2, tag2) ? 1u : 0u;
         uint32_t hit = miss;
-        if (walked) hit = (uint32_t)e;
+        if (walked) { hit = (uint32_t)e; if (hit == 0u && W.zero_absent) hit = miss; }    // (a 9-mer of the proteome that is no key)
         if (__any(again)) {                                            // wave-uniform
             wave_probe64_vals(H2, local2, tag2 | (ok2 << 31), UMGAP_NONE, lane, res);
             const uint32_t q2 = lane_result(res, lane);

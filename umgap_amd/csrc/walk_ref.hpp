@@ -21,6 +21,7 @@ struct WalkRef {
     uint64_t n = 0;
     uint32_t shift = 0;
     uint32_t n_exc = 0;
+    uint32_t zero_absent = 0;             // an entry with taxon 0 is a 9-mer of the proteome that is no key: answered with a miss
     const uint64_t* exc_keys = nullptr;   // sorted packed keys whose group holds another entry with the same low bits
     const uint64_t* exc_pos = nullptr;    // their positions
 };
@@ -33,6 +34,7 @@ inline WalkRef walk_ref_of(const umgap_index* ix) {
     W.n = ix->n_walk;
     W.shift = ix->walk_shift;
     W.n_exc = ix->n_walk_exc;
+    W.zero_absent = ix->walk_zero_absent ? 1u : 0u;
     W.exc_keys = ix->d_walk_exc_keys;
     W.exc_pos = ix->d_walk_exc_pos;
     return W;
@@ -65,7 +67,9 @@ __device__ __forceinline__ uint64_t walk_position(const WalkRef& W, uint32_t q, 
 // the taxon of that entry, or `miss`
 __device__ __forceinline__ uint32_t walk_taxon(const WalkRef& W, uint32_t q, uint64_t key, uint32_t miss) {
     const uint64_t p = walk_position(W, q, key);
-    return p == WALK_NOPOS ? miss : (uint32_t)W.E[p];
+    if (p == WALK_NOPOS) return miss;
+    const uint32_t t = (uint32_t)W.E[p];
+    return (t == 0u && W.zero_absent) ? miss : t;
 }
 
 }  // namespace umgap
