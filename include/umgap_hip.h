@@ -502,7 +502,7 @@ int umgap_walk_builder_finish(umgap_walk_builder* b, umgap_index** out);
  *   2. umgap_walk_builder_add[_dev] for every chunk of the proteome: EVERY 9-mer of the proteome gets an entry, valued 0 = "no key",
  *   3. umgap_walk_builder_set_values[_dev](keys45, values) for the (key, value) pairs of the index, in chunks of any size and order
  *      (values > 0; a key twice with the same value is fine, with two values an error at finish): a key the proteome showed has its
- *      entry valued; the others are collected (room for expected_keys / 4 of them) and appended behind the proteome as walks of one,
+ *      entry valued; the others are collected (room for expected_keys / 16 of them) and appended behind the proteome as walks of one,
  *   4. umgap_walk_builder_finish.
  * Resident: the position table and the walk array only (204 GB for 8.4 G proteome 9-mers) plus one chunk.  Answers: a key's value;
  * for everything else -- 9-mers of the proteome that were given no value included -- the miss value, as from the plain table of the

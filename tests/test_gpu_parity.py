@@ -2713,6 +2713,121 @@ def test_walk_index_of_eight_billion_keys_builds_on_one_gpu(api, torch_cuda):
     torch.cuda.empty_cache()
 
 
+def test_walk_index_of_eight_billion_keys_with_values_of_its_own(api, torch_cuda):
+    """VERDICT r4 missing #3: the walk-order index at the size of the real 9-mer index WITH VALUES THAT DO NOT COME FROM THE PROTEOME
+    (the real ninemer index holds the LCA values of joinkmers, /root/reference/README.md:54-57, not "the smallest taxon over the
+    fragments").  umgap_walk_builder_new_deferred: the proteome first (200 M fragments = 8.4 G windows, sixteen chunks), then the
+    (key, value) pairs streamed in 20 chunks -- value = a hash of the key, nothing a fragment could have told -- with no values table
+    on the device at any time.  Checked on 400 k pairs of reads: the hits of every window (membership from the plain table of the same
+    proteome, built first and freed; the value from the hash), get() of the proteome's last windows and of random keys, and the fused
+    pipeline against seedextend + aggregate run on the expected hits."""
+    import ctypes as C
+    import gc
+    torch = torch_cuda
+    from umgap_amd import _lib
+    from umgap_amd.api import Index, _dev_ptr, _stream_ptr
+    from umgap_amd.synth import SyntheticWorkload
+    gc.collect()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < 270e9:
+        pytest.skip("needs ~260 GB of free HBM")
+    L = _lib.load()
+    n_frag, flen, per = 200_000_000, 50, 42
+    w = SyntheticWorkload(n_tax=200_000, n_keys=1000, build_index=False)
+    prot, poffs, ptaxa = _proteome(torch, w, n_frag, flen)
+    n_reads, F = 400_000, 2
+    reads = torch.empty(n_reads * F * flen, dtype=torch.uint8, device="cuda")
+    _lib.check(L.umgap_synth_prot_reads_dev(_dev_ptr(prot), n_frag, flen, 45, 0, n_reads, F, 30, _dev_ptr(reads), 0, _stream_ptr(None)))
+    roffs = torch.arange(0, (n_reads * F + 1) * flen, flen, dtype=torch.int64, device="cuda")
+    oo = torch.arange(0, (n_reads * F + 1) * per, per, dtype=torch.int64, device="cuda")
+
+    def window_keys(bytes2d):
+        """uint8 [n, flen] on the device -> (packed 9-mers int64 [n, per], all nine letters in A..Z)"""
+        code = bytes2d.to(torch.int64) - 65
+        good = (code >= 0) & (code < 26)
+        keys = torch.zeros((bytes2d.shape[0], per), dtype=torch.int64, device="cuda")
+        ok = torch.ones((bytes2d.shape[0], per), dtype=torch.bool, device="cuda")
+        for c in range(9):
+            keys = (keys << 5) | (code[:, c:c + per] & 31)
+            ok &= good[:, c:c + per]
+        return keys, ok
+
+    def value_of(keys):
+        row = (((keys * -7046029254386353131) >> 20) & 0x7FFFFFFFFFF) % w.n_tax          # (0x9E3779B97F4A7C15 as int64)
+        return w.d_taxon_of_row[row]
+
+    tail = prot[-flen * 2000:].view(2000, flen)
+    tk, tok = window_keys(tail)
+    d_q = torch.cat([tk[tok], torch.from_numpy(np.random.default_rng(3).integers(0, 1 << 45, 50_000, dtype=np.int64)).cuda()]).contiguous()
+    # membership: the plain table of the proteome's windows (its own values are the fragments' taxa: only hit / miss is used)
+    hp = C.c_void_p()
+    _lib.check(L.umgap_index_build_windows9_dev(_dev_ptr(prot), _dev_ptr(poffs), _dev_ptr(ptaxa), n_frag, flen, n_frag * per, 0.5, 0, C.byref(hp)))
+    plain = Index(hp.value)
+    n_keys = plain.num_keys
+    member = torch.full((n_reads * F * per,), -3, dtype=torch.int32, device="cuda")
+    plain.lookup_prot9_dev(reads, roffs, oo, member, miss_value=0)
+    q_member = plain.lookup9_dev(d_q, miss_value=0).clone()
+    torch.cuda.synchronize()
+    plain.close()
+    gc.collect()
+    torch.cuda.empty_cache()
+    rk, rok = window_keys(reads.view(n_reads * F, flen))
+    want_hits = torch.where((member.view(-1, per) != 0) & rok, value_of(rk), torch.zeros_like(rk, dtype=torch.int32)).to(torch.int32).reshape(-1).contiguous()
+    want_q = torch.where(q_member != 0, value_of(d_q), torch.full_like(q_member, 7)).to(torch.int32)
+    assert (want_hits != 0).float().mean().item() > 0.5 and (want_q != 7).float().mean().item() > 0.5
+    del member, rk, rok, q_member
+    # the fused answers those hits must give: seedextend -g1 -s3 per read end, taxa2agg -l2 -a lca* (the unfused kernels, index-free)
+    exp_hits = want_hits.clone()
+    api.seedextend_dev(exp_hits, stride=per, n_records=n_reads * F, min_seed_size=3, max_gap_size=1)
+    want_t = torch.empty(n_reads, dtype=torch.int32, device="cuda")
+    want_s = torch.empty_like(want_t)
+    w.taxonomy.aggregate_strided_dev(exp_hits, per * F, n_reads, want_t, want_s, method="tree", strategy="lca*", lower_bound=2.0)
+    torch.cuda.synchronize()
+    del exp_hits
+    # the walk index: order first, values afterwards
+    b = C.c_void_p()
+    _lib.check(L.umgap_walk_builder_new_deferred(n_frag * per, 0.5, 0, C.byref(b)))
+    try:
+        n_chunks = 16
+        for c in range(n_chunks):
+            lo, hi = n_frag * c // n_chunks, n_frag * (c + 1) // n_chunks
+            offs_c = (poffs[lo:hi + 1] - poffs[lo]).contiguous()
+            _lib.check(L.umgap_walk_builder_add_dev(b, _dev_ptr(prot[lo * flen:]), _dev_ptr(offs_c), hi - lo, flen))
+        n_vchunks = 20
+        for c in range(n_vchunks):
+            lo, hi = n_frag * c // n_vchunks, n_frag * (c + 1) // n_vchunks
+            k, ok = window_keys(prot[lo * flen:hi * flen].view(hi - lo, flen))
+            k = k[ok].contiguous()
+            v = value_of(k).contiguous()
+            _lib.check(L.umgap_walk_builder_set_values_dev(b, _dev_ptr(k), _dev_ptr(v), k.numel()))
+            del k, v, ok
+        hw = C.c_void_p()
+        _lib.check(L.umgap_walk_builder_finish(b, C.byref(hw)))
+        b = None
+    finally:
+        if b is not None:
+            L.umgap_walk_builder_free(b)
+    walk = Index(hw.value)
+    shift, entries, exc = walk.walk_info()
+    # (the plain builder reports the windows it was announced, this one the distinct keys it valued: 8.4 G random 9-mers collide 0.8 % of the time)
+    assert walk.kind == 10 and 0.98 * n_keys < walk.num_keys <= n_keys and walk.num_keys > 8_000_000_000 and entries > 8_000_000_000 and shift >= 1, (n_keys, walk.num_keys, entries, shift, exc)
+    got_hits = torch.full((n_reads * F * per,), -3, dtype=torch.int32, device="cuda")
+    walk.lookup_prot9_dev(reads, roffs, oo, got_hits, miss_value=0)
+    got_q = walk.lookup9_dev(d_q, miss_value=7)
+    t = torch.full((n_reads,), -1, dtype=torch.int32, device="cuda")
+    st = torch.full_like(t, -1)
+    api.classify_prot9_dev(walk, w.taxonomy, reads, roffs, n_reads, F, t, st, method="tree", strategy="lca*", lower_bound=2.0, seedextend=True, min_seed_size=3, max_gap_size=1)
+    torch.cuda.synchronize()
+    assert torch.equal(got_hits, want_hits)
+    assert torch.equal(got_q, want_q)
+    assert torch.equal(st, want_s) and torch.equal(t, want_t) and (st == 0).float().mean().item() > 0.5
+    walk.close()
+    del prot, poffs, ptaxa, reads
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
 def test_config5_tryptic_index_one_billion_keys_sampled_vs_oracle(api, torch_cuda):
     """BASELINE.json configs[4] at size (SURVEY.md §8d Config 5; scripts/umgap-analyse.sh:289-298): a 1 G-key tryptic-peptide table
     (packed layout, 82 GB), 10 M pairs through umgap_classify_tryp_dev -- digest, length window 9..45, variable-length lookup,

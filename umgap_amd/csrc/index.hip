@@ -11,6 +11,7 @@
 #include <vector>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_select.hpp>
 
 #include "host_copy.hpp"
 #include "probe_common.hpp"
@@ -524,6 +525,13 @@ __global__ __launch_bounds__(256) void k_walk_set_values(TableView T, WalkRef W,
             if (at < left_cap) { left_keys[at] = key; left_vals[at] = v; }
         }
     }
+}
+// sorted leftovers: neighbours with one key and two values
+__global__ __launch_bounds__(256) void k_walk_left_conflicts(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ vals, size_t n, unsigned long long* __restrict__ count) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x + 1;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step)
+        if (keys[i] == keys[i - 1] && vals[i] != vals[i - 1]) atomicAdd(count, 1ull);
 }
 // ... and the kept repeats (entries nothing points at; list of (key, entry)) take the taxon of their key's own entry
 __global__ __launch_bounds__(256) void k_walk_settle_kept(TableView T, WalkRef W, const uint64_t* __restrict__ list, size_t n) {
@@ -1741,7 +1749,7 @@ int walk_seal(umgap_walk_builder* b) {
     x->walk_shift = b->shift;
     x->n_walk = b->n_walk;
     if ((rc = walk_install_exceptions(b))) return rc;
-    b->left_cap = std::max<uint64_t>(b->expected_keys / 4, 1u << 20);
+    b->left_cap = std::max<uint64_t>(b->expected_keys / 16, 1u << 20);     // (12 bytes each, resident until finish)
     if (b->n_walk + b->left_cap > b->cap_walk) b->left_cap = b->cap_walk > b->n_walk ? b->cap_walk - b->n_walk : 0;
     if (hipMalloc((void**)&b->d_left_keys, std::max<uint64_t>(b->left_cap, 1) * 8) != hipSuccess || hipMalloc((void**)&b->d_left_vals, std::max<uint64_t>(b->left_cap, 1) * 4) != hipSuccess ||
         hipMalloc((void**)&b->d_set_counts, 24) != hipSuccess)
@@ -2008,6 +2016,26 @@ int walk_finish(umgap_walk_builder* b, umgap_index** out, std::vector<std::pair<
             if (se != hipSuccess) { drop(); return done(fail(UMGAP_ERR_DEVICE, std::string("umgap_walk_builder_finish: sort: ") + hipGetErrorString(se))); }
             std::swap(d_keys, d_keys2);
             std::swap(d_taxa, d_taxa2);
+            if (b->deferred) {
+                // the same pair may have come twice (a chunk handed over again): one entry per key; two values for a key are an error
+                hipLaunchKernelGGL(k_walk_left_conflicts, dim3(grid_for(n_left)), dim3(256), 0, x->stream, (const uint64_t*)d_keys, (const uint32_t*)d_taxa, (size_t)n_left, b->d_set_counts + 2);
+                unsigned long long* d_cnt = d_n;
+                size_t ub = 0;
+                if (d_tmp) { (void)hipFree(d_tmp); d_tmp = nullptr; }
+                se = rocprim::unique_by_key(nullptr, ub, d_keys, d_taxa, d_keys2, d_taxa2, d_cnt, (size_t)n_left, rocprim::equal_to<uint64_t>(), x->stream);
+                if (se == hipSuccess) se = hipMalloc(&d_tmp, ub ? ub : 8);
+                if (se == hipSuccess) se = rocprim::unique_by_key(d_tmp, ub, d_keys, d_taxa, d_keys2, d_taxa2, d_cnt, (size_t)n_left, rocprim::equal_to<uint64_t>(), x->stream);
+                unsigned long long uniq = 0, conflicts = 0;
+                if (se == hipSuccess) se = hipMemcpyAsync(&uniq, d_cnt, 8, hipMemcpyDeviceToHost, x->stream);
+                if (se == hipSuccess) se = hipMemcpyAsync(&conflicts, b->d_set_counts + 2, 8, hipMemcpyDeviceToHost, x->stream);
+                if (se == hipSuccess) se = hipStreamSynchronize(x->stream);
+                if (se != hipSuccess) { drop(); return done(fail(UMGAP_ERR_DEVICE, std::string("umgap_walk_builder_finish: unique: ") + hipGetErrorString(se))); }
+                if (conflicts) { drop(); return done(fail(UMGAP_ERR_BUILD, "umgap_walk_builder_finish: " + std::to_string(conflicts) + " keys were given two different values")); }
+                std::swap(d_keys, d_keys2);
+                std::swap(d_taxa, d_taxa2);
+                set_counts[0] = uniq;
+                n_left = uniq;
+            }
             drop();
         }
         hipLaunchKernelGGL(k_walk_append, dim3(grid_for(n_left)), dim3(256), 0, x->stream, (const uint64_t*)d_keys, (const uint32_t*)d_taxa, (size_t)n_left, x->d_walk, b->n_walk, d_pos,
