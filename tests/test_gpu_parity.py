@@ -1748,9 +1748,43 @@ def test_walk_index_matches_plain_table(api, torch_cuda, mutations_per_mille, sh
         torch.cuda.synchronize()
         assert torch.equal(outs[0][1], outs[1][1]), (method, strategy, "status")
         assert torch.equal(outs[0][0], outs[1][0]), (method, strategy, "taxon")
-    # entry points that want a plain table say so
-    with pytest.raises(api.UmgapError):
-        api.classify9_dev(walk, w.taxonomy, q[:84], 1, 84, torch.empty(1, dtype=torch.int32, device="cuda"), torch.empty(1, dtype=torch.int32, device="cuda"))
+    # surface A on the walk index (round 5): PACKED 9-mers whose neighbours are consecutive windows -- what pept2lca gets from prot2kmer --
+    # through umgap_classify9[_strategy]_dev: one probe per run, the rest from the walk array; answers those of the plain table.  Reads
+    # of 2 x 42 windows (mutated proteome fragments, chimeras, '*' inside: keys that are no 9-mer), with and without the fragment
+    # structure (without it a run may cross from one fragment's last window into the next one's first), other strides
+    frag50 = [frags[int(i)][:50] for i in long_ids]
+    n2 = 1500
+    seqs = []
+    for r in range(n2 * 2):
+        f = bytearray(frag50[int(rng.integers(0, len(frag50)))])
+        for k in range(50):
+            if rng.random() * 1000 < mutations_per_mille:
+                f[k] = int(rng.choice(letters))
+        if mutations_per_mille and rng.random() < 0.1:
+            f[int(rng.integers(0, 50))] = 42
+        if mutations_per_mille and rng.random() < 0.1:
+            g = frag50[int(rng.integers(0, len(frag50)))]
+            k = int(rng.integers(1, 49))
+            f = f[:k] + bytearray(g[k:])
+        seqs.append(bytes(f))
+    arr = np.frombuffer(b"".join(seqs), np.uint8).reshape(n2 * 2, 50)
+    k2, ok2 = _pack_windows(arr)
+    k2 = np.where(ok2, k2, np.uint64(1 << 50)).reshape(-1)                     # (not a packed 9-mer: a miss, and the end of a walk)
+    d_k2 = torch.from_numpy(k2.view(np.int64).copy()).cuda()
+    for stride, fr, method, strategy, lb, se in ((84, 2, "tree", "lca*", 2.0, True), (84, 2, "tree", "lca*", 1.0, False), (84, 0, "rmq", "lca*", 0.0, False),
+                                                 (42, 1, "tree", "hybrid", 1.0, True), (84, 2, "rmq", "mrtl", 1.0, True), (28, 0, "rmq", "hybrid", 0.0, False), (126, 3, "tree", "lca*", 2.0, True)):
+        nr = len(k2) // stride
+        outs = []
+        for ix in (plain, walk):
+            t = torch.full((nr,), -1, dtype=torch.int32, device="cuda")
+            st = torch.full_like(t, -1)
+            api.classify9_dev(ix, w.taxonomy, d_k2, nr, stride, t, st, method=method, strategy=strategy, factor=0.25, lower_bound=lb,
+                              fragments_per_read=fr if se or fr else 0, min_seed_size=2 if se else 1, max_gap_size=1)
+            outs.append((t, st))
+        torch.cuda.synchronize()
+        assert torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][0], outs[1][0]), (stride, fr, method, strategy)
+        if mutations_per_mille == 0 and lb < 2:
+            assert (outs[0][1] == 0).float().mean().item() > 0.5
     # bound to the taxonomy (the walk array's taxa become interval codes, the table of window numbers stays): same answers, and
     # the plain get() calls are refused while bound, as for the plain table
     walk.bind(w.taxonomy)
@@ -2754,7 +2788,9 @@ def test_walk_index_of_eight_billion_keys_with_values_of_its_own(api, torch_cuda
         return keys, ok
 
     def value_of(keys):
-        row = (((keys * -7046029254386353131) >> 20) & 0x7FFFFFFFFFF) % w.n_tax          # (0x9E3779B97F4A7C15 as int64)
+        # one of four taxa, by a hash of the key (0x9E3779B97F4A7C15 as int64): nothing the fragment could have told, and few enough
+        # for runs of equal hits (seeds) and repeated taxa (-l 2) to occur
+        row = (((keys * -7046029254386353131) >> 20) & 3) * 1000 + 17
         return w.d_taxon_of_row[row]
 
     tail = prot[-flen * 2000:].view(2000, flen)
@@ -2821,7 +2857,7 @@ def test_walk_index_of_eight_billion_keys_with_values_of_its_own(api, torch_cuda
     torch.cuda.synchronize()
     assert torch.equal(got_hits, want_hits)
     assert torch.equal(got_q, want_q)
-    assert torch.equal(st, want_s) and torch.equal(t, want_t) and (st == 0).float().mean().item() > 0.5
+    assert torch.equal(st, want_s) and torch.equal(t, want_t) and (st == 0).float().mean().item() > 0.3
     walk.close()
     del prot, poffs, ptaxa, reads
     gc.collect()

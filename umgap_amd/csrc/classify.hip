@@ -111,6 +111,115 @@ __device__ __forceinline__ void probe_group_to_strip(const TableView& T, const u
 }
 
 
+// Walk-order index (round 5): packed 9-mers whose neighbours are consecutive windows of a protein -- the real input of pept2lca is
+// exactly that (prot2kmer prints every window of a fragment, /root/reference/src/commands/prot2kmer.rs) -- are answered by ONE probe per
+// run plus the walk-array entries behind it, as umgap_classify_prot9_dev does for residues.
+// Phase A: a lane owns a run of at most WALK_R consecutive keys of one fragment (runs never cross a fragment of the read).  The run's
+// first key is its anchor: a quad probe gives its entry number p (or says the key is absent: answered), and E[p .. p + WALK_R) are
+// fetched in one trip.  Along those entries the PROTEOME's own windows are rebuilt: entry p + k continues entry p + k - 1 (its flag)
+// means window p + k is the next window of the same protein, so its key is the previous one shifted by a residue -- the entry's low
+// five key bits.  Where that rebuilt key equals the read's key k, the entry is the key's entry (exact: all 45 bits compared) and its
+// taxon the answer; where it does not -- a changed residue in the read -- the key is left for phase B, and the walk goes ON: the read's
+// windows behind the changed residue meet the proteome's again, no second anchor needed.  (The first version re-anchored at every
+// break, step by step: as many requests, but sixteen dependent probe + fetch round trips per pass -- 26 ms per 10 M pairs at 3 %
+// divergence beside 17 ms over the plain table.)
+// Phase B: the keys phase A left open (marked in the strip) are probed like any key, two batches of 64 strip slots at a time; a batch
+// none of whose slots is open costs nothing.  A 9-mer of the proteome that is no key (deferred values) has taxon 0: a miss.
+constexpr uint32_t WALK_R = 16;
+constexpr uint32_t WALK_OPEN = 0xFFFFFFFFu;        // strip marker: not answered by a walk (no taxon id, no interval code is all ones)
+__device__ __forceinline__ void walk_group_to_strip(const TableView& T, const HitSource& H, const uint64_t* __restrict__ kp, uint32_t nk, uint32_t flen, uint32_t* wtaxa,
+                                                    uint32_t* list_words, uint32_t lane) {
+    WalkRef W;
+    W.E = H.walk_E; W.n = H.walk_n; W.shift = H.walk_shift; W.n_exc = H.walk_n_exc; W.exc_keys = H.walk_exc_keys; W.exc_pos = H.walk_exc_pos;
+    const uint32_t rpf = (flen + WALK_R - 1) / WALK_R;            // runs per fragment
+    const uint32_t n_runs = (nk / flen) * rpf;                     // (nk is a multiple of flen)
+    for (uint32_t run0 = 0; run0 < n_runs; run0 += 64) {           // wave-uniform
+        const uint32_t run = run0 + lane;
+        const uint32_t f = run / rpf, jr = run - f * rpf;
+        const uint32_t first = f * flen + jr * WALK_R;
+        const uint32_t n_mine = run < n_runs ? min(WALK_R, flen - jr * WALK_R) : 0u;
+        uint64_t key[WALK_R];
+#pragma unroll
+        for (uint32_t t = 0; t < WALK_R; t++) key[t] = t < n_mine ? __builtin_nontemporal_load(kp + first + t) : ~0ull;
+        uint32_t local = 0, tag = 0, valid = 0;
+        if (n_mine) valid = locate(T, key[0], local, tag) ? 1u : 0u;
+        ProbeBatch B;
+        uint32_t pr[4];
+        probe_issue(T, local, tag | (valid << 31), lane, B);
+        probe_eval(T, B, UMGAP_NONE, lane, pr);
+        // the answer to lane L's key sits, quad-uniform, in quad L & 15 as round L >> 4
+        const int src = 4 * (int)(lane & 15u);
+        const uint32_t v0 = (uint32_t)__shfl((int)pr[0], src, 64), v1 = (uint32_t)__shfl((int)pr[1], src, 64),
+                       v2 = (uint32_t)__shfl((int)pr[2], src, 64), v3 = (uint32_t)__shfl((int)pr[3], src, 64);
+        const uint32_t r4 = lane >> 4;
+        const uint32_t q32 = r4 == 0 ? v0 : (r4 == 1 ? v1 : (r4 == 2 ? v2 : v3));
+        const uint64_t pos = (n_mine && valid) ? walk_position(W, q32, key[0]) : WALK_NOPOS;
+        uint64_t e[WALK_R];
+#pragma unroll
+        for (uint32_t k = 0; k < WALK_R; k++) e[k] = (pos != WALK_NOPOS && k < n_mine && pos + k < W.n) ? W.E[pos + k] : WALK_PAD_ENTRY;
+        if (n_mine) {
+            wtaxa[first] = pos != WALK_NOPOS ? (uint32_t)e[0] : 0u;                 // the anchor was probed: its entry's taxon, or a miss
+            uint64_t K = key[0];
+            bool chain = pos != WALK_NOPOS;
+#pragma unroll
+            for (uint32_t k = 1; k < WALK_R; k++) {
+                if (k < n_mine) {
+                    const uint32_t ey = (uint32_t)(e[k] >> 32);
+                    chain = chain && (ey >> 31);                                     // entry p + k is the next window of the same protein
+                    K = ((K << 5) | (ey & 31u)) & MASK45;
+                    wtaxa[first + k] = (chain && K == key[k]) ? (uint32_t)e[k] : WALK_OPEN;
+                }
+            }
+        }
+    }
+    wave_lds_sync();
+    // ---- phase B: the open slots, COMPACTED (16-bit strip indices in the aggregate stage's count tables, which are idle and all zero now:
+    // 512 words = 1024 items), probed 128 at a time -- dense batches and as few dependent round trips as the open keys need, instead of
+    // one sparse batch per 128 slots of the strip ----
+    uint16_t* list = reinterpret_cast<uint16_t*>(list_words);
+    uint32_t U = 0;                                                // open slots so far (wave-uniform)
+    for (uint32_t c = 0; c * 64 < nk; c++) {                      // wave-uniform
+        const uint32_t i = c * 64 + lane;
+        const bool open = i < nk && wtaxa[i] == WALK_OPEN;
+        const uint64_t m = __ballot(open);
+        if (open) list[U + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = (uint16_t)i;
+        U += (uint32_t)__builtin_popcountll(m);
+    }
+    if (U == 0) return;
+    wave_lds_sync();
+    for (uint32_t i0 = 0; i0 < U; i0 += 128) {                    // wave-uniform
+        ProbeBatch B[2];
+        uint32_t pr[2][4], item[2];
+        uint64_t bkey[2];
+        const bool two = i0 + 64 < U;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            if (h == 1 && !two) { probe_skip(B[1]); item[1] = WALK_OPEN; bkey[1] = ~0ull; break; }   // wave-uniform
+            const uint32_t i = i0 + 64 * h + lane;
+            item[h] = i < U ? (uint32_t)list[i] : WALK_OPEN;
+            uint32_t local = 0, tag = 0, valid = 0;
+            bkey[h] = item[h] != WALK_OPEN ? __builtin_nontemporal_load(kp + item[h]) : ~0ull;
+            if (item[h] != WALK_OPEN) valid = locate(T, bkey[h], local, tag) ? 1u : 0u;
+            probe_issue(T, local, tag | (valid << 31), lane, B[h]);
+        }
+        probe_eval_multi<2>(T, B, UMGAP_NONE, lane, pr);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            if (h == 1 && !two) break;                             // wave-uniform
+            const int src = 4 * (int)(lane & 15u);
+            const uint32_t v0 = (uint32_t)__shfl((int)pr[h][0], src, 64), v1 = (uint32_t)__shfl((int)pr[h][1], src, 64),
+                           v2 = (uint32_t)__shfl((int)pr[h][2], src, 64), v3 = (uint32_t)__shfl((int)pr[h][3], src, 64);
+            const uint32_t r4 = lane >> 4;
+            const uint32_t q32 = r4 == 0 ? v0 : (r4 == 1 ? v1 : (r4 == 2 ? v2 : v3));
+            if (item[h] != WALK_OPEN) wtaxa[item[h]] = walk_taxon(W, q32, bkey[h], 0u);
+        }
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int i = 0; i < 8; i++) list_words[lane + 64 * i] = 0u;    // the count tables go back to all zero
+    wave_lds_sync();
+}
+
 // Sharded mode (shard.hip): the hits of a group were looked up by the shards that own the keys and came back over the
 // exchange.  The group is one RUN of the piece (shard_wire.hpp): the wave walks its keys in rounds of 64, recomputes owner and
 // rank of every key exactly as the pack did and finds the key's value at base[run][owner] + rank of the returned buffer (3 or 4
@@ -203,7 +312,7 @@ __device__ __forceinline__ void gather_run_to_strip(const TableView& T, const Hi
 // G * frags fragments at once (one lane each), and the G reads are aggregated one after another.
 // 94 VGPRs would allow 5 waves/SIMD; 4 measured faster (18.8 vs 19.6 ms): the request rate is the ceiling and a fifth
 // wave only adds contention.
-template <bool BOUND, bool GATHER>
+template <bool BOUND, int GATHER>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_classify9(TableView T, TaxView V, int method, const uint64_t* __restrict__ keys,
                                                    size_t n_reads, uint32_t stride, uint32_t frags, uint32_t min_seed, uint32_t max_gap,
                                                    float lower_bound, uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status, HitSource H) {
@@ -226,7 +335,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         const size_t r0 = g * G;
         const uint32_t nr = (uint32_t)min((size_t)G, n_reads - r0);
         const uint32_t nk = nr * stride;                   // keys of this group (<= STRIP)
-        if (GATHER) gather_run_to_strip(T, H, g, r0 * stride, 0u, nk, wtaxa, lane);
+        if (GATHER == SRC_GATHER) gather_run_to_strip(T, H, g, r0 * stride, 0u, nk, wtaxa, lane);
+        else if (GATHER == SRC_WALK) walk_group_to_strip(T, H, keys + r0 * stride, nk, frags ? stride / frags : stride, wtaxa, S.hkeys, lane);
         else probe_group_to_strip(T, keys + r0 * stride, nk, wtaxa, lane);
         wave_lds_sync();
         // ---- seedextend per fragment (one lane per fragment, nr * frags <= 64) ----
@@ -252,7 +362,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // high-sensitivity pipeline, scripts/umgap-analyse.sh:283-288) and rmq-hybrid: probe and seedextend as above, then every
 // read of the group goes through general_read (agg_general.hpp) with the LDS strip as its source.  A read with more
 // than CAP distinct taxa is deferred to a second launch over the `todo` list with a larger scratch (one read per group).
-template <int CAP, int HCAP, bool BOUND, bool GATHER>
+template <int CAP, int HCAP, bool BOUND, int GATHER>
 __global__ __launch_bounds__(256) void k_classify9_general(TableView T, TaxView V, int method, int strategy, float factor,
                                                            const uint64_t* __restrict__ keys, size_t n_reads, uint32_t stride, uint32_t frags,
                                                            uint32_t min_seed, uint32_t max_gap, float lower_bound,
@@ -276,7 +386,8 @@ __global__ __launch_bounds__(256) void k_classify9_general(TableView T, TaxView 
         const size_t r0 = todo ? (size_t)todo[g] : g * G;
         const uint32_t nr = todo ? 1u : (uint32_t)min((size_t)G, n_reads - r0);
         const uint32_t nk = nr * stride;
-        if (GATHER) {
+        if (GATHER == SRC_WALK) walk_group_to_strip(T, H, keys + r0 * stride, nk, frags ? stride / frags : stride, wtaxa, S.hkeys, lane);
+        else if (GATHER == SRC_GATHER) {
             // the runs of the exchange are the groups of the FIRST pass (H.run keys): a deferred read is found inside its run
             const size_t per_run = H.run / stride, run = r0 / per_run;
             const uint32_t lo = (uint32_t)(r0 - run * per_run) * stride;
@@ -310,7 +421,7 @@ __global__ __launch_bounds__(256) void k_classify9_general(TableView T, TaxView 
 // First pass of the same pipeline with the aggregate batched over the group (agg_group.hpp): the taxonomy round trips are
 // paid once per group and phase instead of once per read.  Reads with more than 64 distinct taxa go to the `defer` list, which
 // k_classify9_general<128, 512> (one read at a time, large scratch) then works through.
-template <bool BOUND, bool GATHER>
+template <bool BOUND, int GATHER>
 __global__ __launch_bounds__(256) void k_classify9_group(TableView T, TaxView V, int method, int strategy, float factor,
                                                          const uint64_t* __restrict__ keys, size_t n_reads, uint32_t stride, uint32_t frags,
                                                          uint32_t min_seed, uint32_t max_gap, float lower_bound,
@@ -332,7 +443,8 @@ __global__ __launch_bounds__(256) void k_classify9_group(TableView T, TaxView V,
         const size_t r0 = g * G;
         const uint32_t nr = (uint32_t)min((size_t)G, n_reads - r0);
         const uint32_t nk = nr * stride;
-        if (GATHER) gather_run_to_strip(T, H, g, r0 * stride, 0u, nk, wtaxa, lane);
+        if (GATHER == SRC_GATHER) gather_run_to_strip(T, H, g, r0 * stride, 0u, nk, wtaxa, lane);
+        else if (GATHER == SRC_WALK) walk_group_to_strip(T, H, keys + r0 * stride, nk, frags ? stride / frags : stride, wtaxa, S.hkeys, lane);
         else probe_group_to_strip(T, keys + r0 * stride, nk, wtaxa, lane);
         wave_lds_sync();
         uint64_t se_panic = 0;
@@ -802,7 +914,7 @@ int launch_classify9_from_hits(umgap_index* ix, umgap_taxonomy* tx, int method, 
     TaxView V = view_of(tx, ranked_only);
     const TableView shard = ix->view;    // the rank's own keys (perm = LOCAL) are probed by these kernels
     if (strategy == UMGAP_STRATEGY_LCA_STAR) {
-        hipLaunchKernelGGL((k_classify9<false, true>), dim3((unsigned)g), dim3(256), 0, s, shard, V, method, (const uint64_t*)nullptr, n_reads, kmers_per_read,
+        hipLaunchKernelGGL((k_classify9<false, SRC_GATHER>), dim3((unsigned)g), dim3(256), 0, s, shard, V, method, (const uint64_t*)nullptr, n_reads, kmers_per_read,
                            fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status, H);
     } else {
         if (n_reads >= 0xFFFFFFFFull) return fail(UMGAP_ERR_INVALID, "at most 2^32 - 2 reads per call");
@@ -811,10 +923,10 @@ int launch_classify9_from_hits(umgap_index* ix, umgap_taxonomy* tx, int method, 
         uint32_t* d_count = d_defer;
         uint32_t* d_list = d_defer + 1;
         UMGAP_HIP(hipMemsetAsync(d_count, 0, sizeof(uint32_t), s));
-        hipLaunchKernelGGL((k_classify9_group<false, true>), dim3((unsigned)g), dim3(256), 0, s, shard, V, method, strategy, factor, (const uint64_t*)nullptr,
+        hipLaunchKernelGGL((k_classify9_group<false, SRC_GATHER>), dim3((unsigned)g), dim3(256), 0, s, shard, V, method, strategy, factor, (const uint64_t*)nullptr,
                            n_reads, kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status,
                            d_list, d_count, H);
-        hipLaunchKernelGGL((k_classify9_general<128, 512, false, true>), dim3(256), dim3(256), 0, s, shard, V, method, strategy, factor, (const uint64_t*)nullptr,
+        hipLaunchKernelGGL((k_classify9_general<128, 512, false, SRC_GATHER>), dim3(256), dim3(256), 0, s, shard, V, method, strategy, factor, (const uint64_t*)nullptr,
                            n_reads, kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status,
                            (const uint32_t*)d_list, (const uint32_t*)d_count, (uint32_t*)nullptr, (uint32_t*)nullptr, H);
     }
@@ -822,6 +934,19 @@ int launch_classify9_from_hits(umgap_index* ix, umgap_taxonomy* tx, int method, 
     return UMGAP_OK;
 }
 }  // namespace umgap
+
+namespace {
+HitSource walk_source(const umgap_index* ix) {
+    HitSource H;
+    H.walk_E = ix->d_walk;
+    H.walk_n = ix->n_walk;
+    H.walk_shift = ix->walk_shift;
+    H.walk_n_exc = ix->n_walk_exc;
+    H.walk_exc_keys = ix->d_walk_exc_keys;
+    H.walk_exc_pos = ix->d_walk_exc_pos;
+    return H;
+}
+}  // namespace
 
 extern "C" int umgap_classify9_dev(umgap_index* ix, umgap_taxonomy* tx, int method, float lower_bound, int ranked_only,
                                    const uint64_t* d_keys45, size_t n_reads, uint32_t kmers_per_read, uint32_t fragments_per_read,
@@ -832,7 +957,7 @@ extern "C" int umgap_classify9_dev(umgap_index* ix, umgap_taxonomy* tx, int meth
     if (fragments_per_read && (kmers_per_read % fragments_per_read) != 0) return fail(UMGAP_ERR_INVALID, "umgap_classify9_dev: kmers_per_read must be a multiple of fragments_per_read");
     if (fragments_per_read > 64) return fail(UMGAP_ERR_INVALID, "umgap_classify9_dev: at most 64 fragments per read");
     if (method != UMGAP_METHOD_TREE && method != UMGAP_METHOD_RMQ) return fail(UMGAP_ERR_INVALID, "unknown method");
-    if (ix->kind != 9) return fail(UMGAP_ERR_INVALID, "umgap_classify9_dev: needs a 9-mer index");
+    if (ix->kind != 9 && ix->kind != 10) return fail(UMGAP_ERR_INVALID, "umgap_classify9_dev: needs a 9-mer index");
     if (ix->device != tx->device) return fail(UMGAP_ERR_INVALID, "umgap_classify9_dev: index and taxonomy live on different devices");
     int rc = use_device(ix->device);
     if (rc) return rc;
@@ -843,11 +968,19 @@ extern "C" int umgap_classify9_dev(umgap_index* ix, umgap_taxonomy* tx, int meth
     size_t g = (groups + 3) / 4;
     if (g > 256 * 8) g = 256 * 8;     // measured: 8 workgroups per CU (two resident rounds) beats 4 and 16
     if (ix->bound_to && ix->bound_to != tx) return fail(UMGAP_ERR_INVALID, "umgap_classify9_dev: the index is bound to another taxonomy");
-    if (ix->bound_to)
-        hipLaunchKernelGGL((k_classify9<true, false>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, d_keys45, n_reads,
+    if (ix->kind == 10) {      // walk order: one probe per run of neighbouring 9-mers, the rest from the walk array (walk_group_to_strip)
+        const HitSource H = walk_source(ix);
+        if (ix->bound_to)
+            hipLaunchKernelGGL((k_classify9<true, SRC_WALK>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, d_keys45, n_reads,
+                               kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status, H);
+        else
+            hipLaunchKernelGGL((k_classify9<false, SRC_WALK>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, d_keys45, n_reads,
+                               kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status, H);
+    } else if (ix->bound_to)
+        hipLaunchKernelGGL((k_classify9<true, SRC_PROBE>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, d_keys45, n_reads,
                            kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status, HitSource{});
     else
-        hipLaunchKernelGGL((k_classify9<false, false>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, d_keys45, n_reads,
+        hipLaunchKernelGGL((k_classify9<false, SRC_PROBE>), dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, ix->view, view_of(tx, ranked_only), method, d_keys45, n_reads,
                            kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status, HitSource{});
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
@@ -862,7 +995,7 @@ extern "C" int umgap_classify9_strategy_dev(umgap_index* ix, umgap_taxonomy* tx,
                                    max_gap_size, d_out_taxon, d_out_status, stream);
     if (!ix || !tx || (n_reads && (!d_keys45 || !d_out_taxon || !d_out_status))) return fail(UMGAP_ERR_INVALID, "umgap_classify9_strategy_dev: null argument");
     if (ix->bound_to && ix->bound_to != tx) return fail(UMGAP_ERR_INVALID, "umgap_classify9_strategy_dev: the index is bound to another taxonomy");
-    if (ix->kind != 9) return fail(UMGAP_ERR_INVALID, "umgap_classify9_strategy_dev: needs a 9-mer index");
+    if (ix->kind != 9 && ix->kind != 10) return fail(UMGAP_ERR_INVALID, "umgap_classify9_strategy_dev: needs a 9-mer index");
     if (kmers_per_read == 0 || kmers_per_read > 128) return fail(UMGAP_ERR_INVALID, "umgap_classify9_strategy_dev: kmers_per_read must be in 1..128 (use lookup9 + aggregate for longer reads)");
     if (fragments_per_read && (kmers_per_read % fragments_per_read) != 0) return fail(UMGAP_ERR_INVALID, "umgap_classify9_strategy_dev: kmers_per_read must be a multiple of fragments_per_read");
     if (fragments_per_read > 64) return fail(UMGAP_ERR_INVALID, "umgap_classify9_strategy_dev: at most 64 fragments per read");
@@ -887,14 +1020,16 @@ extern "C" int umgap_classify9_strategy_dev(umgap_index* ix, umgap_taxonomy* tx,
     if (g > 256 * 8) g = 256 * 8;
     TaxView V = view_of(tx, ranked_only);
     // first pass, then the reads with more than 64 distinct taxa (at most 128: kmers_per_read <= 128)
-#define UMGAP_LAUNCH_GENERAL(BOUND)                                                                                                              \
-    hipLaunchKernelGGL((k_classify9_group<BOUND, false>), dim3((unsigned)g), dim3(256), 0, s, ix->view, V, method, strategy, factor, d_keys45,         \
+    const HitSource HS = ix->kind == 10 ? walk_source(ix) : HitSource{};
+#define UMGAP_LAUNCH_GENERAL(BOUND, SRC)                                                                                                         \
+    hipLaunchKernelGGL((k_classify9_group<BOUND, SRC>), dim3((unsigned)g), dim3(256), 0, s, ix->view, V, method, strategy, factor, d_keys45,           \
                        n_reads, kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status,           \
-                       d_list, d_count, HitSource{});                                                                                              \
-    hipLaunchKernelGGL((k_classify9_general<128, 512, BOUND, false>), dim3(256), dim3(256), 0, s, ix->view, V, method, strategy, factor, d_keys45, n_reads, \
+                       d_list, d_count, HS);                                                                                                       \
+    hipLaunchKernelGGL((k_classify9_general<128, 512, BOUND, SRC>), dim3(256), dim3(256), 0, s, ix->view, V, method, strategy, factor, d_keys45, n_reads, \
                        kmers_per_read, fragments_per_read, min_seed_size, max_gap_size, lower_bound, d_out_taxon, d_out_status,                    \
-                       (const uint32_t*)d_list, (const uint32_t*)d_count, (uint32_t*)nullptr, (uint32_t*)nullptr, HitSource{})
-    if (ix->bound_to) { UMGAP_LAUNCH_GENERAL(true); } else { UMGAP_LAUNCH_GENERAL(false); }
+                       (const uint32_t*)d_list, (const uint32_t*)d_count, (uint32_t*)nullptr, (uint32_t*)nullptr, HS)
+    if (ix->kind == 10) { if (ix->bound_to) { UMGAP_LAUNCH_GENERAL(true, SRC_WALK); } else { UMGAP_LAUNCH_GENERAL(false, SRC_WALK); } }
+    else if (ix->bound_to) { UMGAP_LAUNCH_GENERAL(true, SRC_PROBE); } else { UMGAP_LAUNCH_GENERAL(false, SRC_PROBE); }
 #undef UMGAP_LAUNCH_GENERAL
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;

@@ -35,7 +35,15 @@ struct HitSource {
                                       // (UMGAP_SHARD_NO_LOCAL=1: region `self` is then packed, probed and gathered too)
     uint32_t run = 1024;              // keys per run
     uint64_t cap = 0;                 // slots per region
+    // SRC_WALK (classify.hip): not an exchange at all -- the index is in walk order and these name its walk array
+    const uint64_t* walk_E = nullptr;
+    uint64_t walk_n = 0;
+    uint32_t walk_shift = 0, walk_n_exc = 0;
+    const uint64_t* walk_exc_keys = nullptr;
+    const uint64_t* walk_exc_pos = nullptr;
 };
+// where the hits of a group of the fused 9-mer kernels come from
+constexpr int SRC_PROBE = 0, SRC_GATHER = 1, SRC_WALK = 2;
 
 // reads a wave of the fused classify kernels takes together (classify.hip): the run of the exchange is that many reads
 inline uint32_t classify9_group_reads(uint32_t kmers_per_read, uint32_t fragments_per_read) {
