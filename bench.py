@@ -836,6 +836,18 @@ def main():
             out["surface_b"] = {"error": "%s: %s" % (type(e).__name__, e)}
         torch.cuda.empty_cache()
         try:
+            # surface A with OVERLAPPING k-mers (what pept2lca really gets: every window of a fragment, prot2kmer.rs) over the plain table and
+            # over the walk-order index of the same proteome through umgap_classify9_dev: one probe per run of neighbouring 9-mers
+            # (tools/bench_surface_a_walk.py; requests per k-mer from the PMC pass in profiles/r05_surface_a_pmc.json)
+            import bench_surface_a_walk
+            sa = bench_surface_a_walk.run(50_000_000, 10_000_000, 30, steps=3, workload=w)
+            sa["requests_per_kmer"] = {"source": "profiles/r05_surface_a_pmc.json (TCC_EA0_RDREQ_sum per k-mer, key stream of 0.125 included; not re-measured in this run)",
+                                       "plain_table": 1.02, "walk_order_index": 0.63, "walk_order_index_reads_that_follow_the_proteome": 0.34}
+            out["surface_a_overlapping"] = sa
+        except Exception as e:  # noqa: BLE001
+            out["surface_a_overlapping"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+        try:
             # a pair translated in all six frames (12 fragments, 504 windows: the sensitivity pipelines, umgap-analyse.sh:277-288) through the
             # LONG variant of the fused kernel, beside the 2 x 50 gene-fragment form of the same pairs (tools/bench_six_frame.py)
             import bench_six_frame
