@@ -124,11 +124,15 @@ __global__ void k_varp_selfcheck(const uint32_t* __restrict__ got, const uint32_
 }
 
 // ---- the probe ----------------------------------------------------------------------------------------------------------------
-// four key bytes (one little-endian word, nv of them valid) -> their 20-bit group; a valid byte outside 'A'..'Z' raises `bad`
-// (the byte-parallel test of pack_inline_words, var_index.hpp)
+// four key bytes (one little-endian word, nv of them valid) -> their 20-bit group; a valid byte outside 0x40..0x5F raises `bad`.
+// (Round 5: the test is the two instructions "is the byte in the 32 codes around the capitals", not the six of the exact 'A'..'Z' test
+// of pack_inline_words.  The six bytes it lets through beside the capitals -- '@' and '[' .. '_' -- come out as residue codes 31 and
+// 26 .. 30, which no key of the table holds (the builder takes 'A'..'Z' only, varp_pack_bytes): a query with such a byte cannot equal a
+// key in the slot that holds it and is a miss like before, through a probe instead of without one.  A borrow of the subtraction below
+// can only change the codes of a query that already has such a byte.)
 __device__ __forceinline__ uint32_t varp_group(uint32_t x, int nv, uint32_t& bad) {
     const uint32_t mask = nv >= 4 ? 0xFFFFFFFFu : (nv <= 0 ? 0u : (0xFFFFFFFFu >> (32 - 8 * nv)));
-    bad |= (x | (x + 0x25252525u) | ~((x | 0x80808080u) - 0x41414141u)) & 0x80808080u & mask;
+    bad |= (x ^ 0x40404040u) & 0xE0E0E0E0u & mask;
     const uint32_t c = (x - 0x41414141u) & mask;
     const uint32_t t = (c & 0x001F001Fu) | ((c & 0x1F001F00u) >> 3);
     return (t & 0x3FFu) | ((t >> 6) & 0xFFC00u);
