@@ -738,6 +738,51 @@ __global__ __launch_bounds__(256) void k_gather_mlp(const uint64_t* __restrict__
     if (t < n) out[t] = acc;
 }
 
+// EXPERIMENT (round 5): is there request capacity BESIDE the vector cache?  The ceiling of the gather above is the vector cache's store of
+// outstanding misses; scalar loads go through the scalar data cache, a path of its own.  The same gather -- 128
+// vector probes per wave step -- plus KS random 64-byte buckets per wave step fetched with s_load_dwordx16 (one bucket = one scalar
+// load; the address must be wave-uniform).  If the step takes no longer, the scalar probes came for free.
+typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+template <int KS>
+__global__ __launch_bounds__(256) void k_gather_scalar_mix(const uint64_t* __restrict__ slots, uint32_t nb, size_t n, uint32_t* __restrict__ out) {
+    constexpr int LANES = 4, U = 8;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = ((size_t)gridDim.x * blockDim.x) / LANES;
+    const uint32_t j = threadIdx.x % LANES;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));
+    uint32_t acc = 0, sacc = 0;
+    uint32_t step = 0;
+    for (size_t i = t / LANES; i < n; i += stride * U, step++) {
+        u32x4 e[U];
+        u32x16 sv[KS > 0 ? KS : 1];
+#pragma unroll
+        for (int k = 0; k < KS; k++) {
+            const uint64_t hs = mix45((((uint64_t)wave << 24) ^ ((uint64_t)step * KS + k)) * 0xD1B54A32D192ED03ull >> 19);
+            const uint32_t b = __umulhi((uint32_t)hs, nb);
+            const uint64_t addr = (uint64_t)(uintptr_t)slots + (uint64_t)b * 64;
+            const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)addr), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(addr >> 32));
+            const uint64_t sa = ((uint64_t)hi << 32) | lo;
+            asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=s"(sv[k]) : "s"(sa) : "memory");
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            size_t ii = i + (size_t)u * stride;
+            uint64_t h = mix45(ii * 0x9E3779B97F4A7C15ull >> 19);
+            uint32_t bucket = __umulhi((uint32_t)h, nb);
+            e[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(slots) + ((size_t)bucket * 4 + j));
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) acc ^= e[u].x ^ e[u].y ^ e[u].z ^ e[u].w;
+        if constexpr (KS > 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int k = 0; k < KS; k++)
+#pragma unroll
+                for (int w = 0; w < 16; w++) sacc ^= sv[k][w];
+        }
+    }
+    if (t < n) out[t] = acc ^ sacc;
+}
 // the same 64-byte quad gather, 8 in flight per lane, with the load's cache-policy bits spelled out (gfx950: sc0, sc1, nt):
 // does any policy move the random-sector ceiling?  Loads are inline asm, so the wait is explicit.
 template <int POL>
@@ -2426,6 +2471,14 @@ int umgap_bench_gather_dev(umgap_index* ix, size_t n, uint32_t bytes_per_probe, 
     }
     if (bytes_per_probe >> 16) {   // bits 16+: that many probes in flight per lane, no store per probe (pure random-read rate)
         const uint32_t fl = (bytes_per_probe >> 16) & 0xFFu, bytes = bytes_per_probe & 0xFFFFu;
+        if (bytes == 65 || bytes == 66 || bytes == 68 || bytes == 72) {      // 64 + KS: the gather with KS scalar-path probes per wave step beside it (round 5)
+            if (bytes == 65) hipLaunchKernelGGL((k_gather_scalar_mix<1>), dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out);
+            else if (bytes == 66) hipLaunchKernelGGL((k_gather_scalar_mix<2>), dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out);
+            else if (bytes == 68) hipLaunchKernelGGL((k_gather_scalar_mix<4>), dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out);
+            else hipLaunchKernelGGL((k_gather_scalar_mix<0>), dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out);
+            UMGAP_HIP(hipGetLastError());
+            return UMGAP_OK;
+        }
         if (bytes == 64 && fl == 2) hipLaunchKernelGGL((k_gather_mlp<4, 2>), dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out);
         else if (bytes == 64 && fl == 4) hipLaunchKernelGGL((k_gather_mlp<4, 4>), dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out);
         else if (bytes == 64 && fl == 8) hipLaunchKernelGGL((k_gather_mlp<4, 8>), dim3(g), dim3(256), 0, s, ix->view.slots, nb, n, d_out);
