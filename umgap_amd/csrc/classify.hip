@@ -654,7 +654,7 @@ __global__ __launch_bounds__(256, BIG ? 2 : (GENERAL ? 3 : 4)) void k_classify_p
         }
         if constexpr (WALK) {
             // ---- phase 1: the first window of every run is its ANCHOR: one quad-probe batch (lane = key), then the walk ----
-            uint32_t done_n = 0;                                   // windows [0, done_n) of the run have their answer in the strip
+            uint32_t open_mask = 0;                                // windows of the run (bit t) that phase 1 leaves to phase 2 (a run has at most 16)
             {
                 uint64_t akey = 0;
                 uint32_t apoison = 0;
@@ -681,31 +681,35 @@ __global__ __launch_bounds__(256, BIG ? 2 : (GENERAL ? 3 : 4)) void k_classify_p
                 const WalkRef& WR = WK.W;
                 const uint64_t pos = (run_cnt && valid) ? walk_position(WR, q32, akey) : WALK_NOPOS;
                 if (run_cnt) {
-                    if (pos == WALK_NOPOS) { wtaxa[sb] = 0u; done_n = 1; }   // the anchor is not in the table: no hit
-                    else {
-                        // the walk: entries pos, pos + 1, ... four at a time (consecutive: the next four mostly lie in a sector already fetched),
-                        // each verified against the rolling key
-                        uint64_t wkey = akey;
-                        uint32_t wpoison = 0;
-                        bool go = true;
-                        for (uint32_t c0 = 0; go && c0 < run_cnt; c0 += 16) {
-                            uint64_t e[16];
+                    // The walk (round 5: it goes ON behind a window that does not match).  Along the entries pos, pos + 1, ... the PROTEOME's own
+                    // windows are rebuilt: entry p + t continues entry p + t - 1 (its flag) means window p + t is the next window of the same
+                    // protein, so its key is the previous one shifted by the entry's low five key bits.  Where that key equals the read's
+                    // rolling key (all 45 bits: exact) the entry's taxon is the answer; where not -- a changed residue in the read: nine windows
+                    // -- the window is left to phase 2 and the walk continues: behind the changed residue the read meets the proteome again.
+                    // (Rounds 3-4 stopped the walk at the first mismatch and probed every window behind it.)  A window with a byte outside
+                    // 'A'..'Z' is no key: answered here.
+                    uint64_t wkey = akey, K = akey;
+                    uint32_t wpoison = apoison;
+                    bool chain = pos != WALK_NOPOS;
+                    for (uint32_t c0 = 0; c0 < run_cnt; c0 += 16) {
+                        uint64_t e[16];
 #pragma unroll
-                            for (uint32_t k = 0; k < 16; k++) e[k] = (c0 + k < run_cnt && pos + c0 + k < WR.n) ? WR.E[pos + c0 + k] : WALK_PAD_ENTRY;   // (past the end: low bits that match no window)
+                        for (uint32_t k = 0; k < 16; k++) e[k] = (chain && c0 + k < run_cnt && pos + c0 + k < WR.n) ? WR.E[pos + c0 + k] : WALK_PAD_ENTRY;   // (past the end: continues nothing)
 #pragma unroll
-                            for (uint32_t k = 0; k < 16; k++) {
-                                const uint32_t t = c0 + k;
-                                if (go && t < run_cnt) {
-                                    bool ok = true;
-                                    if (t) {                       // the next residue enters, the oldest leaves
-                                        const uint32_t code = (uint32_t)wbytes[bo + t + 8] - 'A';
-                                        wkey = ((wkey << 5) | (code & 31u)) & MASK45;
-                                        wpoison = code >= 26u ? 9u : (wpoison ? wpoison - 1u : 0u);
-                                        const uint32_t ey = (uint32_t)(e[k] >> 32);
-                                        ok = wpoison == 0 && (ey >> 31) && (ey & 0x7FFFFFFFu) == ((uint32_t)wkey & 0x7FFFFFFFu);
-                                    }
-                                    if (ok) { wtaxa[sb + t] = (uint32_t)e[k]; done_n = t + 1; }
-                                    else go = false;
+                        for (uint32_t k = 0; k < 16; k++) {
+                            const uint32_t t = c0 + k;
+                            if (t < run_cnt) {
+                                if (t == 0) wtaxa[sb] = chain ? (uint32_t)e[0] : 0u;     // the anchor was probed (or holds no key): answered
+                                else {                                                // the next residue enters, the oldest leaves
+                                    const uint32_t code = (uint32_t)wbytes[bo + t + 8] - 'A';
+                                    wkey = ((wkey << 5) | (code & 31u)) & MASK45;
+                                    wpoison = code >= 26u ? 9u : (wpoison ? wpoison - 1u : 0u);
+                                    const uint32_t ey = (uint32_t)(e[k] >> 32);
+                                    chain = chain && (ey >> 31);
+                                    K = ((K << 5) | (uint64_t)(ey & 31u)) & MASK45;
+                                    if (wpoison) wtaxa[sb + t] = 0u;
+                                    else if (chain && K == wkey) wtaxa[sb + t] = (uint32_t)e[k];
+                                    else open_mask |= 1u << (t & 31u);
                                 }
                             }
                         }
@@ -717,16 +721,21 @@ __global__ __launch_bounds__(256, BIG ? 2 : (GENERAL ? 3 : 4)) void k_classify_p
             // lane = list item -- dense batches instead of one sparse step per window of the longest hole; a hit takes its taxon from
             // the walk array ----
             {
-                const uint32_t mine_n = run_cnt - done_n;
+                const uint32_t mine_n = (uint32_t)__builtin_popcount(open_mask);
                 uint32_t incl2 = mine_n;
 #pragma unroll
                 for (int o = 1; o < 64; o <<= 1) { const uint32_t tt = (uint32_t)__shfl_up((int)incl2, o, 64); if (lane >= (uint32_t)o) incl2 += tt; }
                 const uint32_t my_first = incl2 - mine_n, U = (uint32_t)__shfl((int)incl2, 63, 64);       // U = unanswered windows of the group (wave-uniform)
                 uint32_t* list = wkeys;                                  // 512 words: keys[256] and cnt[256] lie back to back
                 for (uint32_t l0 = 0; l0 < U; l0 += 512) {               // wave-uniform; one trip unless more than half the strip is unanswered
-                    for (uint32_t x = 0; x < mine_n; x++) {
-                        const uint32_t at = my_first + x;
-                        if (at >= l0 && at < l0 + 512) list[at - l0] = (sb + done_n + x) | ((bo + done_n + x) << 10);
+                    {
+                        uint32_t m = open_mask, at = my_first;
+                        while (m) {
+                            const uint32_t t = (uint32_t)__builtin_ctz(m);
+                            m &= m - 1u;
+                            if (at >= l0 && at < l0 + 512) list[at - l0] = (sb + t) | ((bo + t) << 10);
+                            at++;
+                        }
                     }
                     wave_lds_sync();
                     const uint32_t n_here = U - l0 < 512u ? U - l0 : 512u;
