@@ -333,6 +333,18 @@ int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int method, int 
                            const uint64_t* frag_offsets, size_t n_fragments, const uint64_t* read_frags,
                            size_t n_reads, int seedextend, uint32_t min_seed_size, uint32_t max_gap_size,
                            uint32_t* out_taxon, uint32_t* out_status);
+/* The same call with the residues in PIECES laid end to end (round 5): piece i holds the bytes [piece_ends[i - 1], piece_ends[i]) of
+ * the array `bytes` would have been (piece_ends[-1] = 0; frag_offsets index that concatenation; a fragment may run across pieces).
+ * A host that tokenizes a block of FASTA on several threads has one residue buffer per thread: pieces from umgap_host_alloc are
+ * copied to the device from where they lie (`umgap prot2kmer2agg` saves the memcpy that gathered them: 16 M pairs stream through
+ * in 0.26-0.29 s instead of 0.34-0.37 s, profiles/r05_fused_pieces_ab.json); pageable pieces are gathered into the pinned staging,
+ * one threaded memcpy as before. */
+int umgap_classify_records_sg(umgap_index* ix, umgap_taxonomy* tx, int method, int strategy, float factor,
+                              float lower_bound, int ranked_only, const uint8_t* const* pieces,
+                              const uint64_t* piece_ends, size_t n_pieces, const uint64_t* frag_offsets,
+                              size_t n_fragments, const uint64_t* read_frags, size_t n_reads, int seedextend,
+                              uint32_t min_seed_size, uint32_t max_gap_size, uint32_t* out_taxon,
+                              uint32_t* out_status);
 /* What `prot2kmer2lca` does per record (src/commands/prot2kmer2lca.rs:172-179: every 9-residue window of the record through
  * fst::Map::get) for a whole block of records in ONE call, the windows cut on the device: fragment f = bytes[frag_offsets[f] ..
  * frag_offsets[f+1]) (host memory; pinned arrays are copied from / to directly), out_hits[b - frag_offsets[0]] = value of the 9-mer

@@ -2293,6 +2293,82 @@ def test_classify_records_long_ragged_reads(api, torch_cuda):
             assert (s == 0).mean() > 0.5
 
 
+@pytest.mark.parametrize("F", [2, 0])
+def test_classify_records_residues_in_pieces(api, torch_cuda, F):
+    """umgap_classify_records_sg: the residues handed over as pieces laid end to end (what a host that tokenizes on several threads
+    holds) -- pageable pieces are gathered into the staging, page-locked ones are copied from where they lie; fragments may run
+    across pieces, pieces may be empty, a chunk of the call may start and end anywhere in a piece.  Same answers as the one-array
+    call, bit for bit (fused route F = 2; general route: ragged reads)."""
+    import torch
+    rng = np.random.default_rng(77 + F)
+    letters = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", np.uint8)
+    from umgap_amd.synth import synthetic_taxonomy
+    ids, par, valid, rank = synthetic_taxonomy(3000, 5000, max_depth=14, seed=23)
+    tx = api.Taxonomy(ids, par, valid, rank)
+    prot = rng.choice(letters, 60_000).astype(np.uint8)
+    windows = np.lib.stride_tricks.sliding_window_view(prot, 9)
+    block_taxon = rng.choice(ids, len(prot) // 300 + 1)      # stretches of 300 residues under one taxon each (seedextend wants runs)
+    table = {}
+    for i, w in enumerate(windows):
+        table.setdefault(w.tobytes(), int(block_taxon[i // 300]))
+    kmers = sorted(table)
+    keys, _ = api.pack9_array(kmers)
+    ix = api.Index.build(keys, np.array([table[k] for k in kmers], np.uint32))
+    n_reads = 30_000
+    nfr = np.full(n_reads, F, np.int64) if F else rng.integers(0, 4, n_reads)
+    read_frags = np.concatenate([[0], np.cumsum(nfr)]).astype(np.uint64)
+    n_frag = int(read_frags[-1])
+    flen = rng.choice([9, 20, 33, 50], n_frag)
+    start = rng.integers(0, len(prot) - 50, n_frag)
+    offs = np.concatenate([[0], np.cumsum(flen)]).astype(np.uint64)
+    data = np.empty(int(offs[-1]), np.uint8)
+    for f in range(n_frag):
+        data[int(offs[f]):int(offs[f + 1])] = prot[start[f]:start[f] + flen[f]]
+    noise = rng.random(len(data)) < 0.02
+    data[noise] = rng.choice(letters, int(noise.sum()))
+    kw = dict(method="tree", strategy="lca*", lower_bound=2.0, seedextend=True, min_seed_size=2, max_gap_size=1)
+    want_t, want_s = api.classify_records_arrays(ix, tx, data, offs, read_frags, **kw)
+    assert (want_s == 0).mean() > 0.3
+    os.environ["UMGAP_RECORDS_CHUNK_MB"] = "1"      # ~3 MB of residues: chunks that begin and end inside pieces
+    try:
+        for how in ("one", "few", "many with empty ones", "single bytes at the seams"):
+            if how == "one":
+                cuts = []
+            elif how == "few":
+                cuts = sorted(rng.integers(0, len(data), 5).tolist())
+            elif how == "many with empty ones":
+                cuts = sorted(rng.integers(0, len(data), 40).tolist() + [0, 0, len(data), 1000, 1000])
+            else:
+                c = int(offs[n_frag // 2])
+                cuts = [c - 1, c, c + 1, c + 2]
+            edges = [0] + cuts + [len(data)]
+            for pinned in (False, True):
+                pieces = []
+                for a, b in zip(edges[:-1], edges[1:]):
+                    if pinned and b > a:
+                        t = torch.empty(b - a, dtype=torch.uint8).pin_memory()
+                        t.numpy()[:] = data[a:b]
+                        pieces.append(t)
+                    else:
+                        pieces.append(data[a:b].copy())
+                t, s = api.classify_records_pieces(ix, tx, [x.numpy() if isinstance(x, torch.Tensor) else x for x in pieces], offs, read_frags, **kw)
+                assert (t == want_t).all() and (s == want_s).all(), (how, pinned, np.flatnonzero((t != want_t) | (s != want_s))[:5])
+    finally:
+        del os.environ["UMGAP_RECORDS_CHUNK_MB"]
+    # pieces that end before the last fragment does / ends that decrease: refused
+    with pytest.raises(api.UmgapError, match="pieces end before"):
+        api.classify_records_pieces(ix, tx, [data[:-5]], offs, read_frags, **kw)
+    import ctypes
+    from umgap_amd import _lib
+    ptrs = (ctypes.c_void_p * 2)(data.ctypes.data, data.ctypes.data)
+    ends = np.array([len(data), 10], np.uint64)
+    out = np.zeros(n_reads, np.uint32)
+    rc = _lib.load().umgap_classify_records_sg(ix._h, tx._h, 0, 0, 0.25, 0.0, 0, ctypes.cast(ptrs, ctypes.c_void_p), ends.ctypes.data_as(ctypes.c_void_p), 2,
+                                               offs.ctypes.data_as(ctypes.c_void_p), n_frag, read_frags.ctypes.data_as(ctypes.c_void_p), n_reads, 1, 2, 0,
+                                               out.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p))
+    assert rc == _lib.ERR_INVALID
+
+
 @pytest.mark.parametrize("F,misfit", [(2, None), (1, None), (6, None), (2, "long read"), (2, "ragged"), (3, "many taxa"), (12, "six frames"), (12, "six frames, all coding"),
                                       (10, "six frames")])
 def test_classify_records_fused_route(api, torch_cuda, F, misfit):

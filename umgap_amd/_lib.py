@@ -110,6 +110,7 @@ def load():
         "umgap_index_unbind_taxonomy": (i32, [vp, vp]),
         "umgap_index_is_bound": (i32, [vp]),
         "umgap_classify_records": (i32, [vp, vp, i32, i32, f32, f32, i32, vp, vp, sz, vp, sz, i32, u32, u32, vp, vp]),
+        "umgap_classify_records_sg": (i32, [vp, vp, i32, i32, f32, f32, i32, vp, vp, sz, vp, sz, vp, sz, i32, u32, u32, vp, vp]),
         "umgap_records_last_route": (i32, []),
         "umgap_comm_unique_id": (i32, [vp]),
         "umgap_comm_init_rank": (i32, [vp, i32, i32, i32, pp]),

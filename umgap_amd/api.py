@@ -498,6 +498,24 @@ def classify_records_arrays(index, taxonomy, data, frag_offsets, read_frags, met
     return out_t, out_s
 
 
+def classify_records_pieces(index, taxonomy, pieces, frag_offsets, read_frags, method="tree", strategy="hybrid", factor=0.25, lower_bound=0.0,
+                            ranked_only=False, seedextend=True, min_seed_size=2, max_gap_size=0):
+    """umgap_classify_records_sg: the residues as a list of uint8 arrays laid end to end (numpy arrays, or HostArray.array views for
+    pinned pieces); frag_offsets index the concatenation.  Returns (out_taxon, out_status)."""
+    import ctypes
+    pieces = [np.ascontiguousarray(x, dtype=np.uint8) for x in pieces]
+    ptrs = (ctypes.c_void_p * max(1, len(pieces)))(*[x.ctypes.data if x.size else None for x in pieces])
+    ends = np.cumsum([x.size for x in pieces], dtype=np.uint64) if pieces else np.zeros(0, np.uint64)
+    offs = np.ascontiguousarray(frag_offsets, dtype=np.uint64)
+    rf = np.ascontiguousarray(read_frags, dtype=np.uint64)
+    n = len(rf) - 1
+    out_t, out_s = np.empty(n, np.uint32), np.empty(n, np.uint32)
+    check(_lib.load().umgap_classify_records_sg(index._h, taxonomy._h, METHODS[method], STRATEGIES[strategy], factor, lower_bound, int(ranked_only),
+                                                ctypes.cast(ptrs, ctypes.c_void_p), _np_ptr(ends), len(pieces), _np_ptr(offs), len(offs) - 1, _np_ptr(rf), n,
+                                                int(seedextend), min_seed_size, max_gap_size, _np_ptr(out_t), _np_ptr(out_s)))
+    return out_t, out_s
+
+
 def seedextend_ranked_dev(taxonomy, d_taxa, d_offsets, min_seed_size=2, max_gap_size=0, penalty=5, d_kept=None, stream=None):
     """seedextend -r (only the best-scoring extended seed of a record stays, src/commands/seedextend.rs:150-163), in place."""
     check(_lib.load().umgap_seedextend_ranked_dev(taxonomy._h, _dev_ptr(d_offsets), d_offsets.numel() - 1, min_seed_size, max_gap_size, penalty,

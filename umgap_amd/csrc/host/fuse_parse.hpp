@@ -18,6 +18,7 @@
 #include <cstdint>
 #include <cstring>
 #include <memory>
+#include <new>
 #include <optional>
 #include <string>
 #include <string_view>
@@ -26,6 +27,34 @@
 #include "text.hpp"
 
 namespace umgap_host {
+
+// The residue buffer of a part: plain memory unless the host installs an allocator -- `umgap prot2kmer2agg` installs the library's
+// page-locked one and hands the buffers to the device call as they lie (umgap_classify_records_sg).  Contents are not kept over a
+// growth.
+struct PartBytes {
+    uint8_t* p = nullptr;
+    void* (*alloc)(size_t) = nullptr;      // both null: new[] / delete[]
+    void (*release)(void*) = nullptr;
+    PartBytes() = default;
+    PartBytes(const PartBytes&) = delete;
+    PartBytes& operator=(const PartBytes&) = delete;
+    PartBytes(PartBytes&& o) noexcept : p(o.p), alloc(o.alloc), release(o.release) { o.p = nullptr; }
+    PartBytes& operator=(PartBytes&& o) noexcept {
+        if (this != &o) { drop(); p = o.p; alloc = o.alloc; release = o.release; o.p = nullptr; }
+        return *this;
+    }
+    ~PartBytes() { drop(); }
+    void drop() {
+        if (p) { if (release) release(p); else delete[] p; }
+        p = nullptr;
+    }
+    void reset_to(size_t bytes) {
+        drop();
+        p = alloc ? (uint8_t*)alloc(bytes) : new uint8_t[bytes];
+        if (!p) throw std::bad_alloc();
+    }
+    uint8_t* get() const { return p; }
+};
 
 // (aligned to two cache lines, and the tokenizer works on its own copies of the vectors: the parts of a block sit side by side in
 // one array and are written by different threads -- three push_backs per record into neighbouring structs had the threads fight
@@ -37,7 +66,7 @@ struct alignas(128) FusePart {
     std::vector<uint32_t> hdr_len;
     std::vector<uint64_t> frag_len;
     std::vector<uint32_t> gstart;   // records that open a new `uniq` group inside this range (record 0 always does)
-    std::unique_ptr<uint8_t[]> bytes;   // the residues of the emitted records, back to back
+    PartBytes bytes;                    // the residues of the emitted records, back to back
     size_t n_bytes = 0, cap_bytes = 0;  // (the buffer and the vectors keep their memory when a part is parsed into again: no fresh pages per block)
     bool bad_utf8 = false, panic = false;
     size_t rec_base = 0, byte_base = 0, group_base = 0, hdr_base = 0, hdr_bytes = 0;
@@ -96,7 +125,7 @@ inline void scan_lines(const char* d, size_t begin, size_t end, bool& stop, Line
 inline void parse_fuse_part(const char* d, size_t begin, size_t end, const std::optional<std::string>& delim, FusePart& P) {
     using namespace fuse_detail;
     const size_t len = end - begin;
-    if (P.cap_bytes < len + 16) { P.cap_bytes = len + len / 8 + 4096; P.bytes.reset(new uint8_t[P.cap_bytes]); }
+    if (P.cap_bytes < len + 16) { P.cap_bytes = len + len / 8 + 4096; P.bytes.reset_to(P.cap_bytes); }
     uint8_t* out = P.bytes.get();
     size_t out_n = 0;
     P.n_bytes = 0; P.bad_utf8 = P.panic = P.merged = false;

@@ -1505,7 +1505,11 @@ int cmd_uniq(const std::vector<std::string>& args) {
 
 // one block's worth of reads, self-contained (nothing points into the block buffer)
 struct FuseJob {
-    PinnedVec<uint8_t> bytes;
+    // the residues stay where the tokenizer threads wrote them: the carried group's first, then one piece per part of the block
+    // (page-locked buffers, umgap_classify_records_sg); `bytes` is only filled with UMGAP_FUSE_PIECES=0 (one array, as before round 5)
+    PinnedVec<uint8_t> carry_bytes, bytes;
+    std::vector<const uint8_t*> pieces;
+    std::vector<uint64_t> piece_ends;
     PinnedVec<uint64_t> frag_off, read_frags;
     std::string hdrs;                 // the reads' headers, back to back
     std::vector<uint64_t> hdr_end;    // n_reads + 1
@@ -1563,9 +1567,9 @@ int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
         double t0 = now();
         J.out_taxon.resize(J.n_reads);
         J.out_status.resize(J.n_reads);
-        if (J.n_reads) LIB(umgap_classify_records(ix, tx, method, strategy, factor, lower_bound, ranked ? 1 : 0, J.bytes.data(), J.frag_off.data(),
-                                                  J.read_frags[J.n_reads], J.read_frags.data(), J.n_reads, se ? 1 : 0, (uint32_t)s, (uint32_t)g,
-                                                  J.out_taxon.data(), J.out_status.data()));
+        if (J.n_reads) LIB(umgap_classify_records_sg(ix, tx, method, strategy, factor, lower_bound, ranked ? 1 : 0, J.pieces.data(), J.piece_ends.data(), J.pieces.size(),
+                                                     J.frag_off.data(), J.read_frags[J.n_reads], J.read_frags.data(), J.n_reads, se ? 1 : 0, (uint32_t)s, (uint32_t)g,
+                                                     J.out_taxon.data(), J.out_status.data()));
         t_dev += now() - t0; t0 = now();
         size_t bad = J.n_reads;
         for (size_t r = 0; r < J.n_reads; r++)
@@ -1613,7 +1617,9 @@ int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
 
     // the group `uniq` is still merging when a block ends (src/commands/uniq.rs:66-79): carried into the next block
     struct Carry { bool have = false; std::string hdr; std::vector<uint8_t> bytes; std::vector<uint64_t> frag_len; } carry;
-    std::vector<FusePart> parts;
+    // two sets of parts: the device call of block b reads the residues out of the parts' own buffers while block b + 1 is tokenized
+    std::vector<FusePart> part_sets[2];
+    const bool gather_first = [] { const char* e = getenv("UMGAP_FUSE_PIECES"); return e && e[0] == '0'; }();
     // 32 MB blocks here also from a mapped file: with two overlapped stages the first block's tokenizing and the last block's device
     // call are not hidden, and 8 M pairs are only 16 blocks of 64 MB (stream 0.217 s against 0.152 s at 32 MB; no difference at 16 M pairs)
     BlockReader blocks(in, BlockReader::piped_block(BlockReader::default_block()));
@@ -1628,7 +1634,15 @@ int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
         if (more && blocks.first_line_error()) { join_worker(); throw CliError("Expected > at beginning of fasta header."); }
         std::vector<size_t> cuts = more ? split_records(d, len, T) : std::vector<size_t>{0};
         const size_t np = cuts.size() - 1;
-        if (parts.size() < np) parts.resize(np);   // the parts keep their buffers from block to block (fresh pages cost more than the parse)
+        std::vector<FusePart>& parts = part_sets[slot];     // (job `slot` of two blocks ago is through: join_worker below, before the last launch)
+        if (parts.size() < np) {                   // the parts keep their buffers from block to block (fresh pages cost more than the parse)
+            const size_t had = parts.size();
+            parts.resize(np);
+            for (size_t i = had; i < np; i++) {
+                parts[i].bytes.alloc = +[](size_t n) -> void* { void* q = nullptr; return umgap_host_alloc(n, &q) == UMGAP_OK ? q : nullptr; };
+                parts[i].bytes.release = +[](void* q) { umgap_host_free(q); };
+            }
+        }
         parallel_for(np, [&](size_t i) { parse_fuse_part(d, cuts[i], cuts[i + 1], delim, parts[i]); });
         t_parse += now() - t0; t0 = now();
         size_t used = np;
@@ -1651,19 +1665,35 @@ int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
             prev = P.header(d, P.hdr_off.size() - 1);
             have_prev = true;
         }
-        J.bytes.resize(n_bytes + 1);
+        J.pieces.clear();
+        J.piece_ends.clear();
+        if (!carry.bytes.empty()) {
+            J.carry_bytes.resize(carry.bytes.size());
+            memcpy(J.carry_bytes.data(), carry.bytes.data(), carry.bytes.size());
+            J.pieces.push_back(J.carry_bytes.data());
+            J.piece_ends.push_back(carry.bytes.size());
+        }
+        for (size_t i = 0; i < used; i++)
+            if (parts[i].n_bytes) { J.pieces.push_back(parts[i].bytes.get()); J.piece_ends.push_back(parts[i].byte_base + parts[i].n_bytes); }
+        // bytes [a, a + len) of the concatenation
+        auto copy_bytes = [&](uint8_t* dst, uint64_t a, uint64_t len) {
+            size_t i = (size_t)(std::upper_bound(J.piece_ends.begin(), J.piece_ends.end(), a) - J.piece_ends.begin());
+            for (uint64_t at = 0; at < len && i < J.pieces.size(); i++) {
+                const uint64_t p0 = i ? J.piece_ends[i - 1] : 0, take = std::min(len - at, J.piece_ends[i] - (a + at));
+                memcpy(dst + at, J.pieces[i] + (a + at - p0), take);
+                at += take;
+            }
+        };
         J.frag_off.resize(n_frag + 1);
         J.read_frags.resize(n_groups + 1);
         J.hdr_end.resize(n_groups + 1);
         const size_t carry_hdr = carry.have ? carry.hdr.size() : 0;
         J.hdrs.resize(carry_hdr + n_hdr);
         J.frag_off[0] = 0;
-        if (!carry.bytes.empty()) memcpy(J.bytes.data(), carry.bytes.data(), carry.bytes.size());
         for (size_t f = 0; f < carry.frag_len.size(); f++) J.frag_off[f + 1] = J.frag_off[f] + carry.frag_len[f];
         if (carry.have) { J.read_frags[0] = 0; J.hdr_end[0] = 0; memcpy(J.hdrs.data(), carry.hdr.data(), carry_hdr); }
         parallel_for(used, [&](size_t i) {
             const FusePart& P = parts[i];
-            if (P.n_bytes) memcpy(J.bytes.data() + P.byte_base, P.bytes.get(), P.n_bytes);
             uint64_t o = P.byte_base;
             for (size_t r = 0; r < P.frag_len.size(); r++) { o += P.frag_len[r]; J.frag_off[P.rec_base + r + 1] = o; }
             size_t gi = P.group_base, ho = carry_hdr + P.hdr_base;
@@ -1684,10 +1714,20 @@ int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
             next.have = true;
             next.hdr.assign(J.hdrs.data() + J.hdr_end[n_now], J.hdr_end[n_groups] - J.hdr_end[n_now]);
             size_t f0 = J.read_frags[n_now];
-            next.bytes.assign(J.bytes.begin() + J.frag_off[f0], J.bytes.begin() + J.frag_off[n_frag]);
+            next.bytes.resize(J.frag_off[n_frag] - J.frag_off[f0]);
+            copy_bytes(next.bytes.data(), J.frag_off[f0], next.bytes.size());
             for (size_t f = f0; f < n_frag; f++) next.frag_len.push_back(J.frag_off[f + 1] - J.frag_off[f]);
         }
         J.n_reads = n_now;
+        if (gather_first) {          // A/B: the pieces gathered into one page-locked array by this stage, as before round 5
+            J.bytes.resize(n_bytes + 1);
+            size_t k = 0;
+            if (!carry.bytes.empty()) k = 1;
+            parallel_for(used, [&](size_t i) { if (parts[i].n_bytes) memcpy(J.bytes.data() + parts[i].byte_base, parts[i].bytes.get(), parts[i].n_bytes); });
+            if (k) memcpy(J.bytes.data(), J.carry_bytes.data(), carry.bytes.size());
+            J.pieces.assign(1, J.bytes.data());
+            J.piece_ends.assign(1, n_bytes);
+        }
         // taxa2agg's reader strips one more CR from the header line it prints (looked for by all threads: 16 M reads per second and
         // thread otherwise stood in front of every block)
         std::atomic<bool> any_cr{false};

@@ -355,10 +355,31 @@ extern "C" int umgap_index_lookup_records(umgap_index* ix, const uint8_t* bytes,
 
 static thread_local int g_last_route = 0;
 
-extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound,
-                                      int ranked_only, const uint8_t* bytes, const uint64_t* frag_offsets, size_t n_fragments,
-                                      const uint64_t* read_frags, size_t n_reads, int seedextend, uint32_t min_seed_size,
-                                      uint32_t max_gap_size, uint32_t* out_taxon, uint32_t* out_status) {
+// The residues of a call: ONE array indexed by the fragment offsets (umgap_classify_records), or pieces laid end to end
+// (umgap_classify_records_sg): piece i holds the bytes [ends[i - 1], ends[i]) of the concatenation (ends[-1] = 0).
+struct ByteParts {
+    const uint8_t* const* ptr;
+    const uint64_t* ends;
+    size_t n;
+    // fn(src, dst_offset, len) for every stretch of [a, a + len) that lies in one piece, in order
+    template <class Fn>
+    void segments(uint64_t a, uint64_t len, Fn&& fn) const {
+        if (!ends) { fn(ptr[0] + a, (uint64_t)0, len); return; }
+        size_t i = (size_t)(std::upper_bound(ends, ends + n, a) - ends);
+        uint64_t at = 0;
+        while (at < len && i < n) {
+            const uint64_t p0 = i ? ends[i - 1] : 0, take = std::min(len - at, ends[i] - (a + at));
+            if (take) fn(ptr[i] + (a + at - p0), at, take);
+            at += take;
+            i++;
+        }
+    }
+};
+
+static int classify_records_parts(umgap_index* ix, umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound,
+                                  int ranked_only, const ByteParts bytes, const uint64_t* frag_offsets, size_t n_fragments,
+                                  const uint64_t* read_frags, size_t n_reads, int seedextend, uint32_t min_seed_size,
+                                  uint32_t max_gap_size, uint32_t* out_taxon, uint32_t* out_status) {
     if (!ix || !tx || (n_reads && (!read_frags || !out_taxon || !out_status)) || (n_fragments && !frag_offsets))
         return fail(UMGAP_ERR_INVALID, "umgap_classify_records: null argument");
     // a table bound to THIS taxonomy (umgap_index_bind_taxonomy: values = preorder interval codes) is what the fused route wants -- no
@@ -379,7 +400,15 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
     const uint64_t base = n_fragments ? frag_offsets[0] : 0;
     if (n_fragments && frag_offsets[n_fragments] < base) return fail(UMGAP_ERR_INVALID, "umgap_classify_records: frag_offsets must not decrease");
     const uint64_t n_bytes = n_fragments ? frag_offsets[n_fragments] - base : 0;
-    if (n_bytes && !bytes) return fail(UMGAP_ERR_INVALID, "umgap_classify_records: null bytes");
+    if (n_bytes) {
+        if (!bytes.ptr || !bytes.n) return fail(UMGAP_ERR_INVALID, "umgap_classify_records: null bytes");
+        for (size_t i = 0; i < bytes.n; i++) {
+            const uint64_t p0 = i && bytes.ends ? bytes.ends[i - 1] : 0;
+            if (bytes.ends && bytes.ends[i] < p0) return fail(UMGAP_ERR_INVALID, "umgap_classify_records_sg: piece_ends must not decrease");
+            if (!bytes.ptr[i] && (!bytes.ends || bytes.ends[i] > p0)) return fail(UMGAP_ERR_INVALID, "umgap_classify_records: null bytes");
+        }
+        if (bytes.ends && bytes.ends[bytes.n - 1] < base + n_bytes) return fail(UMGAP_ERR_INVALID, "umgap_classify_records_sg: the pieces end before the last fragment does");
+    }
 
     // the fused route (k_records_fit): every read of F fragments, F from the first read and the totals; UMGAP_RECORDS_FUSED=0 keeps
     // the general kernels
@@ -443,8 +472,8 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
         }
         return true;
     };
-    const bool in_pinned = (!n_bytes || is_pinned(bytes + base, bytes + base + n_bytes - 1)) && (!n_fragments || is_pinned(frag_offsets, frag_offsets + n_fragments)) &&
-                           is_pinned(read_frags, read_frags + n_reads);
+    bool in_pinned = (!n_fragments || is_pinned(frag_offsets, frag_offsets + n_fragments)) && is_pinned(read_frags, read_frags + n_reads);
+    if (in_pinned && n_bytes) bytes.segments(base, n_bytes, [&](const uint8_t* src, uint64_t, uint64_t len) { in_pinned = in_pinned && is_pinned(src, src + len - 1); });
     const bool out_pinned = is_pinned(out_taxon, out_taxon + n_reads - 1) && is_pinned(out_status, out_status + n_reads - 1);
     const size_t hb_bytes = pad256(max_b + 16), hb_off = pad256((max_f + 1) * 8), hb_rf = pad256((max_r + 1) * 8), hb_out = pad256(max_r * 4 + 4);
     const size_t h_per_slot = (in_pinned ? 0 : hb_bytes + hb_off + hb_rf) + (out_pinned ? 0 : 2 * hb_out);
@@ -516,15 +545,19 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
         // no wait on an event here: those are packets of a compute queue, the runtime folds a process's streams onto four of them
         // (tools/native/queue_probe.hip: streams 0..9 -> queues 0 1 2 3 3 2 1 0 3 2), and on a queue shared with the compute lane such
         // a packet -- and every upload behind it -- waits for the running kernel ----
-        const uint8_t* src_b = bytes + base + b0;
         const uint64_t *src_o = frag_offsets + f0, *src_r = read_frags + r0;
+        hipError_t e_up = hipSuccess;
         if (!in_pinned) {          // (the slot's previous upload is long through: the host waited for that chunk's results below)
-            if (nb) par_memcpy(H[slot].bytes, src_b, nb);
+            if (nb) bytes.segments(base + b0, nb, [&](const uint8_t* src, uint64_t at, uint64_t len) { par_memcpy(H[slot].bytes + at, src, len); });
             if (nf) par_memcpy(H[slot].off, src_o, (nf + 1) * 8);
             par_memcpy(H[slot].rf, src_r, (nr + 1) * 8);
-            src_b = H[slot].bytes; src_o = H[slot].off; src_r = H[slot].rf;
-        }
-        if (nb) UMGAP_HIP_BREAK(hipMemcpyAsync(L.bytes, src_b, nb, hipMemcpyHostToDevice, up));
+            src_o = H[slot].off; src_r = H[slot].rf;
+            if (nb) e_up = hipMemcpyAsync(L.bytes, H[slot].bytes, nb, hipMemcpyHostToDevice, up);
+        } else if (nb)             // pinned pieces are copied from where they lie, one copy per piece the chunk touches
+            bytes.segments(base + b0, nb, [&](const uint8_t* src, uint64_t at, uint64_t len) {
+                if (e_up == hipSuccess) e_up = hipMemcpyAsync(L.bytes + at, src, len, hipMemcpyHostToDevice, up);
+            });
+        UMGAP_HIP_BREAK(e_up);
         if (nf) UMGAP_HIP_BREAK(hipMemcpyAsync(L.off, src_o, (nf + 1) * 8, hipMemcpyHostToDevice, up));
         UMGAP_HIP_BREAK(hipMemcpyAsync(L.rf, src_r, (nr + 1) * 8, hipMemcpyHostToDevice, up));
         UMGAP_HIP_BREAK(hipEventRecord(ev.uploaded[slot], up));
@@ -597,6 +630,24 @@ extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int m
         unfit = false;
     } else g_last_route = 0;
     return run(false);
+}
+
+extern "C" int umgap_classify_records(umgap_index* ix, umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound,
+                                      int ranked_only, const uint8_t* bytes, const uint64_t* frag_offsets, size_t n_fragments,
+                                      const uint64_t* read_frags, size_t n_reads, int seedextend, uint32_t min_seed_size,
+                                      uint32_t max_gap_size, uint32_t* out_taxon, uint32_t* out_status) {
+    return classify_records_parts(ix, tx, method, strategy, factor, lower_bound, ranked_only, ByteParts{&bytes, nullptr, bytes ? (size_t)1 : (size_t)0}, frag_offsets, n_fragments,
+                                  read_frags, n_reads, seedextend, min_seed_size, max_gap_size, out_taxon, out_status);
+}
+
+extern "C" int umgap_classify_records_sg(umgap_index* ix, umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound,
+                                         int ranked_only, const uint8_t* const* pieces, const uint64_t* piece_ends, size_t n_pieces,
+                                         const uint64_t* frag_offsets, size_t n_fragments, const uint64_t* read_frags, size_t n_reads,
+                                         int seedextend, uint32_t min_seed_size, uint32_t max_gap_size, uint32_t* out_taxon,
+                                         uint32_t* out_status) {
+    if (n_pieces && (!pieces || !piece_ends)) return fail(UMGAP_ERR_INVALID, "umgap_classify_records_sg: null argument");
+    return classify_records_parts(ix, tx, method, strategy, factor, lower_bound, ranked_only, ByteParts{pieces, piece_ends, n_pieces}, frag_offsets, n_fragments,
+                                  read_frags, n_reads, seedextend, min_seed_size, max_gap_size, out_taxon, out_status);
 }
 
 // which kernels the last umgap_classify_records of this thread ran: 0 the general ones, 1 the fused one, 2 the fused one and then,
