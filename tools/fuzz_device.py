@@ -165,8 +165,104 @@ def walk_leg(rng, fails):
         api.classify_prot9_dev(ix, tx, d_r, d_ro, n_reads, F, t, st, **kw)
         outs.append((t, st))
     torch.cuda.synchronize()
+    outs_b = outs[0]
     if not (torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])):
         fails.append("walk fused"); print("MISMATCH walk index: fused pipeline differs from the plain table", n_frag, n_reads, F, mut, kw, flush=True)
+    # surface A (round 5): packed 9-mers of consecutive windows through umgap_classify9[_strategy]_dev on the walk index -- one probe
+    # per run, the proteome's keys rebuilt along the entries -- against the plain table; reads of `wpr` windows cut from mutated
+    # fragments, with and without the fragment structure, windows with a byte outside 'A'..'Z' packed as a non-key
+    L = int(rng.choice([17, 29, 50]))
+    long_frags = [f for f in frags if len(f) >= L]
+    if long_frags:
+        n2 = int(rng.integers(1, 400))
+        F2 = int(rng.choice([1, 2, 3]))
+        rows = np.empty((n2 * F2, L), np.uint8)
+        for r in range(n2 * F2):
+            if rng.random() < 0.85:
+                g = long_frags[int(rng.integers(0, len(long_frags)))]
+                a = int(rng.integers(0, len(g) - L + 1))
+                f = bytearray(g[a:a + L])
+                for k in range(L):
+                    if rng.random() < mut:
+                        f[k] = int(rng.choice(letters))
+                if rng.random() < 0.2:       # chimera
+                    g2 = long_frags[int(rng.integers(0, len(long_frags)))]
+                    k = int(rng.integers(1, L - 1))
+                    f = f[:k] + bytearray(g2[k:L])
+                rows[r] = np.frombuffer(bytes(f), np.uint8)
+            else:
+                rows[r] = rng.choice(letters, L)
+        code = rows.astype(np.int64) - 65
+        good = (code >= 0) & (code < 26)
+        W = L - 8
+        keys = np.zeros((n2 * F2, W), np.uint64)
+        ok = np.ones((n2 * F2, W), bool)
+        for c in range(9):
+            keys = (keys << np.uint64(5)) | (code[:, c:c + W] & 31).astype(np.uint64)
+            ok &= good[:, c:c + W]
+        keys = np.where(ok, keys, np.uint64(1 << 50)).reshape(-1)
+        d_k = torch.from_numpy(keys.view(np.int64).copy()).cuda()
+        stride = W * F2
+        fr = int(rng.choice([0, F2]))
+        se = fr > 0 and bool(rng.integers(0, 2))
+        outs = []
+        bind = bool(rng.integers(0, 2))
+        for ix in (plain, walk):
+            t = torch.full((n2,), -1, dtype=torch.int32, device="cuda")
+            st = torch.full_like(t, -1)
+            if bind:
+                ix.bind(tx)
+            api.classify9_dev(ix, tx, d_k, n2, stride, t, st, method=kw["method"], strategy=kw["strategy"], factor=kw["factor"], lower_bound=kw["lower_bound"],
+                              fragments_per_read=fr, min_seed_size=2 if se else 1, max_gap_size=kw["max_gap_size"])
+            torch.cuda.synchronize()
+            if bind:
+                ix.unbind(tx)
+            outs.append((t, st))
+        if not (torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])):
+            fails.append("walk surface A"); print("MISMATCH walk index: classify9 differs from the plain table", n_frag, n2, F2, L, mut, fr, se, bind, kw, flush=True)
+        walk_leg.checks = getattr(walk_leg, "checks", 0) + n2
+    # the deferred builder (round 5): the order from the proteome first, the plain table's (key, value) pairs streamed afterwards in
+    # chunks of any order -> the same answers as the walk index built with its values
+    pk, pv = plain.dump9()
+    if len(pk):
+        perm = rng.permutation(len(pk))
+        pk, pv = pk[perm], pv[perm]
+        # (the proteome in 1..3 chunks of whole fragments, the pairs in chunks of a random size)
+        fcuts = sorted(set([0, n_frag] + rng.integers(0, n_frag + 1, int(rng.integers(0, 3))).tolist()))
+        chunks = []
+        for a, b in zip(fcuts[:-1], fcuts[1:]):
+            cd, co = api._concat(frags[a:b])
+            chunks.append((torch.from_numpy(cd.copy()).cuda() if len(cd) else torch.zeros(1, dtype=torch.uint8, device="cuda"), torch.from_numpy(co.view(np.int64)).cuda(),
+                           max(1, max(len(f) for f in frags[a:b]))))
+        step = int(rng.choice([7, 1000, 1 << 20]))
+        vchunks = [(torch.from_numpy(pk[a:a + step].view(np.int64).copy()).cuda(), torch.from_numpy(pv[a:a + step].view(np.int32).copy()).cuda()) for a in range(0, len(pk), step)]
+        wd = Index.build_walk_deferred(n_win, chunks, vchunks, load_factor=load)
+        if oo[-1]:
+            h2 = torch.full_like(h0, -7)
+            wd.lookup_prot9_dev(d_r, d_ro, d_oo, h2, miss_value=0)
+            torch.cuda.synchronize()
+            if not torch.equal(h0, h2):
+                fails.append("walk deferred"); print("MISMATCH walk index (deferred builder): lookup_prot9 differs from the plain table", n_frag, len(pk), flush=True)
+        wd.close()
+    # the record call with the residues in pieces (round 5), general and fused routes, plain and walk index
+    if len(rdata) > 0 and n_reads:
+        rf = np.arange(0, n_reads * F + 1, F, dtype=np.uint64)
+        ncut = int(rng.integers(0, 6))
+        edges = [0] + sorted(rng.integers(0, len(rdata) + 1, ncut).tolist()) + [len(rdata)]
+        pieces = [rdata[a:b].copy() for a, b in zip(edges[:-1], edges[1:])]
+        rkw = dict(method=kw["method"], strategy=kw["strategy"], factor=kw["factor"], lower_bound=kw["lower_bound"], seedextend=kw["seedextend"],
+                   min_seed_size=kw["min_seed_size"], max_gap_size=kw["max_gap_size"])
+        for ix in (plain, walk):
+            ta, sa = api.classify_records_arrays(ix, tx, rdata, roffs, rf, **rkw)
+            tb, sb = api.classify_records_pieces(ix, tx, pieces, roffs, rf, **rkw)
+            if not ((ta == tb).all() and (sa == sb).all()):
+                fails.append("records in pieces"); print("MISMATCH record call: pieces differ from one array", n_reads, F, edges, rkw, flush=True)
+            # (a read the fused kernel does not take -- more windows than its strip holds -- is UMGAP_READ_UNSUPPORTED = 4 there; the record
+            # call sends the whole call through its general kernels then)
+            sd, td = outs_b[1].cpu().numpy().view(np.uint32), outs_b[0].cpu().numpy().view(np.uint32)
+            took, ok_rows = sd != 4, sd == 0
+            if not ((sa[took] == sd[took]).all() and (ta[ok_rows] == td[ok_rows]).all()):
+                fails.append("records vs device-resident"); print("MISMATCH record call vs classify_prot9_dev", n_reads, F, rkw, flush=True)
     walk_leg.checks = getattr(walk_leg, "checks", 0) + n_reads + int(oo[-1])
 
 
