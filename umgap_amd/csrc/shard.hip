@@ -905,7 +905,8 @@ int put_setup(umgap_sharded* sh) {
           const int brc = comm_barrier(c);
           if (brc) return brc;
         }
-        // every rank has mapped every block, or every rank drops back to the copies
+        // every rank has mapped every block, or the create fails on EVERY rank (a rank that went on alone would wait for the others
+        // in its first collective)
         uint32_t bad = rc ? 1u : 0u;
         const int rc2 = comm_max_u32(c, &bad);
         PUT_TRACE("agreed: bad %u", bad);
@@ -914,7 +915,7 @@ int put_setup(umgap_sharded* sh) {
             for (void* m : sh->peer_maps) (void)hipIpcCloseMemHandle(m);
             sh->peer_maps.clear();
             sh->put = false;
-            if (rc) return rc;
+            return rc ? rc : fail(UMGAP_ERR_DEVICE, "umgap_sharded_create: another rank could not map the exchange blocks (hipIpcOpenMemHandle); UMGAP_SHARD_PUT=0 keeps the copies");
         }
     }
     // the tables: where the pack stores owner o's keys, where the probe stores region r's values
