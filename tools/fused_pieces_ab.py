@@ -19,11 +19,13 @@ rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 work = "/tmp/umgap_e2e"
 os.makedirs(work, exist_ok=True)
 idx, tsv, fasta, _ = E._make_inputs(work, n, 250_000)
-res = {"pairs": n, "runs": {"pieces": [], "gathered": []}}
+res = {"pairs": n, "runs": {"pieces": [], "gathered": [], "pieces_buffers_allocated_by_the_stream": []}}
 digests = set()
 for r in range(rounds):
-    for name, val in (("gathered", "0"), ("pieces", "1")):
+    for name, val in (("gathered", "0"), ("pieces", "1"), ("pieces_buffers_allocated_by_the_stream", "1")):
         env = dict(os.environ, UMGAP_TIMING="1", UMGAP_FUSE_PIECES=val)
+        if name.startswith("pieces_buffers"):
+            env["UMGAP_FUSE_PREALLOC"] = "0"
         out = os.path.join(work, "out.ab")
         t0 = time.perf_counter()
         with open(fasta, "rb") as fi, open(out, "wb") as fo:

@@ -1541,6 +1541,32 @@ int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const bool timing = getenv("UMGAP_TIMING") != nullptr;   // phase times on stderr
     const double t_begin = now();
+    const unsigned T = worker_count();
+    // The page-locked buffers of the two stages belong to the command, not to a stream: they are allocated once, BESIDE the index load
+    // (page-locking ~100 MB takes 20-30 ms, the load of a real index seconds), serve every connection of the socket server and are
+    // freed after the last read is out.  Two sets of parts: the device call of block b reads the residues out of the parts' own
+    // buffers while block b + 1 is tokenized.
+    FuseJob jobs[2];
+    std::vector<FusePart> part_sets[2];
+    auto pinned_part = [](FusePart& P) {
+        P.bytes.alloc = +[](size_t n) -> void* { void* q = nullptr; return umgap_host_alloc(n, &q) == UMGAP_OK ? q : nullptr; };
+        P.bytes.release = +[](void* q) { umgap_host_free(q); };
+    };
+    std::thread prealloc([&]() {
+        if (const char* e = getenv("UMGAP_FUSE_PREALLOC")) if (e[0] == '0') return;      // A/B: buffers allocated by the stream as it goes
+        try {
+            const size_t block = BlockReader::piped_block(BlockReader::default_block());
+            const size_t per_part = block / T + block / (4 * T) + (64u << 10), recs = block / 40 + 4096;   // (a record of 2 x 50 residues: ~66 bytes of text)
+            for (auto& parts : part_sets) {
+                parts.resize(T);
+                for (auto& P : parts) { pinned_part(P); P.bytes.reset_to(per_part); P.cap_bytes = per_part; }
+            }
+            for (auto& J : jobs) {
+                J.frag_off.resize(recs); J.read_frags.resize(recs); J.out_taxon.resize(recs); J.out_status.resize(recs); J.carry_bytes.resize(64u << 10);
+            }
+        } catch (...) {}      // (no device, no memory: the stream allocates as it goes and reports what it meets)
+    });
+    struct JoinPrealloc { std::thread& t; ~JoinPrealloc() { if (t.joinable()) t.join(); } } join_prealloc{prealloc};
     umgap_index* ix = open_index(p.positional[0]);
     if (umgap_index_kind(ix) == 2) throw CliError("prot2kmer2agg needs a 9-mer index");
     umgap_taxonomy* tx = load_taxonomy(p.positional[1]);
@@ -1557,8 +1583,8 @@ int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
         if (!(env && env[0] == '0') && umgap_index_bind_taxonomy(ix, tx) != UMGAP_OK && timing)
             fprintf(stderr, "prot2kmer2agg: table not bound to the taxonomy: %s\n", umgap_last_error());
     }
+    prealloc.join();
     const double t_start = now();
-    const unsigned T = worker_count();
     auto stream = [&](FILE* in, FILE* outf) {
     double t_read = 0, t_parse = 0, t_group = 0, t_wait = 0, t_dev = 0, t_fmt = 0;
 
@@ -1605,7 +1631,6 @@ int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
             throw CliPanic("index out of bounds");
         }
     };
-    FuseJob jobs[2];          // declared before the thread that works on them (destroyed after it is joined)
     int slot = 0;
     std::thread worker;
     std::exception_ptr worker_error;
@@ -1617,8 +1642,6 @@ int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
 
     // the group `uniq` is still merging when a block ends (src/commands/uniq.rs:66-79): carried into the next block
     struct Carry { bool have = false; std::string hdr; std::vector<uint8_t> bytes; std::vector<uint64_t> frag_len; } carry;
-    // two sets of parts: the device call of block b reads the residues out of the parts' own buffers while block b + 1 is tokenized
-    std::vector<FusePart> part_sets[2];
     const bool gather_first = [] { const char* e = getenv("UMGAP_FUSE_PIECES"); return e && e[0] == '0'; }();
     // 32 MB blocks here also from a mapped file: with two overlapped stages the first block's tokenizing and the last block's device
     // call are not hidden, and 8 M pairs are only 16 blocks of 64 MB (stream 0.217 s against 0.152 s at 32 MB; no difference at 16 M pairs)
@@ -1638,10 +1661,7 @@ int cmd_prot2kmer2agg(const std::vector<std::string>& args) {
         if (parts.size() < np) {                   // the parts keep their buffers from block to block (fresh pages cost more than the parse)
             const size_t had = parts.size();
             parts.resize(np);
-            for (size_t i = had; i < np; i++) {
-                parts[i].bytes.alloc = +[](size_t n) -> void* { void* q = nullptr; return umgap_host_alloc(n, &q) == UMGAP_OK ? q : nullptr; };
-                parts[i].bytes.release = +[](void* q) { umgap_host_free(q); };
-            }
+            for (size_t i = had; i < np; i++) pinned_part(parts[i]);
         }
         parallel_for(np, [&](size_t i) { parse_fuse_part(d, cuts[i], cuts[i + 1], delim, parts[i]); });
         t_parse += now() - t0; t0 = now();
