@@ -35,7 +35,7 @@ def pack_windows(bytes2d):
     return torch.where(ok, keys, torch.full_like(keys, 1 << 50))
 
 
-def run(n_frag=50_000_000, n_pairs=10_000_000, mut=30, steps=3, workload=None, pmc=False):
+def run(n_frag=50_000_000, n_pairs=10_000_000, mut=30, steps=3, workload=None, pmc=False, phase_probe=False):
     w = workload if workload is not None else synth.SyntheticWorkload(n_tax=2_500_000, n_keys=1000, build_index=False)
     offs = torch.arange(0, (n_frag + 1) * flen, flen, dtype=torch.int64, device=dev)
     prot = torch.empty(n_frag * flen, dtype=torch.uint8, device=dev)
@@ -89,6 +89,24 @@ def run(n_frag=50_000_000, n_pairs=10_000_000, mut=30, steps=3, workload=None, p
             out[name] = {"ms_per_step": round(ms, 3), "pairs_per_s": round(n_pairs / ms * 1e3, 1), "G_kmers_per_s": round(n_pairs * F * per / ms / 1e6, 2),
                          "bit_identical_to_unbound_plain_table": same, "status_ok_frac": round(float((d_s == 0).float().mean()), 3)}
         res[layout] = out
+    if phase_probe:
+        # where the walk kernel's time goes: the same launch with parts of walk_group_to_strip switched off (UMGAP_WALK_DEBUG bits: 1 no
+        # phase B, 2 no entry loads, 4 no anchor probe, 8 no seedextend, 16 no aggregate; the answers are wrong then -- timing only)
+        probe = {}
+        for mode in (0, 1, 3, 7, 15, 23, 31, 16, 8):
+            os.environ["UMGAP_WALK_DEBUG"] = str(mode)
+            name, kw = legs[1]
+            classify9_dev(walk, w.taxonomy, batches[0], n_pairs, F * per, d_t, d_s, **kw)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for i in range(2 * steps):
+                classify9_dev(walk, w.taxonomy, batches[i % steps], n_pairs, F * per, d_t, d_s, **kw)
+            b.record()
+            torch.cuda.synchronize()
+            probe[str(mode)] = round(a.elapsed_time(b) / (2 * steps), 3)
+        del os.environ["UMGAP_WALK_DEBUG"]
+        res["walk_phase_probe_ms"] = probe
     res["speedup_walk_over_plain"] = {name: round(res["plain_table"][name]["ms_per_step"] / res["walk_order_index"][name]["ms_per_step"], 2) for name, _ in legs}
     plain.unbind(w.taxonomy)
     walk.unbind(w.taxonomy)
@@ -100,4 +118,4 @@ def run(n_frag=50_000_000, n_pairs=10_000_000, mut=30, steps=3, workload=None, p
 if __name__ == "__main__":
     argv = [a for a in sys.argv[1:] if not a.startswith("--")]
     print(json.dumps(run(int(argv[0]) if len(argv) > 0 else 50_000_000, int(argv[1]) if len(argv) > 1 else 10_000_000, int(argv[2]) if len(argv) > 2 else 30,
-                         pmc="--pmc" in sys.argv)))
+                         pmc="--pmc" in sys.argv, phase_probe="--phase-probe" in sys.argv)))

@@ -133,43 +133,60 @@ __device__ __forceinline__ void walk_group_to_strip(const TableView& T, const Hi
     W.E = H.walk_E; W.n = H.walk_n; W.shift = H.walk_shift; W.n_exc = H.walk_n_exc; W.exc_keys = H.walk_exc_keys; W.exc_pos = H.walk_exc_pos;
     const uint32_t rpf = (flen + WALK_R - 1) / WALK_R;            // runs per fragment
     const uint32_t n_runs = (nk / flen) * rpf;                     // (nk is a multiple of flen)
+    const uint32_t row = lane >> 4, k = lane & 15u;
     for (uint32_t run0 = 0; run0 < n_runs; run0 += 64) {           // wave-uniform
+        // ---- A1, lane = run: the run's anchor (its first key) probed, the entry number behind it ----
         const uint32_t run = run0 + lane;
         const uint32_t f = run / rpf, jr = run - f * rpf;
         const uint32_t first = f * flen + jr * WALK_R;
         const uint32_t n_mine = run < n_runs ? min(WALK_R, flen - jr * WALK_R) : 0u;
-        uint64_t key[WALK_R];
-#pragma unroll
-        for (uint32_t t = 0; t < WALK_R; t++) key[t] = t < n_mine ? __builtin_nontemporal_load(kp + first + t) : ~0ull;
+        const uint64_t key0 = n_mine ? __builtin_nontemporal_load(kp + first) : ~0ull;
         uint32_t local = 0, tag = 0, valid = 0;
-        if (n_mine) valid = locate(T, key[0], local, tag) ? 1u : 0u;
-        ProbeBatch B;
+        if (n_mine) valid = locate(T, key0, local, tag) ? 1u : 0u;
         uint32_t pr[4];
-        probe_issue(T, local, tag | (valid << 31), lane, B);
-        probe_eval(T, B, UMGAP_NONE, lane, pr);
+        if (H.walk_debug & 4u) { pr[0] = pr[1] = pr[2] = pr[3] = (uint32_t)(key0 >> 7) & 0xFFFFFu; }
+        else {
+            ProbeBatch B;
+            probe_issue(T, local, tag | (valid << 31), lane, B);
+            probe_eval(T, B, UMGAP_NONE, lane, pr);
+        }
         // the answer to lane L's key sits, quad-uniform, in quad L & 15 as round L >> 4
         const int src = 4 * (int)(lane & 15u);
         const uint32_t v0 = (uint32_t)__shfl((int)pr[0], src, 64), v1 = (uint32_t)__shfl((int)pr[1], src, 64),
                        v2 = (uint32_t)__shfl((int)pr[2], src, 64), v3 = (uint32_t)__shfl((int)pr[3], src, 64);
         const uint32_t r4 = lane >> 4;
         const uint32_t q32 = r4 == 0 ? v0 : (r4 == 1 ? v1 : (r4 == 2 ? v2 : v3));
-        const uint64_t pos = (n_mine && valid) ? walk_position(W, q32, key[0]) : WALK_NOPOS;
-        uint64_t e[WALK_R];
-#pragma unroll
-        for (uint32_t k = 0; k < WALK_R; k++) e[k] = (pos != WALK_NOPOS && k < n_mine && pos + k < W.n) ? W.E[pos + k] : WALK_PAD_ENTRY;
-        if (n_mine) {
-            wtaxa[first] = pos != WALK_NOPOS ? (uint32_t)e[0] : 0u;                 // the anchor was probed: its entry's taxon, or a miss
-            uint64_t K = key[0];
-            bool chain = pos != WALK_NOPOS;
-#pragma unroll
-            for (uint32_t k = 1; k < WALK_R; k++) {
-                if (k < n_mine) {
-                    const uint32_t ey = (uint32_t)(e[k] >> 32);
-                    chain = chain && (ey >> 31);                                     // entry p + k is the next window of the same protein
-                    K = ((K << 5) | (ey & 31u)) & MASK45;
-                    wtaxa[first + k] = (chain && K == key[k]) ? (uint32_t)e[k] : WALK_OPEN;
-                }
-            }
+        const uint64_t pos = (n_mine && valid) ? walk_position(W, q32, key0) : WALK_NOPOS;
+        // ---- A2, TRANSPOSED: a row of 16 lanes = one run, lane k of the row = its k-th key; four runs per step.  The keys and the
+        // entries of a run are 128 contiguous bytes each: a step's two loads touch ~12 lines, not 128 as with a lane per run (sixteen
+        // strided 8-byte loads per lane: the vector cache looked up a line per key and per entry -- 5.9 of the kernel's 12.7 ms went to
+        // the key loads alone, UMGAP_WALK_DEBUG=31), and the steps are independent: their loads are in flight together.
+        // The proteome's key at entry p + k: K_k = (key0 << 5k | sum over j = 1..k of r_j << 5(k - j)) mod 2^45, r_j = the low five key
+        // bits of entry p + j -- the residues of the nine lanes up to k, fetched with row shifts ----
+        const uint32_t steps = (min(64u, n_runs - run0) + 3u) >> 2;
+        for (uint32_t s = 0; s < steps; s++) {                    // wave-uniform
+            const int from = (int)(4u * s + row);
+            const uint32_t r_first = (uint32_t)__shfl((int)first, from, 64), r_n = (uint32_t)__shfl((int)n_mine, from, 64);
+            const uint64_t r_pos = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(pos >> 32), from, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)pos, from, 64);
+            const uint64_t r_key0 = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(key0 >> 32), from, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)key0, from, 64);
+            const bool active = k < r_n, has = r_pos != WALK_NOPOS;
+            const uint64_t key = active ? __builtin_nontemporal_load(kp + r_first + k) : ~0ull;
+            const uint64_t e = (!(H.walk_debug & 2u) && active && has && r_pos + k < W.n) ? W.E[r_pos + k] : WALK_PAD_ENTRY;
+            const uint32_t ey = (uint32_t)(e >> 32);
+            // entries p + 1 .. p + k all continue their predecessor: the row's bits 1..k of the ballot
+            const uint64_t cm = __ballot(k == 0u || (ey >> 31));
+            const uint32_t rb = (uint32_t)(cm >> (16u * row)) & 0xFFFFu;
+            const bool chain = has && ((~rb) & ((2u << k) - 2u)) == 0u;
+            const uint32_t r = k == 0u ? 0u : (ey & 31u);
+            // the nine residues up to lane k, by doubling: pairs, fours, eight + one (row shifts, zero from beyond the row's start)
+#define UMGAP_ROW_SHR(V, N) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(V), 0x110 + (N), 0xF, 0xF, true)
+            const uint32_t p2 = r | (UMGAP_ROW_SHR(r, 1) << 5);
+            const uint32_t p4 = p2 | (UMGAP_ROW_SHR(p2, 2) << 10);
+            const uint32_t s4 = UMGAP_ROW_SHR(p4, 4), r8 = UMGAP_ROW_SHR(r, 8);
+#undef UMGAP_ROW_SHR
+            const uint64_t acc = ((uint64_t)((s4 >> 12) | (r8 << 8)) << 32) | (uint64_t)(p4 | (s4 << 20));
+            const uint64_t K = (k <= 8u ? (r_key0 << (5u * k)) & MASK45 : 0ull) | acc;
+            if (active) wtaxa[r_first + k] = k == 0u ? (has ? (uint32_t)e : 0u) : ((chain && K == key) ? (uint32_t)e : WALK_OPEN);
         }
     }
     wave_lds_sync();
@@ -187,6 +204,7 @@ __device__ __forceinline__ void walk_group_to_strip(const TableView& T, const Hi
     }
     if (U == 0) return;
     wave_lds_sync();
+    if (H.walk_debug & 1u) U = 0;
     for (uint32_t i0 = 0; i0 < U; i0 += 128) {                    // wave-uniform
         ProbeBatch B[2];
         uint32_t pr[2][4], item[2];
@@ -341,13 +359,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         wave_lds_sync();
         // ---- seedextend per fragment (one lane per fragment, nr * frags <= 64) ----
         uint64_t se_panic = 0;   // lanes (= fragments) on which the reference's seedextend panics
-        if (frags) {
+        if (frags && !(GATHER == SRC_WALK && (H.walk_debug & 8u))) {
             const uint32_t flen = stride / frags;
             bool pk = false;
             if (lane < nr * frags) pk = seedextend_lds(wtaxa + lane * flen, flen, min_seed, max_gap);
             se_panic = __ballot(pk);
             wave_lds_sync();
         }
+        if (GATHER == SRC_WALK && (H.walk_debug & 16u)) { if (lane < nr) { out_taxon[r0 + lane] = wtaxa[lane * stride]; out_status[r0 + lane] = 0; } continue; }
         // ---- aggregate the group: taxonomy round trips once per group, not once per read (agg_group.hpp) ----
         lca_group<BOUND>(V, S, tree_like, lower_bound, wtaxa, stride, nr, lane, se_panic, frags, r0, out_taxon, out_status,
                          [&](uint32_t k, uint32_t& res_taxon, uint32_t& res_status) {
@@ -953,6 +972,7 @@ HitSource walk_source(const umgap_index* ix) {
     H.walk_n_exc = ix->n_walk_exc;
     H.walk_exc_keys = ix->d_walk_exc_keys;
     H.walk_exc_pos = ix->d_walk_exc_pos;
+    if (const char* e = getenv("UMGAP_WALK_DEBUG")) H.walk_debug = (uint32_t)atoi(e);
     return H;
 }
 }  // namespace

@@ -41,6 +41,7 @@ struct HitSource {
     uint32_t walk_shift = 0, walk_n_exc = 0;
     const uint64_t* walk_exc_keys = nullptr;
     const uint64_t* walk_exc_pos = nullptr;
+    uint32_t walk_debug = 0;              // timing experiments only (UMGAP_WALK_DEBUG; answers are WRONG when set): 1 no phase B, 2 no entry loads, 4 no anchor probe
 };
 // where the hits of a group of the fused 9-mer kernels come from
 constexpr int SRC_PROBE = 0, SRC_GATHER = 1, SRC_WALK = 2;
