@@ -112,7 +112,17 @@ __device__ __forceinline__ void lds_count(uint32_t* keys, uint32_t* cnt, uint32_
                                           bool& keep0, bool& keep1, float& cnt0, float& cnt1) {
     uint32_t slot0 = 0, slot1 = 0;
     bool lead0 = false, lead1 = false;
-    if (t0 != 0) {
+    // Neighbouring windows of a protein mostly carry the same taxon: a RUN of equal taxa over consecutive lanes is counted by its
+    // first lane alone, with the run's length (round 5).  Sixty-four lanes with one taxon were sixty-four compare-and-swaps and
+    // sixty-four adds on ONE LDS address, served one after another -- for reads that follow a proteome that was most of the aggregate
+    // stage's time (UMGAP_WALK_DEBUG=16: 4.3 of 10.3 ms).
+    const uint32_t p0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t0, 0x138, 0xF, 0xF, true);      // wave_shr:1 (lane 0 sees 0)
+    const uint32_t p1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t1, 0x138, 0xF, 0xF, true);
+    const uint64_t ch0 = __ballot(t0 != p0), ch1 = __ballot(t1 != p1);                                  // where a run starts (runs of misses too)
+    const uint32_t lane = __lane_id();
+    if (t0 != 0 && t0 != p0) {
+        const uint64_t above = (ch0 >> lane) >> 1;
+        const uint32_t len = above ? (uint32_t)__builtin_ctzll(above) + 1u : 64u - lane;
         slot0 = (t0 * 0x9E3779B1u) >> 24;
         for (;;) {
             uint32_t old = atomicCAS(&keys[slot0], 0u, t0);
@@ -120,9 +130,11 @@ __device__ __forceinline__ void lds_count(uint32_t* keys, uint32_t* cnt, uint32_
             if (old == t0) break;
             slot0 = (slot0 + 1) & 255u;
         }
-        atomicAdd(&cnt[slot0], 1u);
+        atomicAdd(&cnt[slot0], len);
     }
-    if (t1 != 0) {
+    if (t1 != 0 && t1 != p1) {
+        const uint64_t above = (ch1 >> lane) >> 1;
+        const uint32_t len = above ? (uint32_t)__builtin_ctzll(above) + 1u : 64u - lane;
         slot1 = (t1 * 0x9E3779B1u) >> 24;
         for (;;) {
             uint32_t old = atomicCAS(&keys[slot1], 0u, t1);
@@ -130,7 +142,7 @@ __device__ __forceinline__ void lds_count(uint32_t* keys, uint32_t* cnt, uint32_
             if (old == t1) break;
             slot1 = (slot1 + 1) & 255u;
         }
-        atomicAdd(&cnt[slot1], 1u);
+        atomicAdd(&cnt[slot1], len);
     }
     keep0 = keep1 = false;
     cnt0 = cnt1 = 0.0f;
