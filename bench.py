@@ -841,9 +841,19 @@ def main():
             # (tools/bench_surface_a_walk.py; requests per k-mer from the PMC pass in profiles/r05_surface_a_pmc.json)
             import bench_surface_a_walk
             sa = bench_surface_a_walk.run(50_000_000, 10_000_000, 30, steps=3, workload=w)
-            sa["requests_per_kmer"] = {"source": "profiles/r05_surface_a_pmc.json (TCC_EA0_RDREQ_sum per k-mer, key stream of 0.125 included; not re-measured in this run)",
-                                       "plain_table": 1.02, "walk_order_index": 0.63, "walk_order_index_reads_that_follow_the_proteome": 0.34}
+            try:
+                prof = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_surface_a_pmc.json")))["runs"]
+                sa["requests_per_kmer"] = {"source": "profiles/r05_surface_a_pmc.json (TCC_EA0_RDREQ_sum per k-mer, key stream of 0.125 included; not re-measured in this run)",
+                                           "plain_table": prof["3.0 % of the residues replaced"]["requests_per_kmer_plain_table"],
+                                           "walk_order_index": prof["3.0 % of the residues replaced"]["requests_per_kmer_walk_index_runs_cut_at_fragments"],
+                                           "walk_order_index_reads_that_follow_the_proteome": prof["0.0 % of the residues replaced"]["requests_per_kmer_walk_index_runs_cut_at_fragments"]}
+            except (OSError, KeyError, ValueError):
+                pass
             out["surface_a_overlapping"] = sa
+            torch.cuda.empty_cache()
+            # the same with reads that follow the proteome exactly (0 % of the residues replaced): what the walk order is for
+            s0 = bench_surface_a_walk.run(50_000_000, 10_000_000, 0, steps=2, workload=w)
+            sa["reads_that_follow_the_proteome"] = {k: s0[k] for k in ("plain_table", "walk_order_index", "speedup_walk_over_plain")}
         except Exception as e:  # noqa: BLE001
             out["surface_a_overlapping"] = {"error": "%s: %s" % (type(e).__name__, e)}
         torch.cuda.empty_cache()
