@@ -407,7 +407,9 @@ uint32_t umgap_sharded_pieces(const umgap_sharded* sh);
  * OWNER's receive buffer and the owner's probe stores each value straight into the REQUESTER's gather buffer, through hipIpc mappings
  * of the peers' exchange blocks (the same mappings run over xGMI between the GPUs of a node), with per-piece counters in device memory
  * instead of copies and host barriers.  Default between the processes of an IPC communicator (UMGAP_SHARD_PUT=0: copies); opt-in
- * under RCCL and between thread-ranks (UMGAP_SHARD_PUT=1).  In put mode umgap_sharded_free is collective. */
+ * under RCCL and between thread-ranks that drive different devices (UMGAP_SHARD_PUT=1; thread-ranks sharing a device share its
+ * hardware queues, where a spinning wait can block the kernel it waits for: they keep the copies).  In put mode umgap_sharded_free
+ * is collective. */
 int umgap_sharded_transport(const umgap_sharded* sh);
 /* get() over the whole sharded table: as umgap_index_lookup9_dev.  Collective: every rank calls it the same number of
  * times (n may differ, 0 included); enqueues on internal streams ordered after `stream` and joins them back into it. */

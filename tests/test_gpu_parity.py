@@ -1190,7 +1190,8 @@ def _run_ranks(world, fn):
             raise e
 
 
-@pytest.mark.parametrize("world,pieces,own_share", [(1, 1, "probed in place"), (2, 3, "probed in place"), (3, 8, "packed"), (8, 4, "probed in place"), (2, 2, "packed")])
+@pytest.mark.parametrize("world,pieces,own_share", [(1, 1, "probed in place"), (2, 3, "probed in place"), (3, 8, "packed"), (8, 4, "probed in place"), (2, 2, "packed"),
+                                                    (3, 5, "peer-written")])
 def test_sharded_table_local_ranks_match_whole_table(api, torch_cuda, world, pieces, own_share, monkeypatch):
     """The N-rank sharded path of the C ABI (pack 6-byte keys -> exchange -> probe on the owner -> 3-byte values back ->
     gather + [seedextend] + aggregate), all ranks on this one GPU through the local communicator: every rank's answers are
@@ -1201,6 +1202,10 @@ def test_sharded_table_local_ranks_match_whole_table(api, torch_cuda, world, pie
     # a rank's own keys are normally probed by the kernel that consumes the hits; UMGAP_SHARD_NO_LOCAL=1 (read when the group is
     # created) sends them through pack / probe / gather like everybody else's
     monkeypatch.setenv("UMGAP_SHARD_NO_LOCAL", "1" if own_share == "packed" else "0")
+    # "peer-written": put mode ASKED FOR between thread-ranks that share the GPU -- refused (they share the process's hardware queues: a
+    # stage spinning on a peer's counter can sit in front of the kernel that would raise it); the hub's copies serve
+    monkeypatch.setenv("UMGAP_SHARD_PUT", "1" if own_share == "peer-written" else "0")
+    monkeypatch.setenv("UMGAP_PUT_TIMEOUT_S", "20")
     n_tax, n_keys, stride = 20_000, 1_500_000, 84
     w = SyntheticWorkload(n_tax=n_tax, n_keys=n_keys)
     n_reads = [4001 + 173 * r for r in range(world)]                       # ragged: every rank owns a different number of reads
@@ -1226,6 +1231,8 @@ def test_sharded_table_local_ranks_match_whole_table(api, torch_cuda, world, pie
         torch.cuda.set_device(0)
         sh = Sharded(shards[r], w.taxonomy, comms[r], max_keys, pieces=pieces)
         assert sh.value_bytes == 3 and sh.pieces == pieces
+        if world > 1:
+            assert sh.transport == "copy", sh.transport      # thread-ranks that share a device keep the hub's copies, asked or not
         st = torch.cuda.Stream()
         with torch.cuda.stream(st):
             for _ in range(2):                                              # buffer sets are reused across calls

@@ -846,6 +846,7 @@ struct PutBlob {
     hipIpcMemHandle_t mem;
     uint64_t block, block_bytes, cap, flags_off;
     uint32_t world, value_bytes, want_put, pid;
+    int32_t device, pad;
 };
 static_assert(sizeof(PutBlob) <= BLOB_BYTES, "the contribution of a rank fits comm_allgather");
 
@@ -872,6 +873,7 @@ int put_setup(umgap_sharded* sh) {
         mine.value_bytes = sh->value_bytes;
         mine.want_put = want ? 1u : 0u;
         mine.pid = (uint32_t)getpid();
+        mine.device = sh->device;
         if (want && !c->hub && hipIpcGetMemHandle(&mine.mem, sh->block) != hipSuccess) { (void)hipGetLastError(); mine.want_put = 0; }
         PUT_TRACE("allgather ...");
         int rc = comm_allgather(c, &mine, all.data(), sizeof(PutBlob));
@@ -882,6 +884,13 @@ int put_setup(umgap_sharded* sh) {
                 return fail(UMGAP_ERR_INVALID, "umgap_sharded_create: rank " + std::to_string(p) + " laid its exchange buffers out differently (max_keys_per_call, pieces and slack must agree on every rank)");
             want = want && all[p].want_put;                 // everybody, or nobody
         }
+        // Ranks that are threads of ONE process on ONE device share that process's hardware queues (the runtime folds its streams onto
+        // four per priority): a stage that spins on a peer's counter can sit in front of the very kernel that would raise it -- seen as
+        // a stall until the time-out with three thread-ranks on one GPU.  Processes have queues of their own; thread-ranks keep the
+        // hub's copies unless every rank drives a device of its own.
+        for (uint32_t p = 0; p < W && want; p++)
+            for (uint32_t q = p + 1; q < W; q++)
+                if (all[p].pid == all[q].pid && all[p].device == all[q].device) want = false;
     }
     sh->put = want;
     sh->peers.base[me] = (uint64_t)(uintptr_t)sh->block;
