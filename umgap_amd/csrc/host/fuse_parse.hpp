@@ -33,25 +33,28 @@ namespace umgap_host {
 // growth.
 struct PartBytes {
     uint8_t* p = nullptr;
+    bool plain = true;                     // p came from new[] (no allocator installed, or the allocator had nothing left)
     void* (*alloc)(size_t) = nullptr;      // both null: new[] / delete[]
     void (*release)(void*) = nullptr;
     PartBytes() = default;
     PartBytes(const PartBytes&) = delete;
     PartBytes& operator=(const PartBytes&) = delete;
-    PartBytes(PartBytes&& o) noexcept : p(o.p), alloc(o.alloc), release(o.release) { o.p = nullptr; }
+    PartBytes(PartBytes&& o) noexcept : p(o.p), plain(o.plain), alloc(o.alloc), release(o.release) { o.p = nullptr; }
     PartBytes& operator=(PartBytes&& o) noexcept {
-        if (this != &o) { drop(); p = o.p; alloc = o.alloc; release = o.release; o.p = nullptr; }
+        if (this != &o) { drop(); p = o.p; plain = o.plain; alloc = o.alloc; release = o.release; o.p = nullptr; }
         return *this;
     }
     ~PartBytes() { drop(); }
     void drop() {
-        if (p) { if (release) release(p); else delete[] p; }
+        if (p) { if (!plain && release) release(p); else delete[] p; }
         p = nullptr;
     }
+    // (a page-locked allocation that fails falls back to plain memory: the device call then gathers the piece through its staging)
     void reset_to(size_t bytes) {
         drop();
-        p = alloc ? (uint8_t*)alloc(bytes) : new uint8_t[bytes];
-        if (!p) throw std::bad_alloc();
+        p = alloc ? (uint8_t*)alloc(bytes) : nullptr;
+        plain = p == nullptr;
+        if (!p) p = new uint8_t[bytes];
     }
     uint8_t* get() const { return p; }
 };
