@@ -624,7 +624,9 @@ __device__ __forceinline__ void lca_group_spans(const TaxView& V, const LcaView&
             uint32_t st = ST_PENDING, M = 0, hp = NONE, ans = 0;
             if (G.rM[r] == NONE) { st = skip_status; ans = 0; }          // a read span() refused
             else if (D == 0) { st = UMGAP_READ_EMPTY; ans = 1; }         // literal "1" (src/commands/taxa2agg.rs:174-175)
-            else if (BOUND) {
+            else if (BOUND && D == 1) {                                  // one surviving taxon (a read out of one organism): it is the answer's M
+                M = bound::pre_of(wtaxa[base + o0]);
+            } else if (BOUND) {
                 const uint32_t v = lane < D ? wtaxa[base + o0 + lane] : 0u;
                 const uint32_t p = lane < D ? bound::pre_of(v) : 0u;
                 M = wave_max(p);
