@@ -164,29 +164,48 @@ __device__ __forceinline__ void walk_group_to_strip(const TableView& T, const Hi
         // The proteome's key at entry p + k: K_k = (key0 << 5k | sum over j = 1..k of r_j << 5(k - j)) mod 2^45, r_j = the low five key
         // bits of entry p + j -- the residues of the nine lanes up to k, fetched with row shifts ----
         const uint32_t steps = (min(64u, n_runs - run0) + 3u) >> 2;
-        for (uint32_t s = 0; s < steps; s++) {                    // wave-uniform
-            const int from = (int)(4u * s + row);
-            const uint32_t r_first = (uint32_t)__shfl((int)first, from, 64), r_n = (uint32_t)__shfl((int)n_mine, from, 64);
-            const uint64_t r_pos = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(pos >> 32), from, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)pos, from, 64);
-            const uint64_t r_key0 = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(key0 >> 32), from, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)key0, from, 64);
-            const bool active = k < r_n, has = r_pos != WALK_NOPOS;
-            const uint64_t key = active ? __builtin_nontemporal_load(kp + r_first + k) : ~0ull;
-            const uint64_t e = (!(H.walk_debug & 2u) && active && has && r_pos + k < W.n) ? W.E[r_pos + k] : WALK_PAD_ENTRY;
-            const uint32_t ey = (uint32_t)(e >> 32);
-            // entries p + 1 .. p + k all continue their predecessor: the row's bits 1..k of the ballot
-            const uint64_t cm = __ballot(k == 0u || (ey >> 31));
-            const uint32_t rb = (uint32_t)(cm >> (16u * row)) & 0xFFFFu;
-            const bool chain = has && ((~rb) & ((2u << k) - 2u)) == 0u;
-            const uint32_t r = k == 0u ? 0u : (ey & 31u);
-            // the nine residues up to lane k, by doubling: pairs, fours, eight + one (row shifts, zero from beyond the row's start)
+        // four steps at a time: their eight loads are issued together, branch-free (a lane with nothing to fetch reads kp[0]), and
+        // only then waited for -- with a load under its own `if` the compiler ended every step in a wait, eighteen round trips per pass
+        constexpr uint32_t UB = 4;
+        for (uint32_t s0 = 0; s0 < steps; s0 += UB) {             // wave-uniform (steps <= 16: 4 (s0 + u) + row <= 63)
+            uint32_t r_first[UB];
+            uint64_t r_key0[UB], key[UB], e[UB];
+            bool active[UB], has[UB];
+#pragma unroll
+            for (uint32_t u = 0; u < UB; u++) {
+                const int from = (int)(4u * (s0 + u) + row);
+                r_first[u] = (uint32_t)__shfl((int)first, from, 64);
+                const uint32_t r_n = (uint32_t)__shfl((int)n_mine, from, 64);
+                const uint64_t r_pos = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(pos >> 32), from, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)pos, from, 64);
+                r_key0[u] = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(key0 >> 32), from, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)key0, from, 64);
+                active[u] = k < r_n;
+                has[u] = r_pos != WALK_NOPOS;
+                const bool fetch = !(H.walk_debug & 2u) && active[u] && has[u] && r_pos + k < W.n;
+                const uint64_t* kq = active[u] ? kp + r_first[u] + k : kp;
+                const uint64_t* eq = fetch ? W.E + r_pos + k : kp;
+                key[u] = __builtin_nontemporal_load(kq);
+                e[u] = *eq;
+                if (!active[u]) key[u] = ~0ull;
+                if (!fetch) e[u] = WALK_PAD_ENTRY;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < UB; u++) {
+                const uint32_t ey = (uint32_t)(e[u] >> 32);
+                // entries p + 1 .. p + k all continue their predecessor: the row's bits 1..k of the ballot
+                const uint64_t cm = __ballot(k == 0u || (ey >> 31));
+                const uint32_t rb = (uint32_t)(cm >> (16u * row)) & 0xFFFFu;
+                const bool chain = has[u] && ((~rb) & ((2u << k) - 2u)) == 0u;
+                const uint32_t r = k == 0u ? 0u : (ey & 31u);
+                // the nine residues up to lane k, by doubling: pairs, fours, eight + one (row shifts, zero from beyond the row's start)
 #define UMGAP_ROW_SHR(V, N) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(V), 0x110 + (N), 0xF, 0xF, true)
-            const uint32_t p2 = r | (UMGAP_ROW_SHR(r, 1) << 5);
-            const uint32_t p4 = p2 | (UMGAP_ROW_SHR(p2, 2) << 10);
-            const uint32_t s4 = UMGAP_ROW_SHR(p4, 4), r8 = UMGAP_ROW_SHR(r, 8);
+                const uint32_t p2 = r | (UMGAP_ROW_SHR(r, 1) << 5);
+                const uint32_t p4 = p2 | (UMGAP_ROW_SHR(p2, 2) << 10);
+                const uint32_t s4 = UMGAP_ROW_SHR(p4, 4), r8 = UMGAP_ROW_SHR(r, 8);
 #undef UMGAP_ROW_SHR
-            const uint64_t acc = ((uint64_t)((s4 >> 12) | (r8 << 8)) << 32) | (uint64_t)(p4 | (s4 << 20));
-            const uint64_t K = (k <= 8u ? (r_key0 << (5u * k)) & MASK45 : 0ull) | acc;
-            if (active) wtaxa[r_first + k] = k == 0u ? (has ? (uint32_t)e : 0u) : ((chain && K == key) ? (uint32_t)e : WALK_OPEN);
+                const uint64_t acc = ((uint64_t)((s4 >> 12) | (r8 << 8)) << 32) | (uint64_t)(p4 | (s4 << 20));
+                const uint64_t K = (k <= 8u ? (r_key0[u] << (5u * k)) & MASK45 : 0ull) | acc;
+                if (active[u]) wtaxa[r_first[u] + k] = k == 0u ? (has[u] ? (uint32_t)e[u] : 0u) : ((chain && K == key[u]) ? (uint32_t)e[u] : WALK_OPEN);
+            }
         }
     }
     wave_lds_sync();
