@@ -585,6 +585,40 @@ __device__ __forceinline__ void lca_group_spans(const TaxView& V, const LcaView&
             if (lane == 0) G.rM[k - k0] = 0;
             const uint32_t* rt = wtaxa + start;
             const uint32_t t0 = lane < stride ? rt[lane] : 0u, t1 = 64 + lane < stride ? rt[64 + lane] : 0u;
+            // A read out of one or two organisms (round 5): its hits hold at most two distinct taxa -- found with four ballots, counted with
+            // popcounts, no hash table, no LDS round trip (the table's three phases are a chain of LDS atomics per read).  Wave-uniform.
+            const uint64_t nz0 = __ballot(t0 != 0u), nz1 = __ballot(t1 != 0u);
+            uint32_t few = 0, T1 = 0, T2 = 0, cn1 = 0, cn2 = 0;       // few: 1 = at most two distinct taxa, counted here
+            if (!(nz0 | nz1)) few = 1;
+            else {
+                T1 = nz0 ? (uint32_t)__builtin_amdgcn_readlane((int)t0, __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(nz0)))
+                         : (uint32_t)__builtin_amdgcn_readlane((int)t1, __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(nz1)));
+                const uint64_t a0 = __ballot(t0 == T1), a1 = __ballot(t1 == T1), r0 = nz0 & ~a0, r1 = nz1 & ~a1;
+                cn1 = (uint32_t)__builtin_popcountll(a0) + (uint32_t)__builtin_popcountll(a1);
+                if (!(r0 | r1)) few = 1;
+                else {
+                    T2 = r0 ? (uint32_t)__builtin_amdgcn_readlane((int)t0, __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(r0)))
+                            : (uint32_t)__builtin_amdgcn_readlane((int)t1, __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(r1)));
+                    const uint64_t c0m = __ballot(t0 == T2), c1m = __ballot(t1 == T2);
+                    cn2 = (uint32_t)__builtin_popcountll(c0m) + (uint32_t)__builtin_popcountll(c1m);
+                    if (!((r0 & ~c0m) | (r1 & ~c1m))) few = 1;
+                }
+            }
+            if (few) {
+                const bool k1 = cn1 != 0u && (float)cn1 >= lower_bound, k2 = cn2 != 0u && (float)cn2 >= lower_bound;     // agg::filter keeps freq >= lower_bound
+                const uint32_t ns = (k1 ? 1u : 0u) + (k2 ? 1u : 0u);
+                if (w + ns > G.cap) break;
+                wave_sync();                     // every lane holds its taxa in registers before the strip is overwritten
+                if (lane == 0) {
+                    if (k1) wtaxa[base + w] = T1;
+                    if (k2) wtaxa[base + w + (k1 ? 1u : 0u)] = T2;
+                    G.roff[k - k0 + 1] = w + ns;
+                }
+                w += ns;
+                wave_sync();
+                k++;
+                continue;
+            }
             bool keep0, keep1;
             float c0, c1;
             lds_count(G.hkeys, G.hcnt, t0, t1, lower_bound, keep0, keep1, c0, c1);
