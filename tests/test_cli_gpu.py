@@ -103,11 +103,14 @@ def test_prot2kmer2lca_matches_oracle(world, k_flags):
     assert rc == 0 == orc and out == oout, err
 
 
-@pytest.mark.parametrize("shards,local", [(1, False), (2, True), (5, True)])
-def test_prot2kmer2lca_shards(world, shards, local):
-    """`umgap prot2kmer2lca --shards N`: the index sharded over N GPUs inside one process (RCCL), what the resident server of
+@pytest.mark.parametrize("shards,local,procs", [(1, False, False), (2, True, False), (5, True, False), (2, True, True), (3, True, True)])
+def test_prot2kmer2lca_shards(world, shards, local, procs):
+    """`umgap prot2kmer2lca --shards N`: the index sharded over N GPUs, what the resident server of
     scripts/umgap-analyse.sh:257-264 becomes when the index outgrows one GPU.  Same bytes out as the single-table command.
-    A one-GPU box runs N = 1 over RCCL and N > 1 with every rank on GPU 0 (UMGAP_SHARDS_LOCAL)."""
+    A one-GPU box runs N = 1 over RCCL and N > 1 with every rank on GPU 0 (UMGAP_SHARDS_LOCAL).  `procs`: the ranks are
+    PROCESSES (`--shard-processes`: this command is rank 0 and starts the others, the exchange is the IPC communicator's
+    peer-written one, the batches travel through a shared-memory block) -- the form a node of GPUs runs, rehearsed here with
+    the processes sharing the one GPU; a small UMGAP_SHARDS_MAX_KEYS makes a batch take several collective rounds."""
     rng = np.random.default_rng(50 + shards)
     recs = []
     for r in range(2000):
@@ -120,11 +123,35 @@ def test_prot2kmer2lca_shards(world, shards, local):
     fasta = "".join(recs).encode()
     rc0, out0, err0 = run(["prot2kmer2lca", "-o", world["idx"]], fasta)
     env = {"UMGAP_SHARDS_LOCAL": "1"} if local else {}
-    rc, out, err = _run_env(["prot2kmer2lca", "-o", "--shards", str(shards), world["idx"]], fasta, UMGAP_BLOCK_BYTES=20000, **env)
+    extra = ["--shard-processes"] if procs else []
+    if procs:
+        env["UMGAP_SHARDS_MAX_KEYS"] = "4096"
+    rc, out, err = _run_env(["prot2kmer2lca", "-o", "--shards", str(shards)] + extra + [world["idx"]], fasta, UMGAP_BLOCK_BYTES=20000, **env)
     assert rc0 == 0 == rc and out == out0, err
     assert sum(1 for l in out.decode().splitlines() if l.isdigit() and l != "0") > 500
-    rc, out, err = _run_env(["prot2kmer2lca", "--shards", str(shards), world["idx"]], fasta, **env)
+    if procs:
+        env.pop("UMGAP_SHARDS_MAX_KEYS")
+        env["UMGAP_SHARDS_PROCS"] = "1"          # the switch in the environment, default batch size
+        extra = []
+    rc, out, err = _run_env(["prot2kmer2lca", "--shards", str(shards)] + extra + [world["idx"]], fasta, **env)
     assert rc == 0 and out == run(["prot2kmer2lca", world["idx"]], fasta)[1], err
+    if procs:
+        # no worker outlives the command, no shared-memory block either
+        ps = subprocess.run(["ps", "-eo", "args"], stdout=subprocess.PIPE).stdout.decode()
+        assert "__shard-worker" not in ps
+        assert not [f for f in os.listdir("/dev/shm") if f.startswith("umgap-gang-") or f.startswith("umgap-hub-")]
+
+
+def test_prot2kmer2lca_shard_processes_errors(world, tmp_path):
+    """A gang of process-ranks that cannot stand ends with the failing rank's message and exit 1; nothing is left behind."""
+    rc, out, err = _run_env(["prot2kmer2lca", "--shards", "2", "--shard-processes", str(tmp_path / "missing.umgapix")], b">a\nAAAAAAAAAA\n",
+                            UMGAP_SHARDS_LOCAL="1", UMGAP_IPC_TIMEOUT_S="20")
+    assert rc == 1 and err.startswith(b"Error: ") and out == b"", err
+    rc, out, err = _run_env(["prot2kmer2lca", "--shards", "65", "--shard-processes", world["idx"]], b"", UMGAP_SHARDS_LOCAL="1")
+    assert rc == 1 and b"--shards must be in 1..64" in err
+    ps = subprocess.run(["ps", "-eo", "args"], stdout=subprocess.PIPE).stdout.decode()
+    assert "__shard-worker" not in ps
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("umgap-gang-")]
 
 
 def _taxa_fasta(w, rng, n_records, unknown=False):

@@ -6,9 +6,15 @@
 //
 // Output order: the reference emits rayon chunks in completion order (src/commands/pept2lca.rs:62-68);
 // this command always emits input order (= the reference under RAYON_NUM_THREADS=1).
+#include <fcntl.h>
 #include <signal.h>
+#include <spawn.h>
+#include <sys/mman.h>
+#include <sys/prctl.h>
 #include <sys/socket.h>
+#include <sys/stat.h>
 #include <sys/un.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <algorithm>
@@ -26,6 +32,8 @@
 #include "fastpath.hpp"
 #include "fuse_parse.hpp"
 #include "text.hpp"
+
+extern char** environ;
 
 using namespace umgap_host;
 
@@ -681,17 +689,43 @@ void stream_kmer_records(FILE* in, FILE* outf, umgap_index* ix, bool one_on_one,
                         t_read, t_parse, t_wait, t_gather, t_lookup, t_format, t_write);
 }
 
-// --shards N: the index sharded by bucket range over N GPUs inside this one process (one host thread per GPU), the exchange
-// over RCCL -- what the resident `umgap prot2kmer2lca -m -o -s <socket>` server of scripts/umgap-analyse.sh:257-264 becomes
-// when the index outgrows one GPU.  Rank r holds shard r (umgap_index_open_shard) on GPU r and looks up the r-th slice of every
-// batch; umgap_sharded_lookup9 routes each k-mer to its owner and back.  UMGAP_SHARDS_LOCAL=1 puts every rank on GPU 0 with
-// the library's device-to-device transport (rehearsal on a one-GPU box; the tests use it).
+// --shards N: the index sharded by bucket range over N GPUs -- what the resident `umgap prot2kmer2lca -m -o -s <socket>` server
+// of scripts/umgap-analyse.sh:257-264 becomes when the index outgrows one GPU.  Rank r holds shard r (umgap_index_open_shard) on
+// GPU r and looks up the r-th slice of every batch; umgap_sharded_lookup9 routes each k-mer to its owner and back.
+//   * ranks as THREADS of this process (default): one host thread per GPU, the exchange over RCCL.
+//   * ranks as PROCESSES (--shard-processes, or UMGAP_SHARDS_PROCS=1): this process is rank 0 and starts N - 1 workers
+//     (`umgap __shard-worker`, started before anything here touches the GPU); the exchange runs over the IPC communicator
+//     (umgap_comm_init_ipc: peer-written keys and values through hipIpc mappings -- between GPUs the same mappings travel over
+//     xGMI), the batches reach the workers through one POSIX shared-memory block (control words, keys, taxa).
+// UMGAP_SHARDS_LOCAL=1 puts every rank on GPU 0 (threads: the library's device-to-device hub; processes: the same IPC
+// communicator) -- the rehearsal on a one-GPU box; the tests use it.
+struct ShardProcCtl {                  // head of the shared block; keys and taxa follow at `keys_off` / `taxa_off`
+    std::atomic<uint64_t> seq;         // rank 0 bumps it per command
+    std::atomic<uint32_t> cmd;         // 1 = lookup of [lo[r], hi[r]), 2 = umgap_sharded_check, 3 = leave
+    std::atomic<uint32_t> ready;       // workers whose group stands
+    std::atomic<uint32_t> done;        // workers that finished command `seq`
+    std::atomic<uint32_t> failed;      // a worker that could not come up (its message is in err[rank])
+    uint32_t world;
+    uint64_t max_keys, keys_off, taxa_off, bytes;
+    uint64_t lo[64], hi[64];
+    std::atomic<int32_t> rc[64];
+    char err[64][232];
+};
+static_assert(std::atomic<uint64_t>::is_always_lock_free && std::atomic<uint32_t>::is_always_lock_free, "the control words live in shared memory");
+
+inline void shard_proc_nap() { struct timespec ts{0, 50000}; nanosleep(&ts, nullptr); }
+
 struct ShardGang {
     std::vector<umgap_index*> ix;
     std::vector<umgap_comm*> comm;
     std::vector<umgap_sharded*> sh;
     uint64_t max_keys = 48u << 20;     // per rank and call
     int n = 0;
+    // ranks as processes
+    bool procs = false;
+    std::vector<pid_t> workers;        // ranks 1 .. n-1
+    ShardProcCtl* ctl = nullptr;
+    std::string shm_name;
     template <class F>
     void each_rank(F f) {              // f(rank) on n threads; the first failure is rethrown
         std::vector<std::thread> ts;
@@ -700,19 +734,21 @@ struct ShardGang {
         for (auto& t : ts) t.join();
         for (auto& e : errs) if (e) std::rethrow_exception(e);
     }
-    ShardGang(const std::string& path, int shards) : n(shards) {
+    // RCCL announces its version on stdout when the first communicator comes up; stdout is this command's data, so it
+    // points at stderr until the gang stands
+    struct StdoutToStderr {
+        int saved;
+        StdoutToStderr() { fflush(stdout); umgap_host::AsyncIo::drain_all(); saved = dup(1); if (saved >= 0) dup2(2, 1); }
+        ~StdoutToStderr() { fflush(stdout); umgap_host::AsyncIo::drain_all(); if (saved >= 0) { dup2(saved, 1); close(saved); } }
+    };
+    ShardGang(const std::string& path, int shards, bool as_processes) : n(shards), procs(as_processes) {
         const bool local = getenv("UMGAP_SHARDS_LOCAL") != nullptr;
         if (shards < 1 || shards > 64) throw CliError("--shards must be in 1..64");
+        if (procs) { start_processes(path, local); return; }
         if (!local && umgap_device_count() < shards) throw CliError("--shards " + std::to_string(shards) + " needs that many GPUs (" + std::to_string(umgap_device_count()) + " visible)");
         ix.assign(n, nullptr); comm.assign(n, nullptr); sh.assign(n, nullptr);
         uint8_t id[128];
-        // RCCL announces its version on stdout when the first communicator comes up; stdout is this command's data, so it
-        // points at stderr until the gang stands
-        struct StdoutToStderr {
-            int saved;
-            StdoutToStderr() { fflush(stdout); umgap_host::AsyncIo::drain_all(); saved = dup(1); if (saved >= 0) dup2(2, 1); }
-            ~StdoutToStderr() { fflush(stdout); umgap_host::AsyncIo::drain_all(); if (saved >= 0) { dup2(saved, 1); close(saved); } }
-        } quiet;
+        StdoutToStderr quiet;
         if (local) { if (umgap_comm_init_local(n, 0, comm.data()) != UMGAP_OK) throw CliError(umgap_last_error()); }
         else if (umgap_comm_unique_id(id) != UMGAP_OK) throw CliError(umgap_last_error());
         each_rank([&](int r) {
@@ -725,11 +761,13 @@ struct ShardGang {
         });
     }
     ~ShardGang() {
+        if (procs) { stop_processes(); return; }
         for (auto s : sh) umgap_sharded_free(s);
         for (auto c : comm) umgap_comm_free(c);
         for (auto i : ix) umgap_index_free(i);
     }
     void lookup(const uint64_t* keys, size_t total, uint32_t* taxa) {
+        if (procs) { lookup_processes(keys, total, taxa); return; }
         // every rank makes the same number of (collective) calls: rounds of at most n * max_keys keys, split evenly
         for (size_t done = 0; done < total;) {
             const size_t round = std::min<size_t>(total - done, (size_t)n * max_keys), per = (round + n - 1) / n;
@@ -742,7 +780,171 @@ struct ShardGang {
         // an overflowed exchange region would have answered some k-mers with a miss: refuse to print such a batch
         each_rank([&](int r) { LIB(umgap_sharded_check(sh[r])); });
     }
+
+    // ---- ranks as processes ----------------------------------------------------------------------------------------------
+    static void* map_block(const char* name, bool create, size_t bytes, std::string& why) {
+        int fd = shm_open(name, create ? (O_CREAT | O_EXCL | O_RDWR) : O_RDWR, 0600);
+        if (fd < 0) { why = std::string("shm_open ") + name + ": " + strerror(errno); return nullptr; }
+        if (create && ftruncate(fd, (off_t)bytes) != 0) { why = std::string("ftruncate: ") + strerror(errno); close(fd); shm_unlink(name); return nullptr; }
+        if (!create) { struct stat st; if (fstat(fd, &st) != 0 || (size_t)st.st_size < sizeof(ShardProcCtl)) { why = "shared block too small"; close(fd); return nullptr; } bytes = (size_t)st.st_size; }
+        void* p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (p == MAP_FAILED) { why = std::string("mmap: ") + strerror(errno); if (create) shm_unlink(name); return nullptr; }
+        return p;
+    }
+    uint64_t* shared_keys() const { return (uint64_t*)((char*)ctl + ctl->keys_off); }
+    uint32_t* shared_taxa() const { return (uint32_t*)((char*)ctl + ctl->taxa_off); }
+    // a worker that died leaves its collective partners waiting: say so instead of waiting with them
+    void reap_or_throw() {
+        for (size_t i = 0; i < workers.size(); i++) {
+            if (workers[i] <= 0) continue;
+            int st = 0;
+            if (waitpid(workers[i], &st, WNOHANG) == workers[i]) {
+                workers[i] = -1;
+                const int r = (int)i + 1;
+                std::string msg = ctl && ctl->err[r][0] ? std::string(ctl->err[r]) : std::string("ended unexpectedly");
+                throw CliError("--shards: rank " + std::to_string(r) + " " + msg);
+            }
+        }
+    }
+    void kill_workers() {
+        for (auto& w : workers) if (w > 0) { kill(w, SIGTERM); int st; waitpid(w, &st, 0); w = -1; }
+    }
+    void start_processes(const std::string& path, bool local) {
+        max_keys = 16u << 20;          // (the shared block holds world x max_keys keys and taxa: 192 MB per rank)
+        if (const char* e = getenv("UMGAP_SHARDS_MAX_KEYS")) { uint64_t v = strtoull(e, nullptr, 10); if (v >= 1024 && v <= (1ull << 28)) max_keys = v; }
+        char tag[64];
+        snprintf(tag, sizeof tag, "%d-%llx", (int)getpid(), (unsigned long long)std::chrono::steady_clock::now().time_since_epoch().count());
+        shm_name = std::string("/umgap-gang-") + tag;
+        const std::string ipc_name = std::string("/umgap-hub-") + tag;
+        const size_t head = (sizeof(ShardProcCtl) + 4095) & ~(size_t)4095;
+        const size_t bytes = head + (size_t)n * max_keys * 12;
+        std::string why;
+        ctl = (ShardProcCtl*)map_block(shm_name.c_str(), true, bytes, why);
+        if (!ctl) throw CliError("--shards: " + why);
+        new (ctl) ShardProcCtl();      // (a fresh shared-memory object is zero-filled; this names the atomics' lifetime)
+        ctl->world = (uint32_t)n; ctl->max_keys = max_keys; ctl->keys_off = head; ctl->taxa_off = head + (size_t)n * max_keys * 8; ctl->bytes = bytes;
+        ix.assign(1, nullptr); comm.assign(1, nullptr); sh.assign(1, nullptr);
+        try {
+            // the workers first: nothing in this process has touched the GPU yet
+            for (int r = 1; r < n; r++) {
+                const std::string rs = std::to_string(r), ws = std::to_string(n), ds = std::to_string(local ? 0 : r), ps = std::to_string((long)getpid());
+                const char* argv[] = {"umgap", "__shard-worker", path.c_str(), rs.c_str(), ws.c_str(), ds.c_str(), ipc_name.c_str(), shm_name.c_str(), ps.c_str(), nullptr};
+                posix_spawn_file_actions_t fa;
+                posix_spawn_file_actions_init(&fa);
+                posix_spawn_file_actions_addopen(&fa, 0, "/dev/null", O_RDONLY, 0);
+                posix_spawn_file_actions_adddup2(&fa, 2, 1);      // a worker's stdout is not this command's data
+                pid_t pid = 0;
+                const int e = posix_spawn(&pid, "/proc/self/exe", &fa, nullptr, (char* const*)argv, environ);
+                posix_spawn_file_actions_destroy(&fa);
+                if (e != 0) throw CliError(std::string("--shards: cannot start a worker: ") + strerror(e));
+                workers.push_back(pid);
+            }
+            if (!local && umgap_device_count() < n) throw CliError("--shards " + std::to_string(n) + " needs that many GPUs (" + std::to_string(umgap_device_count()) + " visible)");
+            StdoutToStderr quiet;
+            LIB(umgap_index_open_shard(path.c_str(), 1u, 0u, (uint32_t)n, &ix[0]));
+            if (umgap_index_kind(ix[0]) != 9) throw CliError("--shards needs a 9-mer index");
+            LIB(umgap_comm_init_ipc(ipc_name.c_str(), n, 0, 0, &comm[0]));
+            LIB(umgap_comm_selftest(comm[0], 1 << 16));
+            LIB(umgap_sharded_create(ix[0], nullptr, comm[0], max_keys, 4, 0.05, &sh[0]));
+            while (ctl->ready.load(std::memory_order_acquire) < (uint32_t)(n - 1)) { reap_or_throw(); shard_proc_nap(); }
+        } catch (...) {
+            std::string first;            // a worker's own message says more than the time-out it caused here
+            if (ctl->failed.load()) for (int r = 1; r < n && first.empty(); r++) if (ctl->err[r][0]) first = "--shards: rank " + std::to_string(r) + " " + ctl->err[r];
+            kill_workers();
+            shm_unlink(shm_name.c_str());
+            munmap(ctl, bytes); ctl = nullptr;
+            if (!first.empty()) throw CliError(first);
+            throw;
+        }
+        shm_unlink(shm_name.c_str());     // everyone is attached: the block goes with its last mapping
+    }
+    void command(uint32_t cmd) {
+        ctl->done.store(0, std::memory_order_relaxed);
+        ctl->cmd.store(cmd, std::memory_order_relaxed);
+        ctl->seq.fetch_add(1, std::memory_order_release);
+    }
+    void wait_done() {
+        while (ctl->done.load(std::memory_order_acquire) < (uint32_t)(n - 1)) { reap_or_throw(); shard_proc_nap(); }
+        for (int r = 1; r < n; r++) if (ctl->rc[r].load()) throw CliError(std::string(ctl->err[r]));
+    }
+    void lookup_processes(const uint64_t* keys, size_t total, uint32_t* taxa) {
+        for (size_t done = 0; done < total;) {
+            const size_t round = std::min<size_t>(total - done, (size_t)n * max_keys), per = (round + n - 1) / n;
+            for (int r = 0; r < n; r++) { ctl->lo[r] = std::min(round, (size_t)r * per); ctl->hi[r] = std::min(round, (size_t)(r + 1) * per); }
+            if (round > ctl->hi[0]) memcpy(shared_keys() + ctl->hi[0], keys + done + ctl->hi[0], (round - ctl->hi[0]) * 8);   // (rank 0 reads its slice where it lies)
+            command(1);
+            const int rc0 = umgap_sharded_lookup9(sh[0], keys + done, ctl->hi[0], 0u, taxa + done);
+            const std::string err0 = rc0 ? umgap_last_error() : "";
+            wait_done();               // (the call is collective: the others are answered whether or not this rank failed)
+            if (rc0) throw CliError(err0);
+            if (round > ctl->hi[0]) memcpy(taxa + done + ctl->hi[0], shared_taxa() + ctl->hi[0], (round - ctl->hi[0]) * 4);
+            done += round;
+        }
+        command(2);
+        const int rc0 = umgap_sharded_check(sh[0]);
+        const std::string err0 = rc0 ? umgap_last_error() : "";
+        wait_done();
+        if (rc0) throw CliError(err0);
+    }
+    void stop_processes() {
+        if (ctl) {
+            command(3);                // (umgap_sharded_free is collective in put mode: every rank leaves together)
+            umgap_sharded_free(sh[0]); umgap_comm_free(comm[0]); umgap_index_free(ix[0]);
+            for (auto& w : workers) if (w > 0) { int st; waitpid(w, &st, 0); w = -1; }
+            munmap(ctl, ctl->bytes);
+            ctl = nullptr;
+        }
+    }
 };
+
+// `umgap __shard-worker <index> <rank> <world> <device> <hub name> <block name> <parent pid>`: rank >= 1 of a --shards gang
+// whose ranks are processes (started by ShardGang::start_processes, not by hand).
+int cmd_shard_worker(const std::vector<std::string>& a) {
+    if (a.size() != 7) usage_error("__shard-worker is started by `umgap prot2kmer2lca --shards N --shard-processes`");
+    const std::string& path = a[0];
+    const int rank = atoi(a[1].c_str()), world = atoi(a[2].c_str()), dev = atoi(a[3].c_str());
+    const pid_t parent = (pid_t)atol(a[6].c_str());
+    prctl(PR_SET_PDEATHSIG, SIGTERM);  // rank 0 gone => so is the gang
+    if (world < 2 || world > 64 || rank < 1 || rank >= world || dev < 0 || dev > 31) usage_error("__shard-worker: bad rank / world / device");
+    std::string why;
+    ShardProcCtl* ctl = (ShardProcCtl*)ShardGang::map_block(a[5].c_str(), false, 0, why);
+    if (!ctl) throw CliError(why);
+    auto note = [&](const std::string& m) { snprintf(ctl->err[rank], sizeof ctl->err[rank], "%s", m.c_str()); };
+    umgap_index* ix = nullptr; umgap_comm* comm = nullptr; umgap_sharded* sh = nullptr;
+    auto up = [&]() -> bool {
+        if (getppid() != parent) { note("lost its parent"); return false; }
+        if (umgap_index_open_shard(path.c_str(), 1u << dev, (uint32_t)rank, (uint32_t)world, &ix) != UMGAP_OK) { note(umgap_last_error()); return false; }
+        if (umgap_index_kind(ix) != 9) { note("--shards needs a 9-mer index"); return false; }
+        if (umgap_comm_init_ipc(a[4].c_str(), world, rank, dev, &comm) != UMGAP_OK) { note(umgap_last_error()); return false; }
+        if (umgap_comm_selftest(comm, 1 << 16) != UMGAP_OK) { note(umgap_last_error()); return false; }
+        if (umgap_sharded_create(ix, nullptr, comm, ctl->max_keys, 4, 0.05, &sh) != UMGAP_OK) { note(umgap_last_error()); return false; }
+        return true;
+    };
+    if (!up()) { ctl->failed.fetch_add(1); fprintf(stderr, "umgap shard worker %d: %s\n", rank, ctl->err[rank]); return 1; }
+    ctl->ready.fetch_add(1, std::memory_order_release);
+    uint64_t* keys = (uint64_t*)((char*)ctl + ctl->keys_off);
+    uint32_t* taxa = (uint32_t*)((char*)ctl + ctl->taxa_off);
+    uint64_t seen = 0;
+    for (;;) {
+        uint64_t s;
+        while ((s = ctl->seq.load(std::memory_order_acquire)) == seen) {
+            if (getppid() != parent) return 1;
+            shard_proc_nap();
+        }
+        seen = s;
+        const uint32_t cmd = ctl->cmd.load(std::memory_order_relaxed);
+        if (cmd == 3) break;
+        int rc = UMGAP_OK;
+        if (cmd == 1) rc = umgap_sharded_lookup9(sh, keys + ctl->lo[rank], ctl->hi[rank] - ctl->lo[rank], 0u, taxa + ctl->lo[rank]);
+        else if (cmd == 2) rc = umgap_sharded_check(sh);
+        if (rc) note(umgap_last_error());
+        ctl->rc[rank].store(rc);
+        ctl->done.fetch_add(1, std::memory_order_release);
+    }
+    umgap_sharded_free(sh); umgap_comm_free(comm); umgap_index_free(ix);
+    return 0;
+}
 
 umgap_index* open_index(const std::string& path) {
     umgap_index* ix = nullptr;
@@ -873,13 +1075,13 @@ int cmd_prot2tryp2lca(const std::vector<std::string>& args) {
 
 int cmd_prot2kmer2lca(const std::vector<std::string>& args) {
     Parsed p = parse_args(args, {{'k', "length", true}, {'o', "one-on-one", false}, {'s', "socket", true}, {'m', "in-memory", false}, {'c', "chunksize", true},
-                                 {0, "shards", true}});
+                                 {0, "shards", true}, {0, "shard-processes", false}});
     size_t k = (size_t)opt_usize(p, "length", 9);
     size_t chunk = (size_t)opt_usize(p, "chunksize", 240);
     std::string path = need_positional(p, "fst-file");
     bool o = p.has("one-on-one");
     std::unique_ptr<ShardGang> gang;
-    if (p.has("shards")) gang.reset(new ShardGang(path, (int)opt_usize(p, "shards", 1)));
+    if (p.has("shards")) gang.reset(new ShardGang(path, (int)opt_usize(p, "shards", 1), p.has("shard-processes") || getenv("UMGAP_SHARDS_PROCS") != nullptr));
     umgap_index* ix = gang ? nullptr : open_index(path);
     // A packed 9-mer table answers k = 9; any other k can only miss there (its keys are 9 residues long), which the fast
     // path emits without asking the device.  A byte-string (variable-length) table serves EVERY k like the reference's fst
@@ -2129,7 +2331,8 @@ int main(int argc, char** argv) {
     std::vector<std::string> args(argv + 1, argv + argc);
     // stdin / stdout behind a reader and a writer thread (async_io.hpp): the stage's pace in a pipe chain is then the slowest of
     // read, work and write instead of their sum.  Everything written is out before the process ends, whichever way it ends.
-    if (umgap_host::AsyncIo::enabled()) {
+    const bool worker = !args.empty() && args[0] == "__shard-worker";   // (no data on its stdin / stdout)
+    if (!worker && umgap_host::AsyncIo::enabled()) {
         FILE* in = umgap_host::AsyncIo::reader(0);
         FILE* out = umgap_host::AsyncIo::writer(1);
         if (in && out) {
@@ -2165,6 +2368,7 @@ static int run_command(std::vector<std::string> args) {
         if (cmd == "uniq") return cmd_uniq(args);
         if (cmd == "buildindex") return cmd_buildindex(args);
         if (cmd == "printindex") return cmd_printindex(args);
+        if (cmd == "__shard-worker") return cmd_shard_worker(args);
         usage_error("Found argument '" + cmd + "' which wasn't expected, or isn't valid in this context");
     } catch (CliError& e) {
         fflush(stdout);
