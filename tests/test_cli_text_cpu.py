@@ -391,3 +391,30 @@ def _feed(pipe, data):
         pipe.close()
     except (BrokenPipeError, OSError):
         pass
+
+
+def test_shard_processes_without_a_gpu_fail_loudly_and_leave_nothing(tmp_path):
+    """`umgap prot2kmer2lca --shards N --shard-processes` starts its worker ranks before it touches the device.  Where the gang cannot
+    stand (here: no GPU, or no index file) the command ends with `Error: ...` and exit 1, no worker outlives it and no shared-memory
+    block stays in /dev/shm; the hidden worker subcommand refuses to be started by hand."""
+    import time
+    if not os.path.exists(UMGAP):
+        pytest.skip("umgap_amd/bin/umgap is not built")
+    idx = tmp_path / "none.umgapix"
+    t0 = time.time()
+    rc, out, err = run(["prot2kmer2lca", "--shards", "3", "--shard-processes", str(idx)], b">a\nACDEFGHIKLM\n", UMGAP_SHARDS_LOCAL="1", UMGAP_IPC_TIMEOUT_S="10")
+    assert rc == 1 and out == b"" and err.startswith(b"Error: "), (rc, out, err)
+    assert time.time() - t0 < 60
+    rc, out, err = run(["prot2kmer2lca", "--shards", "0", "--shard-processes", str(idx)], b"")
+    assert rc == 1 and b"--shards must be in 1..64" in err
+    rc, out, err = run(["__shard-worker"], b"")
+    assert rc == 1 and b"is started by" in err
+    rc, out, err = run(["__shard-worker", str(idx), "1", "2", "0", "/umgap-hub-none", "/umgap-gang-none", "1"], b"")
+    assert rc == 1 and err.startswith(b"Error: "), err
+    for _ in range(50):                                  # (a worker notices its parent's end within a nap)
+        ps = subprocess.run(["ps", "-eo", "args"], stdout=subprocess.PIPE).stdout.decode()
+        if "__shard-worker" not in ps:
+            break
+        time.sleep(0.1)
+    assert "__shard-worker" not in ps
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("umgap-gang-") or f.startswith("umgap-hub-")]

@@ -2120,10 +2120,14 @@ def test_digest_tryp_dev_matches_the_regex(api, torch_cuda):
 
 
 @pytest.mark.parametrize("mode", [("tree", "hybrid", 0.25, 0.0), ("rmq", "mrtl", 0.0, 1.0), ("tree", "lca*", 0.0, 2.0), ("rmq", "hybrid", 0.4, 1.0)])
-def test_classify_tryp_dev_vs_oracle(api, torch_cuda, mode):
+@pytest.mark.parametrize("chunks", [0, 3])
+def test_classify_tryp_dev_vs_oracle(api, torch_cuda, mode, chunks, monkeypatch):
     """umgap_classify_tryp_dev = digest + length window + lookup + aggregate, against the regex digest, a dict and the oracle's
-    taxa2agg -- 1..3 fragments per read, windows 5..50 and 1..63."""
+    taxa2agg -- 1..3 fragments per read, windows 5..50 and 1..63.  chunks: the call cut into chunks of whole reads over two lanes
+    (UMGAP_TRYP_CHUNKS, an opt-in experiment: DESIGN.md section 4)."""
     torch = torch_cuda
+    if chunks:
+        monkeypatch.setenv("UMGAP_TRYP_CHUNKS", str(chunks))
     method, strategy, factor, lb = mode
     rng = np.random.default_rng(17)
     letters = np.frombuffer(b"ACDEFGHILMNPQSTVWY", np.uint8)

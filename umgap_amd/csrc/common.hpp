@@ -143,6 +143,10 @@ struct umgap_index {
     // fused kernel understands them
     const void* bound_to = nullptr;
     // grow-only device scratch of umgap_classify_tryp_dev (tryptic.hip): [0] sized by the bytes of a call, [1] by its pieces
-    void* tryp_scratch[2] = {nullptr, nullptr};
-    size_t tryp_scratch_bytes[2] = {0, 0};
+    // ([2], [3]: the same pair for the second lane of a call that is cut into chunks of reads; the lanes and their events are
+    //  created with the first such call)
+    void* tryp_scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t tryp_scratch_bytes[4] = {0, 0, 0, 0};
+    hipStream_t tryp_lane[2] = {nullptr, nullptr};
+    hipEvent_t tryp_ev_agg[2] = {nullptr, nullptr}, tryp_ev_done[2] = {nullptr, nullptr};
 };

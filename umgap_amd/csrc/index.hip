@@ -1390,6 +1390,11 @@ void umgap_index_free(umgap_index* ix) {
     if (ix->d_walk_exc_keys) (void)hipFree(ix->d_walk_exc_keys);
     if (ix->d_walk_exc_pos) (void)hipFree(ix->d_walk_exc_pos);
     for (void* p : ix->tryp_scratch) if (p) (void)hipFree(p);
+    for (int l = 0; l < 2; l++) {
+        if (ix->tryp_lane[l]) { (void)hipStreamSynchronize(ix->tryp_lane[l]); (void)hipStreamDestroy(ix->tryp_lane[l]); }
+        if (ix->tryp_ev_agg[l]) (void)hipEventDestroy(ix->tryp_ev_agg[l]);
+        if (ix->tryp_ev_done[l]) (void)hipEventDestroy(ix->tryp_ev_done[l]);
+    }
     if (ix->d_slots) (void)hipFree(ix->d_slots);
     if (ix->d_stash_keys) (void)hipFree(ix->d_stash_keys);
     if (ix->d_stash_vals) (void)hipFree(ix->d_stash_vals);

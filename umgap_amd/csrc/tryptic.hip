@@ -313,11 +313,15 @@ int scratch_get(void** cache, size_t* cache_bytes, size_t bytes, hipStream_t s, 
 }
 
 // counts the pieces of fragments [0, n_frag) (host round trip for the count); leaves what k_tryp_write needs in D
-int digest_count(const uint8_t* d_bytes, const uint64_t* d_foff, size_t n_frag, hipStream_t s, Digest& D) {
+// (known_ends: d_foff[0] and d_foff[n_frag] when the caller has them already -- saves the first of the two round trips)
+int digest_count(const uint8_t* d_bytes, const uint64_t* d_foff, size_t n_frag, hipStream_t s, Digest& D, const uint64_t* known_ends = nullptr) {
     uint64_t ends[2] = {0, 0};
-    UMGAP_HIP(hipMemcpyAsync(&ends[0], d_foff, 8, hipMemcpyDeviceToHost, s));
-    UMGAP_HIP(hipMemcpyAsync(&ends[1], d_foff + n_frag, 8, hipMemcpyDeviceToHost, s));
-    UMGAP_HIP(hipStreamSynchronize(s));
+    if (known_ends) { ends[0] = known_ends[0]; ends[1] = known_ends[1]; }
+    else {
+        UMGAP_HIP(hipMemcpyAsync(&ends[0], d_foff, 8, hipMemcpyDeviceToHost, s));
+        UMGAP_HIP(hipMemcpyAsync(&ends[1], d_foff + n_frag, 8, hipMemcpyDeviceToHost, s));
+        UMGAP_HIP(hipStreamSynchronize(s));
+    }
     if (ends[1] < ends[0]) return fail(UMGAP_ERR_INVALID, "tryptic digest: fragment offsets must not decrease");
     D.b0 = ends[0];
     D.n = ends[1] - ends[0];
@@ -405,40 +409,90 @@ int umgap_classify_tryp_dev(umgap_index* ix, umgap_taxonomy* tx, int method, int
     if (n_pieces_out) *n_pieces_out = 0;
     if (!n_reads) return UMGAP_OK;
     hipStream_t s = (hipStream_t)stream;
-    const size_t n_frag = n_reads * fragments_per_read;
-    // scratch: the index handle's two grow-only blocks (no allocation in the steady state, nothing to free, so no sync at the end:
-    // what follows the count is stream-ordered)
-    Digest D;
-    D.cache = &ix->tryp_scratch[0];
-    D.cache_bytes = &ix->tryp_scratch_bytes[0];
-    uint64_t *d_offsets = nullptr, *d_read_pieces = nullptr;
-    uint32_t* d_hits = nullptr;
-    auto done = [&](int code) { return code; };
-    rc = digest_count(d_bytes, d_frag_offsets, n_frag, s, D);
-    if (rc) return done(rc);
-    if (n_pieces_out) *n_pieces_out = D.total;
-    {
-        const size_t b_off = align256((D.total + 1) * 8), b_rp = align256((n_reads + 1) * 8), b_hits = align256(std::max<uint64_t>(D.total, 1) * 4);
+    // One chunk of reads [r0, r1) on stream `ls` with the scratch pair `pair` of the handle: digest -> probe -> aggregate.  Everything
+    // behind the count's host round trip is stream-ordered (grow-only scratch: no allocation in the steady state, nothing to free).
+    // wait_agg / record_agg: the aggregate stages of the chunks of one call run one after another (the general kernels' large
+    // scratch belongs to the taxonomy, not to a stream).
+    auto run_chunk = [&](size_t r0, size_t r1, hipStream_t ls, int pair, const uint64_t* known_ends, hipEvent_t wait_agg, hipEvent_t record_agg) -> int {
+        const size_t nr = r1 - r0, n_frag = nr * fragments_per_read;
+        const uint64_t* foff = d_frag_offsets + r0 * fragments_per_read;
+        Digest D;
+        D.cache = &ix->tryp_scratch[2 * pair];
+        D.cache_bytes = &ix->tryp_scratch_bytes[2 * pair];
+        int rc = digest_count(d_bytes, foff, n_frag, ls, D, known_ends);
+        if (rc) return rc;
+        if (n_pieces_out) *n_pieces_out += D.total;
+        const size_t b_off = align256((D.total + 1) * 8), b_rp = align256((nr + 1) * 8), b_hits = align256(std::max<uint64_t>(D.total, 1) * 4);
         void *mem = nullptr, *unused = nullptr;
-        rc = scratch_get(&ix->tryp_scratch[1], &ix->tryp_scratch_bytes[1], b_off + b_rp + b_hits, s, &mem, &unused);
-        if (rc) return done(rc);
+        rc = scratch_get(&ix->tryp_scratch[2 * pair + 1], &ix->tryp_scratch_bytes[2 * pair + 1], b_off + b_rp + b_hits, ls, &mem, &unused);
+        if (rc) return rc;
         char* p = (char*)mem;
-        d_offsets = (uint64_t*)p; p += b_off;
-        d_read_pieces = (uint64_t*)p; p += b_rp;
-        d_hits = (uint32_t*)p;
+        uint64_t* d_offsets = (uint64_t*)p; p += b_off;
+        uint64_t* d_read_pieces = (uint64_t*)p; p += b_rp;
+        uint32_t* d_hits = (uint32_t*)p;
+        rc = digest_write(ls, D, d_offsets, D.total);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_tryp_reads, dim3(grid_for(nr + 1)), dim3(256), 0, ls, foff, nr, fragments_per_read, D.b0, D.n, D.tile_base, D.slab_base, D.before, D.masks, D.total, d_read_pieces);
+        if (D.total) {
+            rc = var_lookup_dev(ix->var, d_bytes, d_offsets, (size_t)D.total, 0u, d_hits, ls, min_len, max_len);
+            if (rc) return rc;
+            if (min_len <= 1) hipLaunchKernelGGL(k_tryp_drop_stars, dim3(grid_for((size_t)D.total)), dim3(256), 0, ls, d_bytes, d_offsets, D.total, 0u, d_hits);
+        }
+        if (hipGetLastError() != hipSuccess) return fail(UMGAP_ERR_DEVICE, "umgap_classify_tryp_dev: a launch failed");
+        if (wait_agg) UMGAP_HIP(hipStreamWaitEvent(ls, wait_agg, 0));
+        if (ix->bound_to) rc = aggregate_csr_bound_dev(tx, method, strategy, factor, lower_bound, ranked_only, d_hits, D.total, d_read_pieces, nr, d_out_taxon + r0, d_out_status + r0, ls);
+        else rc = umgap_aggregate_dev(tx, method, strategy, factor, lower_bound, ranked_only, d_hits, nullptr, d_read_pieces, nr, d_out_taxon + r0, d_out_status + r0, ls);
+        if (!rc && record_agg) UMGAP_HIP(hipEventRecord(record_agg, ls));
+        return rc;
+    };
+    // UMGAP_TRYP_CHUNKS=C (an experiment that is kept, off by default): the call cut into C chunks of whole reads that alternate
+    // between two lanes (streams of the handle, two priorities = two hardware queues), so that one chunk's digest or aggregate could
+    // run beside the other's probe.  Measured (round 5, tools/ab_tryp_chunks.py, profiles/r05_tryp_chunks_ab.json: 10 M pairs, 400 M
+    // keys): 3.08-3.15 ms unchunked, 3.07 / 3.12 / 3.24 / 3.36 ms with 2 / 4 / 6 / 8 chunks -- nothing to gain: the probe holds four
+    // of a SIMD's wave slots and four fifths of its registers, what runs beside it gets one wave per SIMD, and the per-chunk launches
+    // and round trip cost what little overlap there is.
+    size_t chunks = 1;
+    if (const char* e = getenv("UMGAP_TRYP_CHUNKS")) { const long v = atol(e); if (v >= 1 && v <= 64) chunks = (size_t)v; }
+    chunks = std::min(chunks, n_reads);
+    if (chunks <= 1) return run_chunk(0, n_reads, s, 0, nullptr, nullptr, nullptr);
+    if (!ix->tryp_lane[0]) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);       // (lo = least, hi = greatest priority; numerically hi <= lo)
+        hipStream_t l0 = nullptr, l1 = nullptr;
+        hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+        bool ok = hipStreamCreateWithPriority(&l0, hipStreamNonBlocking, hi) == hipSuccess && hipStreamCreateWithPriority(&l1, hipStreamNonBlocking, lo) == hipSuccess;
+        for (int i = 0; i < 4 && ok; i++) ok = hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {
+            if (l0) (void)hipStreamDestroy(l0);
+            if (l1) (void)hipStreamDestroy(l1);
+            for (auto e : ev) if (e) (void)hipEventDestroy(e);
+            return fail(UMGAP_ERR_DEVICE, "umgap_classify_tryp_dev: cannot create the lanes of a chunked call");
+        }
+        ix->tryp_lane[0] = l0; ix->tryp_lane[1] = l1;
+        ix->tryp_ev_agg[0] = ev[0]; ix->tryp_ev_agg[1] = ev[1]; ix->tryp_ev_done[0] = ev[2]; ix->tryp_ev_done[1] = ev[3];
     }
-    rc = digest_write(s, D, d_offsets, D.total);
-    if (rc) return done(rc);
-    hipLaunchKernelGGL(k_tryp_reads, dim3(grid_for(n_reads + 1)), dim3(256), 0, s, d_frag_offsets, n_reads, fragments_per_read, D.b0, D.n, D.tile_base, D.slab_base, D.before, D.masks, D.total, d_read_pieces);
-    if (D.total) {
-        rc = var_lookup_dev(ix->var, d_bytes, d_offsets, (size_t)D.total, 0u, d_hits, s, min_len, max_len);
-        if (rc) return done(rc);
-        if (min_len <= 1) hipLaunchKernelGGL(k_tryp_drop_stars, dim3(grid_for((size_t)D.total)), dim3(256), 0, s, d_bytes, d_offsets, D.total, 0u, d_hits);
+    // the chunk boundaries in bytes, one round trip for all; it also puts the caller's earlier work (the inputs) before the lanes
+    std::vector<uint64_t> ends(chunks + 1);
+    auto first_read = [&](size_t c) { return (size_t)((unsigned __int128)n_reads * c / chunks); };
+    for (size_t c = 0; c <= chunks; c++) UMGAP_HIP(hipMemcpyAsync(&ends[c], d_frag_offsets + first_read(c) * fragments_per_read, 8, hipMemcpyDeviceToHost, s));
+    UMGAP_HIP(hipStreamSynchronize(s));
+    for (size_t c = 0; c < chunks; c++)
+        if (ends[c + 1] < ends[c]) return fail(UMGAP_ERR_INVALID, "tryptic digest: fragment offsets must not decrease");
+    rc = UMGAP_OK;
+    for (size_t c = 0; c < chunks && !rc; c++) {
+        const int l = (int)(c & 1);
+        rc = run_chunk(first_read(c), first_read(c + 1), ix->tryp_lane[l], l, &ends[c], c ? ix->tryp_ev_agg[1 - l] : nullptr, ix->tryp_ev_agg[l]);
     }
-    if (hipGetLastError() != hipSuccess) return done(fail(UMGAP_ERR_DEVICE, "umgap_classify_tryp_dev: a launch failed"));
-    if (ix->bound_to) rc = aggregate_csr_bound_dev(tx, method, strategy, factor, lower_bound, ranked_only, d_hits, D.total, d_read_pieces, n_reads, d_out_taxon, d_out_status, s);
-    else rc = umgap_aggregate_dev(tx, method, strategy, factor, lower_bound, ranked_only, d_hits, nullptr, d_read_pieces, n_reads, d_out_taxon, d_out_status, stream);
-    return done(rc);
+    if (rc) {       // leave nothing of this call in flight behind an error
+        (void)hipStreamSynchronize(ix->tryp_lane[0]);
+        (void)hipStreamSynchronize(ix->tryp_lane[1]);
+        return rc;
+    }
+    for (int l = 0; l < 2; l++) {
+        UMGAP_HIP(hipEventRecord(ix->tryp_ev_done[l], ix->tryp_lane[l]));
+        UMGAP_HIP(hipStreamWaitEvent(s, ix->tryp_ev_done[l], 0));
+    }
+    return UMGAP_OK;
 }
 
 }  // extern "C"
