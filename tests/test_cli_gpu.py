@@ -541,9 +541,12 @@ def test_tryptic_precision_pipeline_matches_oracle(tryptic, world):
         assert mine == ref and mine.count(b">") == 150
 
 
-def test_prot2kmer2lca_socket_server(world, tmp_path):
+@pytest.mark.parametrize("gang", [None, "processes"])
+def test_prot2kmer2lca_socket_server(world, tmp_path, gang):
     """`umgap prot2kmer2lca -m -o -s <socket>` as scripts/umgap-analyse.sh:260 starts it; clients talk to it like
-    `nc -NU` (send, half-close, read to EOF).  Connections are served sequentially (src/commands/prot2kmer2lca.rs:116-137)."""
+    `nc -NU` (send, half-close, read to EOF).  Connections are served sequentially (src/commands/prot2kmer2lca.rs:116-137).
+    gang = "processes": the resident server over an index sharded between two process-ranks (`--shards 2 --shard-processes`, both on
+    the one GPU): the gang outlives the connections and ends with the server, however that ends."""
     import socket
     import time
     sock = str(tmp_path / "umgap.sock")
@@ -558,7 +561,9 @@ def test_prot2kmer2lca_socket_server(world, tmp_path):
                 pep = pep[:s] + world["kmers"][int(rng.integers(0, len(world["kmers"])))] + pep[s + 9:]
             recs.append(">c%dr%d\n%s\n" % (c, r, pep))
         fastas.append("".join(recs).encode())
-    srv = subprocess.Popen([UMGAP, "prot2kmer2lca", "-m", "-o", "-s", sock, world["idx"]], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    extra = ["--shards", "2", "--shard-processes"] if gang else []
+    srv = subprocess.Popen([UMGAP, "prot2kmer2lca", "-m", "-o", "-s", sock] + extra + [world["idx"]], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           env=dict(os.environ, UMGAP_SHARDS_LOCAL="1"))
     try:
         for _ in range(600):
             if os.path.exists(sock):
@@ -584,6 +589,14 @@ def test_prot2kmer2lca_socket_server(world, tmp_path):
         out, _ = srv.communicate(timeout=10)
     assert out.startswith(b"Socket created, listening for connections.\n")
     assert out.count(b"Connection accepted. Processing...\n") == 3 and out.count(b"Connection finished succesfully.\n") == 3
+    if gang:
+        for _ in range(100):                             # (the workers are told of their parent's death by the kernel)
+            ps = subprocess.run(["ps", "-eo", "args"], stdout=subprocess.PIPE).stdout.decode()
+            if "__shard-worker" not in ps:
+                break
+            time.sleep(0.1)
+        assert "__shard-worker" not in ps
+        assert not [f for f in os.listdir("/dev/shm") if f.startswith("umgap-gang-") or f.startswith("umgap-hub-")]
 
 
 CODON = {}

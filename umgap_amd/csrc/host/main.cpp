@@ -726,6 +726,7 @@ struct ShardGang {
     std::vector<pid_t> workers;        // ranks 1 .. n-1
     ShardProcCtl* ctl = nullptr;
     std::string shm_name;
+    bool broken = false;               // a rank is gone: no collective call can complete any more
     template <class F>
     void each_rank(F f) {              // f(rank) on n threads; the first failure is rethrown
         std::vector<std::thread> ts;
@@ -801,6 +802,7 @@ struct ShardGang {
             int st = 0;
             if (waitpid(workers[i], &st, WNOHANG) == workers[i]) {
                 workers[i] = -1;
+                broken = true;
                 const int r = (int)i + 1;
                 std::string msg = ctl && ctl->err[r][0] ? std::string(ctl->err[r]) : std::string("ended unexpectedly");
                 throw CliError("--shards: rank " + std::to_string(r) + " " + msg);
@@ -889,9 +891,12 @@ struct ShardGang {
     }
     void stop_processes() {
         if (ctl) {
-            command(3);                // (umgap_sharded_free is collective in put mode: every rank leaves together)
-            umgap_sharded_free(sh[0]); umgap_comm_free(comm[0]); umgap_index_free(ix[0]);
-            for (auto& w : workers) if (w > 0) { int st; waitpid(w, &st, 0); w = -1; }
+            if (broken) kill_workers();     // (the group's collective free would wait for the rank that is gone: the process ends instead)
+            else {
+                command(3);            // (umgap_sharded_free is collective in put mode: every rank leaves together)
+                umgap_sharded_free(sh[0]); umgap_comm_free(comm[0]); umgap_index_free(ix[0]);
+                for (auto& w : workers) if (w > 0) { int st; waitpid(w, &st, 0); w = -1; }
+            }
             munmap(ctl, ctl->bytes);
             ctl = nullptr;
         }
