@@ -871,6 +871,7 @@ struct ShardGang {
         for (int r = 1; r < n; r++) if (ctl->rc[r].load()) throw CliError(std::string(ctl->err[r]));
     }
     void lookup_processes(const uint64_t* keys, size_t total, uint32_t* taxa) {
+        if (broken) throw CliError("--shards: the gang has lost a rank");      // (a resident server's later connections end here)
         for (size_t done = 0; done < total;) {
             const size_t round = std::min<size_t>(total - done, (size_t)n * max_keys), per = (round + n - 1) / n;
             for (int r = 0; r < n; r++) { ctl->lo[r] = std::min(round, (size_t)r * per); ctl->hi[r] = std::min(round, (size_t)(r + 1) * per); }
