@@ -2,7 +2,8 @@
 """A/B of umgap_classify_tryp_dev's chunking (UMGAP_TRYP_CHUNKS = 1, 2, 4, 8, ...): one index, one set of batches, every setting timed
 call by call (median of 2 x steps calls) in the MRTL -l1 and tree-hybrid presets on the table bound to the taxonomy, answers compared
 bit for bit with the unchunked call's.  Prints one JSON line.
-    python tools/ab_tryp_chunks.py [n_keys] [n_pairs] [chunk settings, comma separated]"""
+    python tools/ab_tryp_chunks.py [n_keys] [n_pairs] [settings, comma separated] [environment variable to sweep = UMGAP_TRYP_CHUNKS]
+A setting may name several variables: "512:UMGAP_AGG_GRID=10" sets the swept variable to 512 and UMGAP_AGG_GRID to 10."""
 import json
 import os
 import sys
@@ -21,7 +22,8 @@ F, PEPS = 2, 2
 def main():
     n_keys = int(sys.argv[1]) if len(sys.argv) > 1 else 400_000_000
     n_pairs = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
-    settings = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "1,2,4,8,1,4").split(",")]
+    settings = (sys.argv[3] if len(sys.argv) > 3 else "1,2,4,8,1,4").split(",")
+    var = sys.argv[4] if len(sys.argv) > 4 else "UMGAP_TRYP_CHUNKS"
     steps = 3
     w = synth.SyntheticWorkload(n_tax=2_500_000, n_keys=1000, build_index=False)
     tw = synth.TrypticWorkload(n_keys, w, F, PEPS)
@@ -36,8 +38,12 @@ def main():
     res = {"n_keys": n_keys, "pairs_per_step": n_pairs, "runs": []}
     want = {}
     for chunks in settings:
-        os.environ["UMGAP_TRYP_CHUNKS"] = str(chunks)
-        row = {"chunks": chunks}
+        parts = str(chunks).split(":")
+        os.environ[var] = parts[0]
+        extra = [p.split("=") for p in parts[1:]]
+        for k, v in extra:
+            os.environ[k] = v
+        row = {"setting": chunks, "variable": var}
         for name, kw in presets.items():
             per_step, same = [], True
             for i in range(2 * steps + 1):
@@ -53,6 +59,8 @@ def main():
                 else:
                     same = same and n_pieces == want[key][2] and torch.equal(d_t, want[key][0]) and torch.equal(d_s, want[key][1])
             row[name] = {"ms_median": round(sorted(per_step)[len(per_step) // 2], 3), "ms_min": round(min(per_step), 3), "same_answers_as_first_setting": same}
+        for k, _ in extra:
+            del os.environ[k]
         res["runs"].append(row)
         print(json.dumps(row), file=sys.stderr, flush=True)
     ix.unbind(w.taxonomy)

@@ -62,12 +62,17 @@ __device__ __forceinline__ GroupView group_view_over(uint32_t* hkeys, uint32_t* 
 }
 constexpr uint32_t GROUP_VIEW_READ_WORDS = 3 * GREADS + 1 + (GCAP + 3) / 4;
 
-template <bool BOUND, class GS>
+// MODE: 0 = method and strategy as passed (run-time); 1 = MRTL, 2 = tree hybrid, 3 = rmq hybrid fixed at compile time -- a kernel
+// instantiated per mode carries one strategy's code and registers instead of all three (aggregate_group.hip).
+template <bool BOUND, int MODE = 0, class GS>
 __device__ __forceinline__ void general_group(const TaxView& V, GS& G, int method, int strategy, float factor, float lower_bound,
                                               uint32_t* wtaxa, uint32_t stride, uint32_t nr, uint32_t lane, uint64_t se_panic, uint32_t frags,
                                               size_t first_read, uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status,
                                               uint32_t* __restrict__ defer, uint32_t* __restrict__ defer_count, uint64_t unsupported = 0ull,
                                               uint64_t too_long = 0ull) {
+    if (MODE == 1) { method = UMGAP_METHOD_RMQ; strategy = UMGAP_STRATEGY_MRTL; }
+    else if (MODE == 2) { method = UMGAP_METHOD_TREE; strategy = UMGAP_STRATEGY_HYBRID; }
+    else if (MODE == 3) { method = UMGAP_METHOD_RMQ; strategy = UMGAP_STRATEGY_HYBRID; }
     const bool tree_like = method != UMGAP_METHOD_RMQ || strategy == UMGAP_STRATEGY_MRTL;
     uint32_t k0 = 0;
     while (k0 < nr) {

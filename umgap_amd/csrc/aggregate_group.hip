@@ -45,8 +45,14 @@ __global__ __launch_bounds__(256) void k_agg_strided_group(TaxView V, int method
 // the strip are laid out at that stride -- every strip slot fetches its own taxon, the span coming from the owning lane by
 // ds_bpermute -- and aggregated together.  Short reads (tryptic: 4-20 hits) run 32-64 to a sub-round instead of one per wave.
 // BOUND: the hits are interval codes of a table bound to the taxonomy (bound.hpp) -- no by-id gather per distinct taxon.
-template <bool BOUND>
-__global__ __launch_bounds__(256) void k_agg_csr_group(TaxView V, int method, int strategy, float factor, const uint32_t* __restrict__ taxa,
+// MODE (agg_group.hpp): one instantiation per strategy -- MRTL, tree hybrid, rmq hybrid -- so that each carries its own code and
+// registers only: one kernel for all three took 144 registers = 3 waves per SIMD; now 98 / 128 (capped) / 111 = 4, which is also what
+// its 40 KB of LDS per workgroup allow.  The kernel is bound by the latency of its 2-6 dependent taxonomy round trips per sub-batch:
+// 3 -> 4 waves per SIMD took MRTL on 10 M four-hit reads from 506 to 375 us and the tree hybrid from 1273 to 884 (round 5).  A fifth
+// wave (a 512-word strip for short reads: 32 KB per workgroup, MRTL at 96 registers) measured the same on the same box, so the strip
+// stays one size.
+template <bool BOUND, int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_agg_csr_group(TaxView V, int method, int strategy, float factor, const uint32_t* __restrict__ taxa,
                                                        const uint64_t* __restrict__ offsets, size_t n_reads, float lower_bound, uint32_t* __restrict__ out_taxon,
                                                        uint32_t* __restrict__ out_status, uint32_t* __restrict__ defer, uint32_t* __restrict__ defer_count) {
     __shared__ uint32_t lds_taxa[4][STRIP];
@@ -88,8 +94,8 @@ __global__ __launch_bounds__(256) void k_agg_csr_group(TaxView V, int method, in
             }
             wave_sync();
             const uint64_t too_long = (__ballot(big) >> k0) & (nr >= 64 ? ~0ull : ((1ull << nr) - 1ull));
-            general_group<BOUND>(V, S, method, strategy, factor, lower_bound, wtaxa, stride, nr, lane, 0ull, 0u, r0 + k0, out_taxon, out_status, defer, defer_count, 0ull,
-                                 too_long);
+            general_group<BOUND, MODE>(V, S, method, strategy, factor, lower_bound, wtaxa, stride, nr, lane, 0ull, 0u, r0 + k0, out_taxon, out_status, defer, defer_count, 0ull,
+                                       too_long);
             wave_sync();
             k0 += nr;
         }
@@ -106,10 +112,19 @@ int launch_csr_group(const TaxView& V, int method, int strategy, float factor, f
     if (g > 256 * 8) g = 256 * 8;
     if (g < 1) g = 1;
     if (strategy == UMGAP_STRATEGY_LCA_STAR) return fail(UMGAP_ERR_INVALID, "launch_csr_group: LCA* has its own kernel");
-    if (bound_hits) hipLaunchKernelGGL(k_agg_csr_group<true>, dim3((unsigned)g), dim3(256), 0, stream, V, method, strategy, factor, d_taxa, d_offsets, n_reads, lower_bound,
-                                       d_out_taxon, d_out_status, d_list, d_count);
-    else hipLaunchKernelGGL(k_agg_csr_group<false>, dim3((unsigned)g), dim3(256), 0, stream, V, method, strategy, factor, d_taxa, d_offsets, n_reads, lower_bound, d_out_taxon,
-                            d_out_status, d_list, d_count);
+    // one instantiation per strategy (see the kernel)
+    const int mode = strategy == UMGAP_STRATEGY_MRTL ? 1 : (method == UMGAP_METHOD_TREE ? 2 : 3);
+    auto go = [&](auto B, auto M) {
+        hipLaunchKernelGGL((k_agg_csr_group<decltype(B)::value, decltype(M)::value>), dim3((unsigned)g), dim3(256), 0, stream, V, method, strategy, factor, d_taxa, d_offsets,
+                           n_reads, lower_bound, d_out_taxon, d_out_status, d_list, d_count);
+    };
+    auto with_mode = [&](auto B) {
+        if (mode == 1) go(B, std::integral_constant<int, 1>{});
+        else if (mode == 2) go(B, std::integral_constant<int, 2>{});
+        else go(B, std::integral_constant<int, 3>{});
+    };
+    if (bound_hits) with_mode(std::true_type{});
+    else with_mode(std::false_type{});
     UMGAP_HIP(hipGetLastError());
     return UMGAP_OK;
 }
