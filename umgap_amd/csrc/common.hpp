@@ -147,6 +147,7 @@ struct umgap_index {
     //  created with the first such call)
     void* tryp_scratch[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t tryp_scratch_bytes[4] = {0, 0, 0, 0};
+    uint64_t* tryp_host = nullptr;     // 8 page-locked words the digest's kernels report to (two round trips per call without a staged copy)
     hipStream_t tryp_lane[2] = {nullptr, nullptr};
     hipEvent_t tryp_ev_agg[2] = {nullptr, nullptr}, tryp_ev_done[2] = {nullptr, nullptr};
 };

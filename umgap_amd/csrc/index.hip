@@ -1390,6 +1390,7 @@ void umgap_index_free(umgap_index* ix) {
     if (ix->d_walk_exc_keys) (void)hipFree(ix->d_walk_exc_keys);
     if (ix->d_walk_exc_pos) (void)hipFree(ix->d_walk_exc_pos);
     for (void* p : ix->tryp_scratch) if (p) (void)hipFree(p);
+    if (ix->tryp_host) (void)hipHostFree(ix->tryp_host);
     for (int l = 0; l < 2; l++) {
         if (ix->tryp_lane[l]) { (void)hipStreamSynchronize(ix->tryp_lane[l]); (void)hipStreamDestroy(ix->tryp_lane[l]); }
         if (ix->tryp_ev_agg[l]) (void)hipEventDestroy(ix->tryp_ev_agg[l]);

@@ -308,6 +308,8 @@ __device__ __noinline__ VarpKey varp_pack_global(const uint8_t* __restrict__ qby
     return K;
 }
 
+// (Round 5: a fifth wave per SIMD -- strips cut to 4096 bytes, 32 KB per workgroup, 96 registers -- measured 6 % SLOWER on the same box
+// (the tryptic call 3.05-3.08 against 2.85-2.91 ms per 10 M pairs): like the 9-mer probes, this one wants four.)
 // The kernel: the pipeline of k_lookup_var_pipe (index_var.hip) -- while batch t probes, the bytes of batch t + 1 travel from global
 // memory straight into the other LDS strip and the offsets of batch t + 2 are in flight -- with the packed probe in it.
 __global__ __launch_bounds__(256, 4) void k_lookup_varp(const uint8_t* __restrict__ qbytes, const uint64_t* __restrict__ qoff, size_t n, uint32_t miss,

@@ -183,7 +183,9 @@ __global__ __launch_bounds__(1024) void k_tryp_scan(const uint32_t* __restrict__
     for (uint32_t k = 0; k < SCAN_PER; k++) { if (i + k < n_tiles) tile_base[i + k] = at; at += v[k]; }
     if (threadIdx.x == 0) slab_total[blockIdx.x] = total;
 }
-__global__ __launch_bounds__(1024) void k_tryp_scan_slabs(const uint64_t* __restrict__ slab_total, size_t n_slabs, uint64_t* __restrict__ slab_base, uint64_t* __restrict__ total) {
+// (report: page-locked host words, or null -- [2] = the number of pieces, [3] = the fragments k_tryp_mark refused)
+__global__ __launch_bounds__(1024) void k_tryp_scan_slabs(const uint64_t* __restrict__ slab_total, size_t n_slabs, uint64_t* __restrict__ slab_base, uint64_t* __restrict__ total,
+                                                          const unsigned long long* __restrict__ bad, uint64_t* __restrict__ report) {
     __shared__ uint64_t wsum[16];
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint64_t run = 0;
@@ -204,7 +206,14 @@ __global__ __launch_bounds__(1024) void k_tryp_scan_slabs(const uint64_t* __rest
         if (i < n_slabs) slab_base[i] = run + before + incl - v;
         run += all;
     }
-    if (threadIdx.x == 0) *total = run;
+    if (threadIdx.x == 0) {
+        *total = run;
+        if (report) { report[2] = run; report[3] = *bad; }
+    }
+}
+// the first and the last fragment offset, straight into page-locked host memory
+__global__ void k_tryp_ends(const uint64_t* __restrict__ foff, size_t n_frag, uint64_t* __restrict__ report) {
+    if (threadIdx.x == 0) { report[0] = foff[0]; report[1] = foff[n_frag]; }
 }
 
 __global__ __launch_bounds__(256) void k_tryp_write(const uint32_t* __restrict__ masks, const uint16_t* __restrict__ before, uint64_t n, uint64_t b0,
@@ -314,10 +323,17 @@ int scratch_get(void** cache, size_t* cache_bytes, size_t bytes, hipStream_t s, 
 
 // counts the pieces of fragments [0, n_frag) (host round trip for the count); leaves what k_tryp_write needs in D
 // (known_ends: d_foff[0] and d_foff[n_frag] when the caller has them already -- saves the first of the two round trips)
-int digest_count(const uint8_t* d_bytes, const uint64_t* d_foff, size_t n_frag, hipStream_t s, Digest& D, const uint64_t* known_ends = nullptr) {
+// (report: four page-locked words the kernels write the ends and the counts to -- a round trip is then a launch and a wait, not a
+//  staged copy into pageable memory; null: copies)
+int digest_count(const uint8_t* d_bytes, const uint64_t* d_foff, size_t n_frag, hipStream_t s, Digest& D, const uint64_t* known_ends = nullptr,
+                 uint64_t* report = nullptr) {
     uint64_t ends[2] = {0, 0};
     if (known_ends) { ends[0] = known_ends[0]; ends[1] = known_ends[1]; }
-    else {
+    else if (report) {
+        hipLaunchKernelGGL(k_tryp_ends, dim3(1), dim3(64), 0, s, d_foff, n_frag, report);
+        UMGAP_HIP(hipStreamSynchronize(s));
+        ends[0] = report[0]; ends[1] = report[1];
+    } else {
         UMGAP_HIP(hipMemcpyAsync(&ends[0], d_foff, 8, hipMemcpyDeviceToHost, s));
         UMGAP_HIP(hipMemcpyAsync(&ends[1], d_foff + n_frag, 8, hipMemcpyDeviceToHost, s));
         UMGAP_HIP(hipStreamSynchronize(s));
@@ -351,12 +367,18 @@ int digest_count(const uint8_t* d_bytes, const uint64_t* d_foff, size_t n_frag, 
         hipLaunchKernelGGL(k_tryp_count, dim3((unsigned)((D.n_tiles + TILES_PER_GROUP - 1) / TILES_PER_GROUP)), dim3(256), 0, s, d_bytes + D.b0, D.bits, D.n, D.n_tiles, D.tile_counts,
                            D.masks, D.before);
         hipLaunchKernelGGL(k_tryp_scan, dim3((unsigned)D.n_slabs), dim3(1024), 0, s, D.tile_counts, D.n_tiles, D.tile_base, D.slab_total);
-        hipLaunchKernelGGL(k_tryp_scan_slabs, dim3(1), dim3(1024), 0, s, D.slab_total, D.n_slabs, D.slab_base, D.d_total);
+        hipLaunchKernelGGL(k_tryp_scan_slabs, dim3(1), dim3(1024), 0, s, D.slab_total, D.n_slabs, D.slab_base, D.d_total, (const unsigned long long*)D.d_bad, report);
     }
     unsigned long long bad = 0;
-    UMGAP_HIP(hipMemcpyAsync(&D.total, D.d_total, 8, hipMemcpyDeviceToHost, s));
-    UMGAP_HIP(hipMemcpyAsync(&bad, D.d_bad, 8, hipMemcpyDeviceToHost, s));
-    UMGAP_HIP(hipStreamSynchronize(s));
+    if (report && D.n_tiles) {
+        UMGAP_HIP(hipStreamSynchronize(s));
+        D.total = report[2];
+        bad = report[3];
+    } else {
+        UMGAP_HIP(hipMemcpyAsync(&D.total, D.d_total, 8, hipMemcpyDeviceToHost, s));
+        UMGAP_HIP(hipMemcpyAsync(&bad, D.d_bad, 8, hipMemcpyDeviceToHost, s));
+        UMGAP_HIP(hipStreamSynchronize(s));
+    }
     if (bad) return fail(UMGAP_ERR_INVALID, "tryptic digest: fragment offsets must not decrease");
     return UMGAP_OK;
 }
@@ -413,13 +435,18 @@ int umgap_classify_tryp_dev(umgap_index* ix, umgap_taxonomy* tx, int method, int
     // behind the count's host round trip is stream-ordered (grow-only scratch: no allocation in the steady state, nothing to free).
     // wait_agg / record_agg: the aggregate stages of the chunks of one call run one after another (the general kernels' large
     // scratch belongs to the taxonomy, not to a stream).
+    if (!ix->tryp_host && hipHostMalloc((void**)&ix->tryp_host, 64, hipHostMallocDefault) != hipSuccess) {
+        ix->tryp_host = nullptr;       // (without it the round trips are copies, as before: not an error)
+        (void)hipGetLastError();
+    }
+    uint64_t* const report_words = getenv("UMGAP_TRYP_COPIES") ? nullptr : ix->tryp_host;     // (the switch is for A/B measurements)
     auto run_chunk = [&](size_t r0, size_t r1, hipStream_t ls, int pair, const uint64_t* known_ends, hipEvent_t wait_agg, hipEvent_t record_agg) -> int {
         const size_t nr = r1 - r0, n_frag = nr * fragments_per_read;
         const uint64_t* foff = d_frag_offsets + r0 * fragments_per_read;
         Digest D;
         D.cache = &ix->tryp_scratch[2 * pair];
         D.cache_bytes = &ix->tryp_scratch_bytes[2 * pair];
-        int rc = digest_count(d_bytes, foff, n_frag, ls, D, known_ends);
+        int rc = digest_count(d_bytes, foff, n_frag, ls, D, known_ends, report_words ? report_words + 4 * pair : nullptr);
         if (rc) return rc;
         if (n_pieces_out) *n_pieces_out += D.total;
         const size_t b_off = align256((D.total + 1) * 8), b_rp = align256((nr + 1) * 8), b_hits = align256(std::max<uint64_t>(D.total, 1) * 4);
