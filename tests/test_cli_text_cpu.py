@@ -418,3 +418,18 @@ def test_shard_processes_without_a_gpu_fail_loudly_and_leave_nothing(tmp_path):
         time.sleep(0.1)
     assert "__shard-worker" not in ps
     assert not [f for f in os.listdir("/dev/shm") if f.startswith("umgap-gang-") or f.startswith("umgap-hub-")]
+
+
+@pytest.mark.parametrize("ranked", [False, True])
+def test_seedextend_panic_prints_nothing_of_the_records_behind_it(taxonomy, ranked):
+    """A record whose seed is a slice out of range (`0 213` under -s1 -g1: src/commands/seedextend.rs:154-160 / :125) ends the
+    reference with a panic when it is written; the records before it are out, nothing of those behind it -- not even the header of
+    the record whose `>` line made the filter notice (found by tools/fuzz_cli.py's ranked -s 1 cases, round 5)."""
+    flags = ["-s", "1", "-g", "1"] + (["-r", taxonomy["tsv"]] if ranked else [])
+    for before in (b"", b">ok\n7\n7\n"):
+        fasta = before + b">r0/1\n0\n213\n>x y/z\n>\n5\n>later\n9\n"
+        for env in ({}, {"UMGAP_BLOCK_BYTES": "100", "UMGAP_THREADS": "3"}, {"UMGAP_BLOCK_BYTES": "8", "UMGAP_THREADS": "2"}):
+            rc, out, err = run(["seedextend"] + flags, fasta, **env)
+            orc, oout, _ = O.run_cli(["seedextend"] + flags, fasta)
+            assert (rc, out) == (orc, oout) and rc == 101, (env, rc, out, orc, oout, err)
+            assert b"x y/z" not in out and b"later" not in out

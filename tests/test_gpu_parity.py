@@ -226,8 +226,13 @@ def _random_reads(rng, pool, n_reads, max_len, zero_frac=0.3):
 
 @pytest.mark.parametrize("method", ["tree", "rmq"])
 @pytest.mark.parametrize("lower_bound", [0.0, 1.0, 2.0, 3.0])
-def test_lca_star_random_vs_oracle(api, method, lower_bound):
+@pytest.mark.parametrize("group", [None, "1", "0"])
+def test_lca_star_random_vs_oracle(api, method, lower_bound, group, monkeypatch):
+    """group: UMGAP_AGG_LCA_GROUP forces the CSR reads through the group kernel of aggregate_group.hip (what short reads take by
+    themselves; the reads of more than 128 hits here come back to the per-read kernel through its list) or keeps them off it."""
     from umgap_amd.synth import synthetic_taxonomy
+    if group is not None:
+        monkeypatch.setenv("UMGAP_AGG_LCA_GROUP", group)
     rng = np.random.default_rng(int(lower_bound) * 7 + (method == "rmq"))
     ids, par, valid, rank = synthetic_taxonomy(3000, 5000, max_depth=25, seed=9)
     tx = api.Taxonomy(ids, par, valid, rank)
@@ -246,8 +251,12 @@ def test_lca_star_random_vs_oracle(api, method, lower_bound):
 
 
 @pytest.mark.parametrize("method", ["tree", "rmq"])
-def test_lca_star_unknown_and_orphans_vs_oracle(api, method):
-    """Absent ids, ids beyond the list and taxa whose parent chain is broken."""
+@pytest.mark.parametrize("group", [None, "0"])
+def test_lca_star_unknown_and_orphans_vs_oracle(api, method, group, monkeypatch):
+    """Absent ids, ids beyond the list and taxa whose parent chain is broken.  (Reads of six hits: the group kernel by default;
+    group "0" keeps the per-read kernel.)"""
+    if group is not None:
+        monkeypatch.setenv("UMGAP_AGG_LCA_GROUP", group)
     rng = np.random.default_rng(21)
     ids = np.array([1, 2, 3, 4, 5, 6, 7, 8, 20, 21, 22, 30], np.uint32)
     #            root              orphan chain: 20 -> 21 -> 99 (absent)   22 -> 400 (beyond the list)

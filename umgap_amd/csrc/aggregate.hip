@@ -31,6 +31,9 @@ int launch_general(const TaxView& V, int method, int strategy, float factor, flo
                    const uint32_t* d_id_of_pre = nullptr);
 int launch_strided_group(const TaxView& V, int method, int strategy, float factor, float lower_bound, const uint32_t* d_taxa, uint32_t stride,
                          size_t n_reads, uint32_t* d_out_taxon, uint32_t* d_out_status, uint32_t* d_list, uint32_t* d_count, hipStream_t stream);
+int launch_csr_lca_group(const TaxView& V, int method, float lower_bound, const uint32_t* d_taxa, const uint64_t* d_offsets, size_t n_reads, uint32_t* d_out_taxon,
+                         uint32_t* d_out_status, uint32_t* d_list, uint32_t* d_count, hipStream_t stream, bool bound_hits);
+void launch_deferred_codes_to_ids(const uint32_t* d_list, const uint32_t* d_count, const uint64_t* d_offsets, uint32_t* codes, const uint32_t* d_id_of_pre, hipStream_t stream);
 }
 
 namespace {
@@ -99,11 +102,14 @@ template <bool SCORED>
 __global__ __launch_bounds__(256) void k_agg_lca(TaxView V, int method, const uint32_t* __restrict__ taxa,
                                                  const float* __restrict__ scores, const uint64_t* __restrict__ offsets,
                                                  uint32_t stride, size_t n_reads, float lower_bound,
-                                                 uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status) {
+                                                 uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status,
+                                                 const uint32_t* __restrict__ todo = nullptr, const uint32_t* __restrict__ todo_count = nullptr) {
+    // (todo / todo_count: only the reads on that list -- the ones the group kernel of aggregate_group.hip left to this one)
     const uint32_t lane = threadIdx.x & 63;
     const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
     const bool tree_like = method != UMGAP_METHOD_RMQ;
+    if (todo) n_reads = (size_t)*todo_count;
     __shared__ uint32_t lds_keys[4][256], lds_cnt[4][256];
     uint32_t* wkeys = lds_keys[threadIdx.x >> 6];
     uint32_t* wcnt = lds_cnt[threadIdx.x >> 6];
@@ -111,7 +117,8 @@ __global__ __launch_bounds__(256) void k_agg_lca(TaxView V, int method, const ui
 #pragma unroll
         for (int i = 0; i < 4; i++) { wkeys[lane + 64 * i] = 0u; wcnt[lane + 64 * i] = 0u; }
     }
-    for (size_t r = wave0; r < n_reads; r += nwaves) {
+    for (size_t r_it = wave0; r_it < n_reads; r_it += nwaves) {
+        const size_t r = todo ? (size_t)todo[r_it] : r_it;
         uint64_t off, end;
         if (offsets) { off = offsets[r]; end = offsets[r + 1]; } else { off = (uint64_t)r * stride; end = off + stride; }
         uint32_t off_lo = __builtin_amdgcn_readfirstlane((uint32_t)off), off_hi = __builtin_amdgcn_readfirstlane((uint32_t)(off >> 32));
@@ -207,7 +214,8 @@ inline int agg_grid(size_t n_reads) {
     return (int)g;
 }
 
-// bound_codes / n_hits (umgap::aggregate_csr_bound_dev): the hits are interval codes of a table bound to tx, writable, n_hits of them
+// bound_codes (umgap::aggregate_csr_bound_dev): the hits are interval codes of a table bound to tx, writable.  n_hits (0 = not known): how
+// many hits the CSR reads hold together
 int launch(umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound, int ranked_only,
            const uint32_t* d_taxa, const float* d_scores, const uint64_t* d_offsets, uint32_t stride, size_t n_reads,
            uint32_t* d_out_taxon, uint32_t* d_out_status, hipStream_t stream, uint32_t* bound_codes = nullptr, uint64_t n_hits = 0) {
@@ -220,7 +228,21 @@ int launch(umgap_taxonomy* tx, int method, int strategy, float factor, float low
     dim3 grid(agg_grid(n_reads)), block(256);
     // (LCA*: the one-read-per-wave kernel below already spends a single round trip per stage; the group form of
     //  aggregate_group.hip measured 5 % slower on 16-hit reads, so it stays with the strategies that gain 2-3x from it)
-    if (strategy == UMGAP_STRATEGY_LCA_STAR) {
+    // LCA* over CSR reads that are SHORT on average (the caller knows their hits: at most eight a read -- a tryptic pipeline's): the
+    // group kernel of aggregate_group.hip takes 32-64 reads per set of taxonomy round trips instead of one (10 M four-hit reads: 3.5 ms
+    // one read per wave); reads of more than 128 hits are left on a list for the per-read kernel behind it.
+    bool lca_group_path = strategy == UMGAP_STRATEGY_LCA_STAR && !d_scores && d_offsets && n_hits && n_hits <= 8 * (uint64_t)n_reads && n_reads < 0xFFFFFFFFull;
+    if (const char* e = getenv("UMGAP_AGG_LCA_GROUP")) lca_group_path = strategy == UMGAP_STRATEGY_LCA_STAR && !d_scores && d_offsets && n_reads < 0xFFFFFFFFull && atoi(e) != 0;   // (tests, A/B)
+    if (lca_group_path) {
+        uint32_t* d_defer = defer_list_for(tx, stream, (n_reads + 1) * sizeof(uint32_t));
+        if (!d_defer) return UMGAP_ERR_NOMEM;
+        UMGAP_HIP(hipMemsetAsync(d_defer, 0, sizeof(uint32_t), stream));
+        int rc = launch_csr_lca_group(V, method, lower_bound, d_taxa, d_offsets, n_reads, d_out_taxon, d_out_status, d_defer + 1, d_defer, stream, bound_codes != nullptr);
+        if (rc) return rc;
+        if (bound_codes) launch_deferred_codes_to_ids(d_defer + 1, d_defer, d_offsets, bound_codes, (const uint32_t*)tx->d_id_of_pre, stream);
+        hipLaunchKernelGGL(k_agg_lca<false>, dim3(256), block, 0, stream, V, method, d_taxa, d_scores, d_offsets, stride, n_reads, lower_bound, d_out_taxon, d_out_status,
+                           (const uint32_t*)(d_defer + 1), (const uint32_t*)d_defer);
+    } else if (strategy == UMGAP_STRATEGY_LCA_STAR) {
         // (the per-read LCA* kernel knows taxon ids only: bound hits are turned back first)
         if (bound_codes && n_hits) hipLaunchKernelGGL(k_all_codes_to_ids, dim3((unsigned)std::min<uint64_t>((n_hits + 255) / 256, 256 * 8)), dim3(256), 0, stream, bound_codes, n_hits, (const uint32_t*)tx->d_id_of_pre);
         if (d_scores) hipLaunchKernelGGL(k_agg_lca<true>, grid, block, 0, stream, V, method, d_taxa, d_scores, d_offsets, stride, n_reads, lower_bound, d_out_taxon, d_out_status);
@@ -244,6 +266,11 @@ namespace umgap {
 int aggregate_csr_bound_dev(umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound, int ranked_only, uint32_t* d_codes,
                             uint64_t n_hits, const uint64_t* d_read_offsets, size_t n_reads, uint32_t* d_out_taxon, uint32_t* d_out_status, hipStream_t stream) {
     return launch(tx, method, strategy, factor, lower_bound, ranked_only, d_codes, nullptr, d_read_offsets, 0, n_reads, d_out_taxon, d_out_status, stream, d_codes, n_hits);
+}
+// umgap_aggregate_dev for unscored CSR reads by a caller that knows how many hits they hold together (tryptic.hip)
+int aggregate_csr_counted_dev(umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound, int ranked_only, const uint32_t* d_taxa,
+                              uint64_t n_hits, const uint64_t* d_read_offsets, size_t n_reads, uint32_t* d_out_taxon, uint32_t* d_out_status, hipStream_t stream) {
+    return launch(tx, method, strategy, factor, lower_bound, ranked_only, d_taxa, nullptr, d_read_offsets, 0, n_reads, d_out_taxon, d_out_status, stream, nullptr, n_hits);
 }
 }  // namespace umgap
 
@@ -392,7 +419,7 @@ int umgap_aggregate(umgap_taxonomy* tx, int method, int strategy, float factor, 
         UMGAP_HIP_BREAK(hipEventRecord(ev.uploaded[slot], up));
         UMGAP_HIP_BREAK(hipStreamWaitEvent(run, ev.uploaded[slot], 0));
         hipLaunchKernelGGL(k_rebase_read_offsets, dim3((unsigned)std::min<size_t>((nr + 256) / 256, 1024)), dim3(256), 0, run, d_off, nr + 1, t0);
-        rc = launch(tx, method, strategy, factor, lower_bound, ranked_only, d_taxa, d_sc, d_off, 0, nr, d_ot, d_os, run);
+        rc = launch(tx, method, strategy, factor, lower_bound, ranked_only, d_taxa, d_sc, d_off, 0, nr, d_ot, d_os, run, nullptr, nt);
         if (rc) break;
         UMGAP_HIP_BREAK(hipMemcpyAsync(out_pinned ? out_taxon + r0 : H[slot].ot, d_ot, nr * 4, hipMemcpyDeviceToHost, run));
         UMGAP_HIP_BREAK(hipMemcpyAsync(out_pinned ? out_status + r0 : H[slot].os, d_os, nr * 4, hipMemcpyDeviceToHost, run));

@@ -48,6 +48,14 @@ __global__ __launch_bounds__(256) void k_deferred_codes_to_ids(const uint32_t* _
     }
 }
 
+}  // namespace
+namespace umgap {
+void launch_deferred_codes_to_ids(const uint32_t* d_list, const uint32_t* d_count, const uint64_t* d_offsets, uint32_t* codes, const uint32_t* d_id_of_pre, hipStream_t stream) {
+    hipLaunchKernelGGL(k_deferred_codes_to_ids, dim3(64), dim3(256), 0, stream, d_list, d_count, d_offsets, codes, d_id_of_pre);
+}
+}  // namespace umgap
+namespace {
+
 template <bool SCORED, int CAP, int HCAP, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void k_agg_general(TaxView V, int method, int strategy, float factor,
                                                             const uint32_t* __restrict__ taxa, const float* __restrict__ scores,

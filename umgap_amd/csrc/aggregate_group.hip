@@ -102,9 +102,79 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     }
 }
 
+// LCA* over CSR reads the same way (round 5): the sub-rounds of k_agg_csr_group, the group's reads through lca_group (agg_group.hpp:
+// count / filter per read in LDS, {pre, last} of all survivors in one round trip, the range minimum and the snap one lane per read).
+// Reads of more than 128 hits do not fit a strip row: they are answered "empty" here and put on `todo` for the per-read kernel
+// (aggregate.hip k_agg_lca), which runs behind this one over that list and overwrites them.
+template <bool BOUND>
+__global__ __launch_bounds__(256) void k_agg_csr_lca_group(TaxView V, int method, const uint32_t* __restrict__ taxa, const uint64_t* __restrict__ offsets, size_t n_reads,
+                                                           float lower_bound, uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status,
+                                                           uint32_t* __restrict__ todo, uint32_t* __restrict__ todo_count) {
+    __shared__ uint32_t lds_taxa[4][STRIP];
+    __shared__ LcaScratch scratch[4];
+    const uint32_t wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t* wtaxa = lds_taxa[wv];
+    LcaScratch& S = scratch[wv];
+    const bool tree_like = method != UMGAP_METHOD_RMQ;
+    for (uint32_t i = lane; i < 256; i += 64) { S.hkeys[i] = 0u; S.hcnt[i] = 0u; }
+    wave_sync();
+    const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const size_t n_chunks = (n_reads + 63) / 64;
+    for (size_t c = wave0; c < n_chunks; c += nwaves) {
+        const size_t r0 = c * 64;
+        const uint32_t nr_chunk = (uint32_t)min((size_t)64, n_reads - r0);
+        const uint64_t o = offsets[min(r0 + lane, n_reads)], o1 = offsets[min(r0 + lane + 1, n_reads)];
+        const uint64_t l64 = o1 >= o ? o1 - o : 0ull;
+        const bool big = lane < nr_chunk && l64 > 128;
+        if (big) todo[atomicAdd(todo_count, 1u)] = (uint32_t)(r0 + lane);
+        const uint32_t len = big ? 0u : (uint32_t)l64;
+        const uint32_t o_lo = (uint32_t)o, o_hi = (uint32_t)(o >> 32);
+        uint32_t k0 = 0;
+        while (k0 < nr_chunk) {
+            uint32_t m = lane >= k0 && lane < nr_chunk ? len : 0u;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { const uint32_t t = (uint32_t)__shfl_xor((int)m, d, 64); m = t > m ? t : m; }
+            uint32_t stride = 1;
+            while (stride < m) stride <<= 1;                                // wave-uniform
+            const uint32_t sh = (uint32_t)__builtin_ctz(stride);
+            const uint32_t nr = min(nr_chunk - k0, STRIP >> sh);
+            const uint32_t nk = nr << sh;
+            for (uint32_t i = lane; i < ((nk + 63u) & ~63u); i += 64) {     // every lane takes part in the shuffles
+                const uint32_t k = i >> sh, j = i & (stride - 1u);
+                const int src = (int)((k0 + k) & 63u);
+                const uint32_t lk = (uint32_t)__shfl((int)len, src, 64);
+                const uint64_t ok = (uint64_t)(uint32_t)__shfl((int)o_lo, src, 64) | ((uint64_t)(uint32_t)__shfl((int)o_hi, src, 64) << 32);
+                if (i < nk) wtaxa[i] = j < lk ? __builtin_nontemporal_load(taxa + ok + j) : 0u;
+            }
+            wave_sync();
+            lca_group<BOUND>(V, S, tree_like, lower_bound, wtaxa, stride, nr, lane, 0ull, 0u, r0 + k0, out_taxon, out_status,
+                             [&](uint32_t k, uint32_t& res_taxon, uint32_t& res_status) {
+                                 if (BOUND) lca_star_bound_from_lds(V, wtaxa + k * stride, stride, lower_bound, S.hkeys, S.hcnt, lane, res_taxon, res_status);
+                                 else lca_star_from_lds(V, tree_like, wtaxa + k * stride, stride, lower_bound, S.hkeys, S.hcnt, lane, res_taxon, res_status);
+                             });
+            wave_sync();
+            k0 += nr;
+        }
+    }
+}
+
 }  // namespace
 
 namespace umgap {
+
+int launch_csr_lca_group(const TaxView& V, int method, float lower_bound, const uint32_t* d_taxa, const uint64_t* d_offsets, size_t n_reads, uint32_t* d_out_taxon,
+                         uint32_t* d_out_status, uint32_t* d_list, uint32_t* d_count, hipStream_t stream, bool bound_hits) {
+    size_t g = ((n_reads + 63) / 64 + 3) / 4;
+    if (g > 256 * 8) g = 256 * 8;
+    if (g < 1) g = 1;
+    if (bound_hits) hipLaunchKernelGGL(k_agg_csr_lca_group<true>, dim3((unsigned)g), dim3(256), 0, stream, V, method, d_taxa, d_offsets, n_reads, lower_bound, d_out_taxon,
+                                       d_out_status, d_list, d_count);
+    else hipLaunchKernelGGL(k_agg_csr_lca_group<false>, dim3((unsigned)g), dim3(256), 0, stream, V, method, d_taxa, d_offsets, n_reads, lower_bound, d_out_taxon, d_out_status,
+                            d_list, d_count);
+    UMGAP_HIP(hipGetLastError());
+    return UMGAP_OK;
+}
 
 int launch_csr_group(const TaxView& V, int method, int strategy, float factor, float lower_bound, const uint32_t* d_taxa, const uint64_t* d_offsets,
                      size_t n_reads, uint32_t* d_out_taxon, uint32_t* d_out_status, uint32_t* d_list, uint32_t* d_count, hipStream_t stream, bool bound_hits) {

@@ -1555,7 +1555,7 @@ int cmd_seedextend(const std::vector<std::string>& args) {
                     if (at.empty()) at.push_back(line.data());
                     at.push_back(nxt);
                 }
-                flush_record();
+                if (!P.panic) flush_record();        // (a panic was noticed at the NEXT record's header, which is open by now: nothing of it is printed)
             } catch (CliError& e) { P.error = e; }   // the failing record is not printed
         });
         for (size_t i = 0; i < np; i++) {

@@ -27,6 +27,8 @@ int var_lookup_dev(const umgap_var_index* v, const uint8_t* d_bytes, const uint6
                    uint32_t min_len, uint32_t max_len);
 int aggregate_csr_bound_dev(umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound, int ranked_only, uint32_t* d_codes,
                             uint64_t n_hits, const uint64_t* d_read_offsets, size_t n_reads, uint32_t* d_out_taxon, uint32_t* d_out_status, hipStream_t stream);
+int aggregate_csr_counted_dev(umgap_taxonomy* tx, int method, int strategy, float factor, float lower_bound, int ranked_only, const uint32_t* d_taxa,
+                              uint64_t n_hits, const uint64_t* d_read_offsets, size_t n_reads, uint32_t* d_out_taxon, uint32_t* d_out_status, hipStream_t stream);
 }  // namespace umgap
 
 using namespace umgap;
@@ -468,7 +470,7 @@ int umgap_classify_tryp_dev(umgap_index* ix, umgap_taxonomy* tx, int method, int
         if (hipGetLastError() != hipSuccess) return fail(UMGAP_ERR_DEVICE, "umgap_classify_tryp_dev: a launch failed");
         if (wait_agg) UMGAP_HIP(hipStreamWaitEvent(ls, wait_agg, 0));
         if (ix->bound_to) rc = aggregate_csr_bound_dev(tx, method, strategy, factor, lower_bound, ranked_only, d_hits, D.total, d_read_pieces, nr, d_out_taxon + r0, d_out_status + r0, ls);
-        else rc = umgap_aggregate_dev(tx, method, strategy, factor, lower_bound, ranked_only, d_hits, nullptr, d_read_pieces, nr, d_out_taxon + r0, d_out_status + r0, ls);
+        else rc = aggregate_csr_counted_dev(tx, method, strategy, factor, lower_bound, ranked_only, d_hits, D.total, d_read_pieces, nr, d_out_taxon + r0, d_out_status + r0, ls);
         if (!rc && record_agg) UMGAP_HIP(hipEventRecord(record_agg, ls));
         return rc;
     };
