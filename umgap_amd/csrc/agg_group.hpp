@@ -566,7 +566,8 @@ template <bool BOUND, class Span, class OneRead>
 __device__ __forceinline__ void lca_group_spans(const TaxView& V, const LcaView& G, bool tree_like, float lower_bound, uint32_t* wtaxa, Span span,
                                                 uint32_t nr, uint32_t lane, uint64_t se_panic, uint32_t frags, size_t first_read,
                                                 uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status, OneRead one_read,
-                                                uint32_t skip_status = UMGAP_READ_UNSUPPORTED) {
+                                                uint32_t skip_status = UMGAP_READ_UNSUPPORTED, uint32_t fixed_stride = 0) {
+    // fixed_stride (1..16, else 0): read k owns wtaxa[k * fixed_stride .. + fixed_stride) -- short reads, counted 64 / stride to a pass
     auto se_panicked = [&](uint32_t k) -> bool {
         return se_panic && ((se_panic >> (k * frags)) & ((frags >= 64 ? 0ull : (1ull << frags)) - 1ull));
     };
@@ -578,7 +579,38 @@ __device__ __forceinline__ void lca_group_spans(const TaxView& V, const LcaView&
         uint32_t w = 0, k = k0;
         bool big = false;                       // the sub-batch ends in front of a read that takes the per-read path
         if (lane == 0) G.roff[0] = 0;
-        while (k < nr && k - k0 < G.reads) {
+        // Short reads at a fixed stride (the tryptic pipelines, CSR reads of a few hits): 64 / stride reads per pass, one lane per item,
+        // as in general_group -- an item's multiplicity is the number of equal items in its read (stride - 1 shuffles), the item leads
+        // its taxon when no equal item precedes it.  Same survivors in the same order as the per-read loop below.
+        const uint32_t per_pass = fixed_stride >= 1 && fixed_stride <= 16 ? 64u / fixed_stride : 0u;
+        const uint32_t r_in = per_pass ? lane / fixed_stride : 0u, j_in = per_pass ? lane - r_in * fixed_stride : 0u;
+        while (per_pass && k < nr && k - k0 < G.reads) {
+            const uint32_t rp = min(per_pass, min(nr - k, G.reads - (k - k0)));
+            const bool active = r_in < rp;
+            const uint32_t t = active ? wtaxa[(k + r_in) * fixed_stride + j_in] : 0u;
+            uint32_t mult = t != 0u ? 1u : 0u;
+            bool lead = t != 0u;
+            for (uint32_t d = 1; d < fixed_stride; d++) {
+                uint32_t jo = j_in + d;
+                if (jo >= fixed_stride) jo -= fixed_stride;
+                const uint32_t o = (uint32_t)__shfl((int)t, (int)(lane - j_in + jo), 64);    // another item of the same read
+                if (t != 0u && o == t) { mult++; if (jo < j_in) lead = false; }
+            }
+            const bool keep = lead && (float)mult >= lower_bound;                            // agg::filter keeps freq >= lower_bound
+            const uint64_t b = __ballot(keep);
+            const uint32_t n_pass = (uint32_t)__builtin_popcountll(b);
+            if (w + n_pass > G.cap) break;       // (k > k0 here: a pass holds at most 64 survivors <= cap) these reads open the next sub-batch
+            const uint32_t bit0 = r_in * fixed_stride;                                       // first bit of the lane's read
+            const uint32_t seg = (uint32_t)(b >> bit0) & ((1u << fixed_stride) - 1u);
+            const uint32_t before = (uint32_t)__builtin_popcountll(b & ((1ull << bit0) - 1ull));
+            wave_sync();                         // every lane holds its taxon in a register before the strip is overwritten
+            if (keep) wtaxa[base + w + before + (uint32_t)__builtin_popcount(seg & ((1u << j_in) - 1u))] = t;
+            if (active && j_in == 0) { G.rM[k - k0 + r_in] = 0; G.roff[k - k0 + r_in + 1] = w + before + (uint32_t)__builtin_popcount(seg); }
+            w += n_pass;
+            wave_sync();
+            k += rp;
+        }
+        while (!per_pass && k < nr && k - k0 < G.reads) {
             uint32_t start = 0, stride = 0;
             const bool ok = k == k0 ? first_ok : span(k, start, stride);
             if (k == k0) { start = base; stride = n_first; }
@@ -658,7 +690,39 @@ __device__ __forceinline__ void lca_group_spans(const TaxView& V, const LcaView&
             wave_sync();
         }
         // ---- per read: M = the deepest-in-preorder survivor, h' = the first survivor that is not its ancestor (LDS / registers) ----
-        for (uint32_t r = 0; r < nb; r++) {
+        // short reads (at most 16 survivors each): one lane per read walks its own survivors, all reads of the sub-batch at once
+        if (per_pass && lane < nb) {
+            const uint32_t o0 = G.roff[lane], D = G.roff[lane + 1] - o0;
+            uint32_t st = ST_PENDING, M = 0, hp = NONE, ans = 0;
+            if (G.rM[lane] == NONE) { st = skip_status; ans = 0; }
+            else if (D == 0) { st = UMGAP_READ_EMPTY; ans = 1; }                 // literal "1" (src/commands/taxa2agg.rs:174-175)
+            else if (BOUND) {
+                for (uint32_t e = 0; e < D; e++) { const uint32_t p = bound::pre_of(wtaxa[base + o0 + e]); M = p > M ? p : M; }
+                for (uint32_t e = 0; e < D; e++) {
+                    const uint32_t v = wtaxa[base + o0 + e], p = bound::pre_of(v);
+                    uint32_t lo, hi;
+                    bound::size_bounds(v, lo, hi);
+                    bool not_anc = false;
+                    if (M > p + hi) not_anc = true;
+                    else if (M > p + lo) not_anc = V.last_of_pre[p] < M;          // inside the rounding gap: the exact subtree end
+                    if (not_anc && p < hp) hp = p;
+                }
+            } else {
+                uint64_t ek = NOERR;
+                if (any_err)
+                    for (uint32_t e = 0; e < D; e++)
+                        if (wtaxa[base + o0 + e] == NONE) { const uint64_t k2 = ((uint64_t)G.ehi[o0 + e] << 32) | G.last[o0 + e]; ek = k2 < ek ? k2 : ek; }
+                if (ek != NOERR) {
+                    st = ((ek >> 32) & 1) ? UMGAP_READ_PANIC : UMGAP_READ_UNKNOWN_TAXON;
+                    ans = (uint32_t)ek;
+                } else {
+                    for (uint32_t e = 0; e < D; e++) { const uint32_t p = wtaxa[base + o0 + e]; M = p > M ? p : M; }
+                    for (uint32_t e = 0; e < D; e++) { const uint32_t p = wtaxa[base + o0 + e]; if (G.last[o0 + e] < M && p < hp) hp = p; }
+                }
+            }
+            G.rstat[lane] = st; G.rans[lane] = ans; G.rM[lane] = M; G.rhp[lane] = hp;
+        }
+        for (uint32_t r = 0; r < nb && !per_pass; r++) {
             const uint32_t o0 = G.roff[r], D = G.roff[r + 1] - o0;        // D <= 64: one lane per survivor
             uint32_t st = ST_PENDING, M = 0, hp = NONE, ans = 0;
             if (G.rM[r] == NONE) { st = skip_status; ans = 0; }          // a read span() refused
@@ -726,7 +790,7 @@ __device__ __forceinline__ void lca_group(const TaxView& V, LcaScratch& G, bool 
                                           uint32_t nr, uint32_t lane, uint64_t se_panic, uint32_t frags, size_t first_read,
                                           uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status, OneRead one_read) {
     lca_group_spans<BOUND>(V, view_of(G), tree_like, lower_bound, wtaxa, [stride](uint32_t k, uint32_t& start, uint32_t& n) { start = k * stride; n = stride; return true; },
-                           nr, lane, se_panic, frags, first_read, out_taxon, out_status, one_read);
+                           nr, lane, se_panic, frags, first_read, out_taxon, out_status, one_read, UMGAP_READ_UNSUPPORTED, stride <= 16u ? stride : 0u);
 }
 
 }  // namespace agg

@@ -98,18 +98,18 @@ __device__ __forceinline__ bool survives_generic(const uint32_t* __restrict__ rp
 // ---------------------------------------------------------------------------------------------
 // LCA* kernel (both -m tree and -m rmq), one wave per read.
 // ---------------------------------------------------------------------------------------------
-template <bool SCORED>
+// LISTED: only the reads on the list todo[0 .. *todo_count) -- the ones the group kernel of aggregate_group.hip left to this one
+template <bool SCORED, bool LISTED = false>
 __global__ __launch_bounds__(256) void k_agg_lca(TaxView V, int method, const uint32_t* __restrict__ taxa,
                                                  const float* __restrict__ scores, const uint64_t* __restrict__ offsets,
                                                  uint32_t stride, size_t n_reads, float lower_bound,
                                                  uint32_t* __restrict__ out_taxon, uint32_t* __restrict__ out_status,
                                                  const uint32_t* __restrict__ todo = nullptr, const uint32_t* __restrict__ todo_count = nullptr) {
-    // (todo / todo_count: only the reads on that list -- the ones the group kernel of aggregate_group.hip left to this one)
     const uint32_t lane = threadIdx.x & 63;
     const size_t wave0 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const size_t nwaves = ((size_t)gridDim.x * blockDim.x) >> 6;
     const bool tree_like = method != UMGAP_METHOD_RMQ;
-    if (todo) n_reads = (size_t)*todo_count;
+    if (LISTED) n_reads = (size_t)*todo_count;
     __shared__ uint32_t lds_keys[4][256], lds_cnt[4][256];
     uint32_t* wkeys = lds_keys[threadIdx.x >> 6];
     uint32_t* wcnt = lds_cnt[threadIdx.x >> 6];
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void k_agg_lca(TaxView V, int method, const ui
         for (int i = 0; i < 4; i++) { wkeys[lane + 64 * i] = 0u; wcnt[lane + 64 * i] = 0u; }
     }
     for (size_t r_it = wave0; r_it < n_reads; r_it += nwaves) {
-        const size_t r = todo ? (size_t)todo[r_it] : r_it;
+        const size_t r = LISTED ? (size_t)todo[r_it] : r_it;
         uint64_t off, end;
         if (offsets) { off = offsets[r]; end = offsets[r + 1]; } else { off = (uint64_t)r * stride; end = off + stride; }
         uint32_t off_lo = __builtin_amdgcn_readfirstlane((uint32_t)off), off_hi = __builtin_amdgcn_readfirstlane((uint32_t)(off >> 32));
@@ -240,7 +240,7 @@ int launch(umgap_taxonomy* tx, int method, int strategy, float factor, float low
         int rc = launch_csr_lca_group(V, method, lower_bound, d_taxa, d_offsets, n_reads, d_out_taxon, d_out_status, d_defer + 1, d_defer, stream, bound_codes != nullptr);
         if (rc) return rc;
         if (bound_codes) launch_deferred_codes_to_ids(d_defer + 1, d_defer, d_offsets, bound_codes, (const uint32_t*)tx->d_id_of_pre, stream);
-        hipLaunchKernelGGL(k_agg_lca<false>, dim3(256), block, 0, stream, V, method, d_taxa, d_scores, d_offsets, stride, n_reads, lower_bound, d_out_taxon, d_out_status,
+        hipLaunchKernelGGL((k_agg_lca<false, true>), dim3(256), block, 0, stream, V, method, d_taxa, d_scores, d_offsets, stride, n_reads, lower_bound, d_out_taxon, d_out_status,
                            (const uint32_t*)(d_defer + 1), (const uint32_t*)d_defer);
     } else if (strategy == UMGAP_STRATEGY_LCA_STAR) {
         // (the per-read LCA* kernel knows taxon ids only: bound hits are turned back first)
