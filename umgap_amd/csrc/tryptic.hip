@@ -461,6 +461,8 @@ int umgap_classify_tryp_dev(umgap_index* ix, umgap_taxonomy* tx, int method, int
         uint32_t* d_hits = (uint32_t*)p;
         rc = digest_write(ls, D, d_offsets, D.total);
         if (rc) return rc;
+        // (k_tryp_reads needs the count pass only and is needed by the aggregate only; on a stream of its own beside the piece write and the
+        //  probe it measured no gain -- 2.82-2.90 against 2.80 ms per call, same box -- and stays in line)
         hipLaunchKernelGGL(k_tryp_reads, dim3(grid_for(nr + 1)), dim3(256), 0, ls, foff, nr, fragments_per_read, D.b0, D.n, D.tile_base, D.slab_base, D.before, D.masks, D.total, d_read_pieces);
         if (D.total) {
             rc = var_lookup_dev(ix->var, d_bytes, d_offsets, (size_t)D.total, 0u, d_hits, ls, min_len, max_len);
