@@ -690,8 +690,10 @@ __device__ __forceinline__ void lca_group_spans(const TaxView& V, const LcaView&
             wave_sync();
         }
         // ---- per read: M = the deepest-in-preorder survivor, h' = the first survivor that is not its ancestor (LDS / registers) ----
-        // short reads (at most 16 survivors each): one lane per read walks its own survivors, all reads of the sub-batch at once
-        if (per_pass && lane < nb) {
+        // reads of at most 16 survivors each (short reads; long ones out of a few organisms): one lane per read walks its own survivors,
+        // all reads of the sub-batch at once, instead of two wave-wide reductions per read one read after another
+        const bool lane_per_read = per_pass || !__any(lane < nb && G.roff[lane + 1] - G.roff[lane] > 16u);
+        if (lane_per_read && lane < nb) {
             const uint32_t o0 = G.roff[lane], D = G.roff[lane + 1] - o0;
             uint32_t st = ST_PENDING, M = 0, hp = NONE, ans = 0;
             if (G.rM[lane] == NONE) { st = skip_status; ans = 0; }
@@ -722,7 +724,7 @@ __device__ __forceinline__ void lca_group_spans(const TaxView& V, const LcaView&
             }
             G.rstat[lane] = st; G.rans[lane] = ans; G.rM[lane] = M; G.rhp[lane] = hp;
         }
-        for (uint32_t r = 0; r < nb && !per_pass; r++) {
+        for (uint32_t r = 0; r < nb && !lane_per_read; r++) {
             const uint32_t o0 = G.roff[r], D = G.roff[r + 1] - o0;        // D <= 64: one lane per survivor
             uint32_t st = ST_PENDING, M = 0, hp = NONE, ans = 0;
             if (G.rM[r] == NONE) { st = skip_status; ans = 0; }          // a read span() refused
