@@ -433,15 +433,17 @@ int umgap_classify_tryp_dev(umgap_index* ix, umgap_taxonomy* tx, int method, int
     if (n_pieces_out) *n_pieces_out = 0;
     if (!n_reads) return UMGAP_OK;
     hipStream_t s = (hipStream_t)stream;
-    // One chunk of reads [r0, r1) on stream `ls` with the scratch pair `pair` of the handle: digest -> probe -> aggregate.  Everything
-    // behind the count's host round trip is stream-ordered (grow-only scratch: no allocation in the steady state, nothing to free).
-    // wait_agg / record_agg: the aggregate stages of the chunks of one call run one after another (the general kernels' large
-    // scratch belongs to the taxonomy, not to a stream).
+    // eight page-locked words the digest's kernels report to (four per scratch pair): the call's two host round trips are then a launch
+    // and a wait each, not staged copies into pageable memory
     if (!ix->tryp_host && hipHostMalloc((void**)&ix->tryp_host, 64, hipHostMallocDefault) != hipSuccess) {
         ix->tryp_host = nullptr;       // (without it the round trips are copies, as before: not an error)
         (void)hipGetLastError();
     }
     uint64_t* const report_words = getenv("UMGAP_TRYP_COPIES") ? nullptr : ix->tryp_host;     // (the switch is for A/B measurements)
+    // One chunk of reads [r0, r1) on stream `ls` with the scratch pair `pair` of the handle: digest -> probe -> aggregate.  Everything
+    // behind the count's host round trip is stream-ordered (grow-only scratch: no allocation in the steady state, nothing to free).
+    // wait_agg / record_agg: the aggregate stages of the chunks of one call run one after another (the general kernels' large
+    // scratch belongs to the taxonomy, not to a stream).
     auto run_chunk = [&](size_t r0, size_t r1, hipStream_t ls, int pair, const uint64_t* known_ends, hipEvent_t wait_agg, hipEvent_t record_agg) -> int {
         const size_t nr = r1 - r0, n_frag = nr * fragments_per_read;
         const uint64_t* foff = d_frag_offsets + r0 * fragments_per_read;
