@@ -15,7 +15,7 @@ LETTERS = "ACDEFGHIKLMNPQRSTVWY"
 
 
 def run(args, stdin=b""):
-    p = subprocess.run([UMGAP] + list(args), input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    p = subprocess.run([UMGAP] + list(args), input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)   # (a hang is a failure, not a stuck suite)
     return p.returncode, p.stdout, p.stderr
 
 
@@ -649,7 +649,7 @@ def test_config1_testdata_plumbing(tryptic, world, golden):
 def _run_env(args, stdin, **env):
     e = dict(os.environ)
     e.update({k: str(v) for k, v in env.items()})
-    p = subprocess.run([UMGAP] + list(args), input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+    p = subprocess.run([UMGAP] + list(args), input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=600)
     return p.returncode, p.stdout, p.stderr
 
 

@@ -16,7 +16,7 @@ UMGAP = os.path.join(ROOT, "umgap_amd", "bin", "umgap")
 def run(args, stdin=b"", **env):
     e = dict(os.environ)
     e.update({k: str(v) for k, v in env.items()})
-    p = subprocess.run([UMGAP] + list(args), input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e)
+    p = subprocess.run([UMGAP] + list(args), input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=e, timeout=600)
     return p.returncode, p.stdout, p.stderr
 
 
